@@ -1,0 +1,201 @@
+"""numpy restatement of the three schedulers on the hot path (oracle; TEST INFRASTRUCTURE ONLY).
+
+Pinned against the reference's RNG-free full-loop known answers in tests/test_oracle_pins.py
+(DDIM: /root/reference/ppdiffusers/tests/schedulers/test_scheduler_ddim.py:68,121-190;
+Euler: test_scheduler_euler.py:84-163).  FlowMatchEuler has no test in the reference:
+parity unpinned for it (restated from scheduling_flow_match_euler_discrete.py:44-283).
+
+Paths relative to /root/reference/ppdiffusers/ppdiffusers/schedulers/.
+The reference keeps betas / alphas_cumprod / sigmas as float32 tensors; so do we
+(np.float32), because the pinned sums were produced that way.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def _betas(num_train_timesteps, beta_start, beta_end, beta_schedule):
+    """scheduling_ddim.py:199-211 / scheduling_euler_discrete.py:160-172."""
+    if beta_schedule == "linear":
+        return np.linspace(beta_start, beta_end, num_train_timesteps, dtype=np.float32)
+    if beta_schedule == "scaled_linear":
+        return np.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=np.float32) ** 2
+    raise NotImplementedError(beta_schedule)
+
+
+class DDIMRef:
+    """DDIMScheduler: ctor :180-229, set_timesteps :305-348, step :350-475, add_noise :477-."""
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
+                 clip_sample=True, set_alpha_to_one=True, steps_offset=0, prediction_type="epsilon",
+                 clip_sample_range=1.0, timestep_spacing="leading"):
+        self.T = num_train_timesteps
+        self.betas = _betas(num_train_timesteps, beta_start, beta_end, beta_schedule)
+        self.alphas_cumprod = np.cumprod((1.0 - self.betas).astype(np.float32), dtype=np.float32)
+        self.final_alpha_cumprod = np.float32(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self.clip_sample, self.clip_sample_range = clip_sample, clip_sample_range
+        self.steps_offset, self.prediction_type, self.timestep_spacing = steps_offset, prediction_type, timestep_spacing
+        self.init_noise_sigma = 1.0
+        self.num_inference_steps = None
+
+    def set_timesteps(self, n):
+        self.num_inference_steps = n
+        if self.timestep_spacing == "leading":
+            ratio = self.T // n
+            ts = (np.arange(0, n) * ratio).round()[::-1].copy().astype(np.int64) + self.steps_offset
+        elif self.timestep_spacing == "trailing":
+            ts = np.round(np.arange(self.T, 0, -self.T / n)).astype(np.int64) - 1
+        elif self.timestep_spacing == "linspace":
+            ts = np.linspace(0, self.T - 1, n).round()[::-1].copy().astype(np.int64)
+        else:
+            raise ValueError(self.timestep_spacing)
+        self.timesteps = ts
+
+    def _get_variance(self, t, prev_t):
+        a_t = self.alphas_cumprod[t]
+        a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
+        return (1 - a_prev) / (1 - a_t) * (1 - a_t / a_prev)
+
+    def scale_model_input(self, sample, t=None):
+        return sample
+
+    def step(self, model_output, t, sample, eta=0.0):
+        t = int(t)
+        prev_t = t - self.T // self.num_inference_steps
+        a_t = self.alphas_cumprod[t]
+        a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
+        b_t = 1 - a_t
+        if self.prediction_type == "epsilon":
+            x0 = (sample - b_t ** 0.5 * model_output) / a_t ** 0.5
+            eps = model_output
+        elif self.prediction_type == "v_prediction":
+            x0 = a_t ** 0.5 * sample - b_t ** 0.5 * model_output
+            eps = a_t ** 0.5 * model_output + b_t ** 0.5 * sample
+        elif self.prediction_type == "sample":
+            x0 = model_output
+            eps = (sample - a_t ** 0.5 * x0) / b_t ** 0.5
+        else:
+            raise ValueError(self.prediction_type)
+        if self.clip_sample:
+            x0 = np.clip(x0, -self.clip_sample_range, self.clip_sample_range)
+        std = eta * self._get_variance(t, prev_t) ** 0.5
+        direction = (1 - a_prev - std ** 2) ** 0.5 * eps
+        return (a_prev ** 0.5 * x0 + direction).astype(np.float32)
+
+    def add_noise(self, x, noise, t):
+        a = self.alphas_cumprod[int(t)]
+        return (a ** 0.5 * x + (1 - a) ** 0.5 * noise).astype(np.float32)
+
+
+class EulerRef:
+    """EulerDiscreteScheduler: ctor :145-200, scale_model_input :216-238, set_timesteps :240-311,
+    karras :335-358, step :375-478."""
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
+                 prediction_type="epsilon", use_karras_sigmas=False, timestep_spacing="linspace", steps_offset=0):
+        self.T = num_train_timesteps
+        betas = _betas(num_train_timesteps, beta_start, beta_end, beta_schedule)
+        self.alphas_cumprod = np.cumprod((1.0 - betas).astype(np.float32), dtype=np.float32)
+        self.prediction_type, self.use_karras = prediction_type, use_karras_sigmas
+        self.spacing, self.steps_offset = timestep_spacing, steps_offset
+        sig = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5)[::-1].astype(np.float32)
+        self.sigmas = np.concatenate([sig, np.zeros(1, np.float32)])
+        self.timesteps = np.linspace(0, self.T - 1, self.T, dtype=float)[::-1].astype(np.float32)
+        self.step_index = None
+
+    @property
+    def init_noise_sigma(self):
+        m = self.sigmas.max()
+        return m if self.spacing in ("linspace", "trailing") else (m ** 2 + 1) ** 0.5
+
+    def set_timesteps(self, n):
+        self.n = n
+        if self.spacing == "linspace":
+            ts = np.linspace(0, self.T - 1, n, dtype=np.float32)[::-1].copy()
+        elif self.spacing == "leading":
+            ts = (np.arange(0, n) * (self.T // n)).round()[::-1].copy().astype(np.float32) + self.steps_offset
+        elif self.spacing == "trailing":
+            ts = (np.arange(self.T, 0, -self.T / n)).round().copy().astype(np.float32) - 1
+        else:
+            raise ValueError(self.spacing)
+        sig_all = np.array(((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5)
+        log_sig = np.log(sig_all)
+        sig = np.interp(ts, np.arange(0, len(sig_all)), sig_all)
+        if self.use_karras:
+            smin, smax, rho = sig[-1], sig[0], 7.0
+            ramp = np.linspace(0, 1, n)
+            sig = (smax ** (1 / rho) + ramp * (smin ** (1 / rho) - smax ** (1 / rho))) ** rho
+            ts = np.array([self._sigma_to_t(s, log_sig) for s in sig])
+        self.sigmas = np.concatenate([sig.astype(np.float32), np.zeros(1, np.float32)])
+        self.timesteps = ts.astype(np.float32)
+        self.step_index = None
+
+    @staticmethod
+    def _sigma_to_t(sigma, log_sigmas):
+        log_sigma = np.log(np.maximum(sigma, 1e-10))
+        dists = log_sigma - log_sigmas[:, np.newaxis]
+        low = np.cumsum((dists >= 0), axis=0).argmax(axis=0).clip(max=log_sigmas.shape[0] - 2)
+        high = low + 1
+        w = np.clip((log_sigmas[low] - log_sigma) / (log_sigmas[low] - log_sigmas[high]), 0, 1)
+        return ((1 - w) * low + w * high).reshape(np.shape(sigma))
+
+    def _init_step_index(self, t):
+        idx = np.nonzero(self.timesteps == np.float32(t))[0]
+        self.step_index = int(idx[1] if len(idx) > 1 else idx[0])
+
+    def scale_model_input(self, sample, t):
+        if self.step_index is None:
+            self._init_step_index(t)
+        s = self.sigmas[self.step_index]
+        return (sample / ((s ** 2 + 1) ** 0.5)).astype(np.float32)
+
+    def step(self, model_output, t, sample):
+        if self.step_index is None:
+            self._init_step_index(t)
+        s = self.sigmas[self.step_index]
+        if self.prediction_type == "epsilon":
+            x0 = sample - s * model_output
+        elif self.prediction_type == "v_prediction":
+            x0 = model_output * (-s / (s ** 2 + 1) ** 0.5) + sample / (s ** 2 + 1)
+        elif self.prediction_type in ("sample", "original_sample"):
+            x0 = model_output
+        else:
+            raise ValueError(self.prediction_type)
+        d = (sample - x0) / s
+        dt = self.sigmas[self.step_index + 1] - s
+        self.step_index += 1
+        return (sample + d * dt).astype(np.float32)
+
+
+class FlowMatchEulerRef:
+    """FlowMatchEulerDiscreteScheduler (scheduling_flow_match_euler_discrete.py:63-283). Parity unpinned."""
+
+    def __init__(self, num_train_timesteps=1000, shift=1.0):
+        self.T, self.shift = num_train_timesteps, shift
+        ts = np.linspace(1, self.T, self.T, dtype=np.float32)[::-1].copy()
+        sig = ts / self.T
+        sig = shift * sig / (1 + (shift - 1) * sig)
+        self.sigmas = sig.astype(np.float32)
+        self.timesteps = self.sigmas * self.T
+        self.sigma_min, self.sigma_max = float(self.sigmas[-1]), float(self.sigmas[0])
+        self.step_index = None
+
+    def set_timesteps(self, n):
+        ts = np.linspace(self.sigma_max * self.T, self.sigma_min * self.T, n)
+        sig = ts / self.T
+        sig = (self.shift * sig / (1 + (self.shift - 1) * sig)).astype(np.float32)
+        self.timesteps = sig * self.T
+        self.sigmas = np.concatenate([sig, np.zeros(1, np.float32)])
+        self.step_index = None
+
+    def step(self, model_output, t, sample):
+        if self.step_index is None:
+            idx = np.nonzero(self.timesteps == np.float32(t))[0]
+            self.step_index = int(idx[1] if len(idx) > 1 else idx[0])
+        sample = sample.astype(np.float32)
+        s = self.sigmas[self.step_index]
+        denoised = sample - model_output * s
+        d = (sample - denoised) / s
+        dt = self.sigmas[self.step_index + 1] - s
+        self.step_index += 1
+        return (sample + d * dt).astype(model_output.dtype)

@@ -1,0 +1,538 @@
+"""torch-CPU restatement of ppdiffusers' UNet2DConditionModel forward (oracle).
+
+TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py.  Parity unpinned at
+whole-UNet level (no Paddle, no real weights here); the sub-pieces with
+RNG-free known answers are pinned in tests/test_oracle_pins.py.
+
+All paths relative to /root/reference/ppdiffusers/ppdiffusers/ (``PPD/``).
+Parameters live in a flat dict keyed by the reference's parameter names
+(``down_blocks.0.resnets.0.conv1.weight`` ...) in the reference's *Paddle*
+layouts: ``nn.Linear.weight`` is ``[in, out]`` (y = x @ W + b,
+PPD/models/modeling_pytorch_paddle_utils.py:27-63), conv weights are OIHW.
+
+Only the branches the SD-1.5 / SDXL / tiny test configs exercise are restated
+(SURVEY.md section 8a); every other config value raises NotImplementedError so
+that an unsupported model can never silently produce numbers.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+Params = Dict[str, Tensor]
+
+
+# --------------------------------------------------------------------------
+# config handling  (PPD/models/unet_2d_condition.py:172-231 ctor defaults)
+# --------------------------------------------------------------------------
+UNET_DEFAULTS = dict(
+    sample_size=None,
+    in_channels=4,
+    out_channels=4,
+    center_input_sample=False,
+    flip_sin_to_cos=True,
+    freq_shift=0,
+    down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"),
+    mid_block_type="UNetMidBlock2DCrossAttn",
+    up_block_types=("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"),
+    only_cross_attention=False,
+    block_out_channels=(320, 640, 1280, 1280),
+    layers_per_block=2,
+    downsample_padding=1,
+    mid_block_scale_factor=1,
+    act_fn="silu",
+    norm_num_groups=32,
+    norm_eps=1e-5,
+    cross_attention_dim=1280,
+    transformer_layers_per_block=1,
+    attention_head_dim=8,
+    use_linear_projection=False,
+    addition_embed_type=None,
+    addition_time_embed_dim=None,
+    upcast_attention=False,
+    resnet_time_scale_shift="default",
+    resnet_out_scale_factor=1.0,
+    time_embedding_type="positional",
+    projection_class_embeddings_input_dim=None,
+)
+
+_UNSUPPORTED_IF_SET = (
+    "encoder_hid_dim", "encoder_hid_dim_type", "class_embed_type", "num_class_embeds",
+    "time_embedding_dim", "time_embedding_act_fn", "timestep_post_act", "time_cond_proj_dim",
+    "cross_attention_norm", "dual_cross_attention", "class_embeddings_concat", "resnet_skip_time_act",
+)
+
+
+def normalize_config(config: dict) -> dict:
+    cfg = dict(UNET_DEFAULTS)
+    for k, v in config.items():
+        if k.startswith("_"):
+            continue
+        cfg[k] = v
+    for k in _UNSUPPORTED_IF_SET:
+        if cfg.get(k) not in (None, False):
+            raise NotImplementedError(f"oracle: config field {k}={cfg[k]!r} is outside the restated hot path")
+    if cfg["time_embedding_type"] != "positional" or cfg["resnet_time_scale_shift"] != "default":
+        raise NotImplementedError("oracle: only positional time embedding / default resnet time shift restated")
+    if cfg["act_fn"] not in ("silu", "swish"):
+        raise NotImplementedError("oracle: only SiLU resnets restated")
+    if cfg.get("conv_in_kernel", 3) != 3 or cfg.get("conv_out_kernel", 3) != 3:
+        raise NotImplementedError("oracle: 3x3 conv_in / conv_out only")
+    n = len(cfg["down_block_types"])
+
+    def tup(x):
+        return tuple(x) if isinstance(x, (list, tuple)) else (x,) * n
+
+    cfg["block_out_channels"] = tuple(cfg["block_out_channels"])
+    cfg["layers_per_block"] = tup(cfg["layers_per_block"])
+    cfg["transformer_layers_per_block"] = tup(cfg["transformer_layers_per_block"])
+    cfg["cross_attention_dim"] = tup(cfg["cross_attention_dim"])
+    # num_attention_heads = attention_head_dim (the naming quirk at unet_2d_condition.py:245)
+    cfg["num_attention_heads"] = tup(cfg["attention_head_dim"])
+    cfg["only_cross_attention"] = tup(cfg["only_cross_attention"])
+    if any(cfg["only_cross_attention"]):
+        raise NotImplementedError("oracle: only_cross_attention not restated")
+    return cfg
+
+
+# --------------------------------------------------------------------------
+# primitive layers with Paddle semantics
+# --------------------------------------------------------------------------
+def linear(P: Params, name: str, x: Tensor) -> Tensor:
+    """LoRACompatibleLinear.forward without LoRA: F.linear(x, W[in,out], b) (PPD/models/lora.py:453-459)."""
+    w = P[name + ".weight"]
+    y = x @ w
+    b = P.get(name + ".bias")
+    return y if b is None else y + b
+
+
+def conv2d(P: Params, name: str, x: Tensor, stride: int = 1, padding: int = 1) -> Tensor:
+    """LoRACompatibleConv.forward without LoRA: F.conv2d OIHW (PPD/models/lora.py:364-377)."""
+    return F.conv2d(x, P[name + ".weight"], P.get(name + ".bias"), stride=stride, padding=padding)
+
+
+def group_norm(P: Params, name: str, x: Tensor, groups: int, eps: float) -> Tensor:
+    """paddle.nn.GroupNorm(epsilon): biased variance over (C/G, H, W), affine per channel."""
+    return F.group_norm(x, groups, P[name + ".weight"], P[name + ".bias"], eps)
+
+
+def layer_norm(P: Params, name: str, x: Tensor, eps: float = 1e-5) -> Tensor:
+    return F.layer_norm(x, (x.shape[-1],), P.get(name + ".weight"), P.get(name + ".bias"), eps)
+
+
+def get_timestep_embedding(timesteps: Tensor, embedding_dim: int, flip_sin_to_cos: bool = False,
+                           downscale_freq_shift: float = 1, scale: float = 1, max_period: int = 10000) -> Tensor:
+    """PPD/models/embeddings.py:26-64 -- computed in float32 regardless of model dtype."""
+    assert timesteps.ndim == 1
+    half_dim = embedding_dim // 2
+    exponent = -math.log(max_period) * torch.arange(0, half_dim, dtype=torch.float32)
+    exponent = exponent / (half_dim - downscale_freq_shift)
+    emb = torch.exp(exponent)
+    emb = timesteps[:, None].to(torch.float32) * emb[None, :]
+    emb = scale * emb
+    if flip_sin_to_cos:
+        emb = torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1)
+    else:
+        emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
+    if embedding_dim % 2 == 1:
+        emb = F.pad(emb, (0, 1))
+    return emb
+
+
+def timestep_embedding_mlp(P: Params, name: str, x: Tensor) -> Tensor:
+    """TimestepEmbedding.forward: linear_1 -> SiLU -> linear_2 (PPD/models/embeddings.py:283-295)."""
+    x = linear(P, name + ".linear_1", x)
+    x = F.silu(x)
+    return linear(P, name + ".linear_2", x)
+
+
+# --------------------------------------------------------------------------
+# attention  (PPD/models/attention_processor.py)
+# --------------------------------------------------------------------------
+def sdpa_math(q: Tensor, k: Tensor, v: Tensor, attn_mask: Optional[Tensor] = None,
+              scale: Optional[float] = None) -> Tensor:
+    """The "math" branch of scaled_dot_product_attention_ (PPD/patches/paddle_patch.py:445-461).
+
+    q [B,Sq,h,d], k/v [B,Skv,h,d], attn_mask additive [B,h,Sq,Skv] -> [B,Sq,h,d].
+    """
+    if scale is None:
+        scale = 1.0 / math.sqrt(q.shape[-1])
+    qt, kt, vt = q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3)
+    s = (qt * scale) @ kt.transpose(-1, -2)
+    if attn_mask is not None:
+        s = s + attn_mask.to(s.dtype)
+    p = torch.softmax(s, dim=-1)
+    return (p @ vt).permute(0, 2, 1, 3)
+
+
+def prepare_attention_mask(mask: Optional[Tensor], target_length: int, batch_size: int, heads: int):
+    """Attention.prepare_attention_mask, out_dim=4 (attention_processor.py:587-630) incl. its padding quirk."""
+    if mask is None:
+        return None
+    if mask.shape[-1] != target_length:
+        mask = F.pad(mask, (0, target_length), value=0.0)
+    if mask.shape[0] < batch_size * heads:
+        mask = mask.repeat_interleave(heads, dim=0)
+    return mask.reshape(batch_size, heads, -1, mask.shape[-1])
+
+
+def attention(P: Params, name: str, hidden: Tensor, heads: int, encoder_hidden: Optional[Tensor] = None,
+              attention_mask: Optional[Tensor] = None, processor: str = "math") -> Tensor:
+    """Attention.forward through AttnProcessor.__call__ (attention_processor.py:673-735) for the
+    3-D input / no group_norm / no norm_cross / residual_connection=False / rescale=1 case.
+
+    processor="math": head_to_batch_dim + get_attention_scores (:532-586);
+    processor="sdpa": XFormersAttnProcessor layout [B,S,h,d] + sdpa_ math path (:1167-1249).
+    Both are the same arithmetic; the reference pins their equivalence at 1e-3
+    (tests/models/test_modeling_common.py:197-256).
+    """
+    B, Sq, _ = hidden.shape
+    ctx = hidden if encoder_hidden is None else encoder_hidden
+    Skv = ctx.shape[1]
+    q = linear(P, name + ".to_q", hidden)
+    k = linear(P, name + ".to_k", ctx)
+    v = linear(P, name + ".to_v", ctx)
+    inner = q.shape[-1]
+    d = inner // heads
+    mask4 = prepare_attention_mask(attention_mask, Skv, B, heads)
+    scale = d ** -0.5
+    if processor == "math":
+        qh = q.reshape(B, Sq, heads, d).permute(0, 2, 1, 3)
+        kh = k.reshape(B, Skv, heads, d).permute(0, 2, 1, 3)
+        vh = v.reshape(B, Skv, heads, d).permute(0, 2, 1, 3)
+        scores = (qh @ kh.transpose(-1, -2)) * scale
+        if mask4 is not None:
+            scores = scores + mask4
+        probs = torch.softmax(scores, dim=-1)
+        o = (probs @ vh).permute(0, 2, 1, 3).reshape(B, Sq, inner)
+    elif processor == "sdpa":
+        o = sdpa_math(q.reshape(B, Sq, heads, d), k.reshape(B, Skv, heads, d), v.reshape(B, Skv, heads, d),
+                      attn_mask=mask4, scale=scale).reshape(B, Sq, inner)
+    else:
+        raise ValueError(processor)
+    return linear(P, name + ".to_out.0", o)
+
+
+def geglu_ff(P: Params, name: str, x: Tensor) -> Tensor:
+    """FeedForward.forward with GEGLU (attention.py:670-677, activations.py:101-104): erf-GELU gate."""
+    hg = linear(P, name + ".net.0.proj", x)
+    h, g = hg.chunk(2, dim=-1)
+    x = h * F.gelu(g)
+    return linear(P, name + ".net.2", x)
+
+
+def basic_transformer_block(P: Params, name: str, x: Tensor, heads: int, enc: Tensor,
+                            attention_mask=None, encoder_attention_mask=None, processor="math") -> Tensor:
+    """BasicTransformerBlock.forward, layer_norm variant (attention.py:376-489); LN eps 1e-5."""
+    n = layer_norm(P, name + ".norm1", x)
+    x = attention(P, name + ".attn1", n, heads, None, attention_mask, processor) + x
+    n = layer_norm(P, name + ".norm2", x)
+    x = attention(P, name + ".attn2", n, heads, enc, encoder_attention_mask, processor) + x
+    n = layer_norm(P, name + ".norm3", x)
+    x = geglu_ff(P, name + ".ff", n) + x
+    return x
+
+
+def transformer_2d(P: Params, name: str, x: Tensor, heads: int, num_layers: int, groups: int,
+                   use_linear_projection: bool, enc: Tensor, attention_mask=None, encoder_attention_mask=None,
+                   processor="math") -> Tensor:
+    """Transformer2DModel.forward, continuous-input branch (transformer_2d.py:351-379, 406-439, 442-468)."""
+    B, C, H, W = x.shape
+    residual = x
+    h = group_norm(P, name + ".norm", x, groups, 1e-6)
+    if not use_linear_projection:
+        h = conv2d(P, name + ".proj_in", h, padding=0)
+        inner = h.shape[1]
+        h = h.permute(0, 2, 3, 1).reshape(B, H * W, inner)
+    else:
+        h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
+        h = linear(P, name + ".proj_in", h)
+        inner = h.shape[-1]
+    for i in range(num_layers):
+        h = basic_transformer_block(P, f"{name}.transformer_blocks.{i}", h, heads, enc,
+                                    attention_mask, encoder_attention_mask, processor)
+    if not use_linear_projection:
+        h = h.reshape(B, H, W, inner).permute(0, 3, 1, 2)
+        h = conv2d(P, name + ".proj_out", h, padding=0)
+    else:
+        h = linear(P, name + ".proj_out", h)
+        h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
+    return h + residual
+
+
+# --------------------------------------------------------------------------
+# resnet / sampling  (PPD/models/resnet.py)
+# --------------------------------------------------------------------------
+def resnet_block(P: Params, name: str, x: Tensor, temb: Tensor, groups: int, eps: float,
+                 output_scale_factor: float = 1.0) -> Tensor:
+    """ResnetBlock2D.forward, time_embedding_norm="default" (resnet.py:728-808)."""
+    h = group_norm(P, name + ".norm1", x, groups, eps)
+    h = F.silu(h)
+    h = conv2d(P, name + ".conv1", h)
+    t = linear(P, name + ".time_emb_proj", F.silu(temb))[:, :, None, None]
+    h = h + t
+    h = group_norm(P, name + ".norm2", h, groups, eps)
+    h = F.silu(h)
+    h = conv2d(P, name + ".conv2", h)
+    if (name + ".conv_shortcut.weight") in P:
+        x = conv2d(P, name + ".conv_shortcut", x, padding=0)
+    return (x + h) / output_scale_factor
+
+
+def downsample(P: Params, name: str, x: Tensor, padding: int = 1) -> Tensor:
+    """Downsample2D.forward with use_conv=True, name="op" -> param ``.conv`` (resnet.py:271-294)."""
+    if padding == 0:
+        x = F.pad(x, (0, 1, 0, 1))
+    return conv2d(P, name + ".conv", x, stride=2, padding=padding)
+
+
+def upsample(P: Params, name: str, x: Tensor) -> Tensor:
+    """Upsample2D.forward: nearest x2 then conv3x3 (resnet.py:169-218)."""
+    x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+    return conv2d(P, name + ".conv", x)
+
+
+# --------------------------------------------------------------------------
+# UNet2DConditionModel.forward  (PPD/models/unet_2d_condition.py:809-1207)
+# --------------------------------------------------------------------------
+def unet_forward(P: Params, config: dict, sample: Tensor, timestep, encoder_hidden_states: Tensor,
+                 added_cond_kwargs: Optional[dict] = None, attention_mask: Optional[Tensor] = None,
+                 encoder_attention_mask: Optional[Tensor] = None, processor: str = "math",
+                 taps: Optional[dict] = None) -> Tensor:
+    """Returns the noise prediction [B, out_channels, H, W] (the ``(sample,)`` tuple's first element).
+
+    ``taps``: optional dict that receives named intermediate activations (for layer-wise parity tests).
+    """
+    cfg = normalize_config(config)
+    dtype = P["conv_in.weight"].dtype
+    sample = sample.to(dtype)
+    B = sample.shape[0]
+    groups, eps = cfg["norm_num_groups"], cfg["norm_eps"]
+    boc = cfg["block_out_channels"]
+
+    # mask -> additive bias (:921-927)
+    if attention_mask is not None:
+        attention_mask = ((1 - attention_mask.to(dtype)) * -10000.0).unsqueeze(1)
+    if encoder_attention_mask is not None:
+        encoder_attention_mask = ((1 - encoder_attention_mask.to(dtype)) * -10000.0).unsqueeze(1)
+    if cfg["center_input_sample"]:
+        sample = 2 * sample - 1.0
+
+    # time embedding (:933-953): sinusoid in fp32, then cast to model dtype
+    if not torch.is_tensor(timestep):
+        timesteps = torch.tensor([timestep], dtype=torch.float64 if isinstance(timestep, float) else torch.int64)
+    else:
+        timesteps = timestep.reshape(-1) if timestep.ndim == 0 else timestep
+    timesteps = timesteps.expand(B)
+    t_emb = get_timestep_embedding(timesteps, boc[0], cfg["flip_sin_to_cos"], cfg["freq_shift"]).to(dtype)
+    emb = timestep_embedding_mlp(P, "time_embedding", t_emb)
+
+    if cfg["addition_embed_type"] == "text_time":  # SDXL (:991-1010)
+        if added_cond_kwargs is None or "text_embeds" not in added_cond_kwargs:
+            raise ValueError("addition_embed_type 'text_time' requires `text_embeds` in `added_cond_kwargs`")
+        if "time_ids" not in added_cond_kwargs:
+            raise ValueError("addition_embed_type 'text_time' requires `time_ids` in `added_cond_kwargs`")
+        text_embeds = added_cond_kwargs["text_embeds"]
+        time_ids = added_cond_kwargs["time_ids"]
+        time_embeds = get_timestep_embedding(time_ids.flatten(), cfg["addition_time_embed_dim"],
+                                             cfg["flip_sin_to_cos"], cfg["freq_shift"])
+        time_embeds = time_embeds.reshape(text_embeds.shape[0], -1).to(text_embeds.dtype)
+        add_embeds = torch.cat([text_embeds, time_embeds], dim=-1).to(emb.dtype)
+        emb = emb + timestep_embedding_mlp(P, "add_embedding", add_embeds)
+    elif cfg["addition_embed_type"] is not None:
+        raise NotImplementedError(cfg["addition_embed_type"])
+    if taps is not None:
+        taps["emb"] = emb
+
+    enc = encoder_hidden_states.to(dtype)
+    x = conv2d(P, "conv_in", sample)
+    if taps is not None:
+        taps["conv_in"] = x
+
+    # down (:1097-1119)
+    skips = [x]
+    n_blocks = len(cfg["down_block_types"])
+    for i, btype in enumerate(cfg["down_block_types"]):
+        heads = cfg["num_attention_heads"][i]
+        for j in range(cfg["layers_per_block"][i]):
+            x = resnet_block(P, f"down_blocks.{i}.resnets.{j}", x, emb, groups, eps)
+            if btype == "CrossAttnDownBlock2D":
+                x = transformer_2d(P, f"down_blocks.{i}.attentions.{j}", x, heads,
+                                   cfg["transformer_layers_per_block"][i], groups, cfg["use_linear_projection"],
+                                   enc, attention_mask, encoder_attention_mask, processor)
+            elif btype != "DownBlock2D":
+                raise NotImplementedError(btype)
+            skips.append(x)
+        if i != n_blocks - 1:
+            x = downsample(P, f"down_blocks.{i}.downsamplers.0", x, cfg["downsample_padding"])
+            skips.append(x)
+        if taps is not None:
+            taps[f"down_{i}"] = x
+
+    # mid (:1134-1155)
+    if cfg["mid_block_type"] == "UNetMidBlock2DCrossAttn":
+        heads = cfg["num_attention_heads"][-1]
+        x = resnet_block(P, "mid_block.resnets.0", x, emb, groups, eps, cfg["mid_block_scale_factor"])
+        x = transformer_2d(P, "mid_block.attentions.0", x, heads, cfg["transformer_layers_per_block"][-1], groups,
+                           cfg["use_linear_projection"], enc, attention_mask, encoder_attention_mask, processor)
+        x = resnet_block(P, "mid_block.resnets.1", x, emb, groups, eps, cfg["mid_block_scale_factor"])
+    elif cfg["mid_block_type"] is not None:
+        raise NotImplementedError(cfg["mid_block_type"])
+    if taps is not None:
+        taps["mid"] = x
+
+    # up (:1158-1191)
+    rev_heads = tuple(reversed(cfg["num_attention_heads"]))
+    rev_layers = tuple(reversed(cfg["layers_per_block"]))
+    rev_tlayers = tuple(reversed(cfg["transformer_layers_per_block"]))
+    for i, btype in enumerate(cfg["up_block_types"]):
+        for j in range(rev_layers[i] + 1):
+            skip = skips.pop()
+            x = torch.cat([x, skip], dim=1)
+            x = resnet_block(P, f"up_blocks.{i}.resnets.{j}", x, emb, groups, eps)
+            if btype == "CrossAttnUpBlock2D":
+                x = transformer_2d(P, f"up_blocks.{i}.attentions.{j}", x, rev_heads[i], rev_tlayers[i], groups,
+                                   cfg["use_linear_projection"], enc, attention_mask, encoder_attention_mask,
+                                   processor)
+            elif btype != "UpBlock2D":
+                raise NotImplementedError(btype)
+        if i != n_blocks - 1:
+            x = upsample(P, f"up_blocks.{i}.upsamplers.0", x)
+        if taps is not None:
+            taps[f"up_{i}"] = x
+
+    # post (:1193-1196)
+    x = group_norm(P, "conv_norm_out", x, groups, eps)
+    x = F.silu(x)
+    x = conv2d(P, "conv_out", x)
+    return x
+
+
+# --------------------------------------------------------------------------
+# parameter inventory: name -> shape for a config, mirroring the ctor order
+# (PPD/models/unet_2d_condition.py:287-631, unet_2d_blocks.py ctors)
+# --------------------------------------------------------------------------
+def unet_param_shapes(config: dict) -> Dict[str, tuple]:
+    cfg = normalize_config(config)
+    boc = cfg["block_out_channels"]
+    S: Dict[str, tuple] = {}
+    ted = boc[0] * 4
+
+    def lin(name, i, o, bias=True):
+        S[name + ".weight"] = (i, o)
+        if bias:
+            S[name + ".bias"] = (o,)
+
+    def conv(name, i, o, k):
+        S[name + ".weight"] = (o, i, k, k)
+        S[name + ".bias"] = (o,)
+
+    def norm(name, c):
+        S[name + ".weight"] = (c,)
+        S[name + ".bias"] = (c,)
+
+    def resnet(name, cin, cout):
+        norm(name + ".norm1", cin)
+        conv(name + ".conv1", cin, cout, 3)
+        lin(name + ".time_emb_proj", ted, cout)
+        norm(name + ".norm2", cout)
+        conv(name + ".conv2", cout, cout, 3)
+        if cin != cout:
+            conv(name + ".conv_shortcut", cin, cout, 1)
+
+    def attn(name, dim, cross):
+        lin(name + ".to_q", dim, dim, bias=False)
+        lin(name + ".to_k", cross, dim, bias=False)
+        lin(name + ".to_v", cross, dim, bias=False)
+        lin(name + ".to_out.0", dim, dim)
+
+    def transformer(name, c, layers, cross):
+        norm(name + ".norm", c)
+        if cfg["use_linear_projection"]:
+            lin(name + ".proj_in", c, c)
+        else:
+            conv(name + ".proj_in", c, c, 1)
+        for l in range(layers):
+            b = f"{name}.transformer_blocks.{l}"
+            norm(b + ".norm1", c)
+            attn(b + ".attn1", c, c)
+            norm(b + ".norm2", c)
+            attn(b + ".attn2", c, cross)
+            norm(b + ".norm3", c)
+            lin(b + ".ff.net.0.proj", c, 8 * c)
+            lin(b + ".ff.net.2", 4 * c, c)
+        if cfg["use_linear_projection"]:
+            lin(name + ".proj_out", c, c)
+        else:
+            conv(name + ".proj_out", c, c, 1)
+
+    conv("conv_in", cfg["in_channels"], boc[0], 3)
+    lin("time_embedding.linear_1", boc[0], ted)
+    lin("time_embedding.linear_2", ted, ted)
+    if cfg["addition_embed_type"] == "text_time":
+        lin("add_embedding.linear_1", cfg["projection_class_embeddings_input_dim"], ted)
+        lin("add_embedding.linear_2", ted, ted)
+
+    n = len(boc)
+    out_c = boc[0]
+    for i, btype in enumerate(cfg["down_block_types"]):
+        in_c, out_c = out_c, boc[i]
+        for j in range(cfg["layers_per_block"][i]):
+            resnet(f"down_blocks.{i}.resnets.{j}", in_c if j == 0 else out_c, out_c)
+            if btype == "CrossAttnDownBlock2D":
+                transformer(f"down_blocks.{i}.attentions.{j}", out_c, cfg["transformer_layers_per_block"][i],
+                            cfg["cross_attention_dim"][i])
+        if i != n - 1:
+            conv(f"down_blocks.{i}.downsamplers.0.conv", out_c, out_c, 3)
+
+    if cfg["mid_block_type"] == "UNetMidBlock2DCrossAttn":
+        resnet("mid_block.resnets.0", boc[-1], boc[-1])
+        transformer("mid_block.attentions.0", boc[-1], cfg["transformer_layers_per_block"][-1],
+                    cfg["cross_attention_dim"][-1])
+        resnet("mid_block.resnets.1", boc[-1], boc[-1])
+
+    rboc = tuple(reversed(boc))
+    rlayers = tuple(reversed(cfg["layers_per_block"]))
+    rtl = tuple(reversed(cfg["transformer_layers_per_block"]))
+    rcross = tuple(reversed(cfg["cross_attention_dim"]))
+    out_c = rboc[0]
+    for i, btype in enumerate(cfg["up_block_types"]):
+        prev_out, out_c = out_c, rboc[i]
+        in_c = rboc[min(i + 1, n - 1)]
+        nl = rlayers[i] + 1
+        for j in range(nl):
+            skip_c = in_c if j == nl - 1 else out_c
+            rin = prev_out if j == 0 else out_c
+            resnet(f"up_blocks.{i}.resnets.{j}", rin + skip_c, out_c)
+            if btype == "CrossAttnUpBlock2D":
+                transformer(f"up_blocks.{i}.attentions.{j}", out_c, rtl[i], rcross[i])
+        if i != n - 1:
+            conv(f"up_blocks.{i}.upsamplers.0.conv", out_c, out_c, 3)
+
+    norm("conv_norm_out", boc[0])
+    conv("conv_out", boc[0], cfg["out_channels"], 3)
+    return S
+
+
+def synth_unet_params(config: dict, seed: int = 1234, dtype=torch.float32) -> Params:
+    """Synthetic weights per SURVEY.md 8(d): conv/linear N(0, 1/fan_in), biases N(0, 0.02^2),
+    norm gamma = 1 + N(0, 0.02^2), beta = N(0, 0.02^2); one Generator seeded ``seed``,
+    parameters drawn in ``unet_param_shapes`` order."""
+    g = torch.Generator().manual_seed(seed)
+    P: Params = {}
+    for name, shape in unet_param_shapes(config).items():
+        if name.endswith(".bias"):
+            t = torch.randn(shape, generator=g) * 0.02
+        elif len(shape) == 1:  # norm gamma
+            t = 1.0 + torch.randn(shape, generator=g) * 0.02
+        elif len(shape) == 2:  # linear [in, out]
+            t = torch.randn(shape, generator=g) / math.sqrt(shape[0])
+        else:  # conv OIHW
+            fan_in = shape[1] * shape[2] * shape[3]
+            t = torch.randn(shape, generator=g) / math.sqrt(fan_in)
+        P[name] = t.to(dtype)
+    return P

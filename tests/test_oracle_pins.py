@@ -1,0 +1,150 @@
+"""Pins the oracle against every RNG-free known-answer test the reference holds for the hot path.
+
+Golden values are the reference's own (file:line cited per test); they do not depend on Paddle's RNG.
+"""
+import numpy as np
+import torch
+
+from oracle import schedulers_ref as S
+from oracle import unet_ref as U
+
+
+# --- /root/reference/ppdiffusers/tests/models/test_layers_utils.py:90-115 -------------------------------
+def test_sinoid_embeddings_hardcoded():
+    t = torch.arange(128)
+    t1 = U.get_timestep_embedding(t, 64, downscale_freq_shift=1, flip_sin_to_cos=False)
+    t2 = U.get_timestep_embedding(t, 64, downscale_freq_shift=0, flip_sin_to_cos=True)
+    t3 = U.get_timestep_embedding(t, 64, scale=1000)
+    g1 = [0.9646, 0.9804, 0.9892, 0.9615, 0.9787, 0.9882, 0.9582, 0.9769, 0.9872]
+    g2 = [0.3019, 0.228, 0.1716, 0.3146, 0.2377, 0.179, 0.3272, 0.2474, 0.1864]
+    g3 = [-0.9801, -0.9464, -0.9349, -0.3952, 0.8887, -0.9709, 0.5299, -0.2853, -0.9927]
+    assert np.allclose(t1[23:26, 47:50].flatten().numpy(), g1, atol=0.01)
+    assert np.allclose(t2[23:26, 47:50].flatten().numpy(), g2, atol=0.01)
+    assert np.allclose(t3[23:26, 47:50].flatten().numpy(), g3, atol=0.01)
+
+
+# --- test_layers_utils.py:32-88 (structural properties) --------------------------------------------------
+def test_timestep_embeddings_structure():
+    t = torch.arange(16)
+    e = U.get_timestep_embedding(t, 256)
+    assert (e[0, :128] - 0).abs().sum() < 1e-5 and (e[0, 128:] - 1).abs().sum() < 1e-5
+    assert (e[:, -1] - 1).abs().sum() < 1e-5
+    grad_mean = np.abs(np.gradient(e.numpy(), axis=-1)).mean(axis=1)
+    prev = 0.0
+    for g in grad_mean:  # later vectors have higher frequency => larger mean gradient
+        assert g > prev
+        prev = g
+    t10 = torch.arange(10)
+    assert torch.allclose(U.get_timestep_embedding(t10, 16),
+                          U.get_timestep_embedding(t10, 16, flip_sin_to_cos=False, downscale_freq_shift=1,
+                                                   max_period=10_000), atol=1e-2)
+    e1 = U.get_timestep_embedding(t10, 16, flip_sin_to_cos=True)
+    e1 = torch.cat([e1[:, 8:], e1[:, :8]], dim=-1)
+    assert torch.allclose(e1, U.get_timestep_embedding(t10, 16, flip_sin_to_cos=False), 1e-3)
+    d = (U.get_timestep_embedding(t10, 16, downscale_freq_shift=0)
+         - U.get_timestep_embedding(t10, 16, downscale_freq_shift=1))[:, 8:]
+    assert (np.abs((d <= 0).numpy()) - 1).sum() < 1e-5
+
+
+# --- tests/models/test_activations.py:24-62 ---------------------------------------------------------------
+def test_activation_fixed_points():
+    import torch.nn.functional as F
+
+    for act in (F.silu, F.gelu):
+        assert act(torch.tensor(-100.0)).item() == 0
+        assert act(torch.tensor(-1.0)).item() != 0
+        assert act(torch.tensor(0.0)).item() == 0
+        assert abs(act(torch.tensor(20.0)).item() - 20) < 1e-4
+
+
+# --- fixtures: tests/schedulers/test_schedulers.py:261-303 ------------------------------------------------
+def dummy_sample_deter():
+    n = 4 * 3 * 8 * 8
+    s = np.arange(n, dtype=np.float32).reshape(3, 8, 8, 4) / n
+    return np.ascontiguousarray(s.transpose(3, 0, 1, 2)).astype(np.float32)
+
+
+def dummy_noise_deter():
+    n = 4 * 3 * 8 * 8
+    s = np.arange(n, dtype=np.float32)[::-1].reshape(3, 8, 8, 4) / n
+    return np.ascontiguousarray(s.transpose(3, 0, 1, 2)).astype(np.float32)
+
+
+def dummy_model(sample, t):
+    t = np.float32(t)
+    return (sample * t / (t + 1)).astype(np.float32)
+
+
+DDIM_CFG = dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear", clip_sample=True)
+
+
+def ddim_full_loop(**kw):
+    cfg = dict(DDIM_CFG)
+    cfg.update(kw)
+    sch = S.DDIMRef(**cfg)
+    sch.set_timesteps(10)
+    x = dummy_sample_deter()
+    for t in sch.timesteps:
+        x = sch.step(dummy_model(x, t), t, x, 0.0)
+    return x
+
+
+# --- tests/schedulers/test_scheduler_ddim.py:68 ---
+def test_ddim_steps_offset():
+    sch = S.DDIMRef(**dict(DDIM_CFG, steps_offset=1))
+    sch.set_timesteps(5)
+    assert list(sch.timesteps) == [801, 601, 401, 201, 1]
+
+
+# --- test_scheduler_ddim.py:121-126 ---
+def test_ddim_variance():
+    sch = S.DDIMRef(**DDIM_CFG)
+    for (a, b), v in {(0, 0): 0.0, (420, 400): 0.14771, (980, 960): 0.32460, (487, 486): 0.00979,
+                      (999, 998): 0.02}.items():
+        assert abs(float(sch._get_variance(a, b)) - v) < 1e-5
+
+
+# --- test_scheduler_ddim.py:134-135, 143-144, 152-153, 161-162 ---
+def test_ddim_full_loops():
+    for kw, (gs, gm) in [({}, (172.0067, 0.223967)), ({"prediction_type": "v_prediction"}, (52.5302, 0.0684)),
+                         ({"set_alpha_to_one": True, "beta_start": 0.01}, (149.8295, 0.1951)),
+                         ({"set_alpha_to_one": False, "beta_start": 0.01}, (149.0784, 0.1941))]:
+        x = ddim_full_loop(**kw)
+        assert abs(np.abs(x).sum() - gs) < 1e-2, (kw, np.abs(x).sum())
+        assert abs(np.abs(x).mean() - gm) < 1e-3
+
+
+# --- test_scheduler_ddim.py:164-190 ---
+def test_ddim_full_loop_with_noise():
+    sch = S.DDIMRef(**DDIM_CFG)
+    sch.set_timesteps(10)
+    ts = sch.timesteps[8:]
+    x = sch.add_noise(dummy_sample_deter(), dummy_noise_deter(), ts[0])
+    for t in ts:
+        x = sch.step(dummy_model(x, t), t, x, 0.0)
+    assert abs(np.abs(x).sum() - 354.5418) < 1e-2
+    assert abs(np.abs(x).mean() - 0.4616) < 1e-3
+
+
+EULER_CFG = dict(num_train_timesteps=1100, beta_start=0.0001, beta_end=0.02, beta_schedule="linear")
+
+
+def euler_full_loop(**kw):
+    sch = S.EulerRef(**dict(EULER_CFG, **kw))
+    sch.set_timesteps(10)
+    x = dummy_sample_deter() * sch.init_noise_sigma
+    for t in sch.timesteps:
+        x = sch.scale_model_input(x, t)
+        x = sch.step(dummy_model(x, t), t, x)
+    return x
+
+
+# --- tests/schedulers/test_scheduler_euler.py:84-85, 110-111, 162-163 ---
+def test_euler_full_loops():
+    x = euler_full_loop()
+    assert abs(np.abs(x).sum() - 10.0807) < 1e-2 and abs(np.abs(x).mean() - 0.0131) < 1e-3
+    x = euler_full_loop(prediction_type="v_prediction")
+    assert abs(np.abs(x).sum() - 0.0002) < 1e-2 and abs(np.abs(x).mean() - 2.2676e-06) < 1e-3
+    x = euler_full_loop(use_karras_sigmas=True)
+    assert abs(np.abs(x).sum() - 124.52299499511719) < 1e-2
+    assert abs(np.abs(x).mean() - 0.16213932633399963) < 1e-3
