@@ -1,0 +1,121 @@
+/* mi355x_sd.h — C ABI of libmi355x_sd.so: the MI355X (gfx950) implementation of the ppdiffusers
+ * Stable-Diffusion denoising hot path (UNet2DConditionModel forward).
+ *
+ * This is the drop-in boundary.  Every entry point is `extern "C"`, takes plain device pointers, sizes and a
+ * hipStream_t (passed as void*), allocates nothing, is stream-ordered and is safe to capture in a hipGraph.
+ * All functions return 0 on success or a non-zero MI355X_SD_ERR_* code; mi355x_sd_last_error() gives the text.
+ *
+ * The reference (PaddlePaddle/PaddleMIX @ 2024-10-24) reaches this arithmetic through Paddle ops and its own
+ * custom-op mechanism; each entry point cites the reference interface it replaces (paths relative to the
+ * reference checkout; PPD/ = ppdiffusers/ppdiffusers/):
+ *   - the custom-op ABI itself: PD_BUILD_OP(...).SetKernelFn(...) + paddle::Tensor arguments,
+ *     paddlemix/triton_ops/triton_ops.py:641-693, 926-972; Paddle is not available for AMD here, so the tensor
+ *     arguments become (pointer, shape, stride) triples.  INTEGRATION.md shows the PD_BUILD_OP / ctypes stub a
+ *     maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - activations: bf16, token-major rows [rows][C] == NHWC, with an explicit row stride `ld*` in elements
+ *     (a channel concat is two producers writing one buffer); C and all strides multiples of 8.
+ *   - weights: bf16 [N][K] with K contiguous (a Paddle Linear weight [in,out] transposed once at load;
+ *     a conv weight OIHW repacked to [O][kh][kw][I]); biases / norm affine parameters: fp32.
+ *   - accumulation and all statistics in fp32.
+ */
+#ifndef MI355X_SD_H
+#define MI355X_SD_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355X_SD_ABI_VERSION 1
+#define MI355X_SD_OK 0
+#define MI355X_SD_ERR_INVALID 1      /* bad argument (shape <= 0, null pointer ...)          */
+#define MI355X_SD_ERR_UNSUPPORTED 2  /* well-formed but outside the implemented configurations */
+#define MI355X_SD_ERR_HIP 3          /* HIP runtime error; see mi355x_sd_last_error()          */
+
+int mi355x_sd_abi_version(void);
+const char* mi355x_sd_last_error(void);
+/* Selects `device` and verifies it is a gfx950 part. */
+int mi355x_sd_init(int device);
+
+/* flags for mi355x_sd_linear / mi355x_sd_conv3x3 */
+#define MI355X_SD_GEGLU 1    /* W/bias rows interleaved [16 value | 16 gate]; writes N/2 columns value*gelu_erf(gate) */
+#define MI355X_SD_OUT_F32 2  /* C is fp32 */
+#define MI355X_SD_SILU 4     /* SiLU applied to the final value (TimestepEmbedding.act, PPD/models/embeddings.py:283-295) */
+
+/* C[M,N] = ((A[M,K] . W[N,K]^T) + bias[N] + rowbias[m / rows_per_batch][N] + R[M,N]) * out_scale
+ * Replaces LoRACompatibleLinear.forward (PPD/models/lora.py:453-459) and, with conv1x1 weights, the 1x1
+ * LoRACompatibleConv (lora.py:364-377); GEGLU = PPD/models/activations.py:101-104 fused into the epilogue;
+ * R / out_scale = the residual adds of PPD/models/attention.py:429,459,485 and resnet.py:800-806.
+ * bias, rowbias, R may be NULL. */
+int mi355x_sd_linear(const void* A, int lda, const void* W, void* C, int ldc, int M, int N, int K,
+                     const float* bias, const float* rowbias, int rows_per_batch, int ld_rowbias,
+                     const void* R, int ldr, float out_scale, int flags, void* stream);
+
+/* 3x3 convolution, padding 1, stride 1|2, as an implicit GEMM over an NHWC source [B][Hs][Ws][ldx>=Cin];
+ * `upsample` = 1 folds F.interpolate(scale_factor=2, mode="nearest") (PPD/models/resnet.py:169-218) into the
+ * gather.  W is [Cout][3][3][Cin].  Output rows = B*Ho*Wo with Ho = ((Hs<<upsample) + 2 - 3)/stride + 1.
+ * Replaces LoRACompatibleConv.forward (lora.py:364-377) as used by ResnetBlock2D (resnet.py:770,798, temb add
+ * :772-784 via rowbias), Downsample2D (:271-294) and Upsample2D. */
+int mi355x_sd_conv3x3(const void* X, int ldx, int B, int Hs, int Ws, int Cin, int stride, int upsample,
+                      const void* W, void* C, int ldc, int Cout,
+                      const float* bias, const float* rowbias, int ld_rowbias,
+                      const void* R, int ldr, float out_scale, int flags, void* stream);
+
+/* out = softmax(q k^T * scale + bias) v, layouts q [B,Sq,H,D], k/v [B,Skv,H,D], out [B,Sq,H,D] with explicit
+ * batch (bs) and token (ts) strides in elements; bias optional fp32 additive mask addressed
+ * b*bias_bs + h*bias_hs + q*bias_qs + kv (0 strides broadcast).  D % 8 == 0, D <= 160.
+ * Replaces scaled_dot_product_attention_ (PPD/patches/paddle_patch.py:414-529) and the body of
+ * AttnProcessor.__call__ / get_attention_scores (PPD/models/attention_processor.py:673-735, 552-586). */
+int mi355x_sd_sdpa(const void* q, const void* k, const void* v, const float* bias, void* out,
+                   int B, int H, int Sq, int Skv, int D,
+                   int64_t q_bs, int q_ts, int64_t k_bs, int k_ts, int64_t v_bs, int v_ts, int64_t o_bs, int o_ts,
+                   int64_t bias_bs, int64_t bias_hs, int64_t bias_qs, float scale, void* stream);
+
+/* GroupNorm statistics -> scale_shift[B][2][C] fp32 (scale = gamma*rstd, shift = beta - mean*scale); x is
+ * [B][HW][ldx>=C].  `workspace` needs mi355x_sd_groupnorm_workspace_floats(B,HW,C) floats.
+ * paddle.nn.GroupNorm as used at PPD/models/resnet.py:739,789; transformer_2d.py:359; unet_2d_condition.py:1194. */
+int mi355x_sd_groupnorm_workspace_floats(int B, int HW, int C);
+int mi355x_sd_groupnorm_stats(const void* x, int B, int HW, int C, int ldx, int groups, float eps,
+                              const float* gamma, const float* beta, float* workspace, float* scale_shift,
+                              void* stream);
+/* y = act(x*scale[b][c] + shift[b][c]), act = SiLU when silu != 0 (the fused GN+SiLU of resnet.py:739-741). */
+int mi355x_sd_scale_shift_act(const void* x, int B, int HW, int C, int ldx, const float* scale_shift, int silu,
+                              void* y, int ldy, void* stream);
+/* Row LayerNorm with optional affine (PPD/models/attention.py:397,442,463). C <= 2560. */
+int mi355x_sd_layernorm(const void* x, int rows, int C, int ldx, const float* gamma, const float* beta, float eps,
+                        void* y, int ldy, void* stream);
+
+/* get_timestep_embedding (PPD/models/embeddings.py:26-64) in fp32, written as bf16 to
+ * out[(i/group)*ldo + (i%group)*dim + j] for i < n, timestep t[i % t_count] (device fp32). */
+int mi355x_sd_timestep_embedding(const float* t, int t_count, int n, int dim, int group, int flip_sin_to_cos,
+                                 float freq_shift, float scale, float max_period, void* out, int ldo, void* stream);
+int mi355x_sd_silu(const void* x, void* y, int64_t n, int in_f32, int out_f32, void* stream);
+
+/* conv_in (PPD/models/unet_2d_condition.py:1064): x NCHW fp32, optional device scalar in_scale (the scheduler's
+ * scale_model_input), w [9*Cin][Cout] bf16, y NHWC bf16. */
+int mi355x_sd_conv_in3x3(const float* x_nchw, const float* in_scale, const void* w, const float* bias, void* y,
+                         int B, int Cin, int H, int W, int Cout, int ldy, void* stream);
+/* conv_out (unet_2d_condition.py:1196): x NHWC bf16, w [Cout<=4][3][3][Cin] bf16, y NCHW fp32. */
+int mi355x_sd_conv_out3x3(const void* x, int ldx, const void* w, const float* bias, float* y_nchw,
+                          int B, int Cin, int H, int W, int Cout, void* stream);
+int mi355x_sd_copy_rows(const void* x, int ldx, void* y, int ldy, int64_t rows, int C, void* stream);
+/* out = coef[0]*x + coef[1]*y on fp32 latents, coef in device memory: the linear latent update every
+ * epsilon-prediction scheduler step reduces to (PPD/schedulers/scheduling_euler_discrete.py:438-473,
+ * scheduling_ddim.py:410-457 with eta = 0). */
+int mi355x_sd_axpby(const float* x, const float* y, float* out, const float* coef, int64_t n, void* stream);
+
+/* hipGraph capture of a sequence of the calls above issued on `stream` (one denoising step). */
+int mi355x_sd_graph_begin(void* stream);
+int mi355x_sd_graph_end(void* stream, void** graph_exec);
+int mi355x_sd_graph_launch(void* graph_exec, void* stream);
+int mi355x_sd_graph_destroy(void* graph_exec);
+
+/* Test hook: dumps the lane->element maps of the MFMA / LDS-transpose instructions the kernels rely on
+ * (out: 64*(4+16+4) floats, see tests/test_gpu_probe.py). */
+int mi355x_sd_probe_layouts(float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

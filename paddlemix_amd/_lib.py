@@ -1,0 +1,79 @@
+"""ctypes binding of libmi355x_sd.so (C ABI in include/mi355x_sd.h).  Fails loudly when the library is missing."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355x_sd.so")
+
+ABI_VERSION = 1
+GEGLU, OUT_F32, SILU = 1, 2, 4
+
+# name -> (restype, argtypes); must list every symbol include/mi355x_sd.h declares (tests/test_abi.py checks)
+SIGNATURES = {
+    "mi355x_sd_abi_version": (c_int, []),
+    "mi355x_sd_last_error": (c_char_p, []),
+    "mi355x_sd_init": (c_int, [c_int]),
+    "mi355x_sd_linear": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                 c_int, c_int, c_void_p, c_int, c_float, c_int, c_void_p]),
+    "mi355x_sd_conv3x3": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
+                                  c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_float, c_int, c_void_p]),
+    "mi355x_sd_sdpa": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                               c_int64, c_int, c_int64, c_int, c_int64, c_int, c_int64, c_int, c_int64, c_int64,
+                               c_int64, c_float, c_void_p]),
+    "mi355x_sd_groupnorm_workspace_floats": (c_int, [c_int, c_int, c_int]),
+    "mi355x_sd_groupnorm_stats": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_void_p]),
+    "mi355x_sd_scale_shift_act": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
+                                          c_void_p]),
+    "mi355x_sd_layernorm": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int,
+                                    c_void_p]),
+    "mi355x_sd_timestep_embedding": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float,
+                                             c_void_p, c_int, c_void_p]),
+    "mi355x_sd_silu": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "mi355x_sd_conv_in3x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                     c_int, c_int, c_void_p]),
+    "mi355x_sd_conv_out3x3": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                      c_void_p]),
+    "mi355x_sd_copy_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p]),
+    "mi355x_sd_axpby": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mi355x_sd_graph_begin": (c_int, [c_void_p]),
+    "mi355x_sd_graph_end": (c_int, [c_void_p, POINTER(c_void_p)]),
+    "mi355x_sd_graph_launch": (c_int, [c_void_p, c_void_p]),
+    "mi355x_sd_graph_destroy": (c_int, [c_void_p]),
+    "mi355x_sd_probe_layouts": (c_int, [c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+class MI355XError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load the HIP library.  No fallback: a missing/unbuilt library is a hard error."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MI355XError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C paddlemix_amd/csrc`). paddlemix_amd has no CPU / PyTorch fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mi355x_sd_abi_version() != ABI_VERSION:
+        raise MI355XError(f"ABI mismatch: library {lib.mi355x_sd_abi_version()} != binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load().mi355x_sd_last_error()
+        raise MI355XError(f"libmi355x_sd error {rc}: {msg.decode() if msg else '?'}")

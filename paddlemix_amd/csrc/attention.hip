@@ -1,0 +1,267 @@
+// Fused scaled-dot-product attention (flash-style, online softmax) for gfx950, bf16 in / fp32 accumulate.
+//
+// Replaces the math reached from
+//   AttnProcessor.__call__ / Attention.get_attention_scores   ppdiffusers/ppdiffusers/models/attention_processor.py:673-735, 552-586
+//   XFormersAttnProcessor.__call__                             attention_processor.py:1167-1249
+//   scaled_dot_product_attention_ (math branch)                ppdiffusers/ppdiffusers/patches/paddle_patch.py:445-461
+// i.e. out = softmax(q k^T * scale + mask) v, in the sdpa_ layout q [B,Sq,h,d], k/v [B,Skv,h,d] (arbitrary
+// token / batch strides so a fused QKV projection buffer is consumed in place).
+//
+// Design (wave64, MFMA 32x32x16):
+//   * block = 4 waves x 32 query rows; K and V tiles of 64 keys are staged global -> registers -> LDS,
+//     double buffered, the next tile's loads in flight during the current tile's MFMAs;
+//   * S^T = K Q^T ("swapped" QK^T): the 32x32 accumulator then has one query per lane column, so the
+//     softmax row statistics are lane-local except for one exchange between the two half-waves;
+//   * O^T = V^T P^T: P (bf16) is consumed straight from those registers as the MFMA B operand; the matching
+//     V^T A operand comes from ds_read_b64_tr_b16 transpose reads of the row-major V tile;
+//   * K rows padded by 16 B and V rows to a stride == 64 (mod 256) B so both fragment reads are bank-conflict free.
+#include "common.h"
+#include "kernels.h"
+
+namespace sd {
+
+constexpr int ATT_WAVES = 4;
+constexpr int ATT_THREADS = ATT_WAVES * 64;
+constexpr int QROWS = 32;                   // per wave
+constexpr int QBLK = ATT_WAVES * QROWS;     // per block
+constexpr int KVBLK = 64;
+
+template <int DP>
+struct AttLds {
+  static constexpr int KRS = DP * 2 + 16;                            // K row stride (bytes)
+  static constexpr int VRS = (DP == 64) ? 192 : DP * 2;              // V row stride: 192 / 192 / 320 B
+  static constexpr int KBYTES = KVBLK * KRS;
+  static constexpr int VBYTES = KVBLK * VRS;
+  static constexpr int CHUNKS = KVBLK * (DP / 8) / ATT_THREADS;      // 16-B chunks per thread per tile: 2 / 3 / 5
+};
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+template <int DP, bool HAS_BIAS>
+__global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_kernel(const AttnArgs p) {
+  using L = AttLds<DP>;
+  constexpr int NBUF = (DP <= 96) ? 2 : 1;
+  constexpr int KS = DP / 16;   // k-steps of QK^T
+  constexpr int DB = DP / 32;   // 32-row blocks of O^T
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * (L::KBYTES + L::VBYTES)];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;
+  const int lq = lane & 31;
+
+  const int nqb = (p.Sq + QBLK - 1) / QBLK;
+  const int lid = xcd_remap(blockIdx.x, nqb * p.B * p.H);
+  const int qb = lid % nqb;
+  const int bh = lid / nqb;
+  const int b = bh / p.H, h = bh - b * p.H;
+
+  const bf16* Qp = p.Q + (size_t)b * p.q_bs + (size_t)h * p.D;
+  const bf16* Kp = p.K + (size_t)b * p.k_bs + (size_t)h * p.D;
+  const bf16* Vp = p.V + (size_t)b * p.v_bs + (size_t)h * p.D;
+  bf16* Op = p.O + (size_t)b * p.o_bs + (size_t)h * p.D;
+
+  // ---- Q fragments (MFMA B operand): lane (q = lq, hi) holds d = ks*16 + hi*8 .. +8 ----
+  const int q_row = qb * QBLK + wave * QROWS + lq;
+  const bool q_ok = q_row < p.Sq;
+  bf16x8 qf[KS];
+  {
+    const bf16* qr = Qp + (size_t)(q_ok ? q_row : 0) * p.q_ts;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int d0 = ks * 16 + hi * 8;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (q_ok && d0 < p.D) v = *reinterpret_cast<const u32x4*>(qr + d0);
+      qf[ks] = *reinterpret_cast<bf16x8*>(&v);
+    }
+  }
+
+  // ---- K/V tile loader: thread owns CHUNKS 16-B chunks of the K tile and of the V tile ----
+  u32x4 rk[L::CHUNKS], rv[L::CHUNKS];
+  auto load_kv = [&](int kv0) {
+#pragma unroll
+    for (int i = 0; i < L::CHUNKS; ++i) {
+      const int cid = tid + ATT_THREADS * i;
+      const int row = cid / (DP / 8), ch = cid - row * (DP / 8);
+      const int kv = kv0 + row;
+      const bool ok = (kv < p.Skv) && (ch * 8 < p.D);
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      rk[i] = ok ? *reinterpret_cast<const u32x4*>(Kp + (size_t)kv * p.k_ts + ch * 8) : z;
+      rv[i] = ok ? *reinterpret_cast<const u32x4*>(Vp + (size_t)kv * p.v_ts + ch * 8) : z;
+    }
+  };
+  auto store_kv = [&](int buf) {
+    unsigned char* ks_ = smem + buf * (L::KBYTES + L::VBYTES);
+    unsigned char* vs_ = ks_ + L::KBYTES;
+#pragma unroll
+    for (int i = 0; i < L::CHUNKS; ++i) {
+      const int cid = tid + ATT_THREADS * i;
+      const int row = cid / (DP / 8), ch = cid - row * (DP / 8);
+      *reinterpret_cast<u32x4*>(ks_ + row * L::KRS + ch * 16) = rk[i];
+      *reinterpret_cast<u32x4*>(vs_ + row * L::VRS + ch * 16) = rv[i];
+    }
+  };
+
+  f32x16 o[DB];
+#pragma unroll
+  for (int i = 0; i < DB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float m_run = -INFINITY;   // running max of raw scores (q . k [+ bias/scale]), both half-waves agree
+  float l_run = 0.f;         // this half-wave's partial row sum
+  const float c2 = p.scale * 1.4426950408889634f;  // exp(x*scale) = exp2(x*c2)
+
+  const int ntiles = (p.Skv + KVBLK - 1) / KVBLK;
+  load_kv(0);
+  store_kv(0);
+  __syncthreads();
+
+  // transpose-read lane geometry: 16-lane group (hi, dh) reads a [4 keys][16 d] block
+  const int i16 = lane & 15;
+  const int dh = (lane >> 4) & 1;
+  const int tr_row = (i16 >> 2);           // + key base
+  const int tr_col = dh * 16 + (i16 & 3) * 4;
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = (NBUF == 2) ? (t & 1) : 0;
+    if (NBUF == 2 && t + 1 < ntiles) load_kv((t + 1) * KVBLK);
+    const unsigned char* ks_ = smem + buf * (L::KBYTES + L::VBYTES);
+    const unsigned char* vs_ = ks_ + L::KBYTES;
+
+    // ---- S^T = K Q^T : two 32-key blocks ----
+    f32x16 s[2];
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[sb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks_ + (sb * 32 + lq) * L::KRS + (ks * 2 + hi) * 16);
+        s[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[sb], 0, 0, 0);
+      }
+    }
+
+    // ---- mask / bias; s[sb][r] is key kv0 + sb*32 + (r&3) + 8*(r>>2) + 4*hi for query lq ----
+    const int kv0 = t * KVBLK;
+    const bool tail = (kv0 + KVBLK > p.Skv);
+    if (HAS_BIAS) {
+      const float inv = 1.0f / p.scale;
+      const float* bp = p.bias + (size_t)b * p.bias_bs + (size_t)h * p.bias_hs + (size_t)(q_ok ? q_row : 0) * p.bias_qs;
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kv = kv0 + sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (kv < p.Skv) s[sb][r] += bp[kv] * inv;  // (s + bias/scale)*scale = s*scale + bias
+        }
+    }
+    if (tail) {
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kv = kv0 + sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (kv >= p.Skv) s[sb][r] = -INFINITY;
+        }
+    }
+
+    // ---- online softmax (one query per lane column) ----
+    float mloc = s[0][0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[0][r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[1][r]);
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float m_new = fmaxf(m_run, mloc);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * c2);  // m_run = -inf -> 0
+    const float mc = m_use * c2;
+    float psum = 0.f;
+    bf16x8 pf[4];
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sb][r], c2, -mc));
+        psum += e;
+        pf[sb * 2 + (r >> 3)][r & 7] = (bf16)e;
+      }
+    }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < DB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      // B-operand element i of pf[kk] is key kk*16 + (i&3) + 8*(i>>2) + 4*hi -> the A operand must match
+      const unsigned char* vrow = vs_ + (kk * 16 + 4 * hi + tr_row) * L::VRS + tr_col * 2;
+#pragma unroll
+      for (int db = 0; db < DB; ++db) {
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(vrow + db * 64));
+        const bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(vrow + 8 * L::VRS + db * 64));
+        const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kk], o[db], 0, 0, 0);
+      }
+    }
+
+    if (NBUF == 2) {
+      if (t + 1 < ntiles) store_kv(buf ^ 1);
+      __syncthreads();
+    } else {
+      __syncthreads();
+      if (t + 1 < ntiles) {
+        load_kv((t + 1) * KVBLK);
+        store_kv(0);
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- finalize: O[q][d] = O^T[d][q] / l ; lane holds d = db*32 + (r&3) + 8*(r>>2) + 4*hi ----
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv_l = (l_tot > 0.f) ? 1.0f / l_tot : 0.f;
+  if (q_ok) {
+    bf16* orow = Op + (size_t)q_row * p.o_ts;
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int d = db * 32 + 8 * c + 4 * hi;
+        if (d < p.D) {
+          u32x2 pk = {pack_bf16(o[db][4 * c + 0] * inv_l, o[db][4 * c + 1] * inv_l),
+                      pack_bf16(o[db][4 * c + 2] * inv_l, o[db][4 * c + 3] * inv_l)};
+          *reinterpret_cast<u32x2*>(orow + d) = pk;
+        }
+      }
+  }
+}
+
+template <int DP>
+static int launch_dp(const AttnArgs& a, hipStream_t stream) {
+  const int nqb = (a.Sq + QBLK - 1) / QBLK;
+  dim3 grid(nqb * a.B * a.H), block(ATT_THREADS);
+  if (a.bias)
+    hipLaunchKernelGGL((attention_kernel<DP, true>), grid, block, 0, stream, a);
+  else
+    hipLaunchKernelGGL((attention_kernel<DP, false>), grid, block, 0, stream, a);
+  return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+}
+
+int launch_attention(const AttnArgs& a, hipStream_t stream) {
+  if (a.B <= 0 || a.H <= 0 || a.Sq <= 0 || a.Skv <= 0 || a.D <= 0) return SD_ERR_INVALID;
+  if ((a.D & 7) || a.D > 160) return SD_ERR_UNSUPPORTED;
+  if ((a.q_ts & 7) || (a.k_ts & 7) || (a.v_ts & 7) || (a.o_ts & 3) || (a.q_bs & 7) || (a.k_bs & 7) || (a.v_bs & 7) ||
+      (a.o_bs & 3))
+    return SD_ERR_UNSUPPORTED;
+  if (!(a.scale > 0.f)) return SD_ERR_INVALID;
+  if (a.D <= 64) return launch_dp<64>(a, stream);
+  if (a.D <= 96) return launch_dp<96>(a, stream);
+  return launch_dp<160>(a, stream);
+}
+
+}  // namespace sd

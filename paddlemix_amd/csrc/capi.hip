@@ -1,0 +1,235 @@
+// C ABI of libmi355x_sd.so (declared in include/mi355x_sd.h): argument validation + kernel launches.
+#include "../../include/mi355x_sd.h"
+
+#include <stdio.h>
+#include <string.h>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+thread_local char g_err[512] = "";
+int fail(int code, const char* fmt, const char* a = "") {
+  snprintf(g_err, sizeof(g_err), fmt, a);
+  return code;
+}
+int finish(int rc, const char* what) {
+  if (rc == SD_OK) return SD_OK;
+  if (rc == SD_ERR_HIP) {
+    hipError_t e = hipGetLastError();
+    snprintf(g_err, sizeof(g_err), "%s: HIP error: %s", what, hipGetErrorString(e));
+  } else if (rc == SD_ERR_UNSUPPORTED) {
+    snprintf(g_err, sizeof(g_err), "%s: unsupported shape/stride/alignment (see include/mi355x_sd.h)", what);
+  } else {
+    snprintf(g_err, sizeof(g_err), "%s: invalid argument", what);
+  }
+  return rc;
+}
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+}  // namespace
+
+using namespace sd;
+
+// ---- layout probe (tests/test_gpu_probe.py) -------------------------------------------------------------------
+__global__ void probe_kernel(float* out) {
+  __shared__ __attribute__((aligned(16))) bf16 lds[256];
+  const int l = threadIdx.x;
+  for (int i = l; i < 256; i += 64) lds[i] = (bf16)(float)i;
+  __syncthreads();
+  // 16x16x32: a lane supplies A[row = l&15][k = (l>>4)*8 + i], B[k = (l>>4)*8 + i][col = l&15]
+  bf16x8 a, b;
+  for (int i = 0; i < 8; ++i) {
+    const int k = (l >> 4) * 8 + i;
+    a[i] = (bf16)(float)((((l & 15) * 7 + k * 3) % 11) - 5);
+    b[i] = (bf16)(float)(((k * 5 + (l & 15) * 2) % 13) - 6);
+  }
+  f32x4 c = {0.f, 0.f, 0.f, 0.f};
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  for (int i = 0; i < 4; ++i) out[l * 24 + i] = c[i];
+  // 32x32x16: A[row = l&31][k = (l>>5)*8 + i], B[k][col = l&31]
+  for (int i = 0; i < 8; ++i) {
+    const int k = (l >> 5) * 8 + i;
+    a[i] = (bf16)(float)((((l & 31) * 7 + k * 3) % 11) - 5);
+    b[i] = (bf16)(float)(((k * 5 + (l & 31) * 2) % 13) - 6);
+  }
+  f32x16 d;
+  for (int i = 0; i < 16; ++i) d[i] = 0.f;
+  d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, d, 0, 0, 0);
+  for (int i = 0; i < 16; ++i) out[l * 24 + 4 + i] = d[i];
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  const bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(lds + l * 4));
+  for (int i = 0; i < 4; ++i) out[l * 24 + 20 + i] = (float)t[i];
+}
+
+extern "C" {
+
+int mi355x_sd_abi_version(void) { return MI355X_SD_ABI_VERSION; }
+const char* mi355x_sd_last_error(void) { return g_err; }
+
+int mi355x_sd_init(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(SD_ERR_HIP, "mi355x_sd_init: no HIP device visible");
+  if (device < 0 || device >= n) return fail(SD_ERR_INVALID, "mi355x_sd_init: device index out of range");
+  if (hipSetDevice(device) != hipSuccess) return fail(SD_ERR_HIP, "mi355x_sd_init: hipSetDevice failed");
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(SD_ERR_HIP, "mi355x_sd_init: no properties");
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(SD_ERR_UNSUPPORTED, "mi355x_sd_init: device is %s, this library is built for gfx950 only",
+                prop.gcnArchName);
+  return SD_OK;
+}
+
+int mi355x_sd_linear(const void* A, int lda, const void* W, void* C, int ldc, int M, int N, int K, const float* bias,
+                     const float* rowbias, int rows_per_batch, int ld_rowbias, const void* R, int ldr, float out_scale,
+                     int flags, void* stream) {
+  if (!A || !W || !C) return fail(SD_ERR_INVALID, "mi355x_sd_linear: null pointer");
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = (const bf16*)A; g.W = (const bf16*)W; g.C = C;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc;
+  g.bias = bias; g.rowbias = rowbias; g.rows_per_batch = rows_per_batch; g.ld_rowbias = ld_rowbias;
+  g.R = (const bf16*)R; g.ldr = ldr; g.out_scale = out_scale;
+  g.geglu = (flags & MI355X_SD_GEGLU) ? 1 : 0;
+  g.out_f32 = (flags & MI355X_SD_OUT_F32) ? 1 : 0;
+  g.silu = (flags & MI355X_SD_SILU) ? 1 : 0;
+  return finish(launch_gemm(g, S(stream)), "mi355x_sd_linear");
+}
+
+int mi355x_sd_conv3x3(const void* X, int ldx, int B, int Hs, int Ws, int Cin, int stride, int upsample, const void* W,
+                      void* C, int ldc, int Cout, const float* bias, const float* rowbias, int ld_rowbias,
+                      const void* R, int ldr, float out_scale, int flags, void* stream) {
+  if (!X || !W || !C) return fail(SD_ERR_INVALID, "mi355x_sd_conv3x3: null pointer");
+  if (B <= 0 || Hs <= 0 || Ws <= 0 || Cin <= 0 || Cout <= 0 || (stride != 1 && stride != 2) ||
+      (upsample != 0 && upsample != 1))
+    return fail(SD_ERR_INVALID, "mi355x_sd_conv3x3: bad shape");
+  if (flags & MI355X_SD_GEGLU) return fail(SD_ERR_UNSUPPORTED, "mi355x_sd_conv3x3: GEGLU epilogue is linear-only");
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = (const bf16*)X; g.W = (const bf16*)W; g.C = C;
+  g.conv = 1; g.Hs = Hs; g.Ws = Ws; g.Cin = Cin; g.stride = stride; g.up = upsample;
+  const int Hin = Hs << upsample, Win = Ws << upsample;
+  g.Ho = (Hin + 2 - 3) / stride + 1;
+  g.Wo = (Win + 2 - 3) / stride + 1;
+  g.M = B * g.Ho * g.Wo; g.N = Cout; g.K = 9 * Cin; g.lda = ldx; g.ldc = ldc;
+  g.bias = bias; g.rowbias = rowbias; g.rows_per_batch = g.Ho * g.Wo; g.ld_rowbias = ld_rowbias;
+  g.R = (const bf16*)R; g.ldr = ldr; g.out_scale = out_scale;
+  g.out_f32 = (flags & MI355X_SD_OUT_F32) ? 1 : 0;
+  g.silu = (flags & MI355X_SD_SILU) ? 1 : 0;
+  return finish(launch_gemm(g, S(stream)), "mi355x_sd_conv3x3");
+}
+
+int mi355x_sd_sdpa(const void* q, const void* k, const void* v, const float* bias, void* out, int B, int H, int Sq,
+                   int Skv, int D, int64_t q_bs, int q_ts, int64_t k_bs, int k_ts, int64_t v_bs, int v_ts,
+                   int64_t o_bs, int o_ts, int64_t bias_bs, int64_t bias_hs, int64_t bias_qs, float scale,
+                   void* stream) {
+  if (!q || !k || !v || !out) return fail(SD_ERR_INVALID, "mi355x_sd_sdpa: null pointer");
+  AttnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.Q = (const bf16*)q; a.K = (const bf16*)k; a.V = (const bf16*)v; a.O = (bf16*)out;
+  a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.D = D;
+  a.q_bs = q_bs; a.k_bs = k_bs; a.v_bs = v_bs; a.o_bs = o_bs;
+  a.q_ts = q_ts; a.k_ts = k_ts; a.v_ts = v_ts; a.o_ts = o_ts;
+  a.bias = bias; a.bias_bs = bias_bs; a.bias_hs = bias_hs; a.bias_qs = bias_qs;
+  a.scale = scale;
+  return finish(launch_attention(a, S(stream)), "mi355x_sd_sdpa");
+}
+
+int mi355x_sd_groupnorm_workspace_floats(int B, int HW, int C) { return groupnorm_partial_floats(B, HW, C); }
+
+int mi355x_sd_groupnorm_stats(const void* x, int B, int HW, int C, int ldx, int groups, float eps, const float* gamma,
+                              const float* beta, float* workspace, float* scale_shift, void* stream) {
+  if (!x || !gamma || !beta || !workspace || !scale_shift)
+    return fail(SD_ERR_INVALID, "mi355x_sd_groupnorm_stats: null pointer");
+  return finish(launch_groupnorm_stats((const bf16*)x, B, HW, C, ldx, groups, eps, gamma, beta, workspace, scale_shift,
+                                       S(stream)),
+                "mi355x_sd_groupnorm_stats");
+}
+
+int mi355x_sd_scale_shift_act(const void* x, int B, int HW, int C, int ldx, const float* scale_shift, int silu, void* y,
+                              int ldy, void* stream) {
+  if (!x || !scale_shift || !y) return fail(SD_ERR_INVALID, "mi355x_sd_scale_shift_act: null pointer");
+  return finish(launch_scale_shift_act((const bf16*)x, B, HW, C, ldx, scale_shift, silu, (bf16*)y, ldy, S(stream)),
+                "mi355x_sd_scale_shift_act");
+}
+
+int mi355x_sd_layernorm(const void* x, int rows, int C, int ldx, const float* gamma, const float* beta, float eps,
+                        void* y, int ldy, void* stream) {
+  if (!x || !y) return fail(SD_ERR_INVALID, "mi355x_sd_layernorm: null pointer");
+  return finish(launch_layernorm((const bf16*)x, rows, C, ldx, gamma, beta, eps, (bf16*)y, ldy, S(stream)),
+                "mi355x_sd_layernorm");
+}
+
+int mi355x_sd_timestep_embedding(const float* t, int t_count, int n, int dim, int group, int flip_sin_to_cos,
+                                 float freq_shift, float scale, float max_period, void* out, int ldo, void* stream) {
+  if (!t || !out) return fail(SD_ERR_INVALID, "mi355x_sd_timestep_embedding: null pointer");
+  return finish(launch_timestep_embedding(t, t_count, n, dim, group, flip_sin_to_cos, freq_shift, scale, max_period,
+                                          (bf16*)out, ldo, S(stream)),
+                "mi355x_sd_timestep_embedding");
+}
+
+int mi355x_sd_silu(const void* x, void* y, int64_t n, int in_f32, int out_f32, void* stream) {
+  if (!x || !y) return fail(SD_ERR_INVALID, "mi355x_sd_silu: null pointer");
+  return finish(launch_silu(x, y, (long)n, in_f32, out_f32, S(stream)), "mi355x_sd_silu");
+}
+
+int mi355x_sd_conv_in3x3(const float* x_nchw, const float* in_scale, const void* w, const float* bias, void* y, int B,
+                         int Cin, int H, int W, int Cout, int ldy, void* stream) {
+  if (!x_nchw || !w || !y) return fail(SD_ERR_INVALID, "mi355x_sd_conv_in3x3: null pointer");
+  return finish(launch_conv_in3x3(x_nchw, in_scale, (const bf16*)w, bias, (bf16*)y, B, Cin, H, W, Cout, ldy, S(stream)),
+                "mi355x_sd_conv_in3x3");
+}
+
+int mi355x_sd_conv_out3x3(const void* x, int ldx, const void* w, const float* bias, float* y_nchw, int B, int Cin, int H,
+                          int W, int Cout, void* stream) {
+  if (!x || !w || !y_nchw) return fail(SD_ERR_INVALID, "mi355x_sd_conv_out3x3: null pointer");
+  return finish(launch_conv_out3x3((const bf16*)x, ldx, (const bf16*)w, bias, y_nchw, B, Cin, H, W, Cout, S(stream)),
+                "mi355x_sd_conv_out3x3");
+}
+
+int mi355x_sd_copy_rows(const void* x, int ldx, void* y, int ldy, int64_t rows, int C, void* stream) {
+  if (!x || !y) return fail(SD_ERR_INVALID, "mi355x_sd_copy_rows: null pointer");
+  return finish(launch_copy_rows((const bf16*)x, ldx, (bf16*)y, ldy, (long)rows, C, S(stream)), "mi355x_sd_copy_rows");
+}
+
+int mi355x_sd_axpby(const float* x, const float* y, float* out, const float* coef, int64_t n, void* stream) {
+  if (!x || !y || !out || !coef) return fail(SD_ERR_INVALID, "mi355x_sd_axpby: null pointer");
+  return finish(launch_axpby(x, y, out, coef, (long)n, S(stream)), "mi355x_sd_axpby");
+}
+
+int mi355x_sd_graph_begin(void* stream) {
+  if (hipStreamBeginCapture(S(stream), hipStreamCaptureModeThreadLocal) != hipSuccess)
+    return finish(SD_ERR_HIP, "mi355x_sd_graph_begin");
+  return SD_OK;
+}
+
+int mi355x_sd_graph_end(void* stream, void** graph_exec) {
+  if (!graph_exec) return fail(SD_ERR_INVALID, "mi355x_sd_graph_end: null pointer");
+  hipGraph_t graph = nullptr;
+  if (hipStreamEndCapture(S(stream), &graph) != hipSuccess || !graph) return finish(SD_ERR_HIP, "mi355x_sd_graph_end");
+  hipGraphExec_t exec = nullptr;
+  hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) return finish(SD_ERR_HIP, "mi355x_sd_graph_end(instantiate)");
+  *graph_exec = exec;
+  return SD_OK;
+}
+
+int mi355x_sd_graph_launch(void* graph_exec, void* stream) {
+  if (!graph_exec) return fail(SD_ERR_INVALID, "mi355x_sd_graph_launch: null graph");
+  if (hipGraphLaunch(reinterpret_cast<hipGraphExec_t>(graph_exec), S(stream)) != hipSuccess)
+    return finish(SD_ERR_HIP, "mi355x_sd_graph_launch");
+  return SD_OK;
+}
+
+int mi355x_sd_graph_destroy(void* graph_exec) {
+  if (graph_exec) (void)hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(graph_exec));
+  return SD_OK;
+}
+
+int mi355x_sd_probe_layouts(float* out, void* stream) {
+  if (!out) return fail(SD_ERR_INVALID, "mi355x_sd_probe_layouts: null pointer");
+  hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, S(stream), out);
+  return finish(hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP, "mi355x_sd_probe_layouts");
+}
+
+}  // extern "C"

@@ -1,0 +1,59 @@
+// Common device helpers for the MI355X (gfx950 / CDNA4) Stable-Diffusion denoising kernels.
+// Written for wave64 + MFMA; no CUDA compatibility paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sd {
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
+__device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }  // RNE; lowers to v_cvt_pk_bf16_f32
+
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+  bf16x2 p = {(bf16)lo, (bf16)hi};
+  return *reinterpret_cast<uint32_t*>(&p);
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// erf-GELU (paddle F.gelu(approximate=False)); erff is accurate to fp32 ulp-level.
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Bijective XCD-aware remap of a 1-D block id: hardware places block b on XCD b % 8; give every XCD a
+// contiguous chunk of the logical id space so neighbouring tiles share an L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+}  // namespace sd
+
+// status codes of the C ABI (include/mi355x_sd.h)
+#define SD_OK 0
+#define SD_ERR_INVALID 1
+#define SD_ERR_UNSUPPORTED 2
+#define SD_ERR_HIP 3

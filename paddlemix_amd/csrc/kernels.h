@@ -1,0 +1,68 @@
+// Internal launch interfaces between the HIP kernels and the C ABI (capi.hip). Not installed.
+#pragma once
+#include "common.h"
+
+namespace sd {
+
+struct GemmArgs {
+  const bf16* A;   // activations: rows x K (linear) or NHWC source tensor (conv)
+  const bf16* W;   // [N][K], K contiguous
+  void* C;         // bf16 (or fp32 when out_f32) rows x ldc
+  int M, N, K;
+  int lda;         // row / pixel stride of A in elements
+  int ldc;
+  // implicit-GEMM 3x3 convolution, pad 1 (conv != 0): K = 9*Cin ordered (ky, kx, cin)
+  int conv;
+  int Hs, Ws;      // stored source height / width
+  int Ho, Wo;      // output height / width
+  int Cin;
+  int stride;      // 1 | 2
+  int up;          // 1: nearest-2x upsample of the source folded into the gather
+  // epilogue
+  const float* bias;      // [N]
+  const float* rowbias;   // [M / rows_per_batch][ld_rowbias] broadcast over rows of one batch item
+  int rows_per_batch;
+  int ld_rowbias;
+  const bf16* R;          // residual rows x ldr
+  int ldr;
+  float out_scale;        // multiplies (acc + bias + rowbias + R)
+  int geglu;              // W/bias rows interleaved [16 value | 16 gate]; writes N/2 columns value*gelu(gate)
+  int out_f32;
+  int silu;               // SiLU applied last
+};
+int launch_gemm(const GemmArgs& a, hipStream_t stream);
+
+struct AttnArgs {
+  const bf16 *Q, *K, *V;
+  bf16* O;
+  int B, H, Sq, Skv, D;
+  // element strides; head h starts at + h*D inside a token row
+  long q_bs, k_bs, v_bs, o_bs;   // batch strides
+  int q_ts, k_ts, v_ts, o_ts;    // token strides
+  const float* bias;             // optional additive mask, indexed b*bias_bs + h*bias_hs + q*bias_qs + kv
+  long bias_bs, bias_hs, bias_qs;
+  float scale;
+};
+int launch_attention(const AttnArgs& a, hipStream_t stream);
+
+// GroupNorm over NHWC rows: stats -> per-(batch, channel) scale/shift, then fused normalise(+SiLU)
+int launch_groupnorm_stats(const bf16* x, int B, int HW, int C, int ldx, int groups, float eps, const float* gamma,
+                           const float* beta, float* partial, float* scale_shift, hipStream_t stream);
+int groupnorm_partial_floats(int B, int HW, int C);
+int launch_scale_shift_act(const bf16* x, int B, int HW, int C, int ldx, const float* scale_shift, int silu, bf16* y,
+                           int ldy, hipStream_t stream);
+int launch_layernorm(const bf16* x, int rows, int C, int ldx, const float* gamma, const float* beta, float eps, bf16* y,
+                     int ldy, hipStream_t stream);
+
+// small ops
+int launch_timestep_embedding(const float* t, int t_count, int n, int dim, int group, int flip_sin_to_cos,
+                              float freq_shift, float scale, float max_period, bf16* out, int ldo, hipStream_t stream);
+int launch_silu(const void* x, void* y, long n, int in_f32, int out_f32, hipStream_t stream);
+int launch_conv_in3x3(const float* x_nchw, const float* in_scale, const bf16* w, const float* bias, bf16* y, int B,
+                      int Cin, int H, int W, int Cout, int ldy, hipStream_t stream);
+int launch_conv_out3x3(const bf16* x, int ldx, const bf16* w, const float* bias, float* y_nchw, int B, int Cin, int H,
+                       int W, int Cout, hipStream_t stream);
+int launch_copy_rows(const bf16* x, int ldx, bf16* y, int ldy, long rows, int C, hipStream_t stream);
+int launch_axpby(const float* x, const float* y, float* out, const float* coef, long n, hipStream_t stream);
+
+}  // namespace sd

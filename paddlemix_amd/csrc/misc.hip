@@ -1,0 +1,226 @@
+// Small kernels around the UNet body (gfx950): sinusoidal timestep embedding, SiLU, the 4-channel conv_in /
+// conv_out 3x3 convolutions (too thin for the MFMA tile: direct kernels), strided row copy, and the
+// a*x + b*y latent update used by the scheduler steps.
+//
+// Reference semantics:
+//   get_timestep_embedding            ppdiffusers/ppdiffusers/models/embeddings.py:26-64  (fp32 math, then cast to model dtype
+//                                     unet_2d_condition.py:946-951; SDXL time_ids path :1003-1008)
+//   conv_in / conv_out                unet_2d_condition.py:1064, 1196 (3x3, pad 1), NCHW fp32 <-> NHWC bf16 at the boundary
+//   scheduler latent updates          schedulers/scheduling_euler_discrete.py:438-473, scheduling_ddim.py:410-457
+#include "common.h"
+#include "kernels.h"
+
+namespace sd {
+
+// out[(i / group) * ldo + (i % group) * dim + j], i in [0, n), timestep t[i % t_count]
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, int t_count, int n, int dim, int group,
+                                          int flip_sin_to_cos, float freq_shift, float scale, float max_period,
+                                          bf16* __restrict__ out, int ldo) {
+  const int half = dim / 2;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * half) return;
+  const int i = idx / half, j = idx - i * half;
+  const float exponent = -logf(max_period) * (float)j / ((float)half - freq_shift);
+  const float freq = expf(exponent);
+  const float arg = scale * (t[i % t_count] * freq);
+  const float sn = sinf(arg), cs = cosf(arg);
+  bf16* o = out + (size_t)(i / group) * ldo + (size_t)(i % group) * dim;
+  if (flip_sin_to_cos) {
+    o[j] = (bf16)cs;
+    o[half + j] = (bf16)sn;
+  } else {
+    o[j] = (bf16)sn;
+    o[half + j] = (bf16)cs;
+  }
+  if ((dim & 1) && j == 0) o[dim - 1] = (bf16)0.f;
+}
+
+int launch_timestep_embedding(const float* t, int t_count, int n, int dim, int group, int flip_sin_to_cos,
+                              float freq_shift, float scale, float max_period, bf16* out, int ldo,
+                              hipStream_t stream) {
+  if (n <= 0 || dim < 2 || group <= 0 || t_count <= 0) return SD_ERR_INVALID;
+  const int total = n * (dim / 2);
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, t, t_count, n, dim,
+                     group, flip_sin_to_cos, freq_shift, scale, max_period, out, ldo);
+  return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+}
+
+template <bool IN_F32, bool OUT_F32>
+__global__ void silu_kernel(const void* __restrict__ x, void* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = IN_F32 ? reinterpret_cast<const float*>(x)[i] : (float)reinterpret_cast<const bf16*>(x)[i];
+    const float r = silu_f(v);
+    if (OUT_F32)
+      reinterpret_cast<float*>(y)[i] = r;
+    else
+      reinterpret_cast<bf16*>(y)[i] = (bf16)r;
+  }
+}
+
+int launch_silu(const void* x, void* y, long n, int in_f32, int out_f32, hipStream_t stream) {
+  if (n <= 0) return SD_ERR_INVALID;
+  long nb = (n + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  dim3 g((unsigned)nb), b(256);
+  if (in_f32 && out_f32)
+    hipLaunchKernelGGL((silu_kernel<true, true>), g, b, 0, stream, x, y, n);
+  else if (in_f32)
+    hipLaunchKernelGGL((silu_kernel<true, false>), g, b, 0, stream, x, y, n);
+  else if (out_f32)
+    hipLaunchKernelGGL((silu_kernel<false, true>), g, b, 0, stream, x, y, n);
+  else
+    hipLaunchKernelGGL((silu_kernel<false, false>), g, b, 0, stream, x, y, n);
+  return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+}
+
+// conv_in: x NCHW fp32 [B,Cin,H,W] (optionally multiplied by *in_scale: the scheduler's scale_model_input folded in),
+// rounded to bf16 like the reference's sample.cast(self.dtype); w packed [9*Cin][Cout] bf16, k = (ky*3+kx)*Cin + ci.
+// One thread = one pixel x 8 output channels.
+__global__ void conv_in3x3_kernel(const float* __restrict__ x, const float* __restrict__ in_scale,
+                                  const bf16* __restrict__ w, const float* __restrict__ bias, bf16* __restrict__ y,
+                                  int B, int Cin, int H, int W, int Cout, int ldy) {
+  const int cv = Cout >> 3;
+  const long total = (long)B * H * W * cv;
+  const float xs = in_scale ? *in_scale : 1.0f;
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long)gridDim.x * blockDim.x) {
+    const long pix = id / cv;
+    const int cc = (int)(id - pix * cv);
+    const int px = (int)(pix % W);
+    const int py = (int)((pix / W) % H);
+    const int b = (int)(pix / ((long)W * H));
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = bias ? bias[cc * 8 + j] : 0.f;
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = py + ky - 1;
+      if ((unsigned)iy >= (unsigned)H) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = px + kx - 1;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        for (int ci = 0; ci < Cin; ++ci) {
+          const float xv = (float)(bf16)(x[(((size_t)b * Cin + ci) * H + iy) * W + ix] * xs);
+          const u32x4 raw = *reinterpret_cast<const u32x4*>(w + (size_t)((ky * 3 + kx) * Cin + ci) * Cout + cc * 8);
+          const bf16x8 wv = *reinterpret_cast<const bf16x8*>(&raw);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(xv, (float)wv[j], acc[j]);
+        }
+      }
+    }
+    u32x4 pk = {pack_bf16(acc[0], acc[1]), pack_bf16(acc[2], acc[3]), pack_bf16(acc[4], acc[5]),
+                pack_bf16(acc[6], acc[7])};
+    *reinterpret_cast<u32x4*>(y + (size_t)pix * ldy + cc * 8) = pk;
+  }
+}
+
+int launch_conv_in3x3(const float* x_nchw, const float* in_scale, const bf16* w, const float* bias, bf16* y, int B,
+                      int Cin, int H, int W, int Cout, int ldy, hipStream_t stream) {
+  if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return SD_ERR_INVALID;
+  if ((Cout & 7) || (ldy & 7)) return SD_ERR_UNSUPPORTED;
+  const long total = (long)B * H * W * (Cout >> 3);
+  long nb = (total + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(conv_in3x3_kernel, dim3((unsigned)nb), dim3(256), 0, stream, x_nchw, in_scale, w, bias, y, B, Cin,
+                     H, W, Cout, ldy);
+  return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+}
+
+// conv_out: x NHWC bf16 (already GroupNorm+SiLU'd) -> y NCHW fp32 [B,Cout<=4,H,W]; w [Cout][9][Cin] bf16 in LDS.
+// One wave per output pixel: lanes split the 9*Cin reduction in 16-B chunks, then a wave reduction.
+constexpr int CO_MAX = 4;
+__global__ void conv_out3x3_kernel(const bf16* __restrict__ x, int ldx, const bf16* __restrict__ w,
+                                   const float* __restrict__ bias, float* __restrict__ y, int B, int Cin, int H, int W,
+                                   int Cout) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  bf16* ws = reinterpret_cast<bf16*>(dsm);  // [Cout][9*Cin]
+  const int K = 9 * Cin;
+  for (int i = threadIdx.x; i < Cout * K / 8; i += blockDim.x)
+    reinterpret_cast<u32x4*>(ws)[i] = reinterpret_cast<const u32x4*>(w)[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const int cvin = Cin >> 3;
+  const long npix = (long)B * H * W;
+  for (long pix = (long)blockIdx.x * wpb + (threadIdx.x >> 6); pix < npix; pix += (long)gridDim.x * wpb) {
+    const int px = (int)(pix % W);
+    const int py = (int)((pix / W) % H);
+    const int b = (int)(pix / ((long)W * H));
+    float acc[CO_MAX] = {0.f, 0.f, 0.f, 0.f};
+    for (int ch = lane; ch < 9 * cvin; ch += 64) {
+      const int tap = ch / cvin, cc = ch - tap * cvin;
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const int iy = py + ky - 1, ix = px + kx - 1;
+      if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) continue;
+      const u32x4 raw = *reinterpret_cast<const u32x4*>(x + (((size_t)b * H + iy) * W + ix) * ldx + cc * 8);
+      const bf16x8 xv = *reinterpret_cast<const bf16x8*>(&raw);
+#pragma unroll
+      for (int co = 0; co < CO_MAX; ++co) {
+        if (co < Cout) {
+          const bf16x8 wv = *reinterpret_cast<const bf16x8*>(ws + (size_t)co * K + tap * Cin + cc * 8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[co] = __builtin_fmaf((float)xv[j], (float)wv[j], acc[co]);
+        }
+      }
+    }
+#pragma unroll
+    for (int co = 0; co < CO_MAX; ++co) acc[co] = wave_sum(acc[co]);
+    if (lane < Cout) {
+      float v = acc[0];
+      if (lane == 1) v = acc[1];
+      if (lane == 2) v = acc[2];
+      if (lane == 3) v = acc[3];
+      y[(((size_t)b * Cout + lane) * H + py) * W + px] = v + (bias ? bias[lane] : 0.f);
+    }
+  }
+}
+
+int launch_conv_out3x3(const bf16* x, int ldx, const bf16* w, const float* bias, float* y_nchw, int B, int Cin, int H,
+                       int W, int Cout, hipStream_t stream) {
+  if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return SD_ERR_INVALID;
+  if (Cout > CO_MAX || (Cin & 7) || (ldx & 7)) return SD_ERR_UNSUPPORTED;
+  const size_t lds = (size_t)Cout * 9 * Cin * 2;
+  if (lds > 64 * 1024) return SD_ERR_UNSUPPORTED;
+  const long npix = (long)B * H * W;
+  long nb = (npix + 3) / 4;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(conv_out3x3_kernel, dim3((unsigned)nb), dim3(256), lds, stream, x, ldx, w, bias, y_nchw, B, Cin, H,
+                     W, Cout);
+  return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+}
+
+__global__ void copy_rows_kernel(const bf16* __restrict__ x, int ldx, bf16* __restrict__ y, int ldy, long rows, int cv) {
+  const long total = rows * cv;
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long)gridDim.x * blockDim.x) {
+    const long r = id / cv;
+    const int cc = (int)(id - r * cv);
+    *reinterpret_cast<u32x4*>(y + (size_t)r * ldy + cc * 8) = *reinterpret_cast<const u32x4*>(x + (size_t)r * ldx + cc * 8);
+  }
+}
+
+int launch_copy_rows(const bf16* x, int ldx, bf16* y, int ldy, long rows, int C, hipStream_t stream) {
+  if (rows <= 0 || C <= 0) return SD_ERR_INVALID;
+  if ((C & 7) || (ldx & 7) || (ldy & 7)) return SD_ERR_UNSUPPORTED;
+  const long total = rows * (C >> 3);
+  long nb = (total + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)nb), dim3(256), 0, stream, x, ldx, y, ldy, rows, C >> 3);
+  return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+}
+
+// out = coef[0]*x + coef[1]*y  (fp32 latents; coefficients live in device memory so a captured graph can be
+// replayed with per-step values)
+__global__ void axpby_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out,
+                             const float* __restrict__ coef, long n) {
+  const float a = coef[0], b = coef[1];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i] = a * x[i] + b * y[i];
+}
+
+int launch_axpby(const float* x, const float* y, float* out, const float* coef, long n, hipStream_t stream) {
+  if (n <= 0) return SD_ERR_INVALID;
+  long nb = (n + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)nb), dim3(256), 0, stream, x, y, out, coef, n);
+  return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+}
+
+}  // namespace sd

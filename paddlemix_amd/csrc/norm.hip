@@ -1,0 +1,252 @@
+// HBM-bound normalisation kernels (gfx950): GroupNorm(+SiLU) over NHWC rows and LayerNorm over token rows.
+//
+// Reference semantics:
+//   paddle.nn.GroupNorm(num_groups, C, epsilon) + F.silu   ppdiffusers/ppdiffusers/models/resnet.py:739-741, 789-795,
+//                                                          transformer_2d.py:359 (eps 1e-6), unet_2d_condition.py:1194-1195
+//   paddle.nn.LayerNorm(C, epsilon=1e-5)                   ppdiffusers/ppdiffusers/models/attention.py:397, 442, 463
+// Statistics are biased (divide by N), accumulated in fp32 (+ fp64 across blocks), outputs written as bf16.
+//
+// GroupNorm is split in two so the second half is a pure per-channel affine (+SiLU):
+//   1. gn_partial_kernel:  per-(batch, pixel-strip) block sums of x and x^2 per group      (reads x once)
+//      gn_finalize_kernel: mean / rstd per (batch, group) -> scale[b][c] = gamma*rstd, shift[b][c] = beta - mean*scale
+//   2. scale_shift_act_kernel: y = act(x*scale + shift)                                    (reads x once, writes y once)
+// All loads/stores are 16-byte (8 x bf16) per lane.
+#include "common.h"
+#include "kernels.h"
+
+namespace sd {
+
+constexpr int GN_ITERS = 16;      // pixels per thread-slot per block
+constexpr int GN_MAXC = 4096;
+
+struct GnGeom {
+  int cv;        // 16-B chunks per pixel = C / 8
+  int ppp;       // pixels processed per pass by one block
+  int threads;   // active threads = ppp * cv
+  int block;     // launch block size (multiple of 64)
+  int ppb;       // pixels per block
+  int nblk;      // blocks per batch item
+};
+static GnGeom gn_geom(int HW, int C) {
+  GnGeom g;
+  g.cv = C / 8;
+  g.ppp = g.cv <= 256 ? 256 / g.cv : 1;
+  g.threads = g.ppp * g.cv;
+  g.block = (g.threads + 63) / 64 * 64;
+  g.ppb = g.ppp * GN_ITERS;
+  g.nblk = (HW + g.ppb - 1) / g.ppb;
+  return g;
+}
+
+__global__ void gn_partial_kernel(const bf16* __restrict__ x, int HW, int C, int ldx, int groups, int cv, int ppp,
+                                  int nthreads, int ppb, float* __restrict__ partial) {
+  __shared__ float ch_sum[GN_MAXC];
+  __shared__ float ch_sq[GN_MAXC];
+  __shared__ float g_acc[2 * 64];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  for (int i = tid; i < C; i += blockDim.x) {
+    ch_sum[i] = 0.f;
+    ch_sq[i] = 0.f;
+  }
+  if (tid < 2 * groups) g_acc[tid] = 0.f;
+  __syncthreads();
+  if (tid < nthreads) {
+    const int cc = tid % cv, pl = tid / cv;
+    const int p_begin = blockIdx.x * ppb;
+    const int p_end = min(p_begin + ppb, HW);
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
+    const bf16* xb = x + (size_t)b * HW * ldx + cc * 8;
+    for (int pix = p_begin + pl; pix < p_end; pix += ppp) {
+      const u32x4 raw = *reinterpret_cast<const u32x4*>(xb + (size_t)pix * ldx);
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(&raw);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float f = (float)v[j];
+        s[j] += f;
+        q[j] = __builtin_fmaf(f, f, q[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      atomicAdd(&ch_sum[cc * 8 + j], s[j]);
+      atomicAdd(&ch_sq[cc * 8 + j], q[j]);
+    }
+  }
+  __syncthreads();
+  const int cpg = C / groups;
+  for (int c = tid; c < C; c += blockDim.x) {
+    atomicAdd(&g_acc[2 * (c / cpg)], ch_sum[c]);
+    atomicAdd(&g_acc[2 * (c / cpg) + 1], ch_sq[c]);
+  }
+  __syncthreads();
+  if (tid < 2 * groups) partial[((size_t)b * gridDim.x + blockIdx.x) * 2 * groups + tid] = g_acc[tid];
+}
+
+__global__ void gn_finalize_kernel(const float* __restrict__ partial, int nblk, int HW, int C, int groups, float eps,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ scale_shift) {
+  __shared__ float mean_s[64], rstd_s[64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int cpg = C / groups;
+  if (tid < groups) {
+    double s = 0.0, q = 0.0;
+    const float* pp = partial + (size_t)b * nblk * 2 * groups + 2 * tid;
+    for (int i = 0; i < nblk; ++i) {
+      s += (double)pp[(size_t)i * 2 * groups];
+      q += (double)pp[(size_t)i * 2 * groups + 1];
+    }
+    const double n = (double)HW * cpg;
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mean_s[tid] = (float)mean;
+    rstd_s[tid] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  float* sc = scale_shift + (size_t)b * 2 * C;
+  for (int c = tid; c < C; c += blockDim.x) {
+    const int g = c / cpg;
+    const float a = gamma[c] * rstd_s[g];
+    sc[c] = a;
+    sc[C + c] = beta[c] - mean_s[g] * a;
+  }
+}
+
+int groupnorm_partial_floats(int B, int HW, int C) {
+  if (C <= 0 || (C & 7)) return 0;
+  const GnGeom g = gn_geom(HW, C);
+  return B * g.nblk * 2 * 64;
+}
+
+int launch_groupnorm_stats(const bf16* x, int B, int HW, int C, int ldx, int groups, float eps, const float* gamma,
+                           const float* beta, float* partial, float* scale_shift, hipStream_t stream) {
+  if (B <= 0 || HW <= 0 || C <= 0) return SD_ERR_INVALID;
+  if ((C & 7) || (ldx & 7) || C > GN_MAXC || groups <= 0 || groups > 64 || C % groups) return SD_ERR_UNSUPPORTED;
+  const GnGeom g = gn_geom(HW, C);
+  if (g.block > 1024) return SD_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(g.nblk, B), dim3(g.block), 0, stream, x, HW, C, ldx, groups, g.cv, g.ppp,
+                     g.threads, g.ppb, partial);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, stream, partial, g.nblk, HW, C, groups, eps, gamma,
+                     beta, scale_shift);
+  return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+}
+
+template <bool SILU>
+__global__ void scale_shift_act_kernel(const bf16* __restrict__ x, long total_chunks, int HW, int C, int ldx,
+                                       const float* __restrict__ scale_shift, bf16* __restrict__ y, int ldy) {
+  const int cv = C >> 3;
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total_chunks; id += (long)gridDim.x * blockDim.x) {
+    const long pix = id / cv;
+    const int cc = (int)(id - pix * cv);
+    const int b = (int)(pix / HW);
+    const u32x4 raw = *reinterpret_cast<const u32x4*>(x + (size_t)pix * ldx + cc * 8);
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(&raw);
+    const float* sc = scale_shift + (size_t)b * 2 * C + cc * 8;
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(sc), a1 = *reinterpret_cast<const f32x4*>(sc + 4);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(sc + C), b1 = *reinterpret_cast<const f32x4*>(sc + C + 4);
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o[j] = __builtin_fmaf((float)v[j], a0[j], b0[j]);
+      o[4 + j] = __builtin_fmaf((float)v[4 + j], a1[j], b1[j]);
+    }
+    if (SILU) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = silu_f(o[j]);
+    }
+    u32x4 pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7])};
+    *reinterpret_cast<u32x4*>(y + (size_t)pix * ldy + cc * 8) = pk;
+  }
+}
+
+int launch_scale_shift_act(const bf16* x, int B, int HW, int C, int ldx, const float* scale_shift, int silu, bf16* y,
+                           int ldy, hipStream_t stream) {
+  if (B <= 0 || HW <= 0 || C <= 0) return SD_ERR_INVALID;
+  if ((C & 7) || (ldx & 7) || (ldy & 7)) return SD_ERR_UNSUPPORTED;
+  const long total = (long)B * HW * (C >> 3);
+  const int block = 256;
+  long nb = (total + block - 1) / block;
+  if (nb > 256 * 16) nb = 256 * 16;
+  if (silu)
+    hipLaunchKernelGGL(scale_shift_act_kernel<true>, dim3((unsigned)nb), dim3(block), 0, stream, x, total, HW, C, ldx,
+                       scale_shift, y, ldy);
+  else
+    hipLaunchKernelGGL(scale_shift_act_kernel<false>, dim3((unsigned)nb), dim3(block), 0, stream, x, total, HW, C, ldx,
+                       scale_shift, y, ldy);
+  return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+}
+
+// LayerNorm: one wave per row, row kept in registers (C <= 64*8*LN_MAXCH), exact two-pass statistics.
+constexpr int LN_MAXCH = 5;  // C <= 2560
+__global__ void layernorm_kernel(const bf16* __restrict__ x, int rows, int C, int ldx, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, float eps, bf16* __restrict__ y, int ldy) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int cv = C >> 3;
+  const bf16* xr = x + (size_t)row * ldx;
+  float v[LN_MAXCH][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXCH; ++i) {
+    const int cc = lane + 64 * i;
+    if (cc < cv) {
+      const u32x4 raw = *reinterpret_cast<const u32x4*>(xr + cc * 8);
+      const bf16x8 t = *reinterpret_cast<const bf16x8*>(&raw);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[i][j] = (float)t[j];
+        s += v[i][j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXCH; ++i) {
+    const int cc = lane + 64 * i;
+    if (cc < cv) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = v[i][j] - mean;
+        q = __builtin_fmaf(d, d, q);
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  bf16* yr = y + (size_t)row * ldy;
+#pragma unroll
+  for (int i = 0; i < LN_MAXCH; ++i) {
+    const int cc = lane + 64 * i;
+    if (cc < cv) {
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float t = (v[i][j] - mean) * rstd;
+        if (gamma) t *= gamma[cc * 8 + j];
+        if (beta) t += beta[cc * 8 + j];
+        o[j] = t;
+      }
+      u32x4 pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7])};
+      *reinterpret_cast<u32x4*>(yr + cc * 8) = pk;
+    }
+  }
+}
+
+int launch_layernorm(const bf16* x, int rows, int C, int ldx, const float* gamma, const float* beta, float eps, bf16* y,
+                     int ldy, hipStream_t stream) {
+  if (rows <= 0 || C <= 0) return SD_ERR_INVALID;
+  if ((C & 7) || (ldx & 7) || (ldy & 7) || C > 64 * 8 * LN_MAXCH) return SD_ERR_UNSUPPORTED;
+  const int wpb = 4;
+  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + wpb - 1) / wpb), dim3(64 * wpb), 0, stream, x, rows, C, ldx, gamma,
+                     beta, eps, y, ldy);
+  return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+}
+
+}  // namespace sd

@@ -1,0 +1,239 @@
+"""Tensor-level wrappers over the C ABI (one call = one HIP kernel launch on torch's current stream).
+
+torch is used only for device memory and streams; every function here raises if the tensors are not on a
+GPU or the library is missing.  Activations are bf16 rows ``[rows, C]`` (== NHWC) whose row stride may exceed C.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import GEGLU, OUT_F32, SILU, check
+
+Tensor = torch.Tensor
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _rows(t: Tensor, name: str, dtype=torch.bfloat16) -> int:
+    """Validate a 2-D row tensor (unit inner stride) and return its row stride."""
+    if not t.is_cuda:
+        raise _lib.MI355XError(f"{name}: tensor must live on the GPU (no CPU fallback)")
+    if t.dtype != dtype or t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise ValueError(f"{name}: expected 2-D {dtype} rows with unit inner stride, got {t.dtype} {tuple(t.shape)} "
+                         f"strides {t.stride()}")
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def _vec(t: Optional[Tensor], n: int, name: str) -> Optional[Tensor]:
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n or not t.is_cuda:
+        raise ValueError(f"{name}: expected contiguous fp32 cuda vector of {n} elements")
+    return t
+
+
+def init(device: int = 0) -> None:
+    check(_lib.load().mi355x_sd_init(device))
+
+
+def linear(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, rowbias: Optional[Tensor] = None,
+           rows_per_batch: int = 0, residual: Optional[Tensor] = None, out: Optional[Tensor] = None,
+           out_scale: float = 1.0, geglu: bool = False, silu: bool = False, out_f32: bool = False) -> Tensor:
+    """out[M,N] = ((a[M,K] @ w[N,K]^T) + bias + rowbias[m // rows_per_batch] + residual) * out_scale."""
+    lib = _lib.load()
+    lda = _rows(a, "a")
+    M, K = a.shape
+    if w.dtype != torch.bfloat16 or not w.is_contiguous() or w.dim() != 2 or w.shape[1] != K:
+        raise ValueError(f"w: expected contiguous bf16 [N,{K}], got {w.dtype} {tuple(w.shape)}")
+    N = w.shape[0]
+    n_out = N // 2 if geglu else N
+    if out is None:
+        out = torch.empty((M, n_out), device=a.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
+    ldc = _rows(out, "out", torch.float32 if out_f32 else torch.bfloat16)
+    if out.shape != (M, n_out):
+        raise ValueError(f"out: expected {(M, n_out)}, got {tuple(out.shape)}")
+    ldr = _rows(residual, "residual") if residual is not None else 0
+    ld_rb = 0
+    if rowbias is not None:
+        if rowbias.dtype != torch.float32 or rowbias.dim() != 2 or rowbias.stride(1) != 1 or rowbias.shape[1] != N:
+            raise ValueError("rowbias: expected fp32 [batches, N] rows")
+        ld_rb = rowbias.stride(0)
+    flags = (GEGLU if geglu else 0) | (OUT_F32 if out_f32 else 0) | (SILU if silu else 0)
+    check(lib.mi355x_sd_linear(a.data_ptr(), lda, w.data_ptr(), out.data_ptr(), ldc, M, N, K,
+                               _p(_vec(bias, N, "bias")), _p(rowbias), rows_per_batch, ld_rb, _p(residual), ldr,
+                               float(out_scale), flags, _stream()))
+    return out
+
+
+def conv3x3(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, stride: int = 1, upsample: bool = False,
+            rowbias: Optional[Tensor] = None, residual: Optional[Tensor] = None, out: Optional[Tensor] = None,
+            out_scale: float = 1.0) -> Tensor:
+    """x NHWC view [B,H,W,C] (pixel stride >= C), w [Cout, 9*Cin] -> rows [B*Ho*Wo, Cout]."""
+    lib = _lib.load()
+    if x.dim() != 4 or x.dtype != torch.bfloat16 or x.stride(3) != 1 or not x.is_cuda:
+        raise ValueError("x: expected bf16 cuda NHWC [B,H,W,C]")
+    B, H, W, C = x.shape
+    ldx = x.stride(2)
+    if x.stride(1) != W * ldx or x.stride(0) != H * W * ldx:
+        raise ValueError("x: pixels must be densely packed with a common stride")
+    Cout = w.shape[0]
+    if w.dtype != torch.bfloat16 or not w.is_contiguous() or w.shape[1] != 9 * C:
+        raise ValueError(f"w: expected contiguous bf16 [Cout, {9 * C}]")
+    up = 1 if upsample else 0
+    Ho = ((H << up) + 2 - 3) // stride + 1
+    Wo = ((W << up) + 2 - 3) // stride + 1
+    M = B * Ho * Wo
+    if out is None:
+        out = torch.empty((M, Cout), device=x.device, dtype=torch.bfloat16)
+    ldc = _rows(out, "out")
+    ldr = _rows(residual, "residual") if residual is not None else 0
+    ld_rb = rowbias.stride(0) if rowbias is not None else 0
+    check(lib.mi355x_sd_conv3x3(x.data_ptr(), ldx, B, H, W, C, stride, up, w.data_ptr(), out.data_ptr(), ldc, Cout,
+                                _p(_vec(bias, Cout, "bias")), _p(rowbias), ld_rb, _p(residual), ldr, float(out_scale),
+                                0, _stream()))
+    return out
+
+
+def sdpa(q: Tensor, k: Tensor, v: Tensor, bias: Optional[Tensor] = None, scale: Optional[float] = None,
+         out: Optional[Tensor] = None) -> Tensor:
+    """q [B,Sq,H,D], k/v [B,Skv,H,D] (head-contiguous token rows, arbitrary token/batch strides) -> [B,Sq,H,D].
+    bias: optional fp32 additive mask broadcastable to [B,H,Sq,Skv] with unit inner stride."""
+    lib = _lib.load()
+    for name, t in (("q", q), ("k", k), ("v", v)):
+        if t.dim() != 4 or t.dtype != torch.bfloat16 or not t.is_cuda or t.stride(3) != 1 or t.stride(2) != t.shape[3]:
+            raise ValueError(f"{name}: expected bf16 cuda [B,S,H,D] with heads packed inside a token row")
+    B, Sq, H, D = q.shape
+    Skv = k.shape[1]
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    if out is None:
+        out = torch.empty((B, Sq, H, D), device=q.device, dtype=torch.bfloat16)
+    bb = bh = bq = 0
+    if bias is not None:
+        if bias.dtype != torch.float32 or bias.dim() != 4 or bias.shape[-1] != Skv or bias.stride(3) != 1:
+            raise ValueError("bias: expected fp32 [B|1,H|1,Sq|1,Skv]")
+        bb = bias.stride(0) if bias.shape[0] > 1 else 0
+        bh = bias.stride(1) if bias.shape[1] > 1 else 0
+        bq = bias.stride(2) if bias.shape[2] > 1 else 0
+    check(lib.mi355x_sd_sdpa(q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(bias), out.data_ptr(), B, H, Sq, Skv, D,
+                             q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+                             out.stride(0), out.stride(1), bb, bh, bq, float(scale), _stream()))
+    return out
+
+
+def groupnorm_scale_shift(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float) -> Tensor:
+    """x [B,HW,C] (row stride >= C) -> scale_shift fp32 [B,2,C]."""
+    lib = _lib.load()
+    B, HW, C = x.shape
+    if x.dtype != torch.bfloat16 or x.stride(2) != 1 or x.stride(0) != HW * x.stride(1) or not x.is_cuda:
+        raise ValueError("x: expected bf16 cuda [B,HW,C] rows")
+    ws = torch.empty(max(1, lib.mi355x_sd_groupnorm_workspace_floats(B, HW, C)), device=x.device, dtype=torch.float32)
+    ss = torch.empty((B, 2, C), device=x.device, dtype=torch.float32)
+    check(lib.mi355x_sd_groupnorm_stats(x.data_ptr(), B, HW, C, x.stride(1), groups, float(eps),
+                                        _vec(gamma, C, "gamma").data_ptr(), _vec(beta, C, "beta").data_ptr(),
+                                        ws.data_ptr(), ss.data_ptr(), _stream()))
+    return ss
+
+
+def scale_shift_act(x: Tensor, scale_shift: Tensor, silu: bool, out: Optional[Tensor] = None) -> Tensor:
+    lib = _lib.load()
+    B, HW, C = x.shape
+    if out is None:
+        out = torch.empty((B, HW, C), device=x.device, dtype=torch.bfloat16)
+    check(lib.mi355x_sd_scale_shift_act(x.data_ptr(), B, HW, C, x.stride(1), scale_shift.data_ptr(), 1 if silu else 0,
+                                        out.data_ptr(), out.stride(1), _stream()))
+    return out
+
+
+def group_norm(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, silu: bool = False,
+               out: Optional[Tensor] = None) -> Tensor:
+    return scale_shift_act(x, groupnorm_scale_shift(x, gamma, beta, groups, eps), silu, out)
+
+
+def layer_norm(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], eps: float = 1e-5,
+               out: Optional[Tensor] = None) -> Tensor:
+    lib = _lib.load()
+    ldx = _rows(x, "x")
+    rows, C = x.shape
+    if out is None:
+        out = torch.empty((rows, C), device=x.device, dtype=torch.bfloat16)
+    check(lib.mi355x_sd_layernorm(x.data_ptr(), rows, C, ldx, _p(_vec(gamma, C, "gamma")), _p(_vec(beta, C, "beta")),
+                                  float(eps), out.data_ptr(), _rows(out, "out"), _stream()))
+    return out
+
+
+def timestep_embedding(t: Tensor, dim: int, flip_sin_to_cos: bool = False, downscale_freq_shift: float = 1.0,
+                       scale: float = 1.0, max_period: float = 10000.0, n: Optional[int] = None) -> Tensor:
+    """t: fp32 cuda [t_count]; returns bf16 [n, dim] (t broadcast cyclically when n > t_count)."""
+    lib = _lib.load()
+    if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+        raise ValueError("t: expected contiguous fp32 cuda tensor")
+    n = t.numel() if n is None else n
+    out = torch.empty((n, dim), device=t.device, dtype=torch.bfloat16)
+    check(lib.mi355x_sd_timestep_embedding(t.data_ptr(), t.numel(), n, dim, 1, 1 if flip_sin_to_cos else 0,
+                                           float(downscale_freq_shift), float(scale), float(max_period),
+                                           out.data_ptr(), dim, _stream()))
+    return out
+
+
+def silu(x: Tensor, out_dtype=None) -> Tensor:
+    lib = _lib.load()
+    out_dtype = out_dtype or x.dtype
+    if not x.is_contiguous() or not x.is_cuda:
+        raise ValueError("x: expected contiguous cuda tensor")
+    out = torch.empty(x.shape, device=x.device, dtype=out_dtype)
+    check(lib.mi355x_sd_silu(x.data_ptr(), out.data_ptr(), x.numel(), int(x.dtype == torch.float32),
+                             int(out_dtype == torch.float32), _stream()))
+    return out
+
+
+def conv_in3x3(x_nchw: Tensor, w: Tensor, bias: Optional[Tensor], in_scale: Optional[Tensor] = None,
+               out: Optional[Tensor] = None) -> Tensor:
+    """x fp32 NCHW, w bf16 [9*Cin, Cout] -> bf16 rows [B*H*W, Cout]."""
+    lib = _lib.load()
+    B, Cin, H, W = x_nchw.shape
+    Cout = w.shape[1]
+    if x_nchw.dtype != torch.float32 or not x_nchw.is_contiguous() or not x_nchw.is_cuda:
+        raise ValueError("x: expected contiguous fp32 cuda NCHW")
+    if out is None:
+        out = torch.empty((B * H * W, Cout), device=x_nchw.device, dtype=torch.bfloat16)
+    check(lib.mi355x_sd_conv_in3x3(x_nchw.data_ptr(), _p(in_scale), w.data_ptr(), _p(_vec(bias, Cout, "bias")),
+                                   out.data_ptr(), B, Cin, H, W, Cout, _rows(out, "out"), _stream()))
+    return out
+
+
+def conv_out3x3(x: Tensor, w: Tensor, bias: Optional[Tensor], B: int, H: int, W: int) -> Tensor:
+    """x bf16 rows [B*H*W, Cin], w bf16 [Cout, 9*Cin] -> fp32 NCHW [B,Cout,H,W]."""
+    lib = _lib.load()
+    ldx = _rows(x, "x")
+    Cin = x.shape[1]
+    Cout = w.shape[0]
+    out = torch.empty((B, Cout, H, W), device=x.device, dtype=torch.float32)
+    check(lib.mi355x_sd_conv_out3x3(x.data_ptr(), ldx, w.data_ptr(), _p(_vec(bias, Cout, "bias")), out.data_ptr(), B,
+                                    Cin, H, W, Cout, _stream()))
+    return out
+
+
+def axpby(x: Tensor, y: Tensor, coef: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.mi355x_sd_axpby(x.data_ptr(), y.data_ptr(), out.data_ptr(), coef.data_ptr(), x.numel(), _stream()))
+    return out
+
+
+def probe_layouts(device="cuda") -> Tensor:
+    lib = _lib.load()
+    out = torch.zeros((64, 24), device=device, dtype=torch.float32)
+    check(lib.mi355x_sd_probe_layouts(out.data_ptr(), _stream()))
+    return out

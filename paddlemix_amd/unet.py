@@ -1,0 +1,773 @@
+"""MI355X-native UNet2DConditionModel: the drop-in for the reference's denoising-step callable.
+
+Mirrors the call contract of ``UNet2DConditionModel.forward``
+(ppdiffusers/ppdiffusers/models/unet_2d_condition.py:809-1207; seam B1 of SURVEY.md 8b: what
+``StableDiffusionPipeline.__call__`` invokes at pipeline_stable_diffusion.py:866-879):
+
+    unet(sample[B,C,h,w], timestep, encoder_hidden_states[B,L,D], added_cond_kwargs=..., return_dict=False) -> (noise_pred,)
+
+and exposes ``.config`` / ``.dtype`` the way the pipelines read them.  Parameters are taken under the
+reference's parameter names and *Paddle* layouts (Linear weight [in,out], conv OIHW) and repacked once for the
+kernels.  The forward itself is a static program of C-ABI kernel launches (include/mi355x_sd.h) built per input
+geometry and replayed as a hipGraph; sequencing follows the reference block structure
+(unet_2d_blocks.py:750-799, 1142-1223, 1280-1307, 2317-2414, 2470-2524; resnet.py:728-808;
+transformer_2d.py:272-509; attention.py:376-489).
+
+Layout decisions: activations are bf16 token rows [B*H*W, C] (== NHWC) with explicit row strides;
+every skip connection is produced directly inside the buffer its up-block consumer reads ("concat by
+construction", no copy); GEGLU, bias, time-embedding add, residual add and 1/output_scale_factor are GEMM
+epilogues; q/k/v projections are fused into one GEMM; all resnet time_emb_proj layers are one GEMM per step.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import Dict, List, Mapping, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import GEGLU, OUT_F32, SILU
+
+Tensor = torch.Tensor
+
+UNET_DEFAULTS = dict(
+    sample_size=None, in_channels=4, out_channels=4, center_input_sample=False, flip_sin_to_cos=True, freq_shift=0,
+    down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"),
+    mid_block_type="UNetMidBlock2DCrossAttn",
+    up_block_types=("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"),
+    only_cross_attention=False, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2, downsample_padding=1,
+    mid_block_scale_factor=1, act_fn="silu", norm_num_groups=32, norm_eps=1e-5, cross_attention_dim=1280,
+    transformer_layers_per_block=1, attention_head_dim=8, use_linear_projection=False, addition_embed_type=None,
+    addition_time_embed_dim=None, upcast_attention=False, resnet_time_scale_shift="default",
+    resnet_out_scale_factor=1.0, time_embedding_type="positional", projection_class_embeddings_input_dim=None,
+    time_cond_proj_dim=None,
+)
+_UNSUPPORTED_IF_SET = ("encoder_hid_dim", "encoder_hid_dim_type", "class_embed_type", "num_class_embeds",
+                       "time_embedding_dim", "time_embedding_act_fn", "timestep_post_act", "time_cond_proj_dim",
+                       "cross_attention_norm", "dual_cross_attention", "class_embeddings_concat", "resnet_skip_time_act")
+
+
+def normalize_config(config: Mapping) -> dict:
+    """ctor-argument handling of unet_2d_condition.py:172-290 for the branches this implementation covers."""
+    cfg = dict(UNET_DEFAULTS)
+    cfg.update({k: v for k, v in config.items() if not k.startswith("_")})
+    for k in _UNSUPPORTED_IF_SET:
+        if cfg.get(k) not in (None, False):
+            raise NotImplementedError(f"UNet2DConditionModel(mi355x): config {k}={cfg[k]!r} is not implemented")
+    if cfg["time_embedding_type"] != "positional" or cfg["resnet_time_scale_shift"] != "default":
+        raise NotImplementedError("only positional time embedding / default resnet time shift are implemented")
+    if cfg["act_fn"] not in ("silu", "swish"):
+        raise NotImplementedError("only SiLU resnets are implemented")
+    if cfg["downsample_padding"] != 1:
+        raise NotImplementedError("downsample_padding must be 1")
+    if cfg["addition_embed_type"] not in (None, "text_time"):
+        raise NotImplementedError(f"addition_embed_type={cfg['addition_embed_type']!r}")
+    n = len(cfg["down_block_types"])
+    tup = lambda x: tuple(x) if isinstance(x, (list, tuple)) else (x,) * n  # noqa: E731
+    cfg["block_out_channels"] = tuple(cfg["block_out_channels"])
+    for k in ("layers_per_block", "transformer_layers_per_block", "cross_attention_dim", "only_cross_attention"):
+        cfg[k] = tup(cfg[k])
+    cfg["num_attention_heads"] = tup(cfg["attention_head_dim"])  # the naming quirk at unet_2d_condition.py:245
+    if any(cfg["only_cross_attention"]):
+        raise NotImplementedError("only_cross_attention")
+    for b in tuple(cfg["down_block_types"]) + tuple(cfg["up_block_types"]):
+        if b not in ("CrossAttnDownBlock2D", "DownBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"):
+            raise NotImplementedError(f"block type {b}")
+    if cfg["mid_block_type"] != "UNetMidBlock2DCrossAttn":
+        raise NotImplementedError(f"mid_block_type {cfg['mid_block_type']}")
+    if cfg["out_channels"] > 4:
+        raise NotImplementedError("out_channels > 4")
+    return cfg
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# structure walk shared by the parameter inventory and the program builder
+# ---------------------------------------------------------------------------------------------------------------
+def _structure(cfg: dict) -> List[tuple]:
+    """Layer descriptors in execution order.
+    ('resnet', name, cin, cout, scale) | ('attn', name, C, heads, layers, cross) | ('skip',) |
+    ('down', name, C) | ('up', name, C) | ('cat', skip_channels)"""
+    boc = cfg["block_out_channels"]
+    n = len(boc)
+    L: List[tuple] = [("skip",)]
+    out_c = boc[0]
+    for i, bt in enumerate(cfg["down_block_types"]):
+        in_c, out_c = out_c, boc[i]
+        for j in range(cfg["layers_per_block"][i]):
+            L.append(("resnet", f"down_blocks.{i}.resnets.{j}", in_c if j == 0 else out_c, out_c, 1.0))
+            if bt == "CrossAttnDownBlock2D":
+                L.append(("attn", f"down_blocks.{i}.attentions.{j}", out_c, cfg["num_attention_heads"][i],
+                          cfg["transformer_layers_per_block"][i], cfg["cross_attention_dim"][i]))
+            L.append(("skip",))
+        if i != n - 1:
+            L.append(("down", f"down_blocks.{i}.downsamplers.0.conv", out_c))
+            L.append(("skip",))
+    ms = float(cfg["mid_block_scale_factor"])
+    L.append(("resnet", "mid_block.resnets.0", boc[-1], boc[-1], ms))
+    L.append(("attn", "mid_block.attentions.0", boc[-1], cfg["num_attention_heads"][-1],
+              cfg["transformer_layers_per_block"][-1], cfg["cross_attention_dim"][-1]))
+    L.append(("resnet", "mid_block.resnets.1", boc[-1], boc[-1], ms))
+    rboc = tuple(reversed(boc))
+    rlayers = tuple(reversed(cfg["layers_per_block"]))
+    rtl = tuple(reversed(cfg["transformer_layers_per_block"]))
+    rcross = tuple(reversed(cfg["cross_attention_dim"]))
+    rheads = tuple(reversed(cfg["num_attention_heads"]))
+    out_c = rboc[0]
+    for i, bt in enumerate(cfg["up_block_types"]):
+        prev_out, out_c = out_c, rboc[i]
+        in_c = rboc[min(i + 1, n - 1)]
+        nl = rlayers[i] + 1
+        for j in range(nl):
+            skip_c = in_c if j == nl - 1 else out_c
+            rin = prev_out if j == 0 else out_c
+            L.append(("cat", skip_c))
+            L.append(("resnet", f"up_blocks.{i}.resnets.{j}", rin + skip_c, out_c, 1.0))
+            if bt == "CrossAttnUpBlock2D":
+                L.append(("attn", f"up_blocks.{i}.attentions.{j}", out_c, rheads[i], rtl[i], rcross[i]))
+        if i != n - 1:
+            L.append(("up", f"up_blocks.{i}.upsamplers.0.conv", out_c))
+    return L
+
+
+def unet_param_shapes(config: Mapping) -> Dict[str, tuple]:
+    """name -> shape (Paddle layouts) of every parameter the configured UNet owns, in construction order
+    (unet_2d_condition.py:287-631 and the block ctors in unet_2d_blocks.py)."""
+    cfg = normalize_config(config)
+    boc = cfg["block_out_channels"]
+    ted = boc[0] * 4
+    S: Dict[str, tuple] = {}
+
+    def lin(name, i, o, bias=True):
+        S[name + ".weight"] = (i, o)
+        if bias:
+            S[name + ".bias"] = (o,)
+
+    def conv(name, i, o, k):
+        S[name + ".weight"] = (o, i, k, k)
+        S[name + ".bias"] = (o,)
+
+    def norm(name, c):
+        S[name + ".weight"] = (c,)
+        S[name + ".bias"] = (c,)
+
+    conv("conv_in", cfg["in_channels"], boc[0], 3)
+    lin("time_embedding.linear_1", boc[0], ted)
+    lin("time_embedding.linear_2", ted, ted)
+    if cfg["addition_embed_type"] == "text_time":
+        lin("add_embedding.linear_1", cfg["projection_class_embeddings_input_dim"], ted)
+        lin("add_embedding.linear_2", ted, ted)
+    for d in _structure(cfg):
+        if d[0] == "resnet":
+            _, name, cin, cout, _ = d
+            norm(name + ".norm1", cin)
+            conv(name + ".conv1", cin, cout, 3)
+            lin(name + ".time_emb_proj", ted, cout)
+            norm(name + ".norm2", cout)
+            conv(name + ".conv2", cout, cout, 3)
+            if cin != cout:
+                conv(name + ".conv_shortcut", cin, cout, 1)
+        elif d[0] == "attn":
+            _, name, c, heads, layers, cross = d
+            norm(name + ".norm", c)
+            if cfg["use_linear_projection"]:
+                lin(name + ".proj_in", c, c)
+            else:
+                conv(name + ".proj_in", c, c, 1)
+            for l in range(layers):
+                b = f"{name}.transformer_blocks.{l}"
+                norm(b + ".norm1", c)
+                for a, kd in ((".attn1", c), (".attn2", cross)):
+                    lin(b + a + ".to_q", c, c, bias=False)
+                    lin(b + a + ".to_k", kd, c, bias=False)
+                    lin(b + a + ".to_v", kd, c, bias=False)
+                    lin(b + a + ".to_out.0", c, c)
+                    if a == ".attn1":
+                        norm(b + ".norm2", c)
+                norm(b + ".norm3", c)
+                lin(b + ".ff.net.0.proj", c, 8 * c)
+                lin(b + ".ff.net.2", 4 * c, c)
+            if cfg["use_linear_projection"]:
+                lin(name + ".proj_out", c, c)
+            else:
+                conv(name + ".proj_out", c, c, 1)
+        elif d[0] in ("down", "up"):
+            conv(d[1], d[2], d[2], 3)
+    norm("conv_norm_out", boc[0])
+    conv("conv_out", boc[0], cfg["out_channels"], 3)
+    return S
+
+
+def synth_unet_params(config: Mapping, seed: int = 1234, device="cpu", dtype=torch.float32) -> Dict[str, Tensor]:
+    """Random-init parameters (no checkpoints are available offline): conv/linear N(0, 1/fan_in), biases
+    N(0, 0.02^2), norm gamma 1 + N(0, 0.02^2), beta N(0, 0.02^2); one generator, construction order."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    P: Dict[str, Tensor] = {}
+    for name, shape in unet_param_shapes(config).items():
+        r = torch.randn(shape, generator=g, device=device)
+        if name.endswith(".bias"):
+            t = r * 0.02
+        elif len(shape) == 1:
+            t = 1.0 + r * 0.02
+        elif len(shape) == 2:
+            t = r / math.sqrt(shape[0])
+        else:
+            t = r / math.sqrt(shape[1] * shape[2] * shape[3])
+        P[name] = t.to(dtype)
+    return P
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# program builder
+# ---------------------------------------------------------------------------------------------------------------
+class _Ref:
+    """Symbolic device address inside a named scratch buffer (resolved after all sizes are known)."""
+    __slots__ = ("buf", "off")
+
+    def __init__(self, buf: str, off: int = 0):
+        self.buf, self.off = buf, off
+
+    def __add__(self, nbytes: int) -> "_Ref":
+        return _Ref(self.buf, self.off + nbytes)
+
+
+class _V:
+    """Row view: `rows` rows of `C` bf16 channels, row stride `ld` elements, at address `p` (int or _Ref)."""
+    __slots__ = ("p", "rows", "C", "ld")
+
+    def __init__(self, p, rows, C, ld=None):
+        self.p, self.rows, self.C, self.ld = p, rows, C, (C if ld is None else ld)
+
+    def cols(self, off: int, C: int) -> "_V":
+        return _V(self.p + 2 * off, self.rows, C, self.ld)
+
+
+class _Plan:
+    pass
+
+
+class UNet2DConditionOutput(SimpleNamespace):
+    """``.sample`` holder, mirroring unet_2d_condition.py:61-72."""
+
+
+class UNet2DConditionModel:
+    def __init__(self, config: Mapping, params: Mapping[str, Tensor], device="cuda", use_graph: bool = True,
+                 profile: bool = False, _test_backend=None):
+        """``_test_backend``: test-only injection point (tests/abi_emulator.py interprets the emitted C-ABI
+        program on host memory to check the sequencing / packing logic without a GPU).  It is never selected by
+        product code: without it the model needs the built HIP library and a GPU, and raises otherwise."""
+        self._emulated = _test_backend is not None
+        if self._emulated:
+            self._lib = _test_backend
+            self.device = torch.device("cpu")
+            self._stream = None
+            self._stream_ptr = 0
+            use_graph = False
+        else:
+            self._lib = _lib.load()  # hard failure if the HIP library is not built
+            if not torch.cuda.is_available():
+                raise _lib.MI355XError("UNet2DConditionModel(mi355x) needs a GPU; there is no CPU fallback")
+            self.device = torch.device(device)
+            if self.device.index is None:
+                self.device = torch.device("cuda", torch.cuda.current_device())
+            _lib.check(self._lib.mi355x_sd_init(self.device.index))
+            self._stream = torch.cuda.Stream(device=self.device)
+            self._stream_ptr = self._stream.cuda_stream
+        self.cfg = normalize_config(config)
+        pub = dict(self.cfg)
+        pub.pop("num_attention_heads")
+        self.config = SimpleNamespace(**pub)
+        self.dtype = torch.bfloat16
+        self.use_graph = use_graph
+        self.profile = profile
+        self._plans: Dict[tuple, _Plan] = {}
+        self.w: Dict[str, Tensor] = {}
+        self.kernel_times: Dict[str, list] = {}
+        self._load_weights(params)
+
+    # ------------------------------------------------------------------ weights
+    def _load_weights(self, params: Mapping[str, Tensor]) -> None:
+        cfg, dev = self.cfg, self.device
+        shapes = unet_param_shapes(cfg)
+        missing = [k for k in shapes if k not in params]
+        if missing:
+            raise KeyError(f"missing parameters: {missing[:5]}{'...' if len(missing) > 5 else ''}")
+
+        def get(name):
+            t = params[name]
+            if tuple(t.shape) != shapes[name]:
+                raise ValueError(f"{name}: shape {tuple(t.shape)} != expected {shapes[name]} (Paddle layout)")
+            return t.to(device=dev, dtype=torch.float32)
+
+        bf = lambda t: t.to(torch.bfloat16).contiguous()  # noqa: E731
+        W = self.w
+
+        def lin_w(name):  # Paddle [in,out] -> [out,in]
+            return get(name + ".weight").t()
+
+        def put_lin(key, name, bias=True):
+            W[key + ".w"] = bf(lin_w(name))
+            if bias:
+                W[key + ".b"] = get(name + ".bias").contiguous()
+
+        def put_conv(key, name):  # OIHW -> [O][kh][kw][I]
+            w = get(name + ".weight")
+            W[key + ".w"] = bf(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1))
+            W[key + ".b"] = get(name + ".bias").contiguous()
+
+        def put_norm(key, name):
+            W[key + ".g"] = get(name + ".weight").contiguous()
+            W[key + ".b"] = get(name + ".bias").contiguous()
+
+        w = get("conv_in.weight")  # -> [ky][kx][ci][O]
+        W["conv_in.w"] = bf(w.permute(2, 3, 1, 0).reshape(-1, w.shape[0]))
+        W["conv_in.b"] = get("conv_in.bias").contiguous()
+        put_lin("time_embedding.linear_1", "time_embedding.linear_1")
+        put_lin("time_embedding.linear_2", "time_embedding.linear_2")
+        if cfg["addition_embed_type"] == "text_time":
+            put_lin("add_embedding.linear_1", "add_embedding.linear_1")
+            put_lin("add_embedding.linear_2", "add_embedding.linear_2")
+        temb_w, temb_b = [], []
+        self._temb_off: Dict[str, int] = {}
+        off = 0
+        for d in _structure(cfg):
+            if d[0] == "resnet":
+                _, name, cin, cout, _ = d
+                put_norm(name + ".norm1", name + ".norm1")
+                put_conv(name + ".conv1", name + ".conv1")
+                temb_w.append(lin_w(name + ".time_emb_proj"))
+                temb_b.append(get(name + ".time_emb_proj.bias"))
+                self._temb_off[name] = off
+                off += cout
+                put_norm(name + ".norm2", name + ".norm2")
+                put_conv(name + ".conv2", name + ".conv2")
+                if cin != cout:
+                    put_conv(name + ".conv_shortcut", name + ".conv_shortcut")
+            elif d[0] == "attn":
+                _, name, c, heads, layers, cross = d
+                put_norm(name + ".norm", name + ".norm")
+                if cfg["use_linear_projection"]:
+                    put_lin(name + ".proj_in", name + ".proj_in")
+                    put_lin(name + ".proj_out", name + ".proj_out")
+                else:
+                    put_conv(name + ".proj_in", name + ".proj_in")
+                    put_conv(name + ".proj_out", name + ".proj_out")
+                for l in range(layers):
+                    b = f"{name}.transformer_blocks.{l}"
+                    for nm in (".norm1", ".norm2", ".norm3"):
+                        put_norm(b + nm, b + nm)
+                    W[b + ".attn1.qkv.w"] = bf(torch.cat([lin_w(b + ".attn1.to_q"), lin_w(b + ".attn1.to_k"),
+                                                          lin_w(b + ".attn1.to_v")], 0))
+                    put_lin(b + ".attn1.out", b + ".attn1.to_out.0")
+                    W[b + ".attn2.q.w"] = bf(lin_w(b + ".attn2.to_q"))
+                    W[b + ".attn2.kv.w"] = bf(torch.cat([lin_w(b + ".attn2.to_k"), lin_w(b + ".attn2.to_v")], 0))
+                    put_lin(b + ".attn2.out", b + ".attn2.to_out.0")
+                    # GEGLU: interleave [16 value rows | 16 gate rows] so a lane holds both halves of a pair
+                    w1 = lin_w(b + ".ff.net.0.proj")  # [8c, c]
+                    b1 = get(b + ".ff.net.0.proj.bias")
+                    half = w1.shape[0] // 2
+                    W[b + ".ff1.w"] = bf(torch.stack([w1[:half].reshape(half // 16, 16, -1),
+                                                      w1[half:].reshape(half // 16, 16, -1)], 1).reshape(2 * half, -1))
+                    W[b + ".ff1.b"] = torch.stack([b1[:half].reshape(half // 16, 16), b1[half:].reshape(half // 16, 16)],
+                                                  1).reshape(-1).contiguous()
+                    put_lin(b + ".ff2", b + ".ff.net.2")
+            elif d[0] in ("down", "up"):
+                put_conv(d[1], d[1])
+        W["temb_all.w"] = bf(torch.cat(temb_w, 0))
+        W["temb_all.b"] = torch.cat(temb_b, 0).contiguous()
+        self._temb_total = off
+        put_norm("conv_norm_out", "conv_norm_out")
+        w = get("conv_out.weight")
+        W["conv_out.w"] = bf(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1))
+        W["conv_out.b"] = get("conv_out.bias").contiguous()
+
+    def weight_bytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.w.values())
+
+    # ------------------------------------------------------------------ plan
+    def _build_plan(self, B: int, H: int, Wd: int, L: int) -> _Plan:
+        cfg, lib, dev, W = self.cfg, self._lib, self.device, self.w
+        stream = self._stream_ptr
+        boc = cfg["block_out_channels"]
+        groups, eps = cfg["norm_num_groups"], float(cfg["norm_eps"])
+        ted = boc[0] * 4
+        plan = _Plan()
+        prog: List[tuple] = []     # (cfunc, args(list with _Ref placeholders), kind, flops)
+        scratch: Dict[str, int] = {}
+        keep: List[Tensor] = []
+
+        def sc(name: str, nbytes: int) -> _Ref:
+            scratch[name] = max(scratch.get(name, 0), nbytes)
+            return _Ref(name)
+
+        def persist(shape, dtype) -> Tensor:
+            t = torch.empty(shape, device=dev, dtype=dtype)
+            keep.append(t)
+            return t
+
+        def wp(key):
+            return W[key].data_ptr()
+
+        def emit(fn, args, kind, flops=0.0):
+            prog.append((fn, list(args), kind, flops))
+
+        def linear(a: _V, wkey: str, out: _V, bias=True, R: Optional[_V] = None, flags=0, out_scale=1.0,
+                   rowbias=None, rpb=0, ld_rb=0, bkey=None):
+            w = W[wkey + ".w"]
+            N, K = w.shape
+            assert K == a.C, (wkey, K, a.C)
+            b = (W[bkey] if bkey else W[wkey + ".b"]).data_ptr() if bias else None
+            emit(lib.mi355x_sd_linear,
+                 (a.p, a.ld, w.data_ptr(), out.p, out.ld, a.rows, N, K, b, rowbias, rpb, ld_rb,
+                  R.p if R else None, R.ld if R else 0, out_scale, flags, stream), "gemm", 2.0 * a.rows * N * K)
+
+        def conv3(x: _V, h, w_, wkey, out: _V, stride=1, up=0, rowbias=None, R: Optional[_V] = None, out_scale=1.0):
+            w = W[wkey + ".w"]
+            Cout = w.shape[0]
+            ho = ((h << up) + 2 - 3) // stride + 1
+            wo = ((w_ << up) + 2 - 3) // stride + 1
+            emit(lib.mi355x_sd_conv3x3,
+                 (x.p, x.ld, B, h, w_, x.C, stride, up, w.data_ptr(), out.p, out.ld, Cout, W[wkey + ".b"].data_ptr(),
+                  rowbias, self._temb_total if rowbias is not None else 0, R.p if R else None, R.ld if R else 0,
+                  out_scale, 0, stream), "conv", 2.0 * B * ho * wo * Cout * 9 * x.C)
+
+        def gnorm(x: _V, hw, nkey, eps_, silu) -> _V:
+            nws = lib.mi355x_sd_groupnorm_workspace_floats(B, hw, x.C)
+            ws = sc("gn_ws", 4 * nws)
+            ss = sc("gn_ss", 4 * B * 2 * x.C)
+            y = _V(sc("gn", 2 * x.rows * x.C), x.rows, x.C)
+            emit(lib.mi355x_sd_groupnorm_stats, (x.p, B, hw, x.C, x.ld, groups, eps_, wp(nkey + ".g"), wp(nkey + ".b"),
+                                                 ws, ss, stream), "gn_stats")
+            emit(lib.mi355x_sd_scale_shift_act, (x.p, B, hw, x.C, x.ld, ss, 1 if silu else 0, y.p, y.ld, stream),
+                 "gn_apply")
+            return y
+
+        def lnorm(x: _V, nkey, out: _V):
+            emit(lib.mi355x_sd_layernorm, (x.p, x.rows, x.C, x.ld, wp(nkey + ".g"), wp(nkey + ".b"), 1e-5, out.p,
+                                           out.ld, stream), "ln")
+
+        def attention(q: _V, k: _V, v: _V, out: _V, heads, sq, skv):
+            d = q.C // heads
+            emit(lib.mi355x_sd_sdpa, (q.p, k.p, v.p, None, out.p, B, heads, sq, skv, d, sq * q.ld, q.ld, skv * k.ld,
+                                      k.ld, skv * v.ld, v.ld, sq * out.ld, out.ld, 0, 0, 0, d ** -0.5, stream),
+                 "attn", 4.0 * B * heads * sq * skv * d)
+
+        # ---- inputs (static buffers; staged by __call__) ----
+        plan.sample = persist((B, cfg["in_channels"], H, Wd), torch.float32)
+        plan.t = persist((1,), torch.float32)
+        plan.in_scale = persist((1,), torch.float32)
+        plan.in_scale.fill_(1.0)
+        dx = cfg["cross_attention_dim"][0]
+        plan.enc = persist((B * L, dx), torch.bfloat16)
+        enc = _V(plan.enc.data_ptr(), B * L, dx)
+        plan.out = persist((B, cfg["out_channels"], H, Wd), torch.float32)
+
+        # ---- time / added-condition embedding (unet_2d_condition.py:933-1030) ----
+        t0 = persist((B, boc[0]), torch.bfloat16)
+        emit(lib.mi355x_sd_timestep_embedding, (plan.t.data_ptr(), 1, B, boc[0], 1, 1 if cfg["flip_sin_to_cos"] else 0,
+                                                float(cfg["freq_shift"]), 1.0, 10000.0, t0.data_ptr(), boc[0], stream),
+             "misc")
+        e1 = persist((B, ted), torch.bfloat16)
+        emb = persist((B, ted), torch.bfloat16)
+        linear(_V(t0.data_ptr(), B, boc[0]), "time_embedding.linear_1", _V(e1.data_ptr(), B, ted), flags=SILU)
+        linear(_V(e1.data_ptr(), B, ted), "time_embedding.linear_2", _V(emb.data_ptr(), B, ted))
+        plan.add_in = plan.time_ids = None
+        if cfg["addition_embed_type"] == "text_time":
+            pdim = cfg["projection_class_embeddings_input_dim"]
+            atd = cfg["addition_time_embed_dim"]
+            plan.add_in = persist((B, pdim), torch.bfloat16)
+            plan.text_dim = None  # widths of text_embeds / time_ids are only known at the first call
+            plan._pdim, plan._atd = pdim, atd
+            a1 = persist((B, ted), torch.bfloat16)
+            plan._add_emit_index = len(prog)  # the time_ids embedding op is inserted here once widths are known
+            linear(_V(plan.add_in.data_ptr(), B, pdim), "add_embedding.linear_1", _V(a1.data_ptr(), B, ted),
+                   flags=SILU)
+            linear(_V(a1.data_ptr(), B, ted), "add_embedding.linear_2", _V(emb.data_ptr(), B, ted),
+                   R=_V(emb.data_ptr(), B, ted))
+        semb = persist((B, ted), torch.bfloat16)
+        emit(lib.mi355x_sd_silu, (emb.data_ptr(), semb.data_ptr(), B * ted, 0, 0, stream), "misc")
+        temb_all = persist((B, self._temb_total), torch.float32)
+        linear(_V(semb.data_ptr(), B, ted), "temb_all", _V(temb_all.data_ptr(), B, self._temb_total), flags=OUT_F32)
+
+        # ---- skip / concat buffers: pre-walk ----
+        S = _structure(cfg)
+        skips: List[Tuple[int, int, int]] = []  # (C, h, w) in production order
+        h, w_ = H, Wd
+        c_cur = boc[0]
+        for d in S:
+            if d[0] == "resnet":
+                c_cur = d[3]
+            elif d[0] == "down":
+                h, w_ = (h + 2 - 3) // 2 + 1, (w_ + 2 - 3) // 2 + 1
+            elif d[0] == "skip":
+                skips.append((c_cur, h, w_))
+            elif d[0] == "cat":
+                break
+        ups = [d for d in S if d[0] == "resnet" and d[1].startswith("up_blocks.")]
+        assert len(ups) == len(skips)
+        cats: List[_V] = []
+        cat_xc: List[int] = []
+        for u, d in enumerate(ups):  # up resnet u consumes skip n-1-u
+            cs, hs, ws_ = skips[len(skips) - 1 - u]
+            cx = d[2] - cs
+            t = persist((B * hs * ws_, cx + cs), torch.bfloat16)
+            cats.append(_V(t.data_ptr(), B * hs * ws_, cx + cs))
+            cat_xc.append(cx)
+
+        def skip_slot(k: int) -> _V:  # where skip k is produced
+            u = len(skips) - 1 - k
+            return cats[u].cols(cat_xc[u], cats[u].C - cat_xc[u])
+
+        def x_slot(u: int) -> _V:
+            return cats[u].cols(0, cat_xc[u])
+
+        # ---- layer emitters ----
+        def resnet(name, x: _V, h, w_, cout, scale, out: _V):
+            hw = h * w_
+            rows = B * hw
+            g1 = gnorm(x, hw, name + ".norm1", eps, True)
+            h1 = _V(sc("h1", 2 * rows * cout), rows, cout)
+            rb = temb_all.data_ptr() + 4 * self._temb_off[name]
+            conv3(g1, h, w_, name + ".conv1", h1, rowbias=rb)
+            g2 = gnorm(h1, hw, name + ".norm2", eps, True)
+            if x.C != cout:
+                short = _V(sc("short", 2 * rows * cout), rows, cout)
+                linear(x, name + ".conv_shortcut", short)
+            else:
+                short = x
+            conv3(g2, h, w_, name + ".conv2", out, R=short, out_scale=1.0 / scale)
+
+        def transformer(name, x: _V, h, w_, heads, layers, out: _V):
+            hw = h * w_
+            rows = B * hw
+            c = x.C
+            g = gnorm(x, hw, name + ".norm", 1e-6, False)
+            hid = _V(sc("t_h", 2 * rows * c), rows, c)
+            linear(g, name + ".proj_in", hid)
+            ln = _V(sc("t_ln", 2 * rows * c), rows, c)
+            qkv = _V(sc("t_qkv", 2 * rows * 3 * c), rows, 3 * c)
+            ao = _V(sc("t_ao", 2 * rows * c), rows, c)
+            kv = _V(sc("t_kv", 2 * B * L * 2 * c), B * L, 2 * c)
+            ff = _V(sc("t_ff", 2 * rows * 4 * c), rows, 4 * c)
+            for l in range(layers):
+                b = f"{name}.transformer_blocks.{l}"
+                lnorm(hid, b + ".norm1", ln)
+                linear(ln, b + ".attn1.qkv", qkv, bias=False)
+                attention(qkv.cols(0, c), qkv.cols(c, c), qkv.cols(2 * c, c), ao, heads, hw, hw)
+                linear(ao, b + ".attn1.out", hid, R=hid)
+                lnorm(hid, b + ".norm2", ln)
+                q2 = _V(qkv.p, rows, c)
+                linear(ln, b + ".attn2.q", q2, bias=False)
+                linear(enc, b + ".attn2.kv", kv, bias=False)
+                attention(q2, kv.cols(0, c), kv.cols(c, c), ao, heads, hw, L)
+                linear(ao, b + ".attn2.out", hid, R=hid)
+                lnorm(hid, b + ".norm3", ln)
+                linear(ln, b + ".ff1", ff, flags=GEGLU)
+                linear(ff, b + ".ff2", hid, R=hid)
+            linear(hid, name + ".proj_out", out, R=x)
+
+        # ---- body ----
+        h, w_ = H, Wd
+        k = 0            # next skip index to produce
+        u = 0            # next up resnet index
+        cur = skip_slot(0)
+        emit(lib.mi355x_sd_conv_in3x3, (plan.sample.data_ptr(), plan.in_scale.data_ptr(), wp("conv_in.w"),
+                                        wp("conv_in.b"), cur.p, B, cfg["in_channels"], H, Wd, boc[0], cur.ld, stream),
+             "misc")
+        k = 1
+        tmp_i = 0
+
+        def tmp(rows, c) -> _V:
+            nonlocal tmp_i
+            tmp_i ^= 1
+            return _V(sc(f"x{tmp_i}", 2 * rows * c), rows, c)
+
+        i = 1  # S[0] is the conv_in skip
+        n_layers = len(S)
+        while i < n_layers:
+            d = S[i]
+            nxt = S[i + 1] if i + 1 < n_layers else ("end",)
+            rows = B * h * w_
+            if d[0] == "resnet" or d[0] == "attn":
+                cout = d[3] if d[0] == "resnet" else d[2]
+                # destination of this layer's output
+                if nxt[0] == "attn":
+                    dst = tmp(rows, cout)
+                elif nxt[0] == "skip":
+                    dst = skip_slot(k)
+                elif nxt[0] == "cat":
+                    dst = x_slot(u)
+                else:  # followed by mid resnet / upsampler / end
+                    dst = tmp(rows, cout)
+                if d[0] == "resnet":
+                    resnet(d[1], cur, h, w_, cout, d[4], dst)
+                else:
+                    transformer(d[1], cur, h, w_, d[3], d[4], dst)
+                cur = dst
+            elif d[0] == "skip":
+                k += 1
+            elif d[0] == "down":
+                ho, wo = (h + 2 - 3) // 2 + 1, (w_ + 2 - 3) // 2 + 1
+                dst = skip_slot(k)
+                conv3(cur, h, w_, d[1], dst, stride=2)
+                h, w_ = ho, wo
+                cur = dst
+            elif d[0] == "cat":
+                cur = cats[u]
+                u += 1
+            elif d[0] == "up":
+                dst = x_slot(u)
+                conv3(cur, h, w_, d[1], dst, up=1)
+                h, w_ = 2 * h, 2 * w_
+                cur = dst
+            i += 1
+        assert k == len(skips) and u == len(ups) and (h, w_) == (H, Wd)
+
+        # ---- post (unet_2d_condition.py:1193-1196) ----
+        g = gnorm(cur, H * Wd, "conv_norm_out", eps, True)
+        emit(lib.mi355x_sd_conv_out3x3, (g.p, g.ld, wp("conv_out.w"), wp("conv_out.b"), plan.out.data_ptr(), B, g.C, H,
+                                         Wd, cfg["out_channels"], stream), "misc")
+
+        # ---- allocate scratch, resolve addresses ----
+        bufs = {n: persist((max(nb, 16),), torch.uint8) for n, nb in scratch.items()}
+        base = {n: t.data_ptr() for n, t in bufs.items()}
+
+        def res(a):
+            return base[a.buf] + a.off if isinstance(a, _Ref) else a
+
+        plan.prog = [(fn, tuple(res(a) for a in args), kind, fl) for fn, args, kind, fl in prog]
+        plan.keep = keep
+        plan.graph = None
+        plan.B, plan.H, plan.W, plan.L = B, H, Wd, L
+        plan.scratch_bytes = sum(t.numel() * t.element_size() for t in keep)
+        plan.emb_tensors = dict(t0=t0, emb=emb, temb_all=temb_all)
+        return plan
+
+    # ------------------------------------------------------------------ execution
+    def _finish_add_embedding(self, plan: _Plan, text_dim: int, n_ids: int) -> None:
+        """text_time (unet_2d_condition.py:991-1010): add_in = [text_embeds | sinusoid(time_ids.flatten())]."""
+        cfg, lib = self.cfg, self._lib
+        if text_dim + n_ids * plan._atd != plan._pdim:
+            raise ValueError(f"text_embeds ({text_dim}) + time_ids ({n_ids} x {plan._atd}) != "
+                             f"projection_class_embeddings_input_dim ({plan._pdim})")
+        B = plan.B
+        plan.text_dim, plan.n_ids = text_dim, n_ids
+        plan.time_ids = torch.empty((B * n_ids,), device=self.device, dtype=torch.float32)
+        plan.keep.append(plan.time_ids)
+        op = (lib.mi355x_sd_timestep_embedding,
+              (plan.time_ids.data_ptr(), B * n_ids, B * n_ids, plan._atd, n_ids, 1 if cfg["flip_sin_to_cos"] else 0,
+               float(cfg["freq_shift"]), 1.0, 10000.0, plan.add_in.data_ptr() + 2 * text_dim, plan._pdim,
+               self._stream_ptr), "misc", 0.0)
+        plan.prog.insert(plan._add_emit_index, op)
+
+    def _run_eager(self, plan: _Plan) -> None:
+        if not self.profile or self._emulated:
+            for fn, args, _, _ in plan.prog:
+                rc = fn(*args)
+                if rc:
+                    _lib.check(rc)
+            return
+        evs = []
+        for fn, args, kind, fl in plan.prog:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(self._stream)
+            rc = fn(*args)
+            e1.record(self._stream)
+            if rc:
+                _lib.check(rc)
+            evs.append((kind, fl, e0, e1))
+        self._stream.synchronize()
+        for kind, fl, e0, e1 in evs:
+            self.kernel_times.setdefault(kind, []).append((e0.elapsed_time(e1) * 1e-3, fl))
+
+    def _capture(self, plan: _Plan) -> None:
+        lib = self._lib
+        sp = self._stream_ptr
+        _lib.check(lib.mi355x_sd_graph_begin(sp))
+        try:
+            for fn, args, _, _ in plan.prog:
+                rc = fn(*args)
+                if rc:
+                    _lib.check(rc)
+        finally:
+            import ctypes
+            exe = ctypes.c_void_p()
+            rc = lib.mi355x_sd_graph_end(sp, ctypes.byref(exe))
+        _lib.check(rc)
+        plan.graph = exe
+
+    def _get_plan(self, B, H, W, L) -> _Plan:
+        key = (B, H, W, L)
+        if key not in self._plans:
+            self._plans[key] = self._build_plan(B, H, W, L)
+        return self._plans[key]
+
+    def stage_inputs(self, plan: _Plan, sample, timestep, encoder_hidden_states, added_cond_kwargs=None,
+                     in_scale: Optional[float] = None) -> None:
+        cfg = self.cfg
+        if torch.is_tensor(timestep):
+            plan.t.copy_(timestep.reshape(-1)[:1].to(torch.float32), non_blocking=True)
+        else:
+            plan.t.fill_(float(timestep))
+        s = sample.to(torch.float32)
+        if cfg["center_input_sample"]:
+            s = 2 * s - 1.0
+        plan.sample.copy_(s, non_blocking=True)
+        if in_scale is not None:
+            plan.in_scale.fill_(float(in_scale))
+        plan.enc.copy_(encoder_hidden_states.reshape(plan.B * plan.L, -1), non_blocking=True)
+        if cfg["addition_embed_type"] == "text_time":
+            if added_cond_kwargs is None or "text_embeds" not in added_cond_kwargs:
+                raise ValueError(f"{self.__class__} has the config param `addition_embed_type` set to 'text_time' which "
+                                 "requires the keyword argument `text_embeds` to be passed in `added_cond_kwargs`")
+            if "time_ids" not in added_cond_kwargs:
+                raise ValueError(f"{self.__class__} has the config param `addition_embed_type` set to 'text_time' which "
+                                 "requires the keyword argument `time_ids` to be passed in `added_cond_kwargs`")
+            te, ti = added_cond_kwargs["text_embeds"], added_cond_kwargs["time_ids"]
+            if plan.text_dim is None:
+                self._finish_add_embedding(plan, te.shape[-1], ti.shape[-1])
+            plan.add_in[:, :plan.text_dim].copy_(te, non_blocking=True)
+            plan.time_ids.copy_(ti.reshape(-1).to(torch.float32), non_blocking=True)
+
+    def run(self, plan: _Plan) -> Tensor:
+        """Launch the step on the model's stream (inputs already staged); returns the static output buffer."""
+        if self.use_graph and not self.profile:
+            if plan.graph is None:
+                self._run_eager(plan)  # warm-up outside capture (lazy module loading)
+                self._capture(plan)
+            _lib.check(self._lib.mi355x_sd_graph_launch(plan.graph, self._stream_ptr))
+        else:
+            self._run_eager(plan)
+        return plan.out
+
+    def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, timestep_cond=None,
+                attention_mask=None, cross_attention_kwargs=None, added_cond_kwargs=None,
+                down_block_additional_residuals=None, mid_block_additional_residual=None,
+                encoder_attention_mask=None, return_dict: bool = True):
+        for nm, v in (("class_labels", class_labels), ("timestep_cond", timestep_cond),
+                      ("attention_mask", attention_mask), ("encoder_attention_mask", encoder_attention_mask),
+                      ("down_block_additional_residuals", down_block_additional_residuals),
+                      ("mid_block_additional_residual", mid_block_additional_residual)):
+            if v is not None:
+                raise NotImplementedError(f"UNet2DConditionModel(mi355x): `{nm}` is not implemented on this path")
+        if not self._emulated and (not sample.is_cuda or not encoder_hidden_states.is_cuda):
+            raise _lib.MI355XError("inputs must be GPU tensors (no CPU fallback)")
+        B, _, H, W = sample.shape
+        L = encoder_hidden_states.shape[1]
+        plan = self._get_plan(B, H, W, L)
+        if self._emulated:
+            self.stage_inputs(plan, sample, timestep, encoder_hidden_states, added_cond_kwargs)
+            self._run_eager(plan)
+            out = plan.out.clone()
+        else:
+            cur = torch.cuda.current_stream(self.device)
+            self._stream.wait_stream(cur)
+            with torch.cuda.stream(self._stream):
+                self.stage_inputs(plan, sample, timestep, encoder_hidden_states, added_cond_kwargs)
+                out = self.run(plan).clone()
+            cur.wait_stream(self._stream)
+        if not return_dict:
+            return (out,)
+        return UNet2DConditionOutput(sample=out)
+
+    __call__ = forward

@@ -1,0 +1,188 @@
+"""Host-memory interpreter of the C ABI in include/mi355x_sd.h -- TEST INFRASTRUCTURE ONLY.
+
+It executes the same (function, raw-pointer args) program that paddlemix_amd.unet emits for the HIP library, but on
+CPU memory with plain torch fp32 math, so the *host logic* (weight repacking, GEGLU interleave, fused QKV,
+concat-by-construction strides, program order) can be checked against the oracle without a GPU.  It is not a
+fallback: product code never constructs it (see UNet2DConditionModel._test_backend).
+
+``round_bf16=False`` keeps intermediate activations in fp32 buffers?  No -- buffers are bf16 by ABI; the emulator
+therefore shows exactly the rounding points of the device path (bf16 stores, fp32 accumulation).
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+
+import torch
+import torch.nn.functional as F
+
+GEGLU, OUT_F32, SILU = 1, 2, 4
+_ES = {torch.bfloat16: 2, torch.float32: 4}
+
+
+def _flat(ptr: int, n: int, dtype) -> torch.Tensor:
+    buf = (ctypes.c_char * (n * _ES[dtype])).from_address(ptr)
+    return torch.frombuffer(buf, dtype=dtype, count=n)
+
+
+def _rows(ptr: int, rows: int, C: int, ld: int, dtype=torch.bfloat16) -> torch.Tensor:
+    n = (rows - 1) * ld + C
+    return _flat(ptr, n, dtype).as_strided((rows, C), (ld, 1))
+
+
+class Emulator:
+    def __init__(self):
+        self.calls = []
+
+    # ---- bookkeeping ----
+    def mi355x_sd_init(self, device):
+        return 0
+
+    def mi355x_sd_last_error(self):
+        return b"emulator"
+
+    def mi355x_sd_groupnorm_workspace_floats(self, B, HW, C):
+        return 64
+
+    # ---- GEMM family ----
+    def _epilogue(self, acc, N, bias, rowbias, rpb, ld_rb, R, ldr, out_scale, flags, C, ldc):
+        M = acc.shape[0]
+        if bias:
+            acc = acc + _flat(bias, N, torch.float32)
+        if flags & GEGLU:
+            a = acc.reshape(M, N // 32, 2, 16)
+            acc = (a[:, :, 0] * F.gelu(a[:, :, 1])).reshape(M, N // 2)
+            N = N // 2
+        else:
+            if rowbias:
+                nb = (M + rpb - 1) // rpb
+                rb = _rows(rowbias, nb, N, ld_rb, torch.float32)
+                acc = acc + rb.repeat_interleave(rpb, 0)[:M]
+            if R:
+                acc = acc + _rows(R, M, N, ldr).float()
+            acc = acc * out_scale
+            if flags & SILU:
+                acc = F.silu(acc)
+        dt = torch.float32 if flags & OUT_F32 else torch.bfloat16
+        _rows(C, M, N, ldc, dt).copy_(acc.to(dt))
+
+    def mi355x_sd_linear(self, A, lda, W, C, ldc, M, N, K, bias, rowbias, rpb, ld_rb, R, ldr, out_scale, flags, stream):
+        self.calls.append("linear")
+        assert K % 8 == 0 and N % 4 == 0 and lda % 8 == 0 and ldc % 4 == 0
+        a = _rows(A, M, K, lda).float()
+        w = _rows(W, N, K, K).float()
+        self._epilogue(a @ w.t(), N, bias, rowbias, rpb, ld_rb, R, ldr, out_scale, flags, C, ldc)
+        return 0
+
+    def mi355x_sd_conv3x3(self, X, ldx, B, Hs, Ws, Cin, stride, up, W, C, ldc, Cout, bias, rowbias, ld_rb, R, ldr,
+                          out_scale, flags, stream):
+        self.calls.append("conv3x3")
+        assert Cin % 8 == 0 and ldx % 8 == 0
+        x = _rows(X, B * Hs * Ws, Cin, ldx).float().reshape(B, Hs, Ws, Cin).permute(0, 3, 1, 2)
+        if up:
+            x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+        w = _rows(W, Cout, 9 * Cin, 9 * Cin).float().reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+        y = F.conv2d(x, w, None, stride=stride, padding=1)
+        Ho, Wo = y.shape[2], y.shape[3]
+        acc = y.permute(0, 2, 3, 1).reshape(B * Ho * Wo, Cout)
+        self._epilogue(acc, Cout, bias, rowbias, Ho * Wo, ld_rb, R, ldr, out_scale, flags, C, ldc)
+        return 0
+
+    def mi355x_sd_sdpa(self, q, k, v, bias, out, B, H, Sq, Skv, D, q_bs, q_ts, k_bs, k_ts, v_bs, v_ts, o_bs, o_ts,
+                       bias_bs, bias_hs, bias_qs, scale, stream):
+        self.calls.append("sdpa")
+        assert bias is None or bias == 0, "emulator: bias path not needed by the UNet program"
+
+        def view(p, S, bs, ts):
+            n = (B - 1) * bs + (S - 1) * ts + H * D
+            return _flat(p, n, torch.bfloat16).as_strided((B, S, H, D), (bs, ts, D, 1))
+
+        qq, kk, vv = view(q, Sq, q_bs, q_ts).float(), view(k, Skv, k_bs, k_ts).float(), view(v, Skv, v_bs, v_ts).float()
+        s = torch.einsum("bqhd,bkhd->bhqk", qq, kk) * scale
+        p = torch.softmax(s, -1)
+        o = torch.einsum("bhqk,bkhd->bqhd", p, vv)
+        view(out, Sq, o_bs, o_ts).copy_(o.to(torch.bfloat16))
+        return 0
+
+    # ---- norms ----
+    def mi355x_sd_groupnorm_stats(self, x, B, HW, C, ldx, groups, eps, gamma, beta, ws, ss, stream):
+        self.calls.append("gn_stats")
+        xv = _rows(x, B * HW, C, ldx).float().reshape(B, HW, groups, C // groups)
+        mean = xv.mean(dim=(1, 3))
+        var = xv.var(dim=(1, 3), unbiased=False)
+        rstd = (var + eps).rsqrt()
+        g, b = _flat(gamma, C, torch.float32), _flat(beta, C, torch.float32)
+        cpg = C // groups
+        scale = g[None] * rstd.repeat_interleave(cpg, 1)
+        shift = b[None] - mean.repeat_interleave(cpg, 1) * scale
+        _flat(ss, B * 2 * C, torch.float32).reshape(B, 2, C).copy_(torch.stack([scale, shift], 1))
+        return 0
+
+    def mi355x_sd_scale_shift_act(self, x, B, HW, C, ldx, ss, silu, y, ldy, stream):
+        self.calls.append("scale_shift_act")
+        xv = _rows(x, B * HW, C, ldx).float().reshape(B, HW, C)
+        s = _flat(ss, B * 2 * C, torch.float32).reshape(B, 2, C)
+        o = xv * s[:, 0:1] + s[:, 1:2]
+        if silu:
+            o = F.silu(o)
+        _rows(y, B * HW, C, ldy).copy_(o.reshape(B * HW, C).to(torch.bfloat16))
+        return 0
+
+    def mi355x_sd_layernorm(self, x, rows, C, ldx, gamma, beta, eps, y, ldy, stream):
+        self.calls.append("layernorm")
+        g = _flat(gamma, C, torch.float32) if gamma else None
+        b = _flat(beta, C, torch.float32) if beta else None
+        o = F.layer_norm(_rows(x, rows, C, ldx).float(), (C,), g, b, eps)
+        _rows(y, rows, C, ldy).copy_(o.to(torch.bfloat16))
+        return 0
+
+    # ---- small ops ----
+    def mi355x_sd_timestep_embedding(self, t, t_count, n, dim, group, flip, freq_shift, scale, max_period, out, ldo,
+                                     stream):
+        self.calls.append("timestep_embedding")
+        tt = _flat(t, t_count, torch.float32)
+        idx = torch.arange(n) % t_count
+        half = dim // 2
+        exponent = -math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / (half - freq_shift)
+        emb = scale * (tt[idx][:, None] * torch.exp(exponent)[None])
+        e = torch.cat([torch.cos(emb), torch.sin(emb)], -1) if flip else torch.cat([torch.sin(emb), torch.cos(emb)], -1)
+        nb = (n + group - 1) // group
+        o = _rows(out, nb, group * dim, ldo)
+        o.copy_(e.reshape(nb, group * dim).to(torch.bfloat16))
+        return 0
+
+    def mi355x_sd_silu(self, x, y, n, in_f32, out_f32, stream):
+        self.calls.append("silu")
+        xi = _flat(x, n, torch.float32 if in_f32 else torch.bfloat16).float()
+        _flat(y, n, torch.float32 if out_f32 else torch.bfloat16).copy_(F.silu(xi))
+        return 0
+
+    def mi355x_sd_conv_in3x3(self, x, in_scale, w, bias, y, B, Cin, H, W, Cout, ldy, stream):
+        self.calls.append("conv_in")
+        xs = _flat(x, B * Cin * H * W, torch.float32).reshape(B, Cin, H, W)
+        if in_scale:
+            xs = xs * _flat(in_scale, 1, torch.float32)
+        xs = xs.to(torch.bfloat16).float()
+        wt = _flat(w, 9 * Cin * Cout, torch.bfloat16).float().reshape(3, 3, Cin, Cout).permute(3, 2, 0, 1)
+        o = F.conv2d(xs, wt, _flat(bias, Cout, torch.float32) if bias else None, padding=1)
+        _rows(y, B * H * W, Cout, ldy).copy_(o.permute(0, 2, 3, 1).reshape(B * H * W, Cout).to(torch.bfloat16))
+        return 0
+
+    def mi355x_sd_conv_out3x3(self, x, ldx, w, bias, y, B, Cin, H, W, Cout, stream):
+        self.calls.append("conv_out")
+        xs = _rows(x, B * H * W, Cin, ldx).float().reshape(B, H, W, Cin).permute(0, 3, 1, 2)
+        wt = _flat(w, Cout * 9 * Cin, torch.bfloat16).float().reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+        o = F.conv2d(xs, wt, _flat(bias, Cout, torch.float32) if bias else None, padding=1)
+        _flat(y, B * Cout * H * W, torch.float32).reshape(B, Cout, H, W).copy_(o)
+        return 0
+
+    def mi355x_sd_copy_rows(self, x, ldx, y, ldy, rows, C, stream):
+        self.calls.append("copy_rows")
+        _rows(y, rows, C, ldy).copy_(_rows(x, rows, C, ldx))
+        return 0
+
+    def mi355x_sd_axpby(self, x, y, out, coef, n, stream):
+        self.calls.append("axpby")
+        c = _flat(coef, 2, torch.float32)
+        _flat(out, n, torch.float32).copy_(c[0] * _flat(x, n, torch.float32) + c[1] * _flat(y, n, torch.float32))
+        return 0

@@ -1,0 +1,26 @@
+"""UNet configs shared by the tests (shapes follow the reference's own test / model configs)."""
+
+# kernel-compatible shrink of the reference's tiny test config (ppdiffusers/tests/models/test_models_unet_2d_condition.py:181-194:
+# block_out (32,64), cross 32, head_dim 8) -- channels doubled so every GEMM K is a multiple of 8 groups of 32.
+TINY = dict(block_out_channels=(64, 128), down_block_types=("DownBlock2D", "CrossAttnDownBlock2D"),
+            up_block_types=("CrossAttnUpBlock2D", "UpBlock2D"), cross_attention_dim=64, attention_head_dim=8,
+            layers_per_block=2, norm_num_groups=32, sample_size=32)
+
+# SDXL structure in miniature (mirrors ppdiffusers/tests/pipelines/stable_diffusion_xl/test_stable_diffusion_xl.py:66-83):
+# DownBlock + 2 CrossAttnDown, transformer_layers (1,2,2), text_time add-embedding, linear projections, head_dim 32/64
+MINI_XL = dict(block_out_channels=(64, 128, 256), down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+               up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"),
+               transformer_layers_per_block=(1, 2, 2), attention_head_dim=(2, 4, 4), cross_attention_dim=128,
+               use_linear_projection=True, addition_embed_type="text_time", addition_time_embed_dim=32,
+               projection_class_embeddings_input_dim=32 * 6 + 64, layers_per_block=2, sample_size=32)
+
+# SD-1.5 (ppdiffusers/examples/stable_diffusion/sd/unet_config.json)
+SD15 = dict(block_out_channels=(320, 640, 1280, 1280), cross_attention_dim=768, attention_head_dim=8,
+            layers_per_block=2, sample_size=64)
+
+# SDXL base UNet (public model config; structure per SURVEY.md 8a "X")
+SDXL = dict(block_out_channels=(320, 640, 1280), down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+            up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"),
+            transformer_layers_per_block=(1, 2, 10), attention_head_dim=(5, 10, 20), cross_attention_dim=2048,
+            use_linear_projection=True, addition_embed_type="text_time", addition_time_embed_dim=256,
+            projection_class_embeddings_input_dim=2816, layers_per_block=2, sample_size=128)

@@ -1,0 +1,82 @@
+"""CPU tests of the host logic: the program paddlemix_amd.unet emits is interpreted on host memory
+(tests/abi_emulator.py) and compared with the oracle.  No GPU, no HIP compute."""
+import pytest
+import torch
+
+from oracle import unet_ref as U
+from paddlemix_amd.unet import UNet2DConditionModel, synth_unet_params, unet_param_shapes
+from tests.abi_emulator import Emulator
+from tests.configs import MINI_XL, SD15, SDXL, TINY
+
+
+def _inputs(cfg, B, H, W, L=77, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    sample = torch.randn(B, 4, H, W, generator=g)
+    cross = cfg["cross_attention_dim"]
+    enc = torch.randn(B, L, cross, generator=g)
+    added = None
+    if cfg.get("addition_embed_type") == "text_time":
+        td = cfg["projection_class_embeddings_input_dim"] - 6 * cfg["addition_time_embed_dim"]
+        added = dict(text_embeds=torch.randn(B, td, generator=g),
+                     time_ids=torch.tensor([[1024., 1024., 0., 0., 1024., 1024.]]).repeat(B, 1))
+    return sample, enc, added
+
+
+def _rel(a, b):
+    return ((a - b).norm() / b.norm()).item()
+
+
+@pytest.mark.parametrize("cfg,B,H,W,L", [(TINY, 2, 16, 16, 7), (MINI_XL, 1, 16, 16, 77), (TINY, 1, 8, 24, 5)])
+def test_program_matches_oracle(cfg, B, H, W, L):
+    P = synth_unet_params(cfg, seed=1234)
+    Pb = {k: v.to(torch.bfloat16).float() if v.dim() > 1 else v for k, v in P.items()}  # device weights are bf16
+    sample, enc, added = _inputs(cfg, B, H, W, L)
+    t = 501
+    ref = U.unet_forward(Pb, cfg, sample, t, enc, added_cond_kwargs=added)
+    emu = Emulator()
+    model = UNet2DConditionModel(cfg, P, _test_backend=emu)
+    out = model(sample, t, enc, added_cond_kwargs=added, return_dict=False)[0]
+    assert out.shape == ref.shape and out.dtype == torch.float32
+    # bf16 activations between ops: a few 1e-3 of relative error is the rounding floor
+    assert _rel(out, ref) < 2e-2, _rel(out, ref)
+    # second call reuses the plan and is deterministic
+    out2 = model(sample, t, enc, added_cond_kwargs=added).sample
+    assert torch.equal(out, out2)
+    assert len(model._plans) == 1
+
+
+def test_param_inventory_matches_oracle():
+    for cfg in (TINY, MINI_XL, SD15, SDXL):
+        a, b = unet_param_shapes(cfg), U.unet_param_shapes(cfg)
+        assert list(a.items()) == list(b.items())
+
+
+def test_synth_params_match_oracle_generator():
+    a, b = synth_unet_params(TINY, 7), U.synth_unet_params(TINY, 7)
+    assert all(torch.equal(a[k], b[k]) for k in b)
+
+
+def test_errors_mirror_reference():
+    P = synth_unet_params(MINI_XL)
+    model = UNet2DConditionModel(MINI_XL, P, _test_backend=Emulator())
+    sample, enc, added = _inputs(MINI_XL, 1, 8, 8)
+    with pytest.raises(ValueError, match="text_embeds"):
+        model(sample, 1, enc, added_cond_kwargs={})
+    with pytest.raises(ValueError, match="time_ids"):
+        model(sample, 1, enc, added_cond_kwargs={"text_embeds": added["text_embeds"]})
+    with pytest.raises(KeyError):
+        UNet2DConditionModel(MINI_XL, {k: v for k, v in P.items() if k != "conv_in.weight"}, _test_backend=Emulator())
+    bad = dict(P)
+    bad["time_embedding.linear_1.weight"] = bad["time_embedding.linear_1.weight"].t()
+    with pytest.raises(ValueError, match="Paddle layout"):
+        UNet2DConditionModel(MINI_XL, bad, _test_backend=Emulator())
+    with pytest.raises(NotImplementedError):
+        UNet2DConditionModel(dict(MINI_XL, class_embed_type="timestep"), P, _test_backend=Emulator())
+
+
+def test_no_fallback_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from paddlemix_amd._lib import MI355XError
+    with pytest.raises(MI355XError):
+        UNet2DConditionModel(TINY, synth_unet_params(TINY))
