@@ -1,0 +1,249 @@
+#!/usr/bin/env python
+"""Headline benchmark: UNet denoising steps/sec, SD-XL base UNet, 1024x1024 (latents 8x4x128x128), bs=8 per GPU.
+
+One "step" = scheduler.scale_model_input (folded into conv_in) + UNet2DConditionModel forward (hipGraph replay) +
+Euler scheduler latent update, on synthetic inputs already resident in HBM; weights are random-init (no
+checkpoints offline).  N>1: one process per GPU (torchrun), rank 0 generates the weights and RCCL-broadcasts them
+over xGMI, every rank then denoises its own shard of 8 prompts with no per-step collective (weak scaling).
+
+Prints ONE JSON line (see the field notes in DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SDXL = dict(block_out_channels=(320, 640, 1280), down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+            up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"),
+            transformer_layers_per_block=(1, 2, 10), attention_head_dim=(5, 10, 20), cross_attention_dim=2048,
+            use_linear_projection=True, addition_embed_type="text_time", addition_time_embed_dim=256,
+            projection_class_embeddings_input_dim=2816, layers_per_block=2, sample_size=128)
+SD15 = dict(block_out_channels=(320, 640, 1280, 1280), cross_attention_dim=768, attention_head_dim=8, layers_per_block=2,
+            sample_size=64)
+WORKLOADS = {
+    "sdxl-1024-bs8": dict(cfg=SDXL, B=8, H=128, W=128, L=77, gflop_step=54089.8),
+    "sd15-512-bs1": dict(cfg=SD15, B=1, H=64, W=64, L=77, gflop_step=803.3),
+}
+PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16, MI355X_MICROARCH.md chip table
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="sdxl-1024-bs8", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    return ap.parse_args()
+
+
+def broadcast_params(P, rank, world):
+    """RCCL broadcast of the weights from rank 0 (bucketed, ~256 MB per collective: xGMI rings are per-link bound)."""
+    import torch.distributed as dist
+    bucket, size = [], 0
+    names = list(P)
+
+    def flush():
+        nonlocal bucket, size
+        if not bucket:
+            return
+        flat = torch.cat([P[n].reshape(-1) for n in bucket])
+        dist.broadcast(flat, src=0)
+        off = 0
+        for n in bucket:
+            k = P[n].numel()
+            P[n].copy_(flat[off:off + k].view_as(P[n]))
+            off += k
+        bucket, size = [], 0
+
+    for n in names:
+        bucket.append(n)
+        size += P[n].numel() * 4
+        if size >= 256 << 20:
+            flush()
+    flush()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from paddlemix_amd.schedulers import EulerDiscreteScheduler
+    from paddlemix_amd.unet import UNet2DConditionModel, synth_unet_params, unet_param_shapes
+    from paddlemix_amd import _lib
+
+    wl = WORKLOADS[args.workload]
+    cfg, B, H, W, L = wl["cfg"], wl["B"], wl["H"], wl["W"], wl["L"]
+
+    # ---- weights: rank 0 draws them, everyone else receives them over RCCL ----
+    t_w0 = time.time()
+    if rank == 0:
+        P = synth_unet_params(cfg, seed=1234, device=dev)
+    else:
+        P = {n: torch.empty(s, device=dev) for n, s in unet_param_shapes(cfg).items()}
+    bcast_s = None
+    if world > 1:
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.time()
+        broadcast_params(P, rank, world)
+        torch.cuda.synchronize()
+        bcast_s = time.time() - t0
+    model = UNet2DConditionModel(cfg, P, device=dev, use_graph=not args.no_graph)
+    P_cpu_needed = rank == 0 and world == 1 and not args.no_cpu_baseline
+    if not P_cpu_needed:
+        del P
+    torch.cuda.empty_cache()
+
+    # ---- synthetic inputs, resident in HBM ----
+    g = torch.Generator(device=dev).manual_seed(rank)
+    sched = EulerDiscreteScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                                   timestep_spacing="leading", steps_offset=1)
+    n_sched = 30
+    sched.set_timesteps(n_sched)
+    latents = torch.randn(B, 4, H, W, generator=g, device=dev) * sched.init_noise_sigma
+    enc = torch.randn(B, L, cfg["cross_attention_dim"], generator=g, device=dev)
+    added = None
+    if cfg.get("addition_embed_type") == "text_time":
+        td = cfg["projection_class_embeddings_input_dim"] - 6 * cfg["addition_time_embed_dim"]
+        added = dict(text_embeds=torch.randn(B, td, generator=g, device=dev),
+                     time_ids=torch.tensor([[1024., 1024., 0., 0., 1024., 1024.]], device=dev).repeat(B, 1))
+    plan = model._get_plan(B, H, W, L)
+    coef = torch.zeros(2, device=dev)
+    lib = _lib.load()
+    stream = model._stream
+    lat0 = latents.clone()
+
+    def step(i):
+        """one denoising step, everything stream-ordered on the model's stream"""
+        k = i % n_sched
+        if k == 0:
+            sched._step_index = None
+            latents.copy_(lat0)
+        t = sched.timesteps[k]
+        scale = sched.model_input_scale(t)
+        a, b = sched.step_coefficients(t)
+        model.stage_inputs(plan, latents, float(t), enc, added, in_scale=scale)
+        coef.copy_(torch.tensor([a, b]), non_blocking=False)
+        eps = model.run(plan)
+        _lib.check(lib.mi355x_sd_axpby(latents.data_ptr(), eps.data_ptr(), latents.data_ptr(), coef.data_ptr(),
+                                       latents.numel(), stream.cuda_stream))
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    with torch.cuda.stream(stream):
+        for i in range(args.warmup):
+            step(i)
+        sync_all()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i)
+        sync_all()
+        elapsed = time.perf_counter() - t0
+    if not torch.isfinite(latents).all():
+        raise SystemExit("non-finite latents")
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+
+    res = {
+        "metric": "UNet denoising steps/sec (SD-XL 1024^2, bs=8)" if args.workload == "sdxl-1024-bs8"
+        else "UNet denoising steps/sec (SD-1.5 512^2, bs=1)",
+        "value": world * args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": args.workload, "latents": [B, 4, H, W], "text": [B, L, cfg["cross_attention_dim"]],
+                   "batch_per_gpu": B, "global_batch": B * world, "scheduler": "EulerDiscrete/30",
+                   "weights": "random-init bf16 (N(0,1/fan_in)), RCCL-broadcast from rank 0" if world > 1
+                   else "random-init bf16 (N(0,1/fan_in))",
+                   "parallelism": f"prompt-sharded dp{world}, no per-step collective", "hipgraph": not args.no_graph},
+        "tflops_effective": world * args.steps * wl["gflop_step"] / 1e3 / elapsed,
+    }
+    if bcast_s is not None:
+        res["weight_broadcast_s"] = bcast_s
+
+    # ---- roofline of the dominant kernel: per-launch HIP-event timing on the launch stream, one eager step ----
+    if rank == 0 and not args.no_roofline:
+        model.profile = True
+        model.kernel_times.clear()
+        with torch.cuda.stream(stream):
+            for i in range(2):
+                model.kernel_times.clear()
+                model.stage_inputs(plan, latents, 500.0, enc, added, in_scale=0.5)
+                model._run_eager(plan)
+        model.profile = False
+        kinds = {}
+        for kind, xs in model.kernel_times.items():
+            kinds[kind] = dict(launches=len(xs), ms=1e3 * sum(x[0] for x in xs), gflop=sum(x[1] for x in xs) / 1e9)
+        total_ms = sum(v["ms"] for v in kinds.values())
+        dom = max((k for k in kinds if kinds[k]["gflop"] > 0), key=lambda k: kinds[k]["ms"])
+        d = kinds[dom]
+        ach = d["gflop"] / d["ms"]  # GFLOP/ms == TFLOP/s
+        names = {"gemm": "gemm_bf16_kernel<false>", "conv": "gemm_bf16_kernel<true>", "attn": "attention_kernel<64,false>"}
+        res["roofline"] = {"bound": "mfma", "kernel": names.get(dom, dom), "achieved": ach, "peak": PEAK_BF16_TFLOPS,
+                           "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                           "launches_per_step": d["launches"], "avg_launch_ms": d["ms"] / d["launches"],
+                           "algorithmic_gflop_per_step": d["gflop"]}
+        res["kernel_breakdown_ms"] = {k: round(v["ms"], 3) for k, v in sorted(kinds.items(), key=lambda kv: -kv[1]["ms"])}
+        res["kernel_breakdown_tflops"] = {k: round(v["gflop"] / v["ms"], 1) for k, v in kinds.items() if v["gflop"] > 0}
+        res["eager_step_ms_sum_of_kernels"] = total_ms
+
+    # ---- CPU baseline: the torch-CPU oracle on a bounded sample of the same workload (rank 0, N=1 only) ----
+    if P_cpu_needed:
+        from oracle import unet_ref as U
+        threads = torch.get_num_threads()
+        frac_hw = 4  # 1 prompt at 1/4 of the latent side: (B*H*W) / (1*(H/4)*(W/4)) fewer positions
+        hb, wb = max(H // frac_hw, 8), max(W // frac_hw, 8)
+        Pc = {k: v.float().cpu() for k, v in P.items()}
+        del P
+        gs = torch.Generator().manual_seed(0)
+        s = torch.randn(1, 4, hb, wb, generator=gs)
+        e = torch.randn(1, L, cfg["cross_attention_dim"], generator=gs)
+        ad = None
+        if added is not None:
+            ad = dict(text_embeds=torch.randn(1, td, generator=gs), time_ids=added["time_ids"][:1].cpu())
+        with torch.no_grad():
+            U.unet_forward(Pc, cfg, s[:, :, :8, :8], 500, e, added_cond_kwargs=ad)  # page-in
+            t0 = time.perf_counter()
+            U.unet_forward(Pc, cfg, s, 500, e, added_cond_kwargs=ad)
+            cpu_s = time.perf_counter() - t0
+        positions_ratio = (B * H * W) / (hb * wb)
+        res["cpu_baseline"] = {
+            "value": 1.0 / (cpu_s * positions_ratio), "unit": "steps/s", "cores": threads, "kind": "port",
+            "sample": f"torch-CPU fp32 restatement of ppdiffusers (Paddle unavailable): 1 UNet forward, 1 prompt at "
+                      f"{hb}x{wb} latents = 1/{positions_ratio:.0f} of the bs-{B} {H}x{W} step's positions, "
+                      f"{cpu_s:.2f} s on {threads} threads; scaled linearly in positions (optimistic for CPU: "
+                      f"self-attention grows quadratically)",
+        }
+    if rank == 0:
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

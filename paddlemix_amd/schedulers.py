@@ -1,0 +1,294 @@
+"""Scheduler API surface kept for the denoising loop (plumbing, not accelerated math).
+
+Mirrors the reference classes' public contract -- ``set_timesteps`` / ``scale_model_input`` / ``step`` /
+``init_noise_sigma`` / ``timesteps`` -- for the three schedulers BASELINE.json's configs use:
+  DDIMScheduler                      ppdiffusers/ppdiffusers/schedulers/scheduling_ddim.py:131 (step :350-475)
+  EulerDiscreteScheduler             scheduling_euler_discrete.py:94 (scale_model_input :216-238, step :375-478)
+  FlowMatchEulerDiscreteScheduler    scheduling_flow_match_euler_discrete.py:44 (step :187-283)
+Schedule tables are float32 numpy like the reference's float32 tensors; ``step`` works on torch tensors of any device.
+
+For deterministic sampling every ``step`` is a linear map  prev = a*sample + b*model_output ; ``step_coefficients``
+returns (a, b) so the latent update can run as the library's fused ``mi355x_sd_axpby`` inside a captured graph.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+
+def _make_betas(n: int, beta_start: float, beta_end: float, schedule: str) -> np.ndarray:
+    if schedule == "linear":
+        return np.linspace(beta_start, beta_end, n, dtype=np.float32)
+    if schedule == "scaled_linear":  # the latent-diffusion schedule
+        return np.linspace(beta_start ** 0.5, beta_end ** 0.5, n, dtype=np.float32) ** 2
+    raise NotImplementedError(f"{schedule} is not implemented")
+
+
+def _out(prev, return_dict, **extra):
+    if not return_dict:
+        return (prev,)
+    return SimpleNamespace(prev_sample=prev, **extra)
+
+
+class DDIMScheduler:
+    order = 1
+
+    def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.0001, beta_end: float = 0.02,
+                 beta_schedule: str = "linear", clip_sample: bool = True, set_alpha_to_one: bool = True,
+                 steps_offset: int = 0, prediction_type: str = "epsilon", clip_sample_range: float = 1.0,
+                 timestep_spacing: str = "leading"):
+        self.config = SimpleNamespace(**{k: v for k, v in locals().items() if k != "self"})
+        betas = _make_betas(num_train_timesteps, beta_start, beta_end, beta_schedule)
+        self.alphas_cumprod = np.cumprod(1.0 - betas, dtype=np.float32)
+        self.final_alpha_cumprod = np.float32(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self.init_noise_sigma = 1.0
+        self.num_inference_steps = None
+        self.timesteps = np.arange(0, num_train_timesteps)[::-1].copy().astype(np.int64)
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def set_timesteps(self, num_inference_steps: int):
+        c = self.config
+        if num_inference_steps > c.num_train_timesteps:
+            raise ValueError("`num_inference_steps` cannot be larger than `num_train_timesteps`")
+        self.num_inference_steps = num_inference_steps
+        if c.timestep_spacing == "leading":
+            step_ratio = c.num_train_timesteps // num_inference_steps
+            ts = (np.arange(0, num_inference_steps) * step_ratio).round()[::-1].copy().astype(np.int64)
+            ts += c.steps_offset
+        elif c.timestep_spacing == "trailing":
+            ts = np.round(np.arange(c.num_train_timesteps, 0, -c.num_train_timesteps / num_inference_steps))
+            ts = ts.astype(np.int64) - 1
+        elif c.timestep_spacing == "linspace":
+            ts = np.linspace(0, c.num_train_timesteps - 1, num_inference_steps).round()[::-1].copy().astype(np.int64)
+        else:
+            raise ValueError(f"{c.timestep_spacing} is not supported")
+        self.timesteps = ts
+
+    def _alphas(self, timestep: int) -> Tuple[float, float]:
+        prev_t = timestep - self.config.num_train_timesteps // self.num_inference_steps
+        a_t = self.alphas_cumprod[timestep]
+        a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
+        return a_t, a_prev
+
+    def _get_variance(self, timestep, prev_timestep):
+        a_t = self.alphas_cumprod[timestep]
+        a_prev = self.alphas_cumprod[prev_timestep] if prev_timestep >= 0 else self.final_alpha_cumprod
+        return (1 - a_prev) / (1 - a_t) * (1 - a_t / a_prev)
+
+    def step_coefficients(self, timestep) -> Tuple[float, float]:
+        """(a, b) with prev = a*sample + b*model_output; epsilon prediction, eta = 0, no clipping."""
+        c = self.config
+        if c.prediction_type != "epsilon" or c.clip_sample:
+            raise NotImplementedError("linear-update form needs epsilon prediction without clip_sample")
+        a_t, a_prev = (float(v) for v in self._alphas(int(timestep)))
+        a = (a_prev / a_t) ** 0.5
+        b = (1 - a_prev) ** 0.5 - (a_prev * (1 - a_t) / a_t) ** 0.5
+        return a, b
+
+    def step(self, model_output, timestep, sample, eta: float = 0.0, use_clipped_model_output: bool = False,
+             generator=None, variance_noise=None, return_dict: bool = True):
+        if self.num_inference_steps is None:
+            raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating "
+                             "the scheduler")
+        c = self.config
+        t = int(timestep)
+        a_t, a_prev = (float(v) for v in self._alphas(t))
+        b_t = 1.0 - a_t
+        if c.prediction_type == "epsilon":
+            x0 = (sample - b_t ** 0.5 * model_output) / a_t ** 0.5
+            eps = model_output
+        elif c.prediction_type == "sample":
+            x0 = model_output
+            eps = (sample - a_t ** 0.5 * x0) / b_t ** 0.5
+        elif c.prediction_type == "v_prediction":
+            x0 = a_t ** 0.5 * sample - b_t ** 0.5 * model_output
+            eps = a_t ** 0.5 * model_output + b_t ** 0.5 * sample
+        else:
+            raise ValueError(f"prediction_type given as {c.prediction_type} must be one of `epsilon`, `sample`, or "
+                             "`v_prediction`")
+        if c.clip_sample:
+            x0 = x0.clamp(-c.clip_sample_range, c.clip_sample_range)
+        prev_t = t - c.num_train_timesteps // self.num_inference_steps
+        std = eta * float(self._get_variance(t, prev_t)) ** 0.5
+        if use_clipped_model_output:
+            eps = (sample - a_t ** 0.5 * x0) / b_t ** 0.5
+        prev = a_prev ** 0.5 * x0 + (1 - a_prev - std ** 2) ** 0.5 * eps
+        if eta > 0:
+            if variance_noise is None:
+                variance_noise = torch.randn(model_output.shape, generator=generator, device=model_output.device,
+                                             dtype=model_output.dtype)
+            prev = prev + std * variance_noise
+        return _out(prev, return_dict, pred_original_sample=x0)
+
+    def add_noise(self, original_samples, noise, timesteps):
+        a = torch.as_tensor(self.alphas_cumprod)[timesteps].to(original_samples.device)
+        while a.dim() < original_samples.dim():
+            a = a.unsqueeze(-1)
+        return a ** 0.5 * original_samples + (1 - a) ** 0.5 * noise
+
+    def __len__(self):
+        return self.config.num_train_timesteps
+
+
+class EulerDiscreteScheduler:
+    order = 1
+
+    def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.0001, beta_end: float = 0.02,
+                 beta_schedule: str = "linear", prediction_type: str = "epsilon", interpolation_type: str = "linear",
+                 use_karras_sigmas: bool = False, timestep_spacing: str = "linspace", steps_offset: int = 0):
+        self.config = SimpleNamespace(**{k: v for k, v in locals().items() if k != "self"})
+        betas = _make_betas(num_train_timesteps, beta_start, beta_end, beta_schedule)
+        self.alphas_cumprod = np.cumprod(1.0 - betas, dtype=np.float32)
+        self._train_sigmas = ((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5
+        self.sigmas = np.concatenate([self._train_sigmas[::-1], [0.0]]).astype(np.float32)
+        self.timesteps = np.linspace(0, num_train_timesteps - 1, num_train_timesteps, dtype=float)[::-1].astype(
+            np.float32)
+        self.num_inference_steps = None
+        self._step_index: Optional[int] = None
+
+    @property
+    def init_noise_sigma(self):
+        m = float(self.sigmas.max())
+        if self.config.timestep_spacing in ("linspace", "trailing"):
+            return m
+        return (m ** 2 + 1) ** 0.5
+
+    @property
+    def step_index(self):
+        return self._step_index
+
+    def set_timesteps(self, num_inference_steps: int):
+        c = self.config
+        self.num_inference_steps = n = num_inference_steps
+        T = c.num_train_timesteps
+        if c.timestep_spacing == "linspace":
+            ts = np.linspace(0, T - 1, n, dtype=np.float32)[::-1].copy()
+        elif c.timestep_spacing == "leading":
+            ts = (np.arange(0, n) * (T // n)).round()[::-1].copy().astype(np.float32) + c.steps_offset
+        elif c.timestep_spacing == "trailing":
+            ts = (np.arange(T, 0, -T / n)).round().copy().astype(np.float32) - 1
+        else:
+            raise ValueError(f"{c.timestep_spacing} is not supported")
+        sig_all = np.array(self._train_sigmas)
+        log_sig = np.log(sig_all)
+        if c.interpolation_type == "linear":
+            sig = np.interp(ts, np.arange(0, len(sig_all)), sig_all)
+        elif c.interpolation_type == "log_linear":
+            sig = np.exp(np.linspace(np.log(sig_all[-1]), np.log(sig_all[0]), n + 1))
+        else:
+            raise ValueError(f"{c.interpolation_type} is not implemented")
+        if c.use_karras_sigmas:
+            rho = 7.0
+            lo, hi = sig[-1] ** (1 / rho), sig[0] ** (1 / rho)
+            sig = (hi + np.linspace(0, 1, n) * (lo - hi)) ** rho
+            ts = np.array([self._sigma_to_t(s, log_sig) for s in sig])
+        self.sigmas = np.concatenate([sig, [0.0]]).astype(np.float32)
+        self.timesteps = ts.astype(np.float32)
+        self._step_index = None
+
+    @staticmethod
+    def _sigma_to_t(sigma, log_sigmas):
+        log_sigma = np.log(np.maximum(sigma, 1e-10))
+        dists = log_sigma - log_sigmas[:, np.newaxis]
+        low_idx = np.cumsum((dists >= 0), axis=0).argmax(axis=0).clip(max=log_sigmas.shape[0] - 2)
+        high_idx = low_idx + 1
+        low, high = log_sigmas[low_idx], log_sigmas[high_idx]
+        w = np.clip((low - log_sigma) / (low - high), 0, 1)
+        return ((1 - w) * low_idx + w * high_idx).reshape(np.shape(sigma))
+
+    def _init_step_index(self, timestep):
+        t = float(timestep)
+        idx = np.nonzero(self.timesteps == np.float32(t))[0]
+        # "the sigma index that is taken for the **very** first step is always the second index" (duplicates)
+        self._step_index = int(idx[1] if len(idx) > 1 else idx[0])
+
+    def scale_model_input(self, sample, timestep):
+        if self._step_index is None:
+            self._init_step_index(timestep)
+        return sample / ((float(self.sigmas[self._step_index]) ** 2 + 1) ** 0.5)
+
+    def model_input_scale(self, timestep) -> float:
+        if self._step_index is None:
+            self._init_step_index(timestep)
+        return 1.0 / ((float(self.sigmas[self._step_index]) ** 2 + 1) ** 0.5)
+
+    def step_coefficients(self, timestep) -> Tuple[float, float]:
+        """(a, b) with prev = a*sample + b*model_output for epsilon prediction, s_churn = 0; advances the index."""
+        if self.config.prediction_type != "epsilon":
+            raise NotImplementedError("linear-update form is for epsilon prediction")
+        if self._step_index is None:
+            self._init_step_index(timestep)
+        s, s_next = float(self.sigmas[self._step_index]), float(self.sigmas[self._step_index + 1])
+        self._step_index += 1
+        return 1.0, s_next - s
+
+    def step(self, model_output, timestep, sample, s_churn: float = 0.0, s_tmin: float = 0.0,
+             s_tmax: float = float("inf"), s_noise: float = 1.0, generator=None, return_dict: bool = True):
+        if self._step_index is None:
+            self._init_step_index(timestep)
+        sigma = float(self.sigmas[self._step_index])
+        gamma = min(s_churn / (len(self.sigmas) - 1), 2 ** 0.5 - 1) if s_tmin <= sigma <= s_tmax else 0.0
+        sigma_hat = sigma * (gamma + 1)
+        if gamma > 0:
+            noise = torch.randn(model_output.shape, generator=generator, device=model_output.device,
+                                dtype=model_output.dtype)
+            sample = sample + noise * s_noise * (sigma_hat ** 2 - sigma ** 2) ** 0.5
+        pt = self.config.prediction_type
+        if pt in ("original_sample", "sample"):
+            x0 = model_output
+        elif pt == "epsilon":
+            x0 = sample - sigma_hat * model_output
+        elif pt == "v_prediction":
+            x0 = model_output * (-sigma / (sigma ** 2 + 1) ** 0.5) + (sample / (sigma ** 2 + 1))
+        else:
+            raise ValueError(f"prediction_type given as {pt} must be one of `epsilon`, or `v_prediction`")
+        derivative = (sample - x0) / sigma_hat
+        dt = float(self.sigmas[self._step_index + 1]) - sigma_hat
+        prev = sample + derivative * dt
+        self._step_index += 1
+        return _out(prev, return_dict, pred_original_sample=x0)
+
+    def __len__(self):
+        return self.config.num_train_timesteps
+
+
+class FlowMatchEulerDiscreteScheduler:
+    order = 1
+
+    def __init__(self, num_train_timesteps: int = 1000, shift: float = 1.0):
+        self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, shift=shift)
+        ts = np.linspace(1, num_train_timesteps, num_train_timesteps, dtype=np.float32)[::-1].copy()
+        sig = ts / num_train_timesteps
+        sig = shift * sig / (1 + (shift - 1) * sig)
+        self.sigmas = sig.astype(np.float32)
+        self.timesteps = self.sigmas * num_train_timesteps
+        self.sigma_min, self.sigma_max = float(self.sigmas[-1]), float(self.sigmas[0])
+        self._step_index = None
+        self.init_noise_sigma = 1.0
+
+    def set_timesteps(self, num_inference_steps: int):
+        T, shift = self.config.num_train_timesteps, self.config.shift
+        ts = np.linspace(self.sigma_max * T, self.sigma_min * T, num_inference_steps)
+        sig = ts / T
+        sig = (shift * sig / (1 + (shift - 1) * sig)).astype(np.float32)
+        self.timesteps = sig * T
+        self.sigmas = np.concatenate([sig, np.zeros(1, np.float32)])
+        self.num_inference_steps = num_inference_steps
+        self._step_index = None
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def step(self, model_output, timestep, sample, return_dict: bool = True, **unused):
+        if self._step_index is None:
+            idx = np.nonzero(self.timesteps == np.float32(float(timestep)))[0]
+            self._step_index = int(idx[1] if len(idx) > 1 else idx[0])
+        s, s_next = float(self.sigmas[self._step_index]), float(self.sigmas[self._step_index + 1])
+        prev = (sample.to(torch.float32) + (s_next - s) * model_output.to(torch.float32)).to(model_output.dtype)
+        self._step_index += 1
+        return _out(prev, return_dict)

@@ -1,0 +1,289 @@
+"""-m gpu parity tests: every HIP kernel, called through the C ABI, against the CPU oracle (oracle/unet_ref.py) on
+the same seeded inputs.  Tolerances: inputs/outputs are bf16 (8-bit mantissa, ulp 2^-8 = 3.9e-3 relative) with fp32
+accumulation, so a single op is held to rel-L2 <= 4e-3 and max-abs <= 2 bf16 ulps of the output scale against the
+fp32 oracle evaluated on the same bf16-rounded inputs."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import unet_ref as U
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from paddlemix_amd import ops as o
+    o.init(0)
+    return o
+
+
+def bfr(t):  # bf16-representable fp32
+    return t.to(torch.bfloat16).float()
+
+
+def dev(t, dtype=torch.bfloat16):
+    return t.to("cuda", dtype)
+
+
+def check(out, ref, rel=4e-3, what=""):
+    out = out.float().cpu()
+    err = (out - ref).norm() / ref.norm().clamp_min(1e-12)
+    mx = (out - ref).abs().max()
+    scale = ref.abs().max()
+    assert torch.isfinite(out).all(), f"{what}: non-finite output"
+    assert err < rel, f"{what}: rel-L2 {err:.3e} (max abs {mx:.3e}, scale {scale:.3e})"
+    assert mx <= 2 * 2 ** -8 * scale + 1e-6, f"{what}: max abs {mx:.3e} vs scale {scale:.3e}"
+
+
+def test_probe_layouts(ops):
+    """The lane->element maps the kernels assume (cdna guide section 3; asymmetric operands so a transpose shows)."""
+    raw = ops.probe_layouts().cpu()
+    A16 = torch.tensor([[((r * 7 + k * 3) % 11) - 5 for k in range(32)] for r in range(16)], dtype=torch.float32)
+    B16 = torch.tensor([[((k * 5 + c * 2) % 13) - 6 for c in range(16)] for k in range(32)], dtype=torch.float32)
+    C16 = A16 @ B16
+    A32 = torch.tensor([[((r * 7 + k * 3) % 11) - 5 for k in range(16)] for r in range(32)], dtype=torch.float32)
+    B32 = torch.tensor([[((k * 5 + c * 2) % 13) - 6 for c in range(32)] for k in range(16)], dtype=torch.float32)
+    C32 = A32 @ B32
+    for l in range(64):
+        for r in range(4):
+            assert raw[l, r] == C16[(l >> 4) * 4 + r, l & 15], ("mfma16", l, r)
+        for r in range(16):
+            assert raw[l, 4 + r] == C32[(r & 3) + 8 * (r >> 2) + 4 * (l >> 5), l & 31], ("mfma32", l, r)
+        for j in range(4):
+            assert raw[l, 20 + j] == (l & 15) + j * 16 + (l >> 4) * 64, ("tr16", l, j)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 328, 72), (8, 1280, 320), (1024, 640, 2048), (77, 96, 768)])
+def test_linear_plain(ops, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    a, w = bfr(torch.randn(M, K, generator=g)), bfr(torch.randn(K, N, generator=g) / math.sqrt(K))
+    bias = torch.randn(N, generator=g) * 0.1
+    ref = U.linear({"l.weight": w, "l.bias": bias}, "l", a)
+    out = ops.linear(dev(a), dev(w.t().contiguous()), dev(bias, torch.float32))
+    check(out, ref, what=f"linear {M}x{N}x{K}")
+
+
+def test_linear_epilogues_and_strides(ops):
+    g = torch.Generator().manual_seed(3)
+    M, N, K, B = 192, 256, 128, 3
+    a_full = bfr(torch.randn(M, K + 64, generator=g))
+    a = a_full[:, 32:32 + K]                      # strided A view
+    w = bfr(torch.randn(K, N, generator=g) / math.sqrt(K))
+    bias = torch.randn(N, generator=g) * 0.1
+    rowbias = torch.randn(B, N + 8, generator=g)[:, :N]
+    res_full = bfr(torch.randn(M, N + 16, generator=g))
+    res = res_full[:, 8:8 + N]
+    ref = (a @ w + bias + rowbias.repeat_interleave(M // B, 0) + res) * 0.5
+    out_full = torch.zeros(M, N + 24, device="cuda", dtype=torch.bfloat16)
+    a_d = dev(a_full)[:, 32:32 + K]
+    rb_d = dev(rowbias.contiguous(), torch.float32)
+    r_d = dev(res_full)[:, 8:8 + N]
+    ops.linear(a_d, dev(w.t().contiguous()), dev(bias, torch.float32), rowbias=rb_d, rows_per_batch=M // B,
+               residual=r_d, out=out_full[:, 16:16 + N], out_scale=0.5)
+    check(out_full[:, 16:16 + N], ref, what="linear epilogue")
+    assert (out_full[:, :16] == 0).all() and (out_full[:, 16 + N:] == 0).all(), "wrote outside the output view"
+    # SiLU epilogue + fp32 output
+    ref2 = F.silu(a @ w + bias)
+    out2 = ops.linear(a_d, dev(w.t().contiguous()), dev(bias, torch.float32), silu=True, out_f32=True)
+    assert out2.dtype == torch.float32
+    check(out2, ref2, what="linear silu f32")
+
+
+def test_geglu_ff_matches_reference(ops):
+    """FeedForward with GEGLU (attention.py:670-677, activations.py:101-104) through the interleaved-weight epilogue."""
+    g = torch.Generator().manual_seed(5)
+    M, C = 300, 128
+    P = {"ff.net.0.proj.weight": bfr(torch.randn(C, 8 * C, generator=g) / math.sqrt(C)),
+         "ff.net.0.proj.bias": torch.randn(8 * C, generator=g) * 0.1,
+         "ff.net.2.weight": bfr(torch.randn(4 * C, C, generator=g) / math.sqrt(4 * C)),
+         "ff.net.2.bias": torch.randn(C, generator=g) * 0.1}
+    x = bfr(torch.randn(M, C, generator=g))
+    hg = U.linear(P, "ff.net.0.proj", x)
+    h, gate = hg.chunk(2, -1)
+    mid_ref = h * F.gelu(gate)
+    w1 = P["ff.net.0.proj.weight"].t()
+    half = 4 * C
+    w1i = torch.stack([w1[:half].reshape(half // 16, 16, -1), w1[half:].reshape(half // 16, 16, -1)], 1).reshape(2 * half, -1)
+    b1 = P["ff.net.0.proj.bias"]
+    b1i = torch.stack([b1[:half].reshape(half // 16, 16), b1[half:].reshape(half // 16, 16)], 1).reshape(-1)
+    mid = ops.linear(dev(x), dev(w1i.contiguous()), dev(b1i.contiguous(), torch.float32), geglu=True)
+    assert mid.shape == (M, 4 * C)
+    check(mid, mid_ref, what="geglu")
+    out = ops.linear(mid, dev(P["ff.net.2.weight"].t().contiguous()), dev(P["ff.net.2.bias"], torch.float32))
+    check(out, U.linear(P, "ff.net.2", bfr(mid.float().cpu())), what="ff2")
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,up", [(2, 16, 16, 64, 128, 1, False), (1, 9, 13, 32, 64, 1, False),
+                                                      (2, 16, 16, 64, 64, 2, False), (1, 8, 8, 64, 96, 1, True),
+                                                      (1, 32, 32, 320, 320, 1, False), (1, 7, 5, 40, 64, 2, False)])
+def test_conv3x3(ops, B, H, W, Cin, Cout, stride, up):
+    g = torch.Generator().manual_seed(B * H + Cin + Cout + stride)
+    x = bfr(torch.randn(B, Cin, H, W, generator=g))
+    w = bfr(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin))
+    bias = torch.randn(Cout, generator=g) * 0.1
+    P = {"c.conv.weight": w, "c.conv.bias": bias}
+    if up:
+        ref = U.upsample(P, "c", x)
+    elif stride == 2:
+        ref = U.downsample(P, "c", x)
+    else:
+        ref = U.conv2d(P, "c.conv", x)
+    x_nhwc = dev(x.permute(0, 2, 3, 1).contiguous())
+    wk = dev(w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous())
+    out = ops.conv3x3(x_nhwc, wk, dev(bias, torch.float32), stride=stride, upsample=up)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    check(out.reshape(B, Ho, Wo, Cout).permute(0, 3, 1, 2), ref, what=f"conv3x3 {B,H,W,Cin,Cout,stride,up}")
+
+
+def test_conv3x3_resnet_epilogues(ops):
+    """conv1 (+temb broadcast, resnet.py:772-784) and conv2 (+shortcut, /output_scale_factor, :800-806) epilogues on
+    channel-strided (concat-by-construction) views."""
+    g = torch.Generator().manual_seed(11)
+    B, H, W, C1, C2, Cout = 2, 8, 8, 64, 32, 64
+    xcat = bfr(torch.randn(B, H, W, C1 + C2, generator=g))
+    w = bfr(torch.randn(Cout, C1 + C2, 3, 3, generator=g) / math.sqrt(9 * (C1 + C2)))
+    bias = torch.randn(Cout, generator=g) * 0.1
+    temb = torch.randn(B, Cout, generator=g)
+    res = bfr(torch.randn(B * H * W, Cout, generator=g))
+    ref = F.conv2d(xcat.permute(0, 3, 1, 2), w, bias, padding=1) + temb[:, :, None, None]
+    ref = (ref + res.reshape(B, H, W, Cout).permute(0, 3, 1, 2)) / 2.0
+    big = torch.zeros(B * H * W, Cout + 64, device="cuda", dtype=torch.bfloat16)
+    # rowbias is a column slice of a wider fp32 table (the batched time_emb_proj output)
+    temb_d = dev(torch.cat([torch.zeros(B, 8), temb], 1).contiguous(), torch.float32)[:, 8:]
+    ops.conv3x3(dev(xcat), dev(w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous()), dev(bias, torch.float32),
+                rowbias=temb_d, residual=dev(res), out=big[:, 32:32 + Cout], out_scale=0.5)
+    check(big[:, 32:32 + Cout].reshape(B, H, W, Cout).permute(0, 3, 1, 2), ref, what="conv epilogue")
+    assert (big[:, :32] == 0).all() and (big[:, 32 + Cout:] == 0).all()
+
+
+@pytest.mark.parametrize("B,H,Sq,Skv,D", [(2, 4, 256, 256, 64), (1, 8, 1024, 1024, 64), (2, 5, 200, 77, 64),
+                                          (1, 8, 320, 320, 40), (1, 8, 128, 77, 80), (1, 8, 64, 64, 160),
+                                          (1, 2, 33, 130, 8), (1, 2, 4096, 4096, 64)])
+def test_sdpa(ops, B, H, Sq, Skv, D):
+    g = torch.Generator().manual_seed(Sq + Skv + D)
+    q = bfr(torch.randn(B, Sq, H, D, generator=g))
+    k = bfr(torch.randn(B, Skv, H, D, generator=g))
+    v = bfr(torch.randn(B, Skv, H, D, generator=g))
+    ref = U.sdpa_math(q, k, v)
+    out = ops.sdpa(dev(q), dev(k), dev(v))
+    check(out, ref, rel=5e-3, what=f"sdpa {B,H,Sq,Skv,D}")
+
+
+def test_sdpa_fused_qkv_strides_and_spike(ops):
+    """q/k/v consumed in place from a fused [rows, 3C] projection buffer; plus a spiked key that forces the
+    online-softmax rescale at a late tile (cdna guide 5.4 rule 26)."""
+    g = torch.Generator().manual_seed(21)
+    B, S, H, D = 2, 384, 4, 64
+    C = H * D
+    qkv = bfr(torch.randn(B, S, 3 * C, generator=g))
+    qkv[0, 300, C:2 * C] *= 12.0  # key row 300 of batch 0: large scores in tile 4
+    q, k, v = (qkv[..., i * C:(i + 1) * C].reshape(B, S, H, D) for i in range(3))
+    ref = U.sdpa_math(q, k, v)
+    d = dev(qkv)
+    qd, kd, vd = (d[..., i * C:(i + 1) * C].unflatten(-1, (H, D)) for i in range(3))
+    out = ops.sdpa(qd, kd, vd)
+    check(out, ref, rel=5e-3, what="sdpa fused qkv")
+
+
+def test_sdpa_additive_mask(ops):
+    """mask semantics of test_model_xattn_mask (tests/models/test_models_unet_2d_condition.py:486-515): keep-all ==
+    none; masking the last key == truncating it (bias = (1-m)*-10000, unet_2d_condition.py:921-927)."""
+    g = torch.Generator().manual_seed(31)
+    B, H, Sq, Skv, D = 2, 4, 96, 77, 64
+    q, k, v = (bfr(torch.randn(B, s, H, D, generator=g)) for s in (Sq, Skv, Skv))
+    qd, kd, vd = dev(q), dev(k), dev(v)
+    none = ops.sdpa(qd, kd, vd)
+    keep = ops.sdpa(qd, kd, vd, bias=torch.zeros(B, 1, 1, Skv, device="cuda"))
+    assert torch.equal(none, keep)
+    m = torch.ones(B, Skv)
+    m[:, -1] = 0
+    bias = ((1 - m) * -10000.0)[:, None, None, :]
+    masked = ops.sdpa(qd, kd, vd, bias=bias.cuda().contiguous())
+    trunc = ops.sdpa(qd, kd[:, :-1], vd[:, :-1])
+    assert torch.allclose(masked.float(), trunc.float(), rtol=1e-3, atol=1e-5)
+    full = torch.randn(B, H, Sq, Skv, generator=g)
+    ref = U.sdpa_math(q, k, v, attn_mask=full)
+    check(ops.sdpa(qd, kd, vd, bias=full.cuda()), ref, rel=5e-3, what="sdpa full bias")
+
+
+@pytest.mark.parametrize("B,HW,C,groups,pad,silu,eps", [(2, 256, 64, 32, 0, True, 1e-5), (1, 1024, 320, 32, 0, True, 1e-5),
+                                                        (2, 64, 960, 32, 64, True, 1e-5), (1, 100, 1280, 32, 0, False, 1e-6),
+                                                        (1, 4096, 2560, 32, 0, True, 1e-5)])
+def test_groupnorm(ops, B, HW, C, groups, pad, silu, eps):
+    g = torch.Generator().manual_seed(HW + C)
+    x = bfr(torch.randn(B, HW, C + pad, generator=g) * 1.5 + 0.3)
+    gamma, beta = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    xr = x[..., :C].permute(0, 2, 1).reshape(B, C, HW, 1)
+    ref = U.group_norm({"n.weight": gamma, "n.bias": beta}, "n", xr, groups, eps)
+    if silu:
+        ref = F.silu(ref)
+    out = ops.group_norm(dev(x)[..., :C], dev(gamma, torch.float32), dev(beta, torch.float32), groups, eps, silu)
+    check(out.permute(0, 2, 1).reshape(B, C, HW, 1), ref, what=f"groupnorm {B,HW,C}")
+
+
+@pytest.mark.parametrize("rows,C", [(300, 64), (1000, 640), (77, 1280), (16, 2560)])
+def test_layernorm(ops, rows, C):
+    g = torch.Generator().manual_seed(rows + C)
+    x = bfr(torch.randn(rows, C, generator=g) * 2 + 0.5)
+    gamma, beta = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    ref = U.layer_norm({"n.weight": gamma, "n.bias": beta}, "n", x)
+    out = ops.layer_norm(dev(x), dev(gamma, torch.float32), dev(beta, torch.float32))
+    check(out, ref, what=f"layernorm {rows,C}")
+
+
+def test_timestep_embedding_reference_vectors(ops):
+    """The reference's own hard-coded values (ppdiffusers/tests/models/test_layers_utils.py:90-115), atol 0.01."""
+    t = torch.arange(128, dtype=torch.float32, device="cuda")
+    t1 = ops.timestep_embedding(t, 64, downscale_freq_shift=1, flip_sin_to_cos=False).float().cpu()
+    t2 = ops.timestep_embedding(t, 64, downscale_freq_shift=0, flip_sin_to_cos=True).float().cpu()
+    t3 = ops.timestep_embedding(t, 64, scale=1000).float().cpu()
+    g1 = torch.tensor([0.9646, 0.9804, 0.9892, 0.9615, 0.9787, 0.9882, 0.9582, 0.9769, 0.9872])
+    g2 = torch.tensor([0.3019, 0.228, 0.1716, 0.3146, 0.2377, 0.179, 0.3272, 0.2474, 0.1864])
+    g3 = torch.tensor([-0.9801, -0.9464, -0.9349, -0.3952, 0.8887, -0.9709, 0.5299, -0.2853, -0.9927])
+    assert torch.allclose(t1[23:26, 47:50].flatten(), g1, atol=0.01)
+    assert torch.allclose(t2[23:26, 47:50].flatten(), g2, atol=0.01)
+    assert torch.allclose(t3[23:26, 47:50].flatten(), g3, atol=0.01)
+    ts = torch.tensor([981.0, 501.0, 1.0])
+    ref = U.get_timestep_embedding(ts, 320, True, 0)
+    out = ops.timestep_embedding(ts.cuda(), 320, flip_sin_to_cos=True, downscale_freq_shift=0).float().cpu()
+    assert (out - ref).abs().max() < 2 ** -8
+
+
+def test_conv_in_out_and_silu(ops):
+    g = torch.Generator().manual_seed(41)
+    B, H, W, C = 2, 16, 16, 64
+    x = torch.randn(B, 4, H, W, generator=g)
+    w = bfr(torch.randn(C, 4, 3, 3, generator=g) / 6)
+    b = torch.randn(C, generator=g) * 0.1
+    ref = F.conv2d(bfr(x * 0.5), w, b, padding=1)
+    out = ops.conv_in3x3(x.cuda(), dev(w.permute(2, 3, 1, 0).reshape(-1, C).contiguous()), dev(b, torch.float32),
+                         in_scale=torch.tensor([0.5], device="cuda"))
+    check(out.reshape(B, H, W, C).permute(0, 3, 1, 2), ref, what="conv_in")
+    y = bfr(torch.randn(B * H * W, C, generator=g))
+    w2 = bfr(torch.randn(4, C, 3, 3, generator=g) / math.sqrt(9 * C))
+    b2 = torch.randn(4, generator=g) * 0.1
+    ref2 = F.conv2d(y.reshape(B, H, W, C).permute(0, 3, 1, 2), w2, b2, padding=1)
+    out2 = ops.conv_out3x3(dev(y), dev(w2.permute(0, 2, 3, 1).reshape(4, -1).contiguous()), dev(b2, torch.float32), B, H, W)
+    assert out2.dtype == torch.float32
+    err = ((out2.cpu() - ref2).norm() / ref2.norm()).item()
+    assert err < 1e-5, err
+    s = ops.silu(dev(y))
+    check(s, F.silu(y), what="silu")
+    for v, e in ((-100.0, 0.0), (0.0, 0.0), (20.0, 20.0)):  # tests/models/test_activations.py:24-62
+        assert abs(ops.silu(torch.tensor([v], device="cuda"), torch.float32).item() - e) < 1e-4
+    c = torch.tensor([0.25, -1.5], device="cuda")
+    a_, b_ = torch.randn(1000, generator=g), torch.randn(1000, generator=g)
+    assert torch.allclose(ops.axpby(a_.cuda(), b_.cuda(), c).cpu(), 0.25 * a_ - 1.5 * b_, atol=1e-6)
+
+
+def test_errors_are_loud(ops):
+    from paddlemix_amd._lib import MI355XError
+    a = torch.zeros(8, 12, device="cuda", dtype=torch.bfloat16)
+    w = torch.zeros(16, 12, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(MI355XError, match="unsupported"):
+        ops.linear(a, w)  # K not a multiple of 8
+    with pytest.raises(MI355XError):
+        ops.linear(torch.zeros(8, 16, dtype=torch.bfloat16), torch.zeros(16, 16, dtype=torch.bfloat16))  # CPU tensors

@@ -1,0 +1,101 @@
+"""-m gpu whole-model parity: the HIP UNet2DConditionModel against the torch-CPU oracle on identical synthetic
+weights (bf16-representable) and inputs.  Stated tolerance for bf16 activations / fp32 accumulation: rel-L2 of the
+noise prediction <= 2e-2 per forward (the host-memory emulator, which has the same rounding points but fp32 math,
+sits at ~1e-2 against the same oracle; see DESIGN.md "Numerics").  Whole-UNet parity against real checkpoints is
+unpinned in this environment (no Paddle, no weights) -- see oracle/__init__.py."""
+import pytest
+import torch
+
+from oracle import unet_ref as U
+from tests.configs import MINI_XL, SD15, SDXL, TINY
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return ((a - b).norm() / b.norm()).item()
+
+
+def _inputs(cfg, B, H, W, L=77, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    sample = torch.randn(B, 4, H, W, generator=g)
+    enc = torch.randn(B, L, cfg["cross_attention_dim"], generator=g)
+    added = None
+    if cfg.get("addition_embed_type") == "text_time":
+        td = cfg["projection_class_embeddings_input_dim"] - 6 * cfg["addition_time_embed_dim"]
+        added = dict(text_embeds=torch.randn(B, td, generator=g),
+                     time_ids=torch.tensor([[1024., 1024., 0., 0., 1024., 1024.]]).repeat(B, 1))
+    return sample, enc, added
+
+
+def _cuda(x):
+    if x is None:
+        return None
+    if isinstance(x, dict):
+        return {k: v.cuda() for k, v in x.items()}
+    return x.cuda()
+
+
+def _bf16_params(cfg, device):
+    from paddlemix_amd.unet import synth_unet_params
+    P = synth_unet_params(cfg, seed=1234, device=device)
+    for k, v in P.items():
+        if v.dim() > 1:
+            P[k] = v.to(torch.bfloat16).float()
+    return P
+
+
+@pytest.mark.parametrize("name,cfg,B,H,W,L", [("tiny", TINY, 2, 16, 16, 7), ("tiny-ragged", TINY, 1, 8, 24, 5),
+                                              ("mini-xl", MINI_XL, 2, 32, 32, 77)])
+def test_small_unet_vs_oracle(name, cfg, B, H, W, L):
+    from paddlemix_amd.unet import UNet2DConditionModel
+    P = _bf16_params(cfg, "cpu")
+    sample, enc, added = _inputs(cfg, B, H, W, L)
+    ref = U.unet_forward(P, cfg, sample, 501, enc, added_cond_kwargs=added)
+    model = UNet2DConditionModel(cfg, P, use_graph=False)
+    out = model(_cuda(sample), 501, _cuda(enc), added_cond_kwargs=_cuda(added), return_dict=False)[0]
+    assert out.is_cuda and out.dtype == torch.float32 and out.shape == ref.shape
+    r = _rel(out.cpu(), ref)
+    print(f"{name}: rel-L2 vs oracle {r:.3e}")
+    assert r < 2e-2, r
+    # hipGraph replay == eager launches, bit for bit; and deterministic (reference test_determinism, 5e-4)
+    gmodel = UNet2DConditionModel(cfg, P, use_graph=True)
+    o1 = gmodel(_cuda(sample), 501, _cuda(enc), added_cond_kwargs=_cuda(added)).sample
+    o2 = gmodel(_cuda(sample), 501, _cuda(enc), added_cond_kwargs=_cuda(added)).sample
+    assert torch.equal(o1, out) and torch.equal(o1, o2)
+    # a different timestep through the captured graph must change the result (inputs are re-staged, not baked in)
+    o3 = gmodel(_cuda(sample), 21, _cuda(enc), added_cond_kwargs=_cuda(added)).sample
+    ref3 = U.unet_forward(P, cfg, sample, 21, enc, added_cond_kwargs=added)
+    assert _rel(o3.cpu(), ref3) < 2e-2 and not torch.equal(o3, o1)
+
+
+@pytest.mark.parametrize("name,cfg,B,H,W", [("sd15-arch", SD15, 1, 32, 32), ("sdxl-arch", SDXL, 1, 32, 32)])
+def test_real_architectures_reduced_resolution(name, cfg, B, H, W):
+    """Full SD-1.5 / SDXL parameter sets (0.86 B / 2.57 B params), latent reduced so the CPU oracle finishes in seconds."""
+    from paddlemix_amd.unet import UNet2DConditionModel
+    Pd = _bf16_params(cfg, "cuda")
+    model = UNet2DConditionModel(cfg, Pd, use_graph=True)
+    P = {k: v.cpu() for k, v in Pd.items()}
+    del Pd
+    torch.cuda.empty_cache()
+    sample, enc, added = _inputs(cfg, B, H, W)
+    ref = U.unet_forward(P, cfg, sample, 301, enc, added_cond_kwargs=added)
+    out = model(_cuda(sample), 301, _cuda(enc), added_cond_kwargs=_cuda(added)).sample
+    r = _rel(out.cpu(), ref)
+    print(f"{name}: rel-L2 vs oracle {r:.3e}")
+    assert torch.isfinite(out).all() and r < 2e-2, r
+
+
+def test_batch_independence_full_width():
+    """Reference property test_inference_batch_single_identical (tests/pipelines/test_pipelines_common.py:478, 1e-2):
+    the prompts of a batch do not interact -- what makes sharding prompts over GPUs exact."""
+    from paddlemix_amd.unet import UNet2DConditionModel
+    cfg = MINI_XL
+    P = _bf16_params(cfg, "cuda")
+    model = UNet2DConditionModel(cfg, P, use_graph=False)
+    sample, enc, added = _inputs(cfg, 4, 32, 32)
+    full = model(_cuda(sample), 77, _cuda(enc), added_cond_kwargs=_cuda(added)).sample
+    for i in range(4):
+        one = model(_cuda(sample[i:i + 1]), 77, _cuda(enc[i:i + 1]),
+                    added_cond_kwargs={k: v[i:i + 1].cuda() for k, v in added.items()}).sample
+        assert torch.allclose(one, full[i:i + 1], atol=1e-5, rtol=1e-5), (one - full[i:i + 1]).abs().max()

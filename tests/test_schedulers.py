@@ -1,0 +1,110 @@
+"""The product schedulers (paddlemix_amd/schedulers.py) against the reference's own RNG-free golden values
+(ppdiffusers/tests/schedulers/test_scheduler_ddim.py:68,121-190, test_scheduler_euler.py:84-163, fixtures
+test_schedulers.py:261-303) and against the numpy oracle; plus the linear-update form used by the HIP axpby path."""
+import numpy as np
+import torch
+
+from oracle import schedulers_ref as S
+from paddlemix_amd.schedulers import DDIMScheduler, EulerDiscreteScheduler, FlowMatchEulerDiscreteScheduler
+
+
+def dummy_sample_deter():
+    n = 4 * 3 * 8 * 8
+    return torch.arange(n, dtype=torch.float32).reshape(3, 8, 8, 4).div(n).permute(3, 0, 1, 2).contiguous()
+
+
+def dummy_noise_deter():
+    n = 4 * 3 * 8 * 8
+    return torch.arange(n, dtype=torch.float32).flip(0).reshape(3, 8, 8, 4).div(n).permute(3, 0, 1, 2).contiguous()
+
+
+def dummy_model(sample, t):
+    t = float(t)
+    return sample * np.float32(t) / np.float32(t + 1)
+
+
+DDIM_CFG = dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear", clip_sample=True)
+EULER_CFG = dict(num_train_timesteps=1100, beta_start=0.0001, beta_end=0.02, beta_schedule="linear")
+
+
+def test_ddim_golden():
+    sch = DDIMScheduler(**dict(DDIM_CFG, steps_offset=1))
+    sch.set_timesteps(5)
+    assert list(sch.timesteps) == [801, 601, 401, 201, 1]
+    sch = DDIMScheduler(**DDIM_CFG)
+    for (a, b), v in {(0, 0): 0.0, (420, 400): 0.14771, (980, 960): 0.32460, (487, 486): 0.00979, (999, 998): 0.02}.items():
+        assert abs(float(sch._get_variance(a, b)) - v) < 1e-5
+    for kw, (gs, gm) in [({}, (172.0067, 0.223967)), ({"prediction_type": "v_prediction"}, (52.5302, 0.0684)),
+                         ({"set_alpha_to_one": True, "beta_start": 0.01}, (149.8295, 0.1951)),
+                         ({"set_alpha_to_one": False, "beta_start": 0.01}, (149.0784, 0.1941))]:
+        sch = DDIMScheduler(**dict(DDIM_CFG, **kw))
+        sch.set_timesteps(10)
+        x = dummy_sample_deter()
+        for t in sch.timesteps:
+            x = sch.step(dummy_model(x, t), t, x, 0.0).prev_sample
+        assert abs(x.abs().sum().item() - gs) < 1e-2 and abs(x.abs().mean().item() - gm) < 1e-3, kw
+    sch = DDIMScheduler(**DDIM_CFG)
+    sch.set_timesteps(10)
+    ts = sch.timesteps[8:]
+    x = sch.add_noise(dummy_sample_deter(), dummy_noise_deter(), torch.as_tensor(ts[:1]))
+    for t in ts:
+        x = sch.step(dummy_model(x, t), t, x, 0.0).prev_sample
+    assert abs(x.abs().sum().item() - 354.5418) < 1e-2 and abs(x.abs().mean().item() - 0.4616) < 1e-3
+
+
+def test_euler_golden():
+    for kw, (gs, gm) in [({}, (10.0807, 0.0131)), ({"prediction_type": "v_prediction"}, (0.0002, 2.2676e-06)),
+                         ({"use_karras_sigmas": True}, (124.52299499511719, 0.16213932633399963))]:
+        sch = EulerDiscreteScheduler(**dict(EULER_CFG, **kw))
+        sch.set_timesteps(10)
+        x = dummy_sample_deter() * sch.init_noise_sigma
+        for t in sch.timesteps:
+            x = sch.scale_model_input(x, t)
+            x = sch.step(dummy_model(x, t), t, x, return_dict=False)[0]
+        assert abs(x.abs().sum().item() - gs) < 1e-2 and abs(x.abs().mean().item() - gm) < 1e-3, kw
+
+
+def test_tables_match_oracle_and_linear_update():
+    # SDXL bench schedule (tests/pipelines/stable_diffusion_xl/test_stable_diffusion_xl.py:84-90 parameters)
+    kw = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", timestep_spacing="leading", steps_offset=1)
+    a, b = EulerDiscreteScheduler(**kw), S.EulerRef(**kw)
+    a.set_timesteps(30)
+    b.set_timesteps(30)
+    assert np.array_equal(a.timesteps, b.timesteps) and np.allclose(a.sigmas, b.sigmas, rtol=1e-6)
+    assert abs(a.init_noise_sigma - b.init_noise_sigma) < 1e-5
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 4, 8, 8, generator=g) * a.init_noise_sigma
+    x_lin = x.clone()
+    lin = EulerDiscreteScheduler(**kw)
+    lin.set_timesteps(30)
+    for t in a.timesteps:
+        eps = torch.randn(x.shape, generator=g)
+        x = a.step(eps, t, x).prev_sample
+        ca, cb = lin.step_coefficients(t)
+        x_lin = ca * x_lin + cb * eps
+    assert torch.allclose(x, x_lin, rtol=1e-5, atol=1e-5)
+    kw = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", steps_offset=1, clip_sample=False,
+              set_alpha_to_one=False)
+    d, dr = DDIMScheduler(**kw), S.DDIMRef(**kw)
+    d.set_timesteps(20)
+    dr.set_timesteps(20)
+    assert list(d.timesteps) == list(dr.timesteps)
+    x = torch.randn(1, 4, 8, 8, generator=g)
+    for t in d.timesteps[:5]:
+        eps = torch.randn(x.shape, generator=g)
+        ref = torch.from_numpy(dr.step(eps.numpy(), t, x.numpy()))
+        ca, cb = d.step_coefficients(t)
+        assert torch.allclose(d.step(eps, t, x).prev_sample, ref, atol=1e-5)
+        assert torch.allclose(ca * x + cb * eps, ref, atol=1e-5)
+        x = ref
+
+
+def test_flow_match_matches_oracle():
+    a, b = FlowMatchEulerDiscreteScheduler(shift=3.0), S.FlowMatchEulerRef(shift=3.0)
+    a.set_timesteps(28)
+    b.set_timesteps(28)
+    assert np.allclose(a.timesteps, b.timesteps) and np.allclose(a.sigmas, b.sigmas)
+    x = torch.ones(1, 16, 4, 4)
+    v = torch.full_like(x, 0.5)
+    t = a.timesteps[0]
+    assert torch.allclose(a.step(v, t, x).prev_sample, torch.from_numpy(b.step(v.numpy(), t, x.numpy())))
