@@ -40,17 +40,13 @@ static GnGeom gn_geom(int HW, int C) {
 
 __global__ void gn_partial_kernel(const bf16* __restrict__ x, int HW, int C, int ldx, int groups, int cv, int ppp,
                                   int nthreads, int ppb, float* __restrict__ partial) {
-  __shared__ float ch_sum[GN_MAXC];
-  __shared__ float ch_sq[GN_MAXC];
-  __shared__ float g_acc[2 * 64];
+  // Deterministic (fixed-order) reduction: per-thread channel partials -> LDS -> per-channel -> per-group.
+  extern __shared__ __attribute__((aligned(16))) float gsm[];
+  float* t_sum = gsm;                       // [ppp][C]
+  float* t_sq = gsm + (size_t)ppp * C;      // [ppp][C]
+  float* ch = t_sq + (size_t)ppp * C;       // [2][C]
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
-  for (int i = tid; i < C; i += blockDim.x) {
-    ch_sum[i] = 0.f;
-    ch_sq[i] = 0.f;
-  }
-  if (tid < 2 * groups) g_acc[tid] = 0.f;
-  __syncthreads();
   if (tid < nthreads) {
     const int cc = tid % cv, pl = tid / cv;
     const int p_begin = blockIdx.x * ppb;
@@ -69,20 +65,35 @@ __global__ void gn_partial_kernel(const bf16* __restrict__ x, int HW, int C, int
         q[j] = __builtin_fmaf(f, f, q[j]);
       }
     }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      atomicAdd(&ch_sum[cc * 8 + j], s[j]);
-      atomicAdd(&ch_sq[cc * 8 + j], q[j]);
+    float* ts = t_sum + (size_t)pl * C + cc * 8;
+    float* tq = t_sq + (size_t)pl * C + cc * 8;
+    *reinterpret_cast<f32x4*>(ts) = f32x4{s[0], s[1], s[2], s[3]};
+    *reinterpret_cast<f32x4*>(ts + 4) = f32x4{s[4], s[5], s[6], s[7]};
+    *reinterpret_cast<f32x4*>(tq) = f32x4{q[0], q[1], q[2], q[3]};
+    *reinterpret_cast<f32x4*>(tq + 4) = f32x4{q[4], q[5], q[6], q[7]};
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += blockDim.x) {
+    float a = 0.f, d = 0.f;
+    for (int pl = 0; pl < ppp; ++pl) {
+      a += t_sum[(size_t)pl * C + c];
+      d += t_sq[(size_t)pl * C + c];
     }
+    ch[c] = a;
+    ch[C + c] = d;
   }
   __syncthreads();
   const int cpg = C / groups;
-  for (int c = tid; c < C; c += blockDim.x) {
-    atomicAdd(&g_acc[2 * (c / cpg)], ch_sum[c]);
-    atomicAdd(&g_acc[2 * (c / cpg) + 1], ch_sq[c]);
+  if (tid < groups) {
+    float a = 0.f, d = 0.f;
+    for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+      a += ch[c];
+      d += ch[C + c];
+    }
+    float* pp = partial + ((size_t)b * gridDim.x + blockIdx.x) * 2 * groups;
+    pp[2 * tid] = a;
+    pp[2 * tid + 1] = d;
   }
-  __syncthreads();
-  if (tid < 2 * groups) partial[((size_t)b * gridDim.x + blockIdx.x) * 2 * groups + tid] = g_acc[tid];
 }
 
 __global__ void gn_finalize_kernel(const float* __restrict__ partial, int nblk, int HW, int C, int groups, float eps,
@@ -127,8 +138,9 @@ int launch_groupnorm_stats(const bf16* x, int B, int HW, int C, int ldx, int gro
   if ((C & 7) || (ldx & 7) || C > GN_MAXC || groups <= 0 || groups > 64 || C % groups) return SD_ERR_UNSUPPORTED;
   const GnGeom g = gn_geom(HW, C);
   if (g.block > 1024) return SD_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(gn_partial_kernel, dim3(g.nblk, B), dim3(g.block), 0, stream, x, HW, C, ldx, groups, g.cv, g.ppp,
-                     g.threads, g.ppb, partial);
+  const size_t lds = (size_t)(2 * g.ppp + 2) * C * sizeof(float);
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(g.nblk, B), dim3(g.block), lds, stream, x, HW, C, ldx, groups, g.cv,
+                     g.ppp, g.threads, g.ppb, partial);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, stream, partial, g.nblk, HW, C, groups, eps, gamma,
                      beta, scale_shift);
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
