@@ -17,6 +17,9 @@
 // XOR-swizzled 16-B chunks so ds_read_b128 fragment reads are bank-conflict free), the next tile's global
 // loads are in flight while the current tile is multiplied. The MFMA is issued "swapped" (W as the row
 // operand) so that every lane ends up with 4 consecutive output channels of one row -> 8-byte stores.
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -25,7 +28,17 @@ namespace sd {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int GEMM_THREADS = 256;
 
-template <bool CONV>
+// 16 zero bytes: the source of every out-of-range chunk of the LDS-DMA loader (M/N/K tails, conv zero padding)
+__device__ __attribute__((aligned(16))) const unsigned g_zero16[4] = {0u, 0u, 0u, 0u};
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// GLDS = true : operands go HBM -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave instruction, no staging
+//               VGPRs, no ds_write pass); the XOR swizzle is applied on the per-lane SOURCE address because the
+//               LDS destination of an LDS-DMA is lane-linear.
+// GLDS = false: register-staged loader (kept as the A/B baseline; MI355X_SD_GEMM=regs selects it).
+template <bool CONV, bool GLDS>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (BM + BN) * BK * 2];
   unsigned char* As = smem;                       // [2][BM][BK] bf16, swizzled
@@ -120,6 +133,78 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmAr
     }
   };
 
+  // ---- LDS-DMA loader geometry: wave w fills 1-KiB pieces 4w..4w+3 (8 rows x 128 B each) of A and of W ----
+  const int g_sub = lane >> 3;                 // row inside a piece == (row & 7)
+  const int g_cg = (lane & 7) ^ g_sub;         // global 16-B chunk this lane fetches (source-side swizzle)
+  const bf16* ga_base[4];
+  bool ga_ok[4];
+  int goy[4], gox[4];
+  const bf16* gw_base[4];
+  bool gw_ok[4];
+  int gtap = 0, gcch = g_cg * 8;
+  if (GLDS) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wave * 32 + i * 8 + g_sub;
+      const int m = m0 + row;
+      ga_ok[i] = m < p.M;
+      if (CONV) {
+        const int hw = p.Ho * p.Wo;
+        const int mm = ga_ok[i] ? m : 0;
+        const int b = mm / hw;
+        const int rem = mm - b * hw;
+        goy[i] = rem / p.Wo;
+        gox[i] = rem - goy[i] * p.Wo;
+        ga_base[i] = p.A + (size_t)b * p.Hs * p.Ws * p.lda;
+      } else {
+        ga_base[i] = p.A + (size_t)(ga_ok[i] ? m : 0) * p.lda + g_cg * 8;
+        goy[i] = gox[i] = 0;
+      }
+      const int n = n0 + row;
+      gw_ok[i] = n < p.N;
+      gw_base[i] = p.W + (size_t)(gw_ok[i] ? n : 0) * p.K + g_cg * 8;
+    }
+    if (CONV) {
+      gtap = gcch / p.Cin;
+      gcch -= gtap * p.Cin;
+    }
+  }
+  auto issue_tile = [&](int k0, int buf) {
+    const bool k_ok = (k0 + g_cg * 8) < p.K;
+    unsigned char* a = As + buf * (BM * BK * 2) + wave * 4096;
+    unsigned char* w = Ws + buf * (BN * BK * 2) + wave * 4096;
+    const bf16* zsrc = reinterpret_cast<const bf16*>(g_zero16);
+    if (CONV) {
+      const int ky = gtap / 3, kx = gtap - ky * 3;
+      const int Hin = p.Hs << p.up, Win = p.Ws << p.up;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int iy = goy[i] * p.stride + ky - 1;
+        const int ix = gox[i] * p.stride + kx - 1;
+        const bool ok = ga_ok[i] && k_ok && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
+        const size_t off = ((size_t)(iy >> p.up) * p.Ws + (ix >> p.up)) * p.lda + gcch;
+        const bf16* src = ok ? ga_base[i] + off : zsrc;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(a + i * 1024), 16, 0, 0);
+      }
+      gcch += BK;
+      while (gcch >= p.Cin) {
+        gcch -= p.Cin;
+        ++gtap;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bf16* src = (ga_ok[i] && k_ok) ? ga_base[i] + k0 : zsrc;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(a + i * 1024), 16, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bf16* src = (gw_ok[i] && k_ok) ? gw_base[i] + k0 : zsrc;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(w + i * 1024), 16, 0, 0);
+    }
+  };
+
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -134,13 +219,22 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmAr
   const int rsw = frow & 7;
 
   const int nt = (p.K + BK - 1) / BK;
-  load_tile(0);
-  store_tile(0);
+  if (GLDS) {
+    issue_tile(0, 0);
+  } else {
+    load_tile(0);
+    store_tile(0);
+  }
   __syncthreads();
 
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
-    if (t + 1 < nt) load_tile((t + 1) * BK);
+    if (t + 1 < nt) {
+      if (GLDS)
+        issue_tile((t + 1) * BK, buf ^ 1);
+      else
+        load_tile((t + 1) * BK);
+    }
     const unsigned char* a = As + buf * (BM * BK * 2);
     const unsigned char* w = Ws + buf * (BN * BK * 2);
 #pragma unroll
@@ -158,7 +252,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmAr
         for (int tm = 0; tm < 4; ++tm)
           acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[tn], fa[tm], acc[tn][tm], 0, 0, 0);
     }
-    if (t + 1 < nt) store_tile(buf ^ 1);
+    if (!GLDS && t + 1 < nt) store_tile(buf ^ 1);
     __syncthreads();
   }
 
@@ -235,10 +329,21 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   if (a.rowbias && a.rows_per_batch <= 0) return SD_ERR_INVALID;
   const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
   dim3 grid(ntm * ntn), block(GEMM_THREADS);
-  if (a.conv)
-    hipLaunchKernelGGL(gemm_bf16_kernel<true>, grid, block, 0, stream, a);
-  else
-    hipLaunchKernelGGL(gemm_bf16_kernel<false>, grid, block, 0, stream, a);
+  static const bool use_regs = [] {
+    const char* e = getenv("MI355X_SD_GEMM");
+    return e && strcmp(e, "regs") == 0;
+  }();
+  if (use_regs) {
+    if (a.conv)
+      hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, 0, stream, a);
+    else
+      hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, 0, stream, a);
+  } else {
+    if (a.conv)
+      hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, stream, a);
+    else
+      hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, 0, stream, a);
+  }
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
 

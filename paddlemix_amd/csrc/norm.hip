@@ -100,14 +100,29 @@ __global__ void gn_finalize_kernel(const float* __restrict__ partial, int nblk, 
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ scale_shift) {
   __shared__ float mean_s[64], rstd_s[64];
+  __shared__ double part_s[64][8], part_q[64][8];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int cpg = C / groups;
+  {
+    // 8 threads per group, each a fixed strided subset of the block partials (deterministic order)
+    const int g = tid >> 3, j = tid & 7;
+    if (g < groups) {
+      double s = 0.0, q = 0.0;
+      const float* pp = partial + (size_t)b * nblk * 2 * groups + 2 * g;
+      for (int i = j; i < nblk; i += 8) {
+        s += (double)pp[(size_t)i * 2 * groups];
+        q += (double)pp[(size_t)i * 2 * groups + 1];
+      }
+      part_s[g][j] = s;
+      part_q[g][j] = q;
+    }
+  }
+  __syncthreads();
   if (tid < groups) {
     double s = 0.0, q = 0.0;
-    const float* pp = partial + (size_t)b * nblk * 2 * groups + 2 * tid;
-    for (int i = 0; i < nblk; ++i) {
-      s += (double)pp[(size_t)i * 2 * groups];
-      q += (double)pp[(size_t)i * 2 * groups + 1];
+    for (int j = 0; j < 8; ++j) {
+      s += part_s[tid][j];
+      q += part_q[tid][j];
     }
     const double n = (double)HW * cpg;
     const double mean = s / n;
@@ -141,7 +156,7 @@ int launch_groupnorm_stats(const bf16* x, int B, int HW, int C, int ldx, int gro
   const size_t lds = (size_t)(2 * g.ppp + 2) * C * sizeof(float);
   hipLaunchKernelGGL(gn_partial_kernel, dim3(g.nblk, B), dim3(g.block), lds, stream, x, HW, C, ldx, groups, g.cv,
                      g.ppp, g.threads, g.ppb, partial);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, stream, partial, g.nblk, HW, C, groups, eps, gamma,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(512), 0, stream, partial, g.nblk, HW, C, groups, eps, gamma,
                      beta, scale_shift);
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
@@ -191,62 +206,88 @@ int launch_scale_shift_act(const bf16* x, int B, int HW, int C, int ldx, const f
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
 
-// LayerNorm: one wave per row, row kept in registers (C <= 64*8*LN_MAXCH), exact two-pass statistics.
-constexpr int LN_MAXCH = 5;  // C <= 2560
-__global__ void layernorm_kernel(const bf16* __restrict__ x, int rows, int C, int ldx, const float* __restrict__ gamma,
+// LayerNorm: a wave owns ROWS rows at once (all loads issued up front, the ROWS reduction chains interleave),
+// rows live in registers; statistics in one pass over data shifted by the row's first element
+// (sum(x-K), sum((x-K)^2): no cancellation for the O(1..10) activations here), fp32.
+template <int NCH, int ROWS>
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16* __restrict__ x, int rows, int C, int ldx, const float* __restrict__ gamma,
                                  const float* __restrict__ beta, float eps, bf16* __restrict__ y, int ldy) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  const int row0 = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * ROWS;
+  if (row0 >= rows) return;
   const int cv = C >> 3;
-  const bf16* xr = x + (size_t)row * ldx;
-  float v[LN_MAXCH][8];
-  float s = 0.f;
+  float v[ROWS][NCH][8];
 #pragma unroll
-  for (int i = 0; i < LN_MAXCH; ++i) {
-    const int cc = lane + 64 * i;
-    if (cc < cv) {
-      const u32x4 raw = *reinterpret_cast<const u32x4*>(xr + cc * 8);
+  for (int r = 0; r < ROWS; ++r) {
+    const int row = min(row0 + r, rows - 1);
+    const bf16* xr = x + (size_t)row * ldx;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int cc = lane + 64 * i;
+      u32x4 raw = {0u, 0u, 0u, 0u};
+      if (cc < cv) raw = *reinterpret_cast<const u32x4*>(xr + cc * 8);
       const bf16x8 t = *reinterpret_cast<const bf16x8*>(&raw);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        v[i][j] = (float)t[j];
-        s += v[i][j];
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+      for (int j = 0; j < 8; ++j) v[r][i][j] = (float)t[j];
     }
   }
-  const float mean = wave_sum(s) / (float)C;
-  float q = 0.f;
+  float mean[ROWS], rstd[ROWS];
+  float s1[ROWS], s2[ROWS];
 #pragma unroll
-  for (int i = 0; i < LN_MAXCH; ++i) {
-    const int cc = lane + 64 * i;
-    if (cc < cv) {
+  for (int r = 0; r < ROWS; ++r) {
+    const float K = __shfl(v[r][0][0], 0, 64);
+    float a = 0.f, q = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float d = v[i][j] - mean;
-        q = __builtin_fmaf(d, d, q);
+    for (int i = 0; i < NCH; ++i) {
+      if (lane + 64 * i < cv) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float d = v[r][i][j] - K;
+          a += d;
+          q = __builtin_fmaf(d, d, q);
+        }
       }
     }
+    s1[r] = a;
+    s2[r] = q;
+    mean[r] = K;
   }
-  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
-  bf16* yr = y + (size_t)row * ldy;
 #pragma unroll
-  for (int i = 0; i < LN_MAXCH; ++i) {
+  for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      s1[r] += __shfl_xor(s1[r], o, 64);
+      s2[r] += __shfl_xor(s2[r], o, 64);
+    }
+  }
+  const float invC = 1.0f / (float)C;
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    const float m = s1[r] * invC;
+    const float var = fmaxf(s2[r] * invC - m * m, 0.f);
+    mean[r] += m;
+    rstd[r] = rsqrtf(var + eps);
+  }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
     const int cc = lane + 64 * i;
     if (cc < cv) {
-      float o[8];
+      float g[8], bt[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        float t = (v[i][j] - mean) * rstd;
-        if (gamma) t *= gamma[cc * 8 + j];
-        if (beta) t += beta[cc * 8 + j];
-        o[j] = t;
+        g[j] = gamma ? gamma[cc * 8 + j] : 1.f;
+        bt[j] = beta ? beta[cc * 8 + j] : 0.f;
       }
-      u32x4 pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7])};
-      *reinterpret_cast<u32x4*>(yr + cc * 8) = pk;
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) {
+        if (row0 + r < rows) {
+          float o[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = __builtin_fmaf((v[r][i][j] - mean[r]) * rstd[r], g[j], bt[j]);
+          u32x4 pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7])};
+          *reinterpret_cast<u32x4*>(y + (size_t)(row0 + r) * ldy + cc * 8) = pk;
+        }
+      }
     }
   }
 }
@@ -254,10 +295,22 @@ __global__ void layernorm_kernel(const bf16* __restrict__ x, int rows, int C, in
 int launch_layernorm(const bf16* x, int rows, int C, int ldx, const float* gamma, const float* beta, float eps, bf16* y,
                      int ldy, hipStream_t stream) {
   if (rows <= 0 || C <= 0) return SD_ERR_INVALID;
-  if ((C & 7) || (ldx & 7) || (ldy & 7) || C > 64 * 8 * LN_MAXCH) return SD_ERR_UNSUPPORTED;
+  if ((C & 7) || (ldx & 7) || (ldy & 7) || C > 2560) return SD_ERR_UNSUPPORTED;
   const int wpb = 4;
-  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + wpb - 1) / wpb), dim3(64 * wpb), 0, stream, x, rows, C, ldx, gamma,
-                     beta, eps, y, ldy);
+  const int cv = C >> 3;
+  if (cv <= 128) {
+    const int rpb = wpb * 4;
+    hipLaunchKernelGGL((layernorm_kernel<2, 4>), dim3((rows + rpb - 1) / rpb), dim3(64 * wpb), 0, stream, x, rows, C,
+                       ldx, gamma, beta, eps, y, ldy);
+  } else if (cv <= 192) {
+    const int rpb = wpb * 4;
+    hipLaunchKernelGGL((layernorm_kernel<3, 4>), dim3((rows + rpb - 1) / rpb), dim3(64 * wpb), 0, stream, x, rows, C,
+                       ldx, gamma, beta, eps, y, ldy);
+  } else {
+    const int rpb = wpb * 2;
+    hipLaunchKernelGGL((layernorm_kernel<5, 2>), dim3((rows + rpb - 1) / rpb), dim3(64 * wpb), 0, stream, x, rows, C,
+                       ldx, gamma, beta, eps, y, ldy);
+  }
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
 
