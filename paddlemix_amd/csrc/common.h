@@ -50,6 +50,20 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return base + idx;
 }
 
+// Logical tile id -> (tile_m, tile_n), "grouped" order: ids sweep GM row-tiles first, then the column, so the
+// tiles an XCD runs concurrently (a contiguous id range after xcd_remap) form a compact 2-D patch that shares
+// A row-panels and W column-panels in that XCD's L2.
+__device__ __forceinline__ void tile_coords(int lid, int ntm, int ntn, int& tile_m, int& tile_n) {
+  constexpr int GM = 8;
+  const int per_group = GM * ntn;
+  const int g = lid / per_group;
+  const int first_m = g * GM;
+  const int gsz = min(ntm - first_m, GM);
+  const int r = lid - g * per_group;
+  tile_n = r / gsz;
+  tile_m = first_m + (r - tile_n * gsz);
+}
+
 }  // namespace sd
 
 // status codes of the C ABI (include/mi355x_sd.h)

@@ -26,16 +26,12 @@
 #include <string.h>
 
 #include "common.h"
+#include "gemm_epilogue.h"
 #include "kernels.h"
 
 namespace sd {
 
 constexpr int BK = 64;
-
-__device__ __attribute__((aligned(16))) const unsigned g_zero16[4] = {0u, 0u, 0u, 0u};
-
-typedef __attribute__((address_space(1))) const void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int WAVES_M_, int WAVES_N_, int TM_, int TN_>
 struct GemmCfg {
@@ -68,7 +64,8 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_bf16_kernel(const GemmAr
   const int ntn = (p.N + BN - 1) / BN;
   const int ntm = (p.M + BM - 1) / BM;
   const int lid = xcd_remap(blockIdx.x, ntm * ntn);
-  const int tile_m = lid / ntn, tile_n = lid - tile_m * ntn;
+  int tile_m, tile_n;
+  tile_coords(lid, ntm, ntn, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // ---- LDS-DMA loader geometry: wave w fills pieces w*PIECES .. of A and of W (piece = 8 rows x 128 B) ----
@@ -183,62 +180,7 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_bf16_kernel(const GemmAr
     __syncthreads();
   }
 
-  // ---- epilogue: lane holds, for row m = .. + (lane&15), channels n = .. + (lane>>4)*4 + {0..3} ----
-  const int m_wave = m0 + wm * (TM * 16), n_wave = n0 + wn * (TN * 16);
-  const int nq = (lane >> 4) * 4;
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm) {
-    const int m = m_wave + tm * 16 + (lane & 15);
-    if (m >= p.M) continue;
-    const float* rb = p.rowbias ? p.rowbias + (size_t)(m / p.rows_per_batch) * p.ld_rowbias : nullptr;
-    if (p.geglu) {
-#pragma unroll
-      for (int tp = 0; tp < TN / 2; ++tp) {
-        const int n_phys = n_wave + tp * 32 + nq;  // physical (interleaved) column of the value half
-        if (n_phys >= p.N) continue;               // N % 32 == 0: the gate half of the pair is inside too
-        f32x4 h = acc[2 * tp][tm], g = acc[2 * tp + 1][tm];
-        if (p.bias) {
-          h += *reinterpret_cast<const f32x4*>(p.bias + n_phys);
-          g += *reinterpret_cast<const f32x4*>(p.bias + n_phys + 16);
-        }
-        const int n_out = (n_wave >> 1) + tp * 16 + nq;
-        float o[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = h[r] * gelu_erf_f(g[r]);
-        u32x2 pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3])};
-        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n_out) = pk;
-      }
-    } else {
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        const int n = n_wave + tn * 16 + nq;
-        if (n >= p.N) continue;
-        f32x4 v = acc[tn][tm];
-        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-        if (rb) v += *reinterpret_cast<const f32x4*>(rb + n);
-        if (p.R) {
-          const bf16x4 r4 = *reinterpret_cast<const bf16x4*>(p.R + (size_t)m * p.ldr + n);
-          v[0] += (float)r4[0];
-          v[1] += (float)r4[1];
-          v[2] += (float)r4[2];
-          v[3] += (float)r4[3];
-        }
-        v *= p.out_scale;
-        if (p.silu) {
-          v[0] = silu_f(v[0]);
-          v[1] = silu_f(v[1]);
-          v[2] = silu_f(v[2]);
-          v[3] = silu_f(v[3]);
-        }
-        if (p.out_f32) {
-          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = v;
-        } else {
-          u32x2 pk = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
-          *reinterpret_cast<u32x2*>(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n) = pk;
-        }
-      }
-    }
-  }
+  gemm_epilogue<TM, TN>(p, acc, m0 + wm * (TM * 16), n0 + wn * (TN * 16), lane);
 }
 
 template <bool CONV, class CFG>
@@ -260,12 +202,15 @@ static int pick_tile(const GemmArgs& a) {
     const char* e = getenv("MI355X_SD_GEMM_TILE");
     return e ? atoi(e) : 0;
   }();
-  if (forced == 128 || forced == 256) return forced;
+  if (forced == 128 || forced == 256 || forced == 257) return forced;   // 257: the phased 256x256 kernel
   if (a.M < 256 || a.N < 256) return 128;
   const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
   const long waste256 = t256 * 256 * 256 - (long)a.M * a.N;   // padded area of ragged edge tiles
   if (waste256 * 8 > (long)a.M * a.N) return 128;              // > 12.5 % of the tile area would be padding
-  return t256 >= 128 ? 256 : 128;
+  // measured on MI355X (profiles/r01_gemm_tiles.txt): the phased 256x256 kernel wins once every CU has a tile
+  // and the K loop is long enough to amortise its 7-half-tile prologue; otherwise 2 x 128x128 blocks per CU win.
+  if (t256 >= 256 || (t256 >= 128 && a.K >= 2048)) return 257;
+  return 128;
 }
 
 int launch_gemm(const GemmArgs& a, hipStream_t stream) {
@@ -280,6 +225,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   }
   if (a.rowbias && a.rows_per_batch <= 0) return SD_ERR_INVALID;
   const int tile = pick_tile(a);
+  if (tile == 257) return launch_gemm256(a, stream);
   if (tile == 256) return a.conv ? launch_cfg<true, Cfg256>(a, stream) : launch_cfg<false, Cfg256>(a, stream);
   return a.conv ? launch_cfg<true, Cfg128>(a, stream) : launch_cfg<false, Cfg128>(a, stream);
 }

@@ -1,0 +1,250 @@
+// 256x256x64 staggered, phase-pipelined bf16 MFMA GEMM / implicit-GEMM conv for gfx950 (the large-problem path of
+// launch_gemm; same arguments, layouts and epilogue as gemm.hip).
+//
+// Why a second structure: at one 8-wave block per CU the plain "issue next tile / multiply / drain / barrier" loop
+// leaves the matrix pipe idle while both waves of a SIMD wait on the same barrier and the LDS-DMA queue runs dry
+// once per K-tile. Here
+//   * the 8 waves form two groups (wave>>2) that run ONE BARRIER APART: while group 0 multiplies, group 1 reads
+//     its fragments / issues DMA, and vice versa (waves w and w+4 share a SIMD), so every SIMD always has one
+//     wave in an MFMA segment;
+//   * a K-tile is four half-tiles (A rows 0-127 / 128-255, W rows 0-127 / 128-255; 16 KB each) and every phase
+//     issues exactly one half-tile, seven half-tiles ahead of its consumption -> the DMA queue never drains;
+//     the only vmcnt wait is a COUNTED s_waitcnt vmcnt(6) once per K-tile;
+//   * per K-tile a wave runs four phases = the four 64x32 quadrants of its 128x64 output (16 MFMAs each).
+//
+// Schedule (t = K-tile, buffer t&1; half-tile order per tile: B0, B1, A0, A1; I_k = barrier interval):
+//   phase q0: ds_read A rows 0-63 + all of B (16 x b128) | issue A1(t+1)          | barrier | MFMA(A0-63 x B0-31)  | barrier
+//   phase q1:                                            | issue B0(t+2)          | barrier | MFMA(A0-63 x B32-63) | barrier
+//   phase q2: ds_read A rows 64-127 (8 x b128)           | issue B1(t+2)          | barrier | MFMA(A64-127 x B32-63)| barrier
+//   phase q3:                                            | issue A0(t+2), vmcnt(6)| barrier | MFMA(A64-127 x B0-31) | barrier
+// Hazards. RAW: a wave waits for its own DMA pieces (vmcnt) before the barrier that ends its q3 read segment; group
+// 1 does so one interval after group 0, and the first read of tile t+1 (group 0, q0) comes after that barrier.
+// WAR: B(t) is last read in q0 (group 1: I_{8t+1}) and B0(t+2) is issued from I_{8t+2} on; A0(t)/A1(t) are last
+// read in q2 (I_{8t+4}/I_{8t+5}) and re-staged from I_{8t+6} / I_{8t+8} on; every read segment retires its
+// ds_reads (lgkmcnt(0)) before its closing barrier, so "issued after the barrier" implies "after the reads".
+#include "common.h"
+#include "gemm_epilogue.h"
+#include "kernels.h"
+
+namespace sd {
+
+namespace g256 {
+constexpr int BM = 256, BN = 256, BK = 64, THREADS = 512;
+constexpr int HALF = 128 * BK * 2;        // 16 KB
+constexpr int BUF = 4 * HALF;             // A0 A1 B0 B1
+constexpr int LDS_BYTES = 2 * BUF;        // 128 KB
+}  // namespace g256
+
+#define SD_BARRIER()                      \
+  do {                                    \
+    __builtin_amdgcn_sched_barrier(0);    \
+    __builtin_amdgcn_s_barrier();         \
+    __builtin_amdgcn_sched_barrier(0);    \
+  } while (0)
+
+template <bool CONV>
+__global__ __launch_bounds__(g256::THREADS, 2) void gemm256_kernel(const GemmArgs p) {
+  using namespace g256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wc = wave & 3;
+
+  const int ntn = (p.N + BN - 1) / BN;
+  const int ntm = (p.M + BM - 1) / BM;
+  const int lid = xcd_remap(blockIdx.x, ntm * ntn);
+  int tile_m, tile_n;
+  tile_coords(lid, ntm, ntn, tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // ---- LDS-DMA geometry: a half-tile is 16 pieces of 1 KiB (8 rows x 128 B); wave w issues pieces 2w, 2w+1 ----
+  const int sub = lane >> 3;
+  const int cg = (lane & 7) ^ sub;   // source-side XOR swizzle (LDS destination of a DMA is lane-linear)
+  const bf16* a_base[4];             // index h*2 + j : half h, piece j
+  bool a_ok[4];
+  int oy[4], ox[4];
+  const bf16* w_base[4];
+  bool w_ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (i >> 1) * 128 + (2 * wave + (i & 1)) * 8 + sub;
+    const int m = m0 + r;
+    a_ok[i] = m < p.M;
+    if (CONV) {
+      const int hw = p.Ho * p.Wo;
+      const int mm = a_ok[i] ? m : 0;
+      const int b = mm / hw;
+      const int rem = mm - b * hw;
+      oy[i] = rem / p.Wo;
+      ox[i] = rem - oy[i] * p.Wo;
+      a_base[i] = p.A + (size_t)b * p.Hs * p.Ws * p.lda;
+    } else {
+      a_base[i] = p.A + (size_t)(a_ok[i] ? m : 0) * p.lda + cg * 8;
+      oy[i] = ox[i] = 0;
+    }
+    const int n = n0 + r;
+    w_ok[i] = n < p.N;
+    w_base[i] = p.W + (size_t)(w_ok[i] ? n : 0) * p.K + cg * 8;
+  }
+  const bf16* zsrc = reinterpret_cast<const bf16*>(g_zero16);
+  int kA[2] = {0, 0}, kB[2] = {0, 0};              // next K offset of each half-tile stream
+  int tapA[2] = {0, 0}, chA[2] = {cg * 8, cg * 8}; // conv: running (tap, channel) per A stream
+  if (CONV) {
+    tapA[0] = tapA[1] = (cg * 8) / p.Cin;
+    chA[0] = chA[1] = cg * 8 - tapA[0] * p.Cin;
+  }
+
+  auto issue_A = [&](const int h, int buf) {
+    unsigned char* dst = smem + buf * BUF + h * HALF + wave * 2048;
+    const bool k_ok = (kA[h] + cg * 8) < p.K;
+    if (CONV) {
+      const int ky = tapA[h] / 3, kx = tapA[h] - ky * 3;
+      const int Hin = p.Hs << p.up, Win = p.Ws << p.up;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int i = h * 2 + j;
+        const int iy = oy[i] * p.stride + ky - 1;
+        const int ix = ox[i] * p.stride + kx - 1;
+        const bool ok = a_ok[i] && k_ok && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
+        const size_t off = ((size_t)(iy >> p.up) * p.Ws + (ix >> p.up)) * p.lda + chA[h];
+        const bf16* src = ok ? a_base[i] + off : zsrc;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + j * 1024), 16, 0, 0);
+      }
+      chA[h] += BK;
+      while (chA[h] >= p.Cin) {
+        chA[h] -= p.Cin;
+        ++tapA[h];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int i = h * 2 + j;
+        const bf16* src = (a_ok[i] && k_ok) ? a_base[i] + kA[h] : zsrc;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + j * 1024), 16, 0, 0);
+      }
+    }
+    kA[h] += BK;
+  };
+  auto issue_B = [&](const int h, int buf) {
+    unsigned char* dst = smem + buf * BUF + (2 + h) * HALF + wave * 2048;
+    const bool k_ok = (kB[h] + cg * 8) < p.K;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int i = h * 2 + j;
+      const bf16* src = (w_ok[i] && k_ok) ? w_base[i] + kB[h] : zsrc;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + j * 1024), 16, 0, 0);
+    }
+    kB[h] += BK;
+  };
+
+  f32x4 acc[4][8];   // [n-tile][m-tile]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- fragment geometry ----
+  const int frow = lane & 15, fkc = lane >> 4, rsw = frow & 7;
+  const int c0 = ((0 * 4 + fkc) ^ rsw) << 4, c1 = ((1 * 4 + fkc) ^ rsw) << 4;
+  const int a_off = grp * HALF + frow * 128;                              // + (s*64 + mt*16)*128
+  const int b_off = (2 + (wc >> 1)) * HALF + ((wc & 1) * 64 + frow) * 128; // + nt*16*128
+  bf16x8 fa[4][2], fb[4][2];
+
+  auto read_A = [&](const unsigned char* base, const int s) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const unsigned char* r = base + a_off + (s * 64 + mt * 16) * 128;
+      fa[mt][0] = *reinterpret_cast<const bf16x8*>(r + c0);
+      fa[mt][1] = *reinterpret_cast<const bf16x8*>(r + c1);
+    }
+  };
+  auto read_B = [&](const unsigned char* base) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const unsigned char* r = base + b_off + nt * 16 * 128;
+      fb[nt][0] = *reinterpret_cast<const bf16x8*>(r + c0);
+      fb[nt][1] = *reinterpret_cast<const bf16x8*>(r + c1);
+    }
+  };
+  auto mma = [&](const int s, const int j) {   // quadrant: A rows s*64.., B cols j*32..
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+          acc[2 * j + nn][s * 4 + mt] =
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[2 * j + nn][ks], fa[mt][ks], acc[2 * j + nn][s * 4 + mt], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // ---- prologue: tile 0 (B0 B1 A0 A1) and tile 1 (B0 B1 A0): 7 half-tiles = 14 DMAs per lane ----
+  issue_B(0, 0);
+  issue_B(1, 0);
+  issue_A(0, 0);
+  issue_A(1, 0);
+  issue_B(0, 1);
+  issue_B(1, 1);
+  issue_A(0, 1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // tile 0 landed (own pieces)
+  SD_BARRIER();
+  if (grp == 1) SD_BARRIER();                        // stagger: group 1 runs one barrier behind group 0
+
+  const int nt = (p.K + BK - 1) / BK;
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    const unsigned char* base = smem + buf * BUF;
+    // q0
+    read_A(base, 0);
+    read_B(base);
+    issue_A(1, buf ^ 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    SD_BARRIER();
+    mma(0, 0);
+    SD_BARRIER();
+    // q1
+    issue_B(0, buf);
+    SD_BARRIER();
+    mma(0, 1);
+    SD_BARRIER();
+    // q2
+    read_A(base, 1);
+    issue_B(1, buf);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    SD_BARRIER();
+    mma(1, 1);
+    SD_BARRIER();
+    // q3
+    issue_A(0, buf);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // tile t+1 landed (own pieces); 3 half-tiles stay in flight
+    SD_BARRIER();
+    mma(1, 0);
+    SD_BARRIER();
+  }
+  if (grp == 0) SD_BARRIER();                         // re-align the two groups
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // run-out DMAs retired before the LDS is released
+
+  gemm_epilogue<8, 4>(p, acc, m0 + grp * 128, n0 + wc * 64, lane);
+}
+
+int launch_gemm256(const GemmArgs& a, hipStream_t stream) {
+  using namespace g256;
+  static const bool attr_ok = [] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess &&
+           hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
+  }();
+  if (!attr_ok) return SD_ERR_HIP;
+  const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
+  if (a.conv)
+    hipLaunchKernelGGL(gemm256_kernel<true>, dim3(ntm * ntn), dim3(THREADS), LDS_BYTES, stream, a);
+  else
+    hipLaunchKernelGGL(gemm256_kernel<false>, dim3(ntm * ntn), dim3(THREADS), LDS_BYTES, stream, a);
+  return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+}
+
+}  // namespace sd

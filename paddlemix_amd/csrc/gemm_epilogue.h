@@ -1,0 +1,73 @@
+// Shared GEMM epilogue (bias / time-embedding row bias / residual / scale / SiLU / GEGLU, bf16 or fp32 stores).
+// Accumulator layout: acc[tn][tm] is the "swapped" 16x16 MFMA tile whose lane holds, for output row
+// m = m_wave + tm*16 + (lane&15), the 4 consecutive channels n = n_wave + tn*16 + (lane>>4)*4 + {0..3}.
+#pragma once
+#include "common.h"
+#include "kernels.h"
+
+namespace sd {
+
+static __device__ __attribute__((aligned(16))) const unsigned g_zero16[4] = {0u, 0u, 0u, 0u};
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TN][TM], int m_wave, int n_wave,
+                                              int lane) {
+  const int nq = (lane >> 4) * 4;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int m = m_wave + tm * 16 + (lane & 15);
+    if (m >= p.M) continue;
+    const float* rb = p.rowbias ? p.rowbias + (size_t)(m / p.rows_per_batch) * p.ld_rowbias : nullptr;
+    if (p.geglu) {
+#pragma unroll
+      for (int tp = 0; tp < TN / 2; ++tp) {
+        const int n_phys = n_wave + tp * 32 + nq;  // physical (interleaved) column of the value half
+        if (n_phys >= p.N) continue;               // N % 32 == 0: the gate half of the pair is inside too
+        f32x4 h = acc[2 * tp][tm], g = acc[2 * tp + 1][tm];
+        if (p.bias) {
+          h += *reinterpret_cast<const f32x4*>(p.bias + n_phys);
+          g += *reinterpret_cast<const f32x4*>(p.bias + n_phys + 16);
+        }
+        const int n_out = (n_wave >> 1) + tp * 16 + nq;
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = h[r] * gelu_erf_f(g[r]);
+        u32x2 pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3])};
+        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n_out) = pk;
+      }
+    } else {
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int n = n_wave + tn * 16 + nq;
+        if (n >= p.N) continue;
+        f32x4 v = acc[tn][tm];
+        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+        if (rb) v += *reinterpret_cast<const f32x4*>(rb + n);
+        if (p.R) {
+          const bf16x4 r4 = *reinterpret_cast<const bf16x4*>(p.R + (size_t)m * p.ldr + n);
+          v[0] += (float)r4[0];
+          v[1] += (float)r4[1];
+          v[2] += (float)r4[2];
+          v[3] += (float)r4[3];
+        }
+        v *= p.out_scale;
+        if (p.silu) {
+          v[0] = silu_f(v[0]);
+          v[1] = silu_f(v[1]);
+          v[2] = silu_f(v[2]);
+          v[3] = silu_f(v[3]);
+        }
+        if (p.out_f32) {
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = v;
+        } else {
+          u32x2 pk = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+          *reinterpret_cast<u32x2*>(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n) = pk;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace sd

@@ -31,6 +31,7 @@ struct GemmArgs {
   int silu;               // SiLU applied last
 };
 int launch_gemm(const GemmArgs& a, hipStream_t stream);
+int launch_gemm256(const GemmArgs& a, hipStream_t stream);   // phased 256x256 kernel (gemm256.hip); args pre-validated
 
 struct AttnArgs {
   const bf16 *Q, *K, *V;
