@@ -196,9 +196,19 @@ def main():
                 model.stage_inputs(plan, latents, 500.0, enc, added, in_scale=0.5)
                 model._run_eager(plan)
         model.profile = False
-        kinds = {}
-        for kind, xs in model.kernel_times.items():
-            kinds[kind] = dict(launches=len(xs), ms=1e3 * sum(x[0] for x in xs), gflop=sum(x[1] for x in xs) / 1e9)
+        kinds, shapes = {}, {}
+        for key, xs in model.kernel_times.items():
+            kind = key.split(":")[0]
+            k = kinds.setdefault(kind, dict(launches=0, ms=0.0, gflop=0.0))
+            k["launches"] += len(xs)
+            k["ms"] += 1e3 * sum(x[0] for x in xs)
+            k["gflop"] += sum(x[1] for x in xs) / 1e9
+            if ":" in key:
+                shapes[key] = dict(n=len(xs), ms=round(1e3 * sum(x[0] for x in xs), 3),
+                                   tflops=round(sum(x[1] for x in xs) / 1e12 / max(sum(x[0] for x in xs), 1e-12), 1))
+        if os.environ.get("BENCH_SHAPES"):
+            for key, v in sorted(shapes.items(), key=lambda kv: -kv[1]["ms"]):
+                print(f"  {key:40s} n={v['n']:4d} {v['ms']:8.3f} ms {v['tflops']:8.1f} TFLOP/s", file=sys.stderr)
         total_ms = sum(v["ms"] for v in kinds.values())
         dom = max((k for k in kinds if kinds[k]["gflop"] > 0), key=lambda k: kinds[k]["ms"])
         d = kinds[dom]

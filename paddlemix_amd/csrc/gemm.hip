@@ -40,14 +40,15 @@ struct GemmCfg {
   static constexpr int THREADS = NW * 64;
   static constexpr int BM = WAVES_M * TM * 16;
   static constexpr int BN = WAVES_N * TN * 16;
-  static constexpr int A_PIECES = BM / 8 / NW;   // 1-KiB (8 rows x 128 B) LDS-DMA pieces per wave per K-tile
-  static constexpr int W_PIECES = BN / 8 / NW;
+  static constexpr int A_TOTAL = BM / 8, W_TOTAL = BN / 8;   // 1-KiB (8 rows x 128 B) LDS-DMA pieces per K-tile
+  static constexpr int A_PIECES = (A_TOTAL + NW - 1) / NW;    // per wave (the last waves may own one fewer)
+  static constexpr int W_PIECES = (W_TOTAL + NW - 1) / NW;
   static constexpr int LDS_BYTES = 2 * (BM + BN) * BK * 2;
-  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "pieces must divide evenly over the waves");
-  static_assert(TN % 2 == 0, "GEGLU pairs two 16-column tiles");
 };
-using Cfg128 = GemmCfg<2, 2, 4, 4>;
-using Cfg256 = GemmCfg<2, 4, 8, 4>;
+using Cfg128 = GemmCfg<2, 2, 4, 4>;       // 128 x 128, 2 blocks / CU
+using Cfg256 = GemmCfg<2, 4, 8, 4>;       // 256 x 256
+using Cfg256x160 = GemmCfg<4, 2, 4, 5>;   // 256 x 160: N = 1280 -> 8 column tiles (8192 x 1280 = exactly 256 tiles)
+using Cfg256x320 = GemmCfg<2, 4, 8, 5>;   // 256 x 320: N = 640 -> 2 column tiles
 
 template <bool CONV, class CFG>
 __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_bf16_kernel(const GemmArgs p) {
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_bf16_kernel(const GemmAr
   bool gw_ok[CFG::W_PIECES];
 #pragma unroll
   for (int i = 0; i < CFG::A_PIECES; ++i) {
-    const int m = m0 + (wave * CFG::A_PIECES + i) * 8 + g_sub;
+    const int m = m0 + (wave + i * CFG::NW) * 8 + g_sub;   // piece index = wave + i*NW (interleaved over waves)
     ga_ok[i] = m < p.M;
     if (CONV) {
       const int hw = p.Ho * p.Wo;
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_bf16_kernel(const GemmAr
   }
 #pragma unroll
   for (int i = 0; i < CFG::W_PIECES; ++i) {
-    const int n = n0 + (wave * CFG::W_PIECES + i) * 8 + g_sub;
+    const int n = n0 + (wave + i * CFG::NW) * 8 + g_sub;
     gw_ok[i] = n < p.N;
     gw_base[i] = p.W + (size_t)(gw_ok[i] ? n : 0) * p.K + g_cg * 8;
   }
@@ -108,8 +109,8 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_bf16_kernel(const GemmAr
 
   auto issue_tile = [&](int k0, int buf) {
     const bool k_ok = (k0 + g_cg * 8) < p.K;
-    unsigned char* a = As + buf * (BM * BK * 2) + wave * (CFG::A_PIECES * 1024);
-    unsigned char* w = Ws + buf * (BN * BK * 2) + wave * (CFG::W_PIECES * 1024);
+    unsigned char* a = As + buf * (BM * BK * 2) + wave * 1024;   // piece (wave + i*NW)
+    unsigned char* w = Ws + buf * (BN * BK * 2) + wave * 1024;
     if (CONV) {
       const int ky = gtap / 3, kx = gtap - ky * 3;
       const int Hin = p.Hs << p.up, Win = p.Ws << p.up;
@@ -120,7 +121,8 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_bf16_kernel(const GemmAr
         const bool ok = ga_ok[i] && k_ok && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
         const size_t off = ((size_t)(iy >> p.up) * p.Ws + (ix >> p.up)) * p.lda + gcch;
         const bf16* src = ok ? ga_base[i] + off : zsrc;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(a + i * 1024), 16, 0, 0);
+        if (CFG::A_TOTAL % CFG::NW == 0 || wave + i * CFG::NW < CFG::A_TOTAL)
+          __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(a + i * (CFG::NW * 1024)), 16, 0, 0);
       }
       gcch += BK;
       while (gcch >= p.Cin) {
@@ -131,13 +133,15 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_bf16_kernel(const GemmAr
 #pragma unroll
       for (int i = 0; i < CFG::A_PIECES; ++i) {
         const bf16* src = (ga_ok[i] && k_ok) ? ga_base[i] + k0 : zsrc;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(a + i * 1024), 16, 0, 0);
+        if (CFG::A_TOTAL % CFG::NW == 0 || wave + i * CFG::NW < CFG::A_TOTAL)
+          __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(a + i * (CFG::NW * 1024)), 16, 0, 0);
       }
     }
 #pragma unroll
     for (int i = 0; i < CFG::W_PIECES; ++i) {
       const bf16* src = (gw_ok[i] && k_ok) ? gw_base[i] + k0 : zsrc;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(w + i * 1024), 16, 0, 0);
+      if (CFG::W_TOTAL % CFG::NW == 0 || wave + i * CFG::NW < CFG::W_TOTAL)
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(w + i * (CFG::NW * 1024)), 16, 0, 0);
     }
   };
 
@@ -195,22 +199,36 @@ static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
 
-// Tile selection: the 256x256 tile has the higher per-CU efficiency but 1 block per CU; use it when the problem
-// offers enough whole tiles. MI355X_SD_GEMM_TILE=128|256 forces a configuration (A/B measurements).
+// Tile selection. These kernels are bound by the per-CU HBM/L2 -> LDS ingest rate (measured ~35-45 GB/s per CU,
+// profiles/r01_gemm_tiles.txt), so the cost of a configuration is modelled as the bytes the busiest CU must pull:
+//   ceil(tiles / (256 CUs)) * (BM + BN)            (x K, common to all candidates)
+// i.e. prefer the largest tile that still gives every CU work and leaves no mostly-empty last round.
+// MI355X_SD_GEMM_TILE forces a configuration for A/B measurements: 128 | 256 | 257 (phased 256x256) | 160 | 320.
+struct TileChoice { int id, bm, bn; };
 static int pick_tile(const GemmArgs& a) {
   static const int forced = [] {
     const char* e = getenv("MI355X_SD_GEMM_TILE");
     return e ? atoi(e) : 0;
   }();
-  if (forced == 128 || forced == 256 || forced == 257) return forced;   // 257: the phased 256x256 kernel
-  if (a.M < 256 || a.N < 256) return 128;
-  const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-  const long waste256 = t256 * 256 * 256 - (long)a.M * a.N;   // padded area of ragged edge tiles
-  if (waste256 * 8 > (long)a.M * a.N) return 128;              // > 12.5 % of the tile area would be padding
-  // measured on MI355X (profiles/r01_gemm_tiles.txt): the phased 256x256 kernel wins once every CU has a tile
-  // and the K loop is long enough to amortise its 7-half-tile prologue; otherwise 2 x 128x128 blocks per CU win.
-  if (t256 >= 256 || (t256 >= 128 && a.K >= 2048)) return 257;
-  return 128;
+  if (forced) return forced;
+  if (a.M < 256) return 128;
+  const bool wide_ok = (size_t)a.M * a.lda * 2 < (1ull << 31) && (size_t)a.N * a.K * 2 < (1ull << 31);
+  const TileChoice cand[] = {{128, 128, 128}, {160, 256, 160}, {257, 256, 256}, {320, 256, 320}};
+  int best = 128;
+  double best_cost = 1e30;
+  for (const TileChoice& c : cand) {
+    if (c.id == 257 && ((a.K & 63) || (a.conv && (a.Cin & 63)) || !wide_ok)) continue;
+    if (a.geglu && (c.id == 160 || c.id == 320)) continue;   // odd number of 16-column tiles per wave
+    const long tiles = (long)((a.M + c.bm - 1) / c.bm) * ((a.N + c.bn - 1) / c.bn);
+    const long per_cu = (tiles + 255) / 256;
+    double cost = (double)per_cu * (c.bm + c.bn);
+    if (c.id == 128) cost *= 0.95;   // two co-resident blocks hide each other's prologue / epilogue
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = c.id;
+    }
+  }
+  return best;
 }
 
 int launch_gemm(const GemmArgs& a, hipStream_t stream) {
@@ -225,8 +243,12 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   }
   if (a.rowbias && a.rows_per_batch <= 0) return SD_ERR_INVALID;
   const int tile = pick_tile(a);
-  if (tile == 257) return launch_gemm256(a, stream);
-  if (tile == 256) return a.conv ? launch_cfg<true, Cfg256>(a, stream) : launch_cfg<false, Cfg256>(a, stream);
+  if (tile == 257 && !((a.K & 63) || (a.conv && (a.Cin & 63)))) return launch_gemm256(a, stream);
+  if (tile == 256 || tile == 257) return a.conv ? launch_cfg<true, Cfg256>(a, stream) : launch_cfg<false, Cfg256>(a, stream);
+  if (tile == 160 && !a.geglu)
+    return a.conv ? launch_cfg<true, Cfg256x160>(a, stream) : launch_cfg<false, Cfg256x160>(a, stream);
+  if (tile == 320 && !a.geglu)
+    return a.conv ? launch_cfg<true, Cfg256x320>(a, stream) : launch_cfg<false, Cfg256x320>(a, stream);
   return a.conv ? launch_cfg<true, Cfg128>(a, stream) : launch_cfg<false, Cfg128>(a, stream);
 }
 

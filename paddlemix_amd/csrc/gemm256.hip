@@ -22,6 +22,8 @@
 // WAR: B(t) is last read in q0 (group 1: I_{8t+1}) and B0(t+2) is issued from I_{8t+2} on; A0(t)/A1(t) are last
 // read in q2 (I_{8t+4}/I_{8t+5}) and re-staged from I_{8t+6} / I_{8t+8} on; every read segment retires its
 // ds_reads (lgkmcnt(0)) before its closing barrier, so "issued after the barrier" implies "after the reads".
+#include <stdlib.h>
+
 #include "common.h"
 #include "gemm_epilogue.h"
 #include "kernels.h"
@@ -62,11 +64,20 @@ __global__ __launch_bounds__(g256::THREADS, 2) void gemm256_kernel(const GemmArg
   // ---- LDS-DMA geometry: a half-tile is 16 pieces of 1 KiB (8 rows x 128 B); wave w issues pieces 2w, 2w+1 ----
   const int sub = lane >> 3;
   const int cg = (lane & 7) ^ sub;   // source-side XOR swizzle (LDS destination of a DMA is lane-linear)
-  const bf16* a_base[4];             // index h*2 + j : half h, piece j
-  bool a_ok[4];
+  // Buffer (SRD) addressing: 32-bit per-lane byte offsets + a scalar K offset; anything past the last valid
+  // byte (rows >= M / N, conv padding -> offset forced out of range) reads as zero in hardware, so there is no
+  // zero-page select and no 64-bit address arithmetic in the loop. Requires K % 64 == 0 (no in-row K tail).
+  const unsigned a_bytes = CONV ? (unsigned)(((size_t)(p.M / (p.Ho * p.Wo)) * p.Hs * p.Ws - 1) * p.lda + p.Cin) * 2u
+                                : (unsigned)(((size_t)(p.M - 1) * p.lda + p.K) * 2);
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.A), 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.W), 0, (unsigned)((size_t)p.N * p.K * 2), 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  unsigned a_off32[4];               // index h*2 + j : half h, piece j (linear: byte offset of the row's chunk)
   int oy[4], ox[4];
-  const bf16* w_base[4];
-  bool w_ok[4];
+  unsigned a_img[4];                 // conv: byte offset of the row's image
+  bool a_ok[4];
+  unsigned w_off32[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = (i >> 1) * 128 + (2 * wave + (i & 1)) * 8 + sub;
@@ -79,17 +90,17 @@ __global__ __launch_bounds__(g256::THREADS, 2) void gemm256_kernel(const GemmArg
       const int rem = mm - b * hw;
       oy[i] = rem / p.Wo;
       ox[i] = rem - oy[i] * p.Wo;
-      a_base[i] = p.A + (size_t)b * p.Hs * p.Ws * p.lda;
+      a_img[i] = (unsigned)((size_t)b * p.Hs * p.Ws * p.lda * 2);
+      a_off32[i] = 0;
     } else {
-      a_base[i] = p.A + (size_t)(a_ok[i] ? m : 0) * p.lda + cg * 8;
+      a_off32[i] = a_ok[i] ? (unsigned)(((size_t)m * p.lda + cg * 8) * 2) : OOB;
       oy[i] = ox[i] = 0;
+      a_img[i] = 0;
     }
     const int n = n0 + r;
-    w_ok[i] = n < p.N;
-    w_base[i] = p.W + (size_t)(w_ok[i] ? n : 0) * p.K + cg * 8;
+    w_off32[i] = (n < p.N) ? (unsigned)(((size_t)n * p.K + cg * 8) * 2) : OOB;
   }
-  const bf16* zsrc = reinterpret_cast<const bf16*>(g_zero16);
-  int kA[2] = {0, 0}, kB[2] = {0, 0};              // next K offset of each half-tile stream
+  int kA[2] = {0, 0}, kB[2] = {0, 0};              // next K offset (elements) of each half-tile stream
   int tapA[2] = {0, 0}, chA[2] = {cg * 8, cg * 8}; // conv: running (tap, channel) per A stream
   if (CONV) {
     tapA[0] = tapA[1] = (cg * 8) / p.Cin;
@@ -97,20 +108,20 @@ __global__ __launch_bounds__(g256::THREADS, 2) void gemm256_kernel(const GemmArg
   }
 
   auto issue_A = [&](const int h, int buf) {
+    if (p.dbg & 2) return;   // ablation: no DMA
     unsigned char* dst = smem + buf * BUF + h * HALF + wave * 2048;
-    const bool k_ok = (kA[h] + cg * 8) < p.K;
     if (CONV) {
       const int ky = tapA[h] / 3, kx = tapA[h] - ky * 3;
       const int Hin = p.Hs << p.up, Win = p.Ws << p.up;
+      const bool k_ok = tapA[h] < 9;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int i = h * 2 + j;
         const int iy = oy[i] * p.stride + ky - 1;
         const int ix = ox[i] * p.stride + kx - 1;
         const bool ok = a_ok[i] && k_ok && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
-        const size_t off = ((size_t)(iy >> p.up) * p.Ws + (ix >> p.up)) * p.lda + chA[h];
-        const bf16* src = ok ? a_base[i] + off : zsrc;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + j * 1024), 16, 0, 0);
+        const unsigned off = a_img[i] + (unsigned)(((iy >> p.up) * p.Ws + (ix >> p.up)) * p.lda + chA[h]) * 2u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lptr_t)(dst + j * 1024), 16, ok ? off : OOB, 0, 0, 0);
       }
       chA[h] += BK;
       while (chA[h] >= p.Cin) {
@@ -118,24 +129,20 @@ __global__ __launch_bounds__(g256::THREADS, 2) void gemm256_kernel(const GemmArg
         ++tapA[h];
       }
     } else {
+      const int soff = (kA[h] < p.K) ? kA[h] * 2 : (int)0x7FFFFFF0;   // run-out tiles: out of range -> zeros
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int i = h * 2 + j;
-        const bf16* src = (a_ok[i] && k_ok) ? a_base[i] + kA[h] : zsrc;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + j * 1024), 16, 0, 0);
-      }
+      for (int j = 0; j < 2; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lptr_t)(dst + j * 1024), 16, a_off32[h * 2 + j], soff, 0, 0);
     }
     kA[h] += BK;
   };
   auto issue_B = [&](const int h, int buf) {
+    if (p.dbg & 2) return;
     unsigned char* dst = smem + buf * BUF + (2 + h) * HALF + wave * 2048;
-    const bool k_ok = (kB[h] + cg * 8) < p.K;
+    const int soff = (kB[h] < p.K) ? kB[h] * 2 : (int)0x7FFFFFF0;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int i = h * 2 + j;
-      const bf16* src = (w_ok[i] && k_ok) ? w_base[i] + kB[h] : zsrc;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + j * 1024), 16, 0, 0);
-    }
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lptr_t)(dst + j * 1024), 16, w_off32[h * 2 + j], soff, 0, 0);
     kB[h] += BK;
   };
 
@@ -151,8 +158,11 @@ __global__ __launch_bounds__(g256::THREADS, 2) void gemm256_kernel(const GemmArg
   const int a_off = grp * HALF + frow * 128;                              // + (s*64 + mt*16)*128
   const int b_off = (2 + (wc >> 1)) * HALF + ((wc & 1) * 64 + frow) * 128; // + nt*16*128
   bf16x8 fa[4][2], fb[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fa[i][0] = fa[i][1] = fb[i][0] = fb[i][1] = bf16x8{};
 
   auto read_A = [&](const unsigned char* base, const int s) {
+    if (p.dbg & 4) return;   // ablation: no LDS fragment reads
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       const unsigned char* r = base + a_off + (s * 64 + mt * 16) * 128;
@@ -161,6 +171,7 @@ __global__ __launch_bounds__(g256::THREADS, 2) void gemm256_kernel(const GemmArg
     }
   };
   auto read_B = [&](const unsigned char* base) {
+    if (p.dbg & 4) return;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       const unsigned char* r = base + b_off + nt * 16 * 128;
@@ -169,6 +180,13 @@ __global__ __launch_bounds__(g256::THREADS, 2) void gemm256_kernel(const GemmArg
     }
   };
   auto mma = [&](const int s, const int j) {   // quadrant: A rows s*64.., B cols j*32..
+    if (p.dbg & 1) {   // ablation: no MFMAs (fragments kept live)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        asm volatile("" ::"v"(fa[i][0]), "v"(fa[i][1]), "v"(fb[i][0]), "v"(fb[i][1]));
+      }
+      return;
+    }
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -239,11 +257,17 @@ int launch_gemm256(const GemmArgs& a, hipStream_t stream) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
   }();
   if (!attr_ok) return SD_ERR_HIP;
+  static const int dbg = [] {
+    const char* e = getenv("MI355X_SD_GEMM_DBG");
+    return e ? atoi(e) : 0;
+  }();
+  GemmArgs b = a;
+  b.dbg = dbg;
   const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
   if (a.conv)
-    hipLaunchKernelGGL(gemm256_kernel<true>, dim3(ntm * ntn), dim3(THREADS), LDS_BYTES, stream, a);
+    hipLaunchKernelGGL(gemm256_kernel<true>, dim3(ntm * ntn), dim3(THREADS), LDS_BYTES, stream, b);
   else
-    hipLaunchKernelGGL(gemm256_kernel<false>, dim3(ntm * ntn), dim3(THREADS), LDS_BYTES, stream, a);
+    hipLaunchKernelGGL(gemm256_kernel<false>, dim3(ntm * ntn), dim3(THREADS), LDS_BYTES, stream, b);
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
 

@@ -25,7 +25,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TN
       for (int tp = 0; tp < TN / 2; ++tp) {
         const int n_phys = n_wave + tp * 32 + nq;  // physical (interleaved) column of the value half
         if (n_phys >= p.N) continue;               // N % 32 == 0: the gate half of the pair is inside too
-        f32x4 h = acc[2 * tp][tm], g = acc[2 * tp + 1][tm];
+        f32x4 h = acc[2 * tp][tm], g = acc[(2 * tp + 1) % TN][tm];   // (% TN: odd-TN configs never take this path)
         if (p.bias) {
           h += *reinterpret_cast<const f32x4*>(p.bias + n_phys);
           g += *reinterpret_cast<const f32x4*>(p.bias + n_phys + 16);

@@ -29,6 +29,7 @@ struct GemmArgs {
   int geglu;              // W/bias rows interleaved [16 value | 16 gate]; writes N/2 columns value*gelu(gate)
   int out_f32;
   int silu;               // SiLU applied last
+  int dbg;                // ablation switches of gemm256.hip (MI355X_SD_GEMM_DBG; 0 in production)
 };
 int launch_gemm(const GemmArgs& a, hipStream_t stream);
 int launch_gemm256(const GemmArgs& a, hipStream_t stream);   // phased 256x256 kernel (gemm256.hip); args pre-validated

@@ -408,8 +408,8 @@ class UNet2DConditionModel:
         def wp(key):
             return W[key].data_ptr()
 
-        def emit(fn, args, kind, flops=0.0):
-            prog.append((fn, list(args), kind, flops))
+        def emit(fn, args, kind, flops=0.0, desc=""):
+            prog.append((fn, list(args), kind if not desc else f"{kind}:{desc}", flops))
 
         def linear(a: _V, wkey: str, out: _V, bias=True, R: Optional[_V] = None, flags=0, out_scale=1.0,
                    rowbias=None, rpb=0, ld_rb=0, bkey=None):
@@ -419,7 +419,8 @@ class UNet2DConditionModel:
             b = (W[bkey] if bkey else W[wkey + ".b"]).data_ptr() if bias else None
             emit(lib.mi355x_sd_linear,
                  (a.p, a.ld, w.data_ptr(), out.p, out.ld, a.rows, N, K, b, rowbias, rpb, ld_rb,
-                  R.p if R else None, R.ld if R else 0, out_scale, flags, stream), "gemm", 2.0 * a.rows * N * K)
+                  R.p if R else None, R.ld if R else 0, out_scale, flags, stream), "gemm", 2.0 * a.rows * N * K,
+                 f"{a.rows}x{N}x{K}" + ("g" if flags & GEGLU else ""))
 
         def conv3(x: _V, h, w_, wkey, out: _V, stride=1, up=0, rowbias=None, R: Optional[_V] = None, out_scale=1.0):
             w = W[wkey + ".w"]
@@ -429,7 +430,8 @@ class UNet2DConditionModel:
             emit(lib.mi355x_sd_conv3x3,
                  (x.p, x.ld, B, h, w_, x.C, stride, up, w.data_ptr(), out.p, out.ld, Cout, W[wkey + ".b"].data_ptr(),
                   rowbias, self._temb_total if rowbias is not None else 0, R.p if R else None, R.ld if R else 0,
-                  out_scale, 0, stream), "conv", 2.0 * B * ho * wo * Cout * 9 * x.C)
+                  out_scale, 0, stream), "conv", 2.0 * B * ho * wo * Cout * 9 * x.C,
+                 f"{B * ho * wo}x{Cout}x{9 * x.C}" + ("s2" if stride == 2 else "") + ("up" if up else ""))
 
         def gnorm(x: _V, hw, nkey, eps_, silu) -> _V:
             nws = lib.mi355x_sd_groupnorm_workspace_floats(B, hw, x.C)
@@ -450,7 +452,7 @@ class UNet2DConditionModel:
             d = q.C // heads
             emit(lib.mi355x_sd_sdpa, (q.p, k.p, v.p, None, out.p, B, heads, sq, skv, d, sq * q.ld, q.ld, skv * k.ld,
                                       k.ld, skv * v.ld, v.ld, sq * out.ld, out.ld, 0, 0, 0, d ** -0.5, stream),
-                 "attn", 4.0 * B * heads * sq * skv * d)
+                 "attn", 4.0 * B * heads * sq * skv * d, f"{B}x{heads}x{sq}x{skv}x{d}")
 
         # ---- inputs (static buffers; staged by __call__) ----
         plan.sample = persist((B, cfg["in_channels"], H, Wd), torch.float32)
