@@ -15,6 +15,10 @@
 //   * O^T = V^T P^T: P (bf16) is consumed straight from those registers as the MFMA B operand; the matching
 //     V^T A operand comes from ds_read_b64_tr_b16 transpose reads of the row-major V tile;
 //   * K rows padded by 16 B and V rows to a stride == 64 (mod 256) B so both fragment reads are bank-conflict free.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -123,9 +127,19 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_ker
   const int tr_row = (i16 >> 2);           // + key base
   const int tr_col = dh * 16 + (i16 & 3) * 4;
 
-  for (int t = 0; t < ntiles; ++t) {
+  // cross-half exchange without touching the LDS pipe: v_permlane32_swap leaves {lo, lo} / {hi, hi} in the pair
+  auto xhalf_max = [](float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  };
+  constexpr float RESCALE_THR = 4.0f;   // log2 units: skip the O rescale while the row max grew by < 2^4 (P <= 16)
+
+  // one K/V tile; MASK = the (single) ragged last tile, kept out of the steady-state instruction stream
+  auto tile_body = [&](const int t, auto mask_tag) {
+    constexpr bool MASK = decltype(mask_tag)::value;
     const int buf = (NBUF == 2) ? (t & 1) : 0;
-    if (NBUF == 2 && t + 1 < ntiles) load_kv((t + 1) * KVBLK);
+    if (NBUF == 2 && t + 1 < ntiles && !(p.dbg & 1)) load_kv((t + 1) * KVBLK);
     const unsigned char* ks_ = smem + buf * (L::KBYTES + L::VBYTES);
     const unsigned char* vs_ = ks_ + L::KBYTES;
 
@@ -144,7 +158,6 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_ker
 
     // ---- mask / bias; s[sb][r] is key kv0 + sb*32 + (r&3) + 8*(r>>2) + 4*hi for query lq ----
     const int kv0 = t * KVBLK;
-    const bool tail = (kv0 + KVBLK > p.Skv);
     if (HAS_BIAS) {
       const float inv = 1.0f / p.scale;
       const float* bp = p.bias + (size_t)b * p.bias_bs + (size_t)h * p.bias_hs + (size_t)(q_ok ? q_row : 0) * p.bias_qs;
@@ -153,10 +166,10 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_ker
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int kv = kv0 + sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          if (kv < p.Skv) s[sb][r] += bp[kv] * inv;  // (s + bias/scale)*scale = s*scale + bias
+          if (!MASK || kv < p.Skv) s[sb][r] += bp[kv] * inv;  // (s + bias/scale)*scale = s*scale + bias
         }
     }
-    if (tail) {
+    if (MASK) {
 #pragma unroll
       for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
@@ -167,18 +180,32 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_ker
     }
 
     // ---- online softmax (one query per lane column) ----
-    float mloc = s[0][0];
+    float mx[8];
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[0][r]);
+    for (int i = 0; i < 8; ++i)   // 3-input max tree (v_max3_f32)
+      mx[i] = fmaxf(fmaxf(s[i >> 2][(i & 3) * 4], s[i >> 2][(i & 3) * 4 + 1]),
+                    fmaxf(s[i >> 2][(i & 3) * 4 + 2], s[i >> 2][(i & 3) * 4 + 3]));
+    float mloc = fmaxf(fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3])), fmaxf(fmaxf(mx[4], mx[5]), fmaxf(mx[6], mx[7])));
+    mloc = xhalf_max(mloc);
+    // defer the rescale while the running max is still a good reference for every row of the wave
+    if (!__all((mloc - m_run) * c2 <= RESCALE_THR)) {
+      const float m_new = fmaxf(m_run, mloc);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * c2);  // m_run = -inf -> 0
+      l_run *= alpha;
+      m_run = m_use;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[1][r]);
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-    const float m_new = fmaxf(m_run, mloc);
-    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * c2);  // m_run = -inf -> 0
-    const float mc = m_use * c2;
+      for (int i = 0; i < DB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+    }
+    const float mc = m_run * c2;
     float psum = 0.f;
     bf16x8 pf[4];
+    if (p.dbg & 2) {   // ablation: no exp / conversions
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pf[i] = bf16x8{};
+    } else
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb) {
 #pragma unroll
@@ -188,12 +215,7 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_ker
         pf[sb * 2 + (r >> 3)][r & 7] = (bf16)e;
       }
     }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int i = 0; i < DB; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+    l_run += psum;
 
     // ---- O^T += V^T P^T ----
 #pragma unroll
@@ -210,7 +232,7 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_ker
     }
 
     if (NBUF == 2) {
-      if (t + 1 < ntiles) store_kv(buf ^ 1);
+      if (t + 1 < ntiles && !(p.dbg & 1)) store_kv(buf ^ 1);
       __syncthreads();
     } else {
       __syncthreads();
@@ -220,7 +242,11 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_ker
       }
       __syncthreads();
     }
-  }
+  };
+
+  const int nfull = p.Skv / KVBLK;
+  for (int t = 0; t < nfull; ++t) tile_body(t, std::false_type{});
+  if (nfull < ntiles) tile_body(nfull, std::true_type{});
 
   // ---- finalize: O[q][d] = O^T[d][q] / l ; lane holds d = db*32 + (r&3) + 8*(r>>2) + 4*hi ----
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -242,7 +268,13 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_ker
 }
 
 template <int DP>
-static int launch_dp(const AttnArgs& a, hipStream_t stream) {
+static int launch_dp(const AttnArgs& a0, hipStream_t stream) {
+  static const int dbg = [] {
+    const char* e = getenv("MI355X_SD_ATTN_DBG");
+    return e ? atoi(e) : 0;
+  }();
+  AttnArgs a = a0;
+  a.dbg = dbg;
   const int nqb = (a.Sq + QBLK - 1) / QBLK;
   dim3 grid(nqb * a.B * a.H), block(ATT_THREADS);
   if (a.bias)

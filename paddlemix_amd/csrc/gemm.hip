@@ -49,6 +49,7 @@ using Cfg128 = GemmCfg<2, 2, 4, 4>;       // 128 x 128, 2 blocks / CU
 using Cfg256 = GemmCfg<2, 4, 8, 4>;       // 256 x 256
 using Cfg256x160 = GemmCfg<4, 2, 4, 5>;   // 256 x 160: N = 1280 -> 8 column tiles (8192 x 1280 = exactly 256 tiles)
 using Cfg256x320 = GemmCfg<2, 4, 8, 5>;   // 256 x 320: N = 640 -> 2 column tiles
+using Cfg256x320g = GemmCfg<4, 2, 4, 10>; // 256 x 320 with an even tile count per wave (GEGLU value/gate pairs)
 
 template <bool CONV, class CFG>
 __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_bf16_kernel(const GemmArgs p) {
@@ -218,7 +219,7 @@ static int pick_tile(const GemmArgs& a) {
   double best_cost = 1e30;
   for (const TileChoice& c : cand) {
     if (c.id == 257 && ((a.K & 63) || (a.conv && (a.Cin & 63)) || !wide_ok)) continue;
-    if (a.geglu && (c.id == 160 || c.id == 320)) continue;   // odd number of 16-column tiles per wave
+    if (a.geglu && c.id == 160) continue;   // odd number of 16-column tiles per wave
     const long tiles = (long)((a.M + c.bm - 1) / c.bm) * ((a.N + c.bn - 1) / c.bn);
     const long per_cu = (tiles + 255) / 256;
     double cost = (double)per_cu * (c.bm + c.bn);
@@ -249,6 +250,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     return a.conv ? launch_cfg<true, Cfg256x160>(a, stream) : launch_cfg<false, Cfg256x160>(a, stream);
   if (tile == 320 && !a.geglu)
     return a.conv ? launch_cfg<true, Cfg256x320>(a, stream) : launch_cfg<false, Cfg256x320>(a, stream);
+  if (tile == 320 && !a.conv) return launch_cfg<false, Cfg256x320g>(a, stream);
   return a.conv ? launch_cfg<true, Cfg128>(a, stream) : launch_cfg<false, Cfg128>(a, stream);
 }
 

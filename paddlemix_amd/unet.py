@@ -330,6 +330,9 @@ class UNet2DConditionModel:
         temb_w, temb_b = [], []
         self._temb_off: Dict[str, int] = {}
         off = 0
+        kv_w: List[Tensor] = []            # every cross-attention to_k / to_v, batched into one GEMM per step
+        self._kv_off: Dict[str, int] = {}
+        kv_off = 0
         for d in _structure(cfg):
             if d[0] == "resnet":
                 _, name, cin, cout, _ = d
@@ -360,7 +363,11 @@ class UNet2DConditionModel:
                                                           lin_w(b + ".attn1.to_v")], 0))
                     put_lin(b + ".attn1.out", b + ".attn1.to_out.0")
                     W[b + ".attn2.q.w"] = bf(lin_w(b + ".attn2.to_q"))
-                    W[b + ".attn2.kv.w"] = bf(torch.cat([lin_w(b + ".attn2.to_k"), lin_w(b + ".attn2.to_v")], 0))
+                    if any(x != cfg["cross_attention_dim"][0] for x in cfg["cross_attention_dim"]):
+                        raise NotImplementedError("per-block cross_attention_dim")
+                    kv_w.append(bf(torch.cat([lin_w(b + ".attn2.to_k"), lin_w(b + ".attn2.to_v")], 0)))
+                    self._kv_off[b] = kv_off
+                    kv_off += 2 * c
                     put_lin(b + ".attn2.out", b + ".attn2.to_out.0")
                     # GEGLU: interleave [16 value rows | 16 gate rows] so a lane holds both halves of a pair
                     w1 = lin_w(b + ".ff.net.0.proj")  # [8c, c]
@@ -373,6 +380,9 @@ class UNet2DConditionModel:
                     put_lin(b + ".ff2", b + ".ff.net.2")
             elif d[0] in ("down", "up"):
                 put_conv(d[1], d[1])
+        W["kv_all.w"] = torch.cat(kv_w, 0).contiguous()
+        del kv_w
+        self._kv_total = kv_off
         W["temb_all.w"] = bf(torch.cat(temb_w, 0))
         W["temb_all.b"] = torch.cat(temb_b, 0).contiguous()
         self._temb_total = off
@@ -490,6 +500,10 @@ class UNet2DConditionModel:
         emit(lib.mi355x_sd_silu, (emb.data_ptr(), semb.data_ptr(), B * ted, 0, 0, stream), "misc")
         temb_all = persist((B, self._temb_total), torch.float32)
         linear(_V(semb.data_ptr(), B, ted), "temb_all", _V(temb_all.data_ptr(), B, self._temb_total), flags=OUT_F32)
+        # every block's cross-attention K/V projection of encoder_hidden_states in one GEMM (attention_processor.py:711-712)
+        kv_all_t = persist((B * L, self._kv_total), torch.bfloat16)
+        kv_all = _V(kv_all_t.data_ptr(), B * L, self._kv_total)
+        linear(enc, "kv_all", kv_all, bias=False)
 
         # ---- skip / concat buffers: pre-walk ----
         S = _structure(cfg)
@@ -549,7 +563,6 @@ class UNet2DConditionModel:
             ln = _V(sc("t_ln", 2 * rows * c), rows, c)
             qkv = _V(sc("t_qkv", 2 * rows * 3 * c), rows, 3 * c)
             ao = _V(sc("t_ao", 2 * rows * c), rows, c)
-            kv = _V(sc("t_kv", 2 * B * L * 2 * c), B * L, 2 * c)
             ff = _V(sc("t_ff", 2 * rows * 4 * c), rows, 4 * c)
             for l in range(layers):
                 b = f"{name}.transformer_blocks.{l}"
@@ -560,8 +573,8 @@ class UNet2DConditionModel:
                 lnorm(hid, b + ".norm2", ln)
                 q2 = _V(qkv.p, rows, c)
                 linear(ln, b + ".attn2.q", q2, bias=False)
-                linear(enc, b + ".attn2.kv", kv, bias=False)
-                attention(q2, kv.cols(0, c), kv.cols(c, c), ao, heads, hw, L)
+                ko = self._kv_off[b]
+                attention(q2, kv_all.cols(ko, c), kv_all.cols(ko + c, c), ao, heads, hw, L)
                 linear(ao, b + ".attn2.out", hid, R=hid)
                 lnorm(hid, b + ".norm3", ln)
                 linear(ln, b + ".ff1", ff, flags=GEGLU)
