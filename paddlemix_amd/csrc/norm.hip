@@ -298,19 +298,19 @@ int launch_layernorm(const bf16* x, int rows, int C, int ldx, const float* gamma
   if ((C & 7) || (ldx & 7) || (ldy & 7) || C > 2560) return SD_ERR_UNSUPPORTED;
   const int wpb = 4;
   const int cv = C >> 3;
+  // rows per wave: as many as keeps >= 4096 waves in the grid (16 per CU) -- small problems are latency bound
+#define SD_LN_LAUNCH(NCH, R)                                                                                         \
+  hipLaunchKernelGGL((layernorm_kernel<NCH, R>), dim3((rows + wpb * R - 1) / (wpb * R)), dim3(64 * wpb), 0, stream, \
+                     x, rows, C, ldx, gamma, beta, eps, y, ldy)
+  const bool many = rows >= 4096 * 4, some = rows >= 4096 * 2;
   if (cv <= 128) {
-    const int rpb = wpb * 4;
-    hipLaunchKernelGGL((layernorm_kernel<2, 4>), dim3((rows + rpb - 1) / rpb), dim3(64 * wpb), 0, stream, x, rows, C,
-                       ldx, gamma, beta, eps, y, ldy);
+    if (many) SD_LN_LAUNCH(2, 4); else if (some) SD_LN_LAUNCH(2, 2); else SD_LN_LAUNCH(2, 1);
   } else if (cv <= 192) {
-    const int rpb = wpb * 4;
-    hipLaunchKernelGGL((layernorm_kernel<3, 4>), dim3((rows + rpb - 1) / rpb), dim3(64 * wpb), 0, stream, x, rows, C,
-                       ldx, gamma, beta, eps, y, ldy);
+    if (many) SD_LN_LAUNCH(3, 4); else if (some) SD_LN_LAUNCH(3, 2); else SD_LN_LAUNCH(3, 1);
   } else {
-    const int rpb = wpb * 2;
-    hipLaunchKernelGGL((layernorm_kernel<5, 2>), dim3((rows + rpb - 1) / rpb), dim3(64 * wpb), 0, stream, x, rows, C,
-                       ldx, gamma, beta, eps, y, ldy);
+    if (some) SD_LN_LAUNCH(5, 2); else SD_LN_LAUNCH(5, 1);
   }
+#undef SD_LN_LAUNCH
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
 

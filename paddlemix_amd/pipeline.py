@@ -1,0 +1,77 @@
+"""The denoising loop of ``StableDiffusionPipeline.__call__`` / ``StableDiffusionXLPipeline.__call__`` with the
+MI355X UNet in the ``unet`` slot.
+
+Mirrors ppdiffusers/ppdiffusers/pipelines/stable_diffusion/pipeline_stable_diffusion.py:813-908 (SDXL:
+stable_diffusion_xl/pipeline_stable_diffusion_xl.py:1039-1093): classifier-free-guidance batch doubling,
+``scheduler.scale_model_input``, the UNet call, the guidance combine (+ optional ``rescale_noise_cfg`` :69-80),
+``scheduler.step`` and ``callback_on_step_end``.  Prompt encoding (CLIP / T5) and VAE decoding are the "next rows" of
+SURVEY.md 8f and stay outside: the loop starts from ``prompt_embeds`` and returns latents (``output_type="latent"``).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional
+
+import torch
+
+
+def rescale_noise_cfg(noise_cfg, noise_pred_text, guidance_rescale=0.0):
+    dims = list(range(1, noise_pred_text.ndim))
+    std_text = noise_pred_text.std(dim=dims, keepdim=True)
+    std_cfg = noise_cfg.std(dim=dims, keepdim=True)
+    rescaled = noise_cfg * (std_text / std_cfg)
+    return guidance_rescale * rescaled + (1 - guidance_rescale) * noise_cfg
+
+
+class StableDiffusionDenoiser:
+    """``pipe = StableDiffusionDenoiser(unet, scheduler); latents = pipe(prompt_embeds=..., ...)``"""
+
+    def __init__(self, unet, scheduler):
+        self.unet, self.scheduler = unet, scheduler
+
+    def prepare_latents(self, batch_size, num_channels_latents, height, width, dtype, generator=None, latents=None,
+                        device=None):
+        shape = (batch_size, num_channels_latents, height, width)
+        if latents is None:
+            latents = torch.randn(shape, generator=generator, dtype=dtype, device=device)
+        elif tuple(latents.shape) != shape:
+            raise ValueError(f"Unexpected latents shape, got {tuple(latents.shape)}, expected {shape}")
+        return latents * self.scheduler.init_noise_sigma  # pipeline_stable_diffusion.py:581-586
+
+    @torch.no_grad()
+    def __call__(self, prompt_embeds: torch.Tensor, negative_prompt_embeds: Optional[torch.Tensor] = None,
+                 height: Optional[int] = None, width: Optional[int] = None, num_inference_steps: int = 50,
+                 guidance_scale: float = 7.5, guidance_rescale: float = 0.0, latents: Optional[torch.Tensor] = None,
+                 generator=None, added_cond_kwargs: Optional[Dict[str, torch.Tensor]] = None,
+                 negative_added_cond_kwargs: Optional[Dict[str, torch.Tensor]] = None,
+                 callback_on_step_end: Optional[Callable] = None, vae_scale_factor: int = 8):
+        do_cfg = guidance_scale > 1.0
+        if do_cfg and negative_prompt_embeds is None:
+            raise ValueError("classifier-free guidance needs `negative_prompt_embeds`")
+        B = prompt_embeds.shape[0]
+        cfg = self.unet.config
+        h = (height // vae_scale_factor) if height else cfg.sample_size
+        w = (width // vae_scale_factor) if width else cfg.sample_size
+        if latents is not None and height is None and width is None:
+            h, w = latents.shape[-2:]
+        if do_cfg:  # :813-814: [negative, positive]
+            prompt_embeds = torch.cat([negative_prompt_embeds, prompt_embeds])
+            if added_cond_kwargs is not None:
+                neg = negative_added_cond_kwargs or added_cond_kwargs
+                added_cond_kwargs = {k: torch.cat([neg[k], v]) for k, v in added_cond_kwargs.items()}
+        self.scheduler.set_timesteps(num_inference_steps)
+        latents = self.prepare_latents(B, cfg.in_channels, h, w, torch.float32, generator, latents, prompt_embeds.device)
+        for i, t in enumerate(self.scheduler.timesteps):
+            latent_model_input = torch.cat([latents] * 2) if do_cfg else latents
+            latent_model_input = self.scheduler.scale_model_input(latent_model_input, t)
+            noise_pred = self.unet(latent_model_input, t, encoder_hidden_states=prompt_embeds,
+                                   added_cond_kwargs=added_cond_kwargs, return_dict=False)[0]
+            if do_cfg:
+                noise_uncond, noise_text = noise_pred.chunk(2)
+                noise_pred = noise_uncond + guidance_scale * (noise_text - noise_uncond)
+                if guidance_rescale > 0.0:
+                    noise_pred = rescale_noise_cfg(noise_pred, noise_text, guidance_rescale)
+            latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
+            if callback_on_step_end is not None:
+                out = callback_on_step_end(self, i, t, {"latents": latents})
+                latents = out.pop("latents", latents)
+        return latents

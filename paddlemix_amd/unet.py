@@ -395,7 +395,7 @@ class UNet2DConditionModel:
         return sum(t.numel() * t.element_size() for t in self.w.values())
 
     # ------------------------------------------------------------------ plan
-    def _build_plan(self, B: int, H: int, Wd: int, L: int) -> _Plan:
+    def _build_plan(self, B: int, H: int, Wd: int, L: int, masked: bool = False) -> _Plan:
         cfg, lib, dev, W = self.cfg, self._lib, self.device, self.w
         stream = self._stream_ptr
         boc = cfg["block_out_channels"]
@@ -458,10 +458,12 @@ class UNet2DConditionModel:
             emit(lib.mi355x_sd_layernorm, (x.p, x.rows, x.C, x.ld, wp(nkey + ".g"), wp(nkey + ".b"), 1e-5, out.p,
                                            out.ld, stream), "ln")
 
-        def attention(q: _V, k: _V, v: _V, out: _V, heads, sq, skv):
+        def attention(q: _V, k: _V, v: _V, out: _V, heads, sq, skv, bias=None):
             d = q.C // heads
-            emit(lib.mi355x_sd_sdpa, (q.p, k.p, v.p, None, out.p, B, heads, sq, skv, d, sq * q.ld, q.ld, skv * k.ld,
-                                      k.ld, skv * v.ld, v.ld, sq * out.ld, out.ld, 0, 0, 0, d ** -0.5, stream),
+            # bias: additive encoder mask [B, skv] broadcast over heads and queries (unet_2d_condition.py:921-927)
+            emit(lib.mi355x_sd_sdpa, (q.p, k.p, v.p, bias, out.p, B, heads, sq, skv, d, sq * q.ld, q.ld, skv * k.ld,
+                                      k.ld, skv * v.ld, v.ld, sq * out.ld, out.ld, skv if bias else 0, 0, 0,
+                                      d ** -0.5, stream),
                  "attn", 4.0 * B * heads * sq * skv * d, f"{B}x{heads}x{sq}x{skv}x{d}")
 
         # ---- inputs (static buffers; staged by __call__) ----
@@ -473,6 +475,8 @@ class UNet2DConditionModel:
         plan.enc = persist((B * L, dx), torch.bfloat16)
         enc = _V(plan.enc.data_ptr(), B * L, dx)
         plan.out = persist((B, cfg["out_channels"], H, Wd), torch.float32)
+        plan.enc_bias = persist((B, L), torch.float32) if masked else None
+        enc_bias = plan.enc_bias.data_ptr() if masked else None
 
         # ---- time / added-condition embedding (unet_2d_condition.py:933-1030) ----
         t0 = persist((B, boc[0]), torch.bfloat16)
@@ -574,7 +578,7 @@ class UNet2DConditionModel:
                 q2 = _V(qkv.p, rows, c)
                 linear(ln, b + ".attn2.q", q2, bias=False)
                 ko = self._kv_off[b]
-                attention(q2, kv_all.cols(ko, c), kv_all.cols(ko + c, c), ao, heads, hw, L)
+                attention(q2, kv_all.cols(ko, c), kv_all.cols(ko + c, c), ao, heads, hw, L, bias=enc_bias)
                 linear(ao, b + ".attn2.out", hid, R=hid)
                 lnorm(hid, b + ".norm3", ln)
                 linear(ln, b + ".ff1", ff, flags=GEGLU)
@@ -711,15 +715,18 @@ class UNet2DConditionModel:
         _lib.check(rc)
         plan.graph = exe
 
-    def _get_plan(self, B, H, W, L) -> _Plan:
-        key = (B, H, W, L)
+    def _get_plan(self, B, H, W, L, masked: bool = False) -> _Plan:
+        key = (B, H, W, L, masked)
         if key not in self._plans:
-            self._plans[key] = self._build_plan(B, H, W, L)
+            self._plans[key] = self._build_plan(B, H, W, L, masked)
         return self._plans[key]
 
     def stage_inputs(self, plan: _Plan, sample, timestep, encoder_hidden_states, added_cond_kwargs=None,
-                     in_scale: Optional[float] = None) -> None:
+                     in_scale: Optional[float] = None, encoder_attention_mask=None) -> None:
         cfg = self.cfg
+        if plan.enc_bias is not None:
+            # (1 - mask) * -10000 as an additive bias (unet_2d_condition.py:921-927)
+            plan.enc_bias.copy_((1.0 - encoder_attention_mask.to(torch.float32)) * -10000.0, non_blocking=True)
         if torch.is_tensor(timestep):
             plan.t.copy_(timestep.reshape(-1)[:1].to(torch.float32), non_blocking=True)
         else:
@@ -760,7 +767,7 @@ class UNet2DConditionModel:
                 down_block_additional_residuals=None, mid_block_additional_residual=None,
                 encoder_attention_mask=None, return_dict: bool = True):
         for nm, v in (("class_labels", class_labels), ("timestep_cond", timestep_cond),
-                      ("attention_mask", attention_mask), ("encoder_attention_mask", encoder_attention_mask),
+                      ("attention_mask", attention_mask),
                       ("down_block_additional_residuals", down_block_additional_residuals),
                       ("mid_block_additional_residual", mid_block_additional_residual)):
             if v is not None:
@@ -769,16 +776,18 @@ class UNet2DConditionModel:
             raise _lib.MI355XError("inputs must be GPU tensors (no CPU fallback)")
         B, _, H, W = sample.shape
         L = encoder_hidden_states.shape[1]
-        plan = self._get_plan(B, H, W, L)
+        plan = self._get_plan(B, H, W, L, encoder_attention_mask is not None)
         if self._emulated:
-            self.stage_inputs(plan, sample, timestep, encoder_hidden_states, added_cond_kwargs)
+            self.stage_inputs(plan, sample, timestep, encoder_hidden_states, added_cond_kwargs,
+                              encoder_attention_mask=encoder_attention_mask)
             self._run_eager(plan)
             out = plan.out.clone()
         else:
             cur = torch.cuda.current_stream(self.device)
             self._stream.wait_stream(cur)
             with torch.cuda.stream(self._stream):
-                self.stage_inputs(plan, sample, timestep, encoder_hidden_states, added_cond_kwargs)
+                self.stage_inputs(plan, sample, timestep, encoder_hidden_states, added_cond_kwargs,
+                                  encoder_attention_mask=encoder_attention_mask)
                 out = self.run(plan).clone()
             cur.wait_stream(self._stream)
         if not return_dict:

@@ -91,7 +91,6 @@ class Emulator:
     def mi355x_sd_sdpa(self, q, k, v, bias, out, B, H, Sq, Skv, D, q_bs, q_ts, k_bs, k_ts, v_bs, v_ts, o_bs, o_ts,
                        bias_bs, bias_hs, bias_qs, scale, stream):
         self.calls.append("sdpa")
-        assert bias is None or bias == 0, "emulator: bias path not needed by the UNet program"
 
         def view(p, S, bs, ts):
             n = (B - 1) * bs + (S - 1) * ts + H * D
@@ -99,6 +98,9 @@ class Emulator:
 
         qq, kk, vv = view(q, Sq, q_bs, q_ts).float(), view(k, Skv, k_bs, k_ts).float(), view(v, Skv, v_bs, v_ts).float()
         s = torch.einsum("bqhd,bkhd->bhqk", qq, kk) * scale
+        if bias:
+            assert bias_hs == 0 and bias_qs == 0 and bias_bs == Skv, "emulator: only the [B, Skv] encoder mask form"
+            s = s + _flat(bias, B * Skv, torch.float32).reshape(B, 1, 1, Skv)
         p = torch.softmax(s, -1)
         o = torch.einsum("bhqk,bkhd->bqhd", p, vv)
         view(out, Sq, o_bs, o_ts).copy_(o.to(torch.bfloat16))

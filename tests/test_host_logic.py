@@ -80,3 +80,25 @@ def test_no_fallback_without_gpu():
     from paddlemix_amd._lib import MI355XError
     with pytest.raises(MI355XError):
         UNet2DConditionModel(TINY, synth_unet_params(TINY))
+
+
+def test_encoder_attention_mask_semantics():
+    """test_model_xattn_mask (ppdiffusers/tests/models/test_models_unet_2d_condition.py:486-515): keep-all == no mask;
+    masking the last token == truncating it; and the masked forward matches the oracle."""
+    cfg = TINY
+    P = synth_unet_params(cfg, seed=1234)
+    Pb = {k: v.to(torch.bfloat16).float() if v.dim() > 1 else v for k, v in P.items()}
+    sample, enc, _ = _inputs(cfg, 2, 8, 8, L=7)
+    model = UNet2DConditionModel(cfg, P, _test_backend=Emulator())
+    none = model(sample, 10, enc).sample
+    keep = model(sample, 10, enc, encoder_attention_mask=torch.ones(2, 7)).sample
+    assert torch.allclose(none, keep, rtol=1e-3, atol=1e-5)
+    m = torch.ones(2, 7)
+    m[:, -1] = 0
+    masked = model(sample, 10, enc, encoder_attention_mask=m).sample
+    trunc = model(sample, 10, enc[:, :-1]).sample
+    assert torch.allclose(masked, trunc, rtol=1e-3, atol=1e-3)
+    ref = U.unet_forward(Pb, cfg, sample, 10, enc, encoder_attention_mask=m)
+    assert _rel(masked, ref) < 2e-2
+    with pytest.raises(NotImplementedError):
+        model(sample, 10, enc, attention_mask=torch.ones(2, 64))

@@ -1,0 +1,67 @@
+"""Config #1 of BASELINE.json as plumbing: the StableDiffusionPipeline denoising loop (CFG, DDIM, 20 steps) through
+the product host code, checked step by step against the same loop built from the oracle's UNet + numpy scheduler
+(CPU: the UNet program is interpreted by tests/abi_emulator.py; the GPU variant is in test_gpu_unet.py)."""
+import numpy as np
+import torch
+
+from oracle import schedulers_ref as S
+from oracle import unet_ref as U
+from paddlemix_amd.pipeline import StableDiffusionDenoiser
+from paddlemix_amd.schedulers import DDIMScheduler, EulerDiscreteScheduler
+from paddlemix_amd.unet import UNet2DConditionModel, synth_unet_params
+from tests.abi_emulator import Emulator
+from tests.configs import MINI_XL, TINY
+
+SCHED = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", steps_offset=1)
+
+
+def test_sd_ddim_cfg_loop_matches_oracle_loop():
+    cfg = TINY
+    P = synth_unet_params(cfg, seed=1234)
+    Pb = {k: v.to(torch.bfloat16).float() if v.dim() > 1 else v for k, v in P.items()}
+    g = torch.Generator().manual_seed(0)
+    pe, ne = torch.randn(1, 7, 64, generator=g), torch.randn(1, 7, 64, generator=g)
+    lat0 = torch.randn(1, 4, 8, 8, generator=g)
+    steps, gs = 20, 7.5
+    pipe = StableDiffusionDenoiser(UNet2DConditionModel(cfg, P, _test_backend=Emulator()),
+                                   DDIMScheduler(clip_sample=False, set_alpha_to_one=False, **SCHED))
+    seen = []
+    out = pipe(pe, ne, num_inference_steps=steps, guidance_scale=gs, latents=lat0.clone(),
+               callback_on_step_end=lambda p, i, t, kw: (seen.append(int(t)), kw)[1])
+    # oracle loop
+    sch = S.DDIMRef(clip_sample=False, set_alpha_to_one=False, **SCHED)
+    sch.set_timesteps(steps)
+    x = lat0.numpy() * sch.init_noise_sigma
+    emb = torch.cat([ne, pe])
+    for t in sch.timesteps:
+        xin = torch.from_numpy(np.concatenate([x, x]))
+        eps = U.unet_forward(Pb, cfg, xin, int(t), emb).numpy()
+        eps = eps[:1] + gs * (eps[1:] - eps[:1])
+        x = sch.step(eps, t, x)
+    assert seen == [int(t) for t in sch.timesteps] and len(seen) == steps
+    rel = np.linalg.norm(out.numpy() - x) / np.linalg.norm(x)
+    # 20 chained bf16 UNet evaluations with guidance 7.5 amplifying differences: stated tolerance 5e-2 on latents
+    assert rel < 5e-2, rel
+
+
+def test_sdxl_euler_loop_runs_and_matches():
+    cfg = MINI_XL
+    P = synth_unet_params(cfg, seed=1234)
+    Pb = {k: v.to(torch.bfloat16).float() if v.dim() > 1 else v for k, v in P.items()}
+    g = torch.Generator().manual_seed(1)
+    pe = torch.randn(1, 77, cfg["cross_attention_dim"], generator=g)
+    td = cfg["projection_class_embeddings_input_dim"] - 6 * cfg["addition_time_embed_dim"]
+    added = dict(text_embeds=torch.randn(1, td, generator=g), time_ids=torch.tensor([[256., 256., 0., 0., 256., 256.]]))
+    lat0 = torch.randn(1, 4, 8, 8, generator=g)
+    kw = dict(timestep_spacing="leading", **SCHED)
+    pipe = StableDiffusionDenoiser(UNet2DConditionModel(cfg, P, _test_backend=Emulator()), EulerDiscreteScheduler(**kw))
+    out = pipe(pe, num_inference_steps=4, guidance_scale=1.0, latents=lat0.clone(), added_cond_kwargs=added)
+    sch = S.EulerRef(**kw)
+    sch.set_timesteps(4)
+    x = lat0.numpy() * sch.init_noise_sigma
+    for t in sch.timesteps:
+        xin = torch.from_numpy(sch.scale_model_input(x, t))
+        eps = U.unet_forward(Pb, cfg, xin, float(t), pe, added_cond_kwargs=added).numpy()
+        x = sch.step(eps, t, x)
+    rel = np.linalg.norm(out.numpy() - x) / np.linalg.norm(x)
+    assert rel < 3e-2, rel
