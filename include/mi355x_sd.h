@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MI355X_SD_ABI_VERSION 1
+#define MI355X_SD_ABI_VERSION 2
 #define MI355X_SD_OK 0
 #define MI355X_SD_ERR_INVALID 1      /* bad argument (shape <= 0, null pointer ...)          */
 #define MI355X_SD_ERR_UNSUPPORTED 2  /* well-formed but outside the implemented configurations */
@@ -41,6 +41,7 @@ int mi355x_sd_init(int device);
 /* flags for mi355x_sd_linear / mi355x_sd_conv3x3 */
 #define MI355X_SD_GEGLU 1    /* W/bias rows interleaved [16 value | 16 gate]; writes N/2 columns value*gelu_erf(gate) */
 #define MI355X_SD_OUT_F32 2  /* C is fp32 */
+#define MI355X_SD_GELU_TANH 8 /* tanh-GELU applied to the final value (FeedForward "gelu-approximate", PPD/models/attention.py:648-649) */
 #define MI355X_SD_SILU 4     /* SiLU applied to the final value (TimestepEmbedding.act, PPD/models/embeddings.py:283-295) */
 
 /* C[M,N] = ((A[M,K] . W[N,K]^T) + bias[N] + rowbias[m / rows_per_batch][N] + R[M,N]) * out_scale
@@ -51,6 +52,27 @@ int mi355x_sd_init(int device);
 int mi355x_sd_linear(const void* A, int lda, const void* W, void* C, int ldc, int M, int N, int K,
                      const float* bias, const float* rowbias, int rows_per_batch, int ld_rowbias,
                      const void* R, int ldr, float out_scale, int flags, void* stream);
+
+/* mi355x_sd_linear plus what the SD3 MMDiT blocks (PPD/models/attention.py:164-214, attention_processor.py:916-983) need:
+ *   gate  : out = R + gate[m / rows_per_batch][n] * (acc + bias)     (adaLN-Zero gated residuals, attention.py:181-196)
+ *   a_/c_ rows_per_batch + batch_stride: row m of A (C) lives at (m / rpb) * batch_stride + (m % rpb) * lda (ldc) -- the
+ *   projections of the image and the text tokens read / write one joint [B, S_img + S_txt, .] buffer in place, which is
+ *   the fused split + concat of paddlemix/triton_ops/triton_ops.py:1652-1752 (split_concat) folded into the GEMMs. */
+int mi355x_sd_linear_ex(const void* A, int lda, int a_rows_per_batch, int64_t a_batch_stride, const void* W, void* C,
+                        int ldc, int c_rows_per_batch, int64_t c_batch_stride, int M, int N, int K, const float* bias,
+                        const float* rowbias, int ld_rowbias, const float* gate, int ld_gate, int rows_per_batch,
+                        const void* R, int ldr, float out_scale, int flags, void* stream);
+
+/* y = LayerNorm_noaffine(x) * (1 + scale[b]) + shift[b], b = row / rows_per_batch, scale/shift fp32 rows of stride ld_mod.
+ * AdaLayerNormZero / AdaLayerNormContinuous (PPD/models/normalization.py:72-86, 190-202) and the Triton op
+ * adaptive_layer_norm (paddlemix/triton_ops/triton_ops.py:981-1139). */
+int mi355x_sd_adaln(const void* x, int rows, int C, int ldx, const float* scale, const float* shift, int ld_mod,
+                    int rows_per_batch, float eps, void* y, int ldy, void* stream);
+/* PatchEmbed.proj operand (PPD/models/embeddings.py:148-155, 209-219): NCHW fp32 -> rows [B*(H/p)*(W/p), C*p*p] bf16,
+ * columns ordered (c, py, px) like the flattened conv weight; and the inverse at the output (transformer_sd3.py:349-356):
+ * rows [B*h*w, p*p*C] ordered (py, px, c) -> NCHW fp32. */
+int mi355x_sd_patchify(const float* x_nchw, int B, int C, int H, int W, int patch, void* out, int ldo, void* stream);
+int mi355x_sd_unpatchify(const void* x, int ldx, int B, int C, int H, int W, int patch, float* out_nchw, void* stream);
 
 /* 3x3 convolution, padding 1, stride 1|2, as an implicit GEMM over an NHWC source [B][Hs][Ws][ldx>=Cin];
  * `upsample` = 1 folds F.interpolate(scale_factor=2, mode="nearest") (PPD/models/resnet.py:169-218) into the

@@ -1,0 +1,207 @@
+"""torch-CPU restatement of ppdiffusers' SD3Transformer2DModel (MMDiT) forward (oracle; TEST INFRASTRUCTURE ONLY).
+
+PARITY UNPINNED: the reference holds no RNG-free known-answer vectors for this model (its test,
+ppdiffusers/tests/models/test_models_transformer_sd3.py:25-79, checks shapes only) and Paddle cannot run here, so this
+restatement is anchored on a line-by-line reading of the modules below and on the identities the reference itself
+relies on (fused op == unfused expression, paddlemix/triton_ops/triton_ops.py:790-808, 1031-1059).
+
+Follows (paths relative to /root/reference/ppdiffusers/ppdiffusers/models/):
+  SD3Transformer2DModel.forward        transformer_sd3.py:279-365  (ctor :65-124)
+  PatchEmbed + cropped sincos pos-emb  embeddings.py:67-119, 122-247
+  CombinedTimestepTextProjEmbeddings   embeddings.py:530-546 (Timesteps(256, flip_sin_to_cos=True, shift 0), TimestepEmbedding,
+                                       PixArtAlphaTextProjection(act "silu") :889-915)
+  JointTransformerBlock.forward        attention.py:164-214 (ctor :108-157)
+  JointAttnProcessor2_5.__call__       attention_processor.py:916-983
+  AdaLayerNormZero / Continuous        normalization.py:72-86, 190-202
+  FeedForward("gelu-approximate")      attention.py:648-649, activations.py:59-80
+Parameters: flat dict keyed by the reference's names, Paddle layouts (Linear weight [in,out], conv OIHW).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .unet_ref import get_timestep_embedding, linear
+
+Tensor = torch.Tensor
+Params = Dict[str, Tensor]
+
+SD3_DEFAULTS = dict(sample_size=128, patch_size=2, in_channels=16, num_layers=18, attention_head_dim=64,
+                    num_attention_heads=18, joint_attention_dim=4096, caption_projection_dim=1152,
+                    pooled_projection_dim=2048, out_channels=16, pos_embed_max_size=96)
+
+
+def normalize_config(config: dict) -> dict:
+    cfg = dict(SD3_DEFAULTS)
+    cfg.update({k: v for k, v in config.items() if not k.startswith("_")})
+    cfg["inner_dim"] = cfg["num_attention_heads"] * cfg["attention_head_dim"]
+    if cfg["caption_projection_dim"] != cfg["inner_dim"]:
+        raise ValueError("caption_projection_dim must equal heads * head_dim (the context stream shares the block width)")
+    return cfg
+
+
+# ---- embeddings.py:67-119 (numpy, float64 omega like the reference) -------------------------------------------------
+def get_1d_sincos_pos_embed_from_grid(embed_dim, pos):
+    omega = np.arange(embed_dim // 2, dtype=np.float64)
+    omega /= embed_dim / 2.0
+    omega = 1.0 / 10000 ** omega
+    out = np.einsum("m,d->md", pos.reshape(-1), omega)
+    return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+
+
+def get_2d_sincos_pos_embed(embed_dim, grid_size, base_size=16, interpolation_scale=1.0):
+    if isinstance(grid_size, int):
+        grid_size = (grid_size, grid_size)
+    grid_h = np.arange(grid_size[0], dtype=np.float32) / (grid_size[0] / base_size) / interpolation_scale
+    grid_w = np.arange(grid_size[1], dtype=np.float32) / (grid_size[1] / base_size) / interpolation_scale
+    grid = np.stack(np.meshgrid(grid_w, grid_h), axis=0)  # "here w goes first"
+    grid = grid.reshape([2, 1, grid_size[1], grid_size[0]])
+    emb_h = get_1d_sincos_pos_embed_from_grid(embed_dim // 2, grid[0])
+    emb_w = get_1d_sincos_pos_embed_from_grid(embed_dim // 2, grid[1])
+    return np.concatenate([emb_h, emb_w], axis=1)
+
+
+def cropped_pos_embed(cfg: dict, height: int, width: int) -> Tensor:
+    """PatchEmbed.pos_embed buffer (ctor :184-193) + cropped_pos_embed (:195-216); height/width in latent pixels."""
+    D, mx, p = cfg["inner_dim"], cfg["pos_embed_max_size"], cfg["patch_size"]
+    base = cfg["sample_size"] // p
+    pe = torch.from_numpy(get_2d_sincos_pos_embed(D, mx, base_size=base)).to(torch.float32)
+    h, w = height // p, width // p
+    if h > mx or w > mx:
+        raise ValueError("latent larger than pos_embed_max_size")
+    top, left = (mx - h) // 2, (mx - w) // 2
+    return pe.reshape(mx, mx, D)[top:top + h, left:left + w].reshape(1, h * w, D)
+
+
+def layer_norm_noaffine(x: Tensor, eps: float = 1e-6) -> Tensor:
+    return F.layer_norm(x, (x.shape[-1],), None, None, eps)
+
+
+def joint_block(P: Params, name: str, x: Tensor, c: Tensor, temb: Tensor, heads: int, context_pre_only: bool):
+    """JointTransformerBlock.forward (attention.py:164-214)."""
+    st = F.silu(temb)
+    shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = linear(P, name + ".norm1.linear", st).chunk(6, dim=1)
+    nx = layer_norm_noaffine(x) * (1 + scale_msa[:, None]) + shift_msa[:, None]
+    if context_pre_only:  # AdaLayerNormContinuous: scale first, then shift (normalization.py:192-193)
+        c_scale, c_shift = linear(P, name + ".norm1_context.linear", st).chunk(2, dim=1)
+        nc = layer_norm_noaffine(c) * (1 + c_scale)[:, None, :] + c_shift[:, None, :]
+    else:
+        c_shift_msa, c_scale_msa, c_gate_msa, c_shift_mlp, c_scale_mlp, c_gate_mlp = \
+            linear(P, name + ".norm1_context.linear", st).chunk(6, dim=1)
+        nc = layer_norm_noaffine(c) * (1 + c_scale_msa[:, None]) + c_shift_msa[:, None]
+
+    # JointAttnProcessor2_5 (attention_processor.py:938-981)
+    B, S1, D = nx.shape
+    q = torch.cat([linear(P, name + ".attn.to_q", nx), linear(P, name + ".attn.add_q_proj", nc)], dim=1)
+    k = torch.cat([linear(P, name + ".attn.to_k", nx), linear(P, name + ".attn.add_k_proj", nc)], dim=1)
+    v = torch.cat([linear(P, name + ".attn.to_v", nx), linear(P, name + ".attn.add_v_proj", nc)], dim=1)
+    d = D // heads
+    qh, kh, vh = (t.reshape(B, -1, heads, d).permute(0, 2, 1, 3) for t in (q, k, v))
+    s = (qh @ kh.transpose(-1, -2)) / math.sqrt(d)
+    o = (torch.softmax(s, dim=-1) @ vh).permute(0, 2, 1, 3).reshape(B, -1, D)
+    attn_x, attn_c = o[:, :S1], o[:, S1:]
+    attn_x = linear(P, name + ".attn.to_out.0", attn_x)
+
+    x = x + gate_msa[:, None] * attn_x
+    nx = layer_norm_noaffine(x) * (1 + scale_mlp[:, None]) + shift_mlp[:, None]
+    ff = linear(P, name + ".ff.net.2", F.gelu(linear(P, name + ".ff.net.0.proj", nx), approximate="tanh"))
+    x = x + gate_mlp[:, None] * ff
+    if context_pre_only:
+        return None, x
+    attn_c = linear(P, name + ".attn.to_add_out", attn_c)
+    c = c + c_gate_msa[:, None] * attn_c
+    nc = layer_norm_noaffine(c) * (1 + c_scale_mlp[:, None]) + c_shift_mlp[:, None]
+    ffc = linear(P, name + ".ff_context.net.2", F.gelu(linear(P, name + ".ff_context.net.0.proj", nc), approximate="tanh"))
+    c = c + c_gate_mlp[:, None] * ffc
+    return c, x
+
+
+def sd3_forward(P: Params, config: dict, hidden_states: Tensor, encoder_hidden_states: Tensor,
+                pooled_projections: Tensor, timestep) -> Tensor:
+    """SD3Transformer2DModel.forward (transformer_sd3.py:279-365) -> sample [B, out_channels, H, W]."""
+    cfg = normalize_config(config)
+    B, _, H, W = hidden_states.shape
+    p, D, heads = cfg["patch_size"], cfg["inner_dim"], cfg["num_attention_heads"]
+    # pos_embed: conv patchify + cropped sincos (embeddings.py:209-247)
+    x = F.conv2d(hidden_states, P["pos_embed.proj.weight"], P["pos_embed.proj.bias"], stride=p)
+    x = x.flatten(2).transpose(1, 2)
+    x = x + cropped_pos_embed(cfg, H, W).to(x.dtype)
+    # time_text_embed (embeddings.py:538-546)
+    if not torch.is_tensor(timestep):
+        timestep = torch.tensor([timestep], dtype=torch.float32)
+    t = timestep.reshape(-1).expand(B)
+    tproj = get_timestep_embedding(t, 256, flip_sin_to_cos=True, downscale_freq_shift=0).to(pooled_projections.dtype)
+    temb = linear(P, "time_text_embed.timestep_embedder.linear_2",
+                  F.silu(linear(P, "time_text_embed.timestep_embedder.linear_1", tproj)))
+    temb = temb + linear(P, "time_text_embed.text_embedder.linear_2",
+                         F.silu(linear(P, "time_text_embed.text_embedder.linear_1", pooled_projections)))
+    c = linear(P, "context_embedder", encoder_hidden_states)
+    n = cfg["num_layers"]
+    for i in range(n):
+        c, x = joint_block(P, f"transformer_blocks.{i}", x, c, temb, heads, context_pre_only=(i == n - 1))
+    # norm_out (AdaLayerNormContinuous, no affine, eps 1e-6) + proj_out + unpatchify (:341-356)
+    scale, shift = linear(P, "norm_out.linear", F.silu(temb)).chunk(2, dim=1)
+    x = layer_norm_noaffine(x) * (1 + scale)[:, None, :] + shift[:, None, :]
+    x = linear(P, "proj_out", x)
+    h, w = H // p, W // p
+    oc = cfg["out_channels"]
+    x = x.reshape(B, h, w, p, p, oc).permute(0, 5, 1, 3, 2, 4)
+    return x.reshape(B, oc, h * p, w * p)
+
+
+def sd3_param_shapes(config: dict) -> Dict[str, tuple]:
+    cfg = normalize_config(config)
+    D, p, n = cfg["inner_dim"], cfg["patch_size"], cfg["num_layers"]
+    S: Dict[str, tuple] = {}
+
+    def lin(name, i, o):
+        S[name + ".weight"] = (i, o)
+        S[name + ".bias"] = (o,)
+
+    S["pos_embed.proj.weight"] = (D, cfg["in_channels"], p, p)
+    S["pos_embed.proj.bias"] = (D,)
+    lin("time_text_embed.timestep_embedder.linear_1", 256, D)
+    lin("time_text_embed.timestep_embedder.linear_2", D, D)
+    lin("time_text_embed.text_embedder.linear_1", cfg["pooled_projection_dim"], D)
+    lin("time_text_embed.text_embedder.linear_2", D, D)
+    lin("context_embedder", cfg["joint_attention_dim"], D)
+    for i in range(n):
+        b = f"transformer_blocks.{i}"
+        last = i == n - 1
+        lin(b + ".norm1.linear", D, 6 * D)
+        lin(b + ".norm1_context.linear", D, 2 * D if last else 6 * D)
+        for nm in ("to_q", "to_k", "to_v", "add_k_proj", "add_v_proj", "add_q_proj", "to_out.0"):
+            lin(b + ".attn." + nm, D, D)
+        if not last:
+            lin(b + ".attn.to_add_out", D, D)
+        lin(b + ".ff.net.0.proj", D, 4 * D)
+        lin(b + ".ff.net.2", 4 * D, D)
+        if not last:
+            lin(b + ".ff_context.net.0.proj", D, 4 * D)
+            lin(b + ".ff_context.net.2", 4 * D, D)
+    lin("norm_out.linear", D, 2 * D)
+    lin("proj_out", D, p * p * cfg["out_channels"])
+    return S
+
+
+def synth_sd3_params(config: dict, seed: int = 1234, dtype=torch.float32) -> Params:
+    """Synthetic weights: linear/conv N(0, 1/fan_in), biases N(0, 0.02^2); the adaLN modulation linears are drawn at
+    0.3/sqrt(fan_in) so (1 + scale) stays positive-ish and the gates are O(0.3) (random, not the zero-init of training)."""
+    g = torch.Generator().manual_seed(seed)
+    P: Params = {}
+    for name, shape in sd3_param_shapes(config).items():
+        r = torch.randn(shape, generator=g)
+        if name.endswith(".bias"):
+            t = r * 0.02
+        elif len(shape) == 2:
+            t = r / math.sqrt(shape[0])
+            if ".norm1" in name or name.startswith("norm_out"):
+                t = t * 0.3
+        else:
+            t = r / math.sqrt(shape[1] * shape[2] * shape[3])
+        P[name] = t.to(dtype)
+    return P

@@ -8,8 +8,8 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p, POINTER
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi355x_sd.so")
 
-ABI_VERSION = 1
-GEGLU, OUT_F32, SILU = 1, 2, 4
+ABI_VERSION = 2
+GEGLU, OUT_F32, SILU, GELU_TANH = 1, 2, 4, 8
 
 # name -> (restype, argtypes); must list every symbol include/mi355x_sd.h declares (tests/test_abi.py checks)
 SIGNATURES = {
@@ -18,6 +18,13 @@ SIGNATURES = {
     "mi355x_sd_init": (c_int, [c_int]),
     "mi355x_sd_linear": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                  c_int, c_int, c_void_p, c_int, c_float, c_int, c_void_p]),
+    "mi355x_sd_linear_ex": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int,
+                                    c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_float,
+                                    c_int, c_void_p]),
+    "mi355x_sd_adaln": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_int,
+                                c_void_p]),
+    "mi355x_sd_patchify": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "mi355x_sd_unpatchify": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mi355x_sd_conv3x3": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
                                   c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_float, c_int, c_void_p]),
     "mi355x_sd_sdpa": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

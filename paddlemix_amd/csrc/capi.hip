@@ -95,6 +95,45 @@ int mi355x_sd_linear(const void* A, int lda, const void* W, void* C, int ldc, in
   return finish(launch_gemm(g, S(stream)), "mi355x_sd_linear");
 }
 
+int mi355x_sd_linear_ex(const void* A, int lda, int a_rows_per_batch, int64_t a_batch_stride, const void* W, void* C,
+                        int ldc, int c_rows_per_batch, int64_t c_batch_stride, int M, int N, int K, const float* bias,
+                        const float* rowbias, int ld_rowbias, const float* gate, int ld_gate, int rows_per_batch,
+                        const void* R, int ldr, float out_scale, int flags, void* stream) {
+  if (!A || !W || !C) return fail(SD_ERR_INVALID, "mi355x_sd_linear_ex: null pointer");
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = (const bf16*)A; g.W = (const bf16*)W; g.C = C;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc;
+  g.a_rpb = a_rows_per_batch; g.a_bstride = (long)a_batch_stride;
+  g.c_rpb = c_rows_per_batch; g.c_bstride = (long)c_batch_stride;
+  g.bias = bias; g.rowbias = rowbias; g.rows_per_batch = rows_per_batch; g.ld_rowbias = ld_rowbias;
+  g.gate = gate; g.ld_gate = ld_gate;
+  g.R = (const bf16*)R; g.ldr = ldr; g.out_scale = out_scale;
+  g.geglu = (flags & MI355X_SD_GEGLU) ? 1 : 0;
+  g.out_f32 = (flags & MI355X_SD_OUT_F32) ? 1 : 0;
+  g.silu = (flags & MI355X_SD_SILU) ? 1 : 0;
+  g.gelu_tanh = (flags & MI355X_SD_GELU_TANH) ? 1 : 0;
+  return finish(launch_gemm(g, S(stream)), "mi355x_sd_linear_ex");
+}
+
+int mi355x_sd_adaln(const void* x, int rows, int C, int ldx, const float* scale, const float* shift, int ld_mod,
+                    int rows_per_batch, float eps, void* y, int ldy, void* stream) {
+  if (!x || !scale || !shift || !y) return fail(SD_ERR_INVALID, "mi355x_sd_adaln: null pointer");
+  return finish(launch_adaln((const bf16*)x, rows, C, ldx, scale, shift, ld_mod, rows_per_batch, eps, (bf16*)y, ldy,
+                             S(stream)),
+                "mi355x_sd_adaln");
+}
+
+int mi355x_sd_patchify(const float* x_nchw, int B, int C, int H, int W, int patch, void* out, int ldo, void* stream) {
+  if (!x_nchw || !out) return fail(SD_ERR_INVALID, "mi355x_sd_patchify: null pointer");
+  return finish(launch_patchify(x_nchw, B, C, H, W, patch, (bf16*)out, ldo, S(stream)), "mi355x_sd_patchify");
+}
+
+int mi355x_sd_unpatchify(const void* x, int ldx, int B, int C, int H, int W, int patch, float* out_nchw, void* stream) {
+  if (!x || !out_nchw) return fail(SD_ERR_INVALID, "mi355x_sd_unpatchify: null pointer");
+  return finish(launch_unpatchify((const bf16*)x, ldx, B, C, H, W, patch, out_nchw, S(stream)), "mi355x_sd_unpatchify");
+}
+
 int mi355x_sd_conv3x3(const void* X, int ldx, int B, int Hs, int Ws, int Cin, int stride, int upsample, const void* W,
                       void* C, int ldc, int Cout, const float* bias, const float* rowbias, int ld_rowbias,
                       const void* R, int ldr, float out_scale, int flags, void* stream) {

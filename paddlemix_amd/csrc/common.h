@@ -30,6 +30,12 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)
 // erf-GELU (paddle F.gelu(approximate=False)); erff is accurate to fp32 ulp-level.
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
+// tanh-GELU (paddle F.gelu(approximate=True)): 0.5 x (1 + tanh(u)) = x * sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3)
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+  return x / (1.0f + __expf(-2.0f * u));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

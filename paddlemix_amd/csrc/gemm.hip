@@ -91,7 +91,9 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_bf16_kernel(const GemmAr
       gox[i] = rem - goy[i] * p.Wo;
       ga_base[i] = p.A + (size_t)b * p.Hs * p.Ws * p.lda;
     } else {
-      ga_base[i] = p.A + (size_t)(ga_ok[i] ? m : 0) * p.lda + g_cg * 8;
+      const int mm = ga_ok[i] ? m : 0;
+      const size_t arow = p.a_rpb ? (size_t)(mm / p.a_rpb) * p.a_bstride + (size_t)(mm % p.a_rpb) * p.lda : (size_t)mm * p.lda;
+      ga_base[i] = p.A + arow + g_cg * 8;
       goy[i] = gox[i] = 0;
     }
   }
@@ -218,7 +220,7 @@ static int pick_tile(const GemmArgs& a) {
   int best = 128;
   double best_cost = 1e30;
   for (const TileChoice& c : cand) {
-    if (c.id == 257 && ((a.K & 63) || (a.conv && (a.Cin & 63)) || !wide_ok)) continue;
+    if (c.id == 257 && ((a.K & 63) || (a.conv && (a.Cin & 63)) || !wide_ok || a.a_rpb)) continue;
     if (a.geglu && c.id == 160) continue;   // odd number of 16-column tiles per wave
     const long tiles = (long)((a.M + c.bm - 1) / c.bm) * ((a.N + c.bn - 1) / c.bn);
     const long per_cu = (tiles + 255) / 256;
@@ -236,7 +238,9 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return SD_ERR_INVALID;
   if ((a.K & 7) || (a.N & 3) || (a.lda & 7) || (a.ldc & 3)) return SD_ERR_UNSUPPORTED;
   if (a.R && (a.ldr & 3)) return SD_ERR_UNSUPPORTED;
-  if (a.geglu && ((a.N & 31) || a.out_f32 || a.R || a.rowbias)) return SD_ERR_UNSUPPORTED;
+  if (a.geglu && ((a.N & 31) || a.out_f32 || a.R || a.rowbias || a.gate)) return SD_ERR_UNSUPPORTED;
+  if ((a.gate || a.rowbias) && a.rows_per_batch <= 0) return SD_ERR_INVALID;
+  if ((a.a_rpb && (a.conv || (a.a_bstride & 7))) || (a.c_rpb && (a.c_bstride & 3))) return SD_ERR_UNSUPPORTED;
   if (a.conv) {
     if (a.K != 9 * a.Cin || (a.Cin & 7) || (a.stride != 1 && a.stride != 2) || (a.up != 0 && a.up != 1))
       return SD_ERR_UNSUPPORTED;
@@ -244,7 +248,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   }
   if (a.rowbias && a.rows_per_batch <= 0) return SD_ERR_INVALID;
   const int tile = pick_tile(a);
-  if (tile == 257 && !((a.K & 63) || (a.conv && (a.Cin & 63)))) return launch_gemm256(a, stream);
+  if (tile == 257 && !((a.K & 63) || (a.conv && (a.Cin & 63)) || a.a_rpb)) return launch_gemm256(a, stream);
   if (tile == 256 || tile == 257) return a.conv ? launch_cfg<true, Cfg256>(a, stream) : launch_cfg<false, Cfg256>(a, stream);
   if (tile == 160 && !a.geglu)
     return a.conv ? launch_cfg<true, Cfg256x160>(a, stream) : launch_cfg<false, Cfg256x160>(a, stream);

@@ -20,6 +20,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TN
     const int m = m_wave + tm * 16 + (lane & 15);
     if (m >= p.M) continue;
     const float* rb = p.rowbias ? p.rowbias + (size_t)(m / p.rows_per_batch) * p.ld_rowbias : nullptr;
+    const float* gt = p.gate ? p.gate + (size_t)(m / p.rows_per_batch) * p.ld_gate : nullptr;
+    const size_t crow = p.c_rpb ? (size_t)(m / p.c_rpb) * p.c_bstride + (size_t)(m % p.c_rpb) * p.ldc : (size_t)m * p.ldc;
     if (p.geglu) {
 #pragma unroll
       for (int tp = 0; tp < TN / 2; ++tp) {
@@ -35,7 +37,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TN
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = h[r] * gelu_erf_f(g[r]);
         u32x2 pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3])};
-        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n_out) = pk;
+        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16*>(p.C) + crow + n_out) = pk;
       }
     } else {
 #pragma unroll
@@ -45,6 +47,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TN
         f32x4 v = acc[tn][tm];
         if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
         if (rb) v += *reinterpret_cast<const f32x4*>(rb + n);
+        if (gt) v *= *reinterpret_cast<const f32x4*>(gt + n);
         if (p.R) {
           const bf16x4 r4 = *reinterpret_cast<const bf16x4*>(p.R + (size_t)m * p.ldr + n);
           v[0] += (float)r4[0];
@@ -59,11 +62,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TN
           v[2] = silu_f(v[2]);
           v[3] = silu_f(v[3]);
         }
+        if (p.gelu_tanh) {
+          v[0] = gelu_tanh_f(v[0]);
+          v[1] = gelu_tanh_f(v[1]);
+          v[2] = gelu_tanh_f(v[2]);
+          v[3] = gelu_tanh_f(v[3]);
+        }
         if (p.out_f32) {
-          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = v;
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + crow + n) = v;
         } else {
           u32x2 pk = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
-          *reinterpret_cast<u32x2*>(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n) = pk;
+          *reinterpret_cast<u32x2*>(reinterpret_cast<bf16*>(p.C) + crow + n) = pk;
         }
       }
     }

@@ -29,6 +29,13 @@ struct GemmArgs {
   int geglu;              // W/bias rows interleaved [16 value | 16 gate]; writes N/2 columns value*gelu(gate)
   int out_f32;
   int silu;               // SiLU applied last
+  int gelu_tanh;          // tanh-GELU applied last (FeedForward "gelu-approximate", attention.py:648-649)
+  const float* gate;      // optional per-(batch, channel) gate: out = R + gate[m / rows_per_batch][n] * (acc + bias)
+  int ld_gate;            //   (adaLN-Zero gated residual, attention.py:181-196)
+  int a_rpb;              // A row m lives at (m / a_rpb) * a_bstride + (m % a_rpb) * lda   (0: plain m * lda)
+  long a_bstride;
+  int c_rpb;              // same remap for the C rows (joint text+image token buffers of the MMDiT attention)
+  long c_bstride;
   int dbg;                // ablation switches of gemm256.hip (MI355X_SD_GEMM_DBG; 0 in production)
 };
 int launch_gemm(const GemmArgs& a, hipStream_t stream);
@@ -54,6 +61,11 @@ int launch_groupnorm_stats(const bf16* x, int B, int HW, int C, int ldx, int gro
 int groupnorm_partial_floats(int B, int HW, int C);
 int launch_scale_shift_act(const bf16* x, int B, int HW, int C, int ldx, const float* scale_shift, int silu, bf16* y,
                            int ldy, hipStream_t stream);
+// y = LN(x) * (1 + scale[b]) + shift[b]  (no affine; b = row / rows_per_batch): AdaLayerNormZero / Continuous
+int launch_adaln(const bf16* x, int rows, int C, int ldx, const float* scale, const float* shift, int ld_mod,
+                 int rows_per_batch, float eps, bf16* y, int ldy, hipStream_t stream);
+int launch_patchify(const float* x_nchw, int B, int C, int H, int W, int p, bf16* out, int ldo, hipStream_t stream);
+int launch_unpatchify(const bf16* x, int ldx, int B, int C, int H, int W, int p, float* out_nchw, hipStream_t stream);
 int launch_layernorm(const bf16* x, int rows, int C, int ldx, const float* gamma, const float* beta, float eps, bf16* y,
                      int ldy, hipStream_t stream);
 

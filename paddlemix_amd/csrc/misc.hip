@@ -223,4 +223,51 @@ int launch_axpby(const float* x, const float* y, float* out, const float* coef, 
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
 
+// PatchEmbed.proj as a GEMM operand (embeddings.py:148-155, 209-219): x NCHW fp32 -> rows [B*(H/p)*(W/p), C*p*p] bf16 with
+// the column order (c, py, px) of the flattened conv weight [D, C, p, p].
+__global__ void patchify_kernel(const float* __restrict__ x, int B, int C, int H, int W, int p, bf16* __restrict__ out,
+                                int ldo) {
+  const int hp = H / p, wp = W / p, K = C * p * p;
+  const long total = (long)B * hp * wp * K;
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(id % K);
+    const long tok = id / K;
+    const int px = k % p, py = (k / p) % p, c = k / (p * p);
+    const int tx = (int)(tok % wp), ty = (int)((tok / wp) % hp), b = (int)(tok / ((long)wp * hp));
+    out[(size_t)tok * ldo + k] = (bf16)x[(((size_t)b * C + c) * H + ty * p + py) * W + tx * p + px];
+  }
+}
+
+int launch_patchify(const float* x_nchw, int B, int C, int H, int W, int p, bf16* out, int ldo, hipStream_t stream) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || p <= 0 || H % p || W % p) return SD_ERR_INVALID;
+  const long total = (long)B * H * W * C;
+  long nb = (total + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)nb), dim3(256), 0, stream, x_nchw, B, C, H, W, p, out, ldo);
+  return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+}
+
+// unpatchify (transformer_sd3.py:349-356): rows [B*h*w, p*p*C] (column order (py, px, c)) -> NCHW fp32 [B, C, h*p, w*p]
+__global__ void unpatchify_kernel(const bf16* __restrict__ x, int ldx, int B, int C, int H, int W, int p,
+                                  float* __restrict__ out) {
+  const int hp = H / p, wp = W / p;
+  const long total = (long)B * C * H * W;
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long)gridDim.x * blockDim.x) {
+    const int xw = (int)(id % W), yh = (int)((id / W) % H), c = (int)((id / ((long)W * H)) % C);
+    const int b = (int)(id / ((long)W * H * C));
+    const int tx = xw / p, px = xw % p, ty = yh / p, py = yh % p;
+    const size_t tok = ((size_t)b * hp + ty) * wp + tx;
+    out[id] = (float)x[tok * ldx + (py * p + px) * C + c];
+  }
+}
+
+int launch_unpatchify(const bf16* x, int ldx, int B, int C, int H, int W, int p, float* out_nchw, hipStream_t stream) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || p <= 0 || H % p || W % p) return SD_ERR_INVALID;
+  const long total = (long)B * C * H * W;
+  long nb = (total + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(unpatchify_kernel, dim3((unsigned)nb), dim3(256), 0, stream, x, ldx, B, C, H, W, p, out_nchw);
+  return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+}
+
 }  // namespace sd

@@ -317,4 +317,117 @@ int launch_layernorm(const bf16* x, int rows, int C, int ldx, const float* gamma
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
 
+// Adaptive LayerNorm of the MMDiT blocks: y = LN(x) * (1 + scale[b]) + shift[b], LN without affine, b = row / rows_per_batch.
+// Reference: AdaLayerNormZero.forward (ppdiffusers/ppdiffusers/models/normalization.py:72-86), AdaLayerNormContinuous
+// (:190-202), the modulated norm2 of JointTransformerBlock (attention.py:184-185) and the fused Triton op
+// adaptive_layer_norm (paddlemix/triton_ops/triton_ops.py:981-1027).  Same wave layout as layernorm_kernel.
+template <int NCH, int ROWS>
+__global__ __launch_bounds__(256) void adaln_kernel(const bf16* __restrict__ x, int rows, int C, int ldx,
+                                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                                    int ld_mod, int rows_per_batch, float eps, bf16* __restrict__ y,
+                                                    int ldy) {
+  const int lane = threadIdx.x & 63;
+  const int wave_g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * (blockDim.x >> 6);
+  const int cv = C >> 3;
+  const float invC = 1.0f / (float)C;
+  for (int row0 = wave_g * ROWS; row0 < rows; row0 += nwaves * ROWS) {
+    float v[ROWS][NCH][8];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const int row = min(row0 + r, rows - 1);
+      const bf16* xr = x + (size_t)row * ldx;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int cc = lane + 64 * i;
+        u32x4 raw = {0u, 0u, 0u, 0u};
+        if (cc < cv) raw = *reinterpret_cast<const u32x4*>(xr + cc * 8);
+        const bf16x8 t = *reinterpret_cast<const bf16x8*>(&raw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[r][i][j] = (float)t[j];
+      }
+    }
+    float mean[ROWS], rstd[ROWS], s1[ROWS], s2[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const float K = __shfl(v[r][0][0], 0, 64);
+      float a = 0.f, q = 0.f;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        if (lane + 64 * i < cv) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float d = v[r][i][j] - K;
+            a += d;
+            q = __builtin_fmaf(d, d, q);
+          }
+        }
+      }
+      s1[r] = a;
+      s2[r] = q;
+      mean[r] = K;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) {
+        s1[r] += __shfl_xor(s1[r], o, 64);
+        s2[r] += __shfl_xor(s2[r], o, 64);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const float m = s1[r] * invC;
+      const float var = fmaxf(s2[r] * invC - m * m, 0.f);
+      mean[r] += m;
+      rstd[r] = rsqrtf(var + eps);
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      if (row0 + r < rows) {
+        const int bidx = (row0 + r) / rows_per_batch;
+        const float* sc = scale + (size_t)bidx * ld_mod;
+        const float* sh = shift + (size_t)bidx * ld_mod;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          const int cc = lane + 64 * i;
+          if (cc < cv) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(sc + cc * 8), a1 = *reinterpret_cast<const f32x4*>(sc + cc * 8 + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(sh + cc * 8), b1 = *reinterpret_cast<const f32x4*>(sh + cc * 8 + 4);
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              o[j] = __builtin_fmaf((v[r][i][j] - mean[r]) * rstd[r], 1.0f + a0[j], b0[j]);
+              o[4 + j] = __builtin_fmaf((v[r][i][4 + j] - mean[r]) * rstd[r], 1.0f + a1[j], b1[j]);
+            }
+            u32x4 pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7])};
+            *reinterpret_cast<u32x4*>(y + (size_t)(row0 + r) * ldy + cc * 8) = pk;
+          }
+        }
+      }
+    }
+  }
+}
+
+int launch_adaln(const bf16* x, int rows, int C, int ldx, const float* scale, const float* shift, int ld_mod,
+                 int rows_per_batch, float eps, bf16* y, int ldy, hipStream_t stream) {
+  if (rows <= 0 || C <= 0 || rows_per_batch <= 0) return SD_ERR_INVALID;
+  if ((C & 7) || (ldx & 7) || (ldy & 7) || (ld_mod & 3) || C > 2560) return SD_ERR_UNSUPPORTED;
+  const int wpb = 4;
+  const int cv = C >> 3;
+  constexpr int R = 4;
+  int blocks = (rows + wpb * R - 1) / (wpb * R);
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  if (cv <= 128)
+    hipLaunchKernelGGL((adaln_kernel<2, R>), dim3(blocks), dim3(64 * wpb), 0, stream, x, rows, C, ldx, scale, shift, ld_mod,
+                       rows_per_batch, eps, y, ldy);
+  else if (cv <= 192)
+    hipLaunchKernelGGL((adaln_kernel<3, R>), dim3(blocks), dim3(64 * wpb), 0, stream, x, rows, C, ldx, scale, shift, ld_mod,
+                       rows_per_batch, eps, y, ldy);
+  else
+    hipLaunchKernelGGL((adaln_kernel<5, 2>), dim3(blocks), dim3(64 * wpb), 0, stream, x, rows, C, ldx, scale, shift, ld_mod,
+                       rows_per_batch, eps, y, ldy);
+  return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+}
+
 }  // namespace sd

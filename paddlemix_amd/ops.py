@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import GEGLU, OUT_F32, SILU, check
+from ._lib import GEGLU, GELU_TANH, OUT_F32, SILU, check
 
 Tensor = torch.Tensor
 
@@ -236,4 +236,59 @@ def probe_layouts(device="cuda") -> Tensor:
     lib = _lib.load()
     out = torch.zeros((64, 24), device=device, dtype=torch.float32)
     check(lib.mi355x_sd_probe_layouts(out.data_ptr(), _stream()))
+    return out
+
+
+def linear_ex(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, gate: Optional[Tensor] = None,
+              rows_per_batch: int = 0, residual: Optional[Tensor] = None, out: Optional[Tensor] = None,
+              gelu_tanh: bool = False, silu: bool = False, out_f32: bool = False, a_rows_per_batch: int = 0,
+              a_batch_stride: int = 0, c_rows_per_batch: int = 0, c_batch_stride: int = 0, M: Optional[int] = None) -> Tensor:
+    """mi355x_sd_linear_ex: out = residual + gate[m // rows_per_batch] * (a @ w^T + bias), optional row remaps of a / out
+    (then `a` / `out` are the flat base tensors and M is given explicitly)."""
+    lib = _lib.load()
+    N, K = w.shape
+    if a_rows_per_batch:
+        lda = K if a.dim() == 1 else a.stride(0)
+        assert M is not None
+    else:
+        lda = _rows(a, "a")
+        M = a.shape[0]
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
+    ldc = N if c_rows_per_batch else _rows(out, "out", torch.float32 if out_f32 else torch.bfloat16)
+    ld_gate = gate.stride(0) if gate is not None else 0
+    flags = (OUT_F32 if out_f32 else 0) | (SILU if silu else 0) | (GELU_TANH if gelu_tanh else 0)
+    check(lib.mi355x_sd_linear_ex(a.data_ptr(), lda, a_rows_per_batch, a_batch_stride, w.data_ptr(), out.data_ptr(), ldc,
+                                  c_rows_per_batch, c_batch_stride, M, N, K, _p(_vec(bias, N, "bias")), None, 0, _p(gate),
+                                  ld_gate, rows_per_batch, _p(residual), _rows(residual, "residual") if residual is not None else 0,
+                                  1.0, flags, _stream()))
+    return out
+
+
+def adaln(x: Tensor, scale: Tensor, shift: Tensor, rows_per_batch: int, eps: float = 1e-6,
+          out: Optional[Tensor] = None) -> Tensor:
+    """y = LN_noaffine(x) * (1 + scale[b]) + shift[b]; scale/shift fp32 [batches, C] rows sharing one row stride."""
+    lib = _lib.load()
+    ldx = _rows(x, "x")
+    rows, C = x.shape
+    if out is None:
+        out = torch.empty((rows, C), device=x.device, dtype=torch.bfloat16)
+    assert scale.stride(0) == shift.stride(0) and scale.dtype == torch.float32
+    check(lib.mi355x_sd_adaln(x.data_ptr(), rows, C, ldx, scale.data_ptr(), shift.data_ptr(), scale.stride(0),
+                              rows_per_batch, float(eps), out.data_ptr(), _rows(out, "out"), _stream()))
+    return out
+
+
+def patchify(x_nchw: Tensor, patch: int) -> Tensor:
+    lib = _lib.load()
+    B, C, H, W = x_nchw.shape
+    out = torch.empty((B * (H // patch) * (W // patch), C * patch * patch), device=x_nchw.device, dtype=torch.bfloat16)
+    check(lib.mi355x_sd_patchify(x_nchw.data_ptr(), B, C, H, W, patch, out.data_ptr(), out.shape[1], _stream()))
+    return out
+
+
+def unpatchify(x: Tensor, B: int, C: int, H: int, W: int, patch: int) -> Tensor:
+    lib = _lib.load()
+    out = torch.empty((B, C, H, W), device=x.device, dtype=torch.float32)
+    check(lib.mi355x_sd_unpatchify(x.data_ptr(), _rows(x, "x"), B, C, H, W, patch, out.data_ptr(), _stream()))
     return out

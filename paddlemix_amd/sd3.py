@@ -1,0 +1,370 @@
+"""MI355X-native SD3Transformer2DModel (MMDiT): drop-in for the denoising-step callable of StableDiffusion3Pipeline.
+
+Mirrors ``SD3Transformer2DModel.forward(hidden_states, encoder_hidden_states, pooled_projections, timestep,
+return_dict)`` (ppdiffusers/ppdiffusers/models/transformer_sd3.py:279-365, called at
+pipelines/stable_diffusion_3/pipeline_stable_diffusion_3.py:820-827).  The schedule is the fused one the reference
+itself uses for inference (``SimplifiedSD3.forward``, models/simplified_sd3.py:43-160), re-designed for the C ABI:
+
+  * every adaLN modulation vector of the model (24 x (6D + 6D) + 2D at SD3-medium) comes from ONE GEMM per step;
+  * ``adaptive_layer_norm`` (paddlemix/triton_ops/triton_ops.py:981-1139) = ``mi355x_sd_adaln``;
+  * the gate * out + residual half of ``fused_adaLN_scale_residual`` (:702-920) is the GEMM epilogue of to_out / ff.net.2;
+  * ``split_concat`` (:1652-1752) does not exist: the fused QKV GEMMs of the image and the text stream write straight
+    into one joint [B, S_img + S_txt, 3D] buffer (row remap in the epilogue) that the attention kernel consumes in
+    place, and the two output projections read their rows back out of the joint attention output (row remap in the
+    loader);
+  * GELU-tanh is the ff.net.0 GEMM epilogue.
+Weights are bf16 here; the fp8 (e4m3) weight path of BASELINE.json's config 5 is not built yet.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import Dict, List, Mapping, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import GELU_TANH, OUT_F32, SILU
+from .program import DeviceProgram, _Plan, _Ref, _V
+
+Tensor = torch.Tensor
+
+SD3_DEFAULTS = dict(sample_size=128, patch_size=2, in_channels=16, num_layers=18, attention_head_dim=64,
+                    num_attention_heads=18, joint_attention_dim=4096, caption_projection_dim=1152,
+                    pooled_projection_dim=2048, out_channels=16, pos_embed_max_size=96)
+
+
+def normalize_config(config: Mapping) -> dict:
+    cfg = dict(SD3_DEFAULTS)
+    cfg.update({k: v for k, v in config.items() if not k.startswith("_")})
+    cfg["inner_dim"] = cfg["num_attention_heads"] * cfg["attention_head_dim"]
+    if cfg["caption_projection_dim"] != cfg["inner_dim"]:
+        raise ValueError("caption_projection_dim must equal num_attention_heads * attention_head_dim")
+    if cfg["out_channels"] is None:
+        cfg["out_channels"] = cfg["in_channels"]
+    return cfg
+
+
+def sd3_param_shapes(config: Mapping) -> Dict[str, tuple]:
+    """name -> shape (Paddle layouts) in construction order (transformer_sd3.py:65-124, attention.py:108-157)."""
+    cfg = normalize_config(config)
+    D, p, n = cfg["inner_dim"], cfg["patch_size"], cfg["num_layers"]
+    S: Dict[str, tuple] = {}
+
+    def lin(name, i, o):
+        S[name + ".weight"] = (i, o)
+        S[name + ".bias"] = (o,)
+
+    S["pos_embed.proj.weight"] = (D, cfg["in_channels"], p, p)
+    S["pos_embed.proj.bias"] = (D,)
+    lin("time_text_embed.timestep_embedder.linear_1", 256, D)
+    lin("time_text_embed.timestep_embedder.linear_2", D, D)
+    lin("time_text_embed.text_embedder.linear_1", cfg["pooled_projection_dim"], D)
+    lin("time_text_embed.text_embedder.linear_2", D, D)
+    lin("context_embedder", cfg["joint_attention_dim"], D)
+    for i in range(n):
+        b = f"transformer_blocks.{i}"
+        last = i == n - 1
+        lin(b + ".norm1.linear", D, 6 * D)
+        lin(b + ".norm1_context.linear", D, 2 * D if last else 6 * D)
+        for nm in ("to_q", "to_k", "to_v", "add_k_proj", "add_v_proj", "add_q_proj", "to_out.0"):
+            lin(b + ".attn." + nm, D, D)
+        if not last:
+            lin(b + ".attn.to_add_out", D, D)
+        lin(b + ".ff.net.0.proj", D, 4 * D)
+        lin(b + ".ff.net.2", 4 * D, D)
+        if not last:
+            lin(b + ".ff_context.net.0.proj", D, 4 * D)
+            lin(b + ".ff_context.net.2", 4 * D, D)
+    lin("norm_out.linear", D, 2 * D)
+    lin("proj_out", D, p * p * cfg["out_channels"])
+    return S
+
+
+def synth_sd3_params(config: Mapping, seed: int = 1234, device="cpu", dtype=torch.float32) -> Dict[str, Tensor]:
+    """Random-init parameters (same recipe as the oracle's synth_sd3_params)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    P: Dict[str, Tensor] = {}
+    for name, shape in sd3_param_shapes(config).items():
+        r = torch.randn(shape, generator=g, device=device)
+        if name.endswith(".bias"):
+            t = r * 0.02
+        elif len(shape) == 2:
+            t = r / math.sqrt(shape[0])
+            if ".norm1" in name or name.startswith("norm_out"):
+                t = t * 0.3
+        else:
+            t = r / math.sqrt(shape[1] * shape[2] * shape[3])
+        P[name] = t.to(dtype)
+    return P
+
+
+def _sincos_1d(embed_dim, pos):
+    omega = np.arange(embed_dim // 2, dtype=np.float64)
+    omega /= embed_dim / 2.0
+    omega = 1.0 / 10000 ** omega
+    out = np.einsum("m,d->md", pos.reshape(-1), omega)
+    return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+
+
+def pos_embed_table(embed_dim: int, grid: int, base_size: int) -> np.ndarray:
+    """get_2d_sincos_pos_embed (embeddings.py:67-98) for a square grid; [grid*grid, embed_dim]."""
+    g_h = np.arange(grid, dtype=np.float32) / (grid / base_size)
+    g_w = np.arange(grid, dtype=np.float32) / (grid / base_size)
+    mesh = np.stack(np.meshgrid(g_w, g_h), axis=0).reshape([2, 1, grid, grid])  # w first, like the reference
+    return np.concatenate([_sincos_1d(embed_dim // 2, mesh[0]), _sincos_1d(embed_dim // 2, mesh[1])], axis=1)
+
+
+class Transformer2DModelOutput(SimpleNamespace):
+    """``.sample`` holder (models/transformer_2d.py Transformer2DModelOutput)."""
+
+
+class SD3Transformer2DModel(DeviceProgram):
+    def __init__(self, config: Mapping, params: Mapping[str, Tensor], device="cuda", use_graph: bool = True,
+                 profile: bool = False, _test_backend=None):
+        """``_test_backend``: test-only injection (tests/abi_emulator.py); never selected by product code."""
+        self._init_backend(device, use_graph, profile, _test_backend)
+        self.cfg = normalize_config(config)
+        self.config = SimpleNamespace(**self.cfg)
+        self._load_weights(params)
+
+    # ------------------------------------------------------------------ weights
+    def _load_weights(self, params: Mapping[str, Tensor]) -> None:
+        cfg, dev, W = self.cfg, self.device, self.w
+        shapes = sd3_param_shapes(cfg)
+        missing = [k for k in shapes if k not in params]
+        if missing:
+            raise KeyError(f"missing parameters: {missing[:5]}{'...' if len(missing) > 5 else ''}")
+
+        def get(name):
+            t = params[name]
+            if tuple(t.shape) != shapes[name]:
+                raise ValueError(f"{name}: shape {tuple(t.shape)} != expected {shapes[name]} (Paddle layout)")
+            return t.to(device=dev, dtype=torch.float32)
+
+        bf = lambda t: t.to(torch.bfloat16).contiguous()  # noqa: E731
+
+        def put_lin(key, name):
+            W[key + ".w"] = bf(get(name + ".weight").t())
+            W[key + ".b"] = get(name + ".bias").contiguous()
+
+        w = get("pos_embed.proj.weight")
+        W["patch.w"] = bf(w.reshape(w.shape[0], -1))  # [D, C*p*p], columns (c, py, px)
+        W["patch.b"] = get("pos_embed.proj.bias").contiguous()
+        for nm in ("time_text_embed.timestep_embedder.linear_1", "time_text_embed.timestep_embedder.linear_2",
+                   "time_text_embed.text_embedder.linear_1", "time_text_embed.text_embedder.linear_2",
+                   "context_embedder", "proj_out"):
+            put_lin(nm, nm)
+        D, n = cfg["inner_dim"], cfg["num_layers"]
+        mod_w: List[Tensor] = []
+        mod_b: List[Tensor] = []
+        self._mod_off: Dict[str, int] = {}
+        off = 0
+
+        def add_mod(key, name):
+            nonlocal off
+            wt = get(name + ".weight").t()
+            mod_w.append(bf(wt))
+            mod_b.append(get(name + ".bias"))
+            self._mod_off[key] = off
+            off += wt.shape[0]
+
+        for i in range(n):
+            b = f"transformer_blocks.{i}"
+            last = i == n - 1
+            add_mod(b + ".norm1", b + ".norm1.linear")
+            add_mod(b + ".norm1_context", b + ".norm1_context.linear")
+            cat = lambda names: torch.cat([get(b + ".attn." + x + ".weight").t() for x in names], 0)  # noqa: E731
+            catb = lambda names: torch.cat([get(b + ".attn." + x + ".bias") for x in names], 0)  # noqa: E731
+            W[b + ".qkv.w"], W[b + ".qkv.b"] = bf(cat(("to_q", "to_k", "to_v"))), catb(("to_q", "to_k", "to_v")).contiguous()
+            W[b + ".qkv_c.w"] = bf(cat(("add_q_proj", "add_k_proj", "add_v_proj")))
+            W[b + ".qkv_c.b"] = catb(("add_q_proj", "add_k_proj", "add_v_proj")).contiguous()
+            put_lin(b + ".out", b + ".attn.to_out.0")
+            put_lin(b + ".ff1", b + ".ff.net.0.proj")
+            put_lin(b + ".ff2", b + ".ff.net.2")
+            if not last:
+                put_lin(b + ".out_c", b + ".attn.to_add_out")
+                put_lin(b + ".ff1_c", b + ".ff_context.net.0.proj")
+                put_lin(b + ".ff2_c", b + ".ff_context.net.2")
+        add_mod("norm_out", "norm_out.linear")
+        W["mod_all.w"] = torch.cat(mod_w, 0).contiguous()
+        W["mod_all.b"] = torch.cat(mod_b, 0).contiguous()
+        self._mod_total = off
+        mx = cfg["pos_embed_max_size"]
+        self._pos_table = torch.from_numpy(pos_embed_table(D, mx, cfg["sample_size"] // cfg["patch_size"])).to(
+            torch.float32).reshape(mx, mx, D)
+
+    # ------------------------------------------------------------------ plan
+    def _build_plan(self, B: int, H: int, Wd: int, L: int) -> _Plan:
+        cfg, lib, dev, W = self.cfg, self._lib, self.device, self.w
+        stream = self._stream_ptr
+        D, heads, p, n = cfg["inner_dim"], cfg["num_attention_heads"], cfg["patch_size"], cfg["num_layers"]
+        hp, wp = H // p, Wd // p
+        S1, S2, ST = hp * wp, L, hp * wp + L
+        MT = self._mod_total
+        plan = _Plan()
+        prog: List[tuple] = []
+        scratch: Dict[str, int] = {}
+        keep: List[Tensor] = []
+
+        def sc(name, nbytes):
+            scratch[name] = max(scratch.get(name, 0), nbytes)
+            return _Ref(name)
+
+        def persist(shape, dtype):
+            t = torch.empty(shape, device=dev, dtype=dtype)
+            keep.append(t)
+            return t
+
+        def emit(fn, args, kind, flops=0.0, desc=""):
+            prog.append((fn, list(args), kind if not desc else f"{kind}:{desc}", flops))
+
+        def linear(a: _V, wkey: str, out: _V, *, flags=0, R: Optional[_V] = None, gate=None, rpb=0, a_rpb=0, a_bs=0,
+                   c_rpb=0, c_bs=0, bias=True):
+            w = W[wkey + ".w"]
+            N, K = w.shape
+            assert K == a.C, (wkey, K, a.C)
+            emit(lib.mi355x_sd_linear_ex,
+                 (a.p, a.ld, a_rpb, a_bs, w.data_ptr(), out.p, out.ld, c_rpb, c_bs, a.rows, N, K,
+                  W[wkey + ".b"].data_ptr() if bias else None, None, 0, gate, MT if gate is not None else 0, rpb,
+                  R.p if R else None, R.ld if R else 0, 1.0, flags, stream), "gemm", 2.0 * a.rows * N * K,
+                 f"{a.rows}x{N}x{K}")
+
+        def adaln(x: _V, scale_ptr, shift_ptr, rpb, out: _V):
+            emit(lib.mi355x_sd_adaln, (x.p, x.rows, x.C, x.ld, scale_ptr, shift_ptr, MT, rpb, 1e-6, out.p, out.ld,
+                                       stream), "ln")
+
+        # ---- inputs ----
+        plan.sample = persist((B, cfg["in_channels"], H, Wd), torch.float32)
+        plan.t = persist((1,), torch.float32)
+        plan.enc = persist((B * S2, cfg["joint_attention_dim"]), torch.bfloat16)
+        plan.pooled = persist((B, cfg["pooled_projection_dim"]), torch.bfloat16)
+        plan.out = persist((B, cfg["out_channels"], H, Wd), torch.float32)
+        mx = cfg["pos_embed_max_size"]
+        if hp > mx or wp > mx:
+            raise ValueError(f"Height ({hp}) / width ({wp}) cannot be greater than `pos_embed_max_size`: {mx}.")
+        top, left = (mx - hp) // 2, (mx - wp) // 2
+        pos = self._pos_table[top:top + hp, left:left + wp].reshape(1, S1, D).expand(B, S1, D).reshape(B * S1, D)
+        pos_t = persist((B * S1, D), torch.bfloat16)
+        pos_t.copy_(pos)
+
+        # ---- patch embedding + cropped sincos pos-emb (embeddings.py:209-247) ----
+        kp = cfg["in_channels"] * p * p
+        patches = persist((B * S1, kp), torch.bfloat16)
+        emit(lib.mi355x_sd_patchify, (plan.sample.data_ptr(), B, cfg["in_channels"], H, Wd, p, patches.data_ptr(), kp,
+                                      stream), "misc")
+        x_t = persist((B * S1, D), torch.bfloat16)
+        x = _V(x_t.data_ptr(), B * S1, D)
+        linear(_V(patches.data_ptr(), B * S1, kp), "patch", x, R=_V(pos_t.data_ptr(), B * S1, D))
+
+        # ---- conditioning (embeddings.py:538-546) and all modulation vectors in one GEMM ----
+        tproj = persist((B, 256), torch.bfloat16)
+        emit(lib.mi355x_sd_timestep_embedding, (plan.t.data_ptr(), 1, B, 256, 1, 1, 0.0, 1.0, 10000.0,
+                                                tproj.data_ptr(), 256, stream), "misc")
+        e1, temb, st = (persist((B, D), torch.bfloat16) for _ in range(3))
+        v = lambda t, c: _V(t.data_ptr(), B, c)  # noqa: E731
+        linear(v(tproj, 256), "time_text_embed.timestep_embedder.linear_1", v(e1, D), flags=SILU)
+        linear(v(e1, D), "time_text_embed.timestep_embedder.linear_2", v(temb, D))
+        linear(v(plan.pooled, cfg["pooled_projection_dim"]), "time_text_embed.text_embedder.linear_1", v(e1, D), flags=SILU)
+        linear(v(e1, D), "time_text_embed.text_embedder.linear_2", v(temb, D), R=v(temb, D))
+        emit(lib.mi355x_sd_silu, (temb.data_ptr(), st.data_ptr(), B * D, 0, 0, stream), "misc")
+        mod = persist((B, MT), torch.float32)
+        linear(v(st, D), "mod_all", _V(mod.data_ptr(), B, MT), flags=OUT_F32)
+        mp = mod.data_ptr()
+        m_at = lambda key, chunk: mp + 4 * (self._mod_off[key] + chunk * D)  # noqa: E731
+
+        c_t = persist((B * S2, D), torch.bfloat16)
+        c = _V(c_t.data_ptr(), B * S2, D)
+        linear(_V(plan.enc.data_ptr(), B * S2, cfg["joint_attention_dim"]), "context_embedder", c)
+
+        nx = _V(sc("nx", 2 * B * S1 * D), B * S1, D)
+        nc = _V(sc("nc", 2 * B * S2 * D), B * S2, D)
+        jq = sc("joint_qkv", 2 * B * ST * 3 * D)
+        ao = sc("joint_out", 2 * B * ST * D)
+        ffx = _V(sc("ff_x", 2 * B * S1 * 4 * D), B * S1, 4 * D)
+        ffc = _V(sc("ff_c", 2 * B * S2 * 4 * D), B * S2, 4 * D)
+        d = D // heads
+        for i in range(n):
+            b = f"transformer_blocks.{i}"
+            last = i == n - 1
+            kx, kc = b + ".norm1", b + ".norm1_context"
+            # chunks of norm1.linear: 0 shift_msa, 1 scale_msa, 2 gate_msa, 3 shift_mlp, 4 scale_mlp, 5 gate_mlp
+            adaln(x, m_at(kx, 1), m_at(kx, 0), S1, nx)
+            if last:  # AdaLayerNormContinuous: (scale, shift) = chunk(2)
+                adaln(c, m_at(kc, 0), m_at(kc, 1), S2, nc)
+            else:
+                adaln(c, m_at(kc, 1), m_at(kc, 0), S2, nc)
+            # fused QKV of both streams into the joint [B, S1+S2, 3D] buffer (split_concat folded into the epilogue)
+            linear(nx, b + ".qkv", _V(jq, B * S1, 3 * D), c_rpb=S1, c_bs=ST * 3 * D)
+            linear(nc, b + ".qkv_c", _V(jq + 2 * S1 * 3 * D, B * S2, 3 * D), c_rpb=S2, c_bs=ST * 3 * D)
+            emit(lib.mi355x_sd_sdpa, (jq, jq + 2 * D, jq + 4 * D, None, ao, B, heads, ST, ST, d, ST * 3 * D, 3 * D,
+                                      ST * 3 * D, 3 * D, ST * 3 * D, 3 * D, ST * D, D, 0, 0, 0, d ** -0.5, stream),
+                 "attn", 4.0 * B * heads * ST * ST * d, f"{B}x{heads}x{ST}x{ST}x{d}")
+            # to_out with the gated residual: x += gate_msa * (attn @ Wo + b)
+            linear(_V(ao, B * S1, D), b + ".out", x, R=x, gate=m_at(kx, 2), rpb=S1, a_rpb=S1, a_bs=ST * D)
+            adaln(x, m_at(kx, 4), m_at(kx, 3), S1, nx)
+            linear(nx, b + ".ff1", ffx, flags=GELU_TANH)
+            linear(ffx, b + ".ff2", x, R=x, gate=m_at(kx, 5), rpb=S1)
+            if not last:
+                linear(_V(ao + 2 * S1 * D, B * S2, D), b + ".out_c", c, R=c, gate=m_at(kc, 2), rpb=S2, a_rpb=S2,
+                       a_bs=ST * D)
+                adaln(c, m_at(kc, 4), m_at(kc, 3), S2, nc)
+                linear(nc, b + ".ff1_c", ffc, flags=GELU_TANH)
+                linear(ffc, b + ".ff2_c", c, R=c, gate=m_at(kc, 5), rpb=S2)
+
+        # ---- norm_out (scale, shift) + proj_out + unpatchify (transformer_sd3.py:341-356) ----
+        adaln(x, m_at("norm_out", 0), m_at("norm_out", 1), S1, nx)
+        po = p * p * cfg["out_channels"]
+        proj = persist((B * S1, po), torch.bfloat16)
+        linear(nx, "proj_out", _V(proj.data_ptr(), B * S1, po))
+        emit(lib.mi355x_sd_unpatchify, (proj.data_ptr(), po, B, cfg["out_channels"], H, Wd, p, plan.out.data_ptr(),
+                                        stream), "misc")
+
+        bufs = {nm: persist((max(nb, 16),), torch.uint8) for nm, nb in scratch.items()}
+        base = {nm: t.data_ptr() for nm, t in bufs.items()}
+        res = lambda a: base[a.buf] + a.off if isinstance(a, _Ref) else a  # noqa: E731
+        plan.prog = [(fn, tuple(res(a) for a in args), kind, fl) for fn, args, kind, fl in prog]
+        plan.keep, plan.graph = keep, None
+        plan.B, plan.H, plan.W, plan.L = B, H, Wd, L
+        return plan
+
+    def _get_plan(self, B, H, W, L) -> _Plan:
+        key = (B, H, W, L)
+        if key not in self._plans:
+            self._plans[key] = self._build_plan(B, H, W, L)
+        return self._plans[key]
+
+    def stage_inputs(self, plan: _Plan, hidden_states, encoder_hidden_states, pooled_projections, timestep) -> None:
+        if torch.is_tensor(timestep):
+            plan.t.copy_(timestep.reshape(-1)[:1].to(torch.float32), non_blocking=True)
+        else:
+            plan.t.fill_(float(timestep))
+        plan.sample.copy_(hidden_states, non_blocking=True)
+        plan.enc.copy_(encoder_hidden_states.reshape(plan.B * plan.L, -1), non_blocking=True)
+        plan.pooled.copy_(pooled_projections, non_blocking=True)
+
+    def forward(self, hidden_states, encoder_hidden_states=None, pooled_projections=None, timestep=None,
+                joint_attention_kwargs=None, return_dict: bool = True):
+        if encoder_hidden_states is None or pooled_projections is None or timestep is None:
+            raise ValueError("encoder_hidden_states, pooled_projections and timestep are required")
+        if not self._emulated and not hidden_states.is_cuda:
+            raise _lib.MI355XError("inputs must be GPU tensors (no CPU fallback)")
+        B, _, H, W = hidden_states.shape
+        plan = self._get_plan(B, H, W, encoder_hidden_states.shape[1])
+        if self._emulated:
+            self.stage_inputs(plan, hidden_states, encoder_hidden_states, pooled_projections, timestep)
+            self._run_eager(plan)
+            out = plan.out.clone()
+        else:
+            cur = torch.cuda.current_stream(self.device)
+            self._stream.wait_stream(cur)
+            with torch.cuda.stream(self._stream):
+                self.stage_inputs(plan, hidden_states, encoder_hidden_states, pooled_projections, timestep)
+                out = self.run(plan).clone()
+            cur.wait_stream(self._stream)
+        if not return_dict:
+            return (out,)
+        return Transformer2DModelOutput(sample=out)
+
+    __call__ = forward

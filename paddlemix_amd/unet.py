@@ -28,6 +28,7 @@ import torch
 
 from . import _lib
 from ._lib import GEGLU, OUT_F32, SILU
+from .program import DeviceProgram, _Plan, _Ref, _V
 
 Tensor = torch.Tensor
 
@@ -220,69 +221,21 @@ def synth_unet_params(config: Mapping, seed: int = 1234, device="cpu", dtype=tor
 # ---------------------------------------------------------------------------------------------------------------
 # program builder
 # ---------------------------------------------------------------------------------------------------------------
-class _Ref:
-    """Symbolic device address inside a named scratch buffer (resolved after all sizes are known)."""
-    __slots__ = ("buf", "off")
-
-    def __init__(self, buf: str, off: int = 0):
-        self.buf, self.off = buf, off
-
-    def __add__(self, nbytes: int) -> "_Ref":
-        return _Ref(self.buf, self.off + nbytes)
-
-
-class _V:
-    """Row view: `rows` rows of `C` bf16 channels, row stride `ld` elements, at address `p` (int or _Ref)."""
-    __slots__ = ("p", "rows", "C", "ld")
-
-    def __init__(self, p, rows, C, ld=None):
-        self.p, self.rows, self.C, self.ld = p, rows, C, (C if ld is None else ld)
-
-    def cols(self, off: int, C: int) -> "_V":
-        return _V(self.p + 2 * off, self.rows, C, self.ld)
-
-
-class _Plan:
-    pass
-
-
 class UNet2DConditionOutput(SimpleNamespace):
     """``.sample`` holder, mirroring unet_2d_condition.py:61-72."""
 
 
-class UNet2DConditionModel:
+class UNet2DConditionModel(DeviceProgram):
     def __init__(self, config: Mapping, params: Mapping[str, Tensor], device="cuda", use_graph: bool = True,
                  profile: bool = False, _test_backend=None):
         """``_test_backend``: test-only injection point (tests/abi_emulator.py interprets the emitted C-ABI
         program on host memory to check the sequencing / packing logic without a GPU).  It is never selected by
         product code: without it the model needs the built HIP library and a GPU, and raises otherwise."""
-        self._emulated = _test_backend is not None
-        if self._emulated:
-            self._lib = _test_backend
-            self.device = torch.device("cpu")
-            self._stream = None
-            self._stream_ptr = 0
-            use_graph = False
-        else:
-            self._lib = _lib.load()  # hard failure if the HIP library is not built
-            if not torch.cuda.is_available():
-                raise _lib.MI355XError("UNet2DConditionModel(mi355x) needs a GPU; there is no CPU fallback")
-            self.device = torch.device(device)
-            if self.device.index is None:
-                self.device = torch.device("cuda", torch.cuda.current_device())
-            _lib.check(self._lib.mi355x_sd_init(self.device.index))
-            self._stream = torch.cuda.Stream(device=self.device)
-            self._stream_ptr = self._stream.cuda_stream
+        self._init_backend(device, use_graph, profile, _test_backend)
         self.cfg = normalize_config(config)
         pub = dict(self.cfg)
         pub.pop("num_attention_heads")
         self.config = SimpleNamespace(**pub)
-        self.dtype = torch.bfloat16
-        self.use_graph = use_graph
-        self.profile = profile
-        self._plans: Dict[tuple, _Plan] = {}
-        self.w: Dict[str, Tensor] = {}
-        self.kernel_times: Dict[str, list] = {}
         self._load_weights(params)
 
     # ------------------------------------------------------------------ weights
@@ -390,9 +343,6 @@ class UNet2DConditionModel:
         w = get("conv_out.weight")
         W["conv_out.w"] = bf(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1))
         W["conv_out.b"] = get("conv_out.bias").contiguous()
-
-    def weight_bytes(self) -> int:
-        return sum(t.numel() * t.element_size() for t in self.w.values())
 
     # ------------------------------------------------------------------ plan
     def _build_plan(self, B: int, H: int, Wd: int, L: int, masked: bool = False) -> _Plan:
@@ -679,42 +629,6 @@ class UNet2DConditionModel:
                self._stream_ptr), "misc", 0.0)
         plan.prog.insert(plan._add_emit_index, op)
 
-    def _run_eager(self, plan: _Plan) -> None:
-        if not self.profile or self._emulated:
-            for fn, args, _, _ in plan.prog:
-                rc = fn(*args)
-                if rc:
-                    _lib.check(rc)
-            return
-        evs = []
-        for fn, args, kind, fl in plan.prog:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(self._stream)
-            rc = fn(*args)
-            e1.record(self._stream)
-            if rc:
-                _lib.check(rc)
-            evs.append((kind, fl, e0, e1))
-        self._stream.synchronize()
-        for kind, fl, e0, e1 in evs:
-            self.kernel_times.setdefault(kind, []).append((e0.elapsed_time(e1) * 1e-3, fl))
-
-    def _capture(self, plan: _Plan) -> None:
-        lib = self._lib
-        sp = self._stream_ptr
-        _lib.check(lib.mi355x_sd_graph_begin(sp))
-        try:
-            for fn, args, _, _ in plan.prog:
-                rc = fn(*args)
-                if rc:
-                    _lib.check(rc)
-        finally:
-            import ctypes
-            exe = ctypes.c_void_p()
-            rc = lib.mi355x_sd_graph_end(sp, ctypes.byref(exe))
-        _lib.check(rc)
-        plan.graph = exe
-
     def _get_plan(self, B, H, W, L, masked: bool = False) -> _Plan:
         key = (B, H, W, L, masked)
         if key not in self._plans:
@@ -750,17 +664,6 @@ class UNet2DConditionModel:
                 self._finish_add_embedding(plan, te.shape[-1], ti.shape[-1])
             plan.add_in[:, :plan.text_dim].copy_(te, non_blocking=True)
             plan.time_ids.copy_(ti.reshape(-1).to(torch.float32), non_blocking=True)
-
-    def run(self, plan: _Plan) -> Tensor:
-        """Launch the step on the model's stream (inputs already staged); returns the static output buffer."""
-        if self.use_graph and not self.profile:
-            if plan.graph is None:
-                self._run_eager(plan)  # warm-up outside capture (lazy module loading)
-                self._capture(plan)
-            _lib.check(self._lib.mi355x_sd_graph_launch(plan.graph, self._stream_ptr))
-        else:
-            self._run_eager(plan)
-        return plan.out
 
     def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, timestep_cond=None,
                 attention_mask=None, cross_attention_kwargs=None, added_cond_kwargs=None,

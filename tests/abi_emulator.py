@@ -16,7 +16,7 @@ import math
 import torch
 import torch.nn.functional as F
 
-GEGLU, OUT_F32, SILU = 1, 2, 4
+GEGLU, OUT_F32, SILU, GELU_TANH = 1, 2, 4, 8
 _ES = {torch.bfloat16: 2, torch.float32: 4}
 
 
@@ -72,6 +72,63 @@ class Emulator:
         a = _rows(A, M, K, lda).float()
         w = _rows(W, N, K, K).float()
         self._epilogue(a @ w.t(), N, bias, rowbias, rpb, ld_rb, R, ldr, out_scale, flags, C, ldc)
+        return 0
+
+    def mi355x_sd_linear_ex(self, A, lda, a_rpb, a_bs, W, C, ldc, c_rpb, c_bs, M, N, K, bias, rowbias, ld_rb, gate,
+                            ld_gate, rpb, R, ldr, out_scale, flags, stream):
+        self.calls.append("linear_ex")
+        assert K % 8 == 0 and N % 4 == 0 and lda % 8 == 0 and ldc % 4 == 0
+        assert not (flags & GEGLU) and not rowbias
+
+        def remap_rows(ptr, rows, cols, ld, r_pb, bstride, dtype):
+            if not r_pb:
+                return _rows(ptr, rows, cols, ld, dtype)
+            nb = rows // r_pb
+            assert nb * r_pb == rows
+            n = (nb - 1) * bstride + (r_pb - 1) * ld + cols
+            return _flat(ptr, n, dtype).as_strided((nb, r_pb, cols), (bstride, ld, 1))
+
+        a = remap_rows(A, M, K, lda, a_rpb, a_bs, torch.bfloat16).float().reshape(M, K)
+        w = _rows(W, N, K, K).float()
+        acc = a @ w.t()
+        if bias:
+            acc = acc + _flat(bias, N, torch.float32)
+        if gate:
+            g = _rows(gate, M // rpb, N, ld_gate, torch.float32)
+            acc = acc * g.repeat_interleave(rpb, 0)
+        if R:
+            acc = acc + _rows(R, M, N, ldr).float()
+        acc = acc * out_scale
+        if flags & SILU:
+            acc = F.silu(acc)
+        if flags & GELU_TANH:
+            acc = F.gelu(acc, approximate="tanh")
+        dt = torch.float32 if flags & OUT_F32 else torch.bfloat16
+        out = remap_rows(C, M, N, ldc, c_rpb, c_bs, dt)
+        out.copy_(acc.to(dt).reshape(out.shape))
+        return 0
+
+    def mi355x_sd_adaln(self, x, rows, C, ldx, scale, shift, ld_mod, rpb, eps, y, ldy, stream):
+        self.calls.append("adaln")
+        nb = rows // rpb
+        xv = F.layer_norm(_rows(x, rows, C, ldx).float(), (C,), None, None, eps)
+        sc = _rows(scale, nb, C, ld_mod, torch.float32).repeat_interleave(rpb, 0)
+        sh = _rows(shift, nb, C, ld_mod, torch.float32).repeat_interleave(rpb, 0)
+        _rows(y, rows, C, ldy).copy_((xv * (1 + sc) + sh).to(torch.bfloat16))
+        return 0
+
+    def mi355x_sd_patchify(self, x, B, C, H, W, p, out, ldo, stream):
+        self.calls.append("patchify")
+        xs = _flat(x, B * C * H * W, torch.float32).reshape(B, C, H // p, p, W // p, p)
+        rows = xs.permute(0, 2, 4, 1, 3, 5).reshape(B * (H // p) * (W // p), C * p * p)
+        _rows(out, rows.shape[0], rows.shape[1], ldo).copy_(rows.to(torch.bfloat16))
+        return 0
+
+    def mi355x_sd_unpatchify(self, x, ldx, B, C, H, W, p, out, stream):
+        self.calls.append("unpatchify")
+        h, w = H // p, W // p
+        rows = _rows(x, B * h * w, p * p * C, ldx).float().reshape(B, h, w, p, p, C)
+        _flat(out, B * C * H * W, torch.float32).reshape(B, C, H, W).copy_(rows.permute(0, 5, 1, 3, 2, 4).reshape(B, C, H, W))
         return 0
 
     def mi355x_sd_conv3x3(self, X, ldx, B, Hs, Ws, Cin, stride, up, W, C, ldc, Cout, bias, rowbias, ld_rb, R, ldr,

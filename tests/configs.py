@@ -24,3 +24,13 @@ SDXL = dict(block_out_channels=(320, 640, 1280), down_block_types=("DownBlock2D"
             transformer_layers_per_block=(1, 2, 10), attention_head_dim=(5, 10, 20), cross_attention_dim=2048,
             use_linear_projection=True, addition_embed_type="text_time", addition_time_embed_dim=256,
             projection_class_embeddings_input_dim=2816, layers_per_block=2, sample_size=128)
+
+# SD3 MMDiT in miniature (the reference's own tiny test config, ppdiffusers/tests/models/test_models_transformer_sd3.py:60-73,
+# widened so that every GEMM K is a multiple of 8 and head_dim is 32)
+MINI_SD3 = dict(sample_size=32, patch_size=2, in_channels=4, num_layers=3, attention_head_dim=32, num_attention_heads=4,
+                caption_projection_dim=128, joint_attention_dim=64, pooled_projection_dim=64, out_channels=4,
+                pos_embed_max_size=96)
+# SD3-medium (public config: 24 layers, 24 heads x 64, joint dim 4096, pooled 2048, 16 latent channels, pos-embed 192)
+SD3_MEDIUM = dict(sample_size=128, patch_size=2, in_channels=16, num_layers=24, attention_head_dim=64,
+                  num_attention_heads=24, caption_projection_dim=1536, joint_attention_dim=4096,
+                  pooled_projection_dim=2048, out_channels=16, pos_embed_max_size=192)
