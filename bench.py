@@ -26,9 +26,14 @@ SDXL = dict(block_out_channels=(320, 640, 1280), down_block_types=("DownBlock2D"
             projection_class_embeddings_input_dim=2816, layers_per_block=2, sample_size=128)
 SD15 = dict(block_out_channels=(320, 640, 1280, 1280), cross_attention_dim=768, attention_head_dim=8, layers_per_block=2,
             sample_size=64)
+SD3_MEDIUM = dict(sample_size=128, patch_size=2, in_channels=16, num_layers=24, attention_head_dim=64,
+                  num_attention_heads=24, caption_projection_dim=1536, joint_attention_dim=4096,
+                  pooled_projection_dim=2048, out_channels=16, pos_embed_max_size=192)
 WORKLOADS = {
     "sdxl-1024-bs8": dict(cfg=SDXL, B=8, H=128, W=128, L=77, gflop_step=54089.8),
     "sd15-512-bs1": dict(cfg=SD15, B=1, H=64, W=64, L=77, gflop_step=803.3),
+    # SD3-medium MMDiT, bf16 weights (the fp8 weight path of BASELINE config 5 is not built): FLOPs from the plan
+    "sd3-1024-bs8": dict(cfg=SD3_MEDIUM, B=8, H=128, W=128, L=154, gflop_step=None, sd3=True),
 }
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16, MI355X_MICROARCH.md chip table
 
@@ -87,9 +92,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    from paddlemix_amd.schedulers import EulerDiscreteScheduler
+    from paddlemix_amd.schedulers import EulerDiscreteScheduler, FlowMatchEulerDiscreteScheduler
     from paddlemix_amd.unet import UNet2DConditionModel, synth_unet_params, unet_param_shapes
     from paddlemix_amd import _lib
+    is_sd3 = bool(WORKLOADS[args.workload].get("sd3"))
+    if is_sd3:
+        from paddlemix_amd.sd3 import SD3Transformer2DModel as UNet2DConditionModel  # same program interface
+        from paddlemix_amd.sd3 import sd3_param_shapes as unet_param_shapes, synth_sd3_params as synth_unet_params
 
     wl = WORKLOADS[args.workload]
     cfg, B, H, W, L = wl["cfg"], wl["B"], wl["H"], wl["W"], wl["L"]
@@ -109,25 +118,32 @@ def main():
         torch.cuda.synchronize()
         bcast_s = time.time() - t0
     model = UNet2DConditionModel(cfg, P, device=dev, use_graph=not args.no_graph)
-    P_cpu_needed = rank == 0 and world == 1 and not args.no_cpu_baseline
+    P_cpu_needed = rank == 0 and world == 1 and not args.no_cpu_baseline and not is_sd3
     if not P_cpu_needed:
         del P
     torch.cuda.empty_cache()
 
     # ---- synthetic inputs, resident in HBM ----
     g = torch.Generator(device=dev).manual_seed(rank)
-    sched = EulerDiscreteScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
-                                   timestep_spacing="leading", steps_offset=1)
-    n_sched = 30
+    if is_sd3:
+        sched = FlowMatchEulerDiscreteScheduler(shift=3.0)
+        n_sched = 28
+    else:
+        sched = EulerDiscreteScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                                       timestep_spacing="leading", steps_offset=1)
+        n_sched = 30
     sched.set_timesteps(n_sched)
-    latents = torch.randn(B, 4, H, W, generator=g, device=dev) * sched.init_noise_sigma
-    enc = torch.randn(B, L, cfg["cross_attention_dim"], generator=g, device=dev)
+    latents = torch.randn(B, cfg["in_channels"] if is_sd3 else 4, H, W, generator=g, device=dev) * sched.init_noise_sigma
+    enc = torch.randn(B, L, cfg["joint_attention_dim" if is_sd3 else "cross_attention_dim"], generator=g, device=dev)
+    pooled = torch.randn(B, cfg["pooled_projection_dim"], generator=g, device=dev) if is_sd3 else None
     added = None
     if cfg.get("addition_embed_type") == "text_time":
         td = cfg["projection_class_embeddings_input_dim"] - 6 * cfg["addition_time_embed_dim"]
         added = dict(text_embeds=torch.randn(B, td, generator=g, device=dev),
                      time_ids=torch.tensor([[1024., 1024., 0., 0., 1024., 1024.]], device=dev).repeat(B, 1))
     plan = model._get_plan(B, H, W, L)
+    if wl["gflop_step"] is None:
+        wl = dict(wl, gflop_step=sum(fl for _, _, _, fl in plan.prog) / 1e9)
     coef = torch.zeros(2, device=dev)
     lib = _lib.load()
     stream = model._stream
@@ -140,9 +156,13 @@ def main():
             sched._step_index = None
             latents.copy_(lat0)
         t = sched.timesteps[k]
-        scale = sched.model_input_scale(t)
-        a, b = sched.step_coefficients(t)
-        model.stage_inputs(plan, latents, float(t), enc, added, in_scale=scale)
+        if is_sd3:  # flow matching: x += (sigma_next - sigma) * v  (scheduling_flow_match_euler_discrete.py:244-278)
+            a, b = 1.0, float(sched.sigmas[k + 1] - sched.sigmas[k])
+            model.stage_inputs(plan, latents, enc, pooled, float(t))
+        else:
+            scale = sched.model_input_scale(t)
+            a, b = sched.step_coefficients(t)
+            model.stage_inputs(plan, latents, float(t), enc, added, in_scale=scale)
         coef.copy_(torch.tensor([a, b]), non_blocking=False)
         eps = model.run(plan)
         _lib.check(lib.mi355x_sd_axpby(latents.data_ptr(), eps.data_ptr(), latents.data_ptr(), coef.data_ptr(),
@@ -171,13 +191,14 @@ def main():
         elapsed = tmax.item()
 
     res = {
-        "metric": "UNet denoising steps/sec (SD-XL 1024^2, bs=8)" if args.workload == "sdxl-1024-bs8"
-        else "UNet denoising steps/sec (SD-1.5 512^2, bs=1)",
+        "metric": {"sdxl-1024-bs8": "UNet denoising steps/sec (SD-XL 1024^2, bs=8)",
+                   "sd15-512-bs1": "UNet denoising steps/sec (SD-1.5 512^2, bs=1)",
+                   "sd3-1024-bs8": "MMDiT denoising steps/sec (SD3-medium 1024^2, bs=8, bf16 weights)"}[args.workload],
         "value": world * args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": args.workload, "latents": [B, 4, H, W], "text": [B, L, cfg["cross_attention_dim"]],
-                   "batch_per_gpu": B, "global_batch": B * world, "scheduler": "EulerDiscrete/30",
+        "config": {"workload": args.workload, "latents": [B, cfg["in_channels"] if is_sd3 else 4, H, W], "text": [B, L, cfg["joint_attention_dim" if is_sd3 else "cross_attention_dim"]],
+                   "batch_per_gpu": B, "global_batch": B * world, "scheduler": "FlowMatchEuler/28" if is_sd3 else "EulerDiscrete/30",
                    "weights": "random-init bf16 (N(0,1/fan_in)), RCCL-broadcast from rank 0" if world > 1
                    else "random-init bf16 (N(0,1/fan_in))",
                    "parallelism": f"prompt-sharded dp{world}, no per-step collective", "hipgraph": not args.no_graph},
@@ -193,7 +214,10 @@ def main():
         with torch.cuda.stream(stream):
             for i in range(2):
                 model.kernel_times.clear()
-                model.stage_inputs(plan, latents, 500.0, enc, added, in_scale=0.5)
+                if is_sd3:
+                    model.stage_inputs(plan, latents, enc, pooled, 500.0)
+                else:
+                    model.stage_inputs(plan, latents, 500.0, enc, added, in_scale=0.5)
                 model._run_eager(plan)
         model.profile = False
         kinds, shapes = {}, {}
