@@ -242,6 +242,17 @@ def main():
                            "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
                            "launches_per_step": d["launches"], "avg_launch_ms": d["ms"] / d["launches"],
                            "algorithmic_gflop_per_step": d["gflop"]}
+        # HBM traffic comes from rocprofv3 PMC passes (scripts/traffic.sh: FETCH_SIZE / WRITE_SIZE in separate passes,
+        # gfx950 x2 read correction) -- it cannot be sampled from inside this process; the committed measurement of the
+        # same workload is attached when present.
+        tpath = os.path.join(ROOT, "profiles", f"r01_e_traffic_{args.workload}.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            cls = tj["classes"].get(dom)
+            if cls:
+                res["roofline"]["traffic"] = cls["hbm_bytes_per_launch"]
+                res["roofline"]["traffic_unit"] = "B/launch (class average; rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
+                res["roofline"]["traffic_source"] = os.path.relpath(tpath, ROOT)
         res["kernel_breakdown_ms"] = {k: round(v["ms"], 3) for k, v in sorted(kinds.items(), key=lambda kv: -kv[1]["ms"])}
         res["kernel_breakdown_tflops"] = {k: round(v["gflop"] / v["ms"], 1) for k, v in kinds.items() if v["gflop"] > 0}
         res["eager_step_ms_sum_of_kernels"] = total_ms
