@@ -81,18 +81,29 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_ker
     }
   }
 
-  // ---- K/V tile loader: thread owns CHUNKS 16-B chunks of the K tile and of the V tile ----
+  // ---- K/V tile loader: thread owns CHUNKS 16-B chunks of the K tile and of the V tile.  Buffer (SRD) loads: a
+  // per-lane 32-bit byte offset that never changes + a scalar per-tile offset; rows past Skv fall outside the
+  // descriptor's range and read as zero in hardware (no branches, no 64-bit address arithmetic in the loop). ----
   u32x4 rk[L::CHUNKS], rv[L::CHUNKS];
+  const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16*>(Kp), 0, (unsigned)(((size_t)(p.Skv - 1) * p.k_ts + p.D) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16*>(Vp), 0, (unsigned)(((size_t)(p.Skv - 1) * p.v_ts + p.D) * 2), 0x00020000);
+  unsigned k_off[L::CHUNKS], v_off[L::CHUNKS];
+#pragma unroll
+  for (int i = 0; i < L::CHUNKS; ++i) {
+    const int cid = tid + ATT_THREADS * i;
+    const int row = cid / (DP / 8), ch = cid - row * (DP / 8);
+    const bool col_ok = ch * 8 < p.D;   // padded head-dim columns: force out of range -> zeros
+    k_off[i] = col_ok ? (unsigned)((row * p.k_ts + ch * 8) * 2) : 0xFFFFFFF0u;
+    v_off[i] = col_ok ? (unsigned)((row * p.v_ts + ch * 8) * 2) : 0xFFFFFFF0u;
+  }
   auto load_kv = [&](int kv0) {
+    const int ks_off = kv0 * p.k_ts * 2, vs_off = kv0 * p.v_ts * 2;
 #pragma unroll
     for (int i = 0; i < L::CHUNKS; ++i) {
-      const int cid = tid + ATT_THREADS * i;
-      const int row = cid / (DP / 8), ch = cid - row * (DP / 8);
-      const int kv = kv0 + row;
-      const bool ok = (kv < p.Skv) && (ch * 8 < p.D);
-      const u32x4 z = {0u, 0u, 0u, 0u};
-      rk[i] = ok ? *reinterpret_cast<const u32x4*>(Kp + (size_t)kv * p.k_ts + ch * 8) : z;
-      rv[i] = ok ? *reinterpret_cast<const u32x4*>(Vp + (size_t)kv * p.v_ts + ch * 8) : z;
+      rk[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_off[i], ks_off, 0));
+      rv[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, v_off[i], vs_off, 0));
     }
   };
   auto store_kv = [&](int buf) {
@@ -180,15 +191,20 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_ker
     }
 
     // ---- online softmax (one query per lane column) ----
-    float mx[8];
+    // 3-input max tree (v_max3_f32).  This file is built with -fno-honor-nans: otherwise hipcc canonicalises every MFMA
+    // result before fmaxf (one extra v_max per score).  No inline asm here: an asm reader of MFMA results would need
+    // its own MFMA->VALU wait states (cdna guide 5.7).
+    auto max3 = [](float a, float b, float c) { return fmaxf(fmaxf(a, b), c); };
+    float mx[10];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)   // 3-input max tree (v_max3_f32)
-      mx[i] = fmaxf(fmaxf(s[i >> 2][(i & 3) * 4], s[i >> 2][(i & 3) * 4 + 1]),
-                    fmaxf(s[i >> 2][(i & 3) * 4 + 2], s[i >> 2][(i & 3) * 4 + 3]));
-    float mloc = fmaxf(fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3])), fmaxf(fmaxf(mx[4], mx[5]), fmaxf(mx[6], mx[7])));
+    for (int i = 0; i < 10; ++i) mx[i] = max3(s[(3 * i) >> 4][(3 * i) & 15], s[(3 * i + 1) >> 4][(3 * i + 1) & 15],
+                                              s[(3 * i + 2) >> 4][(3 * i + 2) & 15]);
+    float mloc = max3(max3(mx[0], mx[1], mx[2]), max3(mx[3], mx[4], mx[5]), max3(mx[6], mx[7], mx[8]));
+    mloc = max3(mloc, mx[9], fmaxf(s[1][14], s[1][15]));
     mloc = xhalf_max(mloc);
     // defer the rescale while the running max is still a good reference for every row of the wave
     if (!__all((mloc - m_run) * c2 <= RESCALE_THR)) {
+      asm volatile("; online-softmax rescale (rare; asm volatile keeps it from being speculated)");
       const float m_new = fmaxf(m_run, mloc);
       const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
       const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * c2);  // m_run = -inf -> 0
