@@ -32,8 +32,10 @@ SD3_MEDIUM = dict(sample_size=128, patch_size=2, in_channels=16, num_layers=24, 
 WORKLOADS = {
     "sdxl-1024-bs8": dict(cfg=SDXL, B=8, H=128, W=128, L=77, gflop_step=54089.8),
     "sd15-512-bs1": dict(cfg=SD15, B=1, H=64, W=64, L=77, gflop_step=803.3),
-    # SD3-medium MMDiT, bf16 weights (the fp8 weight path of BASELINE config 5 is not built): FLOPs from the plan
+    # SD3-medium MMDiT, bf16 weights (fp8 weights: the -fp8w workload): FLOPs from the plan
     "sd3-1024-bs8": dict(cfg=SD3_MEDIUM, B=8, H=128, W=128, L=154, gflop_step=None, sd3=True),
+    # BASELINE config 5: the same model with weight-only fp8 (e4m3 + per-channel scale) block matrices
+    "sd3-1024-bs8-fp8w": dict(cfg=SD3_MEDIUM, B=8, H=128, W=128, L=154, gflop_step=None, sd3=True, fp8=True),
 }
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16, MI355X_MICROARCH.md chip table
 
@@ -117,7 +119,8 @@ def main():
         broadcast_params(P, rank, world)
         torch.cuda.synchronize()
         bcast_s = time.time() - t0
-    model = UNet2DConditionModel(cfg, P, device=dev, use_graph=not args.no_graph)
+    kw = {"weight_dtype": "fp8"} if WORKLOADS[args.workload].get("fp8") else {}
+    model = UNet2DConditionModel(cfg, P, device=dev, use_graph=not args.no_graph, **kw)
     P_cpu_needed = rank == 0 and world == 1 and not args.no_cpu_baseline and not is_sd3
     if not P_cpu_needed:
         del P
@@ -193,7 +196,8 @@ def main():
     res = {
         "metric": {"sdxl-1024-bs8": "UNet denoising steps/sec (SD-XL 1024^2, bs=8)",
                    "sd15-512-bs1": "UNet denoising steps/sec (SD-1.5 512^2, bs=1)",
-                   "sd3-1024-bs8": "MMDiT denoising steps/sec (SD3-medium 1024^2, bs=8, bf16 weights)"}[args.workload],
+                   "sd3-1024-bs8": "MMDiT denoising steps/sec (SD3-medium 1024^2, bs=8, bf16 weights)",
+                   "sd3-1024-bs8-fp8w": "MMDiT denoising steps/sec (SD3-medium 1024^2, bs=8, fp8 weights)"}[args.workload],
         "value": world * args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",

@@ -56,9 +56,12 @@ int mi355x_sd_linear(const void* A, int lda, const void* W, void* C, int ldc, in
 /* mi355x_sd_linear plus what the SD3 MMDiT blocks (PPD/models/attention.py:164-214, attention_processor.py:916-983) need:
  *   gate  : out = R + gate[m / rows_per_batch][n] * (acc + bias)     (adaLN-Zero gated residuals, attention.py:181-196)
  *   a_/c_ rows_per_batch + batch_stride: row m of A (C) lives at (m / rpb) * batch_stride + (m % rpb) * lda (ldc) -- the
+ *   w_scale != NULL: W is OCP fp8 e4m3 [N][K] (one byte per element) with a per-output-channel fp32 scale, W ~ w_scale[n] * q;
+ *   the kernel widens q to bf16 in registers (exact) and scales the fp32 accumulator (weight-only fp8: BASELINE config 5).
  *   projections of the image and the text tokens read / write one joint [B, S_img + S_txt, .] buffer in place, which is
  *   the fused split + concat of paddlemix/triton_ops/triton_ops.py:1652-1752 (split_concat) folded into the GEMMs. */
-int mi355x_sd_linear_ex(const void* A, int lda, int a_rows_per_batch, int64_t a_batch_stride, const void* W, void* C,
+int mi355x_sd_linear_ex(const void* A, int lda, int a_rows_per_batch, int64_t a_batch_stride, const void* W,
+                        const float* w_scale, void* C,
                         int ldc, int c_rows_per_batch, int64_t c_batch_stride, int M, int N, int K, const float* bias,
                         const float* rowbias, int ld_rowbias, const float* gate, int ld_gate, int rows_per_batch,
                         const void* R, int ldr, float out_scale, int flags, void* stream);

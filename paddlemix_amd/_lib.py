@@ -18,7 +18,7 @@ SIGNATURES = {
     "mi355x_sd_init": (c_int, [c_int]),
     "mi355x_sd_linear": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                  c_int, c_int, c_void_p, c_int, c_float, c_int, c_void_p]),
-    "mi355x_sd_linear_ex": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int,
+    "mi355x_sd_linear_ex": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int,
                                     c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_float,
                                     c_int, c_void_p]),
     "mi355x_sd_adaln": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_int,

@@ -95,7 +95,8 @@ int mi355x_sd_linear(const void* A, int lda, const void* W, void* C, int ldc, in
   return finish(launch_gemm(g, S(stream)), "mi355x_sd_linear");
 }
 
-int mi355x_sd_linear_ex(const void* A, int lda, int a_rows_per_batch, int64_t a_batch_stride, const void* W, void* C,
+int mi355x_sd_linear_ex(const void* A, int lda, int a_rows_per_batch, int64_t a_batch_stride, const void* W,
+                        const float* w_scale, void* C,
                         int ldc, int c_rows_per_batch, int64_t c_batch_stride, int M, int N, int K, const float* bias,
                         const float* rowbias, int ld_rowbias, const float* gate, int ld_gate, int rows_per_batch,
                         const void* R, int ldr, float out_scale, int flags, void* stream) {
@@ -108,6 +109,7 @@ int mi355x_sd_linear_ex(const void* A, int lda, int a_rows_per_batch, int64_t a_
   g.c_rpb = c_rows_per_batch; g.c_bstride = (long)c_batch_stride;
   g.bias = bias; g.rowbias = rowbias; g.rows_per_batch = rows_per_batch; g.ld_rowbias = ld_rowbias;
   g.gate = gate; g.ld_gate = ld_gate;
+  g.wscale = w_scale;
   g.R = (const bf16*)R; g.ldr = ldr; g.out_scale = out_scale;
   g.geglu = (flags & MI355X_SD_GEGLU) ? 1 : 0;
   g.out_f32 = (flags & MI355X_SD_OUT_F32) ? 1 : 0;

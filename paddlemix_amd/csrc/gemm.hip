@@ -51,12 +51,18 @@ using Cfg256x160 = GemmCfg<4, 2, 4, 5>;   // 256 x 160: N = 1280 -> 8 column til
 using Cfg256x320 = GemmCfg<2, 4, 8, 5>;   // 256 x 320: N = 640 -> 2 column tiles
 using Cfg256x320g = GemmCfg<4, 2, 4, 10>; // 256 x 320 with an even tile count per wave (GEGLU value/gate pairs)
 
-template <bool CONV, class CFG>
+// W8 = true: W is fp8 e4m3 (OCP), 64-B LDS rows (16 rows per DMA piece, 16-B chunk index XOR (row>>2)&3 so the 8-byte
+// fragment reads are conflict free); fragments are widened to bf16 in registers (every e4m3 value is exact in bf16) and the
+// per-channel scale is applied to the fp32 accumulator in the epilogue. Halves the weight bytes a CU has to ingest.
+template <bool CONV, class CFG, bool W8 = false>
 __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_bf16_kernel(const GemmArgs p) {
   constexpr int BM = CFG::BM, BN = CFG::BN, TM = CFG::TM, TN = CFG::TN;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* As = smem;                       // [2][BM][BK] bf16, swizzled
-  unsigned char* Ws = smem + 2 * BM * BK * 2;     // [2][BN][BK]
+  unsigned char* Ws = smem + 2 * BM * BK * 2;     // [2][BN][BK] bf16 (or fp8: half of it used)
+  constexpr int W_ROW = W8 ? BK : BK * 2;         // bytes per LDS row of W
+  constexpr int W_PIECES = W8 ? (BN / 16 + CFG::NW - 1) / CFG::NW : CFG::W_PIECES;
+  constexpr int W_TOTAL = W8 ? BN / 16 : CFG::W_TOTAL;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -76,8 +82,8 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_bf16_kernel(const GemmAr
   const bf16* ga_base[CFG::A_PIECES];
   bool ga_ok[CFG::A_PIECES];
   int goy[CFG::A_PIECES], gox[CFG::A_PIECES];
-  const bf16* gw_base[CFG::W_PIECES];
-  bool gw_ok[CFG::W_PIECES];
+  const unsigned char* gw_base[W_PIECES];   // byte pointers (bf16 or fp8 rows)
+  bool gw_ok[W_PIECES];
 #pragma unroll
   for (int i = 0; i < CFG::A_PIECES; ++i) {
     const int m = m0 + (wave + i * CFG::NW) * 8 + g_sub;   // piece index = wave + i*NW (interleaved over waves)
@@ -97,11 +103,13 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_bf16_kernel(const GemmAr
       goy[i] = gox[i] = 0;
     }
   }
+  const int w_sub = W8 ? (lane >> 2) : g_sub;                                  // row inside a W piece
+  const int w_cg = W8 ? ((lane & 3) ^ ((lane >> 4) & 3)) : g_cg;               // source 16-B chunk (swizzled)
 #pragma unroll
-  for (int i = 0; i < CFG::W_PIECES; ++i) {
-    const int n = n0 + (wave + i * CFG::NW) * 8 + g_sub;
+  for (int i = 0; i < W_PIECES; ++i) {
+    const int n = n0 + (wave + i * CFG::NW) * (W8 ? 16 : 8) + w_sub;
     gw_ok[i] = n < p.N;
-    gw_base[i] = p.W + (size_t)(gw_ok[i] ? n : 0) * p.K + g_cg * 8;
+    gw_base[i] = reinterpret_cast<const unsigned char*>(p.W) + (size_t)(gw_ok[i] ? n : 0) * p.K * (W8 ? 1 : 2) + w_cg * 16;
   }
   int gtap = 0, gcch = g_cg * 8;   // conv: running (tap, channel) of this lane's chunk
   if (CONV) {
@@ -113,7 +121,7 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_bf16_kernel(const GemmAr
   auto issue_tile = [&](int k0, int buf) {
     const bool k_ok = (k0 + g_cg * 8) < p.K;
     unsigned char* a = As + buf * (BM * BK * 2) + wave * 1024;   // piece (wave + i*NW)
-    unsigned char* w = Ws + buf * (BN * BK * 2) + wave * 1024;
+    unsigned char* w = Ws + buf * (BN * W_ROW) + wave * 1024;
     if (CONV) {
       const int ky = gtap / 3, kx = gtap - ky * 3;
       const int Hin = p.Hs << p.up, Win = p.Ws << p.up;
@@ -140,10 +148,11 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_bf16_kernel(const GemmAr
           __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(a + i * (CFG::NW * 1024)), 16, 0, 0);
       }
     }
+    const bool kw_ok = W8 ? (k0 + w_cg * 16) < p.K : k_ok;
 #pragma unroll
-    for (int i = 0; i < CFG::W_PIECES; ++i) {
-      const bf16* src = (gw_ok[i] && k_ok) ? gw_base[i] + k0 : zsrc;
-      if (CFG::W_TOTAL % CFG::NW == 0 || wave + i * CFG::NW < CFG::W_TOTAL)
+    for (int i = 0; i < W_PIECES; ++i) {
+      const void* src = (gw_ok[i] && kw_ok) ? (const void*)(gw_base[i] + (size_t)k0 * (W8 ? 1 : 2)) : (const void*)zsrc;
+      if (W_TOTAL % CFG::NW == 0 || wave + i * CFG::NW < W_TOTAL)
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(w + i * (CFG::NW * 1024)), 16, 0, 0);
     }
   };
@@ -169,13 +178,24 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_bf16_kernel(const GemmAr
     const int buf = t & 1;
     if (t + 1 < nt) issue_tile((t + 1) * BK, buf ^ 1);
     const unsigned char* a = As + buf * (BM * BK * 2);
-    const unsigned char* w = Ws + buf * (BN * BK * 2);
+    const unsigned char* w = Ws + buf * (BN * W_ROW);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int coff = ((ks * 4 + fkc) ^ rsw) << 4;
       bf16x8 fa[TM], fw[TN];
 #pragma unroll
-      for (int i = 0; i < TN; ++i) fw[i] = *reinterpret_cast<const bf16x8*>(w + (w_row0 + i * 16) * (BK * 2) + coff);
+      for (int i = 0; i < TN; ++i) {
+        if (W8) {
+          // 8 fp8 of row (w_row0 + 16 i): 16-B chunk 2*ks + (fkc >> 1) swizzled by (row >> 2) & 3, half fkc & 1
+          const int c16 = ((2 * ks + (fkc >> 1)) ^ ((frow >> 2) & 3)) << 4;
+          const u32x2 raw = *reinterpret_cast<const u32x2*>(w + (w_row0 + i * 16) * BK + c16 + (fkc & 1) * 8);
+          const auto f0 = __builtin_amdgcn_cvt_pk_f32_fp8(raw[0], false), f1 = __builtin_amdgcn_cvt_pk_f32_fp8(raw[0], true);
+          const auto f2 = __builtin_amdgcn_cvt_pk_f32_fp8(raw[1], false), f3 = __builtin_amdgcn_cvt_pk_f32_fp8(raw[1], true);
+          fw[i] = bf16x8{(bf16)f0[0], (bf16)f0[1], (bf16)f1[0], (bf16)f1[1], (bf16)f2[0], (bf16)f2[1], (bf16)f3[0], (bf16)f3[1]};
+        } else {
+          fw[i] = *reinterpret_cast<const bf16x8*>(w + (w_row0 + i * 16) * (BK * 2) + coff);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(a + (a_row0 + i * 16) * (BK * 2) + coff);
 #pragma unroll
@@ -190,15 +210,15 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_bf16_kernel(const GemmAr
   gemm_epilogue<TM, TN>(p, acc, m0 + wm * (TM * 16), n0 + wn * (TN * 16), lane);
 }
 
-template <bool CONV, class CFG>
+template <bool CONV, class CFG, bool W8 = false>
 static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
   static const bool attr_ok = [] {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<CONV, CFG>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<CONV, CFG, W8>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES) == hipSuccess;
   }();
   if (!attr_ok) return SD_ERR_HIP;
   const int ntm = (a.M + CFG::BM - 1) / CFG::BM, ntn = (a.N + CFG::BN - 1) / CFG::BN;
-  hipLaunchKernelGGL((gemm_bf16_kernel<CONV, CFG>), dim3(ntm * ntn), dim3(CFG::THREADS), CFG::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL((gemm_bf16_kernel<CONV, CFG, W8>), dim3(ntm * ntn), dim3(CFG::THREADS), CFG::LDS_BYTES, stream, a);
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
 
@@ -216,12 +236,13 @@ static int pick_tile(const GemmArgs& a) {
   if (forced) return forced;
   if (a.M < 256) return 128;
   const bool wide_ok = (size_t)a.M * a.lda * 2 < (1ull << 31) && (size_t)a.N * a.K * 2 < (1ull << 31);
-  const TileChoice cand[] = {{128, 128, 128}, {160, 256, 160}, {257, 256, 256}, {320, 256, 320}};
+  const TileChoice cand[] = {{128, 128, 128}, {160, 256, 160}, {257, 256, 256}, {320, 256, 320}, {256, 256, 256}};
   int best = 128;
   double best_cost = 1e30;
   for (const TileChoice& c : cand) {
-    if (c.id == 257 && ((a.K & 63) || (a.conv && (a.Cin & 63)) || !wide_ok || a.a_rpb)) continue;
+    if (c.id == 257 && ((a.K & 63) || (a.conv && (a.Cin & 63)) || !wide_ok || a.a_rpb || a.wscale)) continue;
     if (a.geglu && c.id == 160) continue;   // odd number of 16-column tiles per wave
+    if (c.id == 256 && !a.wscale && !a.a_rpb) continue;   // the plain 256x256 loop only where the phased kernel cannot run
     const long tiles = (long)((a.M + c.bm - 1) / c.bm) * ((a.N + c.bn - 1) / c.bn);
     const long per_cu = (tiles + 255) / 256;
     double cost = (double)per_cu * (c.bm + c.bn);
@@ -248,6 +269,13 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   }
   if (a.rowbias && a.rows_per_batch <= 0) return SD_ERR_INVALID;
   const int tile = pick_tile(a);
+  if (a.wscale) {   // fp8 weights: generic configurations only
+    if (a.conv || (a.K & 15)) return SD_ERR_UNSUPPORTED;
+    if (tile == 160 && !a.geglu) return launch_cfg<false, Cfg256x160, true>(a, stream);
+    if (tile == 320) return a.geglu ? launch_cfg<false, Cfg256x320g, true>(a, stream) : launch_cfg<false, Cfg256x320, true>(a, stream);
+    if (tile == 256 || tile == 257) return launch_cfg<false, Cfg256, true>(a, stream);
+    return launch_cfg<false, Cfg128, true>(a, stream);
+  }
   if (tile == 257 && !((a.K & 63) || (a.conv && (a.Cin & 63)) || a.a_rpb)) return launch_gemm256(a, stream);
   if (tile == 256 || tile == 257) return a.conv ? launch_cfg<true, Cfg256>(a, stream) : launch_cfg<false, Cfg256>(a, stream);
   if (tile == 160 && !a.geglu)

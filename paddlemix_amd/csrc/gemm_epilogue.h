@@ -28,6 +28,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TN
         const int n_phys = n_wave + tp * 32 + nq;  // physical (interleaved) column of the value half
         if (n_phys >= p.N) continue;               // N % 32 == 0: the gate half of the pair is inside too
         f32x4 h = acc[2 * tp][tm], g = acc[(2 * tp + 1) % TN][tm];   // (% TN: odd-TN configs never take this path)
+        if (p.wscale) {
+          h *= *reinterpret_cast<const f32x4*>(p.wscale + n_phys);
+          g *= *reinterpret_cast<const f32x4*>(p.wscale + n_phys + 16);
+        }
         if (p.bias) {
           h += *reinterpret_cast<const f32x4*>(p.bias + n_phys);
           g += *reinterpret_cast<const f32x4*>(p.bias + n_phys + 16);
@@ -45,6 +49,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TN
         const int n = n_wave + tn * 16 + nq;
         if (n >= p.N) continue;
         f32x4 v = acc[tn][tm];
+        if (p.wscale) v *= *reinterpret_cast<const f32x4*>(p.wscale + n);
         if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
         if (rb) v += *reinterpret_cast<const f32x4*>(rb + n);
         if (gt) v *= *reinterpret_cast<const f32x4*>(gt + n);

@@ -34,6 +34,7 @@ struct GemmArgs {
   int ld_gate;            //   (adaLN-Zero gated residual, attention.py:181-196)
   int a_rpb;              // A row m lives at (m / a_rpb) * a_bstride + (m % a_rpb) * lda   (0: plain m * lda)
   long a_bstride;
+  const float* wscale;    // W is fp8 e4m3 [N][K] (1 byte / element) with per-output-channel scale: acc *= wscale[n]
   int c_rpb;              // same remap for the C rows (joint text+image token buffers of the MMDiT attention)
   long c_bstride;
   int dbg;                // ablation switches of gemm256.hip (MI355X_SD_GEMM_DBG; 0 in production)

@@ -239,7 +239,8 @@ def probe_layouts(device="cuda") -> Tensor:
     return out
 
 
-def linear_ex(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, gate: Optional[Tensor] = None,
+def linear_ex(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, w_scale: Optional[Tensor] = None,
+              gate: Optional[Tensor] = None,
               rows_per_batch: int = 0, residual: Optional[Tensor] = None, out: Optional[Tensor] = None,
               gelu_tanh: bool = False, silu: bool = False, out_f32: bool = False, a_rows_per_batch: int = 0,
               a_batch_stride: int = 0, c_rows_per_batch: int = 0, c_batch_stride: int = 0, M: Optional[int] = None) -> Tensor:
@@ -258,7 +259,7 @@ def linear_ex(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, gate: Opti
     ldc = N if c_rows_per_batch else _rows(out, "out", torch.float32 if out_f32 else torch.bfloat16)
     ld_gate = gate.stride(0) if gate is not None else 0
     flags = (OUT_F32 if out_f32 else 0) | (SILU if silu else 0) | (GELU_TANH if gelu_tanh else 0)
-    check(lib.mi355x_sd_linear_ex(a.data_ptr(), lda, a_rows_per_batch, a_batch_stride, w.data_ptr(), out.data_ptr(), ldc,
+    check(lib.mi355x_sd_linear_ex(a.data_ptr(), lda, a_rows_per_batch, a_batch_stride, w.data_ptr(), _p(w_scale), out.data_ptr(), ldc,
                                   c_rows_per_batch, c_batch_stride, M, N, K, _p(_vec(bias, N, "bias")), None, 0, _p(gate),
                                   ld_gate, rows_per_batch, _p(residual), _rows(residual, "residual") if residual is not None else 0,
                                   1.0, flags, _stream()))

@@ -116,14 +116,30 @@ def pos_embed_table(embed_dim: int, grid: int, base_size: int) -> np.ndarray:
     return np.concatenate([_sincos_1d(embed_dim // 2, mesh[0]), _sincos_1d(embed_dim // 2, mesh[1])], axis=1)
 
 
+def quantize_fp8_rows(w: Tensor):
+    """[N, K] fp32 -> (uint8 view of OCP e4m3 [N, K], fp32 scale [N]) with w ~ scale[n] * q (absmax / 448 per row)."""
+    scale = w.abs().amax(dim=1).clamp_min(1e-12) / 448.0
+    q = (w / scale[:, None]).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8).contiguous(), scale.to(torch.float32).contiguous()
+
+
+def dequantize_fp8_rows(q_u8: Tensor, scale: Tensor) -> Tensor:
+    return q_u8.view(torch.float8_e4m3fn).to(torch.float32) * scale[:, None]
+
+
 class Transformer2DModelOutput(SimpleNamespace):
     """``.sample`` holder (models/transformer_2d.py Transformer2DModelOutput)."""
 
 
 class SD3Transformer2DModel(DeviceProgram):
     def __init__(self, config: Mapping, params: Mapping[str, Tensor], device="cuda", use_graph: bool = True,
-                 profile: bool = False, _test_backend=None):
-        """``_test_backend``: test-only injection (tests/abi_emulator.py); never selected by product code."""
+                 profile: bool = False, weight_dtype: str = "bf16", _test_backend=None):
+        """``weight_dtype``: "bf16" | "fp8" -- fp8 stores the block matrices (QKV, out, FF of both streams) as OCP e4m3
+        with one fp32 scale per output channel (absmax / 448) and runs the weight-only-fp8 GEMM (BASELINE config 5).
+        ``_test_backend``: test-only injection (tests/abi_emulator.py); never selected by product code."""
+        if weight_dtype not in ("bf16", "fp8"):
+            raise ValueError(f"weight_dtype must be 'bf16' or 'fp8', got {weight_dtype!r}")
+        self.weight_dtype = weight_dtype
         self._init_backend(device, use_graph, profile, _test_backend)
         self.cfg = normalize_config(config)
         self.config = SimpleNamespace(**self.cfg)
@@ -148,6 +164,14 @@ class SD3Transformer2DModel(DeviceProgram):
         def put_lin(key, name):
             W[key + ".w"] = bf(get(name + ".weight").t())
             W[key + ".b"] = get(name + ".bias").contiguous()
+
+        def put_q(key, wt, bias):
+            """block matrix [N, K]: bf16, or fp8 e4m3 bytes + per-row scale"""
+            if self.weight_dtype == "fp8":
+                W[key + ".w"], W[key + ".s"] = quantize_fp8_rows(wt)
+            else:
+                W[key + ".w"] = bf(wt)
+            W[key + ".b"] = bias.contiguous()
 
         w = get("pos_embed.proj.weight")
         W["patch.w"] = bf(w.reshape(w.shape[0], -1))  # [D, C*p*p], columns (c, py, px)
@@ -177,16 +201,16 @@ class SD3Transformer2DModel(DeviceProgram):
             add_mod(b + ".norm1_context", b + ".norm1_context.linear")
             cat = lambda names: torch.cat([get(b + ".attn." + x + ".weight").t() for x in names], 0)  # noqa: E731
             catb = lambda names: torch.cat([get(b + ".attn." + x + ".bias") for x in names], 0)  # noqa: E731
-            W[b + ".qkv.w"], W[b + ".qkv.b"] = bf(cat(("to_q", "to_k", "to_v"))), catb(("to_q", "to_k", "to_v")).contiguous()
-            W[b + ".qkv_c.w"] = bf(cat(("add_q_proj", "add_k_proj", "add_v_proj")))
-            W[b + ".qkv_c.b"] = catb(("add_q_proj", "add_k_proj", "add_v_proj")).contiguous()
-            put_lin(b + ".out", b + ".attn.to_out.0")
-            put_lin(b + ".ff1", b + ".ff.net.0.proj")
-            put_lin(b + ".ff2", b + ".ff.net.2")
+            put_q(b + ".qkv", cat(("to_q", "to_k", "to_v")), catb(("to_q", "to_k", "to_v")))
+            put_q(b + ".qkv_c", cat(("add_q_proj", "add_k_proj", "add_v_proj")), catb(("add_q_proj", "add_k_proj", "add_v_proj")))
+            pq = lambda key, name: put_q(key, get(name + ".weight").t(), get(name + ".bias"))  # noqa: E731
+            pq(b + ".out", b + ".attn.to_out.0")
+            pq(b + ".ff1", b + ".ff.net.0.proj")
+            pq(b + ".ff2", b + ".ff.net.2")
             if not last:
-                put_lin(b + ".out_c", b + ".attn.to_add_out")
-                put_lin(b + ".ff1_c", b + ".ff_context.net.0.proj")
-                put_lin(b + ".ff2_c", b + ".ff_context.net.2")
+                pq(b + ".out_c", b + ".attn.to_add_out")
+                pq(b + ".ff1_c", b + ".ff_context.net.0.proj")
+                pq(b + ".ff2_c", b + ".ff_context.net.2")
         add_mod("norm_out", "norm_out.linear")
         W["mod_all.w"] = torch.cat(mod_w, 0).contiguous()
         W["mod_all.b"] = torch.cat(mod_b, 0).contiguous()
@@ -225,8 +249,10 @@ class SD3Transformer2DModel(DeviceProgram):
             w = W[wkey + ".w"]
             N, K = w.shape
             assert K == a.C, (wkey, K, a.C)
+            ws = W.get(wkey + ".s")
             emit(lib.mi355x_sd_linear_ex,
-                 (a.p, a.ld, a_rpb, a_bs, w.data_ptr(), out.p, out.ld, c_rpb, c_bs, a.rows, N, K,
+                 (a.p, a.ld, a_rpb, a_bs, w.data_ptr(), ws.data_ptr() if ws is not None else None, out.p, out.ld, c_rpb,
+                  c_bs, a.rows, N, K,
                   W[wkey + ".b"].data_ptr() if bias else None, None, 0, gate, MT if gate is not None else 0, rpb,
                   R.p if R else None, R.ld if R else 0, 1.0, flags, stream), "gemm", 2.0 * a.rows * N * K,
                  f"{a.rows}x{N}x{K}")

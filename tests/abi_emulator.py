@@ -74,7 +74,7 @@ class Emulator:
         self._epilogue(a @ w.t(), N, bias, rowbias, rpb, ld_rb, R, ldr, out_scale, flags, C, ldc)
         return 0
 
-    def mi355x_sd_linear_ex(self, A, lda, a_rpb, a_bs, W, C, ldc, c_rpb, c_bs, M, N, K, bias, rowbias, ld_rb, gate,
+    def mi355x_sd_linear_ex(self, A, lda, a_rpb, a_bs, W, w_scale, C, ldc, c_rpb, c_bs, M, N, K, bias, rowbias, ld_rb, gate,
                             ld_gate, rpb, R, ldr, out_scale, flags, stream):
         self.calls.append("linear_ex")
         assert K % 8 == 0 and N % 4 == 0 and lda % 8 == 0 and ldc % 4 == 0
@@ -89,8 +89,13 @@ class Emulator:
             return _flat(ptr, n, dtype).as_strided((nb, r_pb, cols), (bstride, ld, 1))
 
         a = remap_rows(A, M, K, lda, a_rpb, a_bs, torch.bfloat16).float().reshape(M, K)
-        w = _rows(W, N, K, K).float()
-        acc = a @ w.t()
+        if w_scale:
+            buf = (ctypes.c_char * (N * K)).from_address(W)
+            q = torch.frombuffer(buf, dtype=torch.uint8, count=N * K).reshape(N, K).view(torch.float8_e4m3fn).float()
+            acc = (a @ q.t()) * _flat(w_scale, N, torch.float32)
+        else:
+            w = _rows(W, N, K, K).float()
+            acc = a @ w.t()
         if bias:
             acc = acc + _flat(bias, N, torch.float32)
         if gate:
