@@ -22,12 +22,13 @@
  */
 #ifndef MI355X_SD_H
 #define MI355X_SD_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define MI355X_SD_ABI_VERSION 2
+#define MI355X_SD_ABI_VERSION 3
 #define MI355X_SD_OK 0
 #define MI355X_SD_ERR_INVALID 1      /* bad argument (shape <= 0, null pointer ...)          */
 #define MI355X_SD_ERR_UNSUPPORTED 2  /* well-formed but outside the implemented configurations */
@@ -37,6 +38,13 @@ int mi355x_sd_abi_version(void);
 const char* mi355x_sd_last_error(void);
 /* Selects `device` and verifies it is a gfx950 part. */
 int mi355x_sd_init(int device);
+
+/* Caller-owned scratch (device memory, 16-byte aligned) for the split-K partial sums of mi355x_sd_linear* /
+ * mi355x_sd_conv3x3. Launches that cannot fill the 256 CUs (batch-1 SD-1.5: 64..1024 rows against K up to 23040)
+ * split K over blockIdx.y, store fp32 slices here and reduce them in fixed order (deterministic). The pointer is read at
+ * launch time, so one stream's launches must not share a workspace with launches running concurrently on another
+ * stream. ptr == NULL (the initial state) disables split-K. The library never allocates ("no hidden allocation"). */
+int mi355x_sd_set_workspace(void* ptr, size_t bytes);
 
 /* flags for mi355x_sd_linear / mi355x_sd_conv3x3 */
 #define MI355X_SD_GEGLU 1    /* W/bias rows interleaved [16 value | 16 gate]; writes N/2 columns value*gelu_erf(gate) */

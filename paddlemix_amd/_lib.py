@@ -8,13 +8,14 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p, POINTER
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi355x_sd.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 GEGLU, OUT_F32, SILU, GELU_TANH = 1, 2, 4, 8
 
 # name -> (restype, argtypes); must list every symbol include/mi355x_sd.h declares (tests/test_abi.py checks)
 SIGNATURES = {
     "mi355x_sd_abi_version": (c_int, []),
     "mi355x_sd_last_error": (c_char_p, []),
+    "mi355x_sd_set_workspace": (c_int, [c_void_p, ctypes.c_size_t]),
     "mi355x_sd_init": (c_int, [c_int]),
     "mi355x_sd_linear": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                  c_int, c_int, c_void_p, c_int, c_float, c_int, c_void_p]),

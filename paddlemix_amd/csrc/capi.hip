@@ -64,6 +64,13 @@ __global__ void probe_kernel(float* out) {
 extern "C" {
 
 int mi355x_sd_abi_version(void) { return MI355X_SD_ABI_VERSION; }
+
+int mi355x_sd_set_workspace(void* ptr, size_t bytes) {
+  if (ptr && (reinterpret_cast<uintptr_t>(ptr) & 15))
+    return fail(SD_ERR_INVALID, "mi355x_sd_set_workspace: pointer must be 16-byte aligned");
+  sd::set_workspace(ptr, bytes);
+  return SD_OK;
+}
 const char* mi355x_sd_last_error(void) { return g_err; }
 
 int mi355x_sd_init(int device) {

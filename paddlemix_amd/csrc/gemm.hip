@@ -111,7 +111,13 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_bf16_kernel(const GemmAr
     gw_ok[i] = n < p.N;
     gw_base[i] = reinterpret_cast<const unsigned char*>(p.W) + (size_t)(gw_ok[i] ? n : 0) * p.K * (W8 ? 1 : 2) + w_cg * 16;
   }
-  int gtap = 0, gcch = g_cg * 8;   // conv: running (tap, channel) of this lane's chunk
+  const int nt_all = (p.K + BK - 1) / BK;
+  int t0 = 0, t1 = nt_all;   // k-tile range of this block (split-K: blockIdx.y picks the slice)
+  if (p.splitk > 1) {
+    t0 = blockIdx.y * p.kc;
+    t1 = min(nt_all, t0 + p.kc);
+  }
+  int gtap = 0, gcch = t0 * BK + g_cg * 8;   // conv: running (tap, channel) of this lane's chunk
   if (CONV) {
     gtap = gcch / p.Cin;
     gcch -= gtap * p.Cin;
@@ -170,13 +176,12 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_bf16_kernel(const GemmAr
   const int w_row0 = wn * (TN * 16) + frow;
   const int rsw = frow & 7;
 
-  const int nt = (p.K + BK - 1) / BK;
-  issue_tile(0, 0);
+  issue_tile(t0 * BK, 0);
   __syncthreads();
 
-  for (int t = 0; t < nt; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < nt) issue_tile((t + 1) * BK, buf ^ 1);
+  for (int t = t0; t < t1; ++t) {
+    const int buf = (t - t0) & 1;
+    if (t + 1 < t1) issue_tile((t + 1) * BK, buf ^ 1);
     const unsigned char* a = As + buf * (BM * BK * 2);
     const unsigned char* w = Ws + buf * (BN * W_ROW);
 #pragma unroll
@@ -207,7 +212,71 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_bf16_kernel(const GemmAr
     __syncthreads();
   }
 
+  if (p.splitk > 1) {   // raw partial sums -> ws[split][m][n]; the epilogue runs in splitk_reduce_kernel
+    float* ws = p.ws + (size_t)blockIdx.y * p.M * p.N;
+    const int nq = (lane >> 4) * 4;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int m = m0 + wm * (TM * 16) + tm * 16 + (lane & 15);
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int n = n0 + wn * (TN * 16) + tn * 16 + nq;
+        if (n < p.N) *reinterpret_cast<f32x4*>(ws + (size_t)m * p.N + n) = acc[tn][tm];
+      }
+    }
+    return;
+  }
   gemm_epilogue<TM, TN>(p, acc, m0 + wm * (TM * 16), n0 + wn * (TN * 16), lane);
+}
+
+// Deterministic split-K tail: wave = 16 rows x 32 columns in the MFMA accumulator layout, slices summed in index
+// order, then the common epilogue (so every fusion -- bias, temb, residual, GEGLU, fp8 scales -- is shared).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m_wave = blockIdx.x * 16, n_wave = blockIdx.y * 128 + wave * 32;
+  const int m = m_wave + (lane & 15), nq = (lane >> 4) * 4;
+  f32x4 acc[2][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}, {f32x4{0.f, 0.f, 0.f, 0.f}}};
+  if (m < p.M) {
+    const size_t slice = (size_t)p.M * p.N;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const int n = n_wave + tn * 16 + nq;
+      if (n >= p.N) continue;
+      const float* src = p.ws + (size_t)m * p.N + n;
+#pragma unroll 4
+      for (int s = 0; s < p.splitk; ++s) acc[tn][0] += *reinterpret_cast<const f32x4*>(src + s * slice);
+    }
+  }
+  gemm_epilogue<1, 2>(p, acc, m_wave, n_wave, lane);
+}
+
+static void* g_ws = nullptr;
+static size_t g_ws_bytes = 0;
+void set_workspace(void* ptr, size_t bytes) {
+  g_ws = ptr;
+  g_ws_bytes = ptr ? bytes : 0;
+}
+
+// Split-K plan for launches that cannot fill the chip (SD-1.5 at batch 1: 64..1024 rows against K up to 23040, i.e.
+// weight-streaming problems where 10-40 tiles would otherwise pull the whole weight matrix through 10-40 CUs).
+// Target ~2 blocks per CU, at least 4 k-tiles per slice, partial sums bounded by the workspace.
+static void plan_splitk(GemmArgs& a, int bm, int bn) {
+  a.splitk = 0;
+  static const bool off = getenv("MI355X_SD_NO_SPLITK") != nullptr;
+  if (!g_ws || off) return;
+  const long tiles = (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn);
+  const int nt = (a.K + BK - 1) / BK;
+  if (tiles > 128 || nt < 8) return;
+  long s = (512 + tiles - 1) / tiles;
+  s = std::min<long>(s, nt / 4);
+  const size_t slice = (size_t)a.M * a.N * sizeof(float);
+  s = std::min<long>(s, (long)(g_ws_bytes / slice));
+  if (s < 2) return;
+  a.kc = (nt + (int)s - 1) / (int)s;
+  a.splitk = (nt + a.kc - 1) / a.kc;
+  a.ws = static_cast<float*>(g_ws);
+  if (a.splitk < 2) a.splitk = 0;
 }
 
 template <bool CONV, class CFG, bool W8 = false>
@@ -218,7 +287,10 @@ static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
   }();
   if (!attr_ok) return SD_ERR_HIP;
   const int ntm = (a.M + CFG::BM - 1) / CFG::BM, ntn = (a.N + CFG::BN - 1) / CFG::BN;
-  hipLaunchKernelGGL((gemm_bf16_kernel<CONV, CFG, W8>), dim3(ntm * ntn), dim3(CFG::THREADS), CFG::LDS_BYTES, stream, a);
+  const int ny = a.splitk > 1 ? a.splitk : 1;
+  hipLaunchKernelGGL((gemm_bf16_kernel<CONV, CFG, W8>), dim3(ntm * ntn, ny), dim3(CFG::THREADS), CFG::LDS_BYTES, stream, a);
+  if (a.splitk > 1)
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((a.M + 15) / 16, (a.N + 127) / 128), dim3(256), 0, stream, a);
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
 
@@ -255,7 +327,9 @@ static int pick_tile(const GemmArgs& a) {
   return best;
 }
 
-int launch_gemm(const GemmArgs& a, hipStream_t stream) {
+int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
+  GemmArgs a = a_in;
+  a.splitk = 0;
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return SD_ERR_INVALID;
   if ((a.K & 7) || (a.N & 3) || (a.lda & 7) || (a.ldc & 3)) return SD_ERR_UNSUPPORTED;
   if (a.R && (a.ldr & 3)) return SD_ERR_UNSUPPORTED;
@@ -269,6 +343,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   }
   if (a.rowbias && a.rows_per_batch <= 0) return SD_ERR_INVALID;
   const int tile = pick_tile(a);
+  if (tile == 128) plan_splitk(a, 128, 128);
   if (a.wscale) {   // fp8 weights: generic configurations only
     if (a.conv || (a.K & 15)) return SD_ERR_UNSUPPORTED;
     if (tile == 160 && !a.geglu) return launch_cfg<false, Cfg256x160, true>(a, stream);

@@ -38,7 +38,13 @@ struct GemmArgs {
   int c_rpb;              // same remap for the C rows (joint text+image token buffers of the MMDiT attention)
   long c_bstride;
   int dbg;                // ablation switches of gemm256.hip (MI355X_SD_GEMM_DBG; 0 in production)
+  // split-K (filled in by launch_gemm, callers leave 0): blockIdx.y owns k-tiles [y*kc, (y+1)*kc) and stores its raw
+  // fp32 accumulators to ws[y][M][N]; splitk_reduce_kernel sums the slices in fixed order and runs the epilogue.
+  int splitk, kc;
+  float* ws;
 };
+// caller-owned scratch for split-K partial sums (mi355x_sd_set_workspace); no workspace -> no split-K
+void set_workspace(void* ptr, size_t bytes);
 int launch_gemm(const GemmArgs& a, hipStream_t stream);
 int launch_gemm256(const GemmArgs& a, hipStream_t stream);   // phased 256x256 kernel (gemm256.hip); args pre-validated
 

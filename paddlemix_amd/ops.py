@@ -20,6 +20,18 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+_workspaces = {}
+
+
+def _bind_workspace(dev: torch.device, nbytes: int = 32 << 20) -> None:
+    """split-K scratch for the stand-alone op wrappers (one per device, bound before every GEMM launch because the
+    library reads the pointer at launch time and a DeviceProgram may have bound its own in between)."""
+    ws = _workspaces.get(dev)
+    if ws is None:
+        ws = _workspaces[dev] = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    check(_lib.load().mi355x_sd_set_workspace(ws.data_ptr(), ws.numel()))
+
+
 def _p(t: Optional[Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -51,6 +63,7 @@ def linear(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, rowbias: Opti
            out_scale: float = 1.0, geglu: bool = False, silu: bool = False, out_f32: bool = False) -> Tensor:
     """out[M,N] = ((a[M,K] @ w[N,K]^T) + bias + rowbias[m // rows_per_batch] + residual) * out_scale."""
     lib = _lib.load()
+    _bind_workspace(a.device)
     lda = _rows(a, "a")
     M, K = a.shape
     if w.dtype != torch.bfloat16 or not w.is_contiguous() or w.dim() != 2 or w.shape[1] != K:
@@ -80,6 +93,7 @@ def conv3x3(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, stride: int 
             out_scale: float = 1.0) -> Tensor:
     """x NHWC view [B,H,W,C] (pixel stride >= C), w [Cout, 9*Cin] -> rows [B*Ho*Wo, Cout]."""
     lib = _lib.load()
+    _bind_workspace(x.device)
     if x.dim() != 4 or x.dtype != torch.bfloat16 or x.stride(3) != 1 or not x.is_cuda:
         raise ValueError("x: expected bf16 cuda NHWC [B,H,W,C]")
     B, H, W, C = x.shape
@@ -247,6 +261,7 @@ def linear_ex(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, w_scale: O
     """mi355x_sd_linear_ex: out = residual + gate[m // rows_per_batch] * (a @ w^T + bias), optional row remaps of a / out
     (then `a` / `out` are the flat base tensors and M is given explicitly)."""
     lib = _lib.load()
+    _bind_workspace(a.device)
     N, K = w.shape
     if a_rows_per_batch:
         lda = K if a.dim() == 1 else a.stride(0)

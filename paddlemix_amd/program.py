@@ -9,6 +9,8 @@ import torch
 
 from . import _lib
 
+WORKSPACE_BYTES = 32 << 20   # split-K partial sums (the planner shrinks the split count to fit)
+
 
 class _Ref:
     """Symbolic device address inside a named scratch buffer (resolved after all sizes are known)."""
@@ -57,6 +59,8 @@ class DeviceProgram:
             _lib.check(self._lib.mi355x_sd_init(self.device.index))
             self._stream = torch.cuda.Stream(device=self.device)
             self._stream_ptr = self._stream.cuda_stream
+            # split-K scratch of this model's stream (mi355x_sd_set_workspace): owned here, baked into the graphs
+            self._workspace = torch.empty(WORKSPACE_BYTES, device=self.device, dtype=torch.uint8)
         self.dtype = torch.bfloat16
         self.use_graph = use_graph
         self.profile = profile
@@ -67,7 +71,12 @@ class DeviceProgram:
     def weight_bytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self.w.values())
 
+    def _bind_workspace(self) -> None:
+        if not self._emulated:
+            _lib.check(self._lib.mi355x_sd_set_workspace(self._workspace.data_ptr(), self._workspace.numel()))
+
     def _run_eager(self, plan: _Plan) -> None:
+        self._bind_workspace()
         if not self.profile or self._emulated:
             for fn, args, _, _ in plan.prog:
                 rc = fn(*args)
@@ -90,6 +99,7 @@ class DeviceProgram:
     def _capture(self, plan: _Plan) -> None:
         lib = self._lib
         sp = self._stream_ptr
+        self._bind_workspace()
         _lib.check(lib.mi355x_sd_graph_begin(sp))
         try:
             for fn, args, _, _ in plan.prog:

@@ -38,6 +38,9 @@ class Emulator:
     def mi355x_sd_init(self, device):
         return 0
 
+    def mi355x_sd_set_workspace(self, ptr, nbytes):
+        return 0
+
     def mi355x_sd_last_error(self):
         return b"emulator"
 

@@ -159,6 +159,59 @@ def test_conv3x3_resnet_epilogues(ops):
     assert (big[:, :32] == 0).all() and (big[:, 32 + Cout:] == 0).all()
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 1280, 11520), (256, 1280, 5120), (1, 1280, 1280), (1000, 328, 2888)])
+def test_linear_splitk_epilogues(ops, M, N, K):
+    """Few rows against a long K: the launch splits K over blockIdx.y and the slices are reduced in fixed order before
+    the fused epilogue (temb row bias + residual + scale); run twice -> bit-identical."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = bfr(torch.randn(M, K, generator=g))
+    w = bfr(torch.randn(N, K, generator=g) / math.sqrt(K))
+    bias = torch.randn(N, generator=g) * 0.1
+    rpb = M // 2 if M % 2 == 0 else M
+    rb = torch.randn(M // rpb, N, generator=g)
+    res = bfr(torch.randn(M, N, generator=g))
+    ref = (a @ w.t() + bias + rb.repeat_interleave(rpb, 0) + res) * 0.5
+    args = (dev(a), dev(w), dev(bias, torch.float32))
+    kw = dict(rowbias=dev(rb, torch.float32), rows_per_batch=rpb, residual=dev(res), out_scale=0.5)
+    out = ops.linear(*args, **kw)
+    check(out, ref, what=f"split-K linear {M,N,K}")
+    assert torch.equal(out, ops.linear(*args, **kw))
+    out32 = ops.linear(dev(a), dev(w), dev(bias, torch.float32), out_f32=True)
+    r32 = a @ w.t() + bias
+    assert out32.dtype == torch.float32 and (out32.cpu() - r32).norm() / r32.norm() < 1e-3
+
+
+def test_geglu_splitk(ops):
+    g = torch.Generator().manual_seed(5)
+    M, C = 64, 1280
+    x = bfr(torch.randn(M, C, generator=g))
+    w1 = bfr(torch.randn(8 * C, C, generator=g) / math.sqrt(C))
+    b1 = torch.randn(8 * C, generator=g) * 0.1
+    half = 4 * C
+    h = x @ w1.t() + b1
+    ref = h[:, :half] * F.gelu(h[:, half:])
+    w1i = torch.stack([w1[:half].reshape(half // 16, 16, C), w1[half:].reshape(half // 16, 16, C)], 1).reshape(8 * C, C)
+    b1i = torch.stack([b1[:half].reshape(half // 16, 16), b1[half:].reshape(half // 16, 16)], 1).reshape(-1)
+    out = ops.linear(dev(x), dev(w1i.contiguous()), dev(b1i.contiguous(), torch.float32), geglu=True)
+    check(out, ref, what="split-K geglu")
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,up", [(1, 8, 8, 1280, 1280, 1, False), (1, 16, 16, 640, 1280, 2, False),
+                                                      (1, 8, 8, 2560, 1280, 1, True), (1, 32, 32, 320, 320, 1, False)])
+def test_conv3x3_splitk(ops, B, H, W, Cin, Cout, stride, up):
+    """SD-1.5 batch-1 low-resolution convolutions: 64..1024 output pixels against K = 9 Cin up to 23040."""
+    g = torch.Generator().manual_seed(H + Cin + Cout + stride)
+    x = bfr(torch.randn(B, Cin, H, W, generator=g))
+    w = bfr(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin))
+    bias = torch.randn(Cout, generator=g) * 0.1
+    xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if up else x
+    ref = F.conv2d(xin, w, bias, stride=stride, padding=1)
+    out = ops.conv3x3(dev(x.permute(0, 2, 3, 1).contiguous()), dev(w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous()),
+                      dev(bias, torch.float32), stride=stride, upsample=up)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    check(out.reshape(B, Ho, Wo, Cout).permute(0, 3, 1, 2), ref, what=f"split-K conv {B,H,W,Cin,Cout,stride,up}")
+
+
 @pytest.mark.parametrize("B,H,Sq,Skv,D", [(2, 4, 256, 256, 64), (1, 8, 1024, 1024, 64), (2, 5, 200, 77, 64),
                                           (1, 8, 320, 320, 40), (1, 8, 128, 77, 80), (1, 8, 64, 64, 160),
                                           (1, 2, 33, 130, 8), (1, 2, 4096, 4096, 64)])
