@@ -133,6 +133,17 @@ int mi355x_sd_conv_in3x3(const float* x_nchw, const float* in_scale, const void*
 int mi355x_sd_conv_out3x3(const void* x, int ldx, const void* w, const float* bias, float* y_nchw,
                           int B, int Cin, int H, int W, int Cout, void* stream);
 int mi355x_sd_copy_rows(const void* x, int ldx, void* y, int ldy, int64_t rows, int C, void* stream);
+
+/* ---- AutoencoderKL decoder (PPD/models/autoencoder_kl.py:288-333, PPD/models/vae.py:182-343) ----
+ * post_quant_conv (autoencoder_kl.py:121,292-293): 1x1 convolution of a small NCHW fp32 tensor, Cin, Cout <= 16,
+ * y[b,co,p] = bias[co] + sum_ci w[co][ci] * bf16(x[b,ci,p] * in_scale); in_scale = 1 / scaling_factor of the calling
+ * pipeline (pipeline_stable_diffusion.py:911). w bf16 [Cout][Cin]. */
+int mi355x_sd_conv1x1_nchw(const float* x_nchw, float in_scale, const void* w, const float* bias, float* y_nchw,
+                           int B, int Cin, int Cout, int64_t HW, void* stream);
+/* y[r][0..n) = softmax(x[r][0..n)), x fp32 (scale already applied), y bf16; n % 4 == 0. The VAE mid-block attention
+ * (one head of width C = 512: Attention(..., heads = C // C), unet_2d_blocks.py:606-619; get_attention_scores with
+ * upcast_softmax, attention_processor.py:552-586) runs as linear(Q K^T, OUT_F32) -> softmax_rows -> linear(P V). */
+int mi355x_sd_softmax_rows(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int n, void* stream);
 /* out = coef[0]*x + coef[1]*y on fp32 latents, coef in device memory: the linear latent update every
  * epsilon-prediction scheduler step reduces to (PPD/schedulers/scheduling_euler_discrete.py:438-473,
  * scheduling_ddim.py:410-457 with eta = 0). */

@@ -46,6 +46,9 @@ SIGNATURES = {
     "mi355x_sd_conv_out3x3": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                       c_void_p]),
     "mi355x_sd_copy_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p]),
+    "mi355x_sd_conv1x1_nchw": (c_int, [c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64,
+                                         c_void_p]),
+    "mi355x_sd_softmax_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "mi355x_sd_axpby": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "mi355x_sd_graph_begin": (c_int, [c_void_p]),
     "mi355x_sd_graph_end": (c_int, [c_void_p, POINTER(c_void_p)]),

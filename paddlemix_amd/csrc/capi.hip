@@ -239,6 +239,19 @@ int mi355x_sd_copy_rows(const void* x, int ldx, void* y, int ldy, int64_t rows, 
   return finish(launch_copy_rows((const bf16*)x, ldx, (bf16*)y, ldy, (long)rows, C, S(stream)), "mi355x_sd_copy_rows");
 }
 
+int mi355x_sd_conv1x1_nchw(const float* x_nchw, float in_scale, const void* w, const float* bias, float* y_nchw, int B,
+                           int Cin, int Cout, int64_t HW, void* stream) {
+  if (!x_nchw || !w || !y_nchw) return fail(SD_ERR_INVALID, "mi355x_sd_conv1x1_nchw: null pointer");
+  return finish(launch_conv1x1_nchw(x_nchw, in_scale, (const bf16*)w, bias, y_nchw, B, Cin, Cout, (long)HW, S(stream)),
+                "mi355x_sd_conv1x1_nchw");
+}
+
+int mi355x_sd_softmax_rows(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int n, void* stream) {
+  if (!x || !y) return fail(SD_ERR_INVALID, "mi355x_sd_softmax_rows: null pointer");
+  return finish(launch_softmax_rows(x, (long)ldx, (bf16*)y, (long)ldy, (long)rows, n, S(stream)),
+                "mi355x_sd_softmax_rows");
+}
+
 int mi355x_sd_axpby(const float* x, const float* y, float* out, const float* coef, int64_t n, void* stream) {
   if (!x || !y || !out || !coef) return fail(SD_ERR_INVALID, "mi355x_sd_axpby: null pointer");
   return finish(launch_axpby(x, y, out, coef, (long)n, S(stream)), "mi355x_sd_axpby");

@@ -187,6 +187,86 @@ int launch_conv_out3x3(const bf16* x, int ldx, const bf16* w, const float* bias,
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
 
+// 1x1 convolution on a small NCHW fp32 tensor (AutoencoderKL.post_quant_conv, autoencoder_kl.py:121,292-293, folded
+// with the 1 / scaling_factor of the pipelines): y[b,co,p] = bias[co] + sum_ci w[co][ci] * bf16(x[b,ci,p] * in_scale).
+constexpr int C1_MAX = 16;
+__global__ void conv1x1_nchw_kernel(const float* __restrict__ x, float in_scale, const bf16* __restrict__ w,
+                                    const float* __restrict__ bias, float* __restrict__ y, int B, int Cin, int Cout,
+                                    long HW) {
+  const long total = (long)B * HW;
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long)gridDim.x * blockDim.x) {
+    const long b = id / HW, px = id - b * HW;
+    float xv[C1_MAX];
+#pragma unroll
+    for (int ci = 0; ci < C1_MAX; ++ci)
+      if (ci < Cin) xv[ci] = (float)(bf16)(x[((size_t)b * Cin + ci) * HW + px] * in_scale);
+    for (int co = 0; co < Cout; ++co) {
+      float acc = bias ? bias[co] : 0.f;
+#pragma unroll
+      for (int ci = 0; ci < C1_MAX; ++ci)
+        if (ci < Cin) acc = __builtin_fmaf(xv[ci], (float)w[co * Cin + ci], acc);
+      y[((size_t)b * Cout + co) * HW + px] = acc;
+    }
+  }
+}
+
+int launch_conv1x1_nchw(const float* x, float in_scale, const bf16* w, const float* bias, float* y, int B, int Cin,
+                        int Cout, long HW, hipStream_t stream) {
+  if (B <= 0 || Cin <= 0 || Cout <= 0 || HW <= 0) return SD_ERR_INVALID;
+  if (Cin > C1_MAX || Cout > C1_MAX) return SD_ERR_UNSUPPORTED;
+  long nb = ((long)B * HW + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(conv1x1_nchw_kernel, dim3((unsigned)nb), dim3(256), 0, stream, x, in_scale, w, bias, y, B, Cin,
+                     Cout, HW);
+  return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+}
+
+// Row softmax of an fp32 score matrix into bf16 probabilities: y[r][j] = softmax_j(x[r][j]) (the scale is already in x).
+// The single-head, head_dim = C attention of the VAE mid block (attention_processor.py:552-586 with upcast_softmax)
+// is run as GEMM -> this -> GEMM because a 512-wide head does not fit the fused kernel's register budget.
+// One 256-thread block per row; the row (<= 64 KB at 16384 keys) is re-read from L2 for the three passes.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, long ldx, bf16* __restrict__ y,
+                                                           long ldy, int n) {
+  __shared__ float red[4];
+  const float* xr = x + (size_t)blockIdx.x * ldx;
+  bf16* yr = y + (size_t)blockIdx.x * ldy;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n4 = n >> 2;
+  float m = -INFINITY;
+  for (int i = tid; i < n4; i += 256) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(xr)[i];
+    m = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+  }
+  m = wave_max(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int i = tid; i < n4; i += 256) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(xr)[i];
+    s += __expf(v[0] - m) + __expf(v[1] - m) + __expf(v[2] - m) + __expf(v[3] - m);
+  }
+  s = wave_sum(s);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  s = (red[0] + red[1]) + (red[2] + red[3]);   // fixed order: deterministic
+  const float inv = 1.0f / s;
+  for (int i = tid; i < n4; i += 256) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(xr)[i];
+    u32x2 pk = {pack_bf16(__expf(v[0] - m) * inv, __expf(v[1] - m) * inv),
+                pack_bf16(__expf(v[2] - m) * inv, __expf(v[3] - m) * inv)};
+    reinterpret_cast<u32x2*>(yr)[i] = pk;
+  }
+}
+
+int launch_softmax_rows(const float* x, long ldx, bf16* y, long ldy, long rows, int n, hipStream_t stream) {
+  if (rows <= 0 || n <= 0) return SD_ERR_INVALID;
+  if ((n & 3) || (ldx & 3) || (ldy & 3) || rows > 0x7fffffffL) return SD_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, stream, x, ldx, y, ldy, n);
+  return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+}
+
 __global__ void copy_rows_kernel(const bf16* __restrict__ x, int ldx, bf16* __restrict__ y, int ldy, long rows, int cv) {
   const long total = rows * cv;
   for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long)gridDim.x * blockDim.x) {

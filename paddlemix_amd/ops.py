@@ -308,3 +308,30 @@ def unpatchify(x: Tensor, B: int, C: int, H: int, W: int, patch: int) -> Tensor:
     out = torch.empty((B, C, H, W), device=x.device, dtype=torch.float32)
     check(lib.mi355x_sd_unpatchify(x.data_ptr(), _rows(x, "x"), B, C, H, W, patch, out.data_ptr(), _stream()))
     return out
+
+
+def conv1x1_nchw(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, in_scale: float = 1.0) -> Tensor:
+    """post_quant_conv: x fp32 [B, Cin, H, W], w bf16 [Cout, Cin] -> fp32 [B, Cout, H, W]."""
+    lib = _lib.load()
+    if not x.is_cuda or x.dtype != torch.float32 or not x.is_contiguous() or x.dim() != 4:
+        raise ValueError("x: expected a contiguous fp32 NCHW GPU tensor")
+    B, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    if w.dtype != torch.bfloat16 or tuple(w.shape) != (Cout, Cin) or not w.is_contiguous():
+        raise ValueError(f"w: expected contiguous bf16 [Cout, {Cin}]")
+    y = torch.empty((B, Cout, H, W), device=x.device, dtype=torch.float32)
+    check(lib.mi355x_sd_conv1x1_nchw(x.data_ptr(), float(in_scale), w.data_ptr(), _p(_vec(bias, Cout, "bias")),
+                                     y.data_ptr(), B, Cin, Cout, H * W, _stream()))
+    return y
+
+
+def softmax_rows(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """bf16 softmax over the last dim of an fp32 [rows, n] matrix."""
+    lib = _lib.load()
+    if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("x: expected an fp32 [rows, n] GPU tensor with unit inner stride")
+    rows, n = x.shape
+    if out is None:
+        out = torch.empty((rows, n), device=x.device, dtype=torch.bfloat16)
+    check(lib.mi355x_sd_softmax_rows(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), rows, n, _stream()))
+    return out

@@ -243,6 +243,22 @@ class Emulator:
         _flat(y, B * Cout * H * W, torch.float32).reshape(B, Cout, H, W).copy_(o)
         return 0
 
+    def mi355x_sd_conv1x1_nchw(self, x, in_scale, w, bias, y, B, Cin, Cout, HW, stream):
+        assert Cin <= 16 and Cout <= 16
+        xi = (_flat(x, B * Cin * HW, torch.float32).reshape(B, Cin, HW) * in_scale).to(torch.bfloat16).float()
+        wt = _flat(w, Cout * Cin, torch.bfloat16).reshape(Cout, Cin).float()
+        out = torch.einsum("oc,bcp->bop", wt, xi)
+        if bias:
+            out = out + _flat(bias, Cout, torch.float32)[None, :, None]
+        _flat(y, B * Cout * HW, torch.float32).copy_(out.reshape(-1))
+        return 0
+
+    def mi355x_sd_softmax_rows(self, x, ldx, y, ldy, rows, n, stream):
+        assert n % 4 == 0 and ldx % 4 == 0 and ldy % 4 == 0
+        xi = _rows(x, rows, n, ldx, torch.float32)
+        _rows(y, rows, n, ldy).copy_(torch.softmax(xi, -1).to(torch.bfloat16))
+        return 0
+
     def mi355x_sd_copy_rows(self, x, ldx, y, ldy, rows, C, stream):
         self.calls.append("copy_rows")
         _rows(y, rows, C, ldy).copy_(_rows(x, rows, C, ldx))

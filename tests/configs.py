@@ -34,3 +34,9 @@ MINI_SD3 = dict(sample_size=32, patch_size=2, in_channels=4, num_layers=3, atten
 SD3_MEDIUM = dict(sample_size=128, patch_size=2, in_channels=16, num_layers=24, attention_head_dim=64,
                   num_attention_heads=24, caption_projection_dim=1536, joint_attention_dim=4096,
                   pooled_projection_dim=2048, out_channels=16, pos_embed_max_size=192)
+# AutoencoderKL decoder in miniature (same structure as the SD VAE: 3 levels here, 32 groups -> channels multiples of 32)
+MINI_VAE = dict(in_channels=3, out_channels=3, latent_channels=4, block_out_channels=(32, 64, 64), layers_per_block=1,
+                norm_num_groups=32, scaling_factor=0.18215, use_post_quant_conv=True)
+# SD-1.5 / SDXL VAE (public config: 128-256-512-512, 2 layers per block; SDXL scaling_factor 0.13025)
+SD_VAE = dict(in_channels=3, out_channels=3, latent_channels=4, block_out_channels=(128, 256, 512, 512),
+              layers_per_block=2, norm_num_groups=32, scaling_factor=0.18215, use_post_quant_conv=True)
