@@ -4,8 +4,10 @@ MI355X UNet in the ``unet`` slot.
 Mirrors ppdiffusers/ppdiffusers/pipelines/stable_diffusion/pipeline_stable_diffusion.py:813-908 (SDXL:
 stable_diffusion_xl/pipeline_stable_diffusion_xl.py:1039-1093): classifier-free-guidance batch doubling,
 ``scheduler.scale_model_input``, the UNet call, the guidance combine (+ optional ``rescale_noise_cfg`` :69-80),
-``scheduler.step`` and ``callback_on_step_end``.  Prompt encoding (CLIP / T5) and VAE decoding are the "next rows" of
-SURVEY.md 8f and stay outside: the loop starts from ``prompt_embeds`` and returns latents (``output_type="latent"``).
+``scheduler.step`` and ``callback_on_step_end``, then -- when a ``vae`` is given and ``output_type`` is not "latent" --
+``vae.decode(latents / scaling_factor)`` and the image processor's denormalise (:911-925,
+image_processor.py VaeImageProcessor.postprocess).  Prompt encoding (CLIP / T5) is a "next row" of SURVEY.md 8f and
+stays outside: the loop starts from ``prompt_embeds``.
 """
 from __future__ import annotations
 
@@ -25,8 +27,18 @@ def rescale_noise_cfg(noise_cfg, noise_pred_text, guidance_rescale=0.0):
 class StableDiffusionDenoiser:
     """``pipe = StableDiffusionDenoiser(unet, scheduler); latents = pipe(prompt_embeds=..., ...)``"""
 
-    def __init__(self, unet, scheduler):
-        self.unet, self.scheduler = unet, scheduler
+    def __init__(self, unet, scheduler, vae=None):
+        self.unet, self.scheduler, self.vae = unet, scheduler, vae
+
+    def decode_latents(self, latents: torch.Tensor, output_type: str = "pt"):
+        """pipeline_stable_diffusion.py:911 + VaeImageProcessor.postprocess: decode, (x / 2 + 0.5).clamp(0, 1)."""
+        if self.vae is None:
+            raise ValueError("output_type != 'latent' needs a `vae`")
+        if output_type not in ("pt", "np"):
+            raise ValueError(f"output_type must be 'latent', 'pt' or 'np', got {output_type!r}")
+        image = self.vae.decode(latents, return_dict=False, in_scale=1.0 / self.vae.config.scaling_factor)[0]
+        image = (image / 2 + 0.5).clamp(0, 1)
+        return image if output_type == "pt" else image.cpu().permute(0, 2, 3, 1).float().numpy()
 
     def prepare_latents(self, batch_size, num_channels_latents, height, width, dtype, generator=None, latents=None,
                         device=None):
@@ -43,7 +55,8 @@ class StableDiffusionDenoiser:
                  guidance_scale: float = 7.5, guidance_rescale: float = 0.0, latents: Optional[torch.Tensor] = None,
                  generator=None, added_cond_kwargs: Optional[Dict[str, torch.Tensor]] = None,
                  negative_added_cond_kwargs: Optional[Dict[str, torch.Tensor]] = None,
-                 callback_on_step_end: Optional[Callable] = None, vae_scale_factor: int = 8):
+                 callback_on_step_end: Optional[Callable] = None, vae_scale_factor: int = 8,
+                 output_type: str = "latent"):
         do_cfg = guidance_scale > 1.0
         if do_cfg and negative_prompt_embeds is None:
             raise ValueError("classifier-free guidance needs `negative_prompt_embeds`")
@@ -74,4 +87,6 @@ class StableDiffusionDenoiser:
             if callback_on_step_end is not None:
                 out = callback_on_step_end(self, i, t, {"latents": latents})
                 latents = out.pop("latents", latents)
-        return latents
+        if output_type == "latent":
+            return latents
+        return self.decode_latents(latents, output_type)

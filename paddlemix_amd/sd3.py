@@ -26,6 +26,7 @@ import torch
 
 from . import _lib
 from ._lib import GELU_TANH, OUT_F32, SILU
+from .checkpoint import PretrainedMixin
 from .program import DeviceProgram, _Plan, _Ref, _V
 
 Tensor = torch.Tensor
@@ -131,7 +132,9 @@ class Transformer2DModelOutput(SimpleNamespace):
     """``.sample`` holder (models/transformer_2d.py Transformer2DModelOutput)."""
 
 
-class SD3Transformer2DModel(DeviceProgram):
+class SD3Transformer2DModel(DeviceProgram, PretrainedMixin):
+    _param_shapes = staticmethod(sd3_param_shapes)
+
     def __init__(self, config: Mapping, params: Mapping[str, Tensor], device="cuda", use_graph: bool = True,
                  profile: bool = False, weight_dtype: str = "bf16", _test_backend=None):
         """``weight_dtype``: "bf16" | "fp8" -- fp8 stores the block matrices (QKV, out, FF of both streams) as OCP e4m3

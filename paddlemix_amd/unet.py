@@ -28,6 +28,7 @@ import torch
 
 from . import _lib
 from ._lib import GEGLU, OUT_F32, SILU
+from .checkpoint import PretrainedMixin
 from .program import DeviceProgram, _Plan, _Ref, _V
 
 Tensor = torch.Tensor
@@ -225,7 +226,9 @@ class UNet2DConditionOutput(SimpleNamespace):
     """``.sample`` holder, mirroring unet_2d_condition.py:61-72."""
 
 
-class UNet2DConditionModel(DeviceProgram):
+class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
+    _param_shapes = staticmethod(unet_param_shapes)
+
     def __init__(self, config: Mapping, params: Mapping[str, Tensor], device="cuda", use_graph: bool = True,
                  profile: bool = False, _test_backend=None):
         """``_test_backend``: test-only injection point (tests/abi_emulator.py interprets the emitted C-ABI
@@ -233,8 +236,9 @@ class UNet2DConditionModel(DeviceProgram):
         product code: without it the model needs the built HIP library and a GPU, and raises otherwise."""
         self._init_backend(device, use_graph, profile, _test_backend)
         self.cfg = normalize_config(config)
-        pub = dict(self.cfg)
-        pub.pop("num_attention_heads")
+        # .config shows the constructor arguments as given (register_to_config), not the per-block expansion
+        pub = dict(UNET_DEFAULTS)
+        pub.update({k: v for k, v in config.items() if not k.startswith("_")})
         self.config = SimpleNamespace(**pub)
         self._load_weights(params)
 

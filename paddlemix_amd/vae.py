@@ -24,6 +24,7 @@ import torch
 
 from . import _lib
 from ._lib import OUT_F32
+from .checkpoint import PretrainedMixin
 from .program import DeviceProgram, _Plan, _Ref, _V
 
 Tensor = torch.Tensor
@@ -111,7 +112,9 @@ class DecoderOutput(SimpleNamespace):
     """``.sample`` holder (PPD/models/vae.py:40-49)."""
 
 
-class AutoencoderKL(DeviceProgram):
+class AutoencoderKL(DeviceProgram, PretrainedMixin):
+    _param_shapes = staticmethod(decoder_param_shapes)
+
     def __init__(self, config: Mapping, params: Mapping[str, Tensor], device="cuda", use_graph: bool = True,
                  profile: bool = False, _test_backend=None):
         """``_test_backend``: test-only injection (tests/abi_emulator.py); never selected by product code."""

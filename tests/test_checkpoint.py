@@ -1,0 +1,105 @@
+"""CPU: checkpoint formats of SURVEY 8f.2 -- Paddle-layout / torch-layout safetensors, sharded index, .pdparams pickle,
+config.json -- round-tripped through ``from_pretrained`` into the model classes (program run by the ABI emulator)."""
+import json
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from paddlemix_amd import checkpoint as C
+from paddlemix_amd.unet import UNet2DConditionModel, synth_unet_params, unet_param_shapes
+from paddlemix_amd.vae import AutoencoderKL, synth_decoder_params
+from tests.abi_emulator import Emulator
+from tests.configs import MINI_VAE, MINI_XL, TINY
+
+
+def _inputs(cfg, B=1):
+    g = torch.Generator().manual_seed(0)
+    return torch.randn(B, 4, 8, 8, generator=g), torch.randn(B, 7, cfg["cross_attention_dim"], generator=g)
+
+
+@pytest.mark.parametrize("fmt", ["pd", "pt"])
+def test_unet_from_pretrained_safetensors(tmp_path, fmt):
+    cfg = TINY
+    P = synth_unet_params(cfg, seed=3)
+    path = C.save_pretrained(str(tmp_path / "unet"), cfg, P, data_format=fmt)
+    assert os.path.basename(path) == {"pd": "diffusion_paddle_model.safetensors",
+                                      "pt": "diffusion_pytorch_model.safetensors"}[fmt]
+    state, f = C.load_state_dict(path)
+    assert f == fmt
+    lin = next(k for k, s in unet_param_shapes(cfg).items() if len(s) == 2 and s[0] != s[1])
+    assert tuple(state[lin].shape) == (tuple(P[lin].shape) if fmt == "pd" else tuple(P[lin].shape)[::-1])
+    x, enc = _inputs(cfg)
+    ref = UNet2DConditionModel(cfg, P, _test_backend=Emulator())(x, 10, enc).sample
+    model = UNet2DConditionModel.from_pretrained(str(tmp_path), subfolder="unet", _test_backend=Emulator())
+    assert model.config.cross_attention_dim == cfg["cross_attention_dim"]
+    assert torch.equal(model(x, 10, enc).sample, ref)
+
+
+def test_sharded_index_and_missing_metadata_defaults_to_torch(tmp_path):
+    from safetensors.torch import save_file
+    cfg = TINY
+    P = synth_unet_params(cfg, seed=4)
+    d = tmp_path / "m"
+    d.mkdir()
+    (d / "config.json").write_text(json.dumps({**cfg, "_class_name": "UNet2DConditionModel"}))
+    pt = C.from_paddle_layout(P, "pt")
+    names = list(pt)
+    half = len(names) // 2
+    wm = {}
+    for i, part in enumerate((names[:half], names[half:])):
+        fn = f"diffusion_pytorch_model-0000{i + 1}-of-00002.safetensors"
+        save_file({k: pt[k] for k in part}, str(d / fn))          # no metadata -> "pt" (modeling_utils.py:170)
+        wm.update({k: fn for k in part})
+    (d / "diffusion_pytorch_model.safetensors.index.json").write_text(json.dumps({"weight_map": wm}))
+    config, params = C.load_pretrained(str(d), unet_param_shapes)
+    assert "_class_name" not in config
+    assert all(torch.equal(params[k], P[k]) for k in P)
+
+
+def test_pdparams_pickle_and_errors(tmp_path):
+    cfg = MINI_VAE
+    P = synth_decoder_params(cfg, seed=5)
+    d = tmp_path / "vae"
+    d.mkdir()
+    (d / "config.json").write_text(json.dumps({k: list(v) if isinstance(v, tuple) else v for k, v in cfg.items()}))
+    blob = {k: v.numpy() for k, v in P.items()}
+    blob["StructuredToParameterName@@"] = {k: k for k in P}
+    with open(d / "model_state.pdparams", "wb") as fh:
+        pickle.dump(blob, fh, protocol=4)
+    vae = AutoencoderKL.from_pretrained(str(d), _test_backend=Emulator())
+    z = torch.randn(1, 4, 4, 4, generator=torch.Generator().manual_seed(1))
+    assert torch.equal(vae.decode(z).sample, AutoencoderKL(cfg, P, _test_backend=Emulator()).decode(z).sample)
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("true",))
+    with open(d / "model_state.pdparams", "wb") as fh:
+        pickle.dump({"w": Evil()}, fh)
+    with pytest.raises(pickle.UnpicklingError):
+        C.load_state_dict(str(d / "model_state.pdparams"))
+    with pytest.raises(OSError):
+        UNet2DConditionModel.from_pretrained(str(tmp_path / "nope"))
+    os.remove(d / "model_state.pdparams")
+    with pytest.raises(OSError):
+        C.resolve_weight_files(str(d))
+    # shape / missing-key diagnostics
+    bad = dict(P)
+    k = "decoder.conv_out.bias"
+    bad[k] = torch.zeros(5)
+    with pytest.raises(ValueError):
+        C.to_paddle_layout(bad, AutoencoderKL._param_shapes(cfg), "pd")
+    bad.pop(k)
+    with pytest.raises(KeyError):
+        C.to_paddle_layout(bad, AutoencoderKL._param_shapes(cfg), "pd")
+
+
+def test_sdxl_style_config_roundtrip(tmp_path):
+    cfg = MINI_XL
+    P = synth_unet_params(cfg, seed=6)
+    C.save_pretrained(str(tmp_path), cfg, P, data_format="pt")
+    config, params = C.load_pretrained(str(tmp_path), unet_param_shapes)
+    assert set(params) == set(P) and all(torch.equal(params[k], P[k]) for k in P)
+    assert isinstance(np.asarray(config["block_out_channels"]), np.ndarray)

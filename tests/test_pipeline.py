@@ -65,3 +65,32 @@ def test_sdxl_euler_loop_runs_and_matches():
         x = sch.step(eps, t, x)
     rel = np.linalg.norm(out.numpy() - x) / np.linalg.norm(x)
     assert rel < 3e-2, rel
+
+
+def test_pipeline_with_vae_decode_outputs_images():
+    """output_type="pt"/"np": latents -> vae.decode(latents / scaling_factor) -> (x / 2 + 0.5).clamp(0, 1)
+    (pipeline_stable_diffusion.py:911-925)."""
+    from oracle import vae_ref as V
+    from paddlemix_amd.vae import AutoencoderKL, synth_decoder_params
+    from tests.configs import MINI_VAE
+    cfg = TINY
+    P = synth_unet_params(cfg, seed=1234)
+    Pv = synth_decoder_params(MINI_VAE, seed=5)
+    g = torch.Generator().manual_seed(0)
+    pe = torch.randn(1, 7, 64, generator=g)
+    lat0 = torch.randn(1, 4, 8, 8, generator=g)
+    pipe = StableDiffusionDenoiser(UNet2DConditionModel(cfg, P, _test_backend=Emulator()),
+                                   DDIMScheduler(clip_sample=False, set_alpha_to_one=False, **SCHED),
+                                   vae=AutoencoderKL(MINI_VAE, Pv, _test_backend=Emulator()))
+    lat = pipe(pe, num_inference_steps=2, guidance_scale=1.0, latents=lat0.clone())
+    img = pipe(pe, num_inference_steps=2, guidance_scale=1.0, latents=lat0.clone(), output_type="pt")
+    assert img.shape == (1, 3, 32, 32) and img.min() >= 0 and img.max() <= 1
+    Pr = {k: (v.to(torch.bfloat16).float() if v.dim() > 1 else v) for k, v in Pv.items()}
+    ref = (V.decode(Pr, MINI_VAE, lat, scaled=True) / 2 + 0.5).clamp(0, 1)
+    assert (img - ref).abs().max() < 2e-2
+    arr = pipe(pe, num_inference_steps=2, guidance_scale=1.0, latents=lat0.clone(), output_type="np")
+    assert arr.shape == (1, 32, 32, 3) and arr.dtype == np.float32
+    import pytest
+    with pytest.raises(ValueError):
+        StableDiffusionDenoiser(pipe.unet, pipe.scheduler)(pe, num_inference_steps=1, guidance_scale=1.0,
+                                                           latents=lat0.clone(), output_type="pt")
