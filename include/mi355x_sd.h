@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MI355X_SD_ABI_VERSION 3
+#define MI355X_SD_ABI_VERSION 4
 #define MI355X_SD_OK 0
 #define MI355X_SD_ERR_INVALID 1      /* bad argument (shape <= 0, null pointer ...)          */
 #define MI355X_SD_ERR_UNSUPPORTED 2  /* well-formed but outside the implemented configurations */
@@ -73,6 +73,17 @@ int mi355x_sd_linear_ex(const void* A, int lda, int a_rows_per_batch, int64_t a_
                         int ldc, int c_rows_per_batch, int64_t c_batch_stride, int M, int N, int K, const float* bias,
                         const float* rowbias, int ld_rowbias, const float* gate, int ld_gate, int rows_per_batch,
                         const void* R, int ldr, float out_scale, int flags, void* stream);
+
+/* LayerNorm folded into the consuming projection (BasicTransformerBlock: norm1 -> attn1.to_q/k/v, norm2 -> attn2.to_q,
+ * norm3 -> ff.net.0.proj; PPD/models/attention.py:405-486).  With W' = W diag(gamma) (bf16), w_rowsum[n] = sum_k W'[n][k]
+ * and bias' = bias + W beta prepared at load time,
+ *     LN(x) W^T + bias  =  rstd[m] * (x W'^T)[m][n] - mean[m] * rstd[m] * w_rowsum[n] + bias'[n],
+ * so the normalised activation is never written to or re-read from HBM: mi355x_sd_row_stats reads the rows once and
+ * stores row_stats[m] = (rstd, -mean * rstd) (fp32 pairs), mi355x_sd_linear_ln multiplies the RAW rows and applies the
+ * correction to its fp32 accumulators before bias / GEGLU / activation flags. */
+int mi355x_sd_row_stats(const void* x, int rows, int C, int ldx, float eps, float* row_stats, void* stream);
+int mi355x_sd_linear_ln(const void* A, int lda, const float* row_stats, const void* W, const float* w_rowsum, void* C,
+                        int ldc, int M, int N, int K, const float* bias, int flags, void* stream);
 
 /* y = LayerNorm_noaffine(x) * (1 + scale[b]) + shift[b], b = row / rows_per_batch, scale/shift fp32 rows of stride ld_mod.
  * AdaLayerNormZero / AdaLayerNormContinuous (PPD/models/normalization.py:72-86, 190-202) and the Triton op

@@ -125,6 +125,27 @@ int mi355x_sd_linear_ex(const void* A, int lda, int a_rows_per_batch, int64_t a_
   return finish(launch_gemm(g, S(stream)), "mi355x_sd_linear_ex");
 }
 
+int mi355x_sd_row_stats(const void* x, int rows, int C, int ldx, float eps, float* stats, void* stream) {
+  if (!x || !stats) return fail(SD_ERR_INVALID, "mi355x_sd_row_stats: null pointer");
+  return finish(launch_row_stats((const bf16*)x, rows, C, ldx, eps, stats, S(stream)), "mi355x_sd_row_stats");
+}
+
+int mi355x_sd_linear_ln(const void* A, int lda, const float* row_stats, const void* W, const float* w_rowsum, void* C,
+                        int ldc, int M, int N, int K, const float* bias, int flags, void* stream) {
+  if (!A || !W || !C || !row_stats || !w_rowsum) return fail(SD_ERR_INVALID, "mi355x_sd_linear_ln: null pointer");
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = (const bf16*)A; g.W = (const bf16*)W; g.C = C;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc;
+  g.rowstat = row_stats; g.wsum = w_rowsum;
+  g.bias = bias; g.out_scale = 1.0f;
+  g.geglu = (flags & MI355X_SD_GEGLU) ? 1 : 0;
+  g.out_f32 = (flags & MI355X_SD_OUT_F32) ? 1 : 0;
+  g.silu = (flags & MI355X_SD_SILU) ? 1 : 0;
+  g.gelu_tanh = (flags & MI355X_SD_GELU_TANH) ? 1 : 0;
+  return finish(launch_gemm(g, S(stream)), "mi355x_sd_linear_ln");
+}
+
 int mi355x_sd_adaln(const void* x, int rows, int C, int ldx, const float* scale, const float* shift, int ld_mod,
                     int rows_per_batch, float eps, void* y, int ldy, void* stream) {
   if (!x || !scale || !shift || !y) return fail(SD_ERR_INVALID, "mi355x_sd_adaln: null pointer");

@@ -54,7 +54,7 @@ using Cfg256x320g = GemmCfg<4, 2, 4, 10>; // 256 x 320 with an even tile count p
 // W8 = true: W is fp8 e4m3 (OCP), 64-B LDS rows (16 rows per DMA piece, 16-B chunk index XOR (row>>2)&3 so the 8-byte
 // fragment reads are conflict free); fragments are widened to bf16 in registers (every e4m3 value is exact in bf16) and the
 // per-channel scale is applied to the fp32 accumulator in the epilogue. Halves the weight bytes a CU has to ingest.
-template <bool CONV, class CFG, bool W8 = false>
+template <bool CONV, class CFG, bool W8 = false, bool LN = false>
 __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_bf16_kernel(const GemmArgs p) {
   constexpr int BM = CFG::BM, BN = CFG::BN, TM = CFG::TM, TN = CFG::TN;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -227,7 +227,8 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_bf16_kernel(const GemmAr
     }
     return;
   }
-  gemm_epilogue<TM, TN>(p, acc, m0 + wm * (TM * 16), n0 + wn * (TN * 16), lane);
+  if constexpr (LN) gemm_epilogue_ln<TM, TN>(p, acc, m0 + wm * (TM * 16), n0 + wn * (TN * 16), lane);
+  else gemm_epilogue<TM, TN>(p, acc, m0 + wm * (TM * 16), n0 + wn * (TN * 16), lane);
 }
 
 // Deterministic split-K tail: wave = 16 rows x 32 columns in the MFMA accumulator layout, slices summed in index
@@ -248,7 +249,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
       for (int s = 0; s < p.splitk; ++s) acc[tn][0] += *reinterpret_cast<const f32x4*>(src + s * slice);
     }
   }
-  gemm_epilogue<1, 2>(p, acc, m_wave, n_wave, lane);
+  if (p.rowstat) gemm_epilogue_ln<1, 2>(p, acc, m_wave, n_wave, lane);
+  else gemm_epilogue<1, 2>(p, acc, m_wave, n_wave, lane);
 }
 
 static void* g_ws = nullptr;
@@ -279,16 +281,16 @@ static void plan_splitk(GemmArgs& a, int bm, int bn) {
   if (a.splitk < 2) a.splitk = 0;
 }
 
-template <bool CONV, class CFG, bool W8 = false>
+template <bool CONV, class CFG, bool W8 = false, bool LN = false>
 static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
   static const bool attr_ok = [] {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<CONV, CFG, W8>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<CONV, CFG, W8, LN>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES) == hipSuccess;
   }();
   if (!attr_ok) return SD_ERR_HIP;
   const int ntm = (a.M + CFG::BM - 1) / CFG::BM, ntn = (a.N + CFG::BN - 1) / CFG::BN;
   const int ny = a.splitk > 1 ? a.splitk : 1;
-  hipLaunchKernelGGL((gemm_bf16_kernel<CONV, CFG, W8>), dim3(ntm * ntn, ny), dim3(CFG::THREADS), CFG::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL((gemm_bf16_kernel<CONV, CFG, W8, LN>), dim3(ntm * ntn, ny), dim3(CFG::THREADS), CFG::LDS_BYTES, stream, a);
   if (a.splitk > 1)
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((a.M + 15) / 16, (a.N + 127) / 128), dim3(256), 0, stream, a);
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
@@ -344,6 +346,15 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
   if (a.rowbias && a.rows_per_batch <= 0) return SD_ERR_INVALID;
   const int tile = pick_tile(a);
   if (tile == 128) plan_splitk(a, 128, 128);
+  if (a.rowstat) {   // LayerNorm-folded projection: own kernel instantiations (epilogue in gemm_epilogue_ln)
+    if (a.conv || a.wscale || a.a_rpb || a.c_rpb || a.R || a.rowbias || a.gate || !a.wsum) return SD_ERR_UNSUPPORTED;
+    if (tile == 257 && !(a.K & 63)) return launch_gemm256(a, stream);
+    if (tile == 256 || tile == 257) return launch_cfg<false, Cfg256, false, true>(a, stream);
+    if (tile == 160 && !a.geglu) return launch_cfg<false, Cfg256x160, false, true>(a, stream);
+    if (tile == 320) return a.geglu ? launch_cfg<false, Cfg256x320g, false, true>(a, stream)
+                                    : launch_cfg<false, Cfg256x320, false, true>(a, stream);
+    return launch_cfg<false, Cfg128, false, true>(a, stream);
+  }
   if (a.wscale) {   // fp8 weights: generic configurations only
     if (a.conv || (a.K & 15)) return SD_ERR_UNSUPPORTED;
     if (tile == 160 && !a.geglu) return launch_cfg<false, Cfg256x160, true>(a, stream);

@@ -44,7 +44,7 @@ constexpr int LDS_BYTES = 2 * BUF;        // 128 KB
     __builtin_amdgcn_sched_barrier(0);    \
   } while (0)
 
-template <bool CONV>
+template <bool CONV, bool LN = false>
 __global__ __launch_bounds__(g256::THREADS, 2) void gemm256_kernel(const GemmArgs p) {
   using namespace g256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -245,7 +245,8 @@ __global__ __launch_bounds__(g256::THREADS, 2) void gemm256_kernel(const GemmArg
   if (grp == 0) SD_BARRIER();                         // re-align the two groups
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // run-out DMAs retired before the LDS is released
 
-  gemm_epilogue<8, 4>(p, acc, m0 + grp * 128, n0 + wc * 64, lane);
+  if constexpr (LN) gemm_epilogue_ln<8, 4>(p, acc, m0 + grp * 128, n0 + wc * 64, lane);
+  else gemm_epilogue<8, 4>(p, acc, m0 + grp * 128, n0 + wc * 64, lane);
 }
 
 int launch_gemm256(const GemmArgs& a, hipStream_t stream) {
@@ -254,6 +255,8 @@ int launch_gemm256(const GemmArgs& a, hipStream_t stream) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess &&
            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess &&
+           hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<false, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
   }();
   if (!attr_ok) return SD_ERR_HIP;
@@ -264,7 +267,9 @@ int launch_gemm256(const GemmArgs& a, hipStream_t stream) {
   GemmArgs b = a;
   b.dbg = dbg;
   const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
-  if (a.conv)
+  if (a.rowstat)
+    hipLaunchKernelGGL((gemm256_kernel<false, true>), dim3(ntm * ntn), dim3(THREADS), LDS_BYTES, stream, b);
+  else if (a.conv)
     hipLaunchKernelGGL(gemm256_kernel<true>, dim3(ntm * ntn), dim3(THREADS), LDS_BYTES, stream, b);
   else
     hipLaunchKernelGGL(gemm256_kernel<false>, dim3(ntm * ntn), dim3(THREADS), LDS_BYTES, stream, b);

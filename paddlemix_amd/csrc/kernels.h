@@ -35,6 +35,8 @@ struct GemmArgs {
   int a_rpb;              // A row m lives at (m / a_rpb) * a_bstride + (m % a_rpb) * lda   (0: plain m * lda)
   long a_bstride;
   const float* wscale;    // W is fp8 e4m3 [N][K] (1 byte / element) with per-output-channel scale: acc *= wscale[n]
+  const float* rowstat;   // LayerNorm folded into the GEMM: per-row (rstd, -mean*rstd) from launch_row_stats and
+  const float* wsum;      //   wsum[n] = sum_k W[n][k]: acc <- rstd[m]*acc - mean[m]*rstd[m]*wsum[n]   (before bias)
   int c_rpb;              // same remap for the C rows (joint text+image token buffers of the MMDiT attention)
   long c_bstride;
   int dbg;                // ablation switches of gemm256.hip (MI355X_SD_GEMM_DBG; 0 in production)
@@ -73,6 +75,7 @@ int launch_adaln(const bf16* x, int rows, int C, int ldx, const float* scale, co
                  int rows_per_batch, float eps, bf16* y, int ldy, hipStream_t stream);
 int launch_patchify(const float* x_nchw, int B, int C, int H, int W, int p, bf16* out, int ldo, hipStream_t stream);
 int launch_unpatchify(const bf16* x, int ldx, int B, int C, int H, int W, int p, float* out_nchw, hipStream_t stream);
+int launch_row_stats(const bf16* x, int rows, int C, int ldx, float eps, float* stats, hipStream_t stream);
 int launch_layernorm(const bf16* x, int rows, int C, int ldx, const float* gamma, const float* beta, float eps, bf16* y,
                      int ldy, hipStream_t stream);
 

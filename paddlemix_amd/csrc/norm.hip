@@ -317,6 +317,88 @@ int launch_layernorm(const bf16* x, int rows, int C, int ldx, const float* gamma
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
 
+// Row statistics for the LayerNorm-folded GEMM (mi355x_sd_linear_ln): stats[row] = (rstd, -mean * rstd), the same
+// shifted one-pass fp32 statistics as layernorm_kernel. The normalised row is never written: the consumer GEMM
+// multiplies the raw rows by W.diag(gamma) and applies  rstd * acc - mean * rstd * rowsum(W')  in its epilogue.
+template <int NCH, int ROWS>
+__global__ __launch_bounds__(256) void row_stats_kernel(const bf16* __restrict__ x, int rows, int C, int ldx, float eps,
+                                                        float* __restrict__ stats) {
+  const int lane = threadIdx.x & 63;
+  const int wave_g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * (blockDim.x >> 6);
+  const int cv = C >> 3;
+  const float invC = 1.0f / (float)C;
+  for (int row0 = wave_g * ROWS; row0 < rows; row0 += nwaves * ROWS) {
+    float s1[ROWS], s2[ROWS], K[ROWS];
+    u32x4 raw[ROWS][NCH];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const bf16* xr = x + (size_t)min(row0 + r, rows - 1) * ldx;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int cc = lane + 64 * i;
+        raw[r][i] = u32x4{0u, 0u, 0u, 0u};
+        if (cc < cv) raw[r][i] = *reinterpret_cast<const u32x4*>(xr + cc * 8);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const bf16x8 t0 = *reinterpret_cast<const bf16x8*>(&raw[r][0]);
+      K[r] = __shfl((float)t0[0], 0, 64);
+      float a = 0.f, q = 0.f;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        if (lane + 64 * i < cv) {
+          const bf16x8 t = *reinterpret_cast<const bf16x8*>(&raw[r][i]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float d = (float)t[j] - K[r];
+            a += d;
+            q = __builtin_fmaf(d, d, q);
+          }
+        }
+      }
+      s1[r] = a;
+      s2[r] = q;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) {
+        s1[r] += __shfl_xor(s1[r], o, 64);
+        s2[r] += __shfl_xor(s2[r], o, 64);
+      }
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) {
+        if (row0 + r < rows) {
+          const float m = s1[r] * invC;
+          const float rstd = rsqrtf(fmaxf(s2[r] * invC - m * m, 0.f) + eps);
+          *reinterpret_cast<float2*>(stats + 2 * (size_t)(row0 + r)) = make_float2(rstd, -(K[r] + m) * rstd);
+        }
+      }
+    }
+  }
+}
+
+int launch_row_stats(const bf16* x, int rows, int C, int ldx, float eps, float* stats, hipStream_t stream) {
+  if (rows <= 0 || C <= 0) return SD_ERR_INVALID;
+  if ((C & 7) || (ldx & 7) || C > 2560) return SD_ERR_UNSUPPORTED;
+  const int wpb = 4, cv = C >> 3;
+  constexpr int R = 4;
+  int blocks = (rows + wpb * R - 1) / (wpb * R);
+  if (blocks > 256 * 8) blocks = 256 * 8;
+#define SD_RS_LAUNCH(NCH) \
+  hipLaunchKernelGGL((row_stats_kernel<NCH, R>), dim3(blocks), dim3(64 * wpb), 0, stream, x, rows, C, ldx, eps, stats)
+  if (cv <= 64) SD_RS_LAUNCH(1);
+  else if (cv <= 128) SD_RS_LAUNCH(2);
+  else if (cv <= 192) SD_RS_LAUNCH(3);
+  else SD_RS_LAUNCH(5);
+#undef SD_RS_LAUNCH
+  return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+}
+
 // Adaptive LayerNorm of the MMDiT blocks: y = LN(x) * (1 + scale[b]) + shift[b], LN without affine, b = row / rows_per_batch.
 // Reference: AdaLayerNormZero.forward (ppdiffusers/ppdiffusers/models/normalization.py:72-86), AdaLayerNormContinuous
 // (:190-202), the modulated norm2 of JointTransformerBlock (attention.py:184-185) and the fused Triton op

@@ -335,3 +335,34 @@ def softmax_rows(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
         out = torch.empty((rows, n), device=x.device, dtype=torch.bfloat16)
     check(lib.mi355x_sd_softmax_rows(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), rows, n, _stream()))
     return out
+
+
+def row_stats(x: Tensor, eps: float = 1e-5) -> Tensor:
+    """fp32 [rows, 2] = (rstd, -mean * rstd) per row of a bf16 [rows, C] view."""
+    lib = _lib.load()
+    ldx = _rows(x, "x")
+    rows, C = x.shape
+    st = torch.empty((rows, 2), device=x.device, dtype=torch.float32)
+    check(lib.mi355x_sd_row_stats(x.data_ptr(), rows, C, ldx, float(eps), st.data_ptr(), _stream()))
+    return st
+
+
+def linear_ln(a: Tensor, stats: Tensor, w: Tensor, w_rowsum: Tensor, bias: Optional[Tensor] = None, *,
+              geglu: bool = False, out: Optional[Tensor] = None) -> Tensor:
+    """LayerNorm-folded projection: out = rstd * (a @ w^T) - mean * rstd * w_rowsum + bias (optionally GEGLU)."""
+    lib = _lib.load()
+    _bind_workspace(a.device)
+    lda = _rows(a, "a")
+    M, K = a.shape
+    N = w.shape[0]
+    if w.dtype != torch.bfloat16 or not w.is_contiguous() or tuple(w.shape) != (N, K):
+        raise ValueError(f"w: expected contiguous bf16 [N,{K}]")
+    if stats.dtype != torch.float32 or tuple(stats.shape) != (M, 2) or not stats.is_contiguous():
+        raise ValueError("stats: expected contiguous fp32 [M, 2]")
+    n_out = N // 2 if geglu else N
+    if out is None:
+        out = torch.empty((M, n_out), device=a.device, dtype=torch.bfloat16)
+    ldc = _rows(out, "out")
+    check(lib.mi355x_sd_linear_ln(a.data_ptr(), lda, stats.data_ptr(), w.data_ptr(), _vec(w_rowsum, N, "w_rowsum").data_ptr(),
+                                  out.data_ptr(), ldc, M, N, K, _p(_vec(bias, N, "bias")), GEGLU if geglu else 0, _stream()))
+    return out

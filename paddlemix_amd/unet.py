@@ -21,6 +21,7 @@ epilogues; q/k/v projections are fused into one GEMM; all resnet time_emb_proj l
 from __future__ import annotations
 
 import math
+import os
 from types import SimpleNamespace
 from typing import Dict, List, Mapping, Optional, Tuple
 
@@ -230,11 +231,17 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
     _param_shapes = staticmethod(unet_param_shapes)
 
     def __init__(self, config: Mapping, params: Mapping[str, Tensor], device="cuda", use_graph: bool = True,
-                 profile: bool = False, _test_backend=None):
+                 profile: bool = False, fold_layernorm: Optional[bool] = None, _test_backend=None):
         """``_test_backend``: test-only injection point (tests/abi_emulator.py interprets the emitted C-ABI
         program on host memory to check the sequencing / packing logic without a GPU).  It is never selected by
         product code: without it the model needs the built HIP library and a GPU, and raises otherwise."""
         self._init_backend(device, use_graph, profile, _test_backend)
+        # fold_layernorm: LayerNorms of the transformer blocks folded into their consuming projections (row statistics
+        # pass + mi355x_sd_linear_ln on the raw rows). Off by default: on MI355X it removes 2.3 ms of LayerNorm
+        # traffic per SDXL step but the GEMMs then multiply the raw residual stream instead of O(1) normalised
+        # activations and run 6-12 % slower (operand-dependent MFMA power), a wash end to end
+        # (profiles/r01_lnfold_ab.txt). MI355X_SD_LNFOLD=1 or fold_layernorm=True turns it on.
+        self.fold_ln = (os.environ.get("MI355X_SD_LNFOLD") is not None) if fold_layernorm is None else bool(fold_layernorm)
         self.cfg = normalize_config(config)
         # .config shows the constructor arguments as given (register_to_config), not the per-block expansion
         pub = dict(UNET_DEFAULTS)
@@ -276,6 +283,15 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
             W[key + ".g"] = get(name + ".weight").contiguous()
             W[key + ".b"] = get(name + ".bias").contiguous()
 
+        def put_ln_lin(key, w, bias, norm):
+            """LayerNorm `norm` folded into the projection w [N, K] (mi355x_sd_linear_ln): W' = W diag(gamma) in bf16,
+            ws = row sums of the bf16 W' (what the MFMAs actually sum), b' = bias + W beta."""
+            wp_ = bf(w * get(norm + ".weight")[None, :])
+            W[key + ".w"] = wp_
+            W[key + ".ws"] = wp_.float().sum(1).contiguous()
+            bb = w @ get(norm + ".bias")
+            W[key + ".b"] = (bb if bias is None else bias + bb).contiguous()
+
         w = get("conv_in.weight")  # -> [ky][kx][ci][O]
         W["conv_in.w"] = bf(w.permute(2, 3, 1, 0).reshape(-1, w.shape[0]))
         W["conv_in.b"] = get("conv_in.bias").contiguous()
@@ -314,12 +330,16 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
                     put_conv(name + ".proj_out", name + ".proj_out")
                 for l in range(layers):
                     b = f"{name}.transformer_blocks.{l}"
-                    for nm in (".norm1", ".norm2", ".norm3"):
-                        put_norm(b + nm, b + nm)
-                    W[b + ".attn1.qkv.w"] = bf(torch.cat([lin_w(b + ".attn1.to_q"), lin_w(b + ".attn1.to_k"),
-                                                          lin_w(b + ".attn1.to_v")], 0))
+                    wqkv = torch.cat([lin_w(b + ".attn1.to_q"), lin_w(b + ".attn1.to_k"), lin_w(b + ".attn1.to_v")], 0)
+                    if self.fold_ln:
+                        put_ln_lin(b + ".attn1.qkv", wqkv, None, b + ".norm1")
+                        put_ln_lin(b + ".attn2.q", lin_w(b + ".attn2.to_q"), None, b + ".norm2")
+                    else:
+                        for nm in (".norm1", ".norm2", ".norm3"):
+                            put_norm(b + nm, b + nm)
+                        W[b + ".attn1.qkv.w"] = bf(wqkv)
+                        W[b + ".attn2.q.w"] = bf(lin_w(b + ".attn2.to_q"))
                     put_lin(b + ".attn1.out", b + ".attn1.to_out.0")
-                    W[b + ".attn2.q.w"] = bf(lin_w(b + ".attn2.to_q"))
                     if any(x != cfg["cross_attention_dim"][0] for x in cfg["cross_attention_dim"]):
                         raise NotImplementedError("per-block cross_attention_dim")
                     kv_w.append(bf(torch.cat([lin_w(b + ".attn2.to_k"), lin_w(b + ".attn2.to_v")], 0)))
@@ -330,10 +350,15 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
                     w1 = lin_w(b + ".ff.net.0.proj")  # [8c, c]
                     b1 = get(b + ".ff.net.0.proj.bias")
                     half = w1.shape[0] // 2
+                    if self.fold_ln:   # norm3 folded in before the row interleave (a row permutation commutes with it)
+                        b1 = b1 + w1 @ get(b + ".norm3.bias")
+                        w1 = w1 * get(b + ".norm3.weight")[None, :]
                     W[b + ".ff1.w"] = bf(torch.stack([w1[:half].reshape(half // 16, 16, -1),
                                                       w1[half:].reshape(half // 16, 16, -1)], 1).reshape(2 * half, -1))
                     W[b + ".ff1.b"] = torch.stack([b1[:half].reshape(half // 16, 16), b1[half:].reshape(half // 16, 16)],
                                                   1).reshape(-1).contiguous()
+                    if self.fold_ln:
+                        W[b + ".ff1.ws"] = W[b + ".ff1.w"].float().sum(1).contiguous()
                     put_lin(b + ".ff2", b + ".ff.net.2")
             elif d[0] in ("down", "up"):
                 put_conv(d[1], d[1])
@@ -411,6 +436,17 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
         def lnorm(x: _V, nkey, out: _V):
             emit(lib.mi355x_sd_layernorm, (x.p, x.rows, x.C, x.ld, wp(nkey + ".g"), wp(nkey + ".b"), 1e-5, out.p,
                                            out.ld, stream), "ln")
+
+        def ln_linear(x: _V, wkey: str, out: _V, flags=0):
+            """LayerNorm(eps 1e-5, attention.py:318-331) folded into the projection: statistics pass + raw-row GEMM"""
+            w = W[wkey + ".w"]
+            N, K = w.shape
+            assert K == x.C, (wkey, K, x.C)
+            st = sc("t_stats", 8 * x.rows)
+            emit(lib.mi355x_sd_row_stats, (x.p, x.rows, x.C, x.ld, 1e-5, st, stream), "ln")
+            emit(lib.mi355x_sd_linear_ln, (x.p, x.ld, st, w.data_ptr(), wp(wkey + ".ws"), out.p, out.ld, x.rows, N, K,
+                                           wp(wkey + ".b"), flags, stream), "gemm", 2.0 * x.rows * N * K,
+                 f"{x.rows}x{N}x{K}" + ("g" if flags & GEGLU else ""))
 
         def attention(q: _V, k: _V, v: _V, out: _V, heads, sq, skv, bias=None):
             d = q.C // heads
@@ -518,24 +554,33 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
             g = gnorm(x, hw, name + ".norm", 1e-6, False)
             hid = _V(sc("t_h", 2 * rows * c), rows, c)
             linear(g, name + ".proj_in", hid)
-            ln = _V(sc("t_ln", 2 * rows * c), rows, c)
+            ln = None if self.fold_ln else _V(sc("t_ln", 2 * rows * c), rows, c)
             qkv = _V(sc("t_qkv", 2 * rows * 3 * c), rows, 3 * c)
             ao = _V(sc("t_ao", 2 * rows * c), rows, c)
             ff = _V(sc("t_ff", 2 * rows * 4 * c), rows, 4 * c)
             for l in range(layers):
                 b = f"{name}.transformer_blocks.{l}"
-                lnorm(hid, b + ".norm1", ln)
-                linear(ln, b + ".attn1.qkv", qkv, bias=False)
+                q2 = _V(qkv.p, rows, c)
+                if self.fold_ln:
+                    ln_linear(hid, b + ".attn1.qkv", qkv)
+                else:
+                    lnorm(hid, b + ".norm1", ln)
+                    linear(ln, b + ".attn1.qkv", qkv, bias=False)
                 attention(qkv.cols(0, c), qkv.cols(c, c), qkv.cols(2 * c, c), ao, heads, hw, hw)
                 linear(ao, b + ".attn1.out", hid, R=hid)
-                lnorm(hid, b + ".norm2", ln)
-                q2 = _V(qkv.p, rows, c)
-                linear(ln, b + ".attn2.q", q2, bias=False)
+                if self.fold_ln:
+                    ln_linear(hid, b + ".attn2.q", q2)
+                else:
+                    lnorm(hid, b + ".norm2", ln)
+                    linear(ln, b + ".attn2.q", q2, bias=False)
                 ko = self._kv_off[b]
                 attention(q2, kv_all.cols(ko, c), kv_all.cols(ko + c, c), ao, heads, hw, L, bias=enc_bias)
                 linear(ao, b + ".attn2.out", hid, R=hid)
-                lnorm(hid, b + ".norm3", ln)
-                linear(ln, b + ".ff1", ff, flags=GEGLU)
+                if self.fold_ln:
+                    ln_linear(hid, b + ".ff1", ff, flags=GEGLU)
+                else:
+                    lnorm(hid, b + ".norm3", ln)
+                    linear(ln, b + ".ff1", ff, flags=GEGLU)
                 linear(ff, b + ".ff2", hid, R=hid)
             linear(hid, name + ".proj_out", out, R=x)
 

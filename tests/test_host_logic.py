@@ -43,6 +43,12 @@ def test_program_matches_oracle(cfg, B, H, W, L):
     out2 = model(sample, t, enc, added_cond_kwargs=added).sample
     assert torch.equal(out, out2)
     assert len(model._plans) == 1
+    # optional program variant: LayerNorms folded into their consuming projections (row_stats + linear_ln)
+    assert "linear_ln" not in emu.calls
+    emu2 = Emulator()
+    folded = UNet2DConditionModel(cfg, P, fold_layernorm=True, _test_backend=emu2)
+    out3 = folded(sample, t, enc, added_cond_kwargs=added).sample
+    assert "linear_ln" in emu2.calls and _rel(out3, ref) < 2e-2
 
 
 def test_param_inventory_matches_oracle():
