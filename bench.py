@@ -147,7 +147,17 @@ def main():
     plan = model._get_plan(B, H, W, L)
     if wl["gflop_step"] is None:
         wl = dict(wl, gflop_step=sum(fl for _, _, _, fl in plan.prog) / 1e9)
-    coef = torch.zeros(2, device=dev)
+    # latent-update coefficients of every scheduler step, resident in HBM (no per-step host->device copy, so the host
+    # can queue steps ahead of the GPU)
+    if is_sd3:
+        coef_host = [(1.0, float(sched.sigmas[k + 1] - sched.sigmas[k])) for k in range(n_sched)]
+    else:
+        coef_host = []
+        for k in range(n_sched):
+            sched._step_index = k
+            coef_host.append(tuple(float(v) for v in sched.step_coefficients(sched.timesteps[k])))
+        sched._step_index = None
+    coef_all = torch.tensor(coef_host, device=dev, dtype=torch.float32).contiguous()
     lib = _lib.load()
     stream = model._stream
     lat0 = latents.clone()
@@ -160,16 +170,14 @@ def main():
             latents.copy_(lat0)
         t = sched.timesteps[k]
         if is_sd3:  # flow matching: x += (sigma_next - sigma) * v  (scheduling_flow_match_euler_discrete.py:244-278)
-            a, b = 1.0, float(sched.sigmas[k + 1] - sched.sigmas[k])
             model.stage_inputs(plan, latents, enc, pooled, float(t))
         else:
+            sched._step_index = k
             scale = sched.model_input_scale(t)
-            a, b = sched.step_coefficients(t)
             model.stage_inputs(plan, latents, float(t), enc, added, in_scale=scale)
-        coef.copy_(torch.tensor([a, b]), non_blocking=False)
         eps = model.run(plan)
-        _lib.check(lib.mi355x_sd_axpby(latents.data_ptr(), eps.data_ptr(), latents.data_ptr(), coef.data_ptr(),
-                                       latents.numel(), stream.cuda_stream))
+        _lib.check(lib.mi355x_sd_axpby(latents.data_ptr(), eps.data_ptr(), latents.data_ptr(),
+                                       coef_all.data_ptr() + 8 * k, latents.numel(), stream.cuda_stream))
 
     def sync_all():
         torch.cuda.synchronize()

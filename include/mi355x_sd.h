@@ -145,6 +145,16 @@ int mi355x_sd_conv_out3x3(const void* x, int ldx, const void* w, const float* bi
                           int B, int Cin, int H, int W, int Cout, void* stream);
 int mi355x_sd_copy_rows(const void* x, int ldx, void* y, int ldy, int64_t rows, int C, void* stream);
 
+/* ---- CLIP text encoder (PPD/transformers/clip/modeling.py) ----
+ * CLIPTextEmbeddings.forward (:214-231): out[i][:] = bf16(token_table[ids[i]] + position_table[i % seq_len]); tables bf16
+ * [V][D] / [P][D], ids int32 in device memory (range-checked by the caller), D % 8 == 0. */
+int mi355x_sd_embed_tokens(const int32_t* ids, int64_t n_tokens, int seq_len, const void* token_table,
+                           const void* position_table, int D, void* out, int ldo, void* stream);
+/* y = act(x) on n bf16 elements (n % 8 == 0): kind 0 quick_gelu (x sigmoid(1.702 x), CLIPMLP :338-350 with
+ * hidden_act="quick_gelu"), 1 gelu (erf), 2 silu. The rest of CLIPEncoderLayer (:353-400) is mi355x_sd_layernorm,
+ * mi355x_sd_linear (bias / residual epilogues) and mi355x_sd_sdpa with the causal mask as its additive bias. */
+int mi355x_sd_activation(const void* x, void* y, int64_t n, int kind, void* stream);
+
 /* ---- AutoencoderKL decoder (PPD/models/autoencoder_kl.py:288-333, PPD/models/vae.py:182-343) ----
  * post_quant_conv (autoencoder_kl.py:121,292-293): 1x1 convolution of a small NCHW fp32 tensor, Cin, Cout <= 16,
  * y[b,co,p] = bias[co] + sum_ci w[co][ci] * bf16(x[b,ci,p] * in_scale); in_scale = 1 / scaling_factor of the calling

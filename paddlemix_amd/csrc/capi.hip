@@ -260,6 +260,18 @@ int mi355x_sd_copy_rows(const void* x, int ldx, void* y, int ldy, int64_t rows, 
   return finish(launch_copy_rows((const bf16*)x, ldx, (bf16*)y, ldy, (long)rows, C, S(stream)), "mi355x_sd_copy_rows");
 }
 
+int mi355x_sd_embed_tokens(const int32_t* ids, int64_t n_tokens, int seq_len, const void* token_table,
+                           const void* position_table, int D, void* out, int ldo, void* stream) {
+  if (!ids || !token_table || !position_table || !out) return fail(SD_ERR_INVALID, "mi355x_sd_embed_tokens: null pointer");
+  return finish(launch_embed_tokens(ids, (long)n_tokens, seq_len, (const bf16*)token_table, (const bf16*)position_table, D,
+                                    (bf16*)out, ldo, S(stream)), "mi355x_sd_embed_tokens");
+}
+
+int mi355x_sd_activation(const void* x, void* y, int64_t n, int kind, void* stream) {
+  if (!x || !y) return fail(SD_ERR_INVALID, "mi355x_sd_activation: null pointer");
+  return finish(launch_activation((const bf16*)x, (bf16*)y, (long)n, kind, S(stream)), "mi355x_sd_activation");
+}
+
 int mi355x_sd_conv1x1_nchw(const float* x_nchw, float in_scale, const void* w, const float* bias, float* y_nchw, int B,
                            int Cin, int Cout, int64_t HW, void* stream) {
   if (!x_nchw || !w || !y_nchw) return fail(SD_ERR_INVALID, "mi355x_sd_conv1x1_nchw: null pointer");

@@ -187,6 +187,63 @@ int launch_conv_out3x3(const bf16* x, int ldx, const bf16* w, const float* bias,
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
 
+// CLIPTextEmbeddings.forward (PPD/transformers/clip/modeling.py:214-231): out[i] = token_embedding[ids[i]] +
+// position_embedding[i % seq_len], summed in fp32 and stored as a bf16 row. ids are validated by the caller (host).
+__global__ void embed_tokens_kernel(const int* __restrict__ ids, long n_tokens, int seq_len, const bf16* __restrict__ tok,
+                                    const bf16* __restrict__ pos, int D, bf16* __restrict__ out, int ldo) {
+  const int cv = D >> 3;
+  const long total = n_tokens * cv;
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long)gridDim.x * blockDim.x) {
+    const long t = id / cv;
+    const int cc = (int)(id - t * cv);
+    const u32x4 ra = *reinterpret_cast<const u32x4*>(tok + (size_t)ids[t] * D + cc * 8);
+    const u32x4 rb = *reinterpret_cast<const u32x4*>(pos + (size_t)(t % seq_len) * D + cc * 8);
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(&ra), b = *reinterpret_cast<const bf16x8*>(&rb);
+    u32x4 pk = {pack_bf16((float)a[0] + (float)b[0], (float)a[1] + (float)b[1]),
+                pack_bf16((float)a[2] + (float)b[2], (float)a[3] + (float)b[3]),
+                pack_bf16((float)a[4] + (float)b[4], (float)a[5] + (float)b[5]),
+                pack_bf16((float)a[6] + (float)b[6], (float)a[7] + (float)b[7])};
+    *reinterpret_cast<u32x4*>(out + (size_t)t * ldo + cc * 8) = pk;
+  }
+}
+
+int launch_embed_tokens(const int* ids, long n_tokens, int seq_len, const bf16* tok, const bf16* pos, int D, bf16* out,
+                        int ldo, hipStream_t stream) {
+  if (n_tokens <= 0 || seq_len <= 0 || D <= 0) return SD_ERR_INVALID;
+  if ((D & 7) || (ldo & 7)) return SD_ERR_UNSUPPORTED;
+  long nb = (n_tokens * (D >> 3) + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(embed_tokens_kernel, dim3((unsigned)nb), dim3(256), 0, stream, ids, n_tokens, seq_len, tok, pos, D,
+                     out, ldo);
+  return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+}
+
+// Elementwise activations of the text encoders on bf16 rows (ACT2FN, PPD/transformers/activations.py):
+// kind 0 = quick_gelu  x * sigmoid(1.702 x)  (CLIP ViT-L text), 1 = gelu (erf; OpenCLIP bigG), 2 = silu.
+__global__ void activation_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, long n8, int kind) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const u32x4 raw = reinterpret_cast<const u32x4*>(x)[i];
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(&raw);
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float f = (float)v[j];
+      o[j] = kind == 0 ? f / (1.0f + __expf(-1.702f * f)) : (kind == 1 ? gelu_erf_f(f) : silu_f(f));
+    }
+    u32x4 pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7])};
+    reinterpret_cast<u32x4*>(y)[i] = pk;
+  }
+}
+
+int launch_activation(const bf16* x, bf16* y, long n, int kind, hipStream_t stream) {
+  if (n <= 0 || kind < 0 || kind > 2) return SD_ERR_INVALID;
+  if (n & 7) return SD_ERR_UNSUPPORTED;
+  long nb = ((n >> 3) + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(activation_kernel, dim3((unsigned)nb), dim3(256), 0, stream, x, y, n >> 3, kind);
+  return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+}
+
 // 1x1 convolution on a small NCHW fp32 tensor (AutoencoderKL.post_quant_conv, autoencoder_kl.py:121,292-293, folded
 // with the 1 / scaling_factor of the pipelines): y[b,co,p] = bias[co] + sum_ci w[co][ci] * bf16(x[b,ci,p] * in_scale).
 constexpr int C1_MAX = 16;

@@ -366,3 +366,28 @@ def linear_ln(a: Tensor, stats: Tensor, w: Tensor, w_rowsum: Tensor, bias: Optio
     check(lib.mi355x_sd_linear_ln(a.data_ptr(), lda, stats.data_ptr(), w.data_ptr(), _vec(w_rowsum, N, "w_rowsum").data_ptr(),
                                   out.data_ptr(), ldc, M, N, K, _p(_vec(bias, N, "bias")), GEGLU if geglu else 0, _stream()))
     return out
+
+
+def embed_tokens(ids: Tensor, token_table: Tensor, position_table: Tensor, seq_len: int) -> Tensor:
+    """CLIPTextEmbeddings: bf16 rows token_table[ids] + position_table[i % seq_len]; ids int32 [n]."""
+    lib = _lib.load()
+    if ids.dtype != torch.int32 or not ids.is_cuda or not ids.is_contiguous():
+        raise ValueError("ids: expected a contiguous int32 GPU tensor")
+    V, D = token_table.shape
+    if int(ids.min()) < 0 or int(ids.max()) >= V or seq_len > position_table.shape[0]:
+        raise ValueError("ids / seq_len out of range of the embedding tables")
+    out = torch.empty((ids.numel(), D), device=ids.device, dtype=torch.bfloat16)
+    check(lib.mi355x_sd_embed_tokens(ids.data_ptr(), ids.numel(), seq_len, token_table.data_ptr(),
+                                     position_table.data_ptr(), D, out.data_ptr(), D, _stream()))
+    return out
+
+
+def activation(x: Tensor, kind: str) -> Tensor:
+    """quick_gelu | gelu | silu on a contiguous bf16 tensor."""
+    lib = _lib.load()
+    kinds = {"quick_gelu": 0, "gelu": 1, "silu": 2}
+    if x.dtype != torch.bfloat16 or not x.is_cuda or not x.is_contiguous():
+        raise ValueError("x: expected a contiguous bf16 GPU tensor")
+    y = torch.empty_like(x)
+    check(lib.mi355x_sd_activation(x.data_ptr(), y.data_ptr(), x.numel(), kinds[kind], _stream()))
+    return y

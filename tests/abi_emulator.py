@@ -181,8 +181,9 @@ class Emulator:
         qq, kk, vv = view(q, Sq, q_bs, q_ts).float(), view(k, Skv, k_bs, k_ts).float(), view(v, Skv, v_bs, v_ts).float()
         s = torch.einsum("bqhd,bkhd->bhqk", qq, kk) * scale
         if bias:
-            assert bias_hs == 0 and bias_qs == 0 and bias_bs == Skv, "emulator: only the [B, Skv] encoder mask form"
-            s = s + _flat(bias, B * Skv, torch.float32).reshape(B, 1, 1, Skv)
+            # general additive mask: bias[b*bias_bs + h*bias_hs + q*bias_qs + kv] (0 strides broadcast)
+            n = (B - 1) * bias_bs + (H - 1) * bias_hs + (Sq - 1) * bias_qs + Skv
+            s = s + _flat(bias, n, torch.float32).as_strided((B, H, Sq, Skv), (bias_bs, bias_hs, bias_qs, 1))
         p = torch.softmax(s, -1)
         o = torch.einsum("bhqk,bkhd->bqhd", p, vv)
         view(out, Sq, o_bs, o_ts).copy_(o.to(torch.bfloat16))
@@ -258,6 +259,21 @@ class Emulator:
         wt = _flat(w, Cout * 9 * Cin, torch.bfloat16).float().reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
         o = F.conv2d(xs, wt, _flat(bias, Cout, torch.float32) if bias else None, padding=1)
         _flat(y, B * Cout * H * W, torch.float32).reshape(B, Cout, H, W).copy_(o)
+        return 0
+
+    def mi355x_sd_embed_tokens(self, ids, n_tokens, seq_len, tok, pos, D, out, ldo, stream):
+        buf = (ctypes.c_char * (4 * n_tokens)).from_address(ids)
+        idx = torch.frombuffer(buf, dtype=torch.int32, count=n_tokens).long()
+        V = int(idx.max()) + 1
+        t = _rows(tok, V, D, D).float()[idx]
+        p_ = _rows(pos, seq_len, D, D).float()[torch.arange(n_tokens) % seq_len]
+        _rows(out, n_tokens, D, ldo).copy_((t + p_).to(torch.bfloat16))
+        return 0
+
+    def mi355x_sd_activation(self, x, y, n, kind, stream):
+        v = _flat(x, n, torch.bfloat16).float()
+        o = v * torch.sigmoid(1.702 * v) if kind == 0 else (F.gelu(v) if kind == 1 else F.silu(v))
+        _flat(y, n, torch.bfloat16).copy_(o.to(torch.bfloat16))
         return 0
 
     def mi355x_sd_conv1x1_nchw(self, x, in_scale, w, bias, y, B, Cin, Cout, HW, stream):

@@ -40,3 +40,11 @@ MINI_VAE = dict(in_channels=3, out_channels=3, latent_channels=4, block_out_chan
 # SD-1.5 / SDXL VAE (public config: 128-256-512-512, 2 layers per block; SDXL scaling_factor 0.13025)
 SD_VAE = dict(in_channels=3, out_channels=3, latent_channels=4, block_out_channels=(128, 256, 512, 512),
               layers_per_block=2, norm_num_groups=32, scaling_factor=0.18215, use_post_quant_conv=True)
+# CLIP text encoder in miniature (reference tiny config shape: ppdiffusers/tests/pipelines/stable_diffusion/test_stable_diffusion.py:137-150,
+# widened so head_dim = 32) and the two SD encoders (public configs)
+MINI_CLIP = dict(vocab_size=1000, hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=2,
+                 max_position_embeddings=77, hidden_act="quick_gelu", projection_dim=32, eos_token_id=2)
+CLIP_L = dict(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12,
+              max_position_embeddings=77, hidden_act="quick_gelu", projection_dim=768, eos_token_id=2)
+CLIP_BIGG = dict(vocab_size=49408, hidden_size=1280, intermediate_size=5120, num_hidden_layers=32, num_attention_heads=20,
+                 max_position_embeddings=77, hidden_act="gelu", projection_dim=1280, eos_token_id=2)

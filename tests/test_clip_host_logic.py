@@ -1,0 +1,78 @@
+"""CPU: the CLIP text-encoder program (embedding gather, fused QKV, causal-mask attention, EOS pooling, projection,
+hidden_states tuple) interpreted by the ABI emulator against the oracle."""
+import pytest
+import torch
+
+from oracle import clip_ref as R
+from paddlemix_amd.clip import CLIPTextModel, CLIPTextModelWithProjection, clip_param_shapes, synth_clip_params
+from tests.abi_emulator import Emulator
+from tests.configs import CLIP_BIGG, CLIP_L, MINI_CLIP
+
+
+def _rel(a, b):
+    return ((a.float() - b.float()).norm() / b.float().norm()).item()
+
+
+def _ids(B, S, vocab, eos, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(3, vocab - 1, (B, S), generator=g)
+    ids[:, 0] = 0
+    for b in range(B):
+        e = 3 + 2 * b
+        ids[b, e] = eos if eos != 2 else vocab - 1   # eos_token_id == 2 pools at argmax(ids)
+        ids[b, e + 1:] = eos if eos != 2 else 1      # padding after EOS
+    return ids
+
+
+def test_param_shapes_and_counts():
+    assert clip_param_shapes(MINI_CLIP) == R.clip_param_shapes(MINI_CLIP)
+    n = sum(torch.Size(s).numel() for s in clip_param_shapes(CLIP_L).values())
+    assert n == 123_060_480   # CLIP ViT-L/14 text model (without position_ids)
+    nb = sum(torch.Size(s).numel() for s in clip_param_shapes(dict(CLIP_BIGG, with_projection=True)).values())
+    assert nb == 694_659_840  # OpenCLIP bigG text model + projection
+
+
+@pytest.mark.parametrize("act,eos", [("quick_gelu", 2), ("gelu", 7)])
+def test_program_matches_oracle(act, eos):
+    cfg = dict(MINI_CLIP, hidden_act=act, eos_token_id=eos)
+    P = synth_clip_params(cfg, seed=5)
+    Pb = {k: (v.to(torch.bfloat16).float() if v.dim() > 1 else v) for k, v in P.items()}
+    ids = _ids(2, 16, cfg["vocab_size"], eos)
+    ref = R.clip_text_forward(Pb, cfg, ids)
+    model = CLIPTextModel(cfg, P, _test_backend=Emulator())
+    out = model(ids, output_hidden_states=True)
+    assert _rel(out.last_hidden_state, ref["last_hidden_state"]) < 1e-2
+    assert _rel(out.pooler_output, ref["pooler_output"]) < 1e-2
+    assert len(out.hidden_states) == cfg["num_hidden_layers"] + 1
+    assert _rel(out.hidden_states[-2], ref["hidden_states"][-2]) < 1e-2   # what SDXL conditions on
+    assert _rel(out[0], ref["last_hidden_state"]) < 1e-2 and model(ids).hidden_states is None
+    # causality: changing a later token leaves earlier positions untouched
+    ids2 = ids.clone()
+    ids2[:, 10] = 5
+    out2 = model(ids2)
+    assert torch.equal(out2.last_hidden_state[:, :10], out.last_hidden_state[:, :10])
+    assert not torch.equal(out2.last_hidden_state[:, 10:], out.last_hidden_state[:, 10:])
+
+
+def test_with_projection_and_errors():
+    cfg = dict(MINI_CLIP)
+    Pp = synth_clip_params(dict(cfg, with_projection=True), seed=6)
+    Pb = {k: (v.to(torch.bfloat16).float() if v.dim() > 1 else v) for k, v in Pp.items()}
+    ids = _ids(1, 12, cfg["vocab_size"], 2)
+    model = CLIPTextModelWithProjection(cfg, Pp, _test_backend=Emulator())
+    out = model(ids, output_hidden_states=True)
+    ref = R.clip_text_forward(Pb, dict(cfg, with_projection=True), ids)
+    assert out.text_embeds.shape == (1, 32) and _rel(out.text_embeds, ref["text_embeds"]) < 1.5e-2
+    tup = model(ids, output_hidden_states=True, return_dict=False)
+    assert torch.equal(tup[0], out.text_embeds) and len(tup[-1]) == cfg["num_hidden_layers"] + 1
+    with pytest.raises(ValueError):
+        model(torch.full((1, 4), cfg["vocab_size"]))
+    with pytest.raises(ValueError):
+        model(torch.zeros(1, 78, dtype=torch.long))
+    with pytest.raises(NotImplementedError):
+        model(ids, attention_mask=torch.ones(1, 12))
+    with pytest.raises(KeyError):
+        CLIPTextModelWithProjection(cfg, {k: v for k, v in Pp.items() if k != "text_projection.weight"},
+                                    _test_backend=Emulator())
+    with pytest.raises(NotImplementedError):
+        CLIPTextModel(dict(cfg, hidden_act="relu"), Pp, _test_backend=Emulator())
