@@ -79,8 +79,10 @@ def synth_clip_params(config: Mapping, seed: int = 1234, device="cpu") -> Dict[s
 class CLIPTextModelOutput(SimpleNamespace):
     """last_hidden_state, pooler_output, hidden_states (tuple or None), text_embeds (with projection)."""
 
-    def __getitem__(self, i):   # tuple-style access used by the pipelines: out[0], out[1]
-        return (self.last_hidden_state, self.pooler_output)[i]
+    def __getitem__(self, i):   # tuple-style access used by the pipelines: out[0] (SDXL: the pooled text_embeds), out[-1]
+        first = (self.text_embeds, self.last_hidden_state) if self.text_embeds is not None else \
+            (self.last_hidden_state, self.pooler_output)
+        return tuple(v for v in first + (self.hidden_states,) if v is not None)[i]
 
 
 class CLIPTextModel(DeviceProgram, PretrainedMixin):

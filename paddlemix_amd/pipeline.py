@@ -27,8 +27,40 @@ def rescale_noise_cfg(noise_cfg, noise_pred_text, guidance_rescale=0.0):
 class StableDiffusionDenoiser:
     """``pipe = StableDiffusionDenoiser(unet, scheduler); latents = pipe(prompt_embeds=..., ...)``"""
 
-    def __init__(self, unet, scheduler, vae=None):
+    def __init__(self, unet, scheduler, vae=None, text_encoder=None, text_encoder_2=None):
         self.unet, self.scheduler, self.vae = unet, scheduler, vae
+        self.text_encoder, self.text_encoder_2 = text_encoder, text_encoder_2
+
+    def encode_prompt(self, input_ids: torch.Tensor, input_ids_2: Optional[torch.Tensor] = None,
+                      clip_skip: Optional[int] = None):
+        """Token ids -> (prompt_embeds, pooled_prompt_embeds or None). Tokenisation stays with the caller (the CLIP
+        vocabulary files are not part of a model's weights).
+        SD (one encoder, pipeline_stable_diffusion.py:368-391): ``text_encoder(ids)[0]``.
+        SDXL (two encoders, pipeline_stable_diffusion_xl.py:363-375): hidden_states[-2] of both encoders concatenated on
+        the channel axis, pooled = ``text_encoder_2(ids)[0]`` (the projected EOS row)."""
+        if self.text_encoder is None:
+            raise ValueError("encode_prompt needs a `text_encoder`")
+        if self.text_encoder_2 is None:
+            if clip_skip is None:
+                return self.text_encoder(input_ids)[0], None
+            raise NotImplementedError("clip_skip for the single-encoder pipeline")
+        embeds, pooled = [], None
+        for enc, ids in ((self.text_encoder, input_ids), (self.text_encoder_2, input_ids if input_ids_2 is None else input_ids_2)):
+            out = enc(ids, output_hidden_states=True)
+            pooled = out[0]   # only the final encoder's pooled output is kept
+            embeds.append(out.hidden_states[-2 if clip_skip is None else -(clip_skip + 2)])
+        return torch.cat(embeds, dim=-1), pooled
+
+    def get_add_time_ids(self, original_size, crops_coords_top_left, target_size, text_encoder_projection_dim: int,
+                         device=None) -> torch.Tensor:
+        """pipeline_stable_diffusion_xl.py:603-619"""
+        ids = list(original_size + crops_coords_top_left + target_size)
+        cfg = self.unet.config
+        passed = cfg.addition_time_embed_dim * len(ids) + text_encoder_projection_dim
+        if passed != cfg.projection_class_embeddings_input_dim:
+            raise ValueError(f"Model expects an added time embedding vector of length "
+                             f"{cfg.projection_class_embeddings_input_dim}, but a vector of {passed} was created.")
+        return torch.tensor([ids], dtype=torch.float32, device=device)
 
     def decode_latents(self, latents: torch.Tensor, output_type: str = "pt"):
         """pipeline_stable_diffusion.py:911 + VaeImageProcessor.postprocess: decode, (x / 2 + 0.5).clamp(0, 1)."""
@@ -50,14 +82,37 @@ class StableDiffusionDenoiser:
         return latents * self.scheduler.init_noise_sigma  # pipeline_stable_diffusion.py:581-586
 
     @torch.no_grad()
-    def __call__(self, prompt_embeds: torch.Tensor, negative_prompt_embeds: Optional[torch.Tensor] = None,
+    def __call__(self, prompt_embeds: Optional[torch.Tensor] = None, negative_prompt_embeds: Optional[torch.Tensor] = None,
                  height: Optional[int] = None, width: Optional[int] = None, num_inference_steps: int = 50,
                  guidance_scale: float = 7.5, guidance_rescale: float = 0.0, latents: Optional[torch.Tensor] = None,
                  generator=None, added_cond_kwargs: Optional[Dict[str, torch.Tensor]] = None,
                  negative_added_cond_kwargs: Optional[Dict[str, torch.Tensor]] = None,
                  callback_on_step_end: Optional[Callable] = None, vae_scale_factor: int = 8,
-                 output_type: str = "latent"):
+                 output_type: str = "latent", prompt_ids: Optional[torch.Tensor] = None,
+                 negative_prompt_ids: Optional[torch.Tensor] = None, prompt_ids_2: Optional[torch.Tensor] = None,
+                 negative_prompt_ids_2: Optional[torch.Tensor] = None, original_size=None,
+                 crops_coords_top_left=(0, 0), target_size=None):
         do_cfg = guidance_scale > 1.0
+        if prompt_embeds is None:
+            if prompt_ids is None:
+                raise ValueError("Provide either `prompt_embeds` or `prompt_ids`")
+            prompt_embeds, pooled = self.encode_prompt(prompt_ids, prompt_ids_2)
+            neg_pooled = None
+            if do_cfg and negative_prompt_embeds is None:
+                if negative_prompt_ids is None:   # force_zeros_for_empty_prompt (pipeline_stable_diffusion_xl.py:378-381)
+                    negative_prompt_embeds = torch.zeros_like(prompt_embeds)
+                    neg_pooled = None if pooled is None else torch.zeros_like(pooled)
+                else:
+                    negative_prompt_embeds, neg_pooled = self.encode_prompt(negative_prompt_ids, negative_prompt_ids_2)
+            if pooled is not None and added_cond_kwargs is None:   # SDXL micro-conditioning (:1007-1036)
+                hw = (height or self.unet.config.sample_size * vae_scale_factor,
+                      width or self.unet.config.sample_size * vae_scale_factor)
+                tids = self.get_add_time_ids(tuple(original_size or hw), tuple(crops_coords_top_left),
+                                             tuple(target_size or hw), pooled.shape[-1], pooled.device)
+                tids = tids.repeat(pooled.shape[0], 1)
+                added_cond_kwargs = {"text_embeds": pooled, "time_ids": tids}
+                if do_cfg:
+                    negative_added_cond_kwargs = {"text_embeds": neg_pooled, "time_ids": tids}
         if do_cfg and negative_prompt_embeds is None:
             raise ValueError("classifier-free guidance needs `negative_prompt_embeds`")
         B = prompt_embeds.shape[0]

@@ -94,3 +94,43 @@ def test_pipeline_with_vae_decode_outputs_images():
     with pytest.raises(ValueError):
         StableDiffusionDenoiser(pipe.unet, pipe.scheduler)(pe, num_inference_steps=1, guidance_scale=1.0,
                                                            latents=lat0.clone(), output_type="pt")
+
+
+def test_full_sdxl_style_pipeline_from_token_ids():
+    """token ids -> two CLIP encoders (hidden_states[-2] concat + projected pooled) -> micro-conditioning ->
+    CFG Euler loop -> VAE decode, all through product host code on the emulator."""
+    from oracle import clip_ref as CR
+    from paddlemix_amd.clip import CLIPTextModel, CLIPTextModelWithProjection, synth_clip_params
+    from paddlemix_amd.vae import AutoencoderKL, synth_decoder_params
+    from tests.configs import MINI_CLIP, MINI_VAE
+    from tests.test_clip_host_logic import _ids
+    cfg = MINI_XL
+    c1, c2 = dict(MINI_CLIP), dict(MINI_CLIP, projection_dim=64, hidden_act="gelu")
+    P1, P2 = synth_clip_params(c1, seed=1), synth_clip_params(dict(c2, with_projection=True), seed=2)
+    pipe = StableDiffusionDenoiser(UNet2DConditionModel(cfg, synth_unet_params(cfg, seed=3), _test_backend=Emulator()),
+                                   EulerDiscreteScheduler(timestep_spacing="leading", **SCHED),
+                                   vae=AutoencoderKL(MINI_VAE, synth_decoder_params(MINI_VAE, seed=4), _test_backend=Emulator()),
+                                   text_encoder=CLIPTextModel(c1, P1, _test_backend=Emulator()),
+                                   text_encoder_2=CLIPTextModelWithProjection(c2, P2, _test_backend=Emulator()))
+    ids = _ids(1, 12, c1["vocab_size"], 2)
+    embeds, pooled = pipe.encode_prompt(ids)
+    assert embeds.shape == (1, 12, 128) and pooled.shape == (1, 64)
+    bf = lambda P: {k: (v.to(torch.bfloat16).float() if v.dim() > 1 else v) for k, v in P.items()}  # noqa: E731
+    r1 = CR.clip_text_forward(bf(P1), c1, ids)
+    r2 = CR.clip_text_forward(bf(P2), dict(c2, with_projection=True), ids)
+    ref = torch.cat([r1["hidden_states"][-2], r2["hidden_states"][-2]], -1)
+    assert ((embeds - ref).norm() / ref.norm()) < 1e-2
+    assert ((pooled - r2["text_embeds"]).norm() / r2["text_embeds"].norm()) < 1.5e-2
+    lat0 = torch.randn(1, 4, 8, 8, generator=torch.Generator().manual_seed(0))
+    img = pipe(prompt_ids=ids, num_inference_steps=2, guidance_scale=5.0, latents=lat0.clone(), height=64, width=64,
+               output_type="pt")
+    assert img.shape == (1, 3, 32, 32) and torch.isfinite(img).all()
+    # same call from precomputed embeddings + explicit micro-conditioning gives the same image
+    tids = pipe.get_add_time_ids((64, 64), (0, 0), (64, 64), 64)
+    img2 = pipe(embeds, torch.zeros_like(embeds), num_inference_steps=2, guidance_scale=5.0, latents=lat0.clone(),
+                added_cond_kwargs={"text_embeds": pooled, "time_ids": tids},
+                negative_added_cond_kwargs={"text_embeds": torch.zeros_like(pooled), "time_ids": tids}, output_type="pt")
+    assert torch.equal(img, img2)
+    import pytest
+    with pytest.raises(ValueError):
+        pipe.get_add_time_ids((64, 64), (0, 0), (64, 64), 32)
