@@ -145,3 +145,62 @@ class StableDiffusionDenoiser:
         if output_type == "latent":
             return latents
         return self.decode_latents(latents, output_type)
+
+
+class StableDiffusion3Denoiser:
+    """The denoising loop of ``StableDiffusion3Pipeline.__call__`` (pipelines/stable_diffusion_3/
+    pipeline_stable_diffusion_3.py:772-870) with the MI355X MMDiT in the ``transformer`` slot: CFG batch doubling
+    ([negative, positive]), the transformer call, the guidance combine, ``FlowMatchEulerDiscreteScheduler.step`` and
+    ``callback_on_step_end``; then (:880-886) ``vae.decode(latents / scaling_factor + shift_factor)``.
+    Prompt encoding (2 x CLIP + T5) stays outside: the loop takes ``prompt_embeds`` [B, L, joint_attention_dim] and
+    ``pooled_prompt_embeds`` [B, pooled_projection_dim]."""
+
+    def __init__(self, transformer, scheduler, vae=None):
+        self.transformer, self.scheduler, self.vae = transformer, scheduler, vae
+
+    @torch.no_grad()
+    def __call__(self, prompt_embeds: torch.Tensor, pooled_prompt_embeds: torch.Tensor,
+                 negative_prompt_embeds: Optional[torch.Tensor] = None,
+                 negative_pooled_prompt_embeds: Optional[torch.Tensor] = None, height: Optional[int] = None,
+                 width: Optional[int] = None, num_inference_steps: int = 28, guidance_scale: float = 7.0,
+                 latents: Optional[torch.Tensor] = None, generator=None, callback_on_step_end: Optional[Callable] = None,
+                 vae_scale_factor: int = 8, output_type: str = "latent"):
+        do_cfg = guidance_scale > 1.0
+        if do_cfg and (negative_prompt_embeds is None or negative_pooled_prompt_embeds is None):
+            raise ValueError("classifier-free guidance needs `negative_prompt_embeds` and `negative_pooled_prompt_embeds`")
+        cfg = self.transformer.config
+        B = prompt_embeds.shape[0]
+        h = (height // vae_scale_factor) if height else cfg.sample_size
+        w = (width // vae_scale_factor) if width else cfg.sample_size
+        shape = (B, cfg.in_channels, h, w)
+        if latents is None:
+            latents = torch.randn(shape, generator=generator, dtype=torch.float32, device=prompt_embeds.device)
+        elif height is None and width is None:
+            shape = tuple(latents.shape)
+        if tuple(latents.shape) != shape:
+            raise ValueError(f"Unexpected latents shape, got {tuple(latents.shape)}, expected {shape}")
+        if do_cfg:
+            prompt_embeds = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0)
+            pooled_prompt_embeds = torch.cat([negative_pooled_prompt_embeds, pooled_prompt_embeds], dim=0)
+        self.scheduler.set_timesteps(num_inference_steps)
+        for i, t in enumerate(self.scheduler.timesteps):
+            x = torch.cat([latents] * 2) if do_cfg else latents
+            v = self.transformer(hidden_states=x, timestep=t, encoder_hidden_states=prompt_embeds,
+                                 pooled_projections=pooled_prompt_embeds, return_dict=False)[0]
+            if do_cfg:
+                v_uncond, v_text = v.chunk(2)
+                v = v_uncond + guidance_scale * (v_text - v_uncond)
+            latents = self.scheduler.step(v, t, latents, return_dict=False)[0]
+            if callback_on_step_end is not None:
+                out = callback_on_step_end(self, i, t, {"latents": latents})
+                latents = out.pop("latents", latents)
+        if output_type == "latent":
+            return latents
+        if self.vae is None:
+            raise ValueError("output_type != 'latent' needs a `vae`")
+        if output_type not in ("pt", "np"):
+            raise ValueError(f"output_type must be 'latent', 'pt' or 'np', got {output_type!r}")
+        vc = self.vae.config
+        z = latents / vc.scaling_factor + getattr(vc, "shift_factor", 0.0)
+        image = (self.vae.decode(z, return_dict=False)[0] / 2 + 0.5).clamp(0, 1)
+        return image if output_type == "pt" else image.cpu().permute(0, 2, 3, 1).float().numpy()
