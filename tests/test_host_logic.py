@@ -108,3 +108,19 @@ def test_encoder_attention_mask_semantics():
     assert _rel(masked, ref) < 2e-2
     with pytest.raises(NotImplementedError):
         model(sample, 10, enc, attention_mask=torch.ones(2, 64))
+
+
+def test_seam_objects_refuse_cpu_tensors():
+    """B2 / B3 seams (paddlemix_amd/attention.py) have no CPU fallback either."""
+    from paddlemix_amd.attention import Attention, scaled_dot_product_attention_
+    from paddlemix_amd._lib import MI355XError
+    q = torch.zeros(1, 8, 2, 16)
+    with pytest.raises(ValueError, match="attention_op"):
+        scaled_dot_product_attention_(q, q, q, attention_op="flash")
+    if not torch.cuda.is_available():
+        with pytest.raises((MI355XError, ValueError)):
+            scaled_dot_product_attention_(q, q, q)
+        P = {f"to_{n}.weight": torch.zeros(32, 32) for n in "qkv"}
+        P.update({"to_out.0.weight": torch.zeros(32, 32), "to_out.0.bias": torch.zeros(32)})
+        with pytest.raises((MI355XError, ValueError)):
+            Attention(P, heads=2, device="cpu")(torch.zeros(1, 8, 32))
