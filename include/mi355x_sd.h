@@ -145,6 +145,11 @@ int mi355x_sd_conv_out3x3(const void* x, int ldx, const void* w, const float* bi
                           int B, int Cin, int H, int W, int Cout, void* stream);
 int mi355x_sd_copy_rows(const void* x, int ldx, void* y, int ldy, int64_t rows, int C, void* stream);
 
+/* ControlNet residual inputs of UNet2DConditionModel.forward (down_block_additional_residuals /
+ * mid_block_additional_residual, PPD/models/unet_2d_condition.py:1121-1132, 1151-1155): x[b*HW + p][c] += r[b][c][p] in place
+ * on a bf16 NHWC row view (row stride ldx; C % 8 == 0), r NCHW fp32 as the reference passes it. */
+int mi355x_sd_add_nchw(void* x, int ldx, const float* r_nchw, int B, int C, int64_t HW, void* stream);
+
 /* ---- CLIP text encoder (PPD/transformers/clip/modeling.py) ----
  * CLIPTextEmbeddings.forward (:214-231): out[i][:] = bf16(token_table[ids[i]] + position_table[i % seq_len]); tables bf16
  * [V][D] / [P][D], ids int32 in device memory (range-checked by the caller), D % 8 == 0. */

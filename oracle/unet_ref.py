@@ -302,7 +302,8 @@ def upsample(P: Params, name: str, x: Tensor) -> Tensor:
 def unet_forward(P: Params, config: dict, sample: Tensor, timestep, encoder_hidden_states: Tensor,
                  added_cond_kwargs: Optional[dict] = None, attention_mask: Optional[Tensor] = None,
                  encoder_attention_mask: Optional[Tensor] = None, processor: str = "math",
-                 taps: Optional[dict] = None) -> Tensor:
+                 taps: Optional[dict] = None, down_block_additional_residuals=None,
+                 mid_block_additional_residual: Optional[Tensor] = None) -> Tensor:
     """Returns the noise prediction [B, out_channels, H, W] (the ``(sample,)`` tuple's first element).
 
     ``taps``: optional dict that receives named intermediate activations (for layer-wise parity tests).
@@ -373,6 +374,14 @@ def unet_forward(P: Params, config: dict, sample: Tensor, timestep, encoder_hidd
         if taps is not None:
             taps[f"down_{i}"] = x
 
+    # ControlNet residuals on the skip tuple (:1121-1132): added after the down path, the mid block still sees x
+    if down_block_additional_residuals is not None:
+        if mid_block_additional_residual is None:
+            raise NotImplementedError("T2I-adapter form (down residuals without a mid residual)")
+        if len(down_block_additional_residuals) != len(skips):
+            raise ValueError("one residual per skip tensor is required")
+        skips = [s_ + r.to(dtype) for s_, r in zip(skips, down_block_additional_residuals)]
+
     # mid (:1134-1155)
     if cfg["mid_block_type"] == "UNetMidBlock2DCrossAttn":
         heads = cfg["num_attention_heads"][-1]
@@ -382,6 +391,8 @@ def unet_forward(P: Params, config: dict, sample: Tensor, timestep, encoder_hidd
         x = resnet_block(P, "mid_block.resnets.1", x, emb, groups, eps, cfg["mid_block_scale_factor"])
     elif cfg["mid_block_type"] is not None:
         raise NotImplementedError(cfg["mid_block_type"])
+    if mid_block_additional_residual is not None and down_block_additional_residuals is not None:
+        x = x + mid_block_additional_residual.to(dtype)   # (:1151-1155)
     if taps is not None:
         taps["mid"] = x
 

@@ -260,6 +260,11 @@ int mi355x_sd_copy_rows(const void* x, int ldx, void* y, int ldy, int64_t rows, 
   return finish(launch_copy_rows((const bf16*)x, ldx, (bf16*)y, ldy, (long)rows, C, S(stream)), "mi355x_sd_copy_rows");
 }
 
+int mi355x_sd_add_nchw(void* x, int ldx, const float* r_nchw, int B, int C, int64_t HW, void* stream) {
+  if (!x || !r_nchw) return fail(SD_ERR_INVALID, "mi355x_sd_add_nchw: null pointer");
+  return finish(launch_add_nchw((bf16*)x, ldx, r_nchw, B, C, (long)HW, S(stream)), "mi355x_sd_add_nchw");
+}
+
 int mi355x_sd_embed_tokens(const int32_t* ids, int64_t n_tokens, int seq_len, const void* token_table,
                            const void* position_table, int D, void* out, int ldo, void* stream) {
   if (!ids || !token_table || !position_table || !out) return fail(SD_ERR_INVALID, "mi355x_sd_embed_tokens: null pointer");

@@ -87,6 +87,7 @@ int launch_conv_in3x3(const float* x_nchw, const float* in_scale, const bf16* w,
                       int Cin, int H, int W, int Cout, int ldy, hipStream_t stream);
 int launch_conv_out3x3(const bf16* x, int ldx, const bf16* w, const float* bias, float* y_nchw, int B, int Cin, int H,
                        int W, int Cout, hipStream_t stream);
+int launch_add_nchw(bf16* x, int ldx, const float* r, int B, int C, long HW, hipStream_t stream);
 int launch_embed_tokens(const int* ids, long n_tokens, int seq_len, const bf16* tok, const bf16* pos, int D, bf16* out,
                         int ldo, hipStream_t stream);
 int launch_activation(const bf16* x, bf16* y, long n, int kind, hipStream_t stream);

@@ -187,6 +187,45 @@ int launch_conv_out3x3(const bf16* x, int ldx, const bf16* w, const float* bias,
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
 
+// x[b*HW + p][c] += r[b][c][p]: a ControlNet residual (NCHW fp32, as the reference hands them over,
+// unet_2d_condition.py:1121-1132, 1151-1155) added in place to a bf16 NHWC row view (row stride ldx, so it can be a
+// channel slice of a concat buffer). 64 pixels x 64 channels per block through LDS: the fp32 reads run along pixels,
+// the bf16 read-modify-write along channels.
+__global__ __launch_bounds__(256) void add_nchw_kernel(bf16* __restrict__ x, int ldx, const float* __restrict__ r, int C,
+                                                       long HW) {
+  __shared__ float tile[64][65];
+  const long p0 = (long)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64, b = blockIdx.z;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int cc = ty; cc < 64; cc += 4) {
+    const int c = c0 + cc;
+    tile[cc][tx] = (c < C && p0 + tx < HW) ? r[((size_t)b * C + c) * HW + p0 + tx] : 0.f;
+  }
+  __syncthreads();
+  const int cg = threadIdx.x & 7;          // 8 channels
+  for (int pp = threadIdx.x >> 3; pp < 64; pp += 32) {
+    const long p = p0 + pp;
+    const int c = c0 + cg * 8;
+    if (p >= HW || c >= C) continue;
+    bf16* xr = x + ((size_t)b * HW + p) * ldx + c;
+    const u32x4 raw = *reinterpret_cast<const u32x4*>(xr);
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(&raw);
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (float)v[j] + tile[cg * 8 + j][pp];
+    u32x4 pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7])};
+    *reinterpret_cast<u32x4*>(xr) = pk;
+  }
+}
+
+int launch_add_nchw(bf16* x, int ldx, const float* r, int B, int C, long HW, hipStream_t stream) {
+  if (B <= 0 || C <= 0 || HW <= 0) return SD_ERR_INVALID;
+  if ((C & 7) || (ldx & 7) || B > 65535 || (C + 63) / 64 > 65535) return SD_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(add_nchw_kernel, dim3((unsigned)((HW + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)B), dim3(256), 0,
+                     stream, x, ldx, r, C, HW);
+  return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+}
+
 // CLIPTextEmbeddings.forward (PPD/transformers/clip/modeling.py:214-231): out[i] = token_embedding[ids[i]] +
 // position_embedding[i % seq_len], summed in fp32 and stored as a bf16 row. ids are validated by the caller (host).
 __global__ void embed_tokens_kernel(const int* __restrict__ ids, long n_tokens, int seq_len, const bf16* __restrict__ tok,

@@ -374,7 +374,7 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
         W["conv_out.b"] = get("conv_out.bias").contiguous()
 
     # ------------------------------------------------------------------ plan
-    def _build_plan(self, B: int, H: int, Wd: int, L: int, masked: bool = False) -> _Plan:
+    def _build_plan(self, B: int, H: int, Wd: int, L: int, masked: bool = False, controlnet: bool = False) -> _Plan:
         cfg, lib, dev, W = self.cfg, self._lib, self.device, self.w
         stream = self._stream_ptr
         boc = cfg["block_out_channels"]
@@ -631,6 +631,17 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
                 h, w_ = ho, wo
                 cur = dst
             elif d[0] == "cat":
+                if u == 0 and controlnet:
+                    # ControlNet residuals (unet_2d_condition.py:1121-1132, 1151-1155): every skip tensor and the mid
+                    # output get their residual once the down path and the mid block have consumed the originals
+                    plan.ctrl_down = []
+                    for kk, (cs, hs, ws_) in enumerate(skips):
+                        rt = persist((B, cs, hs, ws_), torch.float32)
+                        plan.ctrl_down.append(rt)
+                        sl = skip_slot(kk)
+                        emit(lib.mi355x_sd_add_nchw, (sl.p, sl.ld, rt.data_ptr(), B, cs, hs * ws_, stream), "misc")
+                    plan.ctrl_mid = persist((B, cur.C, h, w_), torch.float32)
+                    emit(lib.mi355x_sd_add_nchw, (cur.p, cur.ld, plan.ctrl_mid.data_ptr(), B, cur.C, h * w_, stream), "misc")
                 cur = cats[u]
                 u += 1
             elif d[0] == "up":
@@ -678,15 +689,25 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
                self._stream_ptr), "misc", 0.0)
         plan.prog.insert(plan._add_emit_index, op)
 
-    def _get_plan(self, B, H, W, L, masked: bool = False) -> _Plan:
-        key = (B, H, W, L, masked)
+    def _get_plan(self, B, H, W, L, masked: bool = False, controlnet: bool = False) -> _Plan:
+        key = (B, H, W, L, masked, controlnet)
         if key not in self._plans:
-            self._plans[key] = self._build_plan(B, H, W, L, masked)
+            self._plans[key] = self._build_plan(B, H, W, L, masked, controlnet)
         return self._plans[key]
 
     def stage_inputs(self, plan: _Plan, sample, timestep, encoder_hidden_states, added_cond_kwargs=None,
-                     in_scale: Optional[float] = None, encoder_attention_mask=None) -> None:
+                     in_scale: Optional[float] = None, encoder_attention_mask=None,
+                     down_block_additional_residuals=None, mid_block_additional_residual=None) -> None:
         cfg = self.cfg
+        if getattr(plan, "ctrl_down", None) is not None:
+            if len(down_block_additional_residuals) != len(plan.ctrl_down):
+                raise ValueError(f"expected {len(plan.ctrl_down)} down_block_additional_residuals, got "
+                                 f"{len(down_block_additional_residuals)}")
+            for dst, r in zip(plan.ctrl_down + [plan.ctrl_mid],
+                              list(down_block_additional_residuals) + [mid_block_additional_residual]):
+                if tuple(r.shape) != tuple(dst.shape):
+                    raise ValueError(f"ControlNet residual of shape {tuple(r.shape)}, expected {tuple(dst.shape)}")
+                dst.copy_(r, non_blocking=True)
         if plan.enc_bias is not None:
             # (1 - mask) * -10000 as an additive bias (unet_2d_condition.py:921-927)
             plan.enc_bias.copy_((1.0 - encoder_attention_mask.to(torch.float32)) * -10000.0, non_blocking=True)
@@ -719,19 +740,23 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
                 down_block_additional_residuals=None, mid_block_additional_residual=None,
                 encoder_attention_mask=None, return_dict: bool = True):
         for nm, v in (("class_labels", class_labels), ("timestep_cond", timestep_cond),
-                      ("attention_mask", attention_mask),
-                      ("down_block_additional_residuals", down_block_additional_residuals),
-                      ("mid_block_additional_residual", mid_block_additional_residual)):
+                      ("attention_mask", attention_mask)):
             if v is not None:
                 raise NotImplementedError(f"UNet2DConditionModel(mi355x): `{nm}` is not implemented on this path")
+        controlnet = down_block_additional_residuals is not None
+        if controlnet != (mid_block_additional_residual is not None):
+            raise NotImplementedError("ControlNet residuals need both `down_block_additional_residuals` and "
+                                      "`mid_block_additional_residual` (the T2I-adapter form is not implemented)")
+        ctrl = dict(down_block_additional_residuals=down_block_additional_residuals,
+                    mid_block_additional_residual=mid_block_additional_residual)
         if not self._emulated and (not sample.is_cuda or not encoder_hidden_states.is_cuda):
             raise _lib.MI355XError("inputs must be GPU tensors (no CPU fallback)")
         B, _, H, W = sample.shape
         L = encoder_hidden_states.shape[1]
-        plan = self._get_plan(B, H, W, L, encoder_attention_mask is not None)
+        plan = self._get_plan(B, H, W, L, encoder_attention_mask is not None, controlnet)
         if self._emulated:
             self.stage_inputs(plan, sample, timestep, encoder_hidden_states, added_cond_kwargs,
-                              encoder_attention_mask=encoder_attention_mask)
+                              encoder_attention_mask=encoder_attention_mask, **ctrl)
             self._run_eager(plan)
             out = plan.out.clone()
         else:
@@ -739,7 +764,7 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
             self._stream.wait_stream(cur)
             with torch.cuda.stream(self._stream):
                 self.stage_inputs(plan, sample, timestep, encoder_hidden_states, added_cond_kwargs,
-                                  encoder_attention_mask=encoder_attention_mask)
+                                  encoder_attention_mask=encoder_attention_mask, **ctrl)
                 out = self.run(plan).clone()
             cur.wait_stream(self._stream)
         if not return_dict:

@@ -261,6 +261,12 @@ class Emulator:
         _flat(y, B * Cout * H * W, torch.float32).reshape(B, Cout, H, W).copy_(o)
         return 0
 
+    def mi355x_sd_add_nchw(self, x, ldx, r, B, C, HW, stream):
+        xv = _rows(x, B * HW, C, ldx)
+        rv = _flat(r, B * C * HW, torch.float32).reshape(B, C, HW).permute(0, 2, 1).reshape(B * HW, C)
+        xv.copy_((xv.float() + rv).to(torch.bfloat16))
+        return 0
+
     def mi355x_sd_embed_tokens(self, ids, n_tokens, seq_len, tok, pos, D, out, ldo, stream):
         buf = (ctypes.c_char * (4 * n_tokens)).from_address(ids)
         idx = torch.frombuffer(buf, dtype=torch.int32, count=n_tokens).long()

@@ -370,6 +370,22 @@ def test_conv_in_out_and_silu(ops):
     assert torch.allclose(ops.axpby(a_.cuda(), b_.cuda(), c).cpu(), 0.25 * a_ - 1.5 * b_, atol=1e-6)
 
 
+@pytest.mark.parametrize("B,C,H,W,pad", [(2, 64, 8, 8, 0), (1, 320, 5, 7, 64), (3, 8, 1, 1, 8)])
+def test_add_nchw_residual(ops, B, C, H, W, pad):
+    from paddlemix_amd import _lib
+    g = torch.Generator().manual_seed(B + C + H)
+    x = bfr(torch.randn(B * H * W, C + pad, generator=g))
+    r = torch.randn(B, C, H, W, generator=g)
+    xd = dev(x)
+    view = xd[:, pad // 2: pad // 2 + C] if pad else xd
+    _lib.check(_lib.load().mi355x_sd_add_nchw(view.data_ptr(), xd.stride(0), r.cuda().data_ptr(), B, C, H * W,
+                                              torch.cuda.current_stream().cuda_stream))
+    ref = x.clone()
+    sl = slice(pad // 2, pad // 2 + C)
+    ref[:, sl] = (x[:, sl] + r.permute(0, 2, 3, 1).reshape(B * H * W, C)).to(torch.bfloat16).float()
+    assert torch.equal(xd.float().cpu(), ref)   # in place, the neighbouring channels of the wide rows untouched
+
+
 def test_errors_are_loud(ops):
     from paddlemix_amd._lib import MI355XError
     a = torch.zeros(8, 12, device="cuda", dtype=torch.bfloat16)

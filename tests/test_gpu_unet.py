@@ -120,6 +120,25 @@ def test_encoder_attention_mask_on_device():
     assert _rel(masked.cpu(), ref) < 2e-2
 
 
+def test_controlnet_residuals_on_device():
+    """down_block_additional_residuals / mid_block_additional_residual (unet_2d_condition.py:1121-1155) through the
+    in-place NCHW-residual kernel on the concat-by-construction skip slots."""
+    from paddlemix_amd.unet import UNet2DConditionModel
+    from tests.test_host_logic import _controlnet_residuals
+    cfg = MINI_XL
+    P = _bf16_params(cfg, "cpu")
+    model = UNet2DConditionModel(cfg, P)
+    sample, enc, added = _inputs(cfg, 2, 32, 32, L=77)
+    added_d = {k: v.cuda() for k, v in added.items()}
+    down, mid = _controlnet_residuals(cfg, 2, 32, 32)
+    out = model(sample.cuda(), 300, enc.cuda(), added_cond_kwargs=added_d,
+                down_block_additional_residuals=[d.cuda() for d in down], mid_block_additional_residual=mid.cuda()).sample
+    ref = U.unet_forward(P, cfg, sample, 300, enc, added_cond_kwargs=added, down_block_additional_residuals=down,
+                         mid_block_additional_residual=mid)
+    plain = model(sample.cuda(), 300, enc.cuda(), added_cond_kwargs=added_d).sample
+    assert _rel(out.cpu(), ref) < 2e-2 and _rel(out.cpu(), plain.cpu()) > 5e-2
+
+
 def test_denoise_loop_on_device_config1():
     """BASELINE config: SD pipeline loop, 1 prompt, CFG 7.5, 20 DDIM steps -- device loop vs the oracle loop
     (tiny UNet so the CPU side finishes in seconds). Stated tolerance on the final latents: rel-L2 <= 5e-2."""

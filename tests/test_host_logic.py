@@ -124,3 +124,43 @@ def test_seam_objects_refuse_cpu_tensors():
         P.update({"to_out.0.weight": torch.zeros(32, 32), "to_out.0.bias": torch.zeros(32)})
         with pytest.raises((MI355XError, ValueError)):
             Attention(P, heads=2, device="cpu")(torch.zeros(1, 8, 32))
+
+
+def _controlnet_residuals(cfg, B, H, W, seed=3):
+    """one residual per skip tensor (conv_in, every down resnet/attention output, every downsampler output) + one for
+    the mid block, shaped like a ControlNet's outputs"""
+    from paddlemix_amd.unet import normalize_config
+    g = torch.Generator().manual_seed(seed)
+    c = normalize_config(cfg)
+    boc = c["block_out_channels"]
+    shapes, h, w = [(boc[0], H, W)], H, W
+    for i in range(len(boc)):
+        shapes += [(boc[i], h, w)] * c["layers_per_block"][i]
+        if i != len(boc) - 1:
+            h, w = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+            shapes.append((boc[i], h, w))
+    down = [0.3 * torch.randn(B, cc, hh, ww, generator=g) for cc, hh, ww in shapes]
+    mid = 0.3 * torch.randn(B, boc[-1], h, w, generator=g)
+    return down, mid
+
+
+@pytest.mark.parametrize("cfg", [TINY, MINI_XL])
+def test_controlnet_residual_inputs(cfg):
+    """down_block_additional_residuals / mid_block_additional_residual (unet_2d_condition.py:1121-1155)."""
+    P = synth_unet_params(cfg, seed=1234)
+    Pb = {k: v.to(torch.bfloat16).float() if v.dim() > 1 else v for k, v in P.items()}
+    sample, enc, added = _inputs(cfg, 2, 16, 16, 7)
+    model = UNet2DConditionModel(cfg, P, _test_backend=Emulator())
+    plain = model(sample, 300, enc, added_cond_kwargs=added).sample
+    down, mid = _controlnet_residuals(cfg, 2, 16, 16)
+    ref = U.unet_forward(Pb, cfg, sample, 300, enc, added_cond_kwargs=added, down_block_additional_residuals=down,
+                         mid_block_additional_residual=mid)
+    out = model(sample, 300, enc, added_cond_kwargs=added, down_block_additional_residuals=down,
+                mid_block_additional_residual=mid).sample
+    assert _rel(out, ref) < 2e-2 and _rel(out, plain) > 5e-2     # matches the oracle and is not a no-op
+    assert torch.equal(model(sample, 300, enc, added_cond_kwargs=added).sample, plain)   # the plain plan is untouched
+    with pytest.raises(NotImplementedError):
+        model(sample, 300, enc, added_cond_kwargs=added, down_block_additional_residuals=down)
+    with pytest.raises(ValueError):
+        model(sample, 300, enc, added_cond_kwargs=added, down_block_additional_residuals=down[:-1],
+              mid_block_additional_residual=mid)
