@@ -26,40 +26,37 @@
 #include <string.h>
 
 #include "common.h"
+#include "gemm_cfg.h"
 #include "gemm_epilogue.h"
 #include "kernels.h"
 
 namespace sd {
 
-constexpr int BK = 64;
-
-template <int WAVES_M_, int WAVES_N_, int TM_, int TN_>
-struct GemmCfg {
-  static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, TM = TM_, TN = TN_;
-  static constexpr int NW = WAVES_M * WAVES_N;
-  static constexpr int THREADS = NW * 64;
-  static constexpr int BM = WAVES_M * TM * 16;
-  static constexpr int BN = WAVES_N * TN * 16;
-  static constexpr int A_TOTAL = BM / 8, W_TOTAL = BN / 8;   // 1-KiB (8 rows x 128 B) LDS-DMA pieces per K-tile
-  static constexpr int A_PIECES = (A_TOTAL + NW - 1) / NW;    // per wave (the last waves may own one fewer)
-  static constexpr int W_PIECES = (W_TOTAL + NW - 1) / NW;
-  static constexpr int LDS_BYTES = 2 * (BM + BN) * BK * 2;
-};
-using Cfg128 = GemmCfg<2, 2, 4, 4>;       // 128 x 128, 2 blocks / CU
-using Cfg256 = GemmCfg<2, 4, 8, 4>;       // 256 x 256
-using Cfg256x160 = GemmCfg<4, 2, 4, 5>;   // 256 x 160: N = 1280 -> 8 column tiles (8192 x 1280 = exactly 256 tiles)
-using Cfg256x320 = GemmCfg<2, 4, 8, 5>;   // 256 x 320: N = 640 -> 2 column tiles
-using Cfg256x320g = GemmCfg<4, 2, 4, 10>; // 256 x 320 with an even tile count per wave (GEGLU value/gate pairs)
-
 // W8 = true: W is fp8 e4m3 (OCP), 64-B LDS rows (16 rows per DMA piece, 16-B chunk index XOR (row>>2)&3 so the 8-byte
 // fragment reads are conflict free); fragments are widened to bf16 in registers (every e4m3 value is exact in bf16) and the
 // per-channel scale is applied to the fp32 accumulator in the epilogue. Halves the weight bytes a CU has to ingest.
+// wave-uniform counted wait on the VMEM queue (the count must be an immediate)
+__device__ __forceinline__ void wait_vmcnt(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // never too weak
+  }
+}
+
 template <bool CONV, class CFG, bool W8 = false, bool LN = false>
 __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_bf16_kernel(const GemmArgs p) {
   constexpr int BM = CFG::BM, BN = CFG::BN, TM = CFG::TM, TN = CFG::TN;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* As = smem;                       // [2][BM][BK] bf16, swizzled
-  unsigned char* Ws = smem + 2 * BM * BK * 2;     // [2][BN][BK] bf16 (or fp8: half of it used)
+  unsigned char* As = smem;                                 // [STAGES][BM][BK] bf16, swizzled
+  unsigned char* Ws = smem + CFG::STAGES * BM * BK * 2;     // [STAGES][BN][BK] bf16 (or fp8: half of it used)
   constexpr int W_ROW = W8 ? BK : BK * 2;         // bytes per LDS row of W
   constexpr int W_PIECES = W8 ? (BN / 16 + CFG::NW - 1) / CFG::NW : CFG::W_PIECES;
   constexpr int W_TOTAL = W8 ? BN / 16 : CFG::W_TOTAL;
@@ -176,12 +173,7 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_bf16_kernel(const GemmAr
   const int w_row0 = wn * (TN * 16) + frow;
   const int rsw = frow & 7;
 
-  issue_tile(t0 * BK, 0);
-  __syncthreads();
-
-  for (int t = t0; t < t1; ++t) {
-    const int buf = (t - t0) & 1;
-    if (t + 1 < t1) issue_tile((t + 1) * BK, buf ^ 1);
+  auto multiply = [&](const int buf) {
     const unsigned char* a = As + buf * (BM * BK * 2);
     const unsigned char* w = Ws + buf * (BN * W_ROW);
 #pragma unroll
@@ -209,7 +201,39 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_bf16_kernel(const GemmAr
         for (int tm = 0; tm < TM; ++tm)
           acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[tn], fa[tm], acc[tn][tm], 0, 0, 0);
     }
+  };
+
+  if constexpr (CFG::STAGES == 2) {
+    issue_tile(t0 * BK, 0);
     __syncthreads();
+    for (int t = t0; t < t1; ++t) {
+      const int buf = (t - t0) & 1;
+      if (t + 1 < t1) issue_tile((t + 1) * BK, buf ^ 1);
+      multiply(buf);
+      __syncthreads();
+    }
+  } else {
+    // 3-stage ring. vmcnt retires in issue order, so "at most my pieces of ONE tile outstanding" == tile t has landed
+    // (this wave's share); the barrier then publishes every wave's share and, at the same time, proves that all waves
+    // are done with tile t-1, whose stage the DMA of tile t+2 is about to overwrite.
+    int mine = 0;   // LDS-DMA instructions this wave issues per K-tile
+#pragma unroll
+    for (int i = 0; i < CFG::A_PIECES; ++i) mine += (wave + i * CFG::NW < CFG::A_TOTAL) ? 1 : 0;
+#pragma unroll
+    for (int i = 0; i < W_PIECES; ++i) mine += (wave + i * CFG::NW < W_TOTAL) ? 1 : 0;
+    issue_tile(t0 * BK, 0);
+    if (t0 + 1 < t1) issue_tile((t0 + 1) * BK, 1);
+    int stage = 0;
+    for (int t = t0; t < t1; ++t) {
+      if (t + 1 < t1) wait_vmcnt(mine);
+      else wait_vmcnt(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 2 < t1) issue_tile((t + 2) * BK, stage == 0 ? 2 : stage - 1);
+      multiply(stage);
+      stage = stage == 2 ? 0 : stage + 1;
+    }
   }
 
   if (p.splitk > 1) {   // raw partial sums -> ws[split][m][n]; the epilogue runs in splitk_reduce_kernel
@@ -253,6 +277,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
   else gemm_epilogue<1, 2>(p, acc, m_wave, n_wave, lane);
 }
 
+void launch_splitk_reduce(const GemmArgs& a, hipStream_t stream) {
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((a.M + 15) / 16, (a.N + 127) / 128), dim3(256), 0, stream, a);
+}
+
 static void* g_ws = nullptr;
 static size_t g_ws_bytes = 0;
 void set_workspace(void* ptr, size_t bytes) {
@@ -291,8 +319,7 @@ static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
   const int ntm = (a.M + CFG::BM - 1) / CFG::BM, ntn = (a.N + CFG::BN - 1) / CFG::BN;
   const int ny = a.splitk > 1 ? a.splitk : 1;
   hipLaunchKernelGGL((gemm_bf16_kernel<CONV, CFG, W8, LN>), dim3(ntm * ntn, ny), dim3(CFG::THREADS), CFG::LDS_BYTES, stream, a);
-  if (a.splitk > 1)
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((a.M + 15) / 16, (a.N + 127) / 128), dim3(256), 0, stream, a);
+  if (a.splitk > 1) launch_splitk_reduce(a, stream);
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
 
@@ -346,8 +373,13 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
   if (a.rowbias && a.rows_per_batch <= 0) return SD_ERR_INVALID;
   const int tile = pick_tile(a);
   if (tile == 128) plan_splitk(a, 128, 128);
+  if (a.rowstat && (a.conv || a.wscale || a.a_rpb || a.c_rpb || a.R || a.rowbias || a.gate || !a.wsum))
+    return SD_ERR_UNSUPPORTED;
+  if (tile == 128 || tile == 160) {   // software-pipelined loop (gemm_pipe.hip) where it applies
+    const int rc = launch_gemm_pipe(a, tile, stream);
+    if (rc != SD_ERR_UNSUPPORTED) return rc;
+  }
   if (a.rowstat) {   // LayerNorm-folded projection: own kernel instantiations (epilogue in gemm_epilogue_ln)
-    if (a.conv || a.wscale || a.a_rpb || a.c_rpb || a.R || a.rowbias || a.gate || !a.wsum) return SD_ERR_UNSUPPORTED;
     if (tile == 257 && !(a.K & 63)) return launch_gemm256(a, stream);
     if (tile == 256 || tile == 257) return launch_cfg<false, Cfg256, false, true>(a, stream);
     if (tile == 160 && !a.geglu) return launch_cfg<false, Cfg256x160, false, true>(a, stream);

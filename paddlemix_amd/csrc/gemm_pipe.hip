@@ -1,0 +1,285 @@
+// Software-pipelined bf16 MFMA GEMM / implicit-GEMM conv3x3 for gfx950: the loop the 128x128 and 256x160 tiles run.
+//
+// Same tiles, LDS image (1-KiB LDS-DMA pieces, 128-B rows, 16-B chunk index XOR (row & 7)), MFMA issue order and
+// epilogues as gemm.hip. What changes is the K loop, after reading the ISA of the generic loop: there the compiler
+// places every batch of ds_read_b128 directly in front of the MFMAs that consume it and drains lgkmcnt(0) five times
+// per K-tile (MFMA pipe ~36 % busy), and the DMA issue is ~150 instructions of 64-bit address selects and branches.
+//   * two fragment register sets: the ds_reads of k-step 1 are issued before the MFMAs of k-step 0, and -- with
+//     three LDS stages -- the k-step-0 fragments of tile t+1 before the MFMAs of k-step 1 of tile t, so every LDS
+//     read has >= 16..20 MFMAs (256..320 cycles) to land and the waits become counted lgkmcnt(N);
+//   * three LDS stages where they fit (256x160: 3 x 52 KiB): tile t+2 is in flight while t is multiplied, the only
+//     VMEM wait is a COUNTED vmcnt (this wave's pieces of one tile), one barrier per K-tile;
+//   * buffer (SRD) addressing: 32-bit per-lane offsets computed once + a scalar K offset; rows >= M / N and the conv
+//     padding are an out-of-range offset that the hardware zero-fills (no zero page, no selects). Needs K % 64 == 0 and
+//     operands below 4 GiB; launch_gemm falls back to gemm.hip otherwise.
+// Hazards (STAGES = 3). RAW: a wave waits for its own DMA pieces of tile t+1 (vmcnt) before the mid-iteration barrier
+// of iteration t; every read of tile t+1 comes after that barrier. WAR: stage (t+3) % 3 == t % 3 is re-staged at the top
+// of iteration t+1, i.e. after the mid barrier of iteration t, in front of which every wave has retired its reads of
+// tile t (lgkmcnt(0) before the barrier; the k-step-0 reads of t+1 are issued only after it).
+#include <stdlib.h>
+
+#include "common.h"
+#include "gemm_cfg.h"
+#include "gemm_epilogue.h"
+#include "kernels.h"
+
+namespace sd {
+
+#define SD_PIPE_BARRIER()                 \
+  do {                                    \
+    __builtin_amdgcn_sched_barrier(0);    \
+    __builtin_amdgcn_s_barrier();         \
+    __builtin_amdgcn_sched_barrier(0);    \
+  } while (0)
+
+// 16-byte-per-lane LDS-DMA from a buffer resource. A plain (non-template) function on purpose: called with
+// type-dependent arguments straight from the kernel template, the builtin makes the host pass of hipcc drop the kernel's
+// instantiation without a diagnostic (the device pass is fine), leaving the stub symbol undefined at load time.
+__device__ __forceinline__ void dma(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds, unsigned voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)lds, 16, voff, soff, 0, 0);
+}
+
+template <bool CONV, class CFG, bool LN>
+__global__ __launch_bounds__(CFG::THREADS, 2) void gemm_pipe_kernel(const GemmArgs p) {
+  constexpr int BM = CFG::BM, BN = CFG::BN, TM = CFG::TM, TN = CFG::TN, ST = CFG::STAGES, NW = CFG::NW;
+  constexpr int AP = CFG::A_PIECES, WP = CFG::W_PIECES;
+  constexpr int STAGE_A = BM * BK * 2, STAGE_W = BN * BK * 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* As = smem;                 // [ST][BM][128 B]
+  unsigned char* Ws = smem + ST * STAGE_A;  // [ST][BN][128 B]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / CFG::WAVES_N, wn = wave % CFG::WAVES_N;
+
+  const int ntn = (p.N + BN - 1) / BN;
+  const int ntm = (p.M + BM - 1) / BM;
+  const int lid = xcd_remap(blockIdx.x, ntm * ntn);
+  int tile_m, tile_n;
+  tile_coords(lid, ntm, ntn, tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int nt_all = p.K / BK;   // K % 64 == 0 on this path
+  int t0 = 0, t1 = nt_all;       // k-tile range of this block (split-K: blockIdx.y picks the slice)
+  if (p.splitk > 1) {
+    t0 = blockIdx.y * p.kc;
+    t1 = min(nt_all, t0 + p.kc);
+  }
+
+  // ---- LDS-DMA geometry: piece q = wave + i*NW (8 rows x 128 B); lane -> row q*8 + (lane>>3), 16-B chunk (lane&7)^row ----
+  const int sub = lane >> 3;
+  const int cg = (lane & 7) ^ sub;
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.A), 0, 0xFFFFFFE0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.W), 0, (unsigned)((size_t)p.N * p.K * 2), 0x00020000);
+  unsigned a_off[AP], w_off[WP];
+  int oy[AP], ox[AP];
+  bool a_ok[AP];
+#pragma unroll
+  for (int i = 0; i < AP; ++i) {
+    const int m = m0 + (wave + i * NW) * 8 + sub;
+    a_ok[i] = m < p.M;
+    const int mm = a_ok[i] ? m : 0;
+    if (CONV) {
+      const int hw = p.Ho * p.Wo;
+      const int b = mm / hw;
+      const int rem = mm - b * hw;
+      oy[i] = rem / p.Wo;
+      ox[i] = rem - oy[i] * p.Wo;
+      a_off[i] = (unsigned)((size_t)b * p.Hs * p.Ws * p.lda * 2);   // byte offset of the row's image
+    } else {
+      const size_t arow = p.a_rpb ? (size_t)(mm / p.a_rpb) * p.a_bstride + (size_t)(mm % p.a_rpb) * p.lda : (size_t)mm * p.lda;
+      a_off[i] = a_ok[i] ? (unsigned)((arow + cg * 8) * 2) : OOB;
+      oy[i] = ox[i] = 0;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < WP; ++i) {
+    const int n = n0 + (wave + i * NW) * 8 + sub;
+    w_off[i] = (n < p.N) ? (unsigned)(((size_t)n * p.K + cg * 8) * 2) : OOB;
+  }
+  int mine = 0;   // LDS-DMA instructions this wave issues per K-tile (the last waves may own one piece fewer)
+#pragma unroll
+  for (int i = 0; i < AP; ++i) mine += (wave + i * NW < CFG::A_TOTAL) ? 1 : 0;
+#pragma unroll
+  for (int i = 0; i < WP; ++i) mine += (wave + i * NW < CFG::W_TOTAL) ? 1 : 0;
+
+  int gtap = 0, gcch = t0 * BK + cg * 8;   // conv: running (tap, channel) of this lane's chunk
+  if (CONV) {
+    gtap = gcch / p.Cin;
+    gcch -= gtap * p.Cin;
+  }
+  int kiss = t0 * BK;   // K offset of the next tile to stage
+
+  auto issue_tile = [&](const int stage) {
+    unsigned char* a = As + stage * STAGE_A + wave * 1024;
+    unsigned char* w = Ws + stage * STAGE_W + wave * 1024;
+    if (CONV) {
+      const int ky = gtap / 3, kx = gtap - ky * 3;
+      const int Hin = p.Hs << p.up, Win = p.Ws << p.up;
+#pragma unroll
+      for (int i = 0; i < AP; ++i) {
+        const int iy = oy[i] * p.stride + ky - 1;
+        const int ix = ox[i] * p.stride + kx - 1;
+        const bool ok = a_ok[i] && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
+        const unsigned off = a_off[i] + (unsigned)(((iy >> p.up) * p.Ws + (ix >> p.up)) * p.lda + gcch) * 2u;
+        if (CFG::A_TOTAL % NW == 0 || wave + i * NW < CFG::A_TOTAL) dma(a_rsrc, a + i * (NW * 1024), ok ? off : OOB, 0);
+      }
+      gcch += BK;
+      while (gcch >= p.Cin) {
+        gcch -= p.Cin;
+        ++gtap;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < AP; ++i)
+        if (CFG::A_TOTAL % NW == 0 || wave + i * NW < CFG::A_TOTAL) dma(a_rsrc, a + i * (NW * 1024), a_off[i], kiss * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < WP; ++i)
+      if (CFG::W_TOTAL % NW == 0 || wave + i * NW < CFG::W_TOTAL) dma(w_rsrc, w + i * (NW * 1024), w_off[i], kiss * 2);
+    kiss += BK;
+  };
+  // this wave's pieces of the newest staged tile may stay in flight, everything older has landed
+  auto wait_all_but_newest = [&]() {
+    constexpr int PMAX = AP + WP;
+    if (mine == PMAX) wait_vmcnt_imm<PMAX>();
+    else if (mine == PMAX - 1) wait_vmcnt_imm<(PMAX > 1 ? PMAX - 1 : 0)>();
+    else wait_vmcnt_imm<(PMAX > 2 ? PMAX - 2 : 0)>();
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- fragments: two register sets (k-step 0 / 1 of a K-tile) ----
+  const int frow = lane & 15, fkc = lane >> 4, rsw = frow & 7;
+  const int a_row = (wm * (TM * 16) + frow) * 128, w_row = (wn * (TN * 16) + frow) * 128;
+  const int c0 = ((0 * 4 + fkc) ^ rsw) << 4, c1 = ((1 * 4 + fkc) ^ rsw) << 4;
+  bf16x8 fa[2][TM], fw[2][TN];
+  auto read_frag = [&](const int set, const int stage) {
+    const unsigned char* a = As + stage * STAGE_A + a_row + (set ? c1 : c0);
+    const unsigned char* w = Ws + stage * STAGE_W + w_row + (set ? c1 : c0);
+#pragma unroll
+    for (int i = 0; i < TN; ++i) fw[set][i] = *reinterpret_cast<const bf16x8*>(w + i * 16 * 128);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[set][i] = *reinterpret_cast<const bf16x8*>(a + i * 16 * 128);
+  };
+  auto mma = [&](const int set) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+        acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[set][tn], fa[set][tm], acc[tn][tm], 0, 0, 0);
+  };
+
+  // ---- prologue ----
+  issue_tile(0);
+  if (ST == 3 && t0 + 1 < t1) {
+    issue_tile(1);
+    wait_all_but_newest();
+  } else {
+    wait_vmcnt_imm<0>();
+  }
+  SD_PIPE_BARRIER();
+  read_frag(0, 0);
+
+  if constexpr (ST == 3) {
+    int stage = 0;
+    for (int t = t0; t < t1; ++t) {
+      const int s1 = stage == 2 ? 0 : stage + 1, s2 = stage == 0 ? 2 : stage - 1;
+      if (t + 2 < t1) issue_tile(s2);          // stage of tile t-1: free since the mid barrier of iteration t-1
+      read_frag(1, stage);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < t1) {
+        if (t + 2 < t1) wait_all_but_newest();  // own pieces of tile t+1 have landed (t+2 may stay in flight)
+        else wait_vmcnt_imm<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads of tile t retired (issued >= TM*TN MFMAs ago)
+        SD_PIPE_BARRIER();
+        read_frag(0, s1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mma(1);
+      stage = s1;
+    }
+  } else {
+    for (int t = t0; t < t1; ++t) {
+      const int stage = (t - t0) & 1;
+      if (t + 1 < t1) issue_tile(stage ^ 1);   // stage of tile t-1: free since the barrier that closed iteration t-1
+      read_frag(1, stage);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(0);
+      mma(1);
+      if (t + 1 < t1) {
+        wait_vmcnt_imm<0>();
+        SD_PIPE_BARRIER();                     // (MFMAs above consumed both fragment sets: every read of tile t retired)
+        read_frag(0, stage ^ 1);
+      }
+    }
+  }
+
+  const int m_w = m0 + wm * (TM * 16), n_w = n0 + wn * (TN * 16);
+  if (p.splitk > 1) {   // raw partial sums -> ws[split][m][n]; the epilogue runs in splitk_reduce_kernel (gemm.hip)
+    float* ws = p.ws + (size_t)blockIdx.y * p.M * p.N;
+    const int nq = (lane >> 4) * 4;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int m = m_w + tm * 16 + (lane & 15);
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int n = n_w + tn * 16 + nq;
+        if (n < p.N) *reinterpret_cast<f32x4*>(ws + (size_t)m * p.N + n) = acc[tn][tm];
+      }
+    }
+    return;
+  }
+  if constexpr (LN) gemm_epilogue_ln<TM, TN>(p, acc, m_w, n_w, lane);
+  else gemm_epilogue<TM, TN>(p, acc, m_w, n_w, lane);
+}
+
+template <bool CONV, class CFG, bool LN>
+static int launch_pipe(const GemmArgs& a, hipStream_t stream) {
+  static const bool attr_ok = [] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<CONV, CFG, LN>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES) == hipSuccess;
+  }();
+  if (!attr_ok) return SD_ERR_HIP;
+  const int ntm = (a.M + CFG::BM - 1) / CFG::BM, ntn = (a.N + CFG::BN - 1) / CFG::BN;
+  const int ny = a.splitk > 1 ? a.splitk : 1;
+  hipLaunchKernelGGL((gemm_pipe_kernel<CONV, CFG, LN>), dim3(ntm * ntn, ny), dim3(CFG::THREADS), CFG::LDS_BYTES, stream, a);
+  if (a.splitk > 1) launch_splitk_reduce(a, stream);
+  return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+}
+
+// tile: 128 | 160 (pick_tile ids). Returns SD_ERR_UNSUPPORTED when the fast path does not apply (caller falls back).
+int launch_gemm_pipe(const GemmArgs& a, int tile, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  static const bool off = getenv("MI355X_SD_NO_PIPE") != nullptr;
+  static const bool off128 = getenv("MI355X_SD_NO_PIPE128") != nullptr;   // A/B switch for the 128x128 variant
+  if (tile == 128 && off128) return SD_ERR_UNSUPPORTED;
+  if (off || a.wscale || (a.K & 63) || (tile != 128 && tile != 160) || (tile == 160 && a.geglu)) return SD_ERR_UNSUPPORTED;
+  if (a.conv && (a.Cin & 7)) return SD_ERR_UNSUPPORTED;
+  // 32-bit buffer offsets: every addressed byte of A and W must sit below 4 GiB - 64 KiB
+  const size_t lim = 0xFFFF0000ull;
+  size_t a_ext;
+  if (a.conv) a_ext = (size_t)(a.M / ((size_t)a.Ho * a.Wo)) * a.Hs * a.Ws * a.lda * 2;
+  else if (a.a_rpb) a_ext = ((size_t)((a.M - 1) / a.a_rpb) * a.a_bstride + (size_t)(a.a_rpb - 1) * a.lda + a.K) * 2;
+  else a_ext = ((size_t)(a.M - 1) * a.lda + a.K) * 2;
+  if (a_ext >= lim || (size_t)a.N * a.K * 2 >= lim) return SD_ERR_UNSUPPORTED;
+  const bool ln = a.rowstat != nullptr;
+  if (tile == 160) {
+    if (ln) return launch_pipe<false, Cfg256x160s3, true>(a, stream);
+    return a.conv ? launch_pipe<true, Cfg256x160s3, false>(a, stream) : launch_pipe<false, Cfg256x160s3, false>(a, stream);
+  }
+  if (ln) return launch_pipe<false, Cfg128, true>(a, stream);
+  return a.conv ? launch_pipe<true, Cfg128, false>(a, stream) : launch_pipe<false, Cfg128, false>(a, stream);
+}
+
+}  // namespace sd

@@ -48,7 +48,8 @@ struct GemmArgs {
 // caller-owned scratch for split-K partial sums (mi355x_sd_set_workspace); no workspace -> no split-K
 void set_workspace(void* ptr, size_t bytes);
 int launch_gemm(const GemmArgs& a, hipStream_t stream);
-int launch_gemm256(const GemmArgs& a, hipStream_t stream);   // phased 256x256 kernel (gemm256.hip); args pre-validated
+int launch_gemm256(const GemmArgs& a, hipStream_t stream);
+void launch_splitk_reduce(const GemmArgs& a, hipStream_t stream);   // sums a.splitk slices of a.ws + epilogue (gemm.hip)   // phased 256x256 kernel (gemm256.hip); args pre-validated
 
 struct AttnArgs {
   const bf16 *Q, *K, *V;
