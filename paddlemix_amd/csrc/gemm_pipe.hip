@@ -12,10 +12,10 @@
 //   * buffer (SRD) addressing: 32-bit per-lane offsets computed once + a scalar K offset; rows >= M / N and the conv
 //     padding are an out-of-range offset that the hardware zero-fills (no zero page, no selects). Needs K % 64 == 0 and
 //     operands below 4 GiB; launch_gemm falls back to gemm.hip otherwise.
-// Hazards (STAGES = 3). RAW: a wave waits for its own DMA pieces of tile t+1 (vmcnt) before the mid-iteration barrier
-// of iteration t; every read of tile t+1 comes after that barrier. WAR: stage (t+3) % 3 == t % 3 is re-staged at the top
-// of iteration t+1, i.e. after the mid barrier of iteration t, in front of which every wave has retired its reads of
-// tile t (lgkmcnt(0) before the barrier; the k-step-0 reads of t+1 are issued only after it).
+// Hazards. RAW: a wave waits for its own DMA pieces of tile t+1 (vmcnt) before the mid-iteration barrier of iteration
+// t; every read of tile t+1 comes after that barrier. WAR: the stage of tile t is re-staged at the top of iteration
+// t+1 (as tile t+3 with three stages, t+2 with two), i.e. after the mid barrier of iteration t, in front of which every
+// wave has retired its reads of tile t (lgkmcnt(0) before the barrier; the k-step-0 reads of t+1 are issued after it).
 #include <stdlib.h>
 
 #include "common.h"
@@ -177,9 +177,13 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_pipe_kernel(const GemmAr
         acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[set][tn], fa[set][tm], acc[tn][tm], 0, 0, 0);
   };
 
-  // ---- prologue ----
+  // ---- K loop: AHEAD = ST - 1 tiles staged beyond the one being multiplied ----
+  // Explicit waits use the s_waitcnt BUILTIN (0xC07F = lgkmcnt(0) only), not inline asm: the compiler's own waitcnt
+  // insertion sees them and therefore emits no conservative lgkmcnt(0) in front of the MFMA batches (checked in the ISA:
+  // barrier, 9 ds_read, 20 MFMA, lgkmcnt(0), 7 DMA, 9 ds_read, 20 MFMA, waits, barrier).
+  constexpr int AHEAD = ST - 1;
   issue_tile(0);
-  if (ST == 3 && t0 + 1 < t1) {
+  if (AHEAD == 2 && t0 + 1 < t1) {
     issue_tile(1);
     wait_all_but_newest();
   } else {
@@ -187,41 +191,27 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_pipe_kernel(const GemmAr
   }
   SD_PIPE_BARRIER();
   read_frag(0, 0);
-
-  if constexpr (ST == 3) {
-    int stage = 0;
-    for (int t = t0; t < t1; ++t) {
-      const int s1 = stage == 2 ? 0 : stage + 1, s2 = stage == 0 ? 2 : stage - 1;
-      if (t + 2 < t1) issue_tile(s2);          // stage of tile t-1: free since the mid barrier of iteration t-1
-      read_frag(1, stage);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (t + 1 < t1) {
-        if (t + 2 < t1) wait_all_but_newest();  // own pieces of tile t+1 have landed (t+2 may stay in flight)
-        else wait_vmcnt_imm<0>();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads of tile t retired (issued >= TM*TN MFMAs ago)
-        SD_PIPE_BARRIER();
-        read_frag(0, s1);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      mma(1);
-      stage = s1;
+  int stage = 0;
+  for (int t = t0; t < t1; ++t) {
+    const int s1 = stage == ST - 1 ? 0 : stage + 1;          // stage of tile t+1
+    const int s_new = ST == 3 ? (stage == 0 ? 2 : stage - 1) : s1;   // stage the tile t+AHEAD goes to
+    __builtin_amdgcn_s_waitcnt(0xC07F);        // k-step-0 fragments of tile t (issued under the previous MFMA batch)
+    // re-staged stage: last read as tile t-1 (ST = 3) / t-1 (ST = 2), retired before the mid barrier of iteration t-1
+    if (t + AHEAD < t1) issue_tile(s_new);
+    read_frag(1, stage);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);        // k-step-1 fragments (issued TM*TN MFMAs ago): every read of tile t retired
+    if (t + 1 < t1) {
+      if (AHEAD == 2 && t + 2 < t1) wait_all_but_newest();   // own pieces of tile t+1 landed, t+2 may stay in flight
+      else wait_vmcnt_imm<0>();
+      SD_PIPE_BARRIER();                       // publishes tile t+1; every wave is done reading tile t
+      read_frag(0, s1);
     }
-  } else {
-    for (int t = t0; t < t1; ++t) {
-      const int stage = (t - t0) & 1;
-      if (t + 1 < t1) issue_tile(stage ^ 1);   // stage of tile t-1: free since the barrier that closed iteration t-1
-      read_frag(1, stage);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(0);
-      mma(1);
-      if (t + 1 < t1) {
-        wait_vmcnt_imm<0>();
-        SD_PIPE_BARRIER();                     // (MFMAs above consumed both fragment sets: every read of tile t retired)
-        read_frag(0, stage ^ 1);
-      }
-    }
+    __builtin_amdgcn_sched_barrier(0);
+    mma(1);
+    stage = s1;
   }
 
   const int m_w = m0 + wm * (TM * 16), n_w = n0 + wn * (TN * 16);
