@@ -375,7 +375,7 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
   if (tile == 128) plan_splitk(a, 128, 128);
   if (a.rowstat && (a.conv || a.wscale || a.a_rpb || a.c_rpb || a.R || a.rowbias || a.gate || !a.wsum))
     return SD_ERR_UNSUPPORTED;
-  if (tile == 128 || tile == 160) {   // software-pipelined loop (gemm_pipe.hip) where it applies
+  {   // software-pipelined loop (gemm_pipe.hip) where it applies (128 / 160 tiles; 256 only as an experiment)
     const int rc = launch_gemm_pipe(a, tile, stream);
     if (rc != SD_ERR_UNSUPPORTED) return rc;
   }

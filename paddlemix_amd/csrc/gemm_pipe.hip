@@ -254,7 +254,9 @@ int launch_gemm_pipe(const GemmArgs& a, int tile, void* stream_) {
   static const bool off = getenv("MI355X_SD_NO_PIPE") != nullptr;
   static const bool off128 = getenv("MI355X_SD_NO_PIPE128") != nullptr;   // A/B switch for the 128x128 variant
   if (tile == 128 && off128) return SD_ERR_UNSUPPORTED;
-  if (off || a.wscale || (a.K & 63) || (tile != 128 && tile != 160) || (tile == 160 && a.geglu)) return SD_ERR_UNSUPPORTED;
+  static const bool on256 = getenv("MI355X_SD_PIPE256") != nullptr;   // experiment: pipelined 256x256 instead of the phased kernel
+  if (off || a.wscale || (a.K & 63) || (tile == 160 && a.geglu)) return SD_ERR_UNSUPPORTED;
+  if (tile != 128 && tile != 160 && !(on256 && (tile == 256 || tile == 257))) return SD_ERR_UNSUPPORTED;
   if (a.conv && (a.Cin & 7)) return SD_ERR_UNSUPPORTED;
   // 32-bit buffer offsets: every addressed byte of A and W must sit below 4 GiB - 64 KiB
   const size_t lim = 0xFFFF0000ull;
@@ -264,6 +266,10 @@ int launch_gemm_pipe(const GemmArgs& a, int tile, void* stream_) {
   else a_ext = ((size_t)(a.M - 1) * a.lda + a.K) * 2;
   if (a_ext >= lim || (size_t)a.N * a.K * 2 >= lim) return SD_ERR_UNSUPPORTED;
   const bool ln = a.rowstat != nullptr;
+  if (tile == 256 || tile == 257) {
+    if (ln) return launch_pipe<false, Cfg256, true>(a, stream);
+    return a.conv ? launch_pipe<true, Cfg256, false>(a, stream) : launch_pipe<false, Cfg256, false>(a, stream);
+  }
   if (tile == 160) {
     if (ln) return launch_pipe<false, Cfg256x160s3, true>(a, stream);
     return a.conv ? launch_pipe<true, Cfg256x160s3, false>(a, stream) : launch_pipe<false, Cfg256x160s3, false>(a, stream);
