@@ -6,9 +6,10 @@ namespace sd {
 
 constexpr int BK = 64;
 
-template <int WAVES_M_, int WAVES_N_, int TM_, int TN_, int STAGES_ = 2>
+template <int WAVES_M_, int WAVES_N_, int TM_, int TN_, int STAGES_ = 2, int MIN_WAVES_ = 2>
 struct GemmCfg {
   static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, TM = TM_, TN = TN_, STAGES = STAGES_;
+  static constexpr int MIN_WAVES = MIN_WAVES_;   // __launch_bounds__ occupancy hint (waves per SIMD)
   static constexpr int NW = WAVES_M * WAVES_N;
   static constexpr int THREADS = NW * 64;
   static constexpr int BM = WAVES_M * TM * 16;

@@ -40,7 +40,7 @@ __device__ __forceinline__ void dma(__amdgpu_buffer_rsrc_t rsrc, unsigned char* 
 }
 
 template <bool CONV, class CFG, bool LN>
-__global__ __launch_bounds__(CFG::THREADS, 2) void gemm_pipe_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES) void gemm_pipe_kernel(const GemmArgs p) {
   constexpr int BM = CFG::BM, BN = CFG::BN, TM = CFG::TM, TN = CFG::TN, ST = CFG::STAGES, NW = CFG::NW;
   constexpr int AP = CFG::A_PIECES, WP = CFG::W_PIECES;
   constexpr int STAGE_A = BM * BK * 2, STAGE_W = BN * BK * 2;
@@ -156,10 +156,13 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_pipe_kernel(const GemmAr
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- fragments: two register sets (k-step 0 / 1 of a K-tile) ----
   const int frow = lane & 15, fkc = lane >> 4, rsw = frow & 7;
   const int a_row = (wm * (TM * 16) + frow) * 128, w_row = (wn * (TN * 16) + frow) * 128;
   const int c0 = ((0 * 4 + fkc) ^ rsw) << 4, c1 = ((1 * 4 + fkc) ^ rsw) << 4;
+  constexpr bool STREAM = (TM + TN) > 10;   // two full fragment sets would not fit next to the accumulators
+
+  if constexpr (!STREAM) {
+  // ---- fragments: two register sets (k-step 0 / 1 of a K-tile) ----
   bf16x8 fa[2][TM], fw[2][TN];
   auto read_frag = [&](const int set, const int stage) {
     const unsigned char* a = As + stage * STAGE_A + a_row + (set ? c1 : c0);
@@ -213,6 +216,62 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_pipe_kernel(const GemmAr
     mma(1);
     stage = s1;
   }
+  } else {
+  // ---- streaming variant (256x320 tiles: 160 accumulator registers) ----
+  // The smaller operand of a k-step is HELD (two sets, k-step 0 / 1), the larger one STREAMS through a (Q+1)-slot
+  // register queue: step j of the 2*SN steps of a K-tile multiplies one streamed fragment with the HN held ones
+  // (HN MFMAs) and issues the ds_read of the fragment of step j+Q, so an LDS read has Q*HN MFMAs (>= 192 cycles) to land.
+  // Two LDS stages: the DMA of tile t+1 is issued at the top of iteration t and awaited Q steps before its end (85 % of
+  // an iteration of lead); there one barrier publishes tile t+1 and proves tile t fully read, after which the queue and
+  // the held set roll over into tile t+1 without a bubble.
+  static_assert(ST == 2, "streaming loop is written for two LDS stages");
+  constexpr bool HOLD_A = TM <= TN;
+  constexpr int HN = HOLD_A ? TM : TN, SN = HOLD_A ? TN : TM, Q = 3, QN = Q + 1, STEPS = 2 * SN;
+  const int h_row = HOLD_A ? a_row : w_row, s_row = HOLD_A ? w_row : a_row;
+  bf16x8 hold[2][HN], qf[QN];
+  auto read_hold = [&](const int set, const int stage) {
+    const unsigned char* b = (HOLD_A ? As + stage * STAGE_A : Ws + stage * STAGE_W) + h_row + (set ? c1 : c0);
+#pragma unroll
+    for (int i = 0; i < HN; ++i) hold[set][i] = *reinterpret_cast<const bf16x8*>(b + i * 16 * 128);
+  };
+  auto read_stream = [&](const int slot, const int stage, const int ks, const int s) {
+    const unsigned char* b = (HOLD_A ? Ws + stage * STAGE_W : As + stage * STAGE_A) + s_row + (ks ? c1 : c0);
+    qf[slot] = *reinterpret_cast<const bf16x8*>(b + s * 16 * 128);
+  };
+
+  issue_tile(0);
+  wait_vmcnt_imm<0>();
+  SD_PIPE_BARRIER();
+  read_hold(0, 0);
+#pragma unroll
+  for (int j = 0; j < Q; ++j) read_stream(j % QN, 0, j / SN, j % SN);
+  for (int t = t0; t < t1; ++t) {
+    const int cur = (t - t0) & 1, nxt = cur ^ 1;
+    const bool more = t + 1 < t1;
+    if (more) issue_tile(nxt);   // stage of tile t-1: every wave passed the roll-over barrier of iteration t-1
+#pragma unroll
+    for (int j = 0; j < STEPS; ++j) {
+      const int ks = j / SN, s = j % SN;
+      if (j == 0) read_hold(1, cur);
+      if (j == STEPS - Q && more) {
+        wait_vmcnt_imm<0>();                    // own pieces of tile t+1 (issued STEPS - Q steps ago)
+        __builtin_amdgcn_s_waitcnt(0xC07F);     // every read of tile t retired
+        SD_PIPE_BARRIER();
+        read_hold(0, nxt);
+      }
+      const int jr = j + Q;
+      if (jr < STEPS) read_stream(jr % QN, cur, jr / SN, jr % SN);
+      else if (more) read_stream(jr % QN, nxt, (jr - STEPS) / SN, (jr - STEPS) % SN);
+      __builtin_amdgcn_sched_barrier(0);   // keep the read Q steps ahead of its use (the scheduler would sink it)
+#pragma unroll
+      for (int h = 0; h < HN; ++h) {
+        if (HOLD_A) acc[s][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j % QN], hold[ks][h], acc[s][h], 0, 0, 0);
+        else acc[h][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hold[ks][h], qf[j % QN], acc[h][s], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  }
 
   const int m_w = m0 + wm * (TM * 16), n_w = n0 + wn * (TN * 16);
   if (p.splitk > 1) {   // raw partial sums -> ws[split][m][n]; the epilogue runs in splitk_reduce_kernel (gemm.hip)
@@ -256,7 +315,9 @@ int launch_gemm_pipe(const GemmArgs& a, int tile, void* stream_) {
   if (tile == 128 && off128) return SD_ERR_UNSUPPORTED;
   static const bool on256 = getenv("MI355X_SD_PIPE256") != nullptr;   // experiment: pipelined 256x256 instead of the phased kernel
   if (off || a.wscale || (a.K & 63) || (tile == 160 && a.geglu)) return SD_ERR_UNSUPPORTED;
-  if (tile != 128 && tile != 160 && !(on256 && (tile == 256 || tile == 257))) return SD_ERR_UNSUPPORTED;
+  static const bool off320 = getenv("MI355X_SD_NO_PIPE320") != nullptr;   // A/B switch for the streaming 256x320 variants
+  if (tile == 320 && (off320 || (a.conv && a.geglu))) return SD_ERR_UNSUPPORTED;
+  if (tile != 128 && tile != 160 && tile != 320 && !(on256 && (tile == 256 || tile == 257))) return SD_ERR_UNSUPPORTED;
   if (a.conv && (a.Cin & 7)) return SD_ERR_UNSUPPORTED;
   // 32-bit buffer offsets: every addressed byte of A and W must sit below 4 GiB - 64 KiB
   const size_t lim = 0xFFFF0000ull;
@@ -269,6 +330,11 @@ int launch_gemm_pipe(const GemmArgs& a, int tile, void* stream_) {
   if (tile == 256 || tile == 257) {
     if (ln) return launch_pipe<false, Cfg256, true>(a, stream);
     return a.conv ? launch_pipe<true, Cfg256, false>(a, stream) : launch_pipe<false, Cfg256, false>(a, stream);
+  }
+  if (tile == 320) {
+    if (a.geglu) return ln ? launch_pipe<false, Cfg256x320g, true>(a, stream) : launch_pipe<false, Cfg256x320g, false>(a, stream);
+    if (ln) return launch_pipe<false, Cfg256x320, true>(a, stream);
+    return a.conv ? launch_pipe<true, Cfg256x320, false>(a, stream) : launch_pipe<false, Cfg256x320, false>(a, stream);
   }
   if (tile == 160) {
     if (ln) return launch_pipe<false, Cfg256x160s3, true>(a, stream);
