@@ -317,7 +317,9 @@ int launch_gemm_pipe(const GemmArgs& a, int tile, void* stream_) {
   if (off || a.wscale || (a.K & 63) || (tile == 160 && a.geglu)) return SD_ERR_UNSUPPORTED;
   static const bool off320 = getenv("MI355X_SD_NO_PIPE320") != nullptr;   // A/B switch for the streaming 256x320 variants
   if (tile == 320 && (off320 || (a.conv && a.geglu))) return SD_ERR_UNSUPPORTED;
-  if (tile != 128 && tile != 160 && tile != 320 && !(on256 && (tile == 256 || tile == 257))) return SD_ERR_UNSUPPORTED;
+  // 256x256: the phased kernel (gemm256.hip) stays the default where it can run (id 257); id 256 is what pick_tile
+  // returns when it cannot (A row remap of the MMDiT output projections) and takes the pipelined loop here
+  if (tile != 128 && tile != 160 && tile != 320 && tile != 256 && !(on256 && tile == 257)) return SD_ERR_UNSUPPORTED;
   if (a.conv && (a.Cin & 7)) return SD_ERR_UNSUPPORTED;
   // 32-bit buffer offsets: every addressed byte of A and W must sit below 4 GiB - 64 KiB
   const size_t lim = 0xFFFF0000ull;
