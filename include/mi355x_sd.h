@@ -152,13 +152,24 @@ int mi355x_sd_add_nchw(void* x, int ldx, const float* r_nchw, int B, int C, int6
 
 /* ---- CLIP text encoder (PPD/transformers/clip/modeling.py) ----
  * CLIPTextEmbeddings.forward (:214-231): out[i][:] = bf16(token_table[ids[i]] + position_table[i % seq_len]); tables bf16
- * [V][D] / [P][D], ids int32 in device memory (range-checked by the caller), D % 8 == 0. */
+ * [V][D] / [P][D], ids int32 in device memory (range-checked by the caller), D % 8 == 0. position_table may be NULL
+ * (token embedding only: T5Stack.embed_tokens, PPD/transformers/t5/modeling.py:981-983). */
 int mi355x_sd_embed_tokens(const int32_t* ids, int64_t n_tokens, int seq_len, const void* token_table,
                            const void* position_table, int D, void* out, int ldo, void* stream);
 /* y = act(x) on n bf16 elements (n % 8 == 0): kind 0 quick_gelu (x sigmoid(1.702 x), CLIPMLP :338-350 with
  * hidden_act="quick_gelu"), 1 gelu (erf), 2 silu. The rest of CLIPEncoderLayer (:353-400) is mi355x_sd_layernorm,
  * mi355x_sd_linear (bias / residual epilogues) and mi355x_sd_sdpa with the causal mask as its additive bias. */
 int mi355x_sd_activation(const void* x, void* y, int64_t n, int kind, void* stream);
+
+/* ---- T5 encoder (the third text encoder of SD3; PPD/transformers/t5/modeling.py) ----
+ * T5LayerNorm (:86-108): y = weight * x * rsqrt(mean(x^2) + eps) -- RMS norm, fp32 statistics, no bias; C <= 4096. */
+int mi355x_sd_rmsnorm(const void* x, int rows, int C, int ldx, const float* weight, float eps, void* y, int ldy,
+                      void* stream);
+/* T5DenseGatedActDense (:164-167) on the fused [wi_0 | wi_1] projection x [rows, 2F]: y[r][j] = act(x[r][j]) * x[r][F+j];
+ * kind 0 quick_gelu, 1 gelu (erf), 2 silu, 3 gelu_new (tanh approximation; T5 v1.1 "gated-gelu"). F % 8 == 0.
+ * T5Attention (:308-424) is mi355x_sd_linear (no bias) + mi355x_sd_sdpa with scale 1.0 and the relative position bias
+ * [1, heads, S, S] (compute_bias :293-306) as the additive mask. */
+int mi355x_sd_gated_activation(const void* x, int ldx, void* y, int ldy, int64_t rows, int F, int kind, void* stream);
 
 /* ---- AutoencoderKL decoder (PPD/models/autoencoder_kl.py:288-333, PPD/models/vae.py:182-343) ----
  * post_quant_conv (autoencoder_kl.py:121,292-293): 1x1 convolution of a small NCHW fp32 tensor, Cin, Cout <= 16,

@@ -51,6 +51,8 @@ SIGNATURES = {
     "mi355x_sd_copy_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p]),
     "mi355x_sd_add_nchw": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int64, c_void_p]),
     "mi355x_sd_embed_tokens": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "mi355x_sd_rmsnorm": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_int, c_void_p]),
+    "mi355x_sd_gated_activation": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),
     "mi355x_sd_activation": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "mi355x_sd_conv1x1_nchw": (c_int, [c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64,
                                          c_void_p]),

@@ -267,9 +267,21 @@ int mi355x_sd_add_nchw(void* x, int ldx, const float* r_nchw, int B, int C, int6
 
 int mi355x_sd_embed_tokens(const int32_t* ids, int64_t n_tokens, int seq_len, const void* token_table,
                            const void* position_table, int D, void* out, int ldo, void* stream) {
-  if (!ids || !token_table || !position_table || !out) return fail(SD_ERR_INVALID, "mi355x_sd_embed_tokens: null pointer");
+  if (!ids || !token_table || !out) return fail(SD_ERR_INVALID, "mi355x_sd_embed_tokens: null pointer");
   return finish(launch_embed_tokens(ids, (long)n_tokens, seq_len, (const bf16*)token_table, (const bf16*)position_table, D,
                                     (bf16*)out, ldo, S(stream)), "mi355x_sd_embed_tokens");
+}
+
+int mi355x_sd_rmsnorm(const void* x, int rows, int C, int ldx, const float* weight, float eps, void* y, int ldy,
+                      void* stream) {
+  if (!x || !weight || !y) return fail(SD_ERR_INVALID, "mi355x_sd_rmsnorm: null pointer");
+  return finish(launch_rmsnorm((const bf16*)x, rows, C, ldx, weight, eps, (bf16*)y, ldy, S(stream)), "mi355x_sd_rmsnorm");
+}
+
+int mi355x_sd_gated_activation(const void* x, int ldx, void* y, int ldy, int64_t rows, int F, int kind, void* stream) {
+  if (!x || !y) return fail(SD_ERR_INVALID, "mi355x_sd_gated_activation: null pointer");
+  return finish(launch_gated_activation((const bf16*)x, ldx, (bf16*)y, ldy, (long)rows, F, kind, S(stream)),
+                "mi355x_sd_gated_activation");
 }
 
 int mi355x_sd_activation(const void* x, void* y, int64_t n, int kind, void* stream) {

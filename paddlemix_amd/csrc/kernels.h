@@ -91,6 +91,9 @@ int launch_conv_out3x3(const bf16* x, int ldx, const bf16* w, const float* bias,
 int launch_add_nchw(bf16* x, int ldx, const float* r, int B, int C, long HW, hipStream_t stream);
 int launch_embed_tokens(const int* ids, long n_tokens, int seq_len, const bf16* tok, const bf16* pos, int D, bf16* out,
                         int ldo, hipStream_t stream);
+int launch_gated_activation(const bf16* x, int ldx, bf16* y, int ldy, long rows, int F, int kind, hipStream_t stream);
+int launch_rmsnorm(const bf16* x, int rows, int C, int ldx, const float* weight, float eps, bf16* y, int ldy,
+                   hipStream_t stream);
 int launch_activation(const bf16* x, bf16* y, long n, int kind, hipStream_t stream);
 int launch_conv1x1_nchw(const float* x, float in_scale, const bf16* w, const float* bias, float* y, int B, int Cin,
                         int Cout, long HW, hipStream_t stream);

@@ -236,7 +236,8 @@ __global__ void embed_tokens_kernel(const int* __restrict__ ids, long n_tokens, 
     const long t = id / cv;
     const int cc = (int)(id - t * cv);
     const u32x4 ra = *reinterpret_cast<const u32x4*>(tok + (size_t)ids[t] * D + cc * 8);
-    const u32x4 rb = *reinterpret_cast<const u32x4*>(pos + (size_t)(t % seq_len) * D + cc * 8);
+    u32x4 rb = {0u, 0u, 0u, 0u};   // pos == nullptr: token embedding only (T5)
+    if (pos) rb = *reinterpret_cast<const u32x4*>(pos + (size_t)(t % seq_len) * D + cc * 8);
     const bf16x8 a = *reinterpret_cast<const bf16x8*>(&ra), b = *reinterpret_cast<const bf16x8*>(&rb);
     u32x4 pk = {pack_bf16((float)a[0] + (float)b[0], (float)a[1] + (float)b[1]),
                 pack_bf16((float)a[2] + (float)b[2], (float)a[3] + (float)b[3]),
@@ -272,6 +273,38 @@ __global__ void activation_kernel(const bf16* __restrict__ x, bf16* __restrict__
     u32x4 pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7])};
     reinterpret_cast<u32x4*>(y)[i] = pk;
   }
+}
+
+// T5DenseGatedActDense (PPD/transformers/t5/modeling.py:164-167): y[r][j] = act(x[r][j]) * x[r][F + j] on the fused
+// [wi_0 | wi_1] projection; kind as in activation_kernel plus 3 = gelu_new (tanh approximation, T5 v1.1 "gated-gelu").
+__global__ void gated_activation_kernel(const bf16* __restrict__ x, int ldx, bf16* __restrict__ y, int ldy, long rows, int F8,
+                                        int F, int kind) {
+  const long total = rows * F8;
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long)gridDim.x * blockDim.x) {
+    const long r = id / F8;
+    const int cc = (int)(id - r * F8);
+    const u32x4 ra = *reinterpret_cast<const u32x4*>(x + (size_t)r * ldx + cc * 8);
+    const u32x4 rb = *reinterpret_cast<const u32x4*>(x + (size_t)r * ldx + F + cc * 8);
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(&ra), b = *reinterpret_cast<const bf16x8*>(&rb);
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float f = (float)a[j];
+      const float g = kind == 0 ? f / (1.0f + __expf(-1.702f * f)) : kind == 1 ? gelu_erf_f(f) : kind == 2 ? silu_f(f) : gelu_tanh_f(f);
+      o[j] = g * (float)b[j];
+    }
+    u32x4 pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7])};
+    *reinterpret_cast<u32x4*>(y + (size_t)r * ldy + cc * 8) = pk;
+  }
+}
+
+int launch_gated_activation(const bf16* x, int ldx, bf16* y, int ldy, long rows, int F, int kind, hipStream_t stream) {
+  if (rows <= 0 || F <= 0 || kind < 0 || kind > 3) return SD_ERR_INVALID;
+  if ((F & 7) || (ldx & 7) || (ldy & 7)) return SD_ERR_UNSUPPORTED;
+  long nb = (rows * (F >> 3) + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(gated_activation_kernel, dim3((unsigned)nb), dim3(256), 0, stream, x, ldx, y, ldy, rows, F >> 3, F, kind);
+  return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
 
 int launch_activation(const bf16* x, bf16* y, long n, int kind, hipStream_t stream) {

@@ -399,6 +399,77 @@ int launch_row_stats(const bf16* x, int rows, int C, int ldx, float eps, float* 
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
 
+// T5LayerNorm (RMSNorm; PPD/transformers/t5/modeling.py:86-108): y = weight * x * rsqrt(mean(x^2) + eps), no mean
+// subtraction, no bias; statistics in fp32. Same wave layout as layernorm_kernel (a wave owns ROWS rows).
+template <int NCH, int ROWS>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16* __restrict__ x, int rows, int C, int ldx,
+                                                      const float* __restrict__ weight, float eps, bf16* __restrict__ y,
+                                                      int ldy) {
+  const int lane = threadIdx.x & 63;
+  const int wave_g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * (blockDim.x >> 6);
+  const int cv = C >> 3;
+  const float invC = 1.0f / (float)C;
+  for (int row0 = wave_g * ROWS; row0 < rows; row0 += nwaves * ROWS) {
+    float v[ROWS][NCH][8], ss[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const bf16* xr = x + (size_t)min(row0 + r, rows - 1) * ldx;
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int cc = lane + 64 * i;
+        u32x4 raw = {0u, 0u, 0u, 0u};
+        if (cc < cv) raw = *reinterpret_cast<const u32x4*>(xr + cc * 8);
+        const bf16x8 t = *reinterpret_cast<const bf16x8*>(&raw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          v[r][i][j] = (float)t[j];
+          q = __builtin_fmaf(v[r][i][j], v[r][i][j], q);
+        }
+      }
+      ss[r] = q;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) ss[r] += __shfl_xor(ss[r], o, 64);
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      if (row0 + r >= rows) continue;
+      const float rstd = rsqrtf(ss[r] * invC + eps);
+      bf16* yr = y + (size_t)(row0 + r) * ldy;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int cc = lane + 64 * i;
+        if (cc < cv) {
+          float o8[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o8[j] = v[r][i][j] * rstd * weight[cc * 8 + j];
+          u32x4 pk = {pack_bf16(o8[0], o8[1]), pack_bf16(o8[2], o8[3]), pack_bf16(o8[4], o8[5]), pack_bf16(o8[6], o8[7])};
+          *reinterpret_cast<u32x4*>(yr + cc * 8) = pk;
+        }
+      }
+    }
+  }
+}
+
+int launch_rmsnorm(const bf16* x, int rows, int C, int ldx, const float* weight, float eps, bf16* y, int ldy,
+                   hipStream_t stream) {
+  if (rows <= 0 || C <= 0) return SD_ERR_INVALID;
+  if ((C & 7) || (ldx & 7) || (ldy & 7) || C > 4096) return SD_ERR_UNSUPPORTED;
+  const int cv = C >> 3;
+  int blocks = (rows + 7) / 8;
+  if (blocks > 2048) blocks = 2048;
+#define SD_RMS_LAUNCH(NCH) \
+  hipLaunchKernelGGL((rmsnorm_kernel<NCH, 2>), dim3(blocks), dim3(256), 0, stream, x, rows, C, ldx, weight, eps, y, ldy)
+  if (cv <= 128) SD_RMS_LAUNCH(2);
+  else if (cv <= 256) SD_RMS_LAUNCH(4);
+  else SD_RMS_LAUNCH(8);
+#undef SD_RMS_LAUNCH
+  return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+}
+
 // Adaptive LayerNorm of the MMDiT blocks: y = LN(x) * (1 + scale[b]) + shift[b], LN without affine, b = row / rows_per_batch.
 // Reference: AdaLayerNormZero.forward (ppdiffusers/ppdiffusers/models/normalization.py:72-86), AdaLayerNormContinuous
 // (:190-202), the modulated norm2 of JointTransformerBlock (attention.py:184-185) and the fused Triton op

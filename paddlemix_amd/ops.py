@@ -391,3 +391,25 @@ def activation(x: Tensor, kind: str) -> Tensor:
     y = torch.empty_like(x)
     check(lib.mi355x_sd_activation(x.data_ptr(), y.data_ptr(), x.numel(), kinds[kind], _stream()))
     return y
+
+
+def rms_norm(x: Tensor, weight: Tensor, eps: float = 1e-6) -> Tensor:
+    """T5LayerNorm: weight * x * rsqrt(mean(x^2) + eps) on bf16 rows."""
+    lib = _lib.load()
+    ldx = _rows(x, "x")
+    rows, C = x.shape
+    out = torch.empty((rows, C), device=x.device, dtype=torch.bfloat16)
+    check(lib.mi355x_sd_rmsnorm(x.data_ptr(), rows, C, ldx, _vec(weight, C, "weight").data_ptr(), float(eps), out.data_ptr(),
+                                C, _stream()))
+    return out
+
+
+def gated_activation(x: Tensor, kind: str = "gelu_new") -> Tensor:
+    """[rows, 2F] -> [rows, F]: act(x[:, :F]) * x[:, F:]."""
+    lib = _lib.load()
+    kinds = {"quick_gelu": 0, "gelu": 1, "silu": 2, "gelu_new": 3}
+    ldx = _rows(x, "x")
+    rows, F2 = x.shape
+    out = torch.empty((rows, F2 // 2), device=x.device, dtype=torch.bfloat16)
+    check(lib.mi355x_sd_gated_activation(x.data_ptr(), ldx, out.data_ptr(), F2 // 2, rows, F2 // 2, kinds[kind], _stream()))
+    return out

@@ -272,8 +272,23 @@ class Emulator:
         idx = torch.frombuffer(buf, dtype=torch.int32, count=n_tokens).long()
         V = int(idx.max()) + 1
         t = _rows(tok, V, D, D).float()[idx]
-        p_ = _rows(pos, seq_len, D, D).float()[torch.arange(n_tokens) % seq_len]
-        _rows(out, n_tokens, D, ldo).copy_((t + p_).to(torch.bfloat16))
+        if pos:
+            t = t + _rows(pos, seq_len, D, D).float()[torch.arange(n_tokens) % seq_len]
+        _rows(out, n_tokens, D, ldo).copy_(t.to(torch.bfloat16))
+        return 0
+
+    def mi355x_sd_rmsnorm(self, x, rows, C, ldx, weight, eps, y, ldy, stream):
+        xv = _rows(x, rows, C, ldx).float()
+        o = xv * torch.rsqrt(xv.pow(2).mean(-1, keepdim=True) + eps) * _flat(weight, C, torch.float32)
+        _rows(y, rows, C, ldy).copy_(o.to(torch.bfloat16))
+        return 0
+
+    def mi355x_sd_gated_activation(self, x, ldx, y, ldy, rows, Fd, kind, stream):
+        xv = _rows(x, rows, 2 * Fd, ldx).float()
+        a, b = xv[:, :Fd], xv[:, Fd:]
+        g = (a * torch.sigmoid(1.702 * a) if kind == 0 else F.gelu(a) if kind == 1 else F.silu(a) if kind == 2
+             else F.gelu(a, approximate="tanh"))
+        _rows(y, rows, Fd, ldy).copy_((g * b).to(torch.bfloat16))
         return 0
 
     def mi355x_sd_activation(self, x, y, n, kind, stream):

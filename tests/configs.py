@@ -48,3 +48,6 @@ CLIP_L = dict(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hid
               max_position_embeddings=77, hidden_act="quick_gelu", projection_dim=768, eos_token_id=2)
 CLIP_BIGG = dict(vocab_size=49408, hidden_size=1280, intermediate_size=5120, num_hidden_layers=32, num_attention_heads=20,
                  max_position_embeddings=77, hidden_act="gelu", projection_dim=1280, eos_token_id=2)
+# T5 v1.1 encoder in miniature and the XXL geometry SD3 uses (public config: d_model 4096, 64 heads x 64, d_ff 10240, 24 layers)
+MINI_T5 = dict(vocab_size=500, d_model=64, d_kv=16, d_ff=128, num_layers=3, num_heads=4)
+T5_XXL = dict(vocab_size=32128, d_model=4096, d_kv=64, d_ff=10240, num_layers=24, num_heads=64)
