@@ -155,8 +155,28 @@ class StableDiffusion3Denoiser:
     Prompt encoding (2 x CLIP + T5) stays outside: the loop takes ``prompt_embeds`` [B, L, joint_attention_dim] and
     ``pooled_prompt_embeds`` [B, pooled_projection_dim]."""
 
-    def __init__(self, transformer, scheduler, vae=None):
+    def __init__(self, transformer, scheduler, vae=None, text_encoder=None, text_encoder_2=None, text_encoder_3=None):
         self.transformer, self.scheduler, self.vae = transformer, scheduler, vae
+        self.text_encoder, self.text_encoder_2, self.text_encoder_3 = text_encoder, text_encoder_2, text_encoder_3
+
+    def encode_prompt(self, input_ids: torch.Tensor, input_ids_2: torch.Tensor, input_ids_3: torch.Tensor,
+                      clip_skip: Optional[int] = None):
+        """Token ids of the three tokenizers -> (prompt_embeds [B, S_clip + S_t5, joint_dim], pooled [B, P1 + P2]);
+        pipeline_stable_diffusion_3.py:375-398: both CLIP encoders (with projection) contribute hidden_states[-2],
+        concatenated on the channel axis and zero-padded to the T5 width, then the T5 sequence is appended on the token
+        axis; pooled = the two projected EOS rows side by side."""
+        if self.text_encoder is None or self.text_encoder_2 is None or self.text_encoder_3 is None:
+            raise ValueError("encode_prompt needs `text_encoder`, `text_encoder_2` (CLIP with projection) and "
+                             "`text_encoder_3` (T5)")
+        embeds, pooled = [], []
+        for enc, ids in ((self.text_encoder, input_ids), (self.text_encoder_2, input_ids_2)):
+            out = enc(ids, output_hidden_states=True)
+            pooled.append(out[0])
+            embeds.append(out.hidden_states[-2 if clip_skip is None else -(clip_skip + 2)])
+        clip = torch.cat(embeds, dim=-1)
+        t5 = self.text_encoder_3(input_ids_3)[0]
+        clip = torch.nn.functional.pad(clip, (0, t5.shape[-1] - clip.shape[-1]))
+        return torch.cat([clip, t5], dim=-2), torch.cat(pooled, dim=-1)
 
     @torch.no_grad()
     def __call__(self, prompt_embeds: torch.Tensor, pooled_prompt_embeds: torch.Tensor,

@@ -175,3 +175,37 @@ def test_sd3_flow_match_cfg_loop_matches_oracle_loop():
     Pr = {k: (v.to(torch.bfloat16).float() if v.dim() > 1 else v) for k, v in Pv.items()}
     ref = (V.decode(Pr, vcfg, out / vcfg["scaling_factor"] + vcfg["shift_factor"]) / 2 + 0.5).clamp(0, 1)
     assert img.shape == (1, 3, 64, 64) and (img - ref).abs().max() < 3e-2
+
+
+def test_sd3_encode_prompt_three_encoders():
+    """two projected CLIP encoders + T5 -> [B, 77 + S_t5, joint_dim] / pooled [B, P1 + P2] (pipeline_stable_diffusion_3.py:375-398)"""
+    from oracle import clip_ref as CR
+    from oracle import t5_ref as TR
+    from paddlemix_amd.clip import CLIPTextModelWithProjection, synth_clip_params
+    from paddlemix_amd.pipeline import StableDiffusion3Denoiser
+    from paddlemix_amd.t5 import T5EncoderModel, synth_t5_params
+    from tests.configs import MINI_CLIP, MINI_T5
+    from tests.test_clip_host_logic import _ids
+    c1, c2 = dict(MINI_CLIP, with_projection=True), dict(MINI_CLIP, hidden_size=32, intermediate_size=64, projection_dim=16,
+                                                         hidden_act="gelu", with_projection=True)
+    t5c = dict(MINI_T5, d_model=128, d_ff=256)
+    P1, P2, P3 = synth_clip_params(c1, seed=1), synth_clip_params(c2, seed=2), synth_t5_params(t5c, seed=3)
+    pipe = StableDiffusion3Denoiser(None, None, text_encoder=CLIPTextModelWithProjection(c1, P1, _test_backend=Emulator()),
+                                    text_encoder_2=CLIPTextModelWithProjection(c2, P2, _test_backend=Emulator()),
+                                    text_encoder_3=T5EncoderModel(t5c, P3, _test_backend=Emulator()))
+    ids = _ids(2, 16, c1["vocab_size"], 2)
+    ids3 = torch.randint(0, t5c["vocab_size"], (2, 24), generator=torch.Generator().manual_seed(4))
+    emb, pooled = pipe.encode_prompt(ids, ids, ids3)
+    assert emb.shape == (2, 16 + 24, 128) and pooled.shape == (2, 32 + 16)
+    bf = lambda P: {k: (v.to(torch.bfloat16).float() if v.dim() > 1 and "relative_attention_bias" not in k else v)  # noqa: E731
+                    for k, v in P.items()}
+    r1, r2 = CR.clip_text_forward(bf(P1), c1, ids), CR.clip_text_forward(bf(P2), c2, ids)
+    r3 = TR.t5_encoder_forward(bf(P3), t5c, ids3)
+    ref_clip = torch.cat([r1["hidden_states"][-2], r2["hidden_states"][-2]], -1)
+    assert ((emb[:, :16, :96] - ref_clip).norm() / ref_clip.norm()) < 1.5e-2 and (emb[:, :16, 96:] == 0).all()
+    assert ((emb[:, 16:] - r3).norm() / r3.norm()) < 1.5e-2
+    ref_pooled = torch.cat([r1["text_embeds"], r2["text_embeds"]], -1)
+    assert ((pooled - ref_pooled).norm() / ref_pooled.norm()) < 2e-2
+    import pytest
+    with pytest.raises(ValueError):
+        StableDiffusion3Denoiser(None, None).encode_prompt(ids, ids, ids3)
