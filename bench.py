@@ -249,7 +249,9 @@ def main():
         dom = max((k for k in kinds if kinds[k]["gflop"] > 0), key=lambda k: kinds[k]["ms"])
         d = kinds[dom]
         ach = d["gflop"] / d["ms"]  # GFLOP/ms == TFLOP/s
-        names = {"gemm": "gemm_bf16_kernel<false>", "conv": "gemm_bf16_kernel<true>", "attn": "attention_kernel<64,false>"}
+        names = {"gemm": "linear GEMM class: gemm_pipe_kernel<false,...> / gemm256_kernel<false> / gemm_bf16_kernel<false,...>",
+                 "conv": "conv3x3 implicit-GEMM class: gemm_pipe_kernel<true,...> / gemm256_kernel<true>",
+                 "attn": "attention_kernel<64,false>"}
         res["roofline"] = {"bound": "mfma", "kernel": names.get(dom, dom), "achieved": ach, "peak": PEAK_BF16_TFLOPS,
                            "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
                            "launches_per_step": d["launches"], "avg_launch_ms": d["ms"] / d["launches"],
@@ -257,7 +259,9 @@ def main():
         # HBM traffic comes from rocprofv3 PMC passes (scripts/traffic.sh: FETCH_SIZE / WRITE_SIZE in separate passes,
         # gfx950 x2 read correction) -- it cannot be sampled from inside this process; the committed measurement of the
         # same workload is attached when present.
-        tpath = os.path.join(ROOT, "profiles", f"r01_e_traffic_{args.workload}.json")
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_traffic_{args.workload}.json")))
+        tpath = cands[-1] if cands else os.path.join(ROOT, "profiles", f"r01_f_traffic_{args.workload}.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             cls = tj["classes"].get(dom)
