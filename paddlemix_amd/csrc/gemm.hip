@@ -12,6 +12,10 @@
 // channel-concat is just two producers writing into one buffer. Weights are [N][K] with K contiguous
 // (Paddle's Linear [in,out] is transposed once at load; conv OIHW is repacked to [O][kh][kw][I]).
 //
+// Role: tile selection (pick_tile), argument validation, split-K planning / reduction, and the GENERIC loop that serves
+// what the specialised loops cannot (K % 64 != 0, fp8 weights, operands >= 4 GiB). The default loops are gemm_pipe.hip
+// (128x128, 256x160, 256x320 tiles; software-pipelined) and gemm256.hip (256x256, phased).
+//
 // Kernel shape (template): WAVES_M x WAVES_N waves, each owning TM x TN v_mfma_f32_16x16x32_bf16 tiles, BK = 64.
 //   * 128x128 tile: 2x2 waves of 64x64   (64 KB LDS, 2 blocks / CU)   -- small / ragged problems
 //   * 256x256 tile: 2x4 waves of 128x64  (128 KB LDS, 1 block / CU)   -- large problems (see also gemm256.hip)
@@ -35,22 +39,6 @@ namespace sd {
 // W8 = true: W is fp8 e4m3 (OCP), 64-B LDS rows (16 rows per DMA piece, 16-B chunk index XOR (row>>2)&3 so the 8-byte
 // fragment reads are conflict free); fragments are widened to bf16 in registers (every e4m3 value is exact in bf16) and the
 // per-channel scale is applied to the fp32 accumulator in the epilogue. Halves the weight bytes a CU has to ingest.
-// wave-uniform counted wait on the VMEM queue (the count must be an immediate)
-__device__ __forceinline__ void wait_vmcnt(int n) {
-  switch (n) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // never too weak
-  }
-}
-
 template <bool CONV, class CFG, bool W8 = false, bool LN = false>
 __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_bf16_kernel(const GemmArgs p) {
   constexpr int BM = CFG::BM, BN = CFG::BN, TM = CFG::TM, TN = CFG::TN;
@@ -203,37 +191,14 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_bf16_kernel(const GemmAr
     }
   };
 
-  if constexpr (CFG::STAGES == 2) {
-    issue_tile(t0 * BK, 0);
+  static_assert(CFG::STAGES == 2, "the generic loop double-buffers; the 3-stage ring lives in gemm_pipe.hip");
+  issue_tile(t0 * BK, 0);
+  __syncthreads();
+  for (int t = t0; t < t1; ++t) {
+    const int buf = (t - t0) & 1;
+    if (t + 1 < t1) issue_tile((t + 1) * BK, buf ^ 1);
+    multiply(buf);
     __syncthreads();
-    for (int t = t0; t < t1; ++t) {
-      const int buf = (t - t0) & 1;
-      if (t + 1 < t1) issue_tile((t + 1) * BK, buf ^ 1);
-      multiply(buf);
-      __syncthreads();
-    }
-  } else {
-    // 3-stage ring. vmcnt retires in issue order, so "at most my pieces of ONE tile outstanding" == tile t has landed
-    // (this wave's share); the barrier then publishes every wave's share and, at the same time, proves that all waves
-    // are done with tile t-1, whose stage the DMA of tile t+2 is about to overwrite.
-    int mine = 0;   // LDS-DMA instructions this wave issues per K-tile
-#pragma unroll
-    for (int i = 0; i < CFG::A_PIECES; ++i) mine += (wave + i * CFG::NW < CFG::A_TOTAL) ? 1 : 0;
-#pragma unroll
-    for (int i = 0; i < W_PIECES; ++i) mine += (wave + i * CFG::NW < W_TOTAL) ? 1 : 0;
-    issue_tile(t0 * BK, 0);
-    if (t0 + 1 < t1) issue_tile((t0 + 1) * BK, 1);
-    int stage = 0;
-    for (int t = t0; t < t1; ++t) {
-      if (t + 1 < t1) wait_vmcnt(mine);
-      else wait_vmcnt(0);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      if (t + 2 < t1) issue_tile((t + 2) * BK, stage == 0 ? 2 : stage - 1);
-      multiply(stage);
-      stage = stage == 2 ? 0 : stage + 1;
-    }
   }
 
   if (p.splitk > 1) {   // raw partial sums -> ws[split][m][n]; the epilogue runs in splitk_reduce_kernel
