@@ -257,6 +257,33 @@ def test_conv3x3_pipelined_ragged(ops, B, H, W, Cin, Cout, stride, up):
     check(out.reshape(B, Ho, Wo, Cout).permute(0, 3, 1, 2), ref, what=f"pipelined conv {B,H,W,Cin,Cout,stride,up}")
 
 
+def test_pipelined_loops_race_screen(ops):
+    """The software-pipelined loops order their LDS-DMA writes and ds_reads only through counted vmcnt waits and one
+    barrier per K-tile; a missing wait shows up as run-to-run differences long before it shows up as a wrong mean.
+    40 repetitions each of a long-K GEMM on every pipelined tile family (+ a conv), all bit-identical, under load from a
+    concurrently allocated second problem so the DMA timing varies."""
+    g = torch.Generator().manual_seed(123)
+    cases = [(2048, 1280, 8192, False), (4096, 640, 4096, False), (2048, 2560, 4096, True), (700, 328, 6144, False)]
+    noise_a = dev(torch.randn(4096, 4096, generator=g))
+    noise_w = dev(torch.randn(4096, 4096, generator=g))
+    for M, N, K, geglu in cases:
+        a = dev(bfr(torch.randn(M, K, generator=g)))
+        w = dev(bfr(torch.randn(N, K, generator=g) / math.sqrt(K)))
+        bias = dev(torch.randn(N, generator=g) * 0.1, torch.float32)
+        first = ops.linear(a, w, bias, geglu=geglu).clone()
+        for i in range(40):
+            if i % 4 == 0:
+                ops.linear(noise_a, noise_w)   # perturb cache / DMA timing between repetitions
+            assert torch.equal(ops.linear(a, w, bias, geglu=geglu), first), (M, N, K, geglu, i)
+        if not geglu:
+            check(first, (a.float() @ w.float().t() + bias).cpu(), what=f"race-screen reference {M,N,K}")
+    x = dev(bfr(torch.randn(2, 32, 32, 640, generator=g)))
+    wc = dev(bfr(torch.randn(640, 9 * 640, generator=g) / math.sqrt(9 * 640)))
+    first = ops.conv3x3(x, wc, None).clone()
+    for i in range(40):
+        assert torch.equal(ops.conv3x3(x, wc, None), first), ("conv", i)
+
+
 def test_geglu_splitk(ops):
     g = torch.Generator().manual_seed(5)
     M, C = 64, 1280
