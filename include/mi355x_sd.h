@@ -185,6 +185,11 @@ int mi355x_sd_softmax_rows(const float* x, int64_t ldx, void* y, int64_t ldy, in
  * epsilon-prediction scheduler step reduces to (PPD/schedulers/scheduling_euler_discrete.py:438-473,
  * scheduling_ddim.py:410-457 with eta = 0). */
 int mi355x_sd_axpby(const float* x, const float* y, float* out, const float* coef, int64_t n, void* stream);
+/* The same update with the classifier-free-guidance combine folded in (pipeline_stable_diffusion.py:882-891):
+ * out = coef[0]*x + coef[1]*(eps_uncond + guidance_scale * (eps_text - eps_uncond)); eps_* = the two batch halves of the
+ * UNet output. */
+int mi355x_sd_cfg_axpby(const float* x, const float* eps_uncond, const float* eps_text, float* out, const float* coef,
+                        float guidance_scale, int64_t n, void* stream);
 
 /* hipGraph capture of a sequence of the calls above issued on `stream` (one denoising step). */
 int mi355x_sd_graph_begin(void* stream);

@@ -58,6 +58,7 @@ SIGNATURES = {
                                          c_void_p]),
     "mi355x_sd_softmax_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "mi355x_sd_axpby": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mi355x_sd_cfg_axpby": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_void_p]),
     "mi355x_sd_graph_begin": (c_int, [c_void_p]),
     "mi355x_sd_graph_end": (c_int, [c_void_p, POINTER(c_void_p)]),
     "mi355x_sd_graph_launch": (c_int, [c_void_p, c_void_p]),

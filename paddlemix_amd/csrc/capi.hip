@@ -307,6 +307,12 @@ int mi355x_sd_axpby(const float* x, const float* y, float* out, const float* coe
   return finish(launch_axpby(x, y, out, coef, (long)n, S(stream)), "mi355x_sd_axpby");
 }
 
+int mi355x_sd_cfg_axpby(const float* x, const float* eps_uncond, const float* eps_text, float* out, const float* coef,
+                        float guidance_scale, int64_t n, void* stream) {
+  if (!x || !eps_uncond || !eps_text || !out || !coef) return fail(SD_ERR_INVALID, "mi355x_sd_cfg_axpby: null pointer");
+  return finish(launch_cfg_axpby(x, eps_uncond, eps_text, out, coef, guidance_scale, (long)n, S(stream)), "mi355x_sd_cfg_axpby");
+}
+
 int mi355x_sd_graph_begin(void* stream) {
   if (hipStreamBeginCapture(S(stream), hipStreamCaptureModeThreadLocal) != hipSuccess)
     return finish(SD_ERR_HIP, "mi355x_sd_graph_begin");

@@ -99,6 +99,8 @@ int launch_conv1x1_nchw(const float* x, float in_scale, const bf16* w, const flo
                         int Cout, long HW, hipStream_t stream);
 int launch_softmax_rows(const float* x, long ldx, bf16* y, long ldy, long rows, int n, hipStream_t stream);
 int launch_copy_rows(const bf16* x, int ldx, bf16* y, int ldy, long rows, int C, hipStream_t stream);
+int launch_cfg_axpby(const float* x, const float* eu, const float* et, float* out, const float* coef, float gs, long n,
+                     hipStream_t stream);
 int launch_axpby(const float* x, const float* y, float* out, const float* coef, long n, hipStream_t stream);
 
 }  // namespace sd

@@ -424,6 +424,27 @@ __global__ void axpby_kernel(const float* __restrict__ x, const float* __restric
     out[i] = a * x[i] + b * y[i];
 }
 
+// Classifier-free-guidance combine + linear scheduler update in one pass over the latents
+// (pipeline_stable_diffusion.py:882-891 followed by the epsilon-prediction step of Euler / DDIM(eta=0) / flow matching):
+// out = coef[0] * x + coef[1] * (eu + gs * (et - eu)); eu / et = the unconditional / text halves of the UNet output.
+__global__ void cfg_axpby_kernel(const float* __restrict__ x, const float* __restrict__ eu, const float* __restrict__ et,
+                                 float* __restrict__ out, const float* __restrict__ coef, float gs, long n) {
+  const float a = coef[0], b = coef[1];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float u = eu[i];
+    out[i] = a * x[i] + b * (u + gs * (et[i] - u));
+  }
+}
+
+int launch_cfg_axpby(const float* x, const float* eu, const float* et, float* out, const float* coef, float gs, long n,
+                     hipStream_t stream) {
+  if (n <= 0) return SD_ERR_INVALID;
+  long nb = (n + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(cfg_axpby_kernel, dim3((unsigned)nb), dim3(256), 0, stream, x, eu, et, out, coef, gs, n);
+  return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+}
+
 int launch_axpby(const float* x, const float* y, float* out, const float* coef, long n, hipStream_t stream) {
   if (n <= 0) return SD_ERR_INVALID;
   long nb = (n + 255) / 256;

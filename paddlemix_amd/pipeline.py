@@ -62,6 +62,29 @@ class StableDiffusionDenoiser:
                              f"{cfg.projection_class_embeddings_input_dim}, but a vector of {passed} was created.")
         return torch.tensor([ids], dtype=torch.float32, device=device)
 
+    def _fused_plan(self, guidance_rescale: float, device):
+        """(per-step input scales, device table of (a, b), library, stream getter) when the scheduler's step is the
+        linear epsilon update ``prev = a * x + b * eps`` (``step_coefficients``); None -> the generic torch path."""
+        sch = self.scheduler
+        if guidance_rescale > 0.0 or not hasattr(sch, "step_coefficients") or not hasattr(self.unet, "_lib"):
+            return None
+        try:
+            scales, coefs = [], []
+            for t in sch.timesteps:
+                scales.append(float(sch.model_input_scale(t)) if hasattr(sch, "model_input_scale") else 1.0)
+                coefs.append(tuple(float(v) for v in sch.step_coefficients(t)))   # Euler: advances the step index
+        except NotImplementedError:
+            return None
+        finally:
+            if hasattr(sch, "_step_index"):
+                sch._step_index = None
+        coef = torch.tensor(coefs, dtype=torch.float32, device=device).contiguous()
+        if getattr(self.unet, "_emulated", False):
+            stream = lambda: 0  # noqa: E731
+        else:
+            stream = lambda: torch.cuda.current_stream(device).cuda_stream  # noqa: E731
+        return scales, coef, self.unet._lib, stream
+
     def decode_latents(self, latents: torch.Tensor, output_type: str = "pt"):
         """pipeline_stable_diffusion.py:911 + VaeImageProcessor.postprocess: decode, (x / 2 + 0.5).clamp(0, 1)."""
         if self.vae is None:
@@ -91,7 +114,7 @@ class StableDiffusionDenoiser:
                  output_type: str = "latent", prompt_ids: Optional[torch.Tensor] = None,
                  negative_prompt_ids: Optional[torch.Tensor] = None, prompt_ids_2: Optional[torch.Tensor] = None,
                  negative_prompt_ids_2: Optional[torch.Tensor] = None, original_size=None,
-                 crops_coords_top_left=(0, 0), target_size=None):
+                 crops_coords_top_left=(0, 0), target_size=None, fused_update: bool = True):
         do_cfg = guidance_scale > 1.0
         if prompt_embeds is None:
             if prompt_ids is None:
@@ -128,8 +151,31 @@ class StableDiffusionDenoiser:
                 added_cond_kwargs = {k: torch.cat([neg[k], v]) for k, v in added_cond_kwargs.items()}
         self.scheduler.set_timesteps(num_inference_steps)
         latents = self.prepare_latents(B, cfg.in_channels, h, w, torch.float32, generator, latents, prompt_embeds.device)
+        fused = self._fused_plan(guidance_rescale, latents.device) if fused_update else None
         for i, t in enumerate(self.scheduler.timesteps):
             latent_model_input = torch.cat([latents] * 2) if do_cfg else latents
+            if fused is not None:
+                # guidance combine + scheduler update as ONE device pass over the latents (mi355x_sd_cfg_axpby): the
+                # epsilon-prediction step of Euler / DDIM(eta=0) is prev = a*x + b*eps with per-step (a, b) kept in HBM
+                scales, coef, lib, stream = fused
+                noise_pred = self.unet(latent_model_input * scales[i], t, encoder_hidden_states=prompt_embeds,
+                                       added_cond_kwargs=added_cond_kwargs, return_dict=False)[0]
+                lat = latents.contiguous()
+                out = torch.empty_like(lat)
+                n, cp = lat.numel(), coef.data_ptr() + 8 * i
+                if do_cfg:
+                    rc = lib.mi355x_sd_cfg_axpby(lat.data_ptr(), noise_pred.data_ptr(), noise_pred.data_ptr() + 4 * n,
+                                                 out.data_ptr(), cp, float(guidance_scale), n, stream())
+                else:
+                    rc = lib.mi355x_sd_axpby(lat.data_ptr(), noise_pred.data_ptr(), out.data_ptr(), cp, n, stream())
+                if rc:
+                    from . import _lib
+                    _lib.check(rc)
+                latents = out
+                if callback_on_step_end is not None:
+                    cb = callback_on_step_end(self, i, t, {"latents": latents})
+                    latents = cb.pop("latents", latents)
+                continue
             latent_model_input = self.scheduler.scale_model_input(latent_model_input, t)
             noise_pred = self.unet(latent_model_input, t, encoder_hidden_states=prompt_embeds,
                                    added_cond_kwargs=added_cond_kwargs, return_dict=False)[0]

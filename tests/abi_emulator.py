@@ -318,6 +318,12 @@ class Emulator:
         _rows(y, rows, C, ldy).copy_(_rows(x, rows, C, ldx))
         return 0
 
+    def mi355x_sd_cfg_axpby(self, x, eu, et, out, coef, gs, n, stream):
+        a, b = _flat(coef, 2, torch.float32).tolist()
+        u, t = _flat(eu, n, torch.float32), _flat(et, n, torch.float32)
+        _flat(out, n, torch.float32).copy_(a * _flat(x, n, torch.float32) + b * (u + gs * (t - u)))
+        return 0
+
     def mi355x_sd_axpby(self, x, y, out, coef, n, stream):
         self.calls.append("axpby")
         c = _flat(coef, 2, torch.float32)
