@@ -36,6 +36,8 @@ WORKLOADS = {
     "sd3-1024-bs8": dict(cfg=SD3_MEDIUM, B=8, H=128, W=128, L=154, gflop_step=None, sd3=True),
     # BASELINE config 5: the same model with weight-only fp8 (e4m3 + per-channel scale) block matrices
     "sd3-1024-bs8-fp8w": dict(cfg=SD3_MEDIUM, B=8, H=128, W=128, L=154, gflop_step=None, sd3=True, fp8=True),
+    # the same with fp8 activations into the block GEMMs: W8A8 on the fp8 matrix pipe (v_mfma_scale_f32_16x16x128_f8f6f4)
+    "sd3-1024-bs8-w8a8": dict(cfg=SD3_MEDIUM, B=8, H=128, W=128, L=154, gflop_step=None, sd3=True, fp8=True, a8=True),
 }
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16, MI355X_MICROARCH.md chip table
 
@@ -120,6 +122,8 @@ def main():
         torch.cuda.synchronize()
         bcast_s = time.time() - t0
     kw = {"weight_dtype": "fp8"} if WORKLOADS[args.workload].get("fp8") else {}
+    if WORKLOADS[args.workload].get("a8"):
+        kw["act_dtype"] = "fp8"
     model = UNet2DConditionModel(cfg, P, device=dev, use_graph=not args.no_graph, **kw)
     P_cpu_needed = rank == 0 and world == 1 and not args.no_cpu_baseline and not is_sd3
     if not P_cpu_needed:
@@ -205,7 +209,8 @@ def main():
         "metric": {"sdxl-1024-bs8": "UNet denoising steps/sec (SD-XL 1024^2, bs=8)",
                    "sd15-512-bs1": "UNet denoising steps/sec (SD-1.5 512^2, bs=1)",
                    "sd3-1024-bs8": "MMDiT denoising steps/sec (SD3-medium 1024^2, bs=8, bf16 weights)",
-                   "sd3-1024-bs8-fp8w": "MMDiT denoising steps/sec (SD3-medium 1024^2, bs=8, fp8 weights)"}[args.workload],
+                   "sd3-1024-bs8-fp8w": "MMDiT denoising steps/sec (SD3-medium 1024^2, bs=8, fp8 weights)",
+                   "sd3-1024-bs8-w8a8": "MMDiT denoising steps/sec (SD3-medium 1024^2, bs=8, fp8 weights + activations, fp8 MFMA)"}[args.workload],
         "value": world * args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",

@@ -85,6 +85,26 @@ int mi355x_sd_row_stats(const void* x, int rows, int C, int ldx, float eps, floa
 int mi355x_sd_linear_ln(const void* A, int lda, const float* row_stats, const void* W, const float* w_rowsum, void* C,
                         int ldc, int M, int N, int K, const float* bias, int flags, void* stream);
 
+/* ---- W8A8: fp8 (OCP e4m3) MFMA path of the MMDiT block GEMMs (BASELINE config 5: "fp8 weights ... CDNA4 fp8 MFMA") ----
+ * C[M,N] = (A8 . W8^T) * a_scale[m] * w_scale[n] + bias, then optional gate[m / rows_per_batch][n] * (.) + R, optional
+ * tanh-GELU; bf16 output. A8 [M,K] / W8 [N,K] are e4m3 bytes, K % 128 == 0 (one v_mfma_scale_f32_16x16x128_f8f6f4 per
+ * 16x16 tile and K-tile), lda in elements (= bytes), % 16; a_rows_per_batch / c_rows_per_batch as in mi355x_sd_linear_ex.
+ * Scales: value = scale * q with scale = absmax / 448 per A row (mi355x_sd_adaln_f8 / mi355x_sd_quantize_rows) and per
+ * output channel of W (quantised at load). The reference has no fp8 inference path; parity is defined against the oracle
+ * evaluated on the same quantised operands (tests/test_gpu_sd3.py) and the quantisation error itself is reported. */
+int mi355x_sd_linear_f8(const void* A8, int lda, int a_rows_per_batch, int64_t a_batch_stride, const float* a_scale,
+                        const void* W8, const float* w_scale, void* C, int ldc, int c_rows_per_batch,
+                        int64_t c_batch_stride, int M, int N, int K, const float* bias, const float* gate, int ld_gate,
+                        int rows_per_batch, const void* R, int ldr, int flags, void* stream);
+/* mi355x_sd_adaln with the e4m3 quantisation fused: y8[row][C] bytes (row stride ldy bytes), y_scale[row]. */
+int mi355x_sd_adaln_f8(const void* x, int rows, int C, int ldx, const float* scale, const float* shift, int ld_mod,
+                       int rows_per_batch, float eps, void* y8, int ldy, float* y_scale, void* stream);
+/* bf16 rows -> e4m3 rows + per-row scale (attention output in front of the output projections, GELU output in front
+ * of ff.net.2). Source row m lives at (m / x_rows_per_batch) * x_batch_stride + (m % x_rows_per_batch) * ldx
+ * (x_rows_per_batch = 0: plain m * ldx); the output rows and scales are compact. */
+int mi355x_sd_quantize_rows(const void* x, int64_t rows, int C, int ldx, int x_rows_per_batch, int64_t x_batch_stride,
+                            void* y8, int ldy, float* y_scale, void* stream);
+
 /* y = LayerNorm_noaffine(x) * (1 + scale[b]) + shift[b], b = row / rows_per_batch, scale/shift fp32 rows of stride ld_mod.
  * AdaLayerNormZero / AdaLayerNormContinuous (PPD/models/normalization.py:72-86, 190-202) and the Triton op
  * adaptive_layer_norm (paddlemix/triton_ops/triton_ops.py:981-1139). */

@@ -81,8 +81,18 @@ def layer_norm_noaffine(x: Tensor, eps: float = 1e-6) -> Tensor:
     return F.layer_norm(x, (x.shape[-1],), None, None, eps)
 
 
-def joint_block(P: Params, name: str, x: Tensor, c: Tensor, temb: Tensor, heads: int, context_pre_only: bool):
-    """JointTransformerBlock.forward (attention.py:164-214)."""
+def fake_quant_rows(t: Tensor) -> Tensor:
+    """Per-token e4m3 fake quantisation (scale = absmax / 448 over the last dim): what the device's W8A8 mode feeds its
+    fp8 GEMMs. The reference has no fp8 inference path; this only lets the checker see the same operands."""
+    sc = t.abs().amax(dim=-1, keepdim=True).clamp_min(1e-12) * (1.0 / 448.0)
+    return (t / sc).to(torch.float8_e4m3fn).to(t.dtype) * sc
+
+
+def joint_block(P: Params, name: str, x: Tensor, c: Tensor, temb: Tensor, heads: int, context_pre_only: bool,
+                act_quant: bool = False):
+    """JointTransformerBlock.forward (attention.py:164-214). ``act_quant``: fake-quantise the inputs of the eight block
+    GEMM groups (QKV, out, FF1, FF2 of both streams) like the device's W8A8 mode."""
+    fq = fake_quant_rows if act_quant else (lambda t: t)
     st = F.silu(temb)
     shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = linear(P, name + ".norm1.linear", st).chunk(6, dim=1)
     nx = layer_norm_noaffine(x) * (1 + scale_msa[:, None]) + shift_msa[:, None]
@@ -94,6 +104,7 @@ def joint_block(P: Params, name: str, x: Tensor, c: Tensor, temb: Tensor, heads:
             linear(P, name + ".norm1_context.linear", st).chunk(6, dim=1)
         nc = layer_norm_noaffine(c) * (1 + c_scale_msa[:, None]) + c_shift_msa[:, None]
 
+    nx, nc = fq(nx), fq(nc)
     # JointAttnProcessor2_5 (attention_processor.py:938-981)
     B, S1, D = nx.shape
     q = torch.cat([linear(P, name + ".attn.to_q", nx), linear(P, name + ".attn.add_q_proj", nc)], dim=1)
@@ -103,25 +114,30 @@ def joint_block(P: Params, name: str, x: Tensor, c: Tensor, temb: Tensor, heads:
     qh, kh, vh = (t.reshape(B, -1, heads, d).permute(0, 2, 1, 3) for t in (q, k, v))
     s = (qh @ kh.transpose(-1, -2)) / math.sqrt(d)
     o = (torch.softmax(s, dim=-1) @ vh).permute(0, 2, 1, 3).reshape(B, -1, D)
+    # (the device stores the attention output in bf16 before it is quantised)
     attn_x, attn_c = o[:, :S1], o[:, S1:]
+    if act_quant:
+        attn_x, attn_c = fq(attn_x.to(torch.bfloat16).float()), fq(attn_c.to(torch.bfloat16).float())
     attn_x = linear(P, name + ".attn.to_out.0", attn_x)
 
     x = x + gate_msa[:, None] * attn_x
-    nx = layer_norm_noaffine(x) * (1 + scale_mlp[:, None]) + shift_mlp[:, None]
-    ff = linear(P, name + ".ff.net.2", F.gelu(linear(P, name + ".ff.net.0.proj", nx), approximate="tanh"))
+    nx = fq(layer_norm_noaffine(x) * (1 + scale_mlp[:, None]) + shift_mlp[:, None])
+    hx = F.gelu(linear(P, name + ".ff.net.0.proj", nx), approximate="tanh")
+    ff = linear(P, name + ".ff.net.2", fq(hx.to(torch.bfloat16).float()) if act_quant else hx)
     x = x + gate_mlp[:, None] * ff
     if context_pre_only:
         return None, x
     attn_c = linear(P, name + ".attn.to_add_out", attn_c)
     c = c + c_gate_msa[:, None] * attn_c
-    nc = layer_norm_noaffine(c) * (1 + c_scale_mlp[:, None]) + c_shift_mlp[:, None]
-    ffc = linear(P, name + ".ff_context.net.2", F.gelu(linear(P, name + ".ff_context.net.0.proj", nc), approximate="tanh"))
+    nc = fq(layer_norm_noaffine(c) * (1 + c_scale_mlp[:, None]) + c_shift_mlp[:, None])
+    hc = F.gelu(linear(P, name + ".ff_context.net.0.proj", nc), approximate="tanh")
+    ffc = linear(P, name + ".ff_context.net.2", fq(hc.to(torch.bfloat16).float()) if act_quant else hc)
     c = c + c_gate_mlp[:, None] * ffc
     return c, x
 
 
 def sd3_forward(P: Params, config: dict, hidden_states: Tensor, encoder_hidden_states: Tensor,
-                pooled_projections: Tensor, timestep) -> Tensor:
+                pooled_projections: Tensor, timestep, act_quant: bool = False) -> Tensor:
     """SD3Transformer2DModel.forward (transformer_sd3.py:279-365) -> sample [B, out_channels, H, W]."""
     cfg = normalize_config(config)
     B, _, H, W = hidden_states.shape
@@ -142,7 +158,8 @@ def sd3_forward(P: Params, config: dict, hidden_states: Tensor, encoder_hidden_s
     c = linear(P, "context_embedder", encoder_hidden_states)
     n = cfg["num_layers"]
     for i in range(n):
-        c, x = joint_block(P, f"transformer_blocks.{i}", x, c, temb, heads, context_pre_only=(i == n - 1))
+        c, x = joint_block(P, f"transformer_blocks.{i}", x, c, temb, heads, context_pre_only=(i == n - 1),
+                           act_quant=act_quant)
     # norm_out (AdaLayerNormContinuous, no affine, eps 1e-6) + proj_out + unpatchify (:341-356)
     scale, shift = linear(P, "norm_out.linear", F.silu(temb)).chunk(2, dim=1)
     x = layer_norm_noaffine(x) * (1 + scale)[:, None, :] + shift[:, None, :]

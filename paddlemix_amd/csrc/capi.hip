@@ -146,6 +146,39 @@ int mi355x_sd_linear_ln(const void* A, int lda, const float* row_stats, const vo
   return finish(launch_gemm(g, S(stream)), "mi355x_sd_linear_ln");
 }
 
+int mi355x_sd_linear_f8(const void* A8, int lda, int a_rows_per_batch, int64_t a_batch_stride, const float* a_scale,
+                        const void* W8, const float* w_scale, void* C, int ldc, int c_rows_per_batch,
+                        int64_t c_batch_stride, int M, int N, int K, const float* bias, const float* gate, int ld_gate,
+                        int rows_per_batch, const void* R, int ldr, int flags, void* stream) {
+  if (!A8 || !W8 || !C || !a_scale || !w_scale) return fail(SD_ERR_INVALID, "mi355x_sd_linear_f8: null pointer");
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = (const bf16*)A8; g.W = (const bf16*)W8; g.C = C;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc;
+  g.a_rpb = a_rows_per_batch; g.a_bstride = (long)a_batch_stride;
+  g.c_rpb = c_rows_per_batch; g.c_bstride = (long)c_batch_stride;
+  g.ascale = a_scale; g.wscale = w_scale;
+  g.bias = bias; g.gate = gate; g.ld_gate = ld_gate; g.rows_per_batch = rows_per_batch;
+  g.R = (const bf16*)R; g.ldr = ldr; g.out_scale = 1.0f;
+  g.gelu_tanh = (flags & MI355X_SD_GELU_TANH) ? 1 : 0;
+  if (flags & ~MI355X_SD_GELU_TANH) return fail(SD_ERR_UNSUPPORTED, "mi355x_sd_linear_f8: only MI355X_SD_GELU_TANH is supported");
+  return finish(launch_gemm_f8(g, S(stream)), "mi355x_sd_linear_f8");
+}
+
+int mi355x_sd_adaln_f8(const void* x, int rows, int C, int ldx, const float* scale, const float* shift, int ld_mod,
+                       int rows_per_batch, float eps, void* y8, int ldy, float* y_scale, void* stream) {
+  if (!x || !scale || !shift || !y8 || !y_scale) return fail(SD_ERR_INVALID, "mi355x_sd_adaln_f8: null pointer");
+  return finish(launch_adaln_f8((const bf16*)x, rows, C, ldx, scale, shift, ld_mod, rows_per_batch, eps, (unsigned char*)y8,
+                                ldy, y_scale, S(stream)), "mi355x_sd_adaln_f8");
+}
+
+int mi355x_sd_quantize_rows(const void* x, int64_t rows, int C, int ldx, int x_rows_per_batch, int64_t x_batch_stride,
+                            void* y8, int ldy, float* y_scale, void* stream) {
+  if (!x || !y8 || !y_scale) return fail(SD_ERR_INVALID, "mi355x_sd_quantize_rows: null pointer");
+  return finish(launch_quantize_rows((const bf16*)x, (long)rows, C, ldx, x_rows_per_batch, (long)x_batch_stride,
+                                     (unsigned char*)y8, ldy, y_scale, S(stream)), "mi355x_sd_quantize_rows");
+}
+
 int mi355x_sd_adaln(const void* x, int rows, int C, int ldx, const float* scale, const float* shift, int ld_mod,
                     int rows_per_batch, float eps, void* y, int ldy, void* stream) {
   if (!x || !scale || !shift || !y) return fail(SD_ERR_INVALID, "mi355x_sd_adaln: null pointer");

@@ -44,9 +44,18 @@ constexpr int LDS_BYTES = 2 * BUF;        // 128 KB
     __builtin_amdgcn_sched_barrier(0);    \
   } while (0)
 
-template <bool CONV, bool LN = false>
+// F8 = true: A and W are OCP e4m3 bytes (W8A8), one K-tile = 128 elements = the same 128-byte LDS rows, and the two
+// bf16 MFMAs of a (row-tile, column-tile) pair become ONE v_mfma_scale_f32_16x16x128_f8f6f4 (operand layout probed in
+// scripts/probes/f8_mfma_probe.hip: lane l supplies row l&15, k = (l>>4)*32 .. +31, i.e. the two adjacent 16-byte LDS
+// chunks 2*(l>>4), 2*(l>>4)+1; 2.25x the bf16 issue rate). Same schedule, same register footprint; the per-row (A) and
+// per-channel (W) dequantisation scales are applied to the fp32 accumulators in gemm_epilogue_f8.
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+template <bool CONV, bool LN = false, bool F8 = false>
 __global__ __launch_bounds__(g256::THREADS, 2) void gemm256_kernel(const GemmArgs p) {
   using namespace g256;
+  constexpr int ES = F8 ? 1 : 2;        // bytes per element
+  constexpr int KT = F8 ? 128 : 64;     // elements per K-tile (always 128 bytes)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x;
@@ -68,10 +77,12 @@ __global__ __launch_bounds__(g256::THREADS, 2) void gemm256_kernel(const GemmArg
   // byte (rows >= M / N, conv padding -> offset forced out of range) reads as zero in hardware, so there is no
   // zero-page select and no 64-bit address arithmetic in the loop. Requires K % 64 == 0 (no in-row K tail).
   const unsigned a_bytes = CONV ? (unsigned)(((size_t)(p.M / (p.Ho * p.Wo)) * p.Hs * p.Ws - 1) * p.lda + p.Cin) * 2u
+                           : F8 ? (unsigned)(p.a_rpb ? (size_t)((p.M - 1) / p.a_rpb) * p.a_bstride + (size_t)(p.a_rpb - 1) * p.lda + p.K
+                                                     : (size_t)(p.M - 1) * p.lda + p.K)   // exact: run-out tiles must fall outside
                                 : (unsigned)(((size_t)(p.M - 1) * p.lda + p.K) * 2);
   const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.A), 0, a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.W), 0, (unsigned)((size_t)p.N * p.K * 2), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.W), 0, (unsigned)((size_t)p.N * p.K * ES), 0x00020000);
   constexpr unsigned OOB = 0xFFFFFFF0u;
   unsigned a_off32[4];               // index h*2 + j : half h, piece j (linear: byte offset of the row's chunk)
   int oy[4], ox[4];
@@ -93,12 +104,13 @@ __global__ __launch_bounds__(g256::THREADS, 2) void gemm256_kernel(const GemmArg
       a_img[i] = (unsigned)((size_t)b * p.Hs * p.Ws * p.lda * 2);
       a_off32[i] = 0;
     } else {
-      a_off32[i] = a_ok[i] ? (unsigned)(((size_t)m * p.lda + cg * 8) * 2) : OOB;
+      const size_t arow = (F8 && p.a_rpb) ? (size_t)(m / p.a_rpb) * p.a_bstride + (size_t)(m % p.a_rpb) * p.lda : (size_t)m * p.lda;
+      a_off32[i] = a_ok[i] ? (unsigned)(arow * ES + cg * 16) : OOB;
       oy[i] = ox[i] = 0;
       a_img[i] = 0;
     }
     const int n = n0 + r;
-    w_off32[i] = (n < p.N) ? (unsigned)(((size_t)n * p.K + cg * 8) * 2) : OOB;
+    w_off32[i] = (n < p.N) ? (unsigned)((size_t)n * p.K * ES + cg * 16) : OOB;
   }
   int kA[2] = {0, 0}, kB[2] = {0, 0};              // next K offset (elements) of each half-tile stream
   int tapA[2] = {0, 0}, chA[2] = {cg * 8, cg * 8}; // conv: running (tap, channel) per A stream
@@ -129,21 +141,21 @@ __global__ __launch_bounds__(g256::THREADS, 2) void gemm256_kernel(const GemmArg
         ++tapA[h];
       }
     } else {
-      const int soff = (kA[h] < p.K) ? kA[h] * 2 : (int)0x7FFFFFF0;   // run-out tiles: out of range -> zeros
+      const int soff = (kA[h] < p.K) ? kA[h] * ES : (int)0x7FFFFFF0;   // run-out tiles: out of range -> zeros
 #pragma unroll
       for (int j = 0; j < 2; ++j)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lptr_t)(dst + j * 1024), 16, a_off32[h * 2 + j], soff, 0, 0);
     }
-    kA[h] += BK;
+    kA[h] += KT;
   };
   auto issue_B = [&](const int h, int buf) {
     if (p.dbg & 2) return;
     unsigned char* dst = smem + buf * BUF + (2 + h) * HALF + wave * 2048;
-    const int soff = (kB[h] < p.K) ? kB[h] * 2 : (int)0x7FFFFFF0;
+    const int soff = (kB[h] < p.K) ? kB[h] * ES : (int)0x7FFFFFF0;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lptr_t)(dst + j * 1024), 16, w_off32[h * 2 + j], soff, 0, 0);
-    kB[h] += BK;
+    kB[h] += KT;
   };
 
   f32x4 acc[4][8];   // [n-tile][m-tile]
@@ -154,7 +166,8 @@ __global__ __launch_bounds__(g256::THREADS, 2) void gemm256_kernel(const GemmArg
 
   // ---- fragment geometry ----
   const int frow = lane & 15, fkc = lane >> 4, rsw = frow & 7;
-  const int c0 = ((0 * 4 + fkc) ^ rsw) << 4, c1 = ((1 * 4 + fkc) ^ rsw) << 4;
+  // 16-B chunks of a 128-B row this lane reads: bf16 k-steps 0/1 -> chunks fkc, 4+fkc; fp8 -> the adjacent pair 2fkc, 2fkc+1
+  const int c0 = ((F8 ? 2 * fkc : fkc) ^ rsw) << 4, c1 = ((F8 ? 2 * fkc + 1 : 4 + fkc) ^ rsw) << 4;
   const int a_off = grp * HALF + frow * 128;                              // + (s*64 + mt*16)*128
   const int b_off = (2 + (wc >> 1)) * HALF + ((wc & 1) * 64 + frow) * 128; // + nt*16*128
   bf16x8 fa[4][2], fb[4][2];
@@ -188,14 +201,27 @@ __global__ __launch_bounds__(g256::THREADS, 2) void gemm256_kernel(const GemmArg
       return;
     }
     __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    if constexpr (F8) {
 #pragma unroll
       for (int nn = 0; nn < 2; ++nn)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-          acc[2 * j + nn][s * 4 + mt] =
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[2 * j + nn][ks], fa[mt][ks], acc[2 * j + nn][s * 4 + mt], 0, 0, 0);
+        for (int mt = 0; mt < 4; ++mt) {
+          i32x8 wa, xa;   // 32 operand bytes = the two 16-byte fragments
+          __builtin_memcpy(&wa, &fb[2 * j + nn][0], 32);
+          __builtin_memcpy(&xa, &fa[mt][0], 32);
+          acc[2 * j + nn][s * 4 + mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+              wa, xa, acc[2 * j + nn][s * 4 + mt], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+        }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+            acc[2 * j + nn][s * 4 + mt] =
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[2 * j + nn][ks], fa[mt][ks], acc[2 * j + nn][s * 4 + mt], 0, 0, 0);
+    }
     __builtin_amdgcn_s_setprio(0);
   };
 
@@ -211,7 +237,7 @@ __global__ __launch_bounds__(g256::THREADS, 2) void gemm256_kernel(const GemmArg
   SD_BARRIER();
   if (grp == 1) SD_BARRIER();                        // stagger: group 1 runs one barrier behind group 0
 
-  const int nt = (p.K + BK - 1) / BK;
+  const int nt = (p.K + KT - 1) / KT;
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
     const unsigned char* base = smem + buf * BUF;
@@ -245,7 +271,8 @@ __global__ __launch_bounds__(g256::THREADS, 2) void gemm256_kernel(const GemmArg
   if (grp == 0) SD_BARRIER();                         // re-align the two groups
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // run-out DMAs retired before the LDS is released
 
-  if constexpr (LN) gemm_epilogue_ln<8, 4>(p, acc, m0 + grp * 128, n0 + wc * 64, lane);
+  if constexpr (F8) gemm_epilogue_f8<8, 4>(p, acc, m0 + grp * 128, n0 + wc * 64, lane);
+  else if constexpr (LN) gemm_epilogue_ln<8, 4>(p, acc, m0 + grp * 128, n0 + wc * 64, lane);
   else gemm_epilogue<8, 4>(p, acc, m0 + grp * 128, n0 + wc * 64, lane);
 }
 
@@ -257,6 +284,8 @@ int launch_gemm256(const GemmArgs& a, hipStream_t stream) {
            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess &&
            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<false, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess &&
+           hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<false, false, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
   }();
   if (!attr_ok) return SD_ERR_HIP;
@@ -267,13 +296,30 @@ int launch_gemm256(const GemmArgs& a, hipStream_t stream) {
   GemmArgs b = a;
   b.dbg = dbg;
   const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
-  if (a.rowstat)
+  if (a.ascale)   // W8A8: fp8 e4m3 operands (launch_gemm_f8 validated the arguments)
+    hipLaunchKernelGGL((gemm256_kernel<false, false, true>), dim3(ntm * ntn), dim3(THREADS), LDS_BYTES, stream, b);
+  else if (a.rowstat)
     hipLaunchKernelGGL((gemm256_kernel<false, true>), dim3(ntm * ntn), dim3(THREADS), LDS_BYTES, stream, b);
   else if (a.conv)
     hipLaunchKernelGGL(gemm256_kernel<true>, dim3(ntm * ntn), dim3(THREADS), LDS_BYTES, stream, b);
   else
     hipLaunchKernelGGL(gemm256_kernel<false>, dim3(ntm * ntn), dim3(THREADS), LDS_BYTES, stream, b);
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+}
+
+int launch_gemm_f8(const GemmArgs& a, hipStream_t stream) {
+  if (a.M <= 0 || a.N <= 0 || a.K <= 0 || !a.ascale || !a.wscale) return SD_ERR_INVALID;
+  // K-tiles of 128 bytes with no in-row tail; 16-byte aligned rows; 32-bit byte offsets
+  if ((a.K & 127) || (a.N & 3) || (a.lda & 15) || (a.ldc & 3) || a.conv || a.geglu || a.out_f32 || a.rowbias || a.rowstat ||
+      a.silu)
+    return SD_ERR_UNSUPPORTED;
+  if (a.R && (a.ldr & 3)) return SD_ERR_UNSUPPORTED;
+  if (a.gate && a.rows_per_batch <= 0) return SD_ERR_INVALID;
+  if ((a.a_rpb && (a.a_bstride & 15)) || (a.c_rpb && (a.c_bstride & 3))) return SD_ERR_UNSUPPORTED;
+  const size_t a_ext = a.a_rpb ? (size_t)((a.M - 1) / a.a_rpb) * a.a_bstride + (size_t)(a.a_rpb - 1) * a.lda + a.K
+                               : (size_t)(a.M - 1) * a.lda + a.K;
+  if (a_ext >= 0xFFFF0000ull || (size_t)a.N * a.K >= 0xFFFF0000ull) return SD_ERR_UNSUPPORTED;
+  return launch_gemm256(a, stream);
 }
 
 }  // namespace sd

@@ -151,4 +151,45 @@ __device__ __forceinline__ void gemm_epilogue_ln(const GemmArgs& p, f32x4 (&acc)
   }
 }
 
+// Epilogue of the W8A8 GEMM (mi355x_sd_linear_f8): acc * ascale[m] * wscale[n] + bias, optional gate / residual /
+// tanh-GELU / row-remapped C; bf16 store. Own function + own kernel instantiation (see gemm_epilogue_ln).
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_f8(const GemmArgs& p, f32x4 (&acc)[TN][TM], int m_wave, int n_wave,
+                                                 int lane) {
+  const int nq = (lane >> 4) * 4;
+  float as[TM];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) as[tm] = p.ascale[min(m_wave + tm * 16 + (lane & 15), p.M - 1)];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int m = m_wave + tm * 16 + (lane & 15);
+    if (m >= p.M) continue;
+    const float* gt = p.gate ? p.gate + (size_t)(m / p.rows_per_batch) * p.ld_gate : nullptr;
+    const size_t crow = p.c_rpb ? (size_t)(m / p.c_rpb) * p.c_bstride + (size_t)(m % p.c_rpb) * p.ldc : (size_t)m * p.ldc;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int n = n_wave + tn * 16 + nq;
+      if (n >= p.N) continue;
+      f32x4 v = acc[tn][tm] * as[tm] * *reinterpret_cast<const f32x4*>(p.wscale + n);
+      if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+      if (gt) v *= *reinterpret_cast<const f32x4*>(gt + n);
+      if (p.R) {
+        const bf16x4 r4 = *reinterpret_cast<const bf16x4*>(p.R + (size_t)m * p.ldr + n);
+        v[0] += (float)r4[0];
+        v[1] += (float)r4[1];
+        v[2] += (float)r4[2];
+        v[3] += (float)r4[3];
+      }
+      if (p.gelu_tanh) {
+        v[0] = gelu_tanh_f(v[0]);
+        v[1] = gelu_tanh_f(v[1]);
+        v[2] = gelu_tanh_f(v[2]);
+        v[3] = gelu_tanh_f(v[3]);
+      }
+      u32x2 pk = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+      *reinterpret_cast<u32x2*>(reinterpret_cast<bf16*>(p.C) + crow + n) = pk;
+    }
+  }
+}
+
 }  // namespace sd

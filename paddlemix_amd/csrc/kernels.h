@@ -35,6 +35,7 @@ struct GemmArgs {
   int a_rpb;              // A row m lives at (m / a_rpb) * a_bstride + (m % a_rpb) * lda   (0: plain m * lda)
   long a_bstride;
   const float* wscale;    // W is fp8 e4m3 [N][K] (1 byte / element) with per-output-channel scale: acc *= wscale[n]
+  const float* ascale;    // W8A8: A and W are fp8 e4m3 (wscale per output channel, ascale per A row): acc *= ascale[m]*wscale[n]
   const float* rowstat;   // LayerNorm folded into the GEMM: per-row (rstd, -mean*rstd) from launch_row_stats and
   const float* wsum;      //   wsum[n] = sum_k W[n][k]: acc <- rstd[m]*acc - mean[m]*rstd[m]*wsum[n]   (before bias)
   int c_rpb;              // same remap for the C rows (joint text+image token buffers of the MMDiT attention)
@@ -49,6 +50,7 @@ struct GemmArgs {
 void set_workspace(void* ptr, size_t bytes);
 int launch_gemm(const GemmArgs& a, hipStream_t stream);
 int launch_gemm256(const GemmArgs& a, hipStream_t stream);
+int launch_gemm_f8(const GemmArgs& a, hipStream_t stream);   // W8A8 (gemm256.hip); validates
 void launch_splitk_reduce(const GemmArgs& a, hipStream_t stream);   // sums a.splitk slices of a.ws + epilogue (gemm.hip)   // phased 256x256 kernel (gemm256.hip); args pre-validated
 
 struct AttnArgs {
@@ -74,6 +76,10 @@ int launch_scale_shift_act(const bf16* x, int B, int HW, int C, int ldx, const f
 // y = LN(x) * (1 + scale[b]) + shift[b]  (no affine; b = row / rows_per_batch): AdaLayerNormZero / Continuous
 int launch_adaln(const bf16* x, int rows, int C, int ldx, const float* scale, const float* shift, int ld_mod,
                  int rows_per_batch, float eps, bf16* y, int ldy, hipStream_t stream);
+int launch_adaln_f8(const bf16* x, int rows, int C, int ldx, const float* scale, const float* shift, int ld_mod,
+                    int rows_per_batch, float eps, unsigned char* y8, int ldy, float* yscale, hipStream_t stream);
+int launch_quantize_rows(const bf16* x, long rows, int C, int ldx, int x_rpb, long x_bstride, unsigned char* y8, int ldy,
+                         float* yscale, hipStream_t stream);
 int launch_patchify(const float* x_nchw, int B, int C, int H, int W, int p, bf16* out, int ldo, hipStream_t stream);
 int launch_unpatchify(const bf16* x, int ldx, int B, int C, int H, int W, int p, float* out_nchw, hipStream_t stream);
 int launch_row_stats(const bf16* x, int rows, int C, int ldx, float eps, float* stats, hipStream_t stream);

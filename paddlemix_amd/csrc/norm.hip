@@ -574,6 +574,146 @@ __global__ __launch_bounds__(256) void adaln_kernel(const bf16* __restrict__ x, 
   }
 }
 
+// ---- W8A8 producers: rows quantised to OCP e4m3 with one fp32 scale per row (absmax / 448) ----
+__device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d) {
+  int w = 0;
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);   // bytes 0, 1
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);    // bytes 2, 3
+  return (unsigned)w;
+}
+
+// AdaLayerNorm (same arithmetic as adaln_kernel) with the fp8 quantisation fused: the modulated row never exists in
+// bf16. y8[row][C] bytes (row stride ldy bytes), yscale[row] = absmax / 448 (dequantised value = scale * q).
+template <int NCH>
+__global__ __launch_bounds__(256) void adaln_f8_kernel(const bf16* __restrict__ x, int rows, int C, int ldx,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       int ld_mod, int rows_per_batch, float eps,
+                                                       unsigned char* __restrict__ y8, int ldy, float* __restrict__ yscale) {
+  const int lane = threadIdx.x & 63;
+  const int wave_g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * (blockDim.x >> 6);
+  const int cv = C >> 3;
+  const float invC = 1.0f / (float)C;
+  for (int row = wave_g; row < rows; row += nwaves) {
+    float v[NCH][8];
+    const bf16* xr = x + (size_t)row * ldx;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int cc = lane + 64 * i;
+      u32x4 raw = {0u, 0u, 0u, 0u};
+      if (cc < cv) raw = *reinterpret_cast<const u32x4*>(xr + cc * 8);
+      const bf16x8 t = *reinterpret_cast<const bf16x8*>(&raw);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[i][j] = (float)t[j];
+    }
+    const float K = __shfl(v[0][0], 0, 64);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+      if (lane + 64 * i < cv) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float d = v[i][j] - K;
+          s1 += d;
+          s2 = __builtin_fmaf(d, d, s2);
+        }
+      }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    const float m = s1 * invC;
+    const float mean = K + m, rstd = rsqrtf(fmaxf(s2 * invC - m * m, 0.f) + eps);
+    const int bidx = row / rows_per_batch;
+    const float* sc = scale + (size_t)bidx * ld_mod;
+    const float* sh = shift + (size_t)bidx * ld_mod;
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int cc = lane + 64 * i;
+      if (cc < cv) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          v[i][j] = __builtin_fmaf((v[i][j] - mean) * rstd, 1.0f + sc[cc * 8 + j], sh[cc * 8 + j]);
+          amax = fmaxf(amax, fabsf(v[i][j]));
+        }
+      }
+    }
+    amax = wave_max(amax);
+    const float qs = fmaxf(amax, 1e-12f) * (1.0f / 448.0f), inv = 1.0f / qs;
+    if (lane == 0) yscale[row] = qs;
+    unsigned char* yr = y8 + (size_t)row * ldy;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int cc = lane + 64 * i;
+      if (cc < cv) {
+        u32x2 pk = {pack_fp8x4(v[i][0] * inv, v[i][1] * inv, v[i][2] * inv, v[i][3] * inv),
+                    pack_fp8x4(v[i][4] * inv, v[i][5] * inv, v[i][6] * inv, v[i][7] * inv)};
+        *reinterpret_cast<u32x2*>(yr + cc * 8) = pk;
+      }
+    }
+  }
+}
+
+int launch_adaln_f8(const bf16* x, int rows, int C, int ldx, const float* scale, const float* shift, int ld_mod,
+                    int rows_per_batch, float eps, unsigned char* y8, int ldy, float* yscale, hipStream_t stream) {
+  if (rows <= 0 || C <= 0 || rows_per_batch <= 0) return SD_ERR_INVALID;
+  if ((C & 7) || (ldx & 7) || (ldy & 7) || (ld_mod & 3) || C > 2560) return SD_ERR_UNSUPPORTED;
+  const int cv = C >> 3;
+  int blocks = (rows + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+#define SD_AF8(NCH) \
+  hipLaunchKernelGGL((adaln_f8_kernel<NCH>), dim3(blocks), dim3(256), 0, stream, x, rows, C, ldx, scale, shift, ld_mod, \
+                     rows_per_batch, eps, y8, ldy, yscale)
+  if (cv <= 128) SD_AF8(2);
+  else if (cv <= 192) SD_AF8(3);
+  else SD_AF8(5);
+#undef SD_AF8
+  return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+}
+
+// bf16 rows -> e4m3 rows + per-row scale (the attention output in front of the MMDiT output projections). One wave per
+// row, two passes (absmax, convert); the second pass re-reads the row from L2.
+__global__ __launch_bounds__(256) void quantize_rows_kernel(const bf16* __restrict__ x, long rows, int C, int ldx, int x_rpb,
+                                                            long x_bstride, unsigned char* __restrict__ y8, int ldy,
+                                                            float* __restrict__ yscale) {
+  const int lane = threadIdx.x & 63;
+  const long wave_g = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
+  const int cv = C >> 3;
+  for (long row = wave_g; row < rows; row += nwaves) {
+    // source row remap (rows of one stream inside the joint [B, S_img + S_txt, C] attention output); output is compact
+    const bf16* xr = x_rpb ? x + (size_t)(row / x_rpb) * x_bstride + (size_t)(row % x_rpb) * ldx : x + (size_t)row * ldx;
+    float amax = 0.f;
+    for (int cc = lane; cc < cv; cc += 64) {
+      const u32x4 raw = *reinterpret_cast<const u32x4*>(xr + cc * 8);
+      const bf16x8 t = *reinterpret_cast<const bf16x8*>(&raw);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf((float)t[j]));
+    }
+    amax = wave_max(amax);
+    const float qs = fmaxf(amax, 1e-12f) * (1.0f / 448.0f), inv = 1.0f / qs;
+    if (lane == 0) yscale[row] = qs;
+    unsigned char* yr = y8 + (size_t)row * ldy;
+    for (int cc = lane; cc < cv; cc += 64) {
+      const u32x4 raw = *reinterpret_cast<const u32x4*>(xr + cc * 8);
+      const bf16x8 t = *reinterpret_cast<const bf16x8*>(&raw);
+      u32x2 pk = {pack_fp8x4((float)t[0] * inv, (float)t[1] * inv, (float)t[2] * inv, (float)t[3] * inv),
+                  pack_fp8x4((float)t[4] * inv, (float)t[5] * inv, (float)t[6] * inv, (float)t[7] * inv)};
+      *reinterpret_cast<u32x2*>(yr + cc * 8) = pk;
+    }
+  }
+}
+
+int launch_quantize_rows(const bf16* x, long rows, int C, int ldx, int x_rpb, long x_bstride, unsigned char* y8, int ldy,
+                         float* yscale, hipStream_t stream) {
+  if (rows <= 0 || C <= 0 || x_rpb < 0) return SD_ERR_INVALID;
+  if ((C & 7) || (ldx & 7) || (ldy & 7) || (x_bstride & 7)) return SD_ERR_UNSUPPORTED;
+  long blocks = (rows + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(quantize_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, rows, C, ldx, x_rpb, x_bstride, y8,
+                     ldy, yscale);
+  return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+}
+
 int launch_adaln(const bf16* x, int rows, int C, int ldx, const float* scale, const float* shift, int ld_mod,
                  int rows_per_batch, float eps, bf16* y, int ldy, hipStream_t stream) {
   if (rows <= 0 || C <= 0 || rows_per_batch <= 0) return SD_ERR_INVALID;

@@ -413,3 +413,46 @@ def gated_activation(x: Tensor, kind: str = "gelu_new") -> Tensor:
     out = torch.empty((rows, F2 // 2), device=x.device, dtype=torch.bfloat16)
     check(lib.mi355x_sd_gated_activation(x.data_ptr(), ldx, out.data_ptr(), F2 // 2, rows, F2 // 2, kinds[kind], _stream()))
     return out
+
+
+def quantize_rows(x: Tensor):
+    """bf16 [rows, C] -> (uint8 e4m3 [rows, C], fp32 scale [rows]) with value = scale * q, scale = absmax / 448."""
+    lib = _lib.load()
+    ldx = _rows(x, "x")
+    rows, C = x.shape
+    y = torch.empty((rows, C), device=x.device, dtype=torch.uint8)
+    sc = torch.empty((rows,), device=x.device, dtype=torch.float32)
+    check(lib.mi355x_sd_quantize_rows(x.data_ptr(), rows, C, ldx, 0, 0, y.data_ptr(), C, sc.data_ptr(), _stream()))
+    return y, sc
+
+
+def adaln_f8(x: Tensor, scale: Tensor, shift: Tensor, rows_per_batch: int, eps: float = 1e-6):
+    """adaln() with fused e4m3 quantisation -> (uint8 [rows, C], fp32 scale [rows])."""
+    lib = _lib.load()
+    ldx = _rows(x, "x")
+    rows, C = x.shape
+    y = torch.empty((rows, C), device=x.device, dtype=torch.uint8)
+    sc = torch.empty((rows,), device=x.device, dtype=torch.float32)
+    check(lib.mi355x_sd_adaln_f8(x.data_ptr(), rows, C, ldx, scale.data_ptr(), shift.data_ptr(), scale.stride(0), rows_per_batch,
+                                 float(eps), y.data_ptr(), C, sc.data_ptr(), _stream()))
+    return y, sc
+
+
+def linear_f8(a8: Tensor, a_scale: Tensor, w8: Tensor, w_scale: Tensor, bias: Optional[Tensor] = None, *,
+              gate: Optional[Tensor] = None, rows_per_batch: int = 0, residual: Optional[Tensor] = None,
+              gelu_tanh: bool = False, out: Optional[Tensor] = None) -> Tensor:
+    """W8A8 GEMM on the fp8 matrix pipe: (a8 @ w8^T) * a_scale[:, None] * w_scale[None, :] + bias, bf16 out."""
+    lib = _lib.load()
+    M, K = a8.shape
+    N = w8.shape[0]
+    for t, nm in ((a8, "a8"), (w8, "w8")):
+        if t.dtype != torch.uint8 or not t.is_cuda or t.stride(1) != 1:
+            raise ValueError(f"{nm}: expected uint8 (e4m3 bytes) cuda rows")
+    if out is None:
+        out = torch.empty((M, N), device=a8.device, dtype=torch.bfloat16)
+    check(lib.mi355x_sd_linear_f8(a8.data_ptr(), a8.stride(0), 0, 0, _vec(a_scale, M, "a_scale").data_ptr(), w8.data_ptr(),
+                                  _vec(w_scale, N, "w_scale").data_ptr(), out.data_ptr(), _rows(out, "out"), 0, 0, M, N, K,
+                                  _p(_vec(bias, N, "bias")), _p(gate), gate.stride(0) if gate is not None else 0, rows_per_batch,
+                                  _p(residual), _rows(residual, "residual") if residual is not None else 0,
+                                  GELU_TANH if gelu_tanh else 0, _stream()))
+    return out

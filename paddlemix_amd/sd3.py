@@ -136,13 +136,19 @@ class SD3Transformer2DModel(DeviceProgram, PretrainedMixin):
     _param_shapes = staticmethod(sd3_param_shapes)
 
     def __init__(self, config: Mapping, params: Mapping[str, Tensor], device="cuda", use_graph: bool = True,
-                 profile: bool = False, weight_dtype: str = "bf16", _test_backend=None):
+                 profile: bool = False, weight_dtype: str = "bf16", act_dtype: str = "bf16", _test_backend=None):
         """``weight_dtype``: "bf16" | "fp8" -- fp8 stores the block matrices (QKV, out, FF of both streams) as OCP e4m3
         with one fp32 scale per output channel (absmax / 448) and runs the weight-only-fp8 GEMM (BASELINE config 5).
         ``_test_backend``: test-only injection (tests/abi_emulator.py); never selected by product code."""
         if weight_dtype not in ("bf16", "fp8"):
             raise ValueError(f"weight_dtype must be 'bf16' or 'fp8', got {weight_dtype!r}")
-        self.weight_dtype = weight_dtype
+        if act_dtype not in ("bf16", "fp8") or (act_dtype == "fp8" and weight_dtype != "fp8"):
+            raise ValueError("act_dtype must be 'bf16' or 'fp8' (fp8 activations need weight_dtype='fp8')")
+        # act_dtype="fp8": W8A8 -- the block GEMMs run on the fp8 matrix pipe (mi355x_sd_linear_f8): their inputs are
+        # quantised per token row (absmax / 448) by the producing kernel (adaLN) or a row-quantisation pass (attention
+        # output, GELU output), their weights per output channel at load; accumulation, epilogues and everything
+        # between the GEMMs (attention, residual stream, modulation) stay as in the bf16 path.
+        self.weight_dtype, self.act_dtype = weight_dtype, act_dtype
         self._init_backend(device, use_graph, profile, _test_backend)
         self.cfg = normalize_config(config)
         self.config = SimpleNamespace(**self.cfg)
@@ -264,6 +270,30 @@ class SD3Transformer2DModel(DeviceProgram, PretrainedMixin):
             emit(lib.mi355x_sd_adaln, (x.p, x.rows, x.C, x.ld, scale_ptr, shift_ptr, MT, rpb, 1e-6, out.p, out.ld,
                                        stream), "ln")
 
+        w8a8 = self.act_dtype == "fp8"
+
+        class _Q:   # e4m3 row view: bytes at p (row stride ld bytes) + one fp32 scale per row at s
+            def __init__(q, name, rows, C):
+                q.p, q.s, q.rows, q.C, q.ld = sc(name + "8", rows * C), sc(name + "8s", 4 * rows), rows, C, C
+
+        def adaln8(x: _V, scale_ptr, shift_ptr, rpb, out):
+            emit(lib.mi355x_sd_adaln_f8, (x.p, x.rows, x.C, x.ld, scale_ptr, shift_ptr, MT, rpb, 1e-6, out.p, out.ld, out.s,
+                                          stream), "ln")
+
+        def quant8(x: _V, out, x_rpb=0, x_bs=0):
+            emit(lib.mi355x_sd_quantize_rows, (x.p, x.rows, x.C, x.ld, x_rpb, x_bs, out.p, out.ld, out.s, stream), "ln")
+
+        def linear8(a, wkey: str, out: _V, *, rows=None, a_off=0, s_off=0, flags=0, R: Optional[_V] = None, gate=None,
+                    rpb=0, a_rpb=0, a_bs=0, c_rpb=0, c_bs=0):
+            """W8A8 GEMM; `a` is a _Q (a_off / s_off: byte offsets of the first row / first scale inside it)"""
+            w = W[wkey + ".w"]
+            N, K = w.shape
+            M = a.rows if rows is None else rows
+            emit(lib.mi355x_sd_linear_f8,
+                 (a.p + a_off, a.ld, a_rpb, a_bs, a.s + s_off, w.data_ptr(), W[wkey + ".s"].data_ptr(), out.p, out.ld, c_rpb,
+                  c_bs, M, N, K, W[wkey + ".b"].data_ptr(), gate, MT if gate is not None else 0, rpb,
+                  R.p if R else None, R.ld if R else 0, flags, stream), "gemm", 2.0 * M * N * K, f"{M}x{N}x{K}f8")
+
         # ---- inputs ----
         plan.sample = persist((B, cfg["in_channels"], H, Wd), torch.float32)
         plan.t = persist((1,), torch.float32)
@@ -314,33 +344,57 @@ class SD3Transformer2DModel(DeviceProgram, PretrainedMixin):
         ffx = _V(sc("ff_x", 2 * B * S1 * 4 * D), B * S1, 4 * D)
         ffc = _V(sc("ff_c", 2 * B * S2 * 4 * D), B * S2, 4 * D)
         d = D // heads
+        if w8a8:
+            nx8, nc8 = _Q("nx", B * S1, D), _Q("nc", B * S2, D)
+            ax8, ac8 = _Q("ax", B * S1, D), _Q("ac", B * S2, D)
+            fx8, fc8 = _Q("fx", B * S1, 4 * D), _Q("fc", B * S2, 4 * D)
         for i in range(n):
             b = f"transformer_blocks.{i}"
             last = i == n - 1
             kx, kc = b + ".norm1", b + ".norm1_context"
             # chunks of norm1.linear: 0 shift_msa, 1 scale_msa, 2 gate_msa, 3 shift_mlp, 4 scale_mlp, 5 gate_mlp
-            adaln(x, m_at(kx, 1), m_at(kx, 0), S1, nx)
+            an_x = (lambda sp, hp: adaln8(x, sp, hp, S1, nx8)) if w8a8 else (lambda sp, hp: adaln(x, sp, hp, S1, nx))
+            an_c = (lambda sp, hp: adaln8(c, sp, hp, S2, nc8)) if w8a8 else (lambda sp, hp: adaln(c, sp, hp, S2, nc))
+            lin = linear8 if w8a8 else linear
+            ax, ac = (nx8, nc8) if w8a8 else (nx, nc)
+            an_x(m_at(kx, 1), m_at(kx, 0))
             if last:  # AdaLayerNormContinuous: (scale, shift) = chunk(2)
-                adaln(c, m_at(kc, 0), m_at(kc, 1), S2, nc)
+                an_c(m_at(kc, 0), m_at(kc, 1))
             else:
-                adaln(c, m_at(kc, 1), m_at(kc, 0), S2, nc)
+                an_c(m_at(kc, 1), m_at(kc, 0))
             # fused QKV of both streams into the joint [B, S1+S2, 3D] buffer (split_concat folded into the epilogue)
-            linear(nx, b + ".qkv", _V(jq, B * S1, 3 * D), c_rpb=S1, c_bs=ST * 3 * D)
-            linear(nc, b + ".qkv_c", _V(jq + 2 * S1 * 3 * D, B * S2, 3 * D), c_rpb=S2, c_bs=ST * 3 * D)
+            lin(ax, b + ".qkv", _V(jq, B * S1, 3 * D), c_rpb=S1, c_bs=ST * 3 * D)
+            lin(ac, b + ".qkv_c", _V(jq + 2 * S1 * 3 * D, B * S2, 3 * D), c_rpb=S2, c_bs=ST * 3 * D)
             emit(lib.mi355x_sd_sdpa, (jq, jq + 2 * D, jq + 4 * D, None, ao, B, heads, ST, ST, d, ST * 3 * D, 3 * D,
                                       ST * 3 * D, 3 * D, ST * 3 * D, 3 * D, ST * D, D, 0, 0, 0, d ** -0.5, stream),
                  "attn", 4.0 * B * heads * ST * ST * d, f"{B}x{heads}x{ST}x{ST}x{d}")
             # to_out with the gated residual: x += gate_msa * (attn @ Wo + b)
-            linear(_V(ao, B * S1, D), b + ".out", x, R=x, gate=m_at(kx, 2), rpb=S1, a_rpb=S1, a_bs=ST * D)
-            adaln(x, m_at(kx, 4), m_at(kx, 3), S1, nx)
-            linear(nx, b + ".ff1", ffx, flags=GELU_TANH)
-            linear(ffx, b + ".ff2", x, R=x, gate=m_at(kx, 5), rpb=S1)
+            if w8a8:   # the rows of each stream are gathered out of the joint buffer by the quantiser
+                quant8(_V(ao, B * S1, D), ax8, x_rpb=S1, x_bs=ST * D)
+                linear8(ax8, b + ".out", x, R=x, gate=m_at(kx, 2), rpb=S1)
+            else:
+                linear(_V(ao, B * S1, D), b + ".out", x, R=x, gate=m_at(kx, 2), rpb=S1, a_rpb=S1, a_bs=ST * D)
+            an_x(m_at(kx, 4), m_at(kx, 3))
+            lin(ax, b + ".ff1", ffx, flags=GELU_TANH)
+            if w8a8:
+                quant8(ffx, fx8)
+                linear8(fx8, b + ".ff2", x, R=x, gate=m_at(kx, 5), rpb=S1)
+            else:
+                linear(ffx, b + ".ff2", x, R=x, gate=m_at(kx, 5), rpb=S1)
             if not last:
-                linear(_V(ao + 2 * S1 * D, B * S2, D), b + ".out_c", c, R=c, gate=m_at(kc, 2), rpb=S2, a_rpb=S2,
-                       a_bs=ST * D)
-                adaln(c, m_at(kc, 4), m_at(kc, 3), S2, nc)
-                linear(nc, b + ".ff1_c", ffc, flags=GELU_TANH)
-                linear(ffc, b + ".ff2_c", c, R=c, gate=m_at(kc, 5), rpb=S2)
+                if w8a8:
+                    quant8(_V(ao + 2 * S1 * D, B * S2, D), ac8, x_rpb=S2, x_bs=ST * D)
+                    linear8(ac8, b + ".out_c", c, R=c, gate=m_at(kc, 2), rpb=S2)
+                else:
+                    linear(_V(ao + 2 * S1 * D, B * S2, D), b + ".out_c", c, R=c, gate=m_at(kc, 2), rpb=S2, a_rpb=S2,
+                           a_bs=ST * D)
+                an_c(m_at(kc, 4), m_at(kc, 3))
+                lin(ac, b + ".ff1_c", ffc, flags=GELU_TANH)
+                if w8a8:
+                    quant8(ffc, fc8)
+                    linear8(fc8, b + ".ff2_c", c, R=c, gate=m_at(kc, 5), rpb=S2)
+                else:
+                    linear(ffc, b + ".ff2_c", c, R=c, gate=m_at(kc, 5), rpb=S2)
 
         # ---- norm_out (scale, shift) + proj_out + unpatchify (transformer_sd3.py:341-356) ----
         adaln(x, m_at("norm_out", 0), m_at("norm_out", 1), S1, nx)

@@ -133,6 +133,65 @@ class Emulator:
         self._epilogue(acc, N, bias, None, 0, 0, None, 0, 1.0, flags, C, ldc)
         return 0
 
+    # ---- W8A8 ----
+    @staticmethod
+    def _q8(v):
+        sc = v.abs().amax(dim=1).clamp_min(1e-12) * (1.0 / 448.0)
+        return (v / sc[:, None]).to(torch.float8_e4m3fn), sc
+
+    @staticmethod
+    def _u8(ptr, rows, C, ld):
+        buf = (ctypes.c_char * ((rows - 1) * ld + C)).from_address(ptr)
+        return torch.frombuffer(buf, dtype=torch.uint8, count=(rows - 1) * ld + C).as_strided((rows, C), (ld, 1))
+
+    def mi355x_sd_adaln_f8(self, x, rows, C, ldx, scale, shift, ld_mod, rpb, eps, y8, ldy, y_scale, stream):
+        xv = _rows(x, rows, C, ldx).float()
+        nb = (rows + rpb - 1) // rpb
+        sc = _rows(scale, nb, C, ld_mod, torch.float32).repeat_interleave(rpb, 0)[:rows]
+        sh = _rows(shift, nb, C, ld_mod, torch.float32).repeat_interleave(rpb, 0)[:rows]
+        v = F.layer_norm(xv, (C,), eps=eps) * (1 + sc) + sh
+        q, s = self._q8(v)
+        self._u8(y8, rows, C, ldy).copy_(q.view(torch.uint8))
+        _flat(y_scale, rows, torch.float32).copy_(s)
+        return 0
+
+    def mi355x_sd_quantize_rows(self, x, rows, C, ldx, x_rpb, x_bs, y8, ldy, y_scale, stream):
+        if x_rpb:
+            nb = (rows + x_rpb - 1) // x_rpb
+            n = (nb - 1) * x_bs + (x_rpb - 1) * ldx + C
+            xv = _flat(x, n, torch.bfloat16).as_strided((nb, x_rpb, C), (x_bs, ldx, 1)).reshape(nb * x_rpb, C)[:rows].float()
+        else:
+            xv = _rows(x, rows, C, ldx).float()
+        q, s = self._q8(xv)
+        self._u8(y8, rows, C, ldy).copy_(q.view(torch.uint8))
+        _flat(y_scale, rows, torch.float32).copy_(s)
+        return 0
+
+    def mi355x_sd_linear_f8(self, A8, lda, a_rpb, a_bs, a_scale, W8, w_scale, C, ldc, c_rpb, c_bs, M, N, K, bias, gate, ld_gate,
+                            rpb, R, ldr, flags, stream):
+        self.calls.append("linear_f8")
+        assert K % 128 == 0 and not a_rpb
+        a = self._u8(A8, M, K, lda).view(torch.float8_e4m3fn).float()
+        w = self._u8(W8, N, K, K).view(torch.float8_e4m3fn).float()
+        acc = (a @ w.t()) * _flat(a_scale, M, torch.float32)[:, None] * _flat(w_scale, N, torch.float32)[None, :]
+        if bias:
+            acc = acc + _flat(bias, N, torch.float32)
+        if gate:
+            nb = (M + rpb - 1) // rpb
+            acc = acc * _rows(gate, nb, N, ld_gate, torch.float32).repeat_interleave(rpb, 0)[:M]
+        if R:
+            acc = acc + _rows(R, M, N, ldr).float()
+        if flags & GELU_TANH:
+            acc = F.gelu(acc, approximate="tanh")
+        if c_rpb:
+            nb = (M + c_rpb - 1) // c_rpb
+            n = (nb - 1) * c_bs + (c_rpb - 1) * ldc + N
+            dst = _flat(C, n, torch.bfloat16).as_strided((nb, c_rpb, N), (c_bs, ldc, 1))
+            dst.copy_(acc.reshape(nb, c_rpb, N).to(torch.bfloat16))
+        else:
+            _rows(C, M, N, ldc).copy_(acc.to(torch.bfloat16))
+        return 0
+
     def mi355x_sd_adaln(self, x, rows, C, ldx, scale, shift, ld_mod, rpb, eps, y, ldy, stream):
         self.calls.append("adaln")
         nb = rows // rpb

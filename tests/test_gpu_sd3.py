@@ -84,6 +84,59 @@ def test_fp8_weight_gemm(ops, M, N, K):
     assert _rel(out2.float().cpu(), F.gelu(ref, approximate="tanh")) < 4e-3
 
 
+def _q8(t):
+    """reference row quantisation: (e4m3 bytes, scale) with value = scale * q, scale = absmax / 448"""
+    sc = t.abs().amax(dim=1).clamp_min(1e-12) / 448.0
+    return (t / sc[:, None]).to(torch.float8_e4m3fn), sc
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1000, 520, 1536), (32768, 1536, 1536), (1232, 4608, 1536), (77, 64, 256)])
+def test_w8a8_gemm_on_fp8_mfma(ops, M, N, K):
+    """fp8 x fp8 on v_mfma_scale_f32_16x16x128_f8f6f4: products of e4m3 values are exact in fp32, so against the fp32
+    matmul of the SAME quantised operands only the accumulation order and the bf16 store differ."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g) * (1 + 3 * torch.rand(M, 1, generator=g))
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g) * 0.1
+    qa, sa = _q8(a)
+    qw, sw = _q8(w)
+    ref = (qa.float() @ qw.float().t()) * sa[:, None] * sw[None, :] + bias
+    out = ops.linear_f8(qa.view(torch.uint8).cuda(), sa.cuda(), qw.view(torch.uint8).cuda(), sw.cuda(), bias.cuda())
+    assert _rel(out.float().cpu(), ref) < 4e-3, _rel(out.float().cpu(), ref)
+    # gated residual + tanh-GELU epilogues
+    gate = torch.randn(2, N, generator=g)
+    res = bfr(torch.randn(M, N, generator=g))
+    if M % 2 == 0:
+        out2 = ops.linear_f8(qa.view(torch.uint8).cuda(), sa.cuda(), qw.view(torch.uint8).cuda(), sw.cuda(), bias.cuda(),
+                             gate=gate.cuda(), rows_per_batch=M // 2, residual=res.cuda().to(torch.bfloat16))
+        ref2 = res + gate.repeat_interleave(M // 2, 0) * ref
+        assert _rel(out2.float().cpu(), ref2) < 4e-3
+    out3 = ops.linear_f8(qa.view(torch.uint8).cuda(), sa.cuda(), qw.view(torch.uint8).cuda(), sw.cuda(), bias.cuda(), gelu_tanh=True)
+    assert _rel(out3.float().cpu(), F.gelu(ref, approximate="tanh")) < 4e-3
+    with pytest.raises(Exception):
+        ops.linear_f8(qa.view(torch.uint8).cuda()[:, :64].contiguous(), sa.cuda(), qw.view(torch.uint8).cuda()[:, :64].contiguous(), sw.cuda())
+
+
+def test_fp8_row_quantisers(ops):
+    """mi355x_sd_quantize_rows / mi355x_sd_adaln_f8 == the reference quantiser (same scales; bytes equal up to RNE ties)"""
+    g = torch.Generator().manual_seed(4)
+    x = bfr(torch.randn(300, 1536, generator=g) * 3)
+    q, sc = ops.quantize_rows(x.cuda().to(torch.bfloat16))
+    rq, rs = _q8(x)
+    assert torch.allclose(sc.cpu(), rs, rtol=1e-6)
+    deq = q.cpu().view(torch.float8_e4m3fn).float() * sc.cpu()[:, None]
+    assert _rel(deq, x) < 3e-2 and (q.cpu() != rq.view(torch.uint8)).float().mean() < 2e-3   # bytes equal up to rare ties
+    B, S, C = 2, 150, 1536
+    xx = bfr(torch.randn(B * S, C, generator=g) * 2 + 0.5)
+    mod = torch.randn(B, 2 * C, generator=g) * 0.3
+    ref = F.layer_norm(xx.reshape(B, S, C), (C,), eps=1e-6) * (1 + mod[:, None, C:]) + mod[:, None, :C]
+    md = mod.cuda()
+    q, sc = ops.adaln_f8(xx.cuda().to(torch.bfloat16), md[:, C:], md[:, :C], S)
+    deq = q.cpu().view(torch.float8_e4m3fn).float() * sc.cpu()[:, None]
+    rq, rs = _q8(ref.reshape(B * S, C))
+    assert torch.allclose(sc.cpu(), rs, rtol=1e-4) and _rel(deq, rq.float() * rs[:, None]) < 2e-2
+
+
 def test_patchify_roundtrip(ops):
     g = torch.Generator().manual_seed(9)
     x = torch.randn(2, 16, 8, 12, generator=g)
@@ -163,3 +216,20 @@ def test_mini_sd3_fp8_weights_vs_oracle():
     r = _rel(out.cpu(), ref)
     print(f"mini-sd3 fp8 weights: rel-L2 vs oracle(dequantised) {r:.3e}; quantisation alone {_rel(ref, full):.3e}")
     assert r < 2e-2, r
+
+
+def test_mini_sd3_w8a8_vs_fake_quant_oracle():
+    """BASELINE config 5 on the fp8 matrix pipe (W8A8): device vs the oracle fed the same quantised operands
+    (stated tolerance 3e-2: a flipped e4m3 rounding of an activation is a 6 % change of that element); the end-to-end
+    quantisation error against the fp32 model is printed."""
+    from paddlemix_amd.sd3 import synth_sd3_params
+    cfg = MINI_SD3
+    P = synth_sd3_params(cfg, 1234)
+    out, (x, enc, pooled) = _run(cfg, 2, 32, 32, 154, P, weight_dtype="fp8", act_dtype="fp8")
+    ref = R.sd3_forward(_fp8_roundtrip(P), cfg, x, enc, pooled, 501.0, act_quant=True)
+    full = R.sd3_forward(P, cfg, x, enc, pooled, 501.0)
+    r = _rel(out.cpu(), ref)
+    print(f"mini-sd3 W8A8: rel-L2 vs oracle(same quantised operands) {r:.3e}; total quantisation error {_rel(ref, full):.3e}")
+    assert r < 3e-2, r
+    eager, _ = _run(cfg, 2, 32, 32, 154, P, use_graph=False, weight_dtype="fp8", act_dtype="fp8")
+    assert torch.equal(eager, out)
