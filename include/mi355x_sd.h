@@ -96,9 +96,19 @@ int mi355x_sd_linear_f8(const void* A8, int lda, int a_rows_per_batch, int64_t a
                         const void* W8, const float* w_scale, void* C, int ldc, int c_rows_per_batch,
                         int64_t c_batch_stride, int M, int N, int K, const float* bias, const float* gate, int ld_gate,
                         int rows_per_batch, const void* R, int ldr, int flags, void* stream);
-/* mi355x_sd_adaln with the e4m3 quantisation fused: y8[row][C] bytes (row stride ldy bytes), y_scale[row]. */
+/* mi355x_sd_adaln with the e4m3 quantisation fused: y8[row][C] bytes (row stride ldy bytes), y_scale[row]; y_l2
+ * (optional) receives the row's L2 norm before quantisation (see mi355x_sd_linear_f8_q). */
 int mi355x_sd_adaln_f8(const void* x, int rows, int C, int ldx, const float* scale, const float* shift, int ld_mod,
-                       int rows_per_batch, float eps, void* y8, int ldy, float* y_scale, void* stream);
+                       int rows_per_batch, float eps, void* y8, int ldy, float* y_scale, float* y_l2, void* stream);
+/* W8A8 GEMM with an e4m3 OUTPUT for the next GEMM (ff.net.0 -> tanh-GELU -> ff.net.2 without a re-quantisation pass):
+ * C8[m][n] = e4m3(act(acc * a_scale[m] * w_scale[n] + bias[n]) / c_scale[m]). The output row scale needs no pass over
+ * the row: |acc + bias| <= a_l2[m] * w_norm_max + bias_abs_max (Cauchy-Schwarz; w_norm_max = max_n ||W[n]||_2 of the
+ * dequantised weights, a_l2 from mi355x_sd_adaln_f8), |gelu(x)| <= |x|, so c_scale[m] = 1.1 * that bound / 448 cannot
+ * overflow; e4m3 is a floating-point format, a scale that is ~10x loose costs precision only for elements ~100x below
+ * the typical magnitude. ldc in bytes, % 4. */
+int mi355x_sd_linear_f8_q(const void* A8, int lda, const float* a_scale, const float* a_l2, const void* W8,
+                          const float* w_scale, float w_norm_max, void* C8, int ldc, float* c_scale, int M, int N, int K,
+                          const float* bias, float bias_abs_max, int flags, void* stream);
 /* bf16 rows -> e4m3 rows + per-row scale (attention output in front of the output projections, GELU output in front
  * of ff.net.2). Source row m lives at (m / x_rows_per_batch) * x_batch_stride + (m % x_rows_per_batch) * ldx
  * (x_rows_per_batch = 0: plain m * ldx); the output rows and scales are compact. */

@@ -88,6 +88,13 @@ def fake_quant_rows(t: Tensor) -> Tensor:
     return (t / sc).to(torch.float8_e4m3fn).to(t.dtype) * sc
 
 
+def fake_quant_bound(t: Tensor, l2_in: Tensor, W: Tensor, bias: Tensor) -> Tensor:
+    """e4m3 fake quantisation with the device's bound-based row scale for the FF hidden activations
+    (include/mi355x_sd.h mi355x_sd_linear_f8_q): scale = 1.1 * (||input row||_2 * max_n ||W[:, n]||_2 + max|bias|) / 448."""
+    sc = (1.1 * (l2_in * W.norm(dim=0).max() + bias.abs().max())).clamp_min(1e-12)[..., None] * (1.0 / 448.0)
+    return (t / sc).to(torch.float8_e4m3fn).to(t.dtype) * sc
+
+
 def joint_block(P: Params, name: str, x: Tensor, c: Tensor, temb: Tensor, heads: int, context_pre_only: bool,
                 act_quant: bool = False):
     """JointTransformerBlock.forward (attention.py:164-214). ``act_quant``: fake-quantise the inputs of the eight block
@@ -121,17 +128,23 @@ def joint_block(P: Params, name: str, x: Tensor, c: Tensor, temb: Tensor, heads:
     attn_x = linear(P, name + ".attn.to_out.0", attn_x)
 
     x = x + gate_msa[:, None] * attn_x
-    nx = fq(layer_norm_noaffine(x) * (1 + scale_mlp[:, None]) + shift_mlp[:, None])
-    hx = F.gelu(linear(P, name + ".ff.net.0.proj", nx), approximate="tanh")
-    ff = linear(P, name + ".ff.net.2", fq(hx.to(torch.bfloat16).float()) if act_quant else hx)
+    nx = layer_norm_noaffine(x) * (1 + scale_mlp[:, None]) + shift_mlp[:, None]
+    l2 = nx.norm(dim=-1)
+    hx = F.gelu(linear(P, name + ".ff.net.0.proj", fq(nx)), approximate="tanh")
+    if act_quant:   # the device's ff.net.0 epilogue writes e4m3 with the bound-based scale
+        hx = fake_quant_bound(hx, l2, P[name + ".ff.net.0.proj.weight"], P[name + ".ff.net.0.proj.bias"])
+    ff = linear(P, name + ".ff.net.2", hx)
     x = x + gate_mlp[:, None] * ff
     if context_pre_only:
         return None, x
     attn_c = linear(P, name + ".attn.to_add_out", attn_c)
     c = c + c_gate_msa[:, None] * attn_c
-    nc = fq(layer_norm_noaffine(c) * (1 + c_scale_mlp[:, None]) + c_shift_mlp[:, None])
-    hc = F.gelu(linear(P, name + ".ff_context.net.0.proj", nc), approximate="tanh")
-    ffc = linear(P, name + ".ff_context.net.2", fq(hc.to(torch.bfloat16).float()) if act_quant else hc)
+    nc = layer_norm_noaffine(c) * (1 + c_scale_mlp[:, None]) + c_shift_mlp[:, None]
+    l2 = nc.norm(dim=-1)
+    hc = F.gelu(linear(P, name + ".ff_context.net.0.proj", fq(nc)), approximate="tanh")
+    if act_quant:
+        hc = fake_quant_bound(hc, l2, P[name + ".ff_context.net.0.proj.weight"], P[name + ".ff_context.net.0.proj.bias"])
+    ffc = linear(P, name + ".ff_context.net.2", hc)
     c = c + c_gate_mlp[:, None] * ffc
     return c, x
 

@@ -28,7 +28,9 @@ SIGNATURES = {
     "mi355x_sd_linear_f8": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64,
                                     c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "mi355x_sd_adaln_f8": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_int,
-                                   c_void_p, c_void_p]),
+                                   c_void_p, c_void_p, c_void_p]),
+    "mi355x_sd_linear_f8_q": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p,
+                                      c_int, c_int, c_int, c_void_p, c_float, c_int, c_void_p]),
     "mi355x_sd_quantize_rows": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int64, c_void_p, c_int, c_void_p, c_void_p]),
     "mi355x_sd_adaln": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_int,
                                 c_void_p]),

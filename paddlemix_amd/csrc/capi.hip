@@ -166,10 +166,26 @@ int mi355x_sd_linear_f8(const void* A8, int lda, int a_rows_per_batch, int64_t a
 }
 
 int mi355x_sd_adaln_f8(const void* x, int rows, int C, int ldx, const float* scale, const float* shift, int ld_mod,
-                       int rows_per_batch, float eps, void* y8, int ldy, float* y_scale, void* stream) {
+                       int rows_per_batch, float eps, void* y8, int ldy, float* y_scale, float* y_l2, void* stream) {
   if (!x || !scale || !shift || !y8 || !y_scale) return fail(SD_ERR_INVALID, "mi355x_sd_adaln_f8: null pointer");
   return finish(launch_adaln_f8((const bf16*)x, rows, C, ldx, scale, shift, ld_mod, rows_per_batch, eps, (unsigned char*)y8,
-                                ldy, y_scale, S(stream)), "mi355x_sd_adaln_f8");
+                                ldy, y_scale, y_l2, S(stream)), "mi355x_sd_adaln_f8");
+}
+
+int mi355x_sd_linear_f8_q(const void* A8, int lda, const float* a_scale, const float* a_l2, const void* W8,
+                          const float* w_scale, float w_norm_max, void* C8, int ldc, float* c_scale, int M, int N, int K,
+                          const float* bias, float bias_abs_max, int flags, void* stream) {
+  if (!A8 || !W8 || !C8 || !a_scale || !a_l2 || !w_scale || !c_scale)
+    return fail(SD_ERR_INVALID, "mi355x_sd_linear_f8_q: null pointer");
+  if (flags & ~MI355X_SD_GELU_TANH) return fail(SD_ERR_UNSUPPORTED, "mi355x_sd_linear_f8_q: only MI355X_SD_GELU_TANH is supported");
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = (const bf16*)A8; g.W = (const bf16*)W8; g.C = C8;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc;
+  g.ascale = a_scale; g.wscale = w_scale; g.bias = bias; g.out_scale = 1.0f;
+  g.out_f8 = 1; g.a_l2 = a_l2; g.w_norm_max = w_norm_max; g.bias_abs_max = bias_abs_max; g.oscale = c_scale;
+  g.gelu_tanh = (flags & MI355X_SD_GELU_TANH) ? 1 : 0;
+  return finish(launch_gemm_f8(g, S(stream)), "mi355x_sd_linear_f8_q");
 }
 
 int mi355x_sd_quantize_rows(const void* x, int64_t rows, int C, int ldx, int x_rows_per_batch, int64_t x_batch_stride,

@@ -157,9 +157,18 @@ template <int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue_f8(const GemmArgs& p, f32x4 (&acc)[TN][TM], int m_wave, int n_wave,
                                                  int lane) {
   const int nq = (lane >> 4) * 4;
-  float as[TM];
+  float as[TM], oinv[TM];
 #pragma unroll
-  for (int tm = 0; tm < TM; ++tm) as[tm] = p.ascale[min(m_wave + tm * 16 + (lane & 15), p.M - 1)];
+  for (int tm = 0; tm < TM; ++tm) {
+    const int mc = min(m_wave + tm * 16 + (lane & 15), p.M - 1);
+    as[tm] = p.ascale[mc];
+    oinv[tm] = 0.f;
+    if (p.out_f8) {   // safe row scale for the e4m3 output (1.1: the quantised operands may exceed their fp32 norms slightly)
+      const float bound = 1.1f * (p.a_l2[mc] * p.w_norm_max + p.bias_abs_max);
+      oinv[tm] = 448.0f / fmaxf(bound, 1e-12f);
+      if (n_wave == 0 && (lane >> 4) == 0 && m_wave + tm * 16 + (lane & 15) < p.M) p.oscale[mc] = fmaxf(bound, 1e-12f) * (1.0f / 448.0f);
+    }
+  }
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     const int m = m_wave + tm * 16 + (lane & 15);
@@ -186,8 +195,15 @@ __device__ __forceinline__ void gemm_epilogue_f8(const GemmArgs& p, f32x4 (&acc)
         v[2] = gelu_tanh_f(v[2]);
         v[3] = gelu_tanh_f(v[3]);
       }
-      u32x2 pk = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
-      *reinterpret_cast<u32x2*>(reinterpret_cast<bf16*>(p.C) + crow + n) = pk;
+      if (p.out_f8) {
+        int w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * oinv[tm], v[1] * oinv[tm], w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * oinv[tm], v[3] * oinv[tm], w, true);
+        *reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(p.C) + crow + n) = w;
+      } else {
+        u32x2 pk = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16*>(p.C) + crow + n) = pk;
+      }
     }
   }
 }

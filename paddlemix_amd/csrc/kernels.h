@@ -35,6 +35,12 @@ struct GemmArgs {
   int a_rpb;              // A row m lives at (m / a_rpb) * a_bstride + (m % a_rpb) * lda   (0: plain m * lda)
   long a_bstride;
   const float* wscale;    // W is fp8 e4m3 [N][K] (1 byte / element) with per-output-channel scale: acc *= wscale[n]
+  // W8A8 with an e4m3 OUTPUT (ff.net.0 -> ff.net.2): row scale from the Cauchy-Schwarz bound |out[m][n]| <= a_l2[m] *
+  // w_norm_max + bias_abs_max (no second pass over the row); C is bytes, oscale[m] receives the scale
+  int out_f8;
+  const float* a_l2;
+  float w_norm_max, bias_abs_max;
+  float* oscale;
   const float* ascale;    // W8A8: A and W are fp8 e4m3 (wscale per output channel, ascale per A row): acc *= ascale[m]*wscale[n]
   const float* rowstat;   // LayerNorm folded into the GEMM: per-row (rstd, -mean*rstd) from launch_row_stats and
   const float* wsum;      //   wsum[n] = sum_k W[n][k]: acc <- rstd[m]*acc - mean[m]*rstd[m]*wsum[n]   (before bias)
@@ -77,7 +83,7 @@ int launch_scale_shift_act(const bf16* x, int B, int HW, int C, int ldx, const f
 int launch_adaln(const bf16* x, int rows, int C, int ldx, const float* scale, const float* shift, int ld_mod,
                  int rows_per_batch, float eps, bf16* y, int ldy, hipStream_t stream);
 int launch_adaln_f8(const bf16* x, int rows, int C, int ldx, const float* scale, const float* shift, int ld_mod,
-                    int rows_per_batch, float eps, unsigned char* y8, int ldy, float* yscale, hipStream_t stream);
+                    int rows_per_batch, float eps, unsigned char* y8, int ldy, float* yscale, float* yl2, hipStream_t stream);
 int launch_quantize_rows(const bf16* x, long rows, int C, int ldx, int x_rpb, long x_bstride, unsigned char* y8, int ldy,
                          float* yscale, hipStream_t stream);
 int launch_patchify(const float* x_nchw, int B, int C, int H, int W, int p, bf16* out, int ldo, hipStream_t stream);

@@ -588,7 +588,8 @@ template <int NCH>
 __global__ __launch_bounds__(256) void adaln_f8_kernel(const bf16* __restrict__ x, int rows, int C, int ldx,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        int ld_mod, int rows_per_batch, float eps,
-                                                       unsigned char* __restrict__ y8, int ldy, float* __restrict__ yscale) {
+                                                       unsigned char* __restrict__ y8, int ldy, float* __restrict__ yscale,
+                                                       float* __restrict__ yl2) {
   const int lane = threadIdx.x & 63;
   const int wave_g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * (blockDim.x >> 6);
@@ -625,7 +626,7 @@ __global__ __launch_bounds__(256) void adaln_f8_kernel(const bf16* __restrict__ 
     const int bidx = row / rows_per_batch;
     const float* sc = scale + (size_t)bidx * ld_mod;
     const float* sh = shift + (size_t)bidx * ld_mod;
-    float amax = 0.f;
+    float amax = 0.f, sq = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int cc = lane + 64 * i;
@@ -634,12 +635,17 @@ __global__ __launch_bounds__(256) void adaln_f8_kernel(const bf16* __restrict__ 
         for (int j = 0; j < 8; ++j) {
           v[i][j] = __builtin_fmaf((v[i][j] - mean) * rstd, 1.0f + sc[cc * 8 + j], sh[cc * 8 + j]);
           amax = fmaxf(amax, fabsf(v[i][j]));
+          sq = __builtin_fmaf(v[i][j], v[i][j], sq);
         }
       }
     }
     amax = wave_max(amax);
+    sq = wave_sum(sq);
     const float qs = fmaxf(amax, 1e-12f) * (1.0f / 448.0f), inv = 1.0f / qs;
-    if (lane == 0) yscale[row] = qs;
+    if (lane == 0) {
+      yscale[row] = qs;
+      if (yl2) yl2[row] = sqrtf(sq);   // row L2 norm: bounds every output of the consuming GEMM (Cauchy-Schwarz)
+    }
     unsigned char* yr = y8 + (size_t)row * ldy;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
@@ -654,7 +660,7 @@ __global__ __launch_bounds__(256) void adaln_f8_kernel(const bf16* __restrict__ 
 }
 
 int launch_adaln_f8(const bf16* x, int rows, int C, int ldx, const float* scale, const float* shift, int ld_mod,
-                    int rows_per_batch, float eps, unsigned char* y8, int ldy, float* yscale, hipStream_t stream) {
+                    int rows_per_batch, float eps, unsigned char* y8, int ldy, float* yscale, float* yl2, hipStream_t stream) {
   if (rows <= 0 || C <= 0 || rows_per_batch <= 0) return SD_ERR_INVALID;
   if ((C & 7) || (ldx & 7) || (ldy & 7) || (ld_mod & 3) || C > 2560) return SD_ERR_UNSUPPORTED;
   const int cv = C >> 3;
@@ -662,7 +668,7 @@ int launch_adaln_f8(const bf16* x, int rows, int C, int ldx, const float* scale,
   if (blocks > 2048) blocks = 2048;
 #define SD_AF8(NCH) \
   hipLaunchKernelGGL((adaln_f8_kernel<NCH>), dim3(blocks), dim3(256), 0, stream, x, rows, C, ldx, scale, shift, ld_mod, \
-                     rows_per_batch, eps, y8, ldy, yscale)
+                     rows_per_batch, eps, y8, ldy, yscale, yl2)
   if (cv <= 128) SD_AF8(2);
   else if (cv <= 192) SD_AF8(3);
   else SD_AF8(5);

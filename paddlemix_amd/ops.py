@@ -427,15 +427,35 @@ def quantize_rows(x: Tensor):
 
 
 def adaln_f8(x: Tensor, scale: Tensor, shift: Tensor, rows_per_batch: int, eps: float = 1e-6):
-    """adaln() with fused e4m3 quantisation -> (uint8 [rows, C], fp32 scale [rows])."""
+    """adaln() with fused e4m3 quantisation -> (uint8 [rows, C], fp32 scale [rows], fp32 row L2 norm [rows])."""
     lib = _lib.load()
     ldx = _rows(x, "x")
     rows, C = x.shape
     y = torch.empty((rows, C), device=x.device, dtype=torch.uint8)
     sc = torch.empty((rows,), device=x.device, dtype=torch.float32)
+    l2 = torch.empty((rows,), device=x.device, dtype=torch.float32)
     check(lib.mi355x_sd_adaln_f8(x.data_ptr(), rows, C, ldx, scale.data_ptr(), shift.data_ptr(), scale.stride(0), rows_per_batch,
-                                 float(eps), y.data_ptr(), C, sc.data_ptr(), _stream()))
-    return y, sc
+                                 float(eps), y.data_ptr(), C, sc.data_ptr(), l2.data_ptr(), _stream()))
+    return y, sc, l2
+
+
+def linear_f8_q(a8: Tensor, a_scale: Tensor, a_l2: Tensor, w8: Tensor, w_scale: Tensor, w_norm_max: float,
+                bias: Optional[Tensor] = None, bias_abs_max: float = 0.0, *, gelu_tanh: bool = False):
+    """W8A8 GEMM with an e4m3 output -> (uint8 [M, N], fp32 scale [M]); row scale = 1.1 * (a_l2 * w_norm_max +
+    bias_abs_max) / 448 (include/mi355x_sd.h mi355x_sd_linear_f8_q)."""
+    lib = _lib.load()
+    M, K = a8.shape
+    N = w8.shape[0]
+    for t, nm in ((a8, "a8"), (w8, "w8")):
+        if t.dtype != torch.uint8 or not t.is_cuda or t.stride(1) != 1:
+            raise ValueError(f"{nm}: expected uint8 (e4m3 bytes) cuda rows")
+    out = torch.empty((M, N), device=a8.device, dtype=torch.uint8)
+    sc = torch.empty((M,), device=a8.device, dtype=torch.float32)
+    check(lib.mi355x_sd_linear_f8_q(a8.data_ptr(), a8.stride(0), _vec(a_scale, M, "a_scale").data_ptr(),
+                                    _vec(a_l2, M, "a_l2").data_ptr(), w8.data_ptr(), _vec(w_scale, N, "w_scale").data_ptr(),
+                                    float(w_norm_max), out.data_ptr(), N, sc.data_ptr(), M, N, K, _p(_vec(bias, N, "bias")),
+                                    float(bias_abs_max), GELU_TANH if gelu_tanh else 0, _stream()))
+    return out, sc
 
 
 def linear_f8(a8: Tensor, a_scale: Tensor, w8: Tensor, w_scale: Tensor, bias: Optional[Tensor] = None, *,

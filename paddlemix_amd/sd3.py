@@ -169,6 +169,7 @@ class SD3Transformer2DModel(DeviceProgram, PretrainedMixin):
             return t.to(device=dev, dtype=torch.float32)
 
         bf = lambda t: t.to(torch.bfloat16).contiguous()  # noqa: E731
+        self._bounds: Dict[str, tuple] = {}
 
         def put_lin(key, name):
             W[key + ".w"] = bf(get(name + ".weight").t())
@@ -178,6 +179,10 @@ class SD3Transformer2DModel(DeviceProgram, PretrainedMixin):
             """block matrix [N, K]: bf16, or fp8 e4m3 bytes + per-row scale"""
             if self.weight_dtype == "fp8":
                 W[key + ".w"], W[key + ".s"] = quantize_fp8_rows(wt)
+                # output bound of this layer for mi355x_sd_linear_f8_q: (max_n ||W[n]||_2 of the weights the device
+                # multiplies by, max |bias|)
+                self._bounds[key] = (float(dequantize_fp8_rows(W[key + ".w"], W[key + ".s"]).norm(dim=1).max()),
+                                     float(bias.abs().max()))
             else:
                 W[key + ".w"] = bf(wt)
             W[key + ".b"] = bias.contiguous()
@@ -272,13 +277,23 @@ class SD3Transformer2DModel(DeviceProgram, PretrainedMixin):
 
         w8a8 = self.act_dtype == "fp8"
 
-        class _Q:   # e4m3 row view: bytes at p (row stride ld bytes) + one fp32 scale per row at s
+        class _Q:   # e4m3 row view: bytes at p (row stride ld bytes) + one fp32 scale per row at s (+ row L2 norms at l2)
             def __init__(q, name, rows, C):
                 q.p, q.s, q.rows, q.C, q.ld = sc(name + "8", rows * C), sc(name + "8s", 4 * rows), rows, C, C
+                q.l2 = sc(name + "8n", 4 * rows)
 
         def adaln8(x: _V, scale_ptr, shift_ptr, rpb, out):
             emit(lib.mi355x_sd_adaln_f8, (x.p, x.rows, x.C, x.ld, scale_ptr, shift_ptr, MT, rpb, 1e-6, out.p, out.ld, out.s,
-                                          stream), "ln")
+                                          out.l2, stream), "ln")
+
+        def linear8q(a, wkey: str, out, *, flags=0):
+            """W8A8 GEMM whose output is e4m3 again (row scale from the layer's output bound, no re-quantisation pass)"""
+            w = W[wkey + ".w"]
+            N, K = w.shape
+            wn, bm = self._bounds[wkey]
+            emit(lib.mi355x_sd_linear_f8_q,
+                 (a.p, a.ld, a.s, a.l2, w.data_ptr(), W[wkey + ".s"].data_ptr(), wn, out.p, out.ld, out.s, a.rows, N, K,
+                  W[wkey + ".b"].data_ptr(), bm, flags, stream), "gemm", 2.0 * a.rows * N * K, f"{a.rows}x{N}x{K}f8q")
 
         def quant8(x: _V, out, x_rpb=0, x_bs=0):
             emit(lib.mi355x_sd_quantize_rows, (x.p, x.rows, x.C, x.ld, x_rpb, x_bs, out.p, out.ld, out.s, stream), "ln")
@@ -375,11 +390,11 @@ class SD3Transformer2DModel(DeviceProgram, PretrainedMixin):
             else:
                 linear(_V(ao, B * S1, D), b + ".out", x, R=x, gate=m_at(kx, 2), rpb=S1, a_rpb=S1, a_bs=ST * D)
             an_x(m_at(kx, 4), m_at(kx, 3))
-            lin(ax, b + ".ff1", ffx, flags=GELU_TANH)
-            if w8a8:
-                quant8(ffx, fx8)
+            if w8a8:   # ff.net.0 writes e4m3 for ff.net.2 directly
+                linear8q(nx8, b + ".ff1", fx8, flags=GELU_TANH)
                 linear8(fx8, b + ".ff2", x, R=x, gate=m_at(kx, 5), rpb=S1)
             else:
+                linear(nx, b + ".ff1", ffx, flags=GELU_TANH)
                 linear(ffx, b + ".ff2", x, R=x, gate=m_at(kx, 5), rpb=S1)
             if not last:
                 if w8a8:
@@ -389,11 +404,11 @@ class SD3Transformer2DModel(DeviceProgram, PretrainedMixin):
                     linear(_V(ao + 2 * S1 * D, B * S2, D), b + ".out_c", c, R=c, gate=m_at(kc, 2), rpb=S2, a_rpb=S2,
                            a_bs=ST * D)
                 an_c(m_at(kc, 4), m_at(kc, 3))
-                lin(ac, b + ".ff1_c", ffc, flags=GELU_TANH)
                 if w8a8:
-                    quant8(ffc, fc8)
+                    linear8q(nc8, b + ".ff1_c", fc8, flags=GELU_TANH)
                     linear8(fc8, b + ".ff2_c", c, R=c, gate=m_at(kc, 5), rpb=S2)
                 else:
+                    linear(nc, b + ".ff1_c", ffc, flags=GELU_TANH)
                     linear(ffc, b + ".ff2_c", c, R=c, gate=m_at(kc, 5), rpb=S2)
 
         # ---- norm_out (scale, shift) + proj_out + unpatchify (transformer_sd3.py:341-356) ----

@@ -144,7 +144,7 @@ class Emulator:
         buf = (ctypes.c_char * ((rows - 1) * ld + C)).from_address(ptr)
         return torch.frombuffer(buf, dtype=torch.uint8, count=(rows - 1) * ld + C).as_strided((rows, C), (ld, 1))
 
-    def mi355x_sd_adaln_f8(self, x, rows, C, ldx, scale, shift, ld_mod, rpb, eps, y8, ldy, y_scale, stream):
+    def mi355x_sd_adaln_f8(self, x, rows, C, ldx, scale, shift, ld_mod, rpb, eps, y8, ldy, y_scale, y_l2, stream):
         xv = _rows(x, rows, C, ldx).float()
         nb = (rows + rpb - 1) // rpb
         sc = _rows(scale, nb, C, ld_mod, torch.float32).repeat_interleave(rpb, 0)[:rows]
@@ -153,6 +153,24 @@ class Emulator:
         q, s = self._q8(v)
         self._u8(y8, rows, C, ldy).copy_(q.view(torch.uint8))
         _flat(y_scale, rows, torch.float32).copy_(s)
+        if y_l2:
+            _flat(y_l2, rows, torch.float32).copy_(v.norm(dim=1))
+        return 0
+
+    def mi355x_sd_linear_f8_q(self, A8, lda, a_scale, a_l2, W8, w_scale, w_norm_max, C8, ldc, c_scale, M, N, K, bias,
+                              bias_abs_max, flags, stream):
+        self.calls.append("linear_f8_q")
+        assert K % 128 == 0 and ldc % 4 == 0
+        a = self._u8(A8, M, K, lda).view(torch.float8_e4m3fn).float()
+        w = self._u8(W8, N, K, K).view(torch.float8_e4m3fn).float()
+        acc = (a @ w.t()) * _flat(a_scale, M, torch.float32)[:, None] * _flat(w_scale, N, torch.float32)[None, :]
+        if bias:
+            acc = acc + _flat(bias, N, torch.float32)
+        if flags & GELU_TANH:
+            acc = F.gelu(acc, approximate="tanh")
+        sc = (1.1 * (_flat(a_l2, M, torch.float32) * w_norm_max + bias_abs_max)).clamp_min(1e-12) * (1.0 / 448.0)
+        self._u8(C8, M, N, ldc).copy_((acc / sc[:, None]).to(torch.float8_e4m3fn).view(torch.uint8))
+        _flat(c_scale, M, torch.float32).copy_(sc)
         return 0
 
     def mi355x_sd_quantize_rows(self, x, rows, C, ldx, x_rpb, x_bs, y8, ldy, y_scale, stream):

@@ -131,10 +131,37 @@ def test_fp8_row_quantisers(ops):
     mod = torch.randn(B, 2 * C, generator=g) * 0.3
     ref = F.layer_norm(xx.reshape(B, S, C), (C,), eps=1e-6) * (1 + mod[:, None, C:]) + mod[:, None, :C]
     md = mod.cuda()
-    q, sc = ops.adaln_f8(xx.cuda().to(torch.bfloat16), md[:, C:], md[:, :C], S)
+    q, sc, l2 = ops.adaln_f8(xx.cuda().to(torch.bfloat16), md[:, C:], md[:, :C], S)
     deq = q.cpu().view(torch.float8_e4m3fn).float() * sc.cpu()[:, None]
     rq, rs = _q8(ref.reshape(B * S, C))
     assert torch.allclose(sc.cpu(), rs, rtol=1e-4) and _rel(deq, rq.float() * rs[:, None]) < 2e-2
+    assert torch.allclose(l2.cpu(), ref.reshape(B * S, C).norm(dim=1), rtol=2e-3)
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 6144, 1536), (1232, 6144, 1536), (300, 520, 256)])
+def test_w8a8_gemm_fp8_output(ops, M, N, K):
+    """mi355x_sd_linear_f8_q: e4m3 output with the Cauchy-Schwarz row scale -- scales are exactly the stated bound, no
+    element saturates, and the dequantised output is the GEMM result to e4m3 precision."""
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, K, generator=g) * (1 + 3 * torch.rand(M, 1, generator=g))
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g) * 0.1
+    qa, sa = _q8(a)
+    qw, sw = _q8(w)
+    l2 = a.norm(dim=1)
+    wn = float((qw.float() * sw[:, None]).norm(dim=1).max())
+    bm = float(bias.abs().max())
+    ref = F.gelu((qa.float() @ qw.float().t()) * sa[:, None] * sw[None, :] + bias, approximate="tanh")
+    q, sc = ops.linear_f8_q(qa.view(torch.uint8).cuda(), sa.cuda(), l2.cuda(), qw.view(torch.uint8).cuda(), sw.cuda(), wn,
+                            bias.cuda(), bm, gelu_tanh=True)
+    rsc = 1.1 * (l2 * wn + bm) / 448.0
+    assert torch.allclose(sc.cpu(), rsc, rtol=1e-5)
+    qf = q.cpu().view(torch.float8_e4m3fn).float()
+    assert torch.isfinite(qf).all() and qf.abs().max() < 448.0 and (ref.abs() / rsc[:, None]).max() < 448.0
+    rq = (ref / rsc[:, None]).to(torch.float8_e4m3fn)
+    assert (q.cpu() != rq.view(torch.uint8)).float().mean() < 2e-2   # accumulation-order differences flip rare ties
+    assert _rel(qf * sc.cpu()[:, None], ref) < 4e-2
+
 
 
 def test_patchify_roundtrip(ops):
