@@ -105,7 +105,7 @@ int mi355x_sd_adaln_f8(const void* x, int rows, int C, int ldx, const float* sca
  * the row: |acc + bias| <= a_l2[m] * w_norm_max + bias_abs_max (Cauchy-Schwarz; w_norm_max = max_n ||W[n]||_2 of the
  * dequantised weights, a_l2 from mi355x_sd_adaln_f8), |gelu(x)| <= |x|, so c_scale[m] = 1.1 * that bound / 448 cannot
  * overflow; e4m3 is a floating-point format, a scale that is ~10x loose costs precision only for elements ~100x below
- * the typical magnitude. ldc in bytes, % 4. */
+ * the typical magnitude. ldc in bytes, % 8. */
 int mi355x_sd_linear_f8_q(const void* A8, int lda, const float* a_scale, const float* a_l2, const void* W8,
                           const float* w_scale, float w_norm_max, void* C8, int ldc, float* c_scale, int M, int N, int K,
                           const float* bias, float bias_abs_max, int flags, void* stream);

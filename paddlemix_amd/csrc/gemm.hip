@@ -92,7 +92,7 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_bf16_kernel(const GemmAr
   const int w_cg = W8 ? ((lane & 3) ^ ((lane >> 4) & 3)) : g_cg;               // source 16-B chunk (swizzled)
 #pragma unroll
   for (int i = 0; i < W_PIECES; ++i) {
-    const int n = n0 + (wave + i * CFG::NW) * (W8 ? 16 : 8) + w_sub;
+    const int n = n0 + w_row_of_lds_row<TN>((wave + i * CFG::NW) * (W8 ? 16 : 8) + w_sub, p.geglu);   // epilogue-friendly order
     gw_ok[i] = n < p.N;
     gw_base[i] = reinterpret_cast<const unsigned char*>(p.W) + (size_t)(gw_ok[i] ? n : 0) * p.K * (W8 ? 1 : 2) + w_cg * 16;
   }
@@ -203,14 +203,13 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_bf16_kernel(const GemmAr
 
   if (p.splitk > 1) {   // raw partial sums -> ws[split][m][n]; the epilogue runs in splitk_reduce_kernel
     float* ws = p.ws + (size_t)blockIdx.y * p.M * p.N;
-    const int nq = (lane >> 4) * 4;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       const int m = m0 + wm * (TM * 16) + tm * 16 + (lane & 15);
       if (m >= p.M) continue;
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
-        const int n = n0 + wn * (TN * 16) + tn * 16 + nq;
+        const int n = n0 + wn * (TN * 16) + acc_col<TN>(tn, lane >> 4, p.geglu);
         if (n < p.N) *reinterpret_cast<f32x4*>(ws + (size_t)m * p.N + n) = acc[tn][tm];
       }
     }
@@ -225,13 +224,13 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_bf16_kernel(const GemmAr
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m_wave = blockIdx.x * 16, n_wave = blockIdx.y * 128 + wave * 32;
-  const int m = m_wave + (lane & 15), nq = (lane >> 4) * 4;
+  const int m = m_wave + (lane & 15);
   f32x4 acc[2][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}, {f32x4{0.f, 0.f, 0.f, 0.f}}};
   if (m < p.M) {
     const size_t slice = (size_t)p.M * p.N;
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
-      const int n = n_wave + tn * 16 + nq;
+      const int n = n_wave + acc_col<2>(tn, lane >> 4, p.geglu);
       if (n >= p.N) continue;
       const float* src = p.ws + (size_t)m * p.N + n;
 #pragma unroll 4
@@ -336,6 +335,7 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
     if ((long)a.M % ((long)a.Ho * a.Wo) != 0) return SD_ERR_INVALID;
   }
   if (a.rowbias && a.rows_per_batch <= 0) return SD_ERR_INVALID;
+  a.c_wide = !a.out_f32 && !(reinterpret_cast<uintptr_t>(a.C) & 15) && !(a.ldc & 7) && !(a.c_bstride & 7);
   const int tile = pick_tile(a);
   if (tile == 128) plan_splitk(a, 128, 128);
   if (a.rowstat && (a.conv || a.wscale || a.a_rpb || a.c_rpb || a.R || a.rowbias || a.gate || !a.wsum))

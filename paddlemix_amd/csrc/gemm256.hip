@@ -109,7 +109,7 @@ __global__ __launch_bounds__(g256::THREADS, 2) void gemm256_kernel(const GemmArg
       oy[i] = ox[i] = 0;
       a_img[i] = 0;
     }
-    const int n = n0 + r;
+    const int n = n0 + w_row_of_lds_row<4>(r, p.geglu);   // epilogue-friendly channel order (gemm_epilogue.h)
     w_off32[i] = (n < p.N) ? (unsigned)((size_t)n * p.K * ES + cg * 16) : OOB;
   }
   int kA[2] = {0, 0}, kB[2] = {0, 0};              // next K offset (elements) of each half-tile stream
@@ -307,7 +307,10 @@ int launch_gemm256(const GemmArgs& a, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
 
-int launch_gemm_f8(const GemmArgs& a, hipStream_t stream) {
+int launch_gemm_f8(const GemmArgs& a_in, hipStream_t stream) {
+  GemmArgs a = a_in;
+  a.c_wide = !a.out_f8 && !(reinterpret_cast<uintptr_t>(a.C) & 15) && !(a.ldc & 7) && !(a.c_bstride & 7);
+  if (a.out_f8 && ((a.ldc & 7) || a.c_rpb || a.R || a.gate)) return SD_ERR_UNSUPPORTED;   // 8-byte e4m3 stores
   if (a.M <= 0 || a.N <= 0 || a.K <= 0 || !a.ascale || !a.wscale) return SD_ERR_INVALID;
   // K-tiles of 128 bytes with no in-row tail; 16-byte aligned rows; 32-bit byte offsets
   if ((a.K & 127) || (a.N & 3) || (a.lda & 15) || (a.ldc & 3) || a.conv || a.geglu || a.out_f32 || a.rowbias || a.rowstat ||

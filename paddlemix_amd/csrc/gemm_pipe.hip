@@ -97,7 +97,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES) void gemm_pipe_kernel
   }
 #pragma unroll
   for (int i = 0; i < WP; ++i) {
-    const int n = n0 + (wave + i * NW) * 8 + sub;
+    const int n = n0 + w_row_of_lds_row<TN>((wave + i * NW) * 8 + sub, p.geglu);   // epilogue-friendly channel order
     w_off[i] = (n < p.N) ? (unsigned)(((size_t)n * p.K + cg * 8) * 2) : OOB;
   }
   int mine = 0;   // LDS-DMA instructions this wave issues per K-tile (the last waves may own one piece fewer)
@@ -276,14 +276,13 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES) void gemm_pipe_kernel
   const int m_w = m0 + wm * (TM * 16), n_w = n0 + wn * (TN * 16);
   if (p.splitk > 1) {   // raw partial sums -> ws[split][m][n]; the epilogue runs in splitk_reduce_kernel (gemm.hip)
     float* ws = p.ws + (size_t)blockIdx.y * p.M * p.N;
-    const int nq = (lane >> 4) * 4;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       const int m = m_w + tm * 16 + (lane & 15);
       if (m >= p.M) continue;
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
-        const int n = n_w + tn * 16 + nq;
+        const int n = n_w + acc_col<TN>(tn, lane >> 4, p.geglu);
         if (n < p.N) *reinterpret_cast<f32x4*>(ws + (size_t)m * p.N + n) = acc[tn][tm];
       }
     }

@@ -37,6 +37,7 @@ struct GemmArgs {
   const float* wscale;    // W is fp8 e4m3 [N][K] (1 byte / element) with per-output-channel scale: acc *= wscale[n]
   // W8A8 with an e4m3 OUTPUT (ff.net.0 -> ff.net.2): row scale from the Cauchy-Schwarz bound |out[m][n]| <= a_l2[m] *
   // w_norm_max + bias_abs_max (no second pass over the row); C is bytes, oscale[m] receives the scale
+  int c_wide;             // C rows allow 16-byte stores (set by launch_gemm / launch_gemm_f8)
   int out_f8;
   const float* a_l2;
   float w_norm_max, bias_abs_max;
