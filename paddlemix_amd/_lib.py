@@ -8,7 +8,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p, POINTER
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi355x_sd.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 GEGLU, OUT_F32, SILU, GELU_TANH = 1, 2, 4, 8
 
 # name -> (restype, argtypes); must list every symbol include/mi355x_sd.h declares (tests/test_abi.py checks)
