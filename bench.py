@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"],
+                    help="16-bit element type = which build of the library runs (bf16: BASELINE.json's configurations; "
+                         "fp16: same MFMA rate, ~6x tighter parity)")
     return ap.parse_args()
 
 
@@ -96,9 +99,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
+    from paddlemix_amd import _lib
+    _lib.set_elem_dtype(args.dtype)   # before anything loads the library
     from paddlemix_amd.schedulers import EulerDiscreteScheduler, FlowMatchEulerDiscreteScheduler
     from paddlemix_amd.unet import UNet2DConditionModel, synth_unet_params, unet_param_shapes
-    from paddlemix_amd import _lib
     is_sd3 = bool(WORKLOADS[args.workload].get("sd3"))
     if is_sd3:
         from paddlemix_amd.sd3 import SD3Transformer2DModel as UNet2DConditionModel  # same program interface
@@ -213,11 +217,11 @@ def main():
                    "sd3-1024-bs8-w8a8": "MMDiT denoising steps/sec (SD3-medium 1024^2, bs=8, fp8 weights + activations, fp8 MFMA)"}[args.workload],
         "value": world * args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": args.workload, "latents": [B, cfg["in_channels"] if is_sd3 else 4, H, W], "text": [B, L, cfg["joint_attention_dim" if is_sd3 else "cross_attention_dim"]],
                    "batch_per_gpu": B, "global_batch": B * world, "scheduler": "FlowMatchEuler/28" if is_sd3 else "EulerDiscrete/30",
-                   "weights": "random-init bf16 (N(0,1/fan_in)), RCCL-broadcast from rank 0" if world > 1
-                   else "random-init bf16 (N(0,1/fan_in))",
+                   "weights": f"random-init {args.dtype} (N(0,1/fan_in)), RCCL-broadcast from rank 0" if world > 1
+                   else f"random-init {args.dtype} (N(0,1/fan_in))",
                    "parallelism": f"prompt-sharded dp{world}, no per-step collective", "hipgraph": not args.no_graph},
         "tflops_effective": world * args.steps * wl["gflop_step"] / 1e3 / elapsed,
     }

@@ -28,13 +28,20 @@
 extern "C" {
 #endif
 
-#define MI355X_SD_ABI_VERSION 5
+#define MI355X_SD_ABI_VERSION 6
 #define MI355X_SD_OK 0
 #define MI355X_SD_ERR_INVALID 1      /* bad argument (shape <= 0, null pointer ...)          */
 #define MI355X_SD_ERR_UNSUPPORTED 2  /* well-formed but outside the implemented configurations */
 #define MI355X_SD_ERR_HIP 3          /* HIP runtime error; see mi355x_sd_last_error()          */
 
 int mi355x_sd_abi_version(void);
+/* 16-bit element type of this build: the library comes in two builds of the same sources, libmi355x_sd.so (bfloat16,
+ * the dtype of BASELINE.json's configurations) and libmi355x_sd_f16.so (IEEE half: same speed, 3 more mantissa bits,
+ * the dtype the reference's own GPU pipelines default to -- paddle_dtype=paddle.float16). Wherever this header says
+ * "bf16" read "the element type of the build". */
+#define MI355X_SD_ELEM_BF16 0
+#define MI355X_SD_ELEM_F16 1
+int mi355x_sd_elem_dtype(void);
 const char* mi355x_sd_last_error(void);
 /* Selects `device` and verifies it is a gfx950 part. */
 int mi355x_sd_init(int device);

@@ -6,14 +6,24 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355x_sd.so")
 
-ABI_VERSION = 5
+# The library comes in two builds of the same sources (include/mi355x_sd.h, mi355x_sd_elem_dtype): bfloat16 elements
+# (default; the dtype BASELINE.json's configurations name) and IEEE-half elements (MI355X_SD_DTYPE=fp16 or
+# set_elem_dtype("fp16") before the first load: same speed, 3 more mantissa bits -> ~6x tighter parity). One element
+# type per process.
+_BUILDS = {"bf16": ("libmi355x_sd.so", 0), "fp16": ("libmi355x_sd_f16.so", 1)}
+ELEM_NAME = os.environ.get("MI355X_SD_DTYPE", "bf16")
+if ELEM_NAME not in _BUILDS:
+    raise ValueError(f"MI355X_SD_DTYPE must be one of {sorted(_BUILDS)}, got {ELEM_NAME!r}")
+LIB_PATH = os.path.join(_HERE, _BUILDS[ELEM_NAME][0])
+
+ABI_VERSION = 6
 GEGLU, OUT_F32, SILU, GELU_TANH = 1, 2, 4, 8
 
 # name -> (restype, argtypes); must list every symbol include/mi355x_sd.h declares (tests/test_abi.py checks)
 SIGNATURES = {
     "mi355x_sd_abi_version": (c_int, []),
+    "mi355x_sd_elem_dtype": (c_int, []),
     "mi355x_sd_last_error": (c_char_p, []),
     "mi355x_sd_set_workspace": (c_int, [c_void_p, ctypes.c_size_t]),
     "mi355x_sd_init": (c_int, [c_int]),
@@ -80,6 +90,23 @@ class MI355XError(RuntimeError):
     pass
 
 
+def set_elem_dtype(name: str) -> None:
+    """Select the library build ("bf16" | "fp16"). Must happen before the library is first loaded."""
+    global ELEM_NAME, LIB_PATH
+    if name not in _BUILDS:
+        raise ValueError(f"element dtype must be one of {sorted(_BUILDS)}, got {name!r}")
+    if _lib is not None and name != ELEM_NAME:
+        raise MI355XError(f"library already loaded with {ELEM_NAME} elements; one element type per process")
+    ELEM_NAME = name
+    LIB_PATH = os.path.join(_HERE, _BUILDS[name][0])
+
+
+def elem_dtype():
+    """torch dtype of the 16-bit activations / weights of the selected build"""
+    import torch
+    return torch.float16 if ELEM_NAME == "fp16" else torch.bfloat16
+
+
 def load() -> ctypes.CDLL:
     """Load the HIP library.  No fallback: a missing/unbuilt library is a hard error."""
     global _lib
@@ -96,6 +123,8 @@ def load() -> ctypes.CDLL:
         fn.argtypes = args
     if lib.mi355x_sd_abi_version() != ABI_VERSION:
         raise MI355XError(f"ABI mismatch: library {lib.mi355x_sd_abi_version()} != binding {ABI_VERSION}")
+    if lib.mi355x_sd_elem_dtype() != _BUILDS[ELEM_NAME][1]:
+        raise MI355XError(f"{LIB_PATH} was not built for {ELEM_NAME} elements")
     _lib = lib
     return lib
 

@@ -55,7 +55,7 @@ def scaled_dot_product_attention_(query: Tensor, key: Tensor, value: Tensor, att
         if m.shape[-1] != Skv or any(s not in (1, f) for s, f in zip(m.shape[:3], (B, H, Sq))):
             raise ValueError(f"attn_mask of shape {tuple(attn_mask.shape)} is not broadcastable to {[B, H, Sq, Skv]}")
         bias = m.to(torch.float32).contiguous()
-    to = lambda t: t.to(torch.bfloat16).contiguous()  # noqa: E731
+    to = lambda t: t.to(ops._lib.elem_dtype()).contiguous()  # noqa: E731
     out = ops.sdpa(to(query), to(key), to(value), bias=bias, scale=scale)
     return out.to(query.dtype)
 
@@ -77,7 +77,7 @@ class Attention:
             b = params.get(name + ".bias")
             # the device GEMM wants [N][K] bf16: transpose once here
             return _Linear(weight=w, bias=None if b is None else b.to(device=device, dtype=torch.float32).contiguous(),
-                           w_nk=w.t().to(torch.bfloat16).contiguous())
+                           w_nk=w.t().to(ops._lib.elem_dtype()).contiguous())
 
         self.to_q, self.to_k, self.to_v = lin("to_q"), lin("to_k"), lin("to_v")
         self.to_out = [lin("to_out.0"), None]   # [Linear, Dropout]
@@ -131,13 +131,13 @@ class MI355XAttnProcessor:
             B, C, Hh, Ww = hidden_states.shape
             hidden_states = hidden_states.reshape(B, C, Hh * Ww).transpose(1, 2)
         B, Sq, C = hidden_states.shape
-        x = hidden_states.to(torch.bfloat16).contiguous()
+        x = hidden_states.to(ops._lib.elem_dtype()).contiguous()
         Skv = Sq if encoder_hidden_states is None else encoder_hidden_states.shape[1]
         mask4 = attn.prepare_attention_mask(attention_mask, Skv, B)
         if attn.group_norm is not None:
             gn = attn.group_norm
             x = ops.group_norm(x, gn.weight, gn.bias, gn.num_groups, gn.eps, silu=False)
-        ctx = x if encoder_hidden_states is None else encoder_hidden_states.to(torch.bfloat16).contiguous()
+        ctx = x if encoder_hidden_states is None else encoder_hidden_states.to(ops._lib.elem_dtype()).contiguous()
         q = ops.linear(x.reshape(B * Sq, C), attn.to_q.w_nk, attn.to_q.bias)
         k = ops.linear(ctx.reshape(B * Skv, ctx.shape[-1]), attn.to_k.w_nk, attn.to_k.bias)
         v = ops.linear(ctx.reshape(B * Skv, ctx.shape[-1]), attn.to_v.w_nk, attn.to_v.bias)

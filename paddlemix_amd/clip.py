@@ -112,7 +112,7 @@ class CLIPTextModel(DeviceProgram, PretrainedMixin):
                 raise ValueError(f"{name}: expected shape {shapes[name]} (Paddle layout), got {tuple(t.shape)}")
             return t.to(device=dev, dtype=torch.float32)
 
-        bf = lambda t: t.to(torch.bfloat16).contiguous()  # noqa: E731
+        bf = lambda t: t.to(_lib.elem_dtype()).contiguous()  # noqa: E731
         W["tok"] = bf(get("text_model.embeddings.token_embedding.weight"))
         W["pos"] = bf(get("text_model.embeddings.position_embedding.weight"))
         for i in range(cfg["num_hidden_layers"]):
@@ -165,12 +165,12 @@ class CLIPTextModel(DeviceProgram, PretrainedMixin):
         # causal mask as the attention kernel's additive bias: [S, S] shared by every batch item and head
         mask = persist((S, S), torch.float32)
         mask.copy_(torch.triu(torch.full((S, S), -1e30), diagonal=1))
-        plan.hidden = [persist((rows, D), torch.bfloat16) for _ in range(n + 1)]   # encoder hidden_states tuple
-        ln, ao = persist((rows, D), torch.bfloat16), persist((rows, D), torch.bfloat16)
-        qkv = persist((rows, 3 * D), torch.bfloat16)
-        f1, f2 = persist((rows, I), torch.bfloat16), persist((rows, I), torch.bfloat16)
-        mid = persist((rows, D), torch.bfloat16)
-        plan.last = persist((rows, D), torch.bfloat16)
+        plan.hidden = [persist((rows, D), _lib.elem_dtype()) for _ in range(n + 1)]   # encoder hidden_states tuple
+        ln, ao = persist((rows, D), _lib.elem_dtype()), persist((rows, D), _lib.elem_dtype())
+        qkv = persist((rows, 3 * D), _lib.elem_dtype())
+        f1, f2 = persist((rows, I), _lib.elem_dtype()), persist((rows, I), _lib.elem_dtype())
+        mid = persist((rows, D), _lib.elem_dtype())
+        plan.last = persist((rows, D), _lib.elem_dtype())
         emit(lib.mi355x_sd_embed_tokens, (plan.ids.data_ptr(), rows, S, W["tok"].data_ptr(), W["pos"].data_ptr(), D,
                                           plan.hidden[0].data_ptr(), D, stream), "misc")
         for i in range(n):
@@ -244,7 +244,7 @@ class CLIPTextModel(DeviceProgram, PretrainedMixin):
         w = self.w["proj.w"]
         N, K = w.shape
         B = pooled.shape[0]
-        a = pooled.to(torch.bfloat16).contiguous()
+        a = pooled.to(_lib.elem_dtype()).contiguous()
         out = torch.empty((B, N), device=a.device, dtype=torch.float32)
         s = 0 if self._emulated else torch.cuda.current_stream(self.device).cuda_stream
         _lib.check(self._lib.mi355x_sd_linear(a.data_ptr(), K, w.data_ptr(), out.data_ptr(), N, B, N, K, None, None, 0, 0,

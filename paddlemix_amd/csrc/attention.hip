@@ -39,8 +39,6 @@ struct AttLds {
   static constexpr int CHUNKS = KVBLK * (DP / 8) / ATT_THREADS;      // 16-B chunks per thread per tile: 2 / 3 / 5
 };
 
-typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-
 template <int DP, bool HAS_BIAS>
 __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_kernel(const AttnArgs p) {
   using L = AttLds<DP>;
@@ -163,7 +161,7 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_ker
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks_ + (sb * 32 + lq) * L::KRS + (ks * 2 + hi) * 16);
-        s[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[sb], 0, 0, 0);
+        s[sb] = mfma_32x32x16(kf, qf[ks], s[sb]);
       }
     }
 
@@ -240,10 +238,10 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_ker
       const unsigned char* vrow = vs_ + (kk * 16 + 4 * hi + tr_row) * L::VRS + tr_col * 2;
 #pragma unroll
       for (int db = 0; db < DB; ++db) {
-        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(vrow + db * 64));
-        const bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(vrow + 8 * L::VRS + db * 64));
+        const bf16x4 lo = ds_read_tr16((lds_bf16x4*)(vrow + db * 64));
+        const bf16x4 hi4 = ds_read_tr16((lds_bf16x4*)(vrow + 8 * L::VRS + db * 64));
         const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
-        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kk], o[db], 0, 0, 0);
+        o[db] = mfma_32x32x16(vf, pf[kk], o[db]);
       }
     }
 

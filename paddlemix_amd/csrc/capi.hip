@@ -44,7 +44,7 @@ __global__ void probe_kernel(float* out) {
     b[i] = (bf16)(float)(((k * 5 + (l & 15) * 2) % 13) - 6);
   }
   f32x4 c = {0.f, 0.f, 0.f, 0.f};
-  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  c = mfma_16x16x32(a, b, c);
   for (int i = 0; i < 4; ++i) out[l * 24 + i] = c[i];
   // 32x32x16: A[row = l&31][k = (l>>5)*8 + i], B[k][col = l&31]
   for (int i = 0; i < 8; ++i) {
@@ -54,16 +54,23 @@ __global__ void probe_kernel(float* out) {
   }
   f32x16 d;
   for (int i = 0; i < 16; ++i) d[i] = 0.f;
-  d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, d, 0, 0, 0);
+  d = mfma_32x32x16(a, b, d);
   for (int i = 0; i < 16; ++i) out[l * 24 + 4 + i] = d[i];
-  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-  const bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(lds + l * 4));
+  const bf16x4 t = ds_read_tr16((lds_bf16x4*)(lds + l * 4));
   for (int i = 0; i < 4; ++i) out[l * 24 + 20 + i] = (float)t[i];
 }
 
 extern "C" {
 
 int mi355x_sd_abi_version(void) { return MI355X_SD_ABI_VERSION; }
+
+int mi355x_sd_elem_dtype(void) {
+#ifdef MI355X_SD_F16
+  return MI355X_SD_ELEM_F16;
+#else
+  return MI355X_SD_ELEM_BF16;
+#endif
+}
 
 int mi355x_sd_set_workspace(void* ptr, size_t bytes) {
   if (ptr && (reinterpret_cast<uintptr_t>(ptr) & 15))

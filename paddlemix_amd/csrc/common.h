@@ -6,10 +6,20 @@
 
 namespace sd {
 
-typedef __bf16 bf16;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+// The 16-bit storage / MFMA operand type of this build. The default library (libmi355x_sd.so) is bfloat16 -- the dtype
+// BASELINE.json's configurations name; `-DMI355X_SD_F16` compiles the SAME kernels for IEEE half
+// (libmi355x_sd_f16.so): identical MFMA rates and byte counts, 3 more mantissa bits in every stored activation and
+// weight -> whole-UNet parity 1.3-2e-3 instead of 1e-2, at fp16's range (65504). The kernels keep
+// the historical name `bf16` for "the element type of the build"; mi355x_sd_elem_dtype() reports which one a library is.
+#ifdef MI355X_SD_F16
+typedef _Float16 elem16_t;
+#else
+typedef __bf16 elem16_t;
+#endif
+typedef elem16_t bf16;
+typedef __attribute__((ext_vector_type(2))) elem16_t bf16x2;
+typedef __attribute__((ext_vector_type(4))) elem16_t bf16x4;
+typedef __attribute__((ext_vector_type(8))) elem16_t bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
@@ -17,6 +27,29 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 constexpr int kWave = 64;
+
+// the two MFMA shapes the kernels use, on the build's element type (same issue rate for bf16 and f16)
+__device__ __forceinline__ f32x4 mfma_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
+#ifdef MI355X_SD_F16
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+// transposing LDS read (ds_read_b64_tr_b16): 4 elements of the build's type
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+__device__ __forceinline__ bf16x4 ds_read_tr16(lds_bf16x4* p) {   // (the instruction moves 16-bit lanes; the type is irrelevant)
+  typedef __attribute__((ext_vector_type(4))) __bf16 raw4;
+  typedef __attribute__((address_space(3))) raw4 lds_raw4;
+  return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_raw4*)p));
+}
+__device__ __forceinline__ f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
+#ifdef MI355X_SD_F16
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
+}
 
 __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
 __device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }  // RNE; lowers to v_cvt_pk_bf16_f32

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(g256::THREADS, 2) void gemm256_kernel(const GemmArg
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt)
             acc[2 * j + nn][s * 4 + mt] =
-                __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[2 * j + nn][ks], fa[mt][ks], acc[2 * j + nn][s * 4 + mt], 0, 0, 0);
+                mfma_16x16x32(fb[2 * j + nn][ks], fa[mt][ks], acc[2 * j + nn][s * 4 + mt]);
     }
     __builtin_amdgcn_s_setprio(0);
   };

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES) void gemm_pipe_kernel
     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
-        acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[set][tn], fa[set][tm], acc[tn][tm], 0, 0, 0);
+        acc[tn][tm] = mfma_16x16x32(fw[set][tn], fa[set][tm], acc[tn][tm]);
   };
 
   // ---- K loop: AHEAD = ST - 1 tiles staged beyond the one being multiplied ----
@@ -265,8 +265,8 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES) void gemm_pipe_kernel
       __builtin_amdgcn_sched_barrier(0);   // keep the read Q steps ahead of its use (the scheduler would sink it)
 #pragma unroll
       for (int h = 0; h < HN; ++h) {
-        if (HOLD_A) acc[s][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j % QN], hold[ks][h], acc[s][h], 0, 0, 0);
-        else acc[h][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hold[ks][h], qf[j % QN], acc[h][s], 0, 0, 0);
+        if (HOLD_A) acc[s][h] = mfma_16x16x32(qf[j % QN], hold[ks][h], acc[s][h]);
+        else acc[h][s] = mfma_16x16x32(hold[ks][h], qf[j % QN], acc[h][s]);
       }
       __builtin_amdgcn_sched_barrier(0);
     }

@@ -36,8 +36,10 @@ def _p(t: Optional[Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
-def _rows(t: Tensor, name: str, dtype=torch.bfloat16) -> int:
-    """Validate a 2-D row tensor (unit inner stride) and return its row stride."""
+def _rows(t: Tensor, name: str, dtype=None) -> int:
+    """Validate a 2-D row tensor (unit inner stride; the build's element type unless `dtype` says otherwise) and return
+    its row stride."""
+    dtype = dtype or _lib.elem_dtype()
     if not t.is_cuda:
         raise _lib.MI355XError(f"{name}: tensor must live on the GPU (no CPU fallback)")
     if t.dtype != dtype or t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
@@ -66,13 +68,13 @@ def linear(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, rowbias: Opti
     _bind_workspace(a.device)
     lda = _rows(a, "a")
     M, K = a.shape
-    if w.dtype != torch.bfloat16 or not w.is_contiguous() or w.dim() != 2 or w.shape[1] != K:
+    if w.dtype != _lib.elem_dtype() or not w.is_contiguous() or w.dim() != 2 or w.shape[1] != K:
         raise ValueError(f"w: expected contiguous bf16 [N,{K}], got {w.dtype} {tuple(w.shape)}")
     N = w.shape[0]
     n_out = N // 2 if geglu else N
     if out is None:
-        out = torch.empty((M, n_out), device=a.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
-    ldc = _rows(out, "out", torch.float32 if out_f32 else torch.bfloat16)
+        out = torch.empty((M, n_out), device=a.device, dtype=torch.float32 if out_f32 else _lib.elem_dtype())
+    ldc = _rows(out, "out", torch.float32 if out_f32 else _lib.elem_dtype())
     if out.shape != (M, n_out):
         raise ValueError(f"out: expected {(M, n_out)}, got {tuple(out.shape)}")
     ldr = _rows(residual, "residual") if residual is not None else 0
@@ -94,21 +96,21 @@ def conv3x3(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, stride: int 
     """x NHWC view [B,H,W,C] (pixel stride >= C), w [Cout, 9*Cin] -> rows [B*Ho*Wo, Cout]."""
     lib = _lib.load()
     _bind_workspace(x.device)
-    if x.dim() != 4 or x.dtype != torch.bfloat16 or x.stride(3) != 1 or not x.is_cuda:
+    if x.dim() != 4 or x.dtype != _lib.elem_dtype() or x.stride(3) != 1 or not x.is_cuda:
         raise ValueError("x: expected bf16 cuda NHWC [B,H,W,C]")
     B, H, W, C = x.shape
     ldx = x.stride(2)
     if x.stride(1) != W * ldx or x.stride(0) != H * W * ldx:
         raise ValueError("x: pixels must be densely packed with a common stride")
     Cout = w.shape[0]
-    if w.dtype != torch.bfloat16 or not w.is_contiguous() or w.shape[1] != 9 * C:
+    if w.dtype != _lib.elem_dtype() or not w.is_contiguous() or w.shape[1] != 9 * C:
         raise ValueError(f"w: expected contiguous bf16 [Cout, {9 * C}]")
     up = 1 if upsample else 0
     Ho = ((H << up) + 2 - 3) // stride + 1
     Wo = ((W << up) + 2 - 3) // stride + 1
     M = B * Ho * Wo
     if out is None:
-        out = torch.empty((M, Cout), device=x.device, dtype=torch.bfloat16)
+        out = torch.empty((M, Cout), device=x.device, dtype=_lib.elem_dtype())
     ldc = _rows(out, "out")
     ldr = _rows(residual, "residual") if residual is not None else 0
     ld_rb = rowbias.stride(0) if rowbias is not None else 0
@@ -124,14 +126,14 @@ def sdpa(q: Tensor, k: Tensor, v: Tensor, bias: Optional[Tensor] = None, scale: 
     bias: optional fp32 additive mask broadcastable to [B,H,Sq,Skv] with unit inner stride."""
     lib = _lib.load()
     for name, t in (("q", q), ("k", k), ("v", v)):
-        if t.dim() != 4 or t.dtype != torch.bfloat16 or not t.is_cuda or t.stride(3) != 1 or t.stride(2) != t.shape[3]:
+        if t.dim() != 4 or t.dtype != _lib.elem_dtype() or not t.is_cuda or t.stride(3) != 1 or t.stride(2) != t.shape[3]:
             raise ValueError(f"{name}: expected bf16 cuda [B,S,H,D] with heads packed inside a token row")
     B, Sq, H, D = q.shape
     Skv = k.shape[1]
     if scale is None:
         scale = 1.0 / math.sqrt(D)
     if out is None:
-        out = torch.empty((B, Sq, H, D), device=q.device, dtype=torch.bfloat16)
+        out = torch.empty((B, Sq, H, D), device=q.device, dtype=_lib.elem_dtype())
     bb = bh = bq = 0
     if bias is not None:
         if bias.dtype != torch.float32 or bias.dim() != 4 or bias.shape[-1] != Skv or bias.stride(3) != 1:
@@ -149,7 +151,7 @@ def groupnorm_scale_shift(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, e
     """x [B,HW,C] (row stride >= C) -> scale_shift fp32 [B,2,C]."""
     lib = _lib.load()
     B, HW, C = x.shape
-    if x.dtype != torch.bfloat16 or x.stride(2) != 1 or x.stride(0) != HW * x.stride(1) or not x.is_cuda:
+    if x.dtype != _lib.elem_dtype() or x.stride(2) != 1 or x.stride(0) != HW * x.stride(1) or not x.is_cuda:
         raise ValueError("x: expected bf16 cuda [B,HW,C] rows")
     ws = torch.empty(max(1, lib.mi355x_sd_groupnorm_workspace_floats(B, HW, C)), device=x.device, dtype=torch.float32)
     ss = torch.empty((B, 2, C), device=x.device, dtype=torch.float32)
@@ -163,7 +165,7 @@ def scale_shift_act(x: Tensor, scale_shift: Tensor, silu: bool, out: Optional[Te
     lib = _lib.load()
     B, HW, C = x.shape
     if out is None:
-        out = torch.empty((B, HW, C), device=x.device, dtype=torch.bfloat16)
+        out = torch.empty((B, HW, C), device=x.device, dtype=_lib.elem_dtype())
     check(lib.mi355x_sd_scale_shift_act(x.data_ptr(), B, HW, C, x.stride(1), scale_shift.data_ptr(), 1 if silu else 0,
                                         out.data_ptr(), out.stride(1), _stream()))
     return out
@@ -180,7 +182,7 @@ def layer_norm(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], eps: 
     ldx = _rows(x, "x")
     rows, C = x.shape
     if out is None:
-        out = torch.empty((rows, C), device=x.device, dtype=torch.bfloat16)
+        out = torch.empty((rows, C), device=x.device, dtype=_lib.elem_dtype())
     check(lib.mi355x_sd_layernorm(x.data_ptr(), rows, C, ldx, _p(_vec(gamma, C, "gamma")), _p(_vec(beta, C, "beta")),
                                   float(eps), out.data_ptr(), _rows(out, "out"), _stream()))
     return out
@@ -193,7 +195,7 @@ def timestep_embedding(t: Tensor, dim: int, flip_sin_to_cos: bool = False, downs
     if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
         raise ValueError("t: expected contiguous fp32 cuda tensor")
     n = t.numel() if n is None else n
-    out = torch.empty((n, dim), device=t.device, dtype=torch.bfloat16)
+    out = torch.empty((n, dim), device=t.device, dtype=_lib.elem_dtype())
     check(lib.mi355x_sd_timestep_embedding(t.data_ptr(), t.numel(), n, dim, 1, 1 if flip_sin_to_cos else 0,
                                            float(downscale_freq_shift), float(scale), float(max_period),
                                            out.data_ptr(), dim, _stream()))
@@ -220,7 +222,7 @@ def conv_in3x3(x_nchw: Tensor, w: Tensor, bias: Optional[Tensor], in_scale: Opti
     if x_nchw.dtype != torch.float32 or not x_nchw.is_contiguous() or not x_nchw.is_cuda:
         raise ValueError("x: expected contiguous fp32 cuda NCHW")
     if out is None:
-        out = torch.empty((B * H * W, Cout), device=x_nchw.device, dtype=torch.bfloat16)
+        out = torch.empty((B * H * W, Cout), device=x_nchw.device, dtype=_lib.elem_dtype())
     check(lib.mi355x_sd_conv_in3x3(x_nchw.data_ptr(), _p(in_scale), w.data_ptr(), _p(_vec(bias, Cout, "bias")),
                                    out.data_ptr(), B, Cin, H, W, Cout, _rows(out, "out"), _stream()))
     return out
@@ -270,8 +272,8 @@ def linear_ex(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, w_scale: O
         lda = _rows(a, "a")
         M = a.shape[0]
     if out is None:
-        out = torch.empty((M, N), device=a.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
-    ldc = N if c_rows_per_batch else _rows(out, "out", torch.float32 if out_f32 else torch.bfloat16)
+        out = torch.empty((M, N), device=a.device, dtype=torch.float32 if out_f32 else _lib.elem_dtype())
+    ldc = N if c_rows_per_batch else _rows(out, "out", torch.float32 if out_f32 else _lib.elem_dtype())
     ld_gate = gate.stride(0) if gate is not None else 0
     flags = (OUT_F32 if out_f32 else 0) | (SILU if silu else 0) | (GELU_TANH if gelu_tanh else 0)
     check(lib.mi355x_sd_linear_ex(a.data_ptr(), lda, a_rows_per_batch, a_batch_stride, w.data_ptr(), _p(w_scale), out.data_ptr(), ldc,
@@ -288,7 +290,7 @@ def adaln(x: Tensor, scale: Tensor, shift: Tensor, rows_per_batch: int, eps: flo
     ldx = _rows(x, "x")
     rows, C = x.shape
     if out is None:
-        out = torch.empty((rows, C), device=x.device, dtype=torch.bfloat16)
+        out = torch.empty((rows, C), device=x.device, dtype=_lib.elem_dtype())
     assert scale.stride(0) == shift.stride(0) and scale.dtype == torch.float32
     check(lib.mi355x_sd_adaln(x.data_ptr(), rows, C, ldx, scale.data_ptr(), shift.data_ptr(), scale.stride(0),
                               rows_per_batch, float(eps), out.data_ptr(), _rows(out, "out"), _stream()))
@@ -298,7 +300,7 @@ def adaln(x: Tensor, scale: Tensor, shift: Tensor, rows_per_batch: int, eps: flo
 def patchify(x_nchw: Tensor, patch: int) -> Tensor:
     lib = _lib.load()
     B, C, H, W = x_nchw.shape
-    out = torch.empty((B * (H // patch) * (W // patch), C * patch * patch), device=x_nchw.device, dtype=torch.bfloat16)
+    out = torch.empty((B * (H // patch) * (W // patch), C * patch * patch), device=x_nchw.device, dtype=_lib.elem_dtype())
     check(lib.mi355x_sd_patchify(x_nchw.data_ptr(), B, C, H, W, patch, out.data_ptr(), out.shape[1], _stream()))
     return out
 
@@ -317,7 +319,7 @@ def conv1x1_nchw(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, in_scale: 
         raise ValueError("x: expected a contiguous fp32 NCHW GPU tensor")
     B, Cin, H, W = x.shape
     Cout = w.shape[0]
-    if w.dtype != torch.bfloat16 or tuple(w.shape) != (Cout, Cin) or not w.is_contiguous():
+    if w.dtype != _lib.elem_dtype() or tuple(w.shape) != (Cout, Cin) or not w.is_contiguous():
         raise ValueError(f"w: expected contiguous bf16 [Cout, {Cin}]")
     y = torch.empty((B, Cout, H, W), device=x.device, dtype=torch.float32)
     check(lib.mi355x_sd_conv1x1_nchw(x.data_ptr(), float(in_scale), w.data_ptr(), _p(_vec(bias, Cout, "bias")),
@@ -332,7 +334,7 @@ def softmax_rows(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
         raise ValueError("x: expected an fp32 [rows, n] GPU tensor with unit inner stride")
     rows, n = x.shape
     if out is None:
-        out = torch.empty((rows, n), device=x.device, dtype=torch.bfloat16)
+        out = torch.empty((rows, n), device=x.device, dtype=_lib.elem_dtype())
     check(lib.mi355x_sd_softmax_rows(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), rows, n, _stream()))
     return out
 
@@ -355,13 +357,13 @@ def linear_ln(a: Tensor, stats: Tensor, w: Tensor, w_rowsum: Tensor, bias: Optio
     lda = _rows(a, "a")
     M, K = a.shape
     N = w.shape[0]
-    if w.dtype != torch.bfloat16 or not w.is_contiguous() or tuple(w.shape) != (N, K):
+    if w.dtype != _lib.elem_dtype() or not w.is_contiguous() or tuple(w.shape) != (N, K):
         raise ValueError(f"w: expected contiguous bf16 [N,{K}]")
     if stats.dtype != torch.float32 or tuple(stats.shape) != (M, 2) or not stats.is_contiguous():
         raise ValueError("stats: expected contiguous fp32 [M, 2]")
     n_out = N // 2 if geglu else N
     if out is None:
-        out = torch.empty((M, n_out), device=a.device, dtype=torch.bfloat16)
+        out = torch.empty((M, n_out), device=a.device, dtype=_lib.elem_dtype())
     ldc = _rows(out, "out")
     check(lib.mi355x_sd_linear_ln(a.data_ptr(), lda, stats.data_ptr(), w.data_ptr(), _vec(w_rowsum, N, "w_rowsum").data_ptr(),
                                   out.data_ptr(), ldc, M, N, K, _p(_vec(bias, N, "bias")), GEGLU if geglu else 0, _stream()))
@@ -376,7 +378,7 @@ def embed_tokens(ids: Tensor, token_table: Tensor, position_table: Tensor, seq_l
     V, D = token_table.shape
     if int(ids.min()) < 0 or int(ids.max()) >= V or seq_len > position_table.shape[0]:
         raise ValueError("ids / seq_len out of range of the embedding tables")
-    out = torch.empty((ids.numel(), D), device=ids.device, dtype=torch.bfloat16)
+    out = torch.empty((ids.numel(), D), device=ids.device, dtype=_lib.elem_dtype())
     check(lib.mi355x_sd_embed_tokens(ids.data_ptr(), ids.numel(), seq_len, token_table.data_ptr(),
                                      position_table.data_ptr(), D, out.data_ptr(), D, _stream()))
     return out
@@ -386,7 +388,7 @@ def activation(x: Tensor, kind: str) -> Tensor:
     """quick_gelu | gelu | silu on a contiguous bf16 tensor."""
     lib = _lib.load()
     kinds = {"quick_gelu": 0, "gelu": 1, "silu": 2}
-    if x.dtype != torch.bfloat16 or not x.is_cuda or not x.is_contiguous():
+    if x.dtype != _lib.elem_dtype() or not x.is_cuda or not x.is_contiguous():
         raise ValueError("x: expected a contiguous bf16 GPU tensor")
     y = torch.empty_like(x)
     check(lib.mi355x_sd_activation(x.data_ptr(), y.data_ptr(), x.numel(), kinds[kind], _stream()))
@@ -398,7 +400,7 @@ def rms_norm(x: Tensor, weight: Tensor, eps: float = 1e-6) -> Tensor:
     lib = _lib.load()
     ldx = _rows(x, "x")
     rows, C = x.shape
-    out = torch.empty((rows, C), device=x.device, dtype=torch.bfloat16)
+    out = torch.empty((rows, C), device=x.device, dtype=_lib.elem_dtype())
     check(lib.mi355x_sd_rmsnorm(x.data_ptr(), rows, C, ldx, _vec(weight, C, "weight").data_ptr(), float(eps), out.data_ptr(),
                                 C, _stream()))
     return out
@@ -410,7 +412,7 @@ def gated_activation(x: Tensor, kind: str = "gelu_new") -> Tensor:
     kinds = {"quick_gelu": 0, "gelu": 1, "silu": 2, "gelu_new": 3}
     ldx = _rows(x, "x")
     rows, F2 = x.shape
-    out = torch.empty((rows, F2 // 2), device=x.device, dtype=torch.bfloat16)
+    out = torch.empty((rows, F2 // 2), device=x.device, dtype=_lib.elem_dtype())
     check(lib.mi355x_sd_gated_activation(x.data_ptr(), ldx, out.data_ptr(), F2 // 2, rows, F2 // 2, kinds[kind], _stream()))
     return out
 
@@ -469,7 +471,7 @@ def linear_f8(a8: Tensor, a_scale: Tensor, w8: Tensor, w_scale: Tensor, bias: Op
         if t.dtype != torch.uint8 or not t.is_cuda or t.stride(1) != 1:
             raise ValueError(f"{nm}: expected uint8 (e4m3 bytes) cuda rows")
     if out is None:
-        out = torch.empty((M, N), device=a8.device, dtype=torch.bfloat16)
+        out = torch.empty((M, N), device=a8.device, dtype=_lib.elem_dtype())
     check(lib.mi355x_sd_linear_f8(a8.data_ptr(), a8.stride(0), 0, 0, _vec(a_scale, M, "a_scale").data_ptr(), w8.data_ptr(),
                                   _vec(w_scale, N, "w_scale").data_ptr(), out.data_ptr(), _rows(out, "out"), 0, 0, M, N, K,
                                   _p(_vec(bias, N, "bias")), _p(gate), gate.stride(0) if gate is not None else 0, rows_per_batch,

@@ -61,7 +61,7 @@ class DeviceProgram:
             self._stream_ptr = self._stream.cuda_stream
             # split-K scratch of this model's stream (mi355x_sd_set_workspace): owned here, baked into the graphs
             self._workspace = torch.empty(WORKSPACE_BYTES, device=self.device, dtype=torch.uint8)
-        self.dtype = torch.bfloat16
+        self.dtype = _lib.elem_dtype()
         self.use_graph = use_graph
         self.profile = profile
         self._plans: Dict[tuple, _Plan] = {}

@@ -168,7 +168,7 @@ class SD3Transformer2DModel(DeviceProgram, PretrainedMixin):
                 raise ValueError(f"{name}: shape {tuple(t.shape)} != expected {shapes[name]} (Paddle layout)")
             return t.to(device=dev, dtype=torch.float32)
 
-        bf = lambda t: t.to(torch.bfloat16).contiguous()  # noqa: E731
+        bf = lambda t: t.to(_lib.elem_dtype()).contiguous()  # noqa: E731
         self._bounds: Dict[str, tuple] = {}
 
         def put_lin(key, name):
@@ -312,31 +312,31 @@ class SD3Transformer2DModel(DeviceProgram, PretrainedMixin):
         # ---- inputs ----
         plan.sample = persist((B, cfg["in_channels"], H, Wd), torch.float32)
         plan.t = persist((1,), torch.float32)
-        plan.enc = persist((B * S2, cfg["joint_attention_dim"]), torch.bfloat16)
-        plan.pooled = persist((B, cfg["pooled_projection_dim"]), torch.bfloat16)
+        plan.enc = persist((B * S2, cfg["joint_attention_dim"]), _lib.elem_dtype())
+        plan.pooled = persist((B, cfg["pooled_projection_dim"]), _lib.elem_dtype())
         plan.out = persist((B, cfg["out_channels"], H, Wd), torch.float32)
         mx = cfg["pos_embed_max_size"]
         if hp > mx or wp > mx:
             raise ValueError(f"Height ({hp}) / width ({wp}) cannot be greater than `pos_embed_max_size`: {mx}.")
         top, left = (mx - hp) // 2, (mx - wp) // 2
         pos = self._pos_table[top:top + hp, left:left + wp].reshape(1, S1, D).expand(B, S1, D).reshape(B * S1, D)
-        pos_t = persist((B * S1, D), torch.bfloat16)
+        pos_t = persist((B * S1, D), _lib.elem_dtype())
         pos_t.copy_(pos)
 
         # ---- patch embedding + cropped sincos pos-emb (embeddings.py:209-247) ----
         kp = cfg["in_channels"] * p * p
-        patches = persist((B * S1, kp), torch.bfloat16)
+        patches = persist((B * S1, kp), _lib.elem_dtype())
         emit(lib.mi355x_sd_patchify, (plan.sample.data_ptr(), B, cfg["in_channels"], H, Wd, p, patches.data_ptr(), kp,
                                       stream), "misc")
-        x_t = persist((B * S1, D), torch.bfloat16)
+        x_t = persist((B * S1, D), _lib.elem_dtype())
         x = _V(x_t.data_ptr(), B * S1, D)
         linear(_V(patches.data_ptr(), B * S1, kp), "patch", x, R=_V(pos_t.data_ptr(), B * S1, D))
 
         # ---- conditioning (embeddings.py:538-546) and all modulation vectors in one GEMM ----
-        tproj = persist((B, 256), torch.bfloat16)
+        tproj = persist((B, 256), _lib.elem_dtype())
         emit(lib.mi355x_sd_timestep_embedding, (plan.t.data_ptr(), 1, B, 256, 1, 1, 0.0, 1.0, 10000.0,
                                                 tproj.data_ptr(), 256, stream), "misc")
-        e1, temb, st = (persist((B, D), torch.bfloat16) for _ in range(3))
+        e1, temb, st = (persist((B, D), _lib.elem_dtype()) for _ in range(3))
         v = lambda t, c: _V(t.data_ptr(), B, c)  # noqa: E731
         linear(v(tproj, 256), "time_text_embed.timestep_embedder.linear_1", v(e1, D), flags=SILU)
         linear(v(e1, D), "time_text_embed.timestep_embedder.linear_2", v(temb, D))
@@ -348,7 +348,7 @@ class SD3Transformer2DModel(DeviceProgram, PretrainedMixin):
         mp = mod.data_ptr()
         m_at = lambda key, chunk: mp + 4 * (self._mod_off[key] + chunk * D)  # noqa: E731
 
-        c_t = persist((B * S2, D), torch.bfloat16)
+        c_t = persist((B * S2, D), _lib.elem_dtype())
         c = _V(c_t.data_ptr(), B * S2, D)
         linear(_V(plan.enc.data_ptr(), B * S2, cfg["joint_attention_dim"]), "context_embedder", c)
 
@@ -414,7 +414,7 @@ class SD3Transformer2DModel(DeviceProgram, PretrainedMixin):
         # ---- norm_out (scale, shift) + proj_out + unpatchify (transformer_sd3.py:341-356) ----
         adaln(x, m_at("norm_out", 0), m_at("norm_out", 1), S1, nx)
         po = p * p * cfg["out_channels"]
-        proj = persist((B * S1, po), torch.bfloat16)
+        proj = persist((B * S1, po), _lib.elem_dtype())
         linear(nx, "proj_out", _V(proj.data_ptr(), B * S1, po))
         emit(lib.mi355x_sd_unpatchify, (proj.data_ptr(), po, B, cfg["out_channels"], H, Wd, p, plan.out.data_ptr(),
                                         stream), "misc")

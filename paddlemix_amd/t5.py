@@ -119,7 +119,7 @@ class T5EncoderModel(DeviceProgram, PretrainedMixin):
                 raise ValueError(f"{name}: expected shape {shapes[name]} (Paddle layout), got {tuple(t.shape)}")
             return t.to(device=dev, dtype=torch.float32)
 
-        bf = lambda t: t.to(torch.bfloat16).contiguous()  # noqa: E731
+        bf = lambda t: t.to(_lib.elem_dtype()).contiguous()  # noqa: E731
         W["tok"] = bf(get("shared.weight"))
         for i in range(cfg["num_layers"]):
             b = f"encoder.block.{i}"
@@ -173,13 +173,13 @@ class T5EncoderModel(DeviceProgram, PretrainedMixin):
         plan.ids = persist((rows,), torch.int32)
         bias = persist((H, S, S), torch.float32)
         bias.copy_(self._position_bias(S))
-        xa, xb = persist((rows, D), torch.bfloat16), persist((rows, D), torch.bfloat16)
-        h = persist((rows, D), torch.bfloat16)
-        qkv = persist((rows, 3 * inner), torch.bfloat16)
-        ao = persist((rows, inner), torch.bfloat16)
-        wi = persist((rows, 2 * Fd), torch.bfloat16)
-        ff = persist((rows, Fd), torch.bfloat16)
-        plan.last = persist((rows, D), torch.bfloat16)
+        xa, xb = persist((rows, D), _lib.elem_dtype()), persist((rows, D), _lib.elem_dtype())
+        h = persist((rows, D), _lib.elem_dtype())
+        qkv = persist((rows, 3 * inner), _lib.elem_dtype())
+        ao = persist((rows, inner), _lib.elem_dtype())
+        wi = persist((rows, 2 * Fd), _lib.elem_dtype())
+        ff = persist((rows, Fd), _lib.elem_dtype())
+        plan.last = persist((rows, D), _lib.elem_dtype())
         emit(lib.mi355x_sd_embed_tokens, (plan.ids.data_ptr(), rows, S, W["tok"].data_ptr(), None, D, xa.data_ptr(), D,
                                           stream), "misc")
         for i in range(n):

@@ -263,7 +263,7 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
                 raise ValueError(f"{name}: shape {tuple(t.shape)} != expected {shapes[name]} (Paddle layout)")
             return t.to(device=dev, dtype=torch.float32)
 
-        bf = lambda t: t.to(torch.bfloat16).contiguous()  # noqa: E731
+        bf = lambda t: t.to(_lib.elem_dtype()).contiguous()  # noqa: E731
         W = self.w
 
         def lin_w(name):  # Paddle [in,out] -> [out,in]
@@ -462,40 +462,40 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
         plan.in_scale = persist((1,), torch.float32)
         plan.in_scale.fill_(1.0)
         dx = cfg["cross_attention_dim"][0]
-        plan.enc = persist((B * L, dx), torch.bfloat16)
+        plan.enc = persist((B * L, dx), _lib.elem_dtype())
         enc = _V(plan.enc.data_ptr(), B * L, dx)
         plan.out = persist((B, cfg["out_channels"], H, Wd), torch.float32)
         plan.enc_bias = persist((B, L), torch.float32) if masked else None
         enc_bias = plan.enc_bias.data_ptr() if masked else None
 
         # ---- time / added-condition embedding (unet_2d_condition.py:933-1030) ----
-        t0 = persist((B, boc[0]), torch.bfloat16)
+        t0 = persist((B, boc[0]), _lib.elem_dtype())
         emit(lib.mi355x_sd_timestep_embedding, (plan.t.data_ptr(), 1, B, boc[0], 1, 1 if cfg["flip_sin_to_cos"] else 0,
                                                 float(cfg["freq_shift"]), 1.0, 10000.0, t0.data_ptr(), boc[0], stream),
              "misc")
-        e1 = persist((B, ted), torch.bfloat16)
-        emb = persist((B, ted), torch.bfloat16)
+        e1 = persist((B, ted), _lib.elem_dtype())
+        emb = persist((B, ted), _lib.elem_dtype())
         linear(_V(t0.data_ptr(), B, boc[0]), "time_embedding.linear_1", _V(e1.data_ptr(), B, ted), flags=SILU)
         linear(_V(e1.data_ptr(), B, ted), "time_embedding.linear_2", _V(emb.data_ptr(), B, ted))
         plan.add_in = plan.time_ids = None
         if cfg["addition_embed_type"] == "text_time":
             pdim = cfg["projection_class_embeddings_input_dim"]
             atd = cfg["addition_time_embed_dim"]
-            plan.add_in = persist((B, pdim), torch.bfloat16)
+            plan.add_in = persist((B, pdim), _lib.elem_dtype())
             plan.text_dim = None  # widths of text_embeds / time_ids are only known at the first call
             plan._pdim, plan._atd = pdim, atd
-            a1 = persist((B, ted), torch.bfloat16)
+            a1 = persist((B, ted), _lib.elem_dtype())
             plan._add_emit_index = len(prog)  # the time_ids embedding op is inserted here once widths are known
             linear(_V(plan.add_in.data_ptr(), B, pdim), "add_embedding.linear_1", _V(a1.data_ptr(), B, ted),
                    flags=SILU)
             linear(_V(a1.data_ptr(), B, ted), "add_embedding.linear_2", _V(emb.data_ptr(), B, ted),
                    R=_V(emb.data_ptr(), B, ted))
-        semb = persist((B, ted), torch.bfloat16)
+        semb = persist((B, ted), _lib.elem_dtype())
         emit(lib.mi355x_sd_silu, (emb.data_ptr(), semb.data_ptr(), B * ted, 0, 0, stream), "misc")
         temb_all = persist((B, self._temb_total), torch.float32)
         linear(_V(semb.data_ptr(), B, ted), "temb_all", _V(temb_all.data_ptr(), B, self._temb_total), flags=OUT_F32)
         # every block's cross-attention K/V projection of encoder_hidden_states in one GEMM (attention_processor.py:711-712)
-        kv_all_t = persist((B * L, self._kv_total), torch.bfloat16)
+        kv_all_t = persist((B * L, self._kv_total), _lib.elem_dtype())
         kv_all = _V(kv_all_t.data_ptr(), B * L, self._kv_total)
         linear(enc, "kv_all", kv_all, bias=False)
 
@@ -520,7 +520,7 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
         for u, d in enumerate(ups):  # up resnet u consumes skip n-1-u
             cs, hs, ws_ = skips[len(skips) - 1 - u]
             cx = d[2] - cs
-            t = persist((B * hs * ws_, cx + cs), torch.bfloat16)
+            t = persist((B * hs * ws_, cx + cs), _lib.elem_dtype())
             cats.append(_V(t.data_ptr(), B * hs * ws_, cx + cs))
             cat_xc.append(cx)
 

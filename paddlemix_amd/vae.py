@@ -148,7 +148,7 @@ class AutoencoderKL(DeviceProgram, PretrainedMixin):
                 raise ValueError(f"{name}: expected shape {shapes[name]}, got {tuple(t.shape)}")
             return t.to(device=dev, dtype=torch.float32)
 
-        bf = lambda t: t.to(torch.bfloat16).contiguous()  # noqa: E731
+        bf = lambda t: t.to(_lib.elem_dtype()).contiguous()  # noqa: E731
 
         def put_conv(key):  # OIHW -> [O][kh][kw][I]
             w = get(key + ".weight")

@@ -16,8 +16,10 @@ import math
 import torch
 import torch.nn.functional as F
 
+from paddlemix_amd import _lib
+
 GEGLU, OUT_F32, SILU, GELU_TANH = 1, 2, 4, 8
-_ES = {torch.bfloat16: 2, torch.float32: 4}
+_ES = {torch.bfloat16: 2, torch.float16: 2, torch.float32: 4}
 
 
 def _flat(ptr: int, n: int, dtype) -> torch.Tensor:
@@ -25,7 +27,8 @@ def _flat(ptr: int, n: int, dtype) -> torch.Tensor:
     return torch.frombuffer(buf, dtype=dtype, count=n)
 
 
-def _rows(ptr: int, rows: int, C: int, ld: int, dtype=torch.bfloat16) -> torch.Tensor:
+def _rows(ptr: int, rows: int, C: int, ld: int, dtype=None) -> torch.Tensor:
+    dtype = dtype or _lib.elem_dtype()   # the element type of the selected library build (bf16 | fp16)
     n = (rows - 1) * ld + C
     return _flat(ptr, n, dtype).as_strided((rows, C), (ld, 1))
 
@@ -66,7 +69,7 @@ class Emulator:
             acc = acc * out_scale
             if flags & SILU:
                 acc = F.silu(acc)
-        dt = torch.float32 if flags & OUT_F32 else torch.bfloat16
+        dt = torch.float32 if flags & OUT_F32 else _lib.elem_dtype()
         _rows(C, M, N, ldc, dt).copy_(acc.to(dt))
 
     def mi355x_sd_linear(self, A, lda, W, C, ldc, M, N, K, bias, rowbias, rpb, ld_rb, R, ldr, out_scale, flags, stream):
@@ -91,7 +94,7 @@ class Emulator:
             n = (nb - 1) * bstride + (r_pb - 1) * ld + cols
             return _flat(ptr, n, dtype).as_strided((nb, r_pb, cols), (bstride, ld, 1))
 
-        a = remap_rows(A, M, K, lda, a_rpb, a_bs, torch.bfloat16).float().reshape(M, K)
+        a = remap_rows(A, M, K, lda, a_rpb, a_bs, _lib.elem_dtype()).float().reshape(M, K)
         if w_scale:
             buf = (ctypes.c_char * (N * K)).from_address(W)
             q = torch.frombuffer(buf, dtype=torch.uint8, count=N * K).reshape(N, K).view(torch.float8_e4m3fn).float()
@@ -111,7 +114,7 @@ class Emulator:
             acc = F.silu(acc)
         if flags & GELU_TANH:
             acc = F.gelu(acc, approximate="tanh")
-        dt = torch.float32 if flags & OUT_F32 else torch.bfloat16
+        dt = torch.float32 if flags & OUT_F32 else _lib.elem_dtype()
         out = remap_rows(C, M, N, ldc, c_rpb, c_bs, dt)
         out.copy_(acc.to(dt).reshape(out.shape))
         return 0
@@ -177,7 +180,7 @@ class Emulator:
         if x_rpb:
             nb = (rows + x_rpb - 1) // x_rpb
             n = (nb - 1) * x_bs + (x_rpb - 1) * ldx + C
-            xv = _flat(x, n, torch.bfloat16).as_strided((nb, x_rpb, C), (x_bs, ldx, 1)).reshape(nb * x_rpb, C)[:rows].float()
+            xv = _flat(x, n, _lib.elem_dtype()).as_strided((nb, x_rpb, C), (x_bs, ldx, 1)).reshape(nb * x_rpb, C)[:rows].float()
         else:
             xv = _rows(x, rows, C, ldx).float()
         q, s = self._q8(xv)
@@ -204,10 +207,10 @@ class Emulator:
         if c_rpb:
             nb = (M + c_rpb - 1) // c_rpb
             n = (nb - 1) * c_bs + (c_rpb - 1) * ldc + N
-            dst = _flat(C, n, torch.bfloat16).as_strided((nb, c_rpb, N), (c_bs, ldc, 1))
-            dst.copy_(acc.reshape(nb, c_rpb, N).to(torch.bfloat16))
+            dst = _flat(C, n, _lib.elem_dtype()).as_strided((nb, c_rpb, N), (c_bs, ldc, 1))
+            dst.copy_(acc.reshape(nb, c_rpb, N).to(_lib.elem_dtype()))
         else:
-            _rows(C, M, N, ldc).copy_(acc.to(torch.bfloat16))
+            _rows(C, M, N, ldc).copy_(acc.to(_lib.elem_dtype()))
         return 0
 
     def mi355x_sd_adaln(self, x, rows, C, ldx, scale, shift, ld_mod, rpb, eps, y, ldy, stream):
@@ -216,14 +219,14 @@ class Emulator:
         xv = F.layer_norm(_rows(x, rows, C, ldx).float(), (C,), None, None, eps)
         sc = _rows(scale, nb, C, ld_mod, torch.float32).repeat_interleave(rpb, 0)
         sh = _rows(shift, nb, C, ld_mod, torch.float32).repeat_interleave(rpb, 0)
-        _rows(y, rows, C, ldy).copy_((xv * (1 + sc) + sh).to(torch.bfloat16))
+        _rows(y, rows, C, ldy).copy_((xv * (1 + sc) + sh).to(_lib.elem_dtype()))
         return 0
 
     def mi355x_sd_patchify(self, x, B, C, H, W, p, out, ldo, stream):
         self.calls.append("patchify")
         xs = _flat(x, B * C * H * W, torch.float32).reshape(B, C, H // p, p, W // p, p)
         rows = xs.permute(0, 2, 4, 1, 3, 5).reshape(B * (H // p) * (W // p), C * p * p)
-        _rows(out, rows.shape[0], rows.shape[1], ldo).copy_(rows.to(torch.bfloat16))
+        _rows(out, rows.shape[0], rows.shape[1], ldo).copy_(rows.to(_lib.elem_dtype()))
         return 0
 
     def mi355x_sd_unpatchify(self, x, ldx, B, C, H, W, p, out, stream):
@@ -253,7 +256,7 @@ class Emulator:
 
         def view(p, S, bs, ts):
             n = (B - 1) * bs + (S - 1) * ts + H * D
-            return _flat(p, n, torch.bfloat16).as_strided((B, S, H, D), (bs, ts, D, 1))
+            return _flat(p, n, _lib.elem_dtype()).as_strided((B, S, H, D), (bs, ts, D, 1))
 
         qq, kk, vv = view(q, Sq, q_bs, q_ts).float(), view(k, Skv, k_bs, k_ts).float(), view(v, Skv, v_bs, v_ts).float()
         s = torch.einsum("bqhd,bkhd->bhqk", qq, kk) * scale
@@ -263,7 +266,7 @@ class Emulator:
             s = s + _flat(bias, n, torch.float32).as_strided((B, H, Sq, Skv), (bias_bs, bias_hs, bias_qs, 1))
         p = torch.softmax(s, -1)
         o = torch.einsum("bhqk,bkhd->bqhd", p, vv)
-        view(out, Sq, o_bs, o_ts).copy_(o.to(torch.bfloat16))
+        view(out, Sq, o_bs, o_ts).copy_(o.to(_lib.elem_dtype()))
         return 0
 
     # ---- norms ----
@@ -287,7 +290,7 @@ class Emulator:
         o = xv * s[:, 0:1] + s[:, 1:2]
         if silu:
             o = F.silu(o)
-        _rows(y, B * HW, C, ldy).copy_(o.reshape(B * HW, C).to(torch.bfloat16))
+        _rows(y, B * HW, C, ldy).copy_(o.reshape(B * HW, C).to(_lib.elem_dtype()))
         return 0
 
     def mi355x_sd_layernorm(self, x, rows, C, ldx, gamma, beta, eps, y, ldy, stream):
@@ -295,7 +298,7 @@ class Emulator:
         g = _flat(gamma, C, torch.float32) if gamma else None
         b = _flat(beta, C, torch.float32) if beta else None
         o = F.layer_norm(_rows(x, rows, C, ldx).float(), (C,), g, b, eps)
-        _rows(y, rows, C, ldy).copy_(o.to(torch.bfloat16))
+        _rows(y, rows, C, ldy).copy_(o.to(_lib.elem_dtype()))
         return 0
 
     # ---- small ops ----
@@ -310,13 +313,13 @@ class Emulator:
         e = torch.cat([torch.cos(emb), torch.sin(emb)], -1) if flip else torch.cat([torch.sin(emb), torch.cos(emb)], -1)
         nb = (n + group - 1) // group
         o = _rows(out, nb, group * dim, ldo)
-        o.copy_(e.reshape(nb, group * dim).to(torch.bfloat16))
+        o.copy_(e.reshape(nb, group * dim).to(_lib.elem_dtype()))
         return 0
 
     def mi355x_sd_silu(self, x, y, n, in_f32, out_f32, stream):
         self.calls.append("silu")
-        xi = _flat(x, n, torch.float32 if in_f32 else torch.bfloat16).float()
-        _flat(y, n, torch.float32 if out_f32 else torch.bfloat16).copy_(F.silu(xi))
+        xi = _flat(x, n, torch.float32 if in_f32 else _lib.elem_dtype()).float()
+        _flat(y, n, torch.float32 if out_f32 else _lib.elem_dtype()).copy_(F.silu(xi))
         return 0
 
     def mi355x_sd_conv_in3x3(self, x, in_scale, w, bias, y, B, Cin, H, W, Cout, ldy, stream):
@@ -324,16 +327,16 @@ class Emulator:
         xs = _flat(x, B * Cin * H * W, torch.float32).reshape(B, Cin, H, W)
         if in_scale:
             xs = xs * _flat(in_scale, 1, torch.float32)
-        xs = xs.to(torch.bfloat16).float()
-        wt = _flat(w, 9 * Cin * Cout, torch.bfloat16).float().reshape(3, 3, Cin, Cout).permute(3, 2, 0, 1)
+        xs = xs.to(_lib.elem_dtype()).float()
+        wt = _flat(w, 9 * Cin * Cout, _lib.elem_dtype()).float().reshape(3, 3, Cin, Cout).permute(3, 2, 0, 1)
         o = F.conv2d(xs, wt, _flat(bias, Cout, torch.float32) if bias else None, padding=1)
-        _rows(y, B * H * W, Cout, ldy).copy_(o.permute(0, 2, 3, 1).reshape(B * H * W, Cout).to(torch.bfloat16))
+        _rows(y, B * H * W, Cout, ldy).copy_(o.permute(0, 2, 3, 1).reshape(B * H * W, Cout).to(_lib.elem_dtype()))
         return 0
 
     def mi355x_sd_conv_out3x3(self, x, ldx, w, bias, y, B, Cin, H, W, Cout, stream):
         self.calls.append("conv_out")
         xs = _rows(x, B * H * W, Cin, ldx).float().reshape(B, H, W, Cin).permute(0, 3, 1, 2)
-        wt = _flat(w, Cout * 9 * Cin, torch.bfloat16).float().reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+        wt = _flat(w, Cout * 9 * Cin, _lib.elem_dtype()).float().reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
         o = F.conv2d(xs, wt, _flat(bias, Cout, torch.float32) if bias else None, padding=1)
         _flat(y, B * Cout * H * W, torch.float32).reshape(B, Cout, H, W).copy_(o)
         return 0
@@ -341,7 +344,7 @@ class Emulator:
     def mi355x_sd_add_nchw(self, x, ldx, r, B, C, HW, stream):
         xv = _rows(x, B * HW, C, ldx)
         rv = _flat(r, B * C * HW, torch.float32).reshape(B, C, HW).permute(0, 2, 1).reshape(B * HW, C)
-        xv.copy_((xv.float() + rv).to(torch.bfloat16))
+        xv.copy_((xv.float() + rv).to(_lib.elem_dtype()))
         return 0
 
     def mi355x_sd_embed_tokens(self, ids, n_tokens, seq_len, tok, pos, D, out, ldo, stream):
@@ -351,13 +354,13 @@ class Emulator:
         t = _rows(tok, V, D, D).float()[idx]
         if pos:
             t = t + _rows(pos, seq_len, D, D).float()[torch.arange(n_tokens) % seq_len]
-        _rows(out, n_tokens, D, ldo).copy_(t.to(torch.bfloat16))
+        _rows(out, n_tokens, D, ldo).copy_(t.to(_lib.elem_dtype()))
         return 0
 
     def mi355x_sd_rmsnorm(self, x, rows, C, ldx, weight, eps, y, ldy, stream):
         xv = _rows(x, rows, C, ldx).float()
         o = xv * torch.rsqrt(xv.pow(2).mean(-1, keepdim=True) + eps) * _flat(weight, C, torch.float32)
-        _rows(y, rows, C, ldy).copy_(o.to(torch.bfloat16))
+        _rows(y, rows, C, ldy).copy_(o.to(_lib.elem_dtype()))
         return 0
 
     def mi355x_sd_gated_activation(self, x, ldx, y, ldy, rows, Fd, kind, stream):
@@ -365,19 +368,19 @@ class Emulator:
         a, b = xv[:, :Fd], xv[:, Fd:]
         g = (a * torch.sigmoid(1.702 * a) if kind == 0 else F.gelu(a) if kind == 1 else F.silu(a) if kind == 2
              else F.gelu(a, approximate="tanh"))
-        _rows(y, rows, Fd, ldy).copy_((g * b).to(torch.bfloat16))
+        _rows(y, rows, Fd, ldy).copy_((g * b).to(_lib.elem_dtype()))
         return 0
 
     def mi355x_sd_activation(self, x, y, n, kind, stream):
-        v = _flat(x, n, torch.bfloat16).float()
+        v = _flat(x, n, _lib.elem_dtype()).float()
         o = v * torch.sigmoid(1.702 * v) if kind == 0 else (F.gelu(v) if kind == 1 else F.silu(v))
-        _flat(y, n, torch.bfloat16).copy_(o.to(torch.bfloat16))
+        _flat(y, n, _lib.elem_dtype()).copy_(o.to(_lib.elem_dtype()))
         return 0
 
     def mi355x_sd_conv1x1_nchw(self, x, in_scale, w, bias, y, B, Cin, Cout, HW, stream):
         assert Cin <= 16 and Cout <= 16
-        xi = (_flat(x, B * Cin * HW, torch.float32).reshape(B, Cin, HW) * in_scale).to(torch.bfloat16).float()
-        wt = _flat(w, Cout * Cin, torch.bfloat16).reshape(Cout, Cin).float()
+        xi = (_flat(x, B * Cin * HW, torch.float32).reshape(B, Cin, HW) * in_scale).to(_lib.elem_dtype()).float()
+        wt = _flat(w, Cout * Cin, _lib.elem_dtype()).reshape(Cout, Cin).float()
         out = torch.einsum("oc,bcp->bop", wt, xi)
         if bias:
             out = out + _flat(bias, Cout, torch.float32)[None, :, None]
@@ -387,7 +390,7 @@ class Emulator:
     def mi355x_sd_softmax_rows(self, x, ldx, y, ldy, rows, n, stream):
         assert n % 4 == 0 and ldx % 4 == 0 and ldy % 4 == 0
         xi = _rows(x, rows, n, ldx, torch.float32)
-        _rows(y, rows, n, ldy).copy_(torch.softmax(xi, -1).to(torch.bfloat16))
+        _rows(y, rows, n, ldy).copy_(torch.softmax(xi, -1).to(_lib.elem_dtype()))
         return 0
 
     def mi355x_sd_copy_rows(self, x, ldx, y, ldy, rows, C, stream):

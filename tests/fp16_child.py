@@ -1,0 +1,79 @@
+"""Child process of tests/test_fp16_mode.py / tests/test_gpu_fp16.py: runs with MI355X_SD_DTYPE=fp16 (one element type
+per process) and prints one JSON line of parity numbers for the IEEE-half build of the library.
+
+  python tests/fp16_child.py cpu   -- host logic through the ABI emulator (fp32 math, fp16 stores)
+  python tests/fp16_child.py gpu   -- the HIP kernels of libmi355x_sd_f16.so on cuda:0
+"""
+import json
+import math
+import os
+import sys
+
+os.environ["MI355X_SD_DTYPE"] = "fp16"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+from oracle import unet_ref as U  # noqa: E402
+from paddlemix_amd import _lib  # noqa: E402
+from paddlemix_amd.unet import UNet2DConditionModel, synth_unet_params  # noqa: E402
+from tests.configs import MINI_XL, TINY  # noqa: E402
+from tests.test_host_logic import _inputs, _rel  # noqa: E402
+
+
+def unet_cases(make_model, dev):
+    out = {}
+    for name, cfg, B, H, W, L in (("tiny", TINY, 2, 16, 16, 7), ("mini_xl", MINI_XL, 1, 16, 16, 77)):
+        P = synth_unet_params(cfg, seed=1234)
+        Ph = {k: v.to(torch.float16).float() if v.dim() > 1 else v for k, v in P.items()}   # the weights the device holds
+        sample, enc, added = _inputs(cfg, B, H, W, L)
+        ref = U.unet_forward(Ph, cfg, sample, 501, enc, added_cond_kwargs=added)
+        ref32 = U.unet_forward(P, cfg, sample, 501, enc, added_cond_kwargs=added)
+        model = make_model(cfg, P)
+        mv = (lambda t: t.to(dev)) if dev else (lambda t: t)
+        got = model(mv(sample), 501, mv(enc), added_cond_kwargs=None if added is None else {k: mv(v) for k, v in added.items()},
+                    return_dict=False)[0].float().cpu()
+        out[name] = dict(vs_oracle_same_weights=_rel(got, ref), vs_oracle_fp32_weights=_rel(got, ref32),
+                         finite=bool(torch.isfinite(got).all()))
+    return out
+
+
+def main(mode):
+    res = dict(elem=_lib.ELEM_NAME, lib=os.path.basename(_lib.LIB_PATH))
+    if mode == "cpu":
+        from tests.abi_emulator import Emulator
+        lib = _lib.load()   # dlopen works without a GPU: every declared symbol present, element type matches
+        res["elem_dtype_symbol"] = lib.mi355x_sd_elem_dtype()
+        res["unet"] = unet_cases(lambda cfg, P: UNet2DConditionModel(cfg, P, _test_backend=Emulator()), None)
+    else:
+        from paddlemix_amd import ops
+        ops.init(0)
+        res["elem_dtype_symbol"] = _lib.load().mi355x_sd_elem_dtype()
+        g = torch.Generator().manual_seed(0)
+        h = lambda t: t.to(torch.float16)   # noqa: E731
+        # GEMM (bias + residual), implicit-GEMM conv, attention, GroupNorm+SiLU against fp32 math on the same fp16 operands
+        a, w = h(torch.randn(1000, 1280, generator=g)), h(torch.randn(520, 1280, generator=g) / math.sqrt(1280))
+        bias, r = torch.randn(520, generator=g), h(torch.randn(1000, 520, generator=g))
+        got = ops.linear(a.cuda(), w.cuda(), bias.cuda(), residual=r.cuda()).float().cpu()
+        res["linear"] = _rel(got, a.float() @ w.float().t() + bias + r.float())
+        x = h(torch.randn(2, 24, 24, 64, generator=g))
+        wc = h(torch.randn(96, 64, 3, 3, generator=g) / math.sqrt(576))
+        got = ops.conv3x3(x.cuda(), wc.permute(0, 2, 3, 1).reshape(96, 576).contiguous().cuda(), None).float().cpu()
+        ref = F.conv2d(x.float().permute(0, 3, 1, 2), wc.float(), padding=1).permute(0, 2, 3, 1).reshape(-1, 96)
+        res["conv3x3"] = _rel(got.reshape(-1, 96), ref)
+        q, k, v = (h(torch.randn(2, 300, 5, 64, generator=g)) for _ in range(3))
+        got = ops.sdpa(q.cuda(), k.cuda(), v.cuda()).float().cpu()
+        ref = F.scaled_dot_product_attention(*(t.float().permute(0, 2, 1, 3) for t in (q, k, v))).permute(0, 2, 1, 3)
+        res["sdpa"] = _rel(got, ref)
+        xg = h(torch.randn(2, 256, 128, generator=g) * 2 + 0.5)
+        gam, bet = torch.randn(128, generator=g), torch.randn(128, generator=g)
+        got = ops.group_norm(xg.cuda(), gam.cuda(), bet.cuda(), 32, 1e-5, True).float().cpu()
+        ref = F.silu(F.group_norm(xg.float().permute(0, 2, 1), 32, gam, bet, 1e-5)).permute(0, 2, 1)
+        res["group_norm_silu"] = _rel(got, ref)
+        res["unet"] = unet_cases(lambda cfg, P: UNet2DConditionModel(cfg, P, device="cuda:0"), "cuda:0")
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
