@@ -51,3 +51,17 @@ CLIP_BIGG = dict(vocab_size=49408, hidden_size=1280, intermediate_size=5120, num
 # T5 v1.1 encoder in miniature and the XXL geometry SD3 uses (public config: d_model 4096, 64 heads x 64, d_ff 10240, 24 layers)
 MINI_T5 = dict(vocab_size=500, d_model=64, d_kv=16, d_ff=128, num_layers=3, num_heads=4)
 T5_XXL = dict(vocab_size=32128, d_model=4096, d_kv=64, d_ff=10240, num_layers=24, num_heads=64)
+
+# configuration variants the reference's own model tests exercise (ppdiffusers/tests/models/test_models_unet_2d_condition.py:
+# :250 attention_head_dim tuple, :268 use_linear_projection, :286 cross_attention_dim tuple; :868 the 9-channel inpainting
+# UNet; :924 the SD-2 layout = linear projections + per-level head counts) on the tiny geometry
+UNET_VARIANTS = {
+    "inpaint-9ch": dict(TINY, in_channels=9),
+    "cross-dim-tuple": dict(TINY, cross_attention_dim=(64, 64)),
+    "head-dim-tuple": dict(TINY, attention_head_dim=(8, 16)),
+    "layers-per-block-tuple": dict(TINY, layers_per_block=(1, 2)),
+    "sd2-layout": dict(TINY, use_linear_projection=True, attention_head_dim=(4, 8)),
+    "upcast-attention": dict(TINY, upcast_attention=True),
+    "center-input": dict(TINY, center_input_sample=True),
+    "sin-first-shifted": dict(TINY, flip_sin_to_cos=False, freq_shift=1),
+}

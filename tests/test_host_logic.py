@@ -6,13 +6,14 @@ import torch
 from oracle import unet_ref as U
 from paddlemix_amd.unet import UNet2DConditionModel, synth_unet_params, unet_param_shapes
 from tests.abi_emulator import Emulator
-from tests.configs import MINI_XL, SD15, SDXL, TINY
+from tests.configs import MINI_XL, SD15, SDXL, TINY, UNET_VARIANTS
 
 
 def _inputs(cfg, B, H, W, L=77, seed=0):
     g = torch.Generator().manual_seed(seed)
-    sample = torch.randn(B, 4, H, W, generator=g)
+    sample = torch.randn(B, cfg.get("in_channels", 4), H, W, generator=g)
     cross = cfg["cross_attention_dim"]
+    cross = cross[0] if isinstance(cross, (tuple, list)) else cross
     enc = torch.randn(B, L, cross, generator=g)
     added = None
     if cfg.get("addition_embed_type") == "text_time":
@@ -49,6 +50,18 @@ def test_program_matches_oracle(cfg, B, H, W, L):
     folded = UNet2DConditionModel(cfg, P, fold_layernorm=True, _test_backend=emu2)
     out3 = folded(sample, t, enc, added_cond_kwargs=added).sample
     assert "linear_ln" in emu2.calls and _rel(out3, ref) < 2e-2
+
+
+@pytest.mark.parametrize("name", sorted(UNET_VARIANTS))
+def test_config_variants_match_oracle(name):
+    """the configuration switches the reference's model tests flip (tests/configs.py UNET_VARIANTS)"""
+    cfg = UNET_VARIANTS[name]
+    P = synth_unet_params(cfg, seed=7)
+    Pb = {k: v.to(torch.bfloat16).float() if v.dim() > 1 else v for k, v in P.items()}
+    sample, enc, _ = _inputs(cfg, 2, 16, 16, 7)
+    ref = U.unet_forward(Pb, cfg, sample, 333, enc)
+    out = UNet2DConditionModel(cfg, P, _test_backend=Emulator())(sample, 333, enc, return_dict=False)[0]
+    assert out.shape == ref.shape and _rel(out, ref) < 2e-2, _rel(out, ref)
 
 
 def test_param_inventory_matches_oracle():
