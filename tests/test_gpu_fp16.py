@@ -19,3 +19,6 @@ def test_fp16_build_kernels_and_unet_parity():
         # (weights-only rounding), the device adds the activation stores -> bar 3e-3 (bf16 build: 2e-2)
         assert c["vs_oracle_same_weights"] < 3e-3, (name, c)
         assert c["vs_oracle_fp32_weights"] < 4e-3, (name, c)
+    # SD3 MMDiT, VAE decoder, CLIP and T5 encoders on fp16 elements (bf16 bars: 1e-2 .. 2e-2)
+    m = r["models"]
+    assert m["sd3"] < 2e-3 and m["vae"] < 3e-3 and m["clip"] < 2e-3 and m["t5"] < 3e-3, m
