@@ -39,7 +39,8 @@ struct AttLds {
   static constexpr int CHUNKS = KVBLK * (DP / 8) / ATT_THREADS;      // 16-B chunks per thread per tile: 2 / 3 / 5
 };
 
-template <int DP, bool HAS_BIAS>
+// QT: query tiles per block (1; 2 for the short-KV cross-attention launches, see the query-tile loop at the bottom)
+template <int DP, bool HAS_BIAS, int QT = 1>
 __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_kernel(const AttnArgs p) {
   using L = AttLds<DP>;
   constexpr int NBUF = (DP <= 96) ? 2 : 1;
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_ker
   const int hi = lane >> 5;
   const int lq = lane & 31;
 
-  const int nqb = (p.Sq + QBLK - 1) / QBLK;
+  const int nqb = (p.Sq + QBLK * QT - 1) / (QBLK * QT);
   const int lid = xcd_remap(blockIdx.x, nqb * p.B * p.H);
   const int qb = lid % nqb;
   const int bh = lid / nqb;
@@ -63,21 +64,6 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_ker
   const bf16* Kp = p.K + (size_t)b * p.k_bs + (size_t)h * p.D;
   const bf16* Vp = p.V + (size_t)b * p.v_bs + (size_t)h * p.D;
   bf16* Op = p.O + (size_t)b * p.o_bs + (size_t)h * p.D;
-
-  // ---- Q fragments (MFMA B operand): lane (q = lq, hi) holds d = ks*16 + hi*8 .. +8 ----
-  const int q_row = qb * QBLK + wave * QROWS + lq;
-  const bool q_ok = q_row < p.Sq;
-  bf16x8 qf[KS];
-  {
-    const bf16* qr = Qp + (size_t)(q_ok ? q_row : 0) * p.q_ts;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int d0 = ks * 16 + hi * 8;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (q_ok && d0 < p.D) v = *reinterpret_cast<const u32x4*>(qr + d0);
-      qf[ks] = *reinterpret_cast<bf16x8*>(&v);
-    }
-  }
 
   // ---- K/V tile loader: thread owns CHUNKS 16-B chunks of the K tile and of the V tile.  Buffer (SRD) loads: a
   // per-lane 32-bit byte offset that never changes + a scalar per-tile offset; rows past Skv fall outside the
@@ -116,11 +102,12 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_ker
     }
   };
 
+  // per-query-tile state (re-initialised by the q-tile loop at the bottom)
+  int q_row = 0;
+  bool q_ok = false;
+  bool stage_kv = true;   // false on the 2nd.. query tile of a short-KV block: both K/V tiles are already resident in LDS
+  bf16x8 qf[KS];
   f32x16 o[DB];
-#pragma unroll
-  for (int i = 0; i < DB; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
   float m_run = -INFINITY;   // running max of raw scores (q . k [+ bias/scale]), both half-waves agree
   float l_run = 0.f;         // this half-wave's partial row sum
   const float c2 = p.scale * 1.4426950408889634f;  // exp(x*scale) = exp2(x*c2)
@@ -148,7 +135,7 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_ker
   auto tile_body = [&](const int t, auto mask_tag) {
     constexpr bool MASK = decltype(mask_tag)::value;
     const int buf = (NBUF == 2) ? (t & 1) : 0;
-    if (NBUF == 2 && t + 1 < ntiles && !(p.dbg & 1)) load_kv((t + 1) * KVBLK);
+    if (NBUF == 2 && t + 1 < ntiles && stage_kv && !(p.dbg & 1)) load_kv((t + 1) * KVBLK);
     const unsigned char* ks_ = smem + buf * (L::KBYTES + L::VBYTES);
     const unsigned char* vs_ = ks_ + L::KBYTES;
 
@@ -246,7 +233,7 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_ker
     }
 
     if (NBUF == 2) {
-      if (t + 1 < ntiles && !(p.dbg & 1)) store_kv(buf ^ 1);
+      if (t + 1 < ntiles && stage_kv && !(p.dbg & 1)) store_kv(buf ^ 1);
       __syncthreads();
     } else {
       __syncthreads();
@@ -259,25 +246,52 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_ker
   };
 
   const int nfull = p.Skv / KVBLK;
-  for (int t = 0; t < nfull; ++t) tile_body(t, std::false_type{});
-  if (nfull < ntiles) tile_body(nfull, std::true_type{});
-
-  // ---- finalize: O[q][d] = O^T[d][q] / l ; lane holds d = db*32 + (r&3) + 8*(r>>2) + 4*hi ----
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv_l = (l_tot > 0.f) ? 1.0f / l_tot : 0.f;
-  if (q_ok) {
-    bf16* orow = Op + (size_t)q_row * p.o_ts;
+  // Query-tile loop. Long KV: one tile per block (QT == 1, the loop vanishes). Short KV (cross-attention, Skv <= 2 tiles = the two LDS
+  // buffers): a block walks QT query tiles against K/V staged ONCE -- these launches are launch/latency bound
+  // (SDXL 8x20x1024x77: 21.6 us for 45 MB), and the staging chain global -> registers -> LDS -> barrier is most of a block's life.
+#pragma unroll 1
+  for (int qi = 0; qi < QT; ++qi) {
+    q_row = (qb * QT + qi) * QBLK + wave * QROWS + lq;
+    q_ok = q_row < p.Sq;
+    stage_kv = qi == 0;
+    if (qi > 0 && (qb * QT + qi) * QBLK >= p.Sq) break;   // block-uniform: no query rows left
+    {   // Q fragments (MFMA B operand): lane (q = lq, hi) holds d = ks*16 + hi*8 .. +8
+      const bf16* qr = Qp + (size_t)(q_ok ? q_row : 0) * p.q_ts;
 #pragma unroll
-    for (int db = 0; db < DB; ++db)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int d = db * 32 + 8 * c + 4 * hi;
-        if (d < p.D) {
-          u32x2 pk = {pack_bf16(o[db][4 * c + 0] * inv_l, o[db][4 * c + 1] * inv_l),
-                      pack_bf16(o[db][4 * c + 2] * inv_l, o[db][4 * c + 3] * inv_l)};
-          *reinterpret_cast<u32x2*>(orow + d) = pk;
-        }
+      for (int ks = 0; ks < KS; ++ks) {
+        const int d0 = ks * 16 + hi * 8;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (q_ok && d0 < p.D) v = *reinterpret_cast<const u32x4*>(qr + d0);
+        qf[ks] = *reinterpret_cast<bf16x8*>(&v);
       }
+    }
+#pragma unroll
+    for (int i = 0; i < DB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    m_run = -INFINITY;
+    l_run = 0.f;
+
+    for (int t = 0; t < nfull; ++t) tile_body(t, std::false_type{});
+    if (nfull < ntiles) tile_body(nfull, std::true_type{});
+
+    // ---- finalize: O[q][d] = O^T[d][q] / l ; lane holds d = db*32 + (r&3) + 8*(r>>2) + 4*hi ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv_l = (l_tot > 0.f) ? 1.0f / l_tot : 0.f;
+    if (q_ok) {
+      bf16* orow = Op + (size_t)q_row * p.o_ts;
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int d = db * 32 + 8 * c + 4 * hi;
+          if (d < p.D) {
+            u32x2 pk = {pack_bf16(o[db][4 * c + 0] * inv_l, o[db][4 * c + 1] * inv_l),
+                        pack_bf16(o[db][4 * c + 2] * inv_l, o[db][4 * c + 3] * inv_l)};
+            *reinterpret_cast<u32x2*>(orow + d) = pk;
+          }
+        }
+    }
   }
 }
 
@@ -289,6 +303,16 @@ static int launch_dp(const AttnArgs& a0, hipStream_t stream) {
   }();
   AttnArgs a = a0;
   a.dbg = dbg;
+  // short KV (both tiles stay resident in the two LDS buffers) and enough query tiles to keep every CU busy: two query
+  // tiles per block
+  static const bool no_qt = getenv("MI355X_SD_ATTN_NO_QT") != nullptr;
+  const long qtiles = (long)((a.Sq + QBLK - 1) / QBLK) * a.B * a.H;
+  if (DP == 64 && a.Skv <= 2 * KVBLK && qtiles >= 1024 && !a.bias && !no_qt) {
+    constexpr int QT = 2;
+    const int nqb = (a.Sq + QBLK * QT - 1) / (QBLK * QT);
+    hipLaunchKernelGGL((attention_kernel<DP, false, (DP == 64 ? QT : 1)>), dim3(nqb * a.B * a.H), dim3(ATT_THREADS), 0, stream, a);
+    return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+  }
   const int nqb = (a.Sq + QBLK - 1) / QBLK;
   dim3 grid(nqb * a.B * a.H), block(ATT_THREADS);
   if (a.bias)
