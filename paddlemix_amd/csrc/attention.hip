@@ -112,7 +112,22 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_ker
   float l_run = 0.f;         // this half-wave's partial row sum
   const float c2 = p.scale * 1.4426950408889634f;  // exp(x*scale) = exp2(x*c2)
 
+  // Q fragments (MFMA B operand) of query tile qt: lane (q = lq, hi) holds d = ks*16 + hi*8 .. +8
+  auto load_q = [&](const int qt, bf16x8 (&dst)[KS]) {
+    const int row = qt * QBLK + wave * QROWS + lq;
+    const bool ok = row < p.Sq;
+    const bf16* qr = Qp + (size_t)(ok ? row : 0) * p.q_ts;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int d0 = ks * 16 + hi * 8;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (ok && d0 < p.D) v = *reinterpret_cast<const u32x4*>(qr + d0);
+      dst[ks] = *reinterpret_cast<bf16x8*>(&v);
+    }
+  };
+
   const int ntiles = (p.Skv + KVBLK - 1) / KVBLK;
+  load_q(qb * QT, qf);   // in flight together with the first K/V tile
   load_kv(0);
   store_kv(0);
   __syncthreads();
@@ -255,16 +270,7 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_ker
     q_ok = q_row < p.Sq;
     stage_kv = qi == 0;
     if (qi > 0 && (qb * QT + qi) * QBLK >= p.Sq) break;   // block-uniform: no query rows left
-    {   // Q fragments (MFMA B operand): lane (q = lq, hi) holds d = ks*16 + hi*8 .. +8
-      const bf16* qr = Qp + (size_t)(q_ok ? q_row : 0) * p.q_ts;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const int d0 = ks * 16 + hi * 8;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (q_ok && d0 < p.D) v = *reinterpret_cast<const u32x4*>(qr + d0);
-        qf[ks] = *reinterpret_cast<bf16x8*>(&v);
-      }
-    }
+    if (qi > 0) load_q(qb * QT + qi, qf);   // (prefetching these under the previous tile cost 27 registers and was slower)
 #pragma unroll
     for (int i = 0; i < DB; ++i)
 #pragma unroll
