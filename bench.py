@@ -39,7 +39,8 @@ WORKLOADS = {
     # the same with fp8 activations into the block GEMMs: W8A8 on the fp8 matrix pipe (v_mfma_scale_f32_16x16x128_f8f6f4)
     "sd3-1024-bs8-w8a8": dict(cfg=SD3_MEDIUM, B=8, H=128, W=128, L=154, gflop_step=None, sd3=True, fp8=True, a8=True),
 }
-PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16, MI355X_MICROARCH.md chip table
+PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16 / fp16, MI355X_MICROARCH.md chip table
+PEAK_FP8_TFLOPS = 5000.0   # dense MFMA fp8 (the W8A8 workload's block GEMMs)
 
 
 def parse():
@@ -217,7 +218,8 @@ def main():
                    "sd3-1024-bs8-w8a8": "MMDiT denoising steps/sec (SD3-medium 1024^2, bs=8, fp8 weights + activations, fp8 MFMA)"}[args.workload],
         "value": world * args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "vs_baseline": None,
+        "dtype": ("fp8 e4m3 (block GEMM operands) + " + args.dtype) if wl.get("a8") else args.dtype, "data": "synthetic",
         "config": {"workload": args.workload, "latents": [B, cfg["in_channels"] if is_sd3 else 4, H, W], "text": [B, L, cfg["joint_attention_dim" if is_sd3 else "cross_attention_dim"]],
                    "batch_per_gpu": B, "global_batch": B * world, "scheduler": "FlowMatchEuler/28" if is_sd3 else "EulerDiscrete/30",
                    "weights": f"random-init {args.dtype} (N(0,1/fan_in)), RCCL-broadcast from rank 0" if world > 1
@@ -261,8 +263,10 @@ def main():
         names = {"gemm": "linear GEMM class: gemm_pipe_kernel<false,...> / gemm256_kernel<false> / gemm_bf16_kernel<false,...>",
                  "conv": "conv3x3 implicit-GEMM class: gemm_pipe_kernel<true,...> / gemm256_kernel<true>",
                  "attn": "attention_kernel<64,false>"}
-        res["roofline"] = {"bound": "mfma", "kernel": names.get(dom, dom), "achieved": ach, "peak": PEAK_BF16_TFLOPS,
-                           "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+        # the W8A8 workload's GEMM class runs on the fp8 matrix pipe: price it against the fp8 peak
+        peak = PEAK_FP8_TFLOPS if (wl.get("a8") and dom == "gemm") else PEAK_BF16_TFLOPS
+        res["roofline"] = {"bound": "mfma", "kernel": names.get(dom, dom), "achieved": ach, "peak": peak,
+                           "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
                            "launches_per_step": d["launches"], "avg_launch_ms": d["ms"] / d["launches"],
                            "algorithmic_gflop_per_step": d["gflop"]}
         # HBM traffic comes from rocprofv3 PMC passes (scripts/traffic.sh: FETCH_SIZE / WRITE_SIZE in separate passes,
