@@ -58,12 +58,15 @@ UNET_DEFAULTS = dict(
     resnet_out_scale_factor=1.0,
     time_embedding_type="positional",
     projection_class_embeddings_input_dim=None,
+    class_embed_type=None,
+    num_class_embeds=None,
+    class_embeddings_concat=False,
 )
 
 _UNSUPPORTED_IF_SET = (
-    "encoder_hid_dim", "encoder_hid_dim_type", "class_embed_type", "num_class_embeds",
+    "encoder_hid_dim", "encoder_hid_dim_type",
     "time_embedding_dim", "time_embedding_act_fn", "timestep_post_act", "time_cond_proj_dim",
-    "cross_attention_norm", "dual_cross_attention", "class_embeddings_concat", "resnet_skip_time_act",
+    "cross_attention_norm", "dual_cross_attention", "resnet_skip_time_act",
 )
 
 
@@ -82,6 +85,10 @@ def normalize_config(config: dict) -> dict:
         raise NotImplementedError("oracle: only SiLU resnets restated")
     if cfg.get("conv_in_kernel", 3) != 3 or cfg.get("conv_out_kernel", 3) != 3:
         raise NotImplementedError("oracle: 3x3 conv_in / conv_out only")
+    if cfg["class_embed_type"] not in (None, "timestep", "identity", "projection", "simple_projection"):
+        raise ValueError(f"class_embed_type {cfg['class_embed_type']!r}")
+    if cfg["class_embed_type"] in ("projection", "simple_projection") and cfg["projection_class_embeddings_input_dim"] is None:
+        raise ValueError(f"`class_embed_type`: '{cfg['class_embed_type']}' requires `projection_class_embeddings_input_dim` be set")
     n = len(cfg["down_block_types"])
 
     def tup(x):
@@ -141,6 +148,43 @@ def get_timestep_embedding(timesteps: Tensor, embedding_dim: int, flip_sin_to_co
     if embedding_dim % 2 == 1:
         emb = F.pad(emb, (0, 1))
     return emb
+
+
+def class_embedding_shapes(cfg: dict, S: dict) -> None:
+    """parameters of `class_embedding` (unet_2d_condition.py:354-382), in construction order"""
+    boc = cfg["block_out_channels"]
+    ted = boc[0] * 4
+    ct, pdim = cfg["class_embed_type"], cfg["projection_class_embeddings_input_dim"]
+    if ct is None and cfg["num_class_embeds"] is not None:
+        S["class_embedding.weight"] = (cfg["num_class_embeds"], ted)          # nn.Embedding
+    elif ct in ("timestep", "projection"):                                     # TimestepEmbedding
+        i = boc[0] if ct == "timestep" else pdim
+        S["class_embedding.linear_1.weight"], S["class_embedding.linear_1.bias"] = (i, ted), (ted,)
+        S["class_embedding.linear_2.weight"], S["class_embedding.linear_2.bias"] = (ted, ted), (ted,)
+    elif ct == "simple_projection":                                            # nn.Linear
+        S["class_embedding.weight"], S["class_embedding.bias"] = (pdim, ted), (ted,)
+
+
+def class_embedding(P: Params, cfg: dict, emb: Tensor, class_labels) -> Tensor:
+    """emb (+|concat) class_embedding(class_labels) -- unet_2d_condition.py:953-975"""
+    ct = cfg["class_embed_type"]
+    if ct is None and cfg["num_class_embeds"] is None:
+        return emb
+    if class_labels is None:
+        raise ValueError("class_labels should be provided when num_class_embeds > 0")
+    if ct is None:
+        ce = P["class_embedding.weight"][class_labels.to(torch.int64)]
+    elif ct == "timestep":
+        t = get_timestep_embedding(class_labels.reshape(-1).to(torch.float32), cfg["block_out_channels"][0],
+                                   cfg["flip_sin_to_cos"], cfg["freq_shift"]).to(emb.dtype)
+        ce = timestep_embedding_mlp(P, "class_embedding", t)
+    elif ct == "identity":
+        ce = class_labels.to(emb.dtype)
+    elif ct == "projection":
+        ce = timestep_embedding_mlp(P, "class_embedding", class_labels.to(emb.dtype))
+    else:
+        ce = linear(P, "class_embedding", class_labels.to(emb.dtype))
+    return torch.cat([emb, ce], dim=-1) if cfg["class_embeddings_concat"] else emb + ce
 
 
 def timestep_embedding_mlp(P: Params, name: str, x: Tensor) -> Tensor:
@@ -303,7 +347,7 @@ def unet_forward(P: Params, config: dict, sample: Tensor, timestep, encoder_hidd
                  added_cond_kwargs: Optional[dict] = None, attention_mask: Optional[Tensor] = None,
                  encoder_attention_mask: Optional[Tensor] = None, processor: str = "math",
                  taps: Optional[dict] = None, down_block_additional_residuals=None,
-                 mid_block_additional_residual: Optional[Tensor] = None) -> Tensor:
+                 mid_block_additional_residual: Optional[Tensor] = None, class_labels=None) -> Tensor:
     """Returns the noise prediction [B, out_channels, H, W] (the ``(sample,)`` tuple's first element).
 
     ``taps``: optional dict that receives named intermediate activations (for layer-wise parity tests).
@@ -331,6 +375,7 @@ def unet_forward(P: Params, config: dict, sample: Tensor, timestep, encoder_hidd
     timesteps = timesteps.expand(B)
     t_emb = get_timestep_embedding(timesteps, boc[0], cfg["flip_sin_to_cos"], cfg["freq_shift"]).to(dtype)
     emb = timestep_embedding_mlp(P, "time_embedding", t_emb)
+    emb = class_embedding(P, cfg, emb, class_labels)
 
     if cfg["addition_embed_type"] == "text_time":  # SDXL (:991-1010)
         if added_cond_kwargs is None or "text_embeds" not in added_cond_kwargs:
@@ -449,7 +494,7 @@ def unet_param_shapes(config: dict) -> Dict[str, tuple]:
     def resnet(name, cin, cout):
         norm(name + ".norm1", cin)
         conv(name + ".conv1", cin, cout, 3)
-        lin(name + ".time_emb_proj", ted, cout)
+        lin(name + ".time_emb_proj", ted * (2 if cfg["class_embeddings_concat"] else 1), cout)
         norm(name + ".norm2", cout)
         conv(name + ".conv2", cout, cout, 3)
         if cin != cout:
@@ -484,6 +529,7 @@ def unet_param_shapes(config: dict) -> Dict[str, tuple]:
     conv("conv_in", cfg["in_channels"], boc[0], 3)
     lin("time_embedding.linear_1", boc[0], ted)
     lin("time_embedding.linear_2", ted, ted)
+    class_embedding_shapes(cfg, S)
     if cfg["addition_embed_type"] == "text_time":
         lin("add_embedding.linear_1", cfg["projection_class_embeddings_input_dim"], ted)
         lin("add_embedding.linear_2", ted, ted)

@@ -44,11 +44,11 @@ UNET_DEFAULTS = dict(
     transformer_layers_per_block=1, attention_head_dim=8, use_linear_projection=False, addition_embed_type=None,
     addition_time_embed_dim=None, upcast_attention=False, resnet_time_scale_shift="default",
     resnet_out_scale_factor=1.0, time_embedding_type="positional", projection_class_embeddings_input_dim=None,
-    time_cond_proj_dim=None,
+    time_cond_proj_dim=None, class_embed_type=None, num_class_embeds=None, class_embeddings_concat=False,
 )
-_UNSUPPORTED_IF_SET = ("encoder_hid_dim", "encoder_hid_dim_type", "class_embed_type", "num_class_embeds",
+_UNSUPPORTED_IF_SET = ("encoder_hid_dim", "encoder_hid_dim_type",
                        "time_embedding_dim", "time_embedding_act_fn", "timestep_post_act", "time_cond_proj_dim",
-                       "cross_attention_norm", "dual_cross_attention", "class_embeddings_concat", "resnet_skip_time_act")
+                       "cross_attention_norm", "dual_cross_attention", "resnet_skip_time_act")
 
 
 def normalize_config(config: Mapping) -> dict:
@@ -66,6 +66,14 @@ def normalize_config(config: Mapping) -> dict:
         raise NotImplementedError("downsample_padding must be 1")
     if cfg["addition_embed_type"] not in (None, "text_time"):
         raise NotImplementedError(f"addition_embed_type={cfg['addition_embed_type']!r}")
+    # class embedding (unet_2d_condition.py:354-382; same messages)
+    ct = cfg["class_embed_type"]
+    if ct not in (None, "timestep", "identity", "projection", "simple_projection"):
+        raise ValueError(f"class_embed_type {ct!r}")
+    if ct in ("projection", "simple_projection") and cfg["projection_class_embeddings_input_dim"] is None:
+        raise ValueError(f"`class_embed_type`: '{ct}' requires `projection_class_embeddings_input_dim` be set")
+    if cfg["class_embeddings_concat"] and cfg["addition_embed_type"] is not None:
+        raise NotImplementedError("class_embeddings_concat together with addition_embed_type")
     n = len(cfg["down_block_types"])
     tup = lambda x: tuple(x) if isinstance(x, (list, tuple)) else (x,) * n  # noqa: E731
     cfg["block_out_channels"] = tuple(cfg["block_out_channels"])
@@ -157,15 +165,24 @@ def unet_param_shapes(config: Mapping) -> Dict[str, tuple]:
     conv("conv_in", cfg["in_channels"], boc[0], 3)
     lin("time_embedding.linear_1", boc[0], ted)
     lin("time_embedding.linear_2", ted, ted)
+    ct, pdim = cfg["class_embed_type"], cfg["projection_class_embeddings_input_dim"]
+    if ct is None and cfg["num_class_embeds"] is not None:
+        S["class_embedding.weight"] = (cfg["num_class_embeds"], ted)          # nn.Embedding
+    elif ct in ("timestep", "projection"):                                     # TimestepEmbedding
+        lin("class_embedding.linear_1", boc[0] if ct == "timestep" else pdim, ted)
+        lin("class_embedding.linear_2", ted, ted)
+    elif ct == "simple_projection":
+        lin("class_embedding", pdim, ted)
     if cfg["addition_embed_type"] == "text_time":
         lin("add_embedding.linear_1", cfg["projection_class_embeddings_input_dim"], ted)
         lin("add_embedding.linear_2", ted, ted)
+    ted_b = ted * (2 if cfg["class_embeddings_concat"] else 1)   # blocks_time_embed_dim (unet_2d_condition.py:443-449)
     for d in _structure(cfg):
         if d[0] == "resnet":
             _, name, cin, cout, _ = d
             norm(name + ".norm1", cin)
             conv(name + ".conv1", cin, cout, 3)
-            lin(name + ".time_emb_proj", ted, cout)
+            lin(name + ".time_emb_proj", ted_b, cout)
             norm(name + ".norm2", cout)
             conv(name + ".conv2", cout, cout, 3)
             if cin != cout:
@@ -300,6 +317,15 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
         if cfg["addition_embed_type"] == "text_time":
             put_lin("add_embedding.linear_1", "add_embedding.linear_1")
             put_lin("add_embedding.linear_2", "add_embedding.linear_2")
+        ct = cfg["class_embed_type"]
+        self._class_kind = ("embedding" if (ct is None and cfg["num_class_embeds"] is not None) else ct)
+        if self._class_kind == "embedding":
+            W["class_embedding.table"] = bf(get("class_embedding.weight"))
+        elif ct in ("timestep", "projection"):
+            put_lin("class_embedding.linear_1", "class_embedding.linear_1")
+            put_lin("class_embedding.linear_2", "class_embedding.linear_2")
+        elif ct == "simple_projection":
+            put_lin("class_embedding", "class_embedding")
         temb_w, temb_b = [], []
         self._temb_off: Dict[str, int] = {}
         off = 0
@@ -473,10 +499,50 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
         emit(lib.mi355x_sd_timestep_embedding, (plan.t.data_ptr(), 1, B, boc[0], 1, 1 if cfg["flip_sin_to_cos"] else 0,
                                                 float(cfg["freq_shift"]), 1.0, 10000.0, t0.data_ptr(), boc[0], stream),
              "misc")
+        # class embedding (unet_2d_condition.py:953-975): emb + class_emb, or [emb | class_emb] when class_embeddings_concat.
+        # The add is the residual input of a GEMM epilogue, the concat is a GEMM / gather writing the upper columns.
+        ck = self._class_kind
+        concat = bool(cfg["class_embeddings_concat"])
+        ted_b = ted * (2 if concat else 1)
         e1 = persist((B, ted), _lib.elem_dtype())
-        emb = persist((B, ted), _lib.elem_dtype())
+        emb_t = persist((B, ted_b), _lib.elem_dtype())
+        emb = _V(emb_t.data_ptr(), B, ted, ted_b)          # the time-embedding half (all of it without concat)
+        cls_out = emb.cols(ted, ted) if concat else None     # where the class embedding goes when concatenated
+        plan.class_in = None
+        pre_cls = None   # class embedding available BEFORE the time MLP (gather / identity): added as its residual
+        if ck == "embedding":
+            plan.class_in = persist((B,), torch.int32)
+            dst = cls_out if concat else _V(persist((B, ted), _lib.elem_dtype()).data_ptr(), B, ted)
+            emit(lib.mi355x_sd_embed_tokens, (plan.class_in.data_ptr(), B, 1, wp("class_embedding.table"), None, ted, dst.p,
+                                              dst.ld, stream), "misc")
+            pre_cls = None if concat else dst
+        elif ck == "identity":
+            plan.class_in = persist((B, ted), _lib.elem_dtype())
+            src = _V(plan.class_in.data_ptr(), B, ted)
+            if concat:
+                emit(lib.mi355x_sd_copy_rows, (src.p, src.ld, cls_out.p, cls_out.ld, B, ted, stream), "misc")
+            else:
+                pre_cls = src
         linear(_V(t0.data_ptr(), B, boc[0]), "time_embedding.linear_1", _V(e1.data_ptr(), B, ted), flags=SILU)
-        linear(_V(e1.data_ptr(), B, ted), "time_embedding.linear_2", _V(emb.data_ptr(), B, ted))
+        linear(_V(e1.data_ptr(), B, ted), "time_embedding.linear_2", emb, R=pre_cls)
+        if ck in ("timestep", "projection", "simple_projection"):
+            if ck == "timestep":   # class_labels -> sinusoid (time_proj) -> TimestepEmbedding
+                plan.class_in = persist((B,), torch.float32)
+                cin = _V(persist((B, boc[0]), _lib.elem_dtype()).data_ptr(), B, boc[0])
+                emit(lib.mi355x_sd_timestep_embedding, (plan.class_in.data_ptr(), B, B, boc[0], 1,
+                                                        1 if cfg["flip_sin_to_cos"] else 0, float(cfg["freq_shift"]), 1.0,
+                                                        10000.0, cin.p, cin.ld, stream), "misc")
+            else:
+                pdim = cfg["projection_class_embeddings_input_dim"]
+                plan.class_in = persist((B, pdim), _lib.elem_dtype())
+                cin = _V(plan.class_in.data_ptr(), B, pdim)
+            dst, res = (cls_out, None) if concat else (emb, emb)
+            if ck == "simple_projection":
+                linear(cin, "class_embedding", dst, R=res)
+            else:
+                c1 = _V(persist((B, ted), _lib.elem_dtype()).data_ptr(), B, ted)
+                linear(cin, "class_embedding.linear_1", c1, flags=SILU)
+                linear(c1, "class_embedding.linear_2", dst, R=res)
         plan.add_in = plan.time_ids = None
         if cfg["addition_embed_type"] == "text_time":
             pdim = cfg["projection_class_embeddings_input_dim"]
@@ -488,12 +554,11 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
             plan._add_emit_index = len(prog)  # the time_ids embedding op is inserted here once widths are known
             linear(_V(plan.add_in.data_ptr(), B, pdim), "add_embedding.linear_1", _V(a1.data_ptr(), B, ted),
                    flags=SILU)
-            linear(_V(a1.data_ptr(), B, ted), "add_embedding.linear_2", _V(emb.data_ptr(), B, ted),
-                   R=_V(emb.data_ptr(), B, ted))
-        semb = persist((B, ted), _lib.elem_dtype())
-        emit(lib.mi355x_sd_silu, (emb.data_ptr(), semb.data_ptr(), B * ted, 0, 0, stream), "misc")
+            linear(_V(a1.data_ptr(), B, ted), "add_embedding.linear_2", emb, R=emb)
+        semb = persist((B, ted_b), _lib.elem_dtype())
+        emit(lib.mi355x_sd_silu, (emb_t.data_ptr(), semb.data_ptr(), B * ted_b, 0, 0, stream), "misc")
         temb_all = persist((B, self._temb_total), torch.float32)
-        linear(_V(semb.data_ptr(), B, ted), "temb_all", _V(temb_all.data_ptr(), B, self._temb_total), flags=OUT_F32)
+        linear(_V(semb.data_ptr(), B, ted_b), "temb_all", _V(temb_all.data_ptr(), B, self._temb_total), flags=OUT_F32)
         # every block's cross-attention K/V projection of encoder_hidden_states in one GEMM (attention_processor.py:711-712)
         kv_all_t = persist((B * L, self._kv_total), _lib.elem_dtype())
         kv_all = _V(kv_all_t.data_ptr(), B * L, self._kv_total)
@@ -669,7 +734,7 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
         plan.graph = None
         plan.B, plan.H, plan.W, plan.L = B, H, Wd, L
         plan.scratch_bytes = sum(t.numel() * t.element_size() for t in keep)
-        plan.emb_tensors = dict(t0=t0, emb=emb, temb_all=temb_all)
+        plan.emb_tensors = dict(t0=t0, emb=emb_t, temb_all=temb_all)
         return plan
 
     # ------------------------------------------------------------------ execution
@@ -697,8 +762,18 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
 
     def stage_inputs(self, plan: _Plan, sample, timestep, encoder_hidden_states, added_cond_kwargs=None,
                      in_scale: Optional[float] = None, encoder_attention_mask=None,
-                     down_block_additional_residuals=None, mid_block_additional_residual=None) -> None:
+                     down_block_additional_residuals=None, mid_block_additional_residual=None, class_labels=None) -> None:
         cfg = self.cfg
+        if plan.class_in is not None:
+            if class_labels is None:
+                raise ValueError("class_labels should be provided when num_class_embeds > 0")
+            cl = class_labels if torch.is_tensor(class_labels) else torch.as_tensor(class_labels)
+            if plan.class_in.dim() == 1:   # embedding ids / timestep-like labels: one per batch row
+                cl = cl.reshape(-1)
+                cl = cl.expand(plan.B) if cl.numel() == 1 else cl
+            if tuple(cl.shape) != tuple(plan.class_in.shape):
+                raise ValueError(f"class_labels of shape {tuple(class_labels.shape)}, expected {tuple(plan.class_in.shape)}")
+            plan.class_in.copy_(cl.to(plan.class_in.dtype), non_blocking=True)
         if getattr(plan, "ctrl_down", None) is not None:
             if len(down_block_additional_residuals) != len(plan.ctrl_down):
                 raise ValueError(f"expected {len(plan.ctrl_down)} down_block_additional_residuals, got "
@@ -739,16 +814,16 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
                 attention_mask=None, cross_attention_kwargs=None, added_cond_kwargs=None,
                 down_block_additional_residuals=None, mid_block_additional_residual=None,
                 encoder_attention_mask=None, return_dict: bool = True):
-        for nm, v in (("class_labels", class_labels), ("timestep_cond", timestep_cond),
-                      ("attention_mask", attention_mask)):
+        for nm, v in (("timestep_cond", timestep_cond), ("attention_mask", attention_mask)):
             if v is not None:
                 raise NotImplementedError(f"UNet2DConditionModel(mi355x): `{nm}` is not implemented on this path")
+        # (class_labels without a class embedding are ignored, like unet_2d_condition.py:953)
         controlnet = down_block_additional_residuals is not None
         if controlnet != (mid_block_additional_residual is not None):
             raise NotImplementedError("ControlNet residuals need both `down_block_additional_residuals` and "
                                       "`mid_block_additional_residual` (the T2I-adapter form is not implemented)")
         ctrl = dict(down_block_additional_residuals=down_block_additional_residuals,
-                    mid_block_additional_residual=mid_block_additional_residual)
+                    mid_block_additional_residual=mid_block_additional_residual, class_labels=class_labels)
         if not self._emulated and (not sample.is_cuda or not encoder_hidden_states.is_cuda):
             raise _lib.MI355XError("inputs must be GPU tensors (no CPU fallback)")
         B, _, H, W = sample.shape

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import unet_ref as U
-from tests.configs import MINI_XL, SD15, SDXL, TINY
+from tests.configs import MINI_XL, SD15, SDXL, TINY, UNET_VARIANTS
 
 pytestmark = pytest.mark.gpu
 
@@ -18,8 +18,9 @@ def _rel(a, b):
 
 def _inputs(cfg, B, H, W, L=77, seed=0):
     g = torch.Generator().manual_seed(seed)
-    sample = torch.randn(B, 4, H, W, generator=g)
-    enc = torch.randn(B, L, cfg["cross_attention_dim"], generator=g)
+    sample = torch.randn(B, cfg.get("in_channels", 4), H, W, generator=g)
+    cross = cfg["cross_attention_dim"]
+    enc = torch.randn(B, L, cross[0] if isinstance(cross, (tuple, list)) else cross, generator=g)
     added = None
     if cfg.get("addition_embed_type") == "text_time":
         td = cfg["projection_class_embeddings_input_dim"] - 6 * cfg["addition_time_embed_dim"]
@@ -165,3 +166,35 @@ def test_denoise_loop_on_device_config1():
     rel = np.linalg.norm(out.cpu().numpy() - x) / np.linalg.norm(x)
     print(f"20-step DDIM CFG latents rel-L2 vs oracle loop: {rel:.3e}")
     assert rel < 5e-2, rel
+
+
+@pytest.mark.parametrize("name", ["inpaint-9ch", "sd2-layout", "head-dim-tuple", "sin-first-shifted"])
+def test_config_variants_on_device(name):
+    """configuration switches of the reference's model tests (tests/configs.py UNET_VARIANTS) through the HIP kernels"""
+    from paddlemix_amd.unet import UNet2DConditionModel
+    cfg = UNET_VARIANTS[name]
+    P = _bf16_params(cfg, "cpu")
+    sample, enc, _ = _inputs(cfg, 2, 16, 16, 7)
+    ref = U.unet_forward(P, cfg, sample, 333, enc)
+    out = UNet2DConditionModel(cfg, P)(_cuda(sample), 333, _cuda(enc), return_dict=False)[0]
+    assert _rel(out.cpu(), ref) < 2e-2, _rel(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("kind,concat", [("embedding", False), ("timestep", True), ("identity", True), ("simple_projection", False),
+                                         ("projection", True)])
+def test_class_embeddings_on_device(kind, concat):
+    """class_labels path (unet_2d_condition.py:953-975): gather / sinusoid / projection kernels + residual or
+    concatenating GEMM epilogues"""
+    from paddlemix_amd.unet import UNet2DConditionModel
+    from tests.test_host_logic import CLASS_CASES
+    extra, make = CLASS_CASES[kind]
+    cfg = dict(TINY, class_embeddings_concat=concat, **extra)
+    P = _bf16_params(cfg, "cpu")
+    sample, enc, _ = _inputs(cfg, 2, 16, 16, 7)
+    labels = make(torch.Generator().manual_seed(5), 2, cfg)
+    ref = U.unet_forward(P, cfg, sample, 333, enc, class_labels=labels)
+    model = UNet2DConditionModel(cfg, P)
+    out = model(_cuda(sample), 333, _cuda(enc), class_labels=labels.cuda(), return_dict=False)[0]
+    assert _rel(out.cpu(), ref) < 2e-2, _rel(out.cpu(), ref)
+    with pytest.raises(ValueError, match="class_labels should be provided"):
+        model(_cuda(sample), 333, _cuda(enc))

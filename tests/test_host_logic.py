@@ -64,6 +64,40 @@ def test_config_variants_match_oracle(name):
     assert out.shape == ref.shape and _rel(out, ref) < 2e-2, _rel(out, ref)
 
 
+CLASS_CASES = {
+    "embedding": (dict(num_class_embeds=10), lambda g, B, c: torch.randint(0, 10, (B,), generator=g)),
+    "timestep": (dict(class_embed_type="timestep"), lambda g, B, c: torch.rand(B, generator=g) * 900),
+    "identity": (dict(class_embed_type="identity"), lambda g, B, c: torch.randn(B, c["block_out_channels"][0] * 4, generator=g)),
+    "projection": (dict(class_embed_type="projection", projection_class_embeddings_input_dim=32),
+                   lambda g, B, c: torch.randn(B, 32, generator=g)),
+    "simple_projection": (dict(class_embed_type="simple_projection", projection_class_embeddings_input_dim=32),
+                          lambda g, B, c: torch.randn(B, 32, generator=g)),
+}
+
+
+@pytest.mark.parametrize("kind", sorted(CLASS_CASES))
+@pytest.mark.parametrize("concat", [False, True])
+def test_class_embeddings_match_oracle(kind, concat):
+    """class_labels / class_embed_type / num_class_embeds / class_embeddings_concat (unet_2d_condition.py:354-382, 953-975;
+    the reference's test_model_with_simple_projection / test_model_with_class_embeddings_concat)"""
+    extra, make = CLASS_CASES[kind]
+    cfg = dict(TINY, class_embeddings_concat=concat, **extra)
+    P = synth_unet_params(cfg, seed=3)
+    assert list(unet_param_shapes(cfg).items()) == list(U.unet_param_shapes(cfg).items())
+    Pb = {k: v.to(torch.bfloat16).float() if v.dim() > 1 else v for k, v in P.items()}
+    sample, enc, _ = _inputs(cfg, 2, 16, 16, 7)
+    labels = make(torch.Generator().manual_seed(5), 2, cfg)
+    ref = U.unet_forward(Pb, cfg, sample, 333, enc, class_labels=labels)
+    model = UNet2DConditionModel(cfg, P, _test_backend=Emulator())
+    out = model(sample, 333, enc, class_labels=labels, return_dict=False)[0]
+    assert _rel(out, ref) < 2e-2, _rel(out, ref)
+    # the class embedding matters (different labels -> different output), and is required
+    other = make(torch.Generator().manual_seed(6), 2, cfg)
+    assert not torch.equal(model(sample, 333, enc, class_labels=other).sample, out)
+    with pytest.raises(ValueError, match="class_labels should be provided"):
+        model(sample, 333, enc)
+
+
 def test_param_inventory_matches_oracle():
     for cfg in (TINY, MINI_XL, SD15, SDXL):
         a, b = unet_param_shapes(cfg), U.unet_param_shapes(cfg)
@@ -89,8 +123,10 @@ def test_errors_mirror_reference():
     bad["time_embedding.linear_1.weight"] = bad["time_embedding.linear_1.weight"].t()
     with pytest.raises(ValueError, match="Paddle layout"):
         UNet2DConditionModel(MINI_XL, bad, _test_backend=Emulator())
-    with pytest.raises(NotImplementedError):
-        UNet2DConditionModel(dict(MINI_XL, class_embed_type="timestep"), P, _test_backend=Emulator())
+    with pytest.raises(NotImplementedError):   # config fields outside the implemented path fail loudly at construction
+        UNet2DConditionModel(dict(MINI_XL, dual_cross_attention=True), P, _test_backend=Emulator())
+    with pytest.raises(ValueError, match="requires `projection_class_embeddings_input_dim`"):   # unet_2d_condition.py:363-366
+        UNet2DConditionModel(dict(TINY, class_embed_type="projection"), P, _test_backend=Emulator())
 
 
 def test_no_fallback_without_gpu():
