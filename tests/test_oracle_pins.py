@@ -148,3 +148,40 @@ def test_euler_full_loops():
     x = euler_full_loop(use_karras_sigmas=True)
     assert abs(np.abs(x).sum() - 124.52299499511719) < 1e-2
     assert abs(np.abs(x).mean() - 0.16213932633399963) < 1e-3
+
+
+# --- the same pins driven by the committed fixture (tests/golden/reference_known_answers.json, harvested from the reference's
+# --- test sources by scripts/make_golden.py with file:line provenance) ----------------------------------------------------
+def _golden():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_known_answers.json")) as f:
+        return json.load(f)
+
+
+def test_golden_fixture_sinusoid():
+    g = _golden()["sinusoid"]
+    t = torch.arange(128)
+    assert g["embedding_dim"] == 64 and len(g["cases"]) == 3
+    for case in g["cases"]:
+        e = U.get_timestep_embedding(t, 64, **case["kwargs"])
+        assert np.allclose(e[23:26, 47:50].flatten().numpy(), case["values"], atol=g["atol"]), case["line"]
+
+
+def test_golden_fixture_scheduler_loops():
+    g = _golden()
+    d, e = g["ddim"]["tests"], g["euler"]["tests"]
+    ddim_cases = {"test_full_loop_no_noise": {}, "test_full_loop_with_v_prediction": {"prediction_type": "v_prediction"},
+                  "test_full_loop_with_set_alpha_to_one": {"set_alpha_to_one": True, "beta_start": 0.01},
+                  "test_full_loop_with_no_set_alpha_to_one": {"set_alpha_to_one": False, "beta_start": 0.01}}
+    for name, kw in ddim_cases.items():
+        x = ddim_full_loop(**kw)
+        assert abs(np.abs(x).sum() - d[name]["sum"]["value"]) < d[name]["sum"]["tol"], name
+        assert abs(np.abs(x).mean() - d[name]["mean"]["value"]) < d[name]["mean"]["tol"], name
+    euler_cases = {"test_full_loop_no_noise": {}, "test_full_loop_with_v_prediction": {"prediction_type": "v_prediction"},
+                   "test_full_loop_device": {}, "test_full_loop_device_karras_sigmas": {"use_karras_sigmas": True}}
+    for name, kw in euler_cases.items():
+        x = euler_full_loop(**kw)
+        assert abs(np.abs(x).sum() - e[name]["sum"]["value"]) < e[name]["sum"]["tol"], name
+        assert abs(np.abs(x).mean() - e[name]["mean"]["value"]) < e[name]["mean"]["tol"], name
+    assert len(d) == 5 and len(e) == 5   # every full-loop known answer of the two scheduler test files is in the fixture
