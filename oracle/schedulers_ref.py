@@ -149,6 +149,12 @@ class EulerRef:
         s = self.sigmas[self.step_index]
         return (sample / ((s ** 2 + 1) ** 0.5)).astype(np.float32)
 
+    def add_noise(self, x, noise, timesteps):
+        """scheduling_euler_discrete.py:480-500: x + noise * sigma[index of each timestep]"""
+        idx = [int(np.nonzero(self.timesteps == np.float32(t))[0][0]) for t in np.atleast_1d(timesteps)]
+        sigma = self.sigmas[idx].reshape((-1,) + (1,) * (x.ndim - 1))
+        return (x + noise * sigma).astype(np.float32)
+
     def step(self, model_output, t, sample):
         if self.step_index is None:
             self._init_step_index(t)

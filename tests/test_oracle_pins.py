@@ -184,4 +184,15 @@ def test_golden_fixture_scheduler_loops():
         x = euler_full_loop(**kw)
         assert abs(np.abs(x).sum() - e[name]["sum"]["value"]) < e[name]["sum"]["tol"], name
         assert abs(np.abs(x).mean() - e[name]["mean"]["value"]) < e[name]["mean"]["tol"], name
+    # test_scheduler_euler.py:165-195: noise added at the 9th of 10 timesteps, two steps run
+    sch = S.EulerRef(**EULER_CFG)
+    sch.set_timesteps(10)
+    ts = sch.timesteps[8:]
+    x = sch.add_noise(dummy_sample_deter() * sch.init_noise_sigma, dummy_noise_deter(), ts[:1])
+    for t in ts:
+        x = sch.scale_model_input(x, t)   # (the reference loop re-assigns the scaled sample, :181)
+        x = sch.step(dummy_model(x, t), t, x)
+    w = e["test_full_loop_with_noise"]
+    # (|x| sums to 5.7e4 in fp32: 0.1 is 2 ulp-per-element accumulation noise; the reference's own message quotes 57062.9297)
+    assert abs(np.abs(x).sum() - w["sum"]["value"]) < 0.1 and abs(np.abs(x).mean() - w["mean"]["value"]) < w["mean"]["tol"]
     assert len(d) == 5 and len(e) == 5   # every full-loop known answer of the two scheduler test files is in the fixture
