@@ -253,6 +253,16 @@ class EulerDiscreteScheduler:
         self._step_index += 1
         return _out(prev, return_dict, pred_original_sample=x0)
 
+    def add_noise(self, original_samples, noise, timesteps):
+        """scheduling_euler_discrete.py:480-500: x + noise * sigma[index of each timestep in the current schedule]"""
+        ts = np.atleast_1d(np.asarray(timesteps.detach().cpu() if torch.is_tensor(timesteps) else timesteps, dtype=np.float32))
+        idx = [int(np.nonzero(self.timesteps == t)[0][0]) for t in ts]
+        sigma = torch.as_tensor(np.asarray(self.sigmas, dtype=np.float32)[idx]).to(original_samples.device,
+                                                                                  original_samples.dtype)
+        while sigma.dim() < original_samples.dim():
+            sigma = sigma.unsqueeze(-1)
+        return original_samples + noise * sigma
+
     def __len__(self):
         return self.config.num_train_timesteps
 

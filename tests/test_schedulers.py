@@ -64,6 +64,18 @@ def test_euler_golden():
         assert abs(x.abs().sum().item() - gs) < 1e-2 and abs(x.abs().mean().item() - gm) < 1e-3, kw
 
 
+def test_euler_with_noise_golden():
+    """ppdiffusers/tests/schedulers/test_scheduler_euler.py:165-195 (known answer in tests/golden/)"""
+    sch = EulerDiscreteScheduler(**EULER_CFG)
+    sch.set_timesteps(10)
+    ts = sch.timesteps[8:]
+    x = sch.add_noise(dummy_sample_deter() * sch.init_noise_sigma, dummy_noise_deter(), ts[:1])
+    for t in ts:
+        x = sch.scale_model_input(x, t)
+        x = sch.step(dummy_model(x, t), t, x, return_dict=False)[0]
+    assert abs(x.abs().sum().item() - 57062.9023) < 0.1 and abs(x.abs().mean().item() - 74.3007) < 1e-3
+
+
 def test_tables_match_oracle_and_linear_update():
     # SDXL bench schedule (tests/pipelines/stable_diffusion_xl/test_stable_diffusion_xl.py:84-90 parameters)
     kw = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", timestep_spacing="leading", steps_offset=1)
