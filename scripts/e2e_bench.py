@@ -4,7 +4,8 @@ denoising loop, VAE decode), 512x512, batch 1, 50 steps, after a warm-up call. R
 architectures (no checkpoints offline), synthetic token ids. ORIENTATION ONLY next to BASELINE.md section 1 (other
 hardware, other metric than bench.py's); never used as `vs_baseline`.
 
-  python scripts/e2e_bench.py [--model sd15|sdxl] [--calls 5] [--steps 50] [--side 512]
+  python scripts/e2e_bench.py [--model sd15|sdxl|sd3] [--calls 5] [--steps 50] [--side 512]
+(sd3: the reference quotes seconds per image, ppdiffusers/deploy/sd3/README.md:27-31: 1.2 s Paddle-Inference on A100-40G)
 """
 import argparse
 import json
@@ -25,13 +26,16 @@ from tests.configs import CLIP_BIGG, CLIP_L, SD15, SD_VAE, SDXL  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--model", default="sd15", choices=["sd15", "sdxl"])
+    ap.add_argument("--model", default="sd15", choices=["sd15", "sdxl", "sd3"])
+    ap.add_argument("--act-dtype", default="bf16", choices=["bf16", "fp8"], help="sd3 only: W8A8 block GEMMs")
     ap.add_argument("--calls", type=int, default=5)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--side", type=int, default=512)
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
+    if a.model == "sd3":
+        return sd3(a, dev)
     xl = a.model == "sdxl"
     ucfg = SDXL if xl else SD15
     unet = UNet2DConditionModel(ucfg, synth_unet_params(ucfg, seed=1, device=dev), device=dev)
@@ -73,6 +77,55 @@ def main():
                       "image_shape": list(img.shape), "finite": bool(torch.isfinite(img.float()).all()),
                       "orientation": "reference deploy README: SD15 47.22 / SDXL 31.98 it/s on A100-80G TensorRT fp16 "
                                      "(ppdiffusers/deploy/README.md:44,47); not the same hardware or weights"}))
+
+
+def sd3(a, dev):
+    """StableDiffusion3Pipeline.__call__ (pipeline_stable_diffusion_3.py:772-886): 2 x CLIP + T5-XXL, 28-or-N-step CFG loop on
+    the MMDiT, 16-channel VAE decode"""
+    from paddlemix_amd.pipeline import StableDiffusion3Denoiser
+    from paddlemix_amd.schedulers import FlowMatchEulerDiscreteScheduler
+    from paddlemix_amd.sd3 import SD3Transformer2DModel, synth_sd3_params
+    from paddlemix_amd.t5 import T5EncoderModel, synth_t5_params
+    from tests.configs import SD3_MEDIUM, T5_XXL
+    kw = dict(weight_dtype="fp8", act_dtype="fp8") if a.act_dtype == "fp8" else {}
+    tr = SD3Transformer2DModel(SD3_MEDIUM, synth_sd3_params(SD3_MEDIUM, seed=1, device=dev), device=dev, **kw)
+    vcfg = dict(SD_VAE, latent_channels=16, use_post_quant_conv=False, scaling_factor=1.5305, shift_factor=0.0609)
+    vae = AutoencoderKL(vcfg, synth_decoder_params(vcfg, seed=2, device=dev), device=dev)
+    c1, c2 = dict(CLIP_L, with_projection=True), dict(CLIP_BIGG, with_projection=True)
+    te = CLIPTextModelWithProjection(c1, synth_clip_params(c1, seed=3, device=dev), device=dev)
+    te2 = CLIPTextModelWithProjection(c2, synth_clip_params(c2, seed=4, device=dev), device=dev)
+    te3 = T5EncoderModel(T5_XXL, synth_t5_params(T5_XXL, seed=5, device=dev), device=dev)
+    pipe = StableDiffusion3Denoiser(tr, FlowMatchEulerDiscreteScheduler(shift=3.0), vae=vae, text_encoder=te,
+                                    text_encoder_2=te2, text_encoder_3=te3)
+    g = torch.Generator(device=dev).manual_seed(0)
+    ids = torch.randint(3, 40000, (1, 77), generator=g, device=dev)
+    ids[:, 0], ids[:, 20:] = 49406, 49407
+    neg = torch.full((1, 77), 49407, device=dev)
+    neg[:, 0] = 49406
+    t5_ids = torch.randint(2, 32000, (1, 256), generator=g, device=dev)
+    t5_neg = torch.zeros((1, 256), dtype=torch.long, device=dev)
+
+    def call():
+        pe, pp = pipe.encode_prompt(ids, ids, t5_ids)
+        ne, npool = pipe.encode_prompt(neg, neg, t5_neg)
+        return pipe(pe, pp, ne, npool, height=a.side, width=a.side, num_inference_steps=a.steps, guidance_scale=7.0,
+                    generator=g, output_type="pt")
+
+    img = call()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(a.calls):
+        t0 = time.perf_counter()
+        img = call()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    mean = sum(ts) / len(ts)
+    print(json.dumps({"what": f"sd3-medium text2img end to end, {a.side}x{a.side}, bs 1, {a.steps} steps, CFG, 2 CLIP + T5-XXL "
+                              f"(256 tokens) + MMDiT ({a.act_dtype} block GEMMs) + VAE decode, random-init weights",
+                      "s_per_image": mean, "it_per_s": a.steps / mean, "calls": a.calls, "image_shape": list(img.shape),
+                      "finite": bool(torch.isfinite(img.float()).all()),
+                      "orientation": "reference: 1.2 s (Paddle-Inference + Triton fused ops) / 1.78 s (PyTorch) on A100-SXM4-40GB, "
+                                     "fp16, 512x512, 50 steps (ppdiffusers/deploy/sd3/README.md:27-31); not the same hardware or weights"}))
 
 
 if __name__ == "__main__":
