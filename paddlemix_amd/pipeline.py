@@ -270,3 +270,58 @@ class StableDiffusion3Denoiser:
         z = latents / vc.scaling_factor + getattr(vc, "shift_factor", 0.0)
         image = (self.vae.decode(z, return_dict=False)[0] / 2 + 0.5).clamp(0, 1)
         return image if output_type == "pt" else image.cpu().permute(0, 2, 3, 1).float().numpy()
+
+
+class DiTDenoiser:
+    """The loop of ``DiTPipeline.__call__`` (pipelines/dit/pipeline_dit.py:158-246) with the MI355X DiT in the ``transformer``
+    slot: class-conditional classifier-free guidance with the null class (index ``num_embeds_ada_norm``) on the DUPLICATED
+    latent half (:182-184), guidance applied to the epsilon channels only (:209-216), the learned-sigma channels dropped
+    before ``scheduler.step`` (:219-225), then ``vae.decode(latents / scaling_factor)`` and the denormalise (:235-246)."""
+
+    def __init__(self, transformer, scheduler, vae=None):
+        self.transformer, self.scheduler, self.vae = transformer, scheduler, vae
+
+    @torch.no_grad()
+    def __call__(self, class_labels, guidance_scale: float = 4.0, num_inference_steps: int = 50, generator=None,
+                 latents: Optional[torch.Tensor] = None, output_type: str = "latent",
+                 callback_on_step_end: Optional[Callable] = None, device=None):
+        cfg = self.transformer.config
+        labels = torch.as_tensor(class_labels).reshape(-1)
+        device = device or (latents.device if latents is not None else labels.device)
+        labels = labels.to(device)
+        B, C, side = labels.numel(), cfg.in_channels, cfg.sample_size
+        if latents is None:
+            latents = torch.randn((B, C, side, side), generator=generator, dtype=torch.float32, device=device)
+        elif tuple(latents.shape[:2]) != (B, C):
+            raise ValueError(f"Unexpected latents shape, got {tuple(latents.shape)}, expected ({B}, {C}, h, w)")
+        do_cfg = guidance_scale > 1
+        x = torch.cat([latents] * 2) if do_cfg else latents
+        null = torch.full((B,), cfg.num_embeds_ada_norm, dtype=labels.dtype, device=device)
+        labels_in = torch.cat([labels, null]) if do_cfg else labels
+        self.scheduler.set_timesteps(num_inference_steps)
+        for i, t in enumerate(self.scheduler.timesteps):
+            if do_cfg:
+                half = x[: len(x) // 2]
+                x = torch.cat([half, half], dim=0)
+            x = self.scheduler.scale_model_input(x, t)
+            ts = torch.as_tensor(t, device=device).reshape(-1).expand(x.shape[0])
+            noise = self.transformer(x, timestep=ts, class_labels=labels_in, return_dict=False)[0]
+            if do_cfg:
+                eps, rest = noise[:, :C], noise[:, C:]
+                cond, uncond = eps.chunk(2, dim=0)
+                half_eps = uncond + guidance_scale * (cond - uncond)
+                noise = torch.cat([torch.cat([half_eps, half_eps], dim=0), rest], dim=1)
+            model_output = noise[:, :C] if cfg.out_channels // 2 == C else noise   # learned sigma is not used by the step
+            x = self.scheduler.step(model_output, t, x, return_dict=False)[0]
+            if callback_on_step_end is not None:
+                x = callback_on_step_end(self, i, t, {"latents": x}).pop("latents", x)
+        latents = x.chunk(2, dim=0)[0] if do_cfg else x
+        if output_type == "latent":
+            return latents
+        if self.vae is None:
+            raise ValueError("output_type != 'latent' needs a `vae`")
+        if output_type not in ("pt", "np"):
+            raise ValueError(f"output_type must be 'latent', 'pt' or 'np', got {output_type!r}")
+        image = self.vae.decode(latents, return_dict=False, in_scale=1.0 / self.vae.config.scaling_factor)[0]
+        image = (image / 2 + 0.5).clamp(0, 1)
+        return image if output_type == "pt" else image.cpu().permute(0, 2, 3, 1).float().numpy()

@@ -13,7 +13,8 @@ itself uses for inference (``SimplifiedSD3.forward``, models/simplified_sd3.py:4
     place, and the two output projections read their rows back out of the joint attention output (row remap in the
     loader);
   * GELU-tanh is the ff.net.0 GEMM epilogue.
-Weights are bf16 here; the fp8 (e4m3) weight path of BASELINE.json's config 5 is not built yet.
+Block matrices: bf16, weight-only fp8 (``weight_dtype="fp8"``, BASELINE.json config 5) or W8A8 on the fp8 matrix pipe
+(``act_dtype="fp8"``); see ``__init__``.
 """
 from __future__ import annotations
 

@@ -26,7 +26,7 @@ from tests.configs import CLIP_BIGG, CLIP_L, SD15, SD_VAE, SDXL  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--model", default="sd15", choices=["sd15", "sdxl", "sd3"])
+    ap.add_argument("--model", default="sd15", choices=["sd15", "sdxl", "sd3", "dit"])
     ap.add_argument("--act-dtype", default="bf16", choices=["bf16", "fp8"], help="sd3 only: W8A8 block GEMMs")
     ap.add_argument("--calls", type=int, default=5)
     ap.add_argument("--steps", type=int, default=50)
@@ -36,6 +36,8 @@ def main():
     torch.cuda.set_device(dev)
     if a.model == "sd3":
         return sd3(a, dev)
+    if a.model == "dit":
+        return dit(a, dev)
     xl = a.model == "sdxl"
     ucfg = SDXL if xl else SD15
     unet = UNet2DConditionModel(ucfg, synth_unet_params(ucfg, seed=1, device=dev), device=dev)
@@ -77,6 +79,38 @@ def main():
                       "image_shape": list(img.shape), "finite": bool(torch.isfinite(img.float()).all()),
                       "orientation": "reference deploy README: SD15 47.22 / SDXL 31.98 it/s on A100-80G TensorRT fp16 "
                                      "(ppdiffusers/deploy/README.md:44,47); not the same hardware or weights"}))
+
+
+def dit(a, dev):
+    """DiTPipeline.__call__ as the reference benchmarks it (examples/inference/class_conditional_image_generation-dit.py:82-103):
+    DiT-XL/2-256, one class label, 25 DDIM steps, guidance 4.0, VAE decode, wall time of the whole call"""
+    from paddlemix_amd.dit import DiTTransformer2DModel, synth_dit_params
+    from paddlemix_amd.pipeline import DiTDenoiser
+    from tests.configs import DIT_XL2
+    tr = DiTTransformer2DModel(DIT_XL2, synth_dit_params(DIT_XL2, seed=1, device=dev), device=dev)
+    vae = AutoencoderKL(SD_VAE, synth_decoder_params(SD_VAE, seed=2, device=dev), device=dev)
+    sched = DDIMScheduler(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear", clip_sample=False)
+    pipe = DiTDenoiser(tr, sched, vae=vae)
+    g = torch.Generator(device=dev).manual_seed(42)
+    labels = torch.tensor([207], device=dev)
+    steps = 25 if a.steps == 50 else a.steps
+    call = lambda: pipe(labels, guidance_scale=4.0, num_inference_steps=steps, generator=g, output_type="pt", device=dev)  # noqa: E731
+    for _ in range(3):
+        img = call()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(a.calls):
+        t0 = time.perf_counter()
+        img = call()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    mean = sum(ts) / len(ts)
+    print(json.dumps({"what": f"DiT-XL/2-256 class-conditional generation end to end, 1 label, {steps} DDIM steps, guidance 4.0, "
+                              "DiT + VAE decode, random-init weights", "ms_per_image": 1e3 * mean, "calls": a.calls,
+                      "image_shape": list(img.shape), "finite": bool(torch.isfinite(img.float()).all()),
+                      "orientation": "reference: 219 ms (Paddle-Inference) / 242 ms (TensorRT-LLM) / 1200 ms (Paddle dygraph) on "
+                                     "A100-SXM4-40GB fp16 (ppdiffusers/examples/class_conditional_image_generation/DiT/README.md:419-421); "
+                                     "not the same hardware or weights"}))
 
 
 def sd3(a, dev):

@@ -65,3 +65,10 @@ UNET_VARIANTS = {
     "center-input": dict(TINY, center_input_sample=True),
     "sin-first-shifted": dict(TINY, flip_sin_to_cos=False, freq_shift=1),
 }
+
+# class-conditional DiT in miniature (the reference's tiny test config, ppdiffusers/tests/pipelines/dit/test_dit.py:46-60,
+# widened to head_dim 32 / K % 8) and DiT-XL/2 (public config: 28 layers, 16 heads x 72, 1000 classes, learned sigma)
+MINI_DIT = dict(sample_size=16, num_layers=3, patch_size=2, attention_head_dim=32, num_attention_heads=4, in_channels=4,
+                out_channels=8, num_embeds_ada_norm=10)
+DIT_XL2 = dict(sample_size=32, num_layers=28, patch_size=2, attention_head_dim=72, num_attention_heads=16, in_channels=4,
+               out_channels=8, num_embeds_ada_norm=1000)
