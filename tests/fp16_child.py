@@ -68,6 +68,14 @@ def other_models(backend_kw, dev):
     ids = _ids(2, 16, MINI_CLIP["vocab_size"], MINI_CLIP["eos_token_id"])
     ref = clip_ref.clip_text_forward(h(P), MINI_CLIP, ids)["last_hidden_state"]
     out["clip"] = _rel(CLIPTextModel(MINI_CLIP, P, **backend_kw)(mv(ids)).last_hidden_state.float().cpu(), ref)
+    from oracle import dit_ref
+    from paddlemix_amd.dit import DiTTransformer2DModel, synth_dit_params
+    from tests.configs import MINI_DIT
+    P = synth_dit_params(MINI_DIT, seed=21)
+    xd = torch.randn(2, 4, 16, 16, generator=g)
+    lab, td = torch.tensor([3, 10]), torch.tensor([999.0, 20.0])
+    ref = dit_ref.dit_forward(h(P), MINI_DIT, xd, td, lab)
+    out["dit"] = _rel(DiTTransformer2DModel(MINI_DIT, P, **backend_kw)(mv(xd), timestep=mv(td), class_labels=mv(lab)).sample.float().cpu(), ref)
     P = synth_t5_params(MINI_T5, seed=11)
     ids = torch.randint(0, MINI_T5["vocab_size"], (2, 24), generator=g)
     ref = t5_ref.t5_encoder_forward(h(P, skip=("relative_attention_bias",)), MINI_T5, ids)

@@ -27,7 +27,7 @@ def test_fp16_build_loads_and_host_logic_parity():
         assert c["vs_oracle_same_weights"] < 3e-3, (name, c)
         assert c["vs_oracle_fp32_weights"] < 4e-3, (name, c)
     # the other model families on fp16 elements (bf16 bars: 1e-2 .. 2e-2)
-    assert r["models"]["sd3"] < 2e-3 and r["models"]["vae"] < 3e-3 and r["models"]["clip"] < 2e-3 and r["models"]["t5"] < 3e-3, r
+    assert r["models"]["sd3"] < 2e-3 and r["models"]["vae"] < 3e-3 and r["models"]["clip"] < 2e-3 and r["models"]["t5"] < 3e-3 and r["models"]["dit"] < 2e-3, r
 
 
 def test_one_element_type_per_process():
