@@ -205,3 +205,103 @@ class FlowMatchEulerRef:
         dt = self.sigmas[self.step_index + 1] - s
         self.step_index += 1
         return (sample + d * dt).astype(model_output.dtype)
+
+
+class PNDMRef:
+    """PNDMScheduler (the scheduler SD-1.x checkpoints ship with, ``skip_prk_steps=True``): ctor scheduling_pndm.py:117-176,
+    set_timesteps :178-235, step_prk :260-320, step_plms :322-395, _get_prev_sample :410-453. Pinned by the reference's full-loop
+    known answers (tests/schedulers/test_scheduler_pndm.py:224-256)."""
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear", skip_prk_steps=False,
+                 set_alpha_to_one=False, prediction_type="epsilon", timestep_spacing="leading", steps_offset=0):
+        self.T = num_train_timesteps
+        self.alphas_cumprod = np.cumprod((1.0 - _betas(num_train_timesteps, beta_start, beta_end, beta_schedule)).astype(np.float32),
+                                         dtype=np.float32)
+        self.final_alpha_cumprod = np.float32(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self.skip_prk, self.prediction_type = skip_prk_steps, prediction_type
+        self.spacing, self.steps_offset = timestep_spacing, steps_offset
+        self.init_noise_sigma, self.order = 1.0, 4
+        self.n = None
+
+    def set_timesteps(self, n):
+        self.n = n
+        if self.spacing == "linspace":
+            ts = np.linspace(0, self.T - 1, n).round().astype(np.int64)
+        elif self.spacing == "leading":
+            ts = (np.arange(0, n) * (self.T // n)).round().astype(np.int64) + self.steps_offset
+        elif self.spacing == "trailing":
+            ts = np.round(np.arange(self.T, 0, -self.T / n))[::-1].astype(np.int64) - 1
+        else:
+            raise ValueError(self.spacing)
+        if self.skip_prk:
+            self.prk_timesteps = np.array([], dtype=np.int64)
+            self.plms_timesteps = np.concatenate([ts[:-1], ts[-2:-1], ts[-1:]])[::-1].copy()
+        else:
+            prk = np.array(ts[-self.order:]).repeat(2) + np.tile(np.array([0, self.T // n // 2]), self.order)
+            self.prk_timesteps = (prk[:-1].repeat(2)[1:-1])[::-1].copy()
+            self.plms_timesteps = ts[:-3][::-1].copy()
+        self.timesteps = np.concatenate([self.prk_timesteps, self.plms_timesteps]).astype(np.int64)
+        self.ets, self.counter, self.cur_model_output, self.cur_sample = [], 0, 0, None
+
+    def scale_model_input(self, sample, t=None):
+        return sample
+
+    def step(self, model_output, t, sample):
+        if self.counter < len(self.prk_timesteps) and not self.skip_prk:
+            return self.step_prk(model_output, t, sample)
+        return self.step_plms(model_output, t, sample)
+
+    def step_prk(self, model_output, t, sample):
+        diff = 0 if self.counter % 2 else self.T // self.n // 2
+        prev_t = t - diff
+        t = self.prk_timesteps[self.counter // 4 * 4]
+        if self.counter % 4 == 0:
+            self.cur_model_output = self.cur_model_output + 1 / 6 * model_output
+            self.ets.append(model_output)
+            self.cur_sample = sample
+        elif (self.counter - 1) % 4 == 0 or (self.counter - 2) % 4 == 0:
+            self.cur_model_output = self.cur_model_output + 1 / 3 * model_output
+        else:
+            model_output = self.cur_model_output + 1 / 6 * model_output
+            self.cur_model_output = 0
+        cur = self.cur_sample if self.cur_sample is not None else sample
+        prev = self._get_prev_sample(cur, t, prev_t, model_output)
+        self.counter += 1
+        return prev
+
+    def step_plms(self, model_output, t, sample):
+        if not self.skip_prk and len(self.ets) < 3:
+            raise ValueError("PNDM can only be run AFTER scheduler has been run in 'prk' mode for at least 12 iterations")
+        prev_t = t - self.T // self.n
+        if self.counter != 1:
+            self.ets = self.ets[-3:]
+            self.ets.append(model_output)
+        else:
+            prev_t, t = t, t + self.T // self.n
+        e = self.ets
+        if len(e) == 1 and self.counter == 0:
+            self.cur_sample = sample
+        elif len(e) == 1 and self.counter == 1:
+            model_output = (model_output + e[-1]) / 2
+            sample, self.cur_sample = self.cur_sample, None
+        elif len(e) == 2:
+            model_output = (3 * e[-1] - e[-2]) / 2
+        elif len(e) == 3:
+            model_output = (23 * e[-1] - 16 * e[-2] + 5 * e[-3]) / 12
+        else:
+            model_output = (1 / 24) * (55 * e[-1] - 59 * e[-2] + 37 * e[-3] - 9 * e[-4])
+        prev = self._get_prev_sample(sample, t, prev_t, model_output)
+        self.counter += 1
+        return prev
+
+    def _get_prev_sample(self, sample, t, prev_t, model_output):
+        a_t = self.alphas_cumprod[t]
+        a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
+        b_t, b_prev = 1 - a_t, 1 - a_prev
+        if self.prediction_type == "v_prediction":
+            model_output = (a_t ** 0.5) * model_output + (b_t ** 0.5) * sample
+        elif self.prediction_type != "epsilon":
+            raise ValueError(self.prediction_type)
+        coeff = (a_prev / a_t) ** 0.5
+        denom = a_t * b_prev ** 0.5 + (a_t * b_t * a_prev) ** 0.5
+        return (coeff * sample - (a_prev - a_t) * model_output / denom).astype(np.float32)

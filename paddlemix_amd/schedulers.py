@@ -1,10 +1,11 @@
 """Scheduler API surface kept for the denoising loop (plumbing, not accelerated math).
 
 Mirrors the reference classes' public contract -- ``set_timesteps`` / ``scale_model_input`` / ``step`` /
-``init_noise_sigma`` / ``timesteps`` -- for the three schedulers BASELINE.json's configs use:
+``init_noise_sigma`` / ``timesteps`` -- for the schedulers BASELINE.json's configs use (PNDM is what the SD-1.x checkpoints ship with):
   DDIMScheduler                      ppdiffusers/ppdiffusers/schedulers/scheduling_ddim.py:131 (step :350-475)
   EulerDiscreteScheduler             scheduling_euler_discrete.py:94 (scale_model_input :216-238, step :375-478)
   FlowMatchEulerDiscreteScheduler    scheduling_flow_match_euler_discrete.py:44 (step :187-283)
+  PNDMScheduler                      scheduling_pndm.py:69 (set_timesteps :178-235, step_prk :260-320, step_plms :322-395)
 Schedule tables are float32 numpy like the reference's float32 tensors; ``step`` works on torch tensors of any device.
 
 For deterministic sampling every ``step`` is a linear map  prev = a*sample + b*model_output ; ``step_coefficients``
@@ -124,6 +125,133 @@ class DDIMScheduler:
                                              dtype=model_output.dtype)
             prev = prev + std * variance_noise
         return _out(prev, return_dict, pred_original_sample=x0)
+
+    def add_noise(self, original_samples, noise, timesteps):
+        a = torch.as_tensor(self.alphas_cumprod)[timesteps].to(original_samples.device)
+        while a.dim() < original_samples.dim():
+            a = a.unsqueeze(-1)
+        return a ** 0.5 * original_samples + (1 - a) ** 0.5 * noise
+
+    def __len__(self):
+        return self.config.num_train_timesteps
+
+
+class PNDMScheduler:
+    """Pseudo numerical methods for diffusion models: Runge-Kutta warm-up (``step_prk``) + linear multistep (``step_plms``);
+    Stable Diffusion uses ``skip_prk_steps=True`` (crowsonkb's PLMS, scheduling_pndm.py:216-223)."""
+    order = 1
+
+    def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.0001, beta_end: float = 0.02,
+                 beta_schedule: str = "linear", skip_prk_steps: bool = False, set_alpha_to_one: bool = False,
+                 prediction_type: str = "epsilon", timestep_spacing: str = "leading", steps_offset: int = 0):
+        self.config = SimpleNamespace(**{k: v for k, v in locals().items() if k != "self"})
+        betas = _make_betas(num_train_timesteps, beta_start, beta_end, beta_schedule)
+        self.alphas_cumprod = np.cumprod(1.0 - betas, dtype=np.float32)
+        self.final_alpha_cumprod = np.float32(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self.init_noise_sigma = 1.0
+        self.pndm_order = 4
+        self.cur_model_output, self.counter, self.cur_sample, self.ets = 0, 0, None, []
+        self.num_inference_steps = None
+        self._timesteps = np.arange(0, num_train_timesteps)[::-1].copy()
+        self.prk_timesteps = self.plms_timesteps = self.timesteps = None
+
+    def set_timesteps(self, num_inference_steps: int):
+        c = self.config
+        self.num_inference_steps = n = num_inference_steps
+        if c.timestep_spacing == "linspace":
+            ts = np.linspace(0, c.num_train_timesteps - 1, n).round().astype(np.int64)
+        elif c.timestep_spacing == "leading":
+            ts = (np.arange(0, n) * (c.num_train_timesteps // n)).round().astype(np.int64) + c.steps_offset
+        elif c.timestep_spacing == "trailing":
+            ts = np.round(np.arange(c.num_train_timesteps, 0, -c.num_train_timesteps / n))[::-1].astype(np.int64) - 1
+        else:
+            raise ValueError(f"{c.timestep_spacing} is not supported. Please make sure to choose one of 'linspace', "
+                             "'leading' or 'trailing'.")
+        self._timesteps = ts
+        if c.skip_prk_steps:
+            self.prk_timesteps = np.array([], dtype=np.int64)
+            self.plms_timesteps = np.concatenate([ts[:-1], ts[-2:-1], ts[-1:]])[::-1].copy()
+        else:
+            prk = np.array(ts[-self.pndm_order:]).repeat(2) + np.tile(np.array([0, c.num_train_timesteps // n // 2]),
+                                                                        self.pndm_order)
+            self.prk_timesteps = (prk[:-1].repeat(2)[1:-1])[::-1].copy()
+            self.plms_timesteps = ts[:-3][::-1].copy()
+        self.timesteps = np.concatenate([self.prk_timesteps, self.plms_timesteps]).astype(np.int64)
+        self.ets, self.counter, self.cur_model_output = [], 0, 0
+
+    def scale_model_input(self, sample, *args, **kwargs):
+        return sample
+
+    def step(self, model_output, timestep, sample, return_dict: bool = True):
+        if self.counter < len(self.prk_timesteps) and not self.config.skip_prk_steps:
+            return self.step_prk(model_output, timestep, sample, return_dict)
+        return self.step_plms(model_output, timestep, sample, return_dict)
+
+    def _require_steps(self):
+        if self.num_inference_steps is None:
+            raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
+
+    def step_prk(self, model_output, timestep, sample, return_dict: bool = True):
+        self._require_steps()
+        n, T = self.num_inference_steps, self.config.num_train_timesteps
+        timestep = int(timestep)
+        prev_timestep = timestep - (0 if self.counter % 2 else T // n // 2)
+        timestep = int(self.prk_timesteps[self.counter // 4 * 4])
+        if self.counter % 4 == 0:
+            self.cur_model_output = self.cur_model_output + 1 / 6 * model_output
+            self.ets.append(model_output)
+            self.cur_sample = sample
+        elif (self.counter - 1) % 4 == 0 or (self.counter - 2) % 4 == 0:
+            self.cur_model_output = self.cur_model_output + 1 / 3 * model_output
+        else:
+            model_output = self.cur_model_output + 1 / 6 * model_output
+            self.cur_model_output = 0
+        cur_sample = self.cur_sample if self.cur_sample is not None else sample
+        prev = self._get_prev_sample(cur_sample, timestep, prev_timestep, model_output)
+        self.counter += 1
+        return _out(prev, return_dict)
+
+    def step_plms(self, model_output, timestep, sample, return_dict: bool = True):
+        self._require_steps()
+        if not self.config.skip_prk_steps and len(self.ets) < 3:
+            raise ValueError(f"{self.__class__} can only be run AFTER scheduler has been run in 'prk' mode for at least 12 "
+                             "iterations")
+        step = self.config.num_train_timesteps // self.num_inference_steps
+        timestep = int(timestep)
+        prev_timestep = timestep - step
+        if self.counter != 1:
+            self.ets = self.ets[-3:]
+            self.ets.append(model_output)
+        else:
+            prev_timestep, timestep = timestep, timestep + step
+        e = self.ets
+        if len(e) == 1 and self.counter == 0:
+            self.cur_sample = sample
+        elif len(e) == 1 and self.counter == 1:
+            model_output = (model_output + e[-1]) / 2
+            sample, self.cur_sample = self.cur_sample, None
+        elif len(e) == 2:
+            model_output = (3 * e[-1] - e[-2]) / 2
+        elif len(e) == 3:
+            model_output = (23 * e[-1] - 16 * e[-2] + 5 * e[-3]) / 12
+        else:
+            model_output = (1 / 24) * (55 * e[-1] - 59 * e[-2] + 37 * e[-3] - 9 * e[-4])
+        prev = self._get_prev_sample(sample, timestep, prev_timestep, model_output)
+        self.counter += 1
+        return _out(prev, return_dict)
+
+    def _get_prev_sample(self, sample, timestep, prev_timestep, model_output):
+        """formula (9) of the PNDM paper (scheduling_pndm.py:410-453), coefficients in float32 like the reference's tables"""
+        a_t = self.alphas_cumprod[timestep]
+        a_prev = self.alphas_cumprod[prev_timestep] if prev_timestep >= 0 else self.final_alpha_cumprod
+        b_t, b_prev = 1 - a_t, 1 - a_prev
+        if self.config.prediction_type == "v_prediction":
+            model_output = float(a_t ** 0.5) * model_output + float(b_t ** 0.5) * sample
+        elif self.config.prediction_type != "epsilon":
+            raise ValueError(f"prediction_type given as {self.config.prediction_type} must be one of `epsilon` or `v_prediction`")
+        coeff = float((a_prev / a_t) ** 0.5)
+        denom = a_t * b_prev ** 0.5 + (a_t * b_t * a_prev) ** 0.5
+        return coeff * sample - float((a_prev - a_t) / denom) * model_output
 
     def add_noise(self, original_samples, noise, timesteps):
         a = torch.as_tensor(self.alphas_cumprod)[timesteps].to(original_samples.device)

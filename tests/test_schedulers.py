@@ -2,6 +2,7 @@
 (ppdiffusers/tests/schedulers/test_scheduler_ddim.py:68,121-190, test_scheduler_euler.py:84-163, fixtures
 test_schedulers.py:261-303) and against the numpy oracle; plus the linear-update form used by the HIP axpby path."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import schedulers_ref as S
@@ -120,3 +121,52 @@ def test_flow_match_matches_oracle():
     v = torch.full_like(x, 0.5)
     t = a.timesteps[0]
     assert torch.allclose(a.step(v, t, x).prev_sample, torch.from_numpy(b.step(v.numpy(), t, x.numpy())))
+
+
+def _pndm_full_loop(cls, step_fn, **kw):
+    """tests/schedulers/test_scheduler_pndm.py:107-125"""
+    sch = cls(**{**dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear"), **kw})
+    sch.set_timesteps(10)
+    x = dummy_sample_deter()
+    for t in sch.prk_timesteps:
+        x = step_fn(sch.step_prk, dummy_model(x, t), t, x)
+    for t in sch.plms_timesteps:
+        x = step_fn(sch.step_plms, dummy_model(x, t), t, x)
+    return sch, x
+
+
+def test_pndm_golden_and_oracle():
+    """PNDMScheduler against the reference's four full-loop known answers (tests/golden/, harvested from
+    test_scheduler_pndm.py:224-256) -- product class and oracle restatement"""
+    import json
+    import os
+    from paddlemix_amd.schedulers import PNDMScheduler
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_known_answers.json")) as f:
+        g = json.load(f)["pndm"]["tests"]
+    cases = {"test_full_loop_no_noise": {}, "test_full_loop_with_v_prediction": {"prediction_type": "v_prediction"},
+             "test_full_loop_with_set_alpha_to_one": {"set_alpha_to_one": True, "beta_start": 0.01},
+             "test_full_loop_with_no_set_alpha_to_one": {"set_alpha_to_one": False, "beta_start": 0.01}}
+    assert set(cases) == set(g)
+    for name, kw in cases.items():
+        _, x = _pndm_full_loop(PNDMScheduler, lambda f, mo, t, s: f(mo, t, s, return_dict=False)[0], **kw)
+        assert abs(x.abs().sum().item() - g[name]["sum"]["value"]) < g[name]["sum"]["tol"], name
+        assert abs(x.abs().mean().item() - g[name]["mean"]["value"]) < g[name]["mean"]["tol"], name
+        _, xo = _pndm_full_loop(S.PNDMRef, lambda f, mo, t, s: f(mo.numpy() if torch.is_tensor(mo) else mo, int(t),
+                                                               s.numpy() if torch.is_tensor(s) else s), **kw)
+        xo = torch.as_tensor(xo)
+        assert abs(xo.abs().sum().item() - g[name]["sum"]["value"]) < g[name]["sum"]["tol"], name
+    # Stable Diffusion's configuration: skip_prk_steps, scaled_linear betas, steps_offset 1 -> 51 PLMS calls for 50 steps,
+    # the second one re-visiting the first timestep (scheduling_pndm.py:216-223)
+    sd = PNDMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", skip_prk_steps=True, steps_offset=1)
+    sd.set_timesteps(50)
+    assert len(sd.timesteps) == 51 and sd.timesteps[0] == sd.timesteps[1] + 20 == 981 and sd.timesteps[-1] == 1
+    ref = S.PNDMRef(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", skip_prk_steps=True, steps_offset=1)
+    ref.set_timesteps(50)
+    x = dummy_sample_deter()
+    xr = x.numpy().copy()
+    for t in sd.timesteps:
+        x = sd.step(dummy_model(x, t), t, x).prev_sample
+        xr = ref.step(dummy_model(torch.as_tensor(xr), t).numpy(), int(t), xr)
+    assert torch.allclose(x, torch.as_tensor(xr), rtol=1e-5, atol=1e-6)
+    with pytest.raises(ValueError):
+        PNDMScheduler().step_plms(x, 1, x)
