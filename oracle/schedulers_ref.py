@@ -305,3 +305,93 @@ class PNDMRef:
         coeff = (a_prev / a_t) ** 0.5
         denom = a_t * b_prev ** 0.5 + (a_t * b_t * a_prev) ** 0.5
         return (coeff * sample - (a_prev - a_t) * model_output / denom).astype(np.float32)
+
+
+class DPMSolverMultistepRef:
+    """DPMSolverMultistepScheduler, deterministic variants (scheduling_dpmsolver_multistep.py: ctor :150-218, set_timesteps
+    :226-299, convert_model_output :407-506, first / second order updates :508-698, step :802-878). Orders 1-2,
+    algorithm_type dpmsolver++ / dpmsolver, midpoint / heun, Karras sigmas. Pinned by the reference's full-loop means
+    (tests/schedulers/test_scheduler_dpm_multi.py:229-303)."""
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear", solver_order=2,
+                 prediction_type="epsilon", algorithm_type="dpmsolver++", solver_type="midpoint", lower_order_final=True,
+                 euler_at_final=False, use_karras_sigmas=False, timestep_spacing="linspace", steps_offset=0):
+        self.T = num_train_timesteps
+        self.alphas_cumprod = np.cumprod((1.0 - _betas(num_train_timesteps, beta_start, beta_end, beta_schedule)).astype(np.float32),
+                                         dtype=np.float32)
+        self.order, self.prediction_type, self.algorithm, self.solver = solver_order, prediction_type, algorithm_type, solver_type
+        self.lower_order_final, self.euler_at_final, self.karras = lower_order_final, euler_at_final, use_karras_sigmas
+        self.spacing, self.steps_offset = timestep_spacing, steps_offset
+        self.init_noise_sigma = 1.0
+
+    def set_timesteps(self, n):
+        last = self.T   # lambda_min_clipped = -inf
+        if self.spacing == "linspace":
+            ts = np.linspace(0, last - 1, n + 1).round()[::-1][:-1].copy().astype(np.int64)
+        elif self.spacing == "leading":
+            ts = (np.arange(0, n + 1) * (last // (n + 1))).round()[::-1][:-1].copy().astype(np.int64) + self.steps_offset
+        elif self.spacing == "trailing":
+            ts = np.arange(last, 0, -self.T / n).round().copy().astype(np.int64) - 1
+        else:
+            raise ValueError(self.spacing)
+        sig = np.array(((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5)
+        log_sig = np.log(sig)
+        if self.karras:
+            s = np.flip(sig).copy()
+            rho, ramp = 7.0, np.linspace(0, 1, n)
+            s = (s[0] ** (1 / rho) + ramp * (s[-1] ** (1 / rho) - s[0] ** (1 / rho))) ** rho
+            ts = np.array([EulerRef._sigma_to_t(x, log_sig) for x in s]).round()
+            sig = np.concatenate([s, s[-1:]]).astype(np.float32)
+        else:
+            sig = np.interp(ts, np.arange(0, len(sig)), sig)
+            sig = np.concatenate([sig, [((1 - self.alphas_cumprod[0]) / self.alphas_cumprod[0]) ** 0.5]]).astype(np.float32)
+        self.sigmas, self.timesteps = sig, ts.astype(np.int64)
+        self.outs, self.lower, self.idx = [None] * self.order, 0, None
+
+    def scale_model_input(self, sample, t=None):
+        return sample
+
+    @staticmethod
+    def _as(sigma):
+        a = 1 / ((sigma ** 2 + 1) ** 0.5)
+        return a, sigma * a
+
+    def _convert(self, m, x):
+        a, s = self._as(self.sigmas[self.idx])
+        if self.algorithm == "dpmsolver++":   # data prediction
+            return {"epsilon": (x - s * m) / a, "sample": m, "v_prediction": a * x - s * m}[self.prediction_type]
+        return {"epsilon": m, "sample": (x - a * m) / s, "v_prediction": a * m + s * x}[self.prediction_type]   # noise prediction
+
+    def step(self, model_output, t, sample):
+        if self.idx is None:
+            c = np.nonzero(self.timesteps == t)[0]
+            self.idx = len(self.timesteps) - 1 if len(c) == 0 else int(c[1] if len(c) > 1 else c[0])
+        n = len(self.timesteps)
+        final1 = self.idx == n - 1 and (self.euler_at_final or (self.lower_order_final and n < 15))
+        final2 = self.idx == n - 2 and self.lower_order_final and n < 15
+        m = self._convert(model_output, sample)
+        self.outs = self.outs[1:] + [m]
+        at, st = self._as(self.sigmas[self.idx + 1])
+        a0, s0 = self._as(self.sigmas[self.idx])
+        lt, l0 = np.log(at) - np.log(st), np.log(a0) - np.log(s0)
+        h = lt - l0
+        pp = self.algorithm == "dpmsolver++"
+        if self.order == 1 or self.lower < 1 or final1:
+            x = (st / s0) * sample - (at * (np.exp(-h) - 1.0)) * m if pp else (at / a0) * sample - (st * (np.exp(h) - 1.0)) * m
+        elif self.order == 2 or self.lower < 2 or final2:
+            a1, s1 = self._as(self.sigmas[self.idx - 1])
+            h0 = l0 - (np.log(a1) - np.log(s1))
+            with np.errstate(divide="ignore"):   # Karras schedules repeat the last sigma: h = 0 -> 1 / r0 = 0, like the reference
+                d0, d1 = self.outs[-1], (1.0 / (h0 / h)) * (self.outs[-1] - self.outs[-2])
+            if pp:
+                x = (st / s0) * sample - (at * (np.exp(-h) - 1.0)) * d0
+                x = x - 0.5 * (at * (np.exp(-h) - 1.0)) * d1 if self.solver == "midpoint" else x + (at * ((np.exp(-h) - 1.0) / h + 1.0)) * d1
+            else:
+                x = (at / a0) * sample - (st * (np.exp(h) - 1.0)) * d0
+                x = x - 0.5 * (st * (np.exp(h) - 1.0)) * d1 if self.solver == "midpoint" else x - (st * ((np.exp(h) - 1.0) / h - 1.0)) * d1
+        else:
+            raise NotImplementedError("third-order update not restated")
+        if self.lower < self.order:
+            self.lower += 1
+        self.idx += 1
+        return x.astype(np.float32)

@@ -6,6 +6,7 @@ Mirrors the reference classes' public contract -- ``set_timesteps`` / ``scale_mo
   EulerDiscreteScheduler             scheduling_euler_discrete.py:94 (scale_model_input :216-238, step :375-478)
   FlowMatchEulerDiscreteScheduler    scheduling_flow_match_euler_discrete.py:44 (step :187-283)
   PNDMScheduler                      scheduling_pndm.py:69 (set_timesteps :178-235, step_prk :260-320, step_plms :322-395)
+  DPMSolverMultistepScheduler        scheduling_dpmsolver_multistep.py:66 (deterministic variants, orders 1-2; step :802-878)
 Schedule tables are float32 numpy like the reference's float32 tensors; ``step`` works on torch tensors of any device.
 
 For deterministic sampling every ``step`` is a linear map  prev = a*sample + b*model_output ; ``step_coefficients``
@@ -390,6 +391,142 @@ class EulerDiscreteScheduler:
         while sigma.dim() < original_samples.dim():
             sigma = sigma.unsqueeze(-1)
         return original_samples + noise * sigma
+
+    def __len__(self):
+        return self.config.num_train_timesteps
+
+
+class DPMSolverMultistepScheduler:
+    """The fast multistep solver most SD pipelines switch to (20-25 steps; the reference's DiT example uses it). Implemented:
+    ``algorithm_type`` "dpmsolver++" / "dpmsolver", ``solver_order`` 1-2, "midpoint" / "heun", epsilon / v_prediction / sample,
+    ``lower_order_final``, ``euler_at_final``, Karras sigmas. Not implemented (NotImplementedError): the SDE variants,
+    third order, thresholding, ``use_lu_lambdas``, a finite ``lambda_min_clipped``."""
+    order = 1
+
+    def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.0001, beta_end: float = 0.02,
+                 beta_schedule: str = "linear", solver_order: int = 2, prediction_type: str = "epsilon",
+                 thresholding: bool = False, dynamic_thresholding_ratio: float = 0.995, sample_max_value: float = 1.0,
+                 algorithm_type: str = "dpmsolver++", solver_type: str = "midpoint", lower_order_final: bool = True,
+                 euler_at_final: bool = False, use_karras_sigmas: bool = False, use_lu_lambdas: bool = False,
+                 lambda_min_clipped: float = -float("inf"), variance_type: Optional[str] = None,
+                 timestep_spacing: str = "linspace", steps_offset: int = 0):
+        self.config = SimpleNamespace(**{k: v for k, v in locals().items() if k != "self"})
+        if algorithm_type not in ("dpmsolver", "dpmsolver++"):
+            raise NotImplementedError(f"{algorithm_type} is not implemented for {self.__class__}")
+        if solver_type not in ("midpoint", "heun"):
+            raise NotImplementedError(f"{solver_type} is not implemented for {self.__class__}")
+        if solver_order not in (1, 2) or thresholding or use_lu_lambdas or lambda_min_clipped != -float("inf") or variance_type:
+            raise NotImplementedError("DPMSolverMultistepScheduler(mi355x): solver_order 3, thresholding, use_lu_lambdas, "
+                                      "lambda_min_clipped and learned variance are not implemented")
+        betas = _make_betas(num_train_timesteps, beta_start, beta_end, beta_schedule)
+        self.alphas_cumprod = np.cumprod(1.0 - betas, dtype=np.float32)
+        self.init_noise_sigma = 1.0
+        self.num_inference_steps = None
+        self.timesteps = np.linspace(0, num_train_timesteps - 1, num_train_timesteps, dtype=np.float32)[::-1].copy().astype(np.int64)
+        self.model_outputs = [None] * solver_order
+        self.lower_order_nums = 0
+        self._step_index = None
+
+    @property
+    def step_index(self):
+        return self._step_index
+
+    def set_timesteps(self, num_inference_steps: int):
+        c, n = self.config, num_inference_steps
+        last = c.num_train_timesteps
+        if c.timestep_spacing == "linspace":
+            ts = np.linspace(0, last - 1, n + 1).round()[::-1][:-1].copy().astype(np.int64)
+        elif c.timestep_spacing == "leading":
+            ts = (np.arange(0, n + 1) * (last // (n + 1))).round()[::-1][:-1].copy().astype(np.int64) + c.steps_offset
+        elif c.timestep_spacing == "trailing":
+            ts = np.arange(last, 0, -c.num_train_timesteps / n).round().copy().astype(np.int64) - 1
+        else:
+            raise ValueError(f"{c.timestep_spacing} is not supported. Please make sure to choose one of 'linspace', "
+                             "'leading' or 'trailing'.")
+        sigmas = np.array(((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5)
+        log_sigmas = np.log(sigmas)
+        if c.use_karras_sigmas:
+            s = np.flip(sigmas).copy()
+            rho, ramp = 7.0, np.linspace(0, 1, n)
+            s = (s[0] ** (1 / rho) + ramp * (s[-1] ** (1 / rho) - s[0] ** (1 / rho))) ** rho
+            ts = np.array([EulerDiscreteScheduler._sigma_to_t(x, log_sigmas) for x in s]).round()
+            sigmas = np.concatenate([s, s[-1:]]).astype(np.float32)
+        else:
+            sigmas = np.interp(ts, np.arange(0, len(sigmas)), sigmas)
+            sigma_last = ((1 - self.alphas_cumprod[0]) / self.alphas_cumprod[0]) ** 0.5
+            sigmas = np.concatenate([sigmas, [sigma_last]]).astype(np.float32)
+        self.sigmas, self.timesteps = sigmas, ts.astype(np.int64)
+        self.num_inference_steps = len(ts)
+        self.model_outputs = [None] * c.solver_order
+        self.lower_order_nums = 0
+        self._step_index = None
+
+    def scale_model_input(self, sample, *args, **kwargs):
+        return sample
+
+    @staticmethod
+    def _sigma_to_alpha_sigma_t(sigma):
+        alpha_t = 1 / ((sigma ** 2 + 1) ** 0.5)
+        return alpha_t, sigma * alpha_t
+
+    def convert_model_output(self, model_output, sample):
+        """model output -> x0 prediction (dpmsolver++) or epsilon prediction (dpmsolver), :407-506"""
+        a, s = (float(v) for v in self._sigma_to_alpha_sigma_t(self.sigmas[self._step_index]))
+        pt = self.config.prediction_type
+        if pt not in ("epsilon", "sample", "v_prediction"):
+            raise ValueError(f"prediction_type given as {pt} must be one of `epsilon`, `sample`, or `v_prediction` for the "
+                             "DPMSolverMultistepScheduler.")
+        if self.config.algorithm_type == "dpmsolver++":
+            return (sample - s * model_output) / a if pt == "epsilon" else model_output if pt == "sample" else a * sample - s * model_output
+        return model_output if pt == "epsilon" else (sample - a * model_output) / s if pt == "sample" else a * model_output + s * sample
+
+    def _init_step_index(self, timestep):
+        c = np.nonzero(self.timesteps == int(timestep))[0]
+        self._step_index = len(self.timesteps) - 1 if len(c) == 0 else int(c[1] if len(c) > 1 else c[0])
+
+    def step(self, model_output, timestep, sample, generator=None, return_dict: bool = True):
+        if self.num_inference_steps is None:
+            raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
+        if self._step_index is None:
+            self._init_step_index(timestep)
+        c, n, i = self.config, len(self.timesteps), self._step_index
+        lower_order_final = i == n - 1 and (c.euler_at_final or (c.lower_order_final and n < 15))
+        lower_order_second = i == n - 2 and c.lower_order_final and n < 15
+        m = self.convert_model_output(model_output, sample)
+        self.model_outputs = self.model_outputs[1:] + [m]
+        at, st = self._sigma_to_alpha_sigma_t(self.sigmas[i + 1])
+        a0, s0 = self._sigma_to_alpha_sigma_t(self.sigmas[i])
+        lt, l0 = np.log(at) - np.log(st), np.log(a0) - np.log(s0)
+        h = lt - l0
+        pp = c.algorithm_type == "dpmsolver++"
+        f = float
+        if c.solver_order == 1 or self.lower_order_nums < 1 or lower_order_final:    # first-order update (:508-575)
+            prev = (f(st / s0) * sample - f(at * (np.exp(-h) - 1.0)) * m) if pp else (f(at / a0) * sample - f(st * (np.exp(h) - 1.0)) * m)
+        else:                                                                          # second-order multistep (:577-698)
+            a1, s1 = self._sigma_to_alpha_sigma_t(self.sigmas[i - 1])
+            h_0 = l0 - (np.log(a1) - np.log(s1))
+            with np.errstate(divide="ignore"):   # Karras schedules repeat the last sigma: h = 0 -> 1 / r0 = 0, like the reference
+                r_inv = f(1.0 / (h_0 / h))
+            d0, d1 = self.model_outputs[-1], r_inv * (self.model_outputs[-1] - self.model_outputs[-2])
+            if pp:
+                prev = f(st / s0) * sample - f(at * (np.exp(-h) - 1.0)) * d0
+                prev = prev - f(0.5 * at * (np.exp(-h) - 1.0)) * d1 if c.solver_type == "midpoint" else \
+                    prev + f(at * ((np.exp(-h) - 1.0) / h + 1.0)) * d1
+            else:
+                prev = f(at / a0) * sample - f(st * (np.exp(h) - 1.0)) * d0
+                prev = prev - f(0.5 * st * (np.exp(h) - 1.0)) * d1 if c.solver_type == "midpoint" else \
+                    prev - f(st * ((np.exp(h) - 1.0) / h - 1.0)) * d1
+        _ = lower_order_second   # (with solver_order <= 2 the second-order branch is taken whenever history exists)
+        if self.lower_order_nums < c.solver_order:
+            self.lower_order_nums += 1
+        self._step_index += 1
+        return _out(prev, return_dict)
+
+    def add_noise(self, original_samples, noise, timesteps):
+        a = torch.as_tensor(self.alphas_cumprod)[timesteps].to(original_samples.device)
+        while a.dim() < original_samples.dim():
+            a = a.unsqueeze(-1)
+        return a ** 0.5 * original_samples + (1 - a) ** 0.5 * noise
 
     def __len__(self):
         return self.config.num_train_timesteps
