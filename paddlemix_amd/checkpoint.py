@@ -151,6 +151,58 @@ def load_pretrained(model_dir: str, shapes_fn: Callable[[Mapping], Mapping[str, 
     return config, to_paddle_layout(state, shapes_fn(config), "pd" if fmt == "np" else fmt)
 
 
+def fuse_lora(params: Mapping[str, Tensor], lora: Mapping[str, Tensor], lora_scale: float = 1.0,
+              network_alphas: Optional[Mapping[str, float]] = None, prefix: str = "unet.", safe_fusing: bool = False
+              ) -> Dict[str, Tensor]:
+    """The LoRA branch of LoRACompatibleLinear / LoRACompatibleConv (PPD/models/lora.py:364-377, 453-459), taken the way the
+    reference takes it for inference: merged into the weights (``_fuse_lora``, lora.py:312-344 conv, :404-425 linear) --
+    ``W + lora_scale * (down @ up) * network_alpha / rank`` -- so the kernels never see a second GEMM.
+
+    ``params``: the model's state dict in Paddle layouts (Linear ``[in, out]``, conv OIHW). ``lora``: LoRA tensors named
+    ``[prefix]<layer>.lora.down.weight`` / ``.lora.up.weight`` in Paddle layouts (Linear down ``[in, rank]``, up ``[rank, out]``;
+    conv down ``[rank, in, kh, kw]``, up ``[out, rank, 1, 1]``), optional ``<layer>.alpha`` scalars (kohya ``network_alpha``) or a
+    ``network_alphas`` mapping. Returns a new dict; raises on LoRA entries that match no layer."""
+    out = dict(params)
+    layers = {}
+    for k in lora:
+        name = k[len(prefix):] if prefix and k.startswith(prefix) else k
+        for tail in (".lora.down.weight", ".lora.up.weight", ".alpha"):
+            if name.endswith(tail):
+                layers.setdefault(name[: -len(tail)], {})[tail] = lora[k]
+                break
+        else:
+            raise KeyError(f"{k}: not a LoRA tensor name (<layer>.lora.down.weight / .lora.up.weight / .alpha)")
+    for layer, t in layers.items():
+        wkey = layer + ".weight"
+        if wkey not in params:
+            raise KeyError(f"LoRA layer {layer!r} has no counterpart {wkey!r} in the model")
+        if ".lora.down.weight" not in t or ".lora.up.weight" not in t:
+            raise KeyError(f"LoRA layer {layer!r} needs both .lora.down.weight and .lora.up.weight")
+        w = params[wkey].to(torch.float32)
+        down, up = t[".lora.down.weight"].to(torch.float32).to(w.device), t[".lora.up.weight"].to(torch.float32).to(w.device)
+        alpha = t.get(".alpha")
+        if alpha is None and network_alphas is not None:
+            alpha = network_alphas.get(layer, network_alphas.get(prefix + layer if prefix else layer))
+        if w.dim() == 2:     # Linear [in, out]: down [in, rank], up [rank, out]
+            rank = down.shape[1]
+            if alpha is not None:
+                up = up * (float(alpha) / rank)
+            delta = down @ up
+        else:                # conv OIHW: up [O, rank, 1, 1] x down [rank, I, kh, kw]
+            rank = down.shape[0]
+            if alpha is not None:
+                up = up * (float(alpha) / rank)
+            delta = (up.flatten(1) @ down.flatten(1)).reshape(w.shape)
+        if tuple(delta.shape) != tuple(w.shape):
+            raise ValueError(f"{layer}: LoRA delta of shape {tuple(delta.shape)} does not fit weight {tuple(w.shape)}")
+        fused = w + lora_scale * delta
+        if safe_fusing and torch.isnan(fused).any():
+            raise ValueError(f"This LoRA weight seems to be broken. Encountered NaN values when trying to fuse LoRA weights "
+                             f"for {layer}. LoRA weights will not be fused.")
+        out[wkey] = fused.to(params[wkey].dtype)
+    return out
+
+
 class PretrainedMixin:
     """``Model.from_pretrained(dir, subfolder=..., **ctor_kwargs)`` for the MI355X model classes; the class names its
     parameter table in ``_param_shapes``."""

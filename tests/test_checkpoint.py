@@ -103,3 +103,47 @@ def test_sdxl_style_config_roundtrip(tmp_path):
     config, params = C.load_pretrained(str(tmp_path), unet_param_shapes)
     assert set(params) == set(P) and all(torch.equal(params[k], P[k]) for k in P)
     assert isinstance(np.asarray(config["block_out_channels"]), np.ndarray)
+
+
+def test_fuse_lora_matches_the_unfused_branch():
+    """LoRACompatibleLinear / LoRACompatibleConv with a LoRA layer compute W x + scale * up(down(x)) * alpha / rank
+    (PPD/models/lora.py:364-377, 453-459, 215-240); fuse_lora folds that branch into the weights (the reference's own
+    _fuse_lora, :312-344 / :404-425). Check the algebra on random layers and the key handling on a UNet state dict."""
+    import torch.nn.functional as F
+    from paddlemix_amd.checkpoint import fuse_lora
+    from paddlemix_amd.unet import UNet2DConditionModel, synth_unet_params
+    from oracle import unet_ref as U
+    from tests.abi_emulator import Emulator
+    from tests.configs import TINY
+    g = torch.Generator().manual_seed(0)
+    P = synth_unet_params(TINY, seed=2)
+    lin = "down_blocks.1.attentions.0.transformer_blocks.0.attn1.to_q"
+    conv = "down_blocks.0.resnets.0.conv1"
+    cin, cout = P[lin + ".weight"].shape
+    O, I, kh, kw = P[conv + ".weight"].shape
+    r = 4
+    lora = {"unet." + lin + ".lora.down.weight": torch.randn(cin, r, generator=g) / r,
+            "unet." + lin + ".lora.up.weight": torch.randn(r, cout, generator=g) * 0.1,
+            "unet." + lin + ".alpha": torch.tensor(8.0),
+            conv + ".lora.down.weight": torch.randn(r, I, kh, kw, generator=g) * 0.05,
+            conv + ".lora.up.weight": torch.randn(O, r, 1, 1, generator=g) * 0.1}
+    fused = fuse_lora(P, lora, lora_scale=0.7)
+    x = torch.randn(5, cin, generator=g)
+    want = x @ P[lin + ".weight"] + 0.7 * ((x @ lora["unet." + lin + ".lora.down.weight"]) @ lora["unet." + lin + ".lora.up.weight"]) * (8.0 / r)
+    assert torch.allclose(x @ fused[lin + ".weight"], want, atol=1e-5)
+    xc = torch.randn(2, I, 8, 8, generator=g)
+    wantc = F.conv2d(xc, P[conv + ".weight"], padding=1) + 0.7 * F.conv2d(F.conv2d(xc, lora[conv + ".lora.down.weight"], padding=1),
+                                                                          lora[conv + ".lora.up.weight"])
+    assert torch.allclose(F.conv2d(xc, fused[conv + ".weight"], padding=1), wantc, atol=1e-4)
+    assert sum(not torch.equal(fused[k], P[k]) for k in P) == 2 and fused[lin + ".weight"].dtype == P[lin + ".weight"].dtype
+    # the fused state dict drives the device program like any other (and moves the output)
+    s, e = torch.randn(1, 4, 16, 16, generator=g), torch.randn(1, 7, 64, generator=g)
+    Pb = {k: v.to(torch.bfloat16).float() if v.dim() > 1 else v for k, v in fused.items()}
+    out = UNet2DConditionModel(TINY, fused, _test_backend=Emulator())(s, 10, e).sample
+    ref = U.unet_forward(Pb, TINY, s, 10, e)
+    assert ((out - ref).norm() / ref.norm()).item() < 2e-2
+    assert not torch.allclose(ref, U.unet_forward({k: v.to(torch.bfloat16).float() if v.dim() > 1 else v for k, v in P.items()}, TINY, s, 10, e))
+    with pytest.raises(KeyError):
+        fuse_lora(P, {"unet.nope.lora.down.weight": torch.zeros(4, 4), "unet.nope.lora.up.weight": torch.zeros(4, 4)})
+    with pytest.raises(KeyError):
+        fuse_lora(P, {"unet." + lin + ".lora.down.weight": lora["unet." + lin + ".lora.down.weight"]})
