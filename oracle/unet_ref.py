@@ -59,13 +59,14 @@ UNET_DEFAULTS = dict(
     time_embedding_type="positional",
     projection_class_embeddings_input_dim=None,
     class_embed_type=None,
+    time_cond_proj_dim=None,
     num_class_embeds=None,
     class_embeddings_concat=False,
 )
 
 _UNSUPPORTED_IF_SET = (
     "encoder_hid_dim", "encoder_hid_dim_type",
-    "time_embedding_dim", "time_embedding_act_fn", "timestep_post_act", "time_cond_proj_dim",
+    "time_embedding_dim", "time_embedding_act_fn", "timestep_post_act",
     "cross_attention_norm", "dual_cross_attention", "resnet_skip_time_act",
 )
 
@@ -347,7 +348,8 @@ def unet_forward(P: Params, config: dict, sample: Tensor, timestep, encoder_hidd
                  added_cond_kwargs: Optional[dict] = None, attention_mask: Optional[Tensor] = None,
                  encoder_attention_mask: Optional[Tensor] = None, processor: str = "math",
                  taps: Optional[dict] = None, down_block_additional_residuals=None,
-                 mid_block_additional_residual: Optional[Tensor] = None, class_labels=None) -> Tensor:
+                 mid_block_additional_residual: Optional[Tensor] = None, class_labels=None,
+                 timestep_cond: Optional[Tensor] = None) -> Tensor:
     """Returns the noise prediction [B, out_channels, H, W] (the ``(sample,)`` tuple's first element).
 
     ``taps``: optional dict that receives named intermediate activations (for layer-wise parity tests).
@@ -374,6 +376,8 @@ def unet_forward(P: Params, config: dict, sample: Tensor, timestep, encoder_hidd
         timesteps = timestep.reshape(-1) if timestep.ndim == 0 else timestep
     timesteps = timesteps.expand(B)
     t_emb = get_timestep_embedding(timesteps, boc[0], cfg["flip_sin_to_cos"], cfg["freq_shift"]).to(dtype)
+    if cfg["time_cond_proj_dim"] is not None and timestep_cond is not None:   # embeddings.py:284-285 (LCM guidance embedding)
+        t_emb = t_emb + linear(P, "time_embedding.cond_proj", timestep_cond.to(dtype))
     emb = timestep_embedding_mlp(P, "time_embedding", t_emb)
     emb = class_embedding(P, cfg, emb, class_labels)
 
@@ -528,6 +532,8 @@ def unet_param_shapes(config: dict) -> Dict[str, tuple]:
 
     conv("conv_in", cfg["in_channels"], boc[0], 3)
     lin("time_embedding.linear_1", boc[0], ted)
+    if cfg["time_cond_proj_dim"] is not None:   # TimestepEmbedding.cond_proj, no bias (embeddings.py:265-266)
+        lin("time_embedding.cond_proj", cfg["time_cond_proj_dim"], boc[0], bias=False)
     lin("time_embedding.linear_2", ted, ted)
     class_embedding_shapes(cfg, S)
     if cfg["addition_embed_type"] == "text_time":

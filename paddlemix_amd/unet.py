@@ -47,7 +47,7 @@ UNET_DEFAULTS = dict(
     time_cond_proj_dim=None, class_embed_type=None, num_class_embeds=None, class_embeddings_concat=False,
 )
 _UNSUPPORTED_IF_SET = ("encoder_hid_dim", "encoder_hid_dim_type",
-                       "time_embedding_dim", "time_embedding_act_fn", "timestep_post_act", "time_cond_proj_dim",
+                       "time_embedding_dim", "time_embedding_act_fn", "timestep_post_act",
                        "cross_attention_norm", "dual_cross_attention", "resnet_skip_time_act")
 
 
@@ -164,6 +164,8 @@ def unet_param_shapes(config: Mapping) -> Dict[str, tuple]:
 
     conv("conv_in", cfg["in_channels"], boc[0], 3)
     lin("time_embedding.linear_1", boc[0], ted)
+    if cfg["time_cond_proj_dim"] is not None:   # TimestepEmbedding.cond_proj, no bias (embeddings.py:265-266)
+        lin("time_embedding.cond_proj", cfg["time_cond_proj_dim"], boc[0], bias=False)
     lin("time_embedding.linear_2", ted, ted)
     ct, pdim = cfg["class_embed_type"], cfg["projection_class_embeddings_input_dim"]
     if ct is None and cfg["num_class_embeds"] is not None:
@@ -317,6 +319,8 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
         if cfg["addition_embed_type"] == "text_time":
             put_lin("add_embedding.linear_1", "add_embedding.linear_1")
             put_lin("add_embedding.linear_2", "add_embedding.linear_2")
+        if cfg["time_cond_proj_dim"] is not None:
+            put_lin("time_embedding.cond_proj", "time_embedding.cond_proj", bias=False)
         ct = cfg["class_embed_type"]
         self._class_kind = ("embedding" if (ct is None and cfg["num_class_embeds"] is not None) else ct)
         if self._class_kind == "embedding":
@@ -523,6 +527,12 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
                 emit(lib.mi355x_sd_copy_rows, (src.p, src.ld, cls_out.p, cls_out.ld, B, ted, stream), "misc")
             else:
                 pre_cls = src
+        plan.tcond = None
+        if cfg["time_cond_proj_dim"] is not None:   # t_emb += cond_proj(timestep_cond) (embeddings.py:284-285; zeros when not given)
+            plan.tcond = persist((B, cfg["time_cond_proj_dim"]), _lib.elem_dtype())
+            plan.tcond.zero_()
+            tv = _V(t0.data_ptr(), B, boc[0])
+            linear(_V(plan.tcond.data_ptr(), B, cfg["time_cond_proj_dim"]), "time_embedding.cond_proj", tv, bias=False, R=tv)
         linear(_V(t0.data_ptr(), B, boc[0]), "time_embedding.linear_1", _V(e1.data_ptr(), B, ted), flags=SILU)
         linear(_V(e1.data_ptr(), B, ted), "time_embedding.linear_2", emb, R=pre_cls)
         if ck in ("timestep", "projection", "simple_projection"):
@@ -762,8 +772,18 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
 
     def stage_inputs(self, plan: _Plan, sample, timestep, encoder_hidden_states, added_cond_kwargs=None,
                      in_scale: Optional[float] = None, encoder_attention_mask=None,
-                     down_block_additional_residuals=None, mid_block_additional_residual=None, class_labels=None) -> None:
+                     down_block_additional_residuals=None, mid_block_additional_residual=None, class_labels=None,
+                     timestep_cond=None) -> None:
         cfg = self.cfg
+        if plan.tcond is not None:
+            if timestep_cond is None:
+                plan.tcond.zero_()   # cond_proj has no bias: a zero condition adds nothing, like the reference's `condition is None`
+            else:
+                if tuple(timestep_cond.shape) != tuple(plan.tcond.shape):
+                    raise ValueError(f"timestep_cond of shape {tuple(timestep_cond.shape)}, expected {tuple(plan.tcond.shape)}")
+                plan.tcond.copy_(timestep_cond.to(plan.tcond.dtype), non_blocking=True)
+        elif timestep_cond is not None:
+            raise ValueError("timestep_cond was passed but the model has no `time_cond_proj_dim`")
         if plan.class_in is not None:
             if class_labels is None:
                 raise ValueError("class_labels should be provided when num_class_embeds > 0")
@@ -814,16 +834,16 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
                 attention_mask=None, cross_attention_kwargs=None, added_cond_kwargs=None,
                 down_block_additional_residuals=None, mid_block_additional_residual=None,
                 encoder_attention_mask=None, return_dict: bool = True):
-        for nm, v in (("timestep_cond", timestep_cond), ("attention_mask", attention_mask)):
-            if v is not None:
-                raise NotImplementedError(f"UNet2DConditionModel(mi355x): `{nm}` is not implemented on this path")
+        if attention_mask is not None:
+            raise NotImplementedError("UNet2DConditionModel(mi355x): `attention_mask` is not implemented on this path")
         # (class_labels without a class embedding are ignored, like unet_2d_condition.py:953)
         controlnet = down_block_additional_residuals is not None
         if controlnet != (mid_block_additional_residual is not None):
             raise NotImplementedError("ControlNet residuals need both `down_block_additional_residuals` and "
                                       "`mid_block_additional_residual` (the T2I-adapter form is not implemented)")
         ctrl = dict(down_block_additional_residuals=down_block_additional_residuals,
-                    mid_block_additional_residual=mid_block_additional_residual, class_labels=class_labels)
+                    mid_block_additional_residual=mid_block_additional_residual, class_labels=class_labels,
+                    timestep_cond=timestep_cond)
         if not self._emulated and (not sample.is_cuda or not encoder_hidden_states.is_cuda):
             raise _lib.MI355XError("inputs must be GPU tensors (no CPU fallback)")
         B, _, H, W = sample.shape

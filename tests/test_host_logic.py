@@ -98,6 +98,25 @@ def test_class_embeddings_match_oracle(kind, concat):
         model(sample, 333, enc)
 
 
+def test_timestep_cond_matches_oracle():
+    """time_cond_proj_dim / timestep_cond: the guidance-scale embedding of LCM-distilled UNets (embeddings.py:265-285,
+    unet_2d_condition.py:953)"""
+    cfg = dict(TINY, time_cond_proj_dim=32)
+    P = synth_unet_params(cfg, seed=9)
+    assert list(unet_param_shapes(cfg).items()) == list(U.unet_param_shapes(cfg).items())
+    assert "time_embedding.cond_proj.bias" not in P and P["time_embedding.cond_proj.weight"].shape == (32, 64)
+    Pb = {k: v.to(torch.bfloat16).float() if v.dim() > 1 else v for k, v in P.items()}
+    sample, enc, _ = _inputs(cfg, 2, 16, 16, 7)
+    w = torch.randn(2, 32, generator=torch.Generator().manual_seed(1))
+    model = UNet2DConditionModel(cfg, P, _test_backend=Emulator())
+    out = model(sample, 200, enc, timestep_cond=w).sample
+    assert _rel(out, U.unet_forward(Pb, cfg, sample, 200, enc, timestep_cond=w)) < 2e-2
+    out0 = model(sample, 200, enc).sample     # no condition: the projection adds nothing
+    assert _rel(out0, U.unet_forward(Pb, cfg, sample, 200, enc)) < 2e-2 and not torch.equal(out0, out)
+    with pytest.raises(ValueError, match="timestep_cond"):
+        UNet2DConditionModel(TINY, synth_unet_params(TINY, seed=9), _test_backend=Emulator())(sample, 200, enc, timestep_cond=w)
+
+
 def test_param_inventory_matches_oracle():
     for cfg in (TINY, MINI_XL, SD15, SDXL):
         a, b = unet_param_shapes(cfg), U.unet_param_shapes(cfg)
