@@ -198,3 +198,17 @@ def test_class_embeddings_on_device(kind, concat):
     assert _rel(out.cpu(), ref) < 2e-2, _rel(out.cpu(), ref)
     with pytest.raises(ValueError, match="class_labels should be provided"):
         model(_cuda(sample), 333, _cuda(enc))
+
+
+def test_timestep_cond_on_device():
+    """time_cond_proj_dim / timestep_cond (LCM guidance embedding): bias-free projection added to the sinusoid in place"""
+    from paddlemix_amd.unet import UNet2DConditionModel
+    cfg = dict(TINY, time_cond_proj_dim=32)
+    P = _bf16_params(cfg, "cpu")
+    sample, enc, _ = _inputs(cfg, 2, 16, 16, 7)
+    w = torch.randn(2, 32, generator=torch.Generator().manual_seed(1))
+    model = UNet2DConditionModel(cfg, P)
+    out = model(_cuda(sample), 200, _cuda(enc), timestep_cond=w.cuda()).sample.cpu()
+    assert _rel(out, U.unet_forward(P, cfg, sample, 200, enc, timestep_cond=w)) < 2e-2
+    out0 = model(_cuda(sample), 200, _cuda(enc)).sample.cpu()
+    assert _rel(out0, U.unet_forward(P, cfg, sample, 200, enc)) < 2e-2 and not torch.equal(out0, out)
