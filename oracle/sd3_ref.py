@@ -97,8 +97,9 @@ def fake_quant_bound(t: Tensor, l2_in: Tensor, W: Tensor, bias: Tensor) -> Tenso
 
 def joint_block(P: Params, name: str, x: Tensor, c: Tensor, temb: Tensor, heads: int, context_pre_only: bool,
                 act_quant: bool = False):
-    """JointTransformerBlock.forward (attention.py:164-214). ``act_quant``: fake-quantise the inputs of the eight block
-    GEMM groups (QKV, out, FF1, FF2 of both streams) like the device's W8A8 mode."""
+    """JointTransformerBlock.forward (attention.py:164-214). ``act_quant``: fake-quantise the inputs of the block GEMMs the
+    device's W8A8 mode runs in fp8 -- QKV, out, FF1, FF2 of the image stream, QKV and FF1 of the context stream (its two
+    N = D projections keep bf16 activations, paddlemix_amd/sd3.py)."""
     fq = fake_quant_rows if act_quant else (lambda t: t)
     st = F.silu(temb)
     shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = linear(P, name + ".norm1.linear", st).chunk(6, dim=1)
@@ -124,7 +125,7 @@ def joint_block(P: Params, name: str, x: Tensor, c: Tensor, temb: Tensor, heads:
     # (the device stores the attention output in bf16 before it is quantised)
     attn_x, attn_c = o[:, :S1], o[:, S1:]
     if act_quant:
-        attn_x, attn_c = fq(attn_x.to(torch.bfloat16).float()), fq(attn_c.to(torch.bfloat16).float())
+        attn_x = fq(attn_x.to(torch.bfloat16).float())
     attn_x = linear(P, name + ".attn.to_out.0", attn_x)
 
     x = x + gate_msa[:, None] * attn_x
@@ -140,10 +141,7 @@ def joint_block(P: Params, name: str, x: Tensor, c: Tensor, temb: Tensor, heads:
     attn_c = linear(P, name + ".attn.to_add_out", attn_c)
     c = c + c_gate_msa[:, None] * attn_c
     nc = layer_norm_noaffine(c) * (1 + c_scale_mlp[:, None]) + c_shift_mlp[:, None]
-    l2 = nc.norm(dim=-1)
     hc = F.gelu(linear(P, name + ".ff_context.net.0.proj", fq(nc)), approximate="tanh")
-    if act_quant:
-        hc = fake_quant_bound(hc, l2, P[name + ".ff_context.net.0.proj.weight"], P[name + ".ff_context.net.0.proj.bias"])
     ffc = linear(P, name + ".ff_context.net.2", hc)
     c = c + c_gate_mlp[:, None] * ffc
     return c, x

@@ -362,8 +362,8 @@ class SD3Transformer2DModel(DeviceProgram, PretrainedMixin):
         d = D // heads
         if w8a8:
             nx8, nc8 = _Q("nx", B * S1, D), _Q("nc", B * S2, D)
-            ax8, ac8 = _Q("ax", B * S1, D), _Q("ac", B * S2, D)
-            fx8, fc8 = _Q("fx", B * S1, 4 * D), _Q("fc", B * S2, 4 * D)
+            ax8 = _Q("ax", B * S1, D)
+            fx8 = _Q("fx", B * S1, 4 * D)
         for i in range(n):
             b = f"transformer_blocks.{i}"
             last = i == n - 1
@@ -398,19 +398,17 @@ class SD3Transformer2DModel(DeviceProgram, PretrainedMixin):
                 linear(nx, b + ".ff1", ffx, flags=GELU_TANH)
                 linear(ffx, b + ".ff2", x, R=x, gate=m_at(kx, 5), rpb=S1)
             if not last:
-                if w8a8:
-                    quant8(_V(ao + 2 * S1 * D, B * S2, D), ac8, x_rpb=S2, x_bs=ST * D)
-                    linear8(ac8, b + ".out_c", c, R=c, gate=m_at(kc, 2), rpb=S2)
-                else:
-                    linear(_V(ao + 2 * S1 * D, B * S2, D), b + ".out_c", c, R=c, gate=m_at(kc, 2), rpb=S2, a_rpb=S2,
-                           a_bs=ST * D)
+                # Context stream (B * S2 = 1232 rows at bs 8): its two N = D projections are 30-tile launches that the fp8
+                # 256x256 kernel (no split-K) runs at half the speed of the weight-only-fp8 path, so in W8A8 mode to_add_out
+                # and ff_context.net.2 take bf16 activations (fp8 weights, split-K); QKV and ff_context.net.0 stay W8A8.
+                linear(_V(ao + 2 * S1 * D, B * S2, D), b + ".out_c", c, R=c, gate=m_at(kc, 2), rpb=S2, a_rpb=S2,
+                       a_bs=ST * D)
                 an_c(m_at(kc, 4), m_at(kc, 3))
                 if w8a8:
-                    linear8q(nc8, b + ".ff1_c", fc8, flags=GELU_TANH)
-                    linear8(fc8, b + ".ff2_c", c, R=c, gate=m_at(kc, 5), rpb=S2)
+                    linear8(nc8, b + ".ff1_c", ffc, flags=GELU_TANH)
                 else:
                     linear(nc, b + ".ff1_c", ffc, flags=GELU_TANH)
-                    linear(ffc, b + ".ff2_c", c, R=c, gate=m_at(kc, 5), rpb=S2)
+                linear(ffc, b + ".ff2_c", c, R=c, gate=m_at(kc, 5), rpb=S2)
 
         # ---- norm_out (scale, shift) + proj_out + unpatchify (transformer_sd3.py:341-356) ----
         adaln(x, m_at("norm_out", 0), m_at("norm_out", 1), S1, nx)
