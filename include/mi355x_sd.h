@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MI355X_SD_ABI_VERSION 6
+#define MI355X_SD_ABI_VERSION 7
 #define MI355X_SD_OK 0
 #define MI355X_SD_ERR_INVALID 1      /* bad argument (shape <= 0, null pointer ...)          */
 #define MI355X_SD_ERR_UNSUPPORTED 2  /* well-formed but outside the implemented configurations */
@@ -58,6 +58,9 @@ int mi355x_sd_set_workspace(void* ptr, size_t bytes);
 #define MI355X_SD_OUT_F32 2  /* C is fp32 */
 #define MI355X_SD_GELU_TANH 8 /* tanh-GELU applied to the final value (FeedForward "gelu-approximate", PPD/models/attention.py:648-649) */
 #define MI355X_SD_SILU 4     /* SiLU applied to the final value (TimestepEmbedding.act, PPD/models/embeddings.py:283-295) */
+#define MI355X_SD_PAD_BR 16  /* conv3x3, stride 2 only: zero padding is one row / column at the bottom / right instead of all round
+                              * (Downsample2D with padding=0: F.pad (0,1,0,1) then an unpadded conv, PPD/models/resnet.py:277-279 --
+                              * the VAE encoder's downsamplers, vae.py:113) */
 
 /* C[M,N] = ((A[M,K] . W[N,K]^T) + bias[N] + rowbias[m / rows_per_batch][N] + R[M,N]) * out_scale
  * Replaces LoRACompatibleLinear.forward (PPD/models/lora.py:453-459) and, with conv1x1 weights, the 1x1
@@ -133,9 +136,10 @@ int mi355x_sd_adaln(const void* x, int rows, int C, int ldx, const float* scale,
 int mi355x_sd_patchify(const float* x_nchw, int B, int C, int H, int W, int patch, void* out, int ldo, void* stream);
 int mi355x_sd_unpatchify(const void* x, int ldx, int B, int C, int H, int W, int patch, float* out_nchw, void* stream);
 
-/* 3x3 convolution, padding 1, stride 1|2, as an implicit GEMM over an NHWC source [B][Hs][Ws][ldx>=Cin];
+/* 3x3 convolution, padding 1 (or bottom/right only with MI355X_SD_PAD_BR), stride 1|2, as an implicit GEMM over an NHWC source [B][Hs][Ws][ldx>=Cin];
  * `upsample` = 1 folds F.interpolate(scale_factor=2, mode="nearest") (PPD/models/resnet.py:169-218) into the
- * gather.  W is [Cout][3][3][Cin].  Output rows = B*Ho*Wo with Ho = ((Hs<<upsample) + 2 - 3)/stride + 1.
+ * gather.  W is [Cout][3][3][Cin].  Output rows = B*Ho*Wo with Ho = ((Hs<<upsample) + 2 - 3)/stride + 1
+ * (PAD_BR: ((Hs + 1 - 3)/2 + 1).
  * Replaces LoRACompatibleConv.forward (lora.py:364-377) as used by ResnetBlock2D (resnet.py:770,798, temb add
  * :772-784 via rowbias), Downsample2D (:271-294) and Upsample2D. */
 int mi355x_sd_conv3x3(const void* X, int ldx, int B, int Hs, int Ws, int Cin, int stride, int upsample,
@@ -186,6 +190,13 @@ int mi355x_sd_copy_rows(const void* x, int ldx, void* y, int ldy, int64_t rows, 
  * mid_block_additional_residual, PPD/models/unet_2d_condition.py:1121-1132, 1151-1155): x[b*HW + p][c] += r[b][c][p] in place
  * on a bf16 NHWC row view (row stride ldx; C % 8 == 0), r NCHW fp32 as the reference passes it. */
 int mi355x_sd_add_nchw(void* x, int ldx, const float* r_nchw, int B, int C, int64_t HW, void* stream);
+
+/* DiagonalGaussianDistribution (PPD/models/vae.py:744-763, built by AutoencoderKL.encode, autoencoder_kl.py:266-283) from
+ * the encoder's moments held as fp32 rows [B*HW][ld >= 2L] (channels mean_0..L-1, logvar_0..L-1): writes NCHW fp32
+ * mean ( = .mode()), logvar clipped to [-30, 20] and -- sample_nchw != NULL -- (mean + exp(0.5 logvar) * noise) * out_scale
+ * ( = .sample() with the caller's noise, times the pipelines' vae.config.scaling_factor; noise NULL: mean * out_scale). */
+int mi355x_sd_latent_dist(const float* moments, int ld, int B, int L, int64_t HW, const float* noise_nchw, float out_scale,
+                          float* mean_nchw, float* logvar_nchw, float* sample_nchw, void* stream);
 
 /* ---- CLIP text encoder (PPD/transformers/clip/modeling.py) ----
  * CLIPTextEmbeddings.forward (:214-231): out[i][:] = bf16(token_table[ids[i]] + position_table[i % seq_len]); tables bf16

@@ -1,4 +1,4 @@
-"""TEST INFRASTRUCTURE ONLY -- CPU oracle of ppdiffusers' AutoencoderKL *decode* path.
+"""TEST INFRASTRUCTURE ONLY -- CPU oracle of ppdiffusers' AutoencoderKL decode and encode paths.
 
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline leg may import this module; the product
 (``paddlemix_amd/``) never does.
@@ -12,7 +12,12 @@ torch-CPU fp32 restatement of
                                                  Upsample2D with conv)
   * ``ResnetBlock2D`` with ``temb_channels=None``  PPD/models/resnet.py:728-808 (no time_emb_proj)
   * ``AttnProcessor.__call__`` on a 4-D input    PPD/models/attention_processor.py:673-735
-and the pipelines' ``latents / vae.config.scaling_factor`` (pipeline_stable_diffusion.py:911).
+and the pipelines' ``latents / vae.config.scaling_factor`` (pipeline_stable_diffusion.py:911); for ``encode``
+  * ``AutoencoderKL.encode``                     PPD/models/autoencoder_kl.py:250-283 (quant_conv :120, :274-277)
+  * ``Encoder.__init__`` / ``forward``           PPD/models/vae.py:76-180
+  * ``DownEncoderBlock2D``                       PPD/models/unet_2d_blocks.py:1301-1367 (layers_per_block resnets, Downsample2D
+                                                 with padding=0 -> F.pad (0, 1, 0, 1) + unpadded stride-2 conv, resnet.py:277-279)
+  * ``DiagonalGaussianDistribution``             PPD/models/vae.py:744-795
 
 PARITY UNPINNED: the reference's VAE tests (ppdiffusers/tests/models/test_models_vae.py) compare against slices produced
 with Paddle's RNG / real checkpoints, neither of which exists here; Paddle itself cannot be imported. The op-level
@@ -34,7 +39,7 @@ Params = Dict[str, Tensor]
 
 VAE_DEFAULTS = dict(in_channels=3, out_channels=3, latent_channels=4, block_out_channels=(128, 256, 512, 512),
                     layers_per_block=2, norm_num_groups=32, act_fn="silu", scaling_factor=0.18215,
-                    use_post_quant_conv=True, sample_size=512)
+                    use_post_quant_conv=True, use_quant_conv=True, sample_size=512)
 
 
 def normalize_config(config: dict) -> dict:
@@ -154,3 +159,74 @@ def decode(P: Params, config: dict, z: Tensor, scaled: bool = False) -> Tensor:
             x = U.upsample(P, f"decoder.up_blocks.{i}.upsamplers.0", x)
     x = F.silu(U.group_norm(P, "decoder.conv_norm_out", x, groups, 1e-6))
     return U.conv2d(P, "decoder.conv_out", x)
+
+
+def encoder_param_shapes(config: dict) -> Dict[str, tuple]:
+    """Parameter names/shapes of the encode path in construction order (Encoder.__init__, vae.py:76-144)."""
+    cfg = normalize_config(config)
+    boc, lc = cfg["block_out_channels"], cfg["latent_channels"]
+    S: Dict[str, tuple] = {}
+
+    def put(name, wshape):
+        S[name + ".weight"] = wshape
+        S[name + ".bias"] = (wshape[0] if len(wshape) != 2 else wshape[1],)
+
+    def resnet(name, cin, cout):
+        put(name + ".norm1", (cin,))
+        put(name + ".conv1", (cout, cin, 3, 3))
+        put(name + ".norm2", (cout,))
+        put(name + ".conv2", (cout, cout, 3, 3))
+        if cin != cout:
+            put(name + ".conv_shortcut", (cout, cin, 1, 1))
+
+    put("encoder.conv_in", (boc[0], cfg["in_channels"], 3, 3))
+    ch = boc[0]
+    for i, c in enumerate(boc):
+        for j in range(cfg["layers_per_block"]):
+            resnet(f"encoder.down_blocks.{i}.resnets.{j}", ch, c)
+            ch = c
+        if i != len(boc) - 1:
+            put(f"encoder.down_blocks.{i}.downsamplers.0.conv", (c, c, 3, 3))
+    resnet("encoder.mid_block.resnets.0", ch, ch)
+    put("encoder.mid_block.attentions.0.group_norm", (ch,))
+    for nm in ("to_q", "to_k", "to_v", "to_out.0"):
+        put(f"encoder.mid_block.attentions.0.{nm}", (ch, ch))
+    resnet("encoder.mid_block.resnets.1", ch, ch)
+    put("encoder.conv_norm_out", (ch,))
+    put("encoder.conv_out", (2 * lc, ch, 3, 3))
+    if cfg["use_quant_conv"]:
+        put("quant_conv", (2 * lc, 2 * lc, 1, 1))
+    return S
+
+
+def encode_moments(P: Params, config: dict, x: Tensor) -> Tensor:
+    """quant_conv(Encoder.forward(x)): [B, 2 * latent_channels, H / 2^(n-1), W / 2^(n-1)] (autoencoder_kl.py:266-277)."""
+    cfg = normalize_config(config)
+    groups, n = cfg["norm_num_groups"], len(cfg["block_out_channels"])
+    h = U.conv2d(P, "encoder.conv_in", x)
+    for i in range(n):
+        for j in range(cfg["layers_per_block"]):
+            h = resnet_block(P, f"encoder.down_blocks.{i}.resnets.{j}", h, groups)
+        if i != n - 1:
+            name = f"encoder.down_blocks.{i}.downsamplers.0.conv"
+            h = F.conv2d(F.pad(h, (0, 1, 0, 1), mode="constant", value=0.0), P[name + ".weight"], P[name + ".bias"], stride=2)
+    h = resnet_block(P, "encoder.mid_block.resnets.0", h, groups)
+    h = mid_attention(P, "encoder.mid_block.attentions.0", h, groups)
+    h = resnet_block(P, "encoder.mid_block.resnets.1", h, groups)
+    h = U.conv2d(P, "encoder.conv_out", F.silu(U.group_norm(P, "encoder.conv_norm_out", h, groups, 1e-6)))
+    if cfg["use_quant_conv"]:
+        h = U.conv2d(P, "quant_conv", h, padding=0)
+    return h
+
+
+def posterior(moments: Tensor):
+    """DiagonalGaussianDistribution(moments) -> (mean, logvar clipped to [-30, 20], std) (vae.py:745-750)."""
+    mean, logvar = torch.chunk(moments, 2, dim=1)
+    logvar = torch.clamp(logvar, -30.0, 20.0)
+    return mean, logvar, torch.exp(0.5 * logvar)
+
+
+def encode(P: Params, config: dict, x: Tensor, noise: Tensor = None):
+    """-> (mean, logvar, sample): ``.latent_dist.mode()``, ``.logvar`` and ``.sample()`` with the given noise (mean if None)."""
+    mean, logvar, std = posterior(encode_moments(P, config, x))
+    return mean, logvar, (mean if noise is None else mean + std * noise)

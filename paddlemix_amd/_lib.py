@@ -17,8 +17,8 @@ if ELEM_NAME not in _BUILDS:
     raise ValueError(f"MI355X_SD_DTYPE must be one of {sorted(_BUILDS)}, got {ELEM_NAME!r}")
 LIB_PATH = os.path.join(_HERE, _BUILDS[ELEM_NAME][0])
 
-ABI_VERSION = 6
-GEGLU, OUT_F32, SILU, GELU_TANH = 1, 2, 4, 8
+ABI_VERSION = 7
+GEGLU, OUT_F32, SILU, GELU_TANH, PAD_BR = 1, 2, 4, 8, 16
 
 # name -> (restype, argtypes); must list every symbol include/mi355x_sd.h declares (tests/test_abi.py checks)
 SIGNATURES = {
@@ -67,6 +67,8 @@ SIGNATURES = {
                                       c_void_p]),
     "mi355x_sd_copy_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p]),
     "mi355x_sd_add_nchw": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int64, c_void_p]),
+    "mi355x_sd_latent_dist": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
+                                      c_void_p]),
     "mi355x_sd_embed_tokens": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "mi355x_sd_rmsnorm": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_int, c_void_p]),
     "mi355x_sd_gated_activation": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),

@@ -232,9 +232,12 @@ int mi355x_sd_conv3x3(const void* X, int ldx, int B, int Hs, int Ws, int Cin, in
   memset(&g, 0, sizeof(g));
   g.A = (const bf16*)X; g.W = (const bf16*)W; g.C = C;
   g.conv = 1; g.Hs = Hs; g.Ws = Ws; g.Cin = Cin; g.stride = stride; g.up = upsample;
+  g.pad = (flags & MI355X_SD_PAD_BR) ? 0 : 1;
+  if (!g.pad && (stride != 2 || upsample))
+    return fail(SD_ERR_UNSUPPORTED, "mi355x_sd_conv3x3: MI355X_SD_PAD_BR is the stride-2 downsampler's padding");
   const int Hin = Hs << upsample, Win = Ws << upsample;
-  g.Ho = (Hin + 2 - 3) / stride + 1;
-  g.Wo = (Win + 2 - 3) / stride + 1;
+  g.Ho = (Hin + 1 + g.pad - 3) / stride + 1;
+  g.Wo = (Win + 1 + g.pad - 3) / stride + 1;
   g.M = B * g.Ho * g.Wo; g.N = Cout; g.K = 9 * Cin; g.lda = ldx; g.ldc = ldc;
   g.bias = bias; g.rowbias = rowbias; g.rows_per_batch = g.Ho * g.Wo; g.ld_rowbias = ld_rowbias;
   g.R = (const bf16*)R; g.ldr = ldr; g.out_scale = out_scale;
@@ -319,6 +322,13 @@ int mi355x_sd_copy_rows(const void* x, int ldx, void* y, int ldy, int64_t rows, 
 int mi355x_sd_add_nchw(void* x, int ldx, const float* r_nchw, int B, int C, int64_t HW, void* stream) {
   if (!x || !r_nchw) return fail(SD_ERR_INVALID, "mi355x_sd_add_nchw: null pointer");
   return finish(launch_add_nchw((bf16*)x, ldx, r_nchw, B, C, (long)HW, S(stream)), "mi355x_sd_add_nchw");
+}
+
+int mi355x_sd_latent_dist(const float* moments, int ld, int B, int L, int64_t HW, const float* noise_nchw, float out_scale,
+                          float* mean_nchw, float* logvar_nchw, float* sample_nchw, void* stream) {
+  if (!moments || !mean_nchw || !logvar_nchw) return fail(SD_ERR_INVALID, "mi355x_sd_latent_dist: null pointer");
+  return finish(launch_latent_dist(moments, ld, B, L, (long)HW, noise_nchw, out_scale, mean_nchw, logvar_nchw, sample_nchw,
+                                   S(stream)), "mi355x_sd_latent_dist");
 }
 
 int mi355x_sd_embed_tokens(const int32_t* ids, int64_t n_tokens, int seq_len, const void* token_table,

@@ -118,8 +118,8 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_bf16_kernel(const GemmAr
       const int Hin = p.Hs << p.up, Win = p.Ws << p.up;
 #pragma unroll
       for (int i = 0; i < CFG::A_PIECES; ++i) {
-        const int iy = goy[i] * p.stride + ky - 1;
-        const int ix = gox[i] * p.stride + kx - 1;
+        const int iy = goy[i] * p.stride + ky - p.pad;
+        const int ix = gox[i] * p.stride + kx - p.pad;
         const bool ok = ga_ok[i] && k_ok && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
         const size_t off = ((size_t)(iy >> p.up) * p.Ws + (ix >> p.up)) * p.lda + gcch;
         const bf16* src = ok ? ga_base[i] + off : zsrc;

@@ -129,8 +129,8 @@ __global__ __launch_bounds__(g256::THREADS, 2) void gemm256_kernel(const GemmArg
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int i = h * 2 + j;
-        const int iy = oy[i] * p.stride + ky - 1;
-        const int ix = ox[i] * p.stride + kx - 1;
+        const int iy = oy[i] * p.stride + ky - p.pad;
+        const int ix = ox[i] * p.stride + kx - p.pad;
         const bool ok = a_ok[i] && k_ok && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
         const unsigned off = a_img[i] + (unsigned)(((iy >> p.up) * p.Ws + (ix >> p.up)) * p.lda + chA[h]) * 2u;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lptr_t)(dst + j * 1024), 16, ok ? off : OOB, 0, 0, 0);

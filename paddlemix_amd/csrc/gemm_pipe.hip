@@ -121,8 +121,8 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES) void gemm_pipe_kernel
       const int Hin = p.Hs << p.up, Win = p.Ws << p.up;
 #pragma unroll
       for (int i = 0; i < AP; ++i) {
-        const int iy = oy[i] * p.stride + ky - 1;
-        const int ix = ox[i] * p.stride + kx - 1;
+        const int iy = oy[i] * p.stride + ky - p.pad;
+        const int ix = ox[i] * p.stride + kx - p.pad;
         const bool ok = a_ok[i] && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
         const unsigned off = a_off[i] + (unsigned)(((iy >> p.up) * p.Ws + (ix >> p.up)) * p.lda + gcch) * 2u;
         if (CFG::A_TOTAL % NW == 0 || wave + i * NW < CFG::A_TOTAL) dma(a_rsrc, a + i * (NW * 1024), ok ? off : OOB, 0);

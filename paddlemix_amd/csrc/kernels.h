@@ -18,6 +18,7 @@ struct GemmArgs {
   int Cin;
   int stride;      // 1 | 2
   int up;          // 1: nearest-2x upsample of the source folded into the gather
+  int pad;         // 1: zero padding all round; 0: one row / column at the bottom / right only (MI355X_SD_PAD_BR)
   // epilogue
   const float* bias;      // [N]
   const float* rowbias;   // [M / rows_per_batch][ld_rowbias] broadcast over rows of one batch item
@@ -102,6 +103,8 @@ int launch_conv_in3x3(const float* x_nchw, const float* in_scale, const bf16* w,
 int launch_conv_out3x3(const bf16* x, int ldx, const bf16* w, const float* bias, float* y_nchw, int B, int Cin, int H,
                        int W, int Cout, hipStream_t stream);
 int launch_add_nchw(bf16* x, int ldx, const float* r, int B, int C, long HW, hipStream_t stream);
+int launch_latent_dist(const float* m, int ld, int B, int L, long HW, const float* noise, float out_scale, float* mean,
+                       float* logvar, float* sample, hipStream_t stream);
 int launch_embed_tokens(const int* ids, long n_tokens, int seq_len, const bf16* tok, const bf16* pos, int D, bf16* out,
                         int ldo, hipStream_t stream);
 int launch_gated_activation(const bf16* x, int ldx, bf16* y, int ldy, long rows, int F, int kind, hipStream_t stream);

@@ -500,4 +500,36 @@ int launch_unpatchify(const bf16* x, int ldx, int B, int C, int H, int W, int p,
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
 
+// DiagonalGaussianDistribution (PPD/models/vae.py:744-763) from the encoder's moment rows: m [B*HW][ld >= 2L] fp32 (the
+// fp32 output of the conv_out GEMM, channels (mean_0..L-1, logvar_0..L-1)) -> NCHW fp32 mean, logvar clipped to [-30, 20],
+// and (noise != NULL) sample = (mean + exp(0.5 logvar) * noise) * out_scale. One thread per output element: the row
+// reads hit 2L*4 <= 128 B per pixel, the NCHW writes are unit-stride.
+__global__ void latent_dist_kernel(const float* __restrict__ m, int ld, int B, int L, long HW,
+                                   const float* __restrict__ noise, float out_scale, float* __restrict__ mean,
+                                   float* __restrict__ logvar, float* __restrict__ sample) {
+  const long total = (long)B * L * HW;
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long)gridDim.x * blockDim.x) {
+    const long pix = id % HW;
+    const int c = (int)((id / HW) % L);
+    const int b = (int)(id / (HW * L));
+    const float* row = m + ((size_t)b * HW + pix) * ld;
+    const float mu = row[c];
+    const float lv = fminf(fmaxf(row[L + c], -30.f), 20.f);
+    mean[id] = mu;
+    logvar[id] = lv;
+    if (sample) sample[id] = (mu + (noise ? __expf(0.5f * lv) * noise[id] : 0.f)) * out_scale;
+  }
+}
+
+int launch_latent_dist(const float* m, int ld, int B, int L, long HW, const float* noise, float out_scale, float* mean,
+                       float* logvar, float* sample, hipStream_t stream) {
+  if (B <= 0 || L <= 0 || HW <= 0 || ld < 2 * L) return SD_ERR_INVALID;
+  const long total = (long)B * L * HW;
+  long nb = (total + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(latent_dist_kernel, dim3((unsigned)nb), dim3(256), 0, stream, m, ld, B, L, HW, noise, out_scale,
+                     mean, logvar, sample);
+  return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+}
+
 }  // namespace sd

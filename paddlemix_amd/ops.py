@@ -92,8 +92,9 @@ def linear(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, rowbias: Opti
 
 def conv3x3(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, stride: int = 1, upsample: bool = False,
             rowbias: Optional[Tensor] = None, residual: Optional[Tensor] = None, out: Optional[Tensor] = None,
-            out_scale: float = 1.0) -> Tensor:
-    """x NHWC view [B,H,W,C] (pixel stride >= C), w [Cout, 9*Cin] -> rows [B*Ho*Wo, Cout]."""
+            out_scale: float = 1.0, pad_br: bool = False) -> Tensor:
+    """x NHWC view [B,H,W,C] (pixel stride >= C), w [Cout, 9*Cin] -> rows [B*Ho*Wo, Cout]. ``pad_br`` (stride 2): zero
+    padding at the bottom / right only -- Downsample2D(padding=0), resnet.py:277-279."""
     lib = _lib.load()
     _bind_workspace(x.device)
     if x.dim() != 4 or x.dtype != _lib.elem_dtype() or x.stride(3) != 1 or not x.is_cuda:
@@ -106,8 +107,9 @@ def conv3x3(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, stride: int 
     if w.dtype != _lib.elem_dtype() or not w.is_contiguous() or w.shape[1] != 9 * C:
         raise ValueError(f"w: expected contiguous bf16 [Cout, {9 * C}]")
     up = 1 if upsample else 0
-    Ho = ((H << up) + 2 - 3) // stride + 1
-    Wo = ((W << up) + 2 - 3) // stride + 1
+    pad2 = 1 if pad_br else 2
+    Ho = ((H << up) + pad2 - 3) // stride + 1
+    Wo = ((W << up) + pad2 - 3) // stride + 1
     M = B * Ho * Wo
     if out is None:
         out = torch.empty((M, Cout), device=x.device, dtype=_lib.elem_dtype())
@@ -116,8 +118,28 @@ def conv3x3(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, stride: int 
     ld_rb = rowbias.stride(0) if rowbias is not None else 0
     check(lib.mi355x_sd_conv3x3(x.data_ptr(), ldx, B, H, W, C, stride, up, w.data_ptr(), out.data_ptr(), ldc, Cout,
                                 _p(_vec(bias, Cout, "bias")), _p(rowbias), ld_rb, _p(residual), ldr, float(out_scale),
-                                0, _stream()))
+                                _lib.PAD_BR if pad_br else 0, _stream()))
     return out
+
+
+def latent_dist(moments: Tensor, B: int, L: int, noise: Optional[Tensor] = None, out_scale: float = 1.0,
+                want_sample: bool = True):
+    """moments fp32 rows [B*HW, >= 2L] -> (mean, logvar, sample | None), NCHW-flattened fp32 [B, L, HW]
+    (DiagonalGaussianDistribution, PPD/models/vae.py:744-763)."""
+    lib = _lib.load()
+    if not moments.is_cuda or moments.dtype != torch.float32 or moments.dim() != 2 or moments.stride(1) != 1:
+        raise ValueError("moments: expected fp32 GPU rows")
+    if moments.shape[0] % B or moments.shape[1] < 2 * L:
+        raise ValueError("moments: expected [B*HW, >= 2L]")
+    HW = moments.shape[0] // B
+    mk = lambda: torch.empty((B, L, HW), device=moments.device, dtype=torch.float32)  # noqa: E731
+    mean, logvar = mk(), mk()
+    sample = mk() if want_sample else None
+    if noise is not None and (noise.dtype != torch.float32 or noise.numel() != B * L * HW or not noise.is_contiguous()):
+        raise ValueError("noise: expected contiguous fp32 [B, L, HW]")
+    check(lib.mi355x_sd_latent_dist(moments.data_ptr(), moments.stride(0), B, L, HW, _p(noise), float(out_scale),
+                                    mean.data_ptr(), logvar.data_ptr(), _p(sample), _stream()))
+    return mean, logvar, sample
 
 
 def sdpa(q: Tensor, k: Tensor, v: Tensor, bias: Optional[Tensor] = None, scale: Optional[float] = None,

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 from typing import Callable, Dict, Optional
 
+import numpy as np
 import torch
 
 
@@ -104,6 +105,34 @@ class StableDiffusionDenoiser:
             raise ValueError(f"Unexpected latents shape, got {tuple(latents.shape)}, expected {shape}")
         return latents * self.scheduler.init_noise_sigma  # pipeline_stable_diffusion.py:581-586
 
+    def get_timesteps(self, num_inference_steps: int, strength: float):
+        """img2img: keep the last ``int(steps * strength)`` steps (pipeline_stable_diffusion_img2img.py:616-623)."""
+        init_timestep = min(int(num_inference_steps * strength), num_inference_steps)
+        t_start = max(num_inference_steps - init_timestep, 0)
+        order = getattr(self.scheduler, "order", 1)
+        return self.scheduler.timesteps[t_start * order:], num_inference_steps - t_start, t_start * order
+
+    def prepare_image_latents(self, image: torch.Tensor, timestep, batch_size: int, generator=None) -> torch.Tensor:
+        """img2img ``prepare_latents`` (pipeline_stable_diffusion_img2img.py:625-681): encode (unless `image` already has the
+        latent channel count), ``* scaling_factor``, duplicate to the prompt batch, ``scheduler.add_noise`` at the first kept
+        timestep. The posterior sample and its scaling are one launch (``latent_dist.sample(out_scale=...)``)."""
+        if not torch.is_tensor(image) or image.dim() != 4:
+            raise ValueError(f"`image` has to be a [B, C, H, W] tensor but is {type(image)}")
+        if image.shape[1] == self.unet.config.in_channels:
+            init = image.to(torch.float32)
+        else:
+            if self.vae is None:
+                raise ValueError("an image input needs a `vae` with encoder parameters")
+            dist = self.vae.encode(image.to(torch.float32)).latent_dist
+            init = dist.sample(generator, out_scale=self.vae.config.scaling_factor)
+        if batch_size > init.shape[0]:
+            if batch_size % init.shape[0]:
+                raise ValueError(f"Cannot duplicate `image` of batch size {init.shape[0]} to {batch_size} text prompts.")
+            init = torch.cat([init] * (batch_size // init.shape[0]))
+        noise = torch.randn(init.shape, generator=generator, dtype=torch.float32, device=init.device)
+        ts = torch.as_tensor(np.asarray(timestep).reshape(-1)[:1]).repeat(init.shape[0])
+        return self.scheduler.add_noise(init, noise, ts)
+
     @torch.no_grad()
     def __call__(self, prompt_embeds: Optional[torch.Tensor] = None, negative_prompt_embeds: Optional[torch.Tensor] = None,
                  height: Optional[int] = None, width: Optional[int] = None, num_inference_steps: int = 50,
@@ -114,8 +143,14 @@ class StableDiffusionDenoiser:
                  output_type: str = "latent", prompt_ids: Optional[torch.Tensor] = None,
                  negative_prompt_ids: Optional[torch.Tensor] = None, prompt_ids_2: Optional[torch.Tensor] = None,
                  negative_prompt_ids_2: Optional[torch.Tensor] = None, original_size=None,
-                 crops_coords_top_left=(0, 0), target_size=None, fused_update: bool = True):
+                 crops_coords_top_left=(0, 0), target_size=None, fused_update: bool = True,
+                 image: Optional[torch.Tensor] = None, strength: float = 0.8):
+        """``image`` (extension of the text2img call = StableDiffusionImg2ImgPipeline.__call__,
+        pipeline_stable_diffusion_img2img.py:735-1010): start from the encoded, re-noised image and run the last
+        ``int(num_inference_steps * strength)`` steps."""
         do_cfg = guidance_scale > 1.0
+        if image is not None and (strength < 0 or strength > 1):
+            raise ValueError(f"The value of strength should in [0.0, 1.0] but is {strength}")
         if prompt_embeds is None:
             if prompt_ids is None:
                 raise ValueError("Provide either `prompt_embeds` or `prompt_ids`")
@@ -150,9 +185,17 @@ class StableDiffusionDenoiser:
                 neg = negative_added_cond_kwargs or added_cond_kwargs
                 added_cond_kwargs = {k: torch.cat([neg[k], v]) for k, v in added_cond_kwargs.items()}
         self.scheduler.set_timesteps(num_inference_steps)
-        latents = self.prepare_latents(B, cfg.in_channels, h, w, torch.float32, generator, latents, prompt_embeds.device)
+        timesteps, first = self.scheduler.timesteps, 0
+        if image is not None:
+            timesteps, _, first = self.get_timesteps(num_inference_steps, strength)
+            if len(timesteps) < 1:
+                raise ValueError(f"After adjusting the num_inference_steps by strength parameter: {strength}, the number of "
+                                 "pipeline steps is 0 which is < 1 and not appropriate for this pipeline.")
+            latents = self.prepare_image_latents(image, timesteps[:1], B, generator)
+        else:
+            latents = self.prepare_latents(B, cfg.in_channels, h, w, torch.float32, generator, latents, prompt_embeds.device)
         fused = self._fused_plan(guidance_rescale, latents.device) if fused_update else None
-        for i, t in enumerate(self.scheduler.timesteps):
+        for i, t in enumerate(timesteps, start=first):
             latent_model_input = torch.cat([latents] * 2) if do_cfg else latents
             if fused is not None:
                 # guidance combine + scheduler update as ONE device pass over the latents (mi355x_sd_cfg_axpby): the

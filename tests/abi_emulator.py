@@ -244,7 +244,11 @@ class Emulator:
         if up:
             x = F.interpolate(x, scale_factor=2.0, mode="nearest")
         w = _rows(W, Cout, 9 * Cin, 9 * Cin).float().reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
-        y = F.conv2d(x, w, None, stride=stride, padding=1)
+        if flags & 16:   # MI355X_SD_PAD_BR
+            assert stride == 2 and not up
+            y = F.conv2d(F.pad(x, (0, 1, 0, 1)), w, None, stride=2, padding=0)
+        else:
+            y = F.conv2d(x, w, None, stride=stride, padding=1)
         Ho, Wo = y.shape[2], y.shape[3]
         acc = y.permute(0, 2, 3, 1).reshape(B * Ho * Wo, Cout)
         self._epilogue(acc, Cout, bias, rowbias, Ho * Wo, ld_rb, R, ldr, out_scale, flags, C, ldc)
@@ -345,6 +349,17 @@ class Emulator:
         xv = _rows(x, B * HW, C, ldx)
         rv = _flat(r, B * C * HW, torch.float32).reshape(B, C, HW).permute(0, 2, 1).reshape(B * HW, C)
         xv.copy_((xv.float() + rv).to(_lib.elem_dtype()))
+        return 0
+
+    def mi355x_sd_latent_dist(self, m, ld, B, L, HW, noise, out_scale, mean, logvar, sample, stream):
+        mv = _flat(m, B * HW * ld, torch.float32).reshape(B, HW, ld)
+        mu = mv[:, :, :L].permute(0, 2, 1).reshape(-1)
+        lv = mv[:, :, L:2 * L].permute(0, 2, 1).reshape(-1).clamp(-30.0, 20.0)
+        _flat(mean, B * L * HW, torch.float32).copy_(mu)
+        _flat(logvar, B * L * HW, torch.float32).copy_(lv)
+        if sample:
+            x = mu + (torch.exp(0.5 * lv) * _flat(noise, B * L * HW, torch.float32) if noise else 0.0)
+            _flat(sample, B * L * HW, torch.float32).copy_(x * out_scale)
         return 0
 
     def mi355x_sd_embed_tokens(self, ids, n_tokens, seq_len, tok, pos, D, out, ldo, stream):

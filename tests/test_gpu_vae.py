@@ -89,3 +89,88 @@ def test_sd_vae_decoder_256px():
     r = _rel(out.cpu(), ref)
     print(f"sd-vae decode 256px: rel-L2 vs oracle {r:.3e}")
     assert out.shape == (1, 3, 256, 256) and torch.isfinite(out).all() and r < 2e-2, r
+
+
+# ---------------------------------------------------------------- encode path
+@pytest.mark.parametrize("B,H,W,C,Cout", [(2, 16, 16, 32, 32), (1, 9, 7, 64, 16), (1, 64, 64, 128, 128)])
+def test_conv3x3_stride2_bottom_right_padding(ops, B, H, W, C, Cout):
+    """MI355X_SD_PAD_BR = Downsample2D(padding=0): F.pad (0, 1, 0, 1) then an unpadded stride-2 conv (resnet.py:277-279)"""
+    g = torch.Generator().manual_seed(H * W + C)
+    x = torch.randn(B, H, W, C, generator=g).to(torch.bfloat16)
+    w = (torch.randn(Cout, C, 3, 3, generator=g) / (9 * C) ** 0.5).to(torch.bfloat16)
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(F.pad(x.float().permute(0, 3, 1, 2), (0, 1, 0, 1)), w.float(), b, stride=2)
+    wk = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous()
+    out = ops.conv3x3(x.cuda(), wk.cuda(), b.cuda(), stride=2, pad_br=True)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    assert out.shape == (B * Ho * Wo, Cout)
+    assert _rel(out.float().cpu().reshape(B, Ho, Wo, Cout).permute(0, 3, 1, 2), ref) < 4e-3
+    sym = ops.conv3x3(x.cuda(), wk.cuda(), b.cuda(), stride=2)            # the UNet's symmetric padding is a different conv
+    ref_sym = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), b, stride=2, padding=1)
+    assert _rel(sym.float().cpu().reshape(B, ref_sym.shape[2], ref_sym.shape[3], Cout).permute(0, 3, 1, 2), ref_sym) < 4e-3
+    from paddlemix_amd._lib import MI355XError
+    with pytest.raises(MI355XError):
+        ops.conv3x3(x.cuda(), wk.cuda(), b.cuda(), stride=1, pad_br=True)
+
+
+def test_latent_dist_kernel(ops):
+    g = torch.Generator().manual_seed(0)
+    B, L, HW = 3, 4, 77
+    m = torch.randn(B * HW, 2 * L, generator=g) * 20.0      # logvars beyond both clip bounds
+    noise = torch.randn(B, L, HW, generator=g)
+    mean, logvar, std = R.posterior(m.reshape(B, HW, 2 * L).permute(0, 2, 1))
+    gm, gl, gs = ops.latent_dist(m.cuda(), B, L, noise.cuda(), out_scale=0.18215)
+    assert torch.equal(gm.cpu(), mean) and torch.equal(gl.cpu(), logvar)
+    assert (logvar == 20).any() and (logvar == -30).any()
+    assert torch.allclose(gs.cpu(), (mean + std * noise) * 0.18215, rtol=1e-5, atol=1e-6)
+    _, _, mode = ops.latent_dist(m.cuda(), B, L, None, out_scale=2.0)
+    assert torch.equal(mode.cpu(), mean * 2.0)
+    # wider rows than 2L (a channel slice of a larger buffer)
+    wide = torch.zeros(B * HW, 16)
+    wide[:, :8] = m
+    assert torch.equal(ops.latent_dist(wide.cuda(), B, L, want_sample=False)[0].cpu(), mean)
+
+
+def _bf(P):
+    return {k: (v.to(torch.bfloat16).float() if v.dim() > 1 else v) for k, v in P.items()}
+
+
+def test_mini_vae_encode_vs_oracle():
+    from paddlemix_amd.vae import AutoencoderKL, synth_vae_params
+    cfg = MINI_VAE
+    P = _bf(synth_vae_params(cfg, 9))
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    vae = AutoencoderKL(cfg, P)
+    post = vae.encode(x.cuda()).latent_dist
+    noise = torch.randn(post.mean.shape, generator=g)
+    mean, logvar, sample = R.encode(P, cfg, x, noise)
+    r = _rel(post.mean.cpu(), mean)
+    print(f"mini-vae encode: rel-L2 vs oracle mean {r:.3e} logvar {_rel(post.logvar.cpu(), logvar):.3e}")
+    assert post.mean.shape == mean.shape and r < 2e-2, r
+    assert _rel(post.logvar.cpu(), logvar) < 2e-2
+    got = post.sample(noise=noise.cuda())
+    assert _rel(got.cpu(), sample) < 2e-2
+    assert torch.equal(vae.encode(x.cuda()).latent_dist.mean, post.mean)          # graph replay is deterministic
+    eager = AutoencoderKL(cfg, P, use_graph=False).encode(x.cuda()).latent_dist
+    assert torch.equal(eager.mean, post.mean) and torch.equal(eager.logvar, post.logvar)
+    a = post.sample(generator=torch.Generator(device="cuda").manual_seed(3))
+    assert torch.equal(a, post.sample(generator=torch.Generator(device="cuda").manual_seed(3)))
+    vae.enable_slicing()
+    assert _rel(vae.encode(x.cuda()).latent_dist.mean, post.mean) < 2e-2
+    # img2img seam: decode(encode(x).mode()) runs on the same object and keeps the size
+    assert vae.decode(post.mode()).sample.shape == x.shape
+
+
+def test_sd_vae_encoder_256px():
+    """The full SD VAE encoder (34.2 M parameters) on a 256x256 image -> 32x32 latents."""
+    from paddlemix_amd.vae import AutoencoderKL, synth_vae_params
+    cfg = SD_VAE
+    P = _bf(synth_vae_params(cfg, 13))
+    x = torch.rand(1, 3, 256, 256, generator=torch.Generator().manual_seed(6)) * 2 - 1
+    post = AutoencoderKL(cfg, P).encode(x.cuda()).latent_dist
+    mean, logvar, _ = R.encode(P, cfg, x)
+    r = _rel(post.mean.cpu(), mean)
+    print(f"sd-vae encode 256px: rel-L2 vs oracle mean {r:.3e} logvar {_rel(post.logvar.cpu(), logvar):.3e}")
+    assert post.mean.shape == (1, 4, 32, 32) and torch.isfinite(post.mean).all() and r < 2e-2, r
+    assert _rel(post.logvar.cpu(), logvar) < 2e-2

@@ -228,3 +228,62 @@ def test_fused_cfg_scheduler_update_equals_generic_path():
             assert torch.allclose(a, b, rtol=2e-5, atol=2e-5), (type(sched).__name__, gs, (a - b).abs().max())
     # guidance_rescale needs the per-sample std -> generic path is taken silently
     pipe(pe, ne, num_inference_steps=2, guidance_scale=7.5, guidance_rescale=0.7, latents=lat0.clone())
+
+
+def test_img2img_loop_matches_oracle_loop():
+    """StableDiffusionImg2ImgPipeline semantics (pipeline_stable_diffusion_img2img.py:616-681, 905-915): encode ->
+    posterior sample * scaling_factor -> add_noise at the first kept timestep -> the last int(steps * strength) steps."""
+    import pytest
+    from oracle import vae_ref as V
+    from paddlemix_amd.vae import AutoencoderKL, synth_vae_params
+    from tests.configs import MINI_VAE
+    cfg = TINY
+    P = synth_unet_params(cfg, seed=1234)
+    Pb = {k: v.to(torch.bfloat16).float() if v.dim() > 1 else v for k, v in P.items()}
+    Pv = synth_vae_params(MINI_VAE, seed=6)
+    Pvb = {k: (v.to(torch.bfloat16).float() if v.dim() > 1 else v) for k, v in Pv.items()}
+    g = torch.Generator().manual_seed(3)
+    pe, ne = torch.randn(2, 7, 64, generator=g), torch.randn(2, 7, 64, generator=g)
+    image = torch.rand(1, 3, 32, 32, generator=g) * 2 - 1       # one image, two prompts: duplicated (:656-666)
+    steps, strength, gs, sf = 10, 0.6, 5.0, MINI_VAE["scaling_factor"]
+    for sched_cls, ref_cls, kw in ((DDIMScheduler, S.DDIMRef, dict(clip_sample=False, set_alpha_to_one=False, **SCHED)),
+                                   (EulerDiscreteScheduler, S.EulerRef, dict(timestep_spacing="leading", **SCHED))):
+        pipe = StableDiffusionDenoiser(UNet2DConditionModel(cfg, P, _test_backend=Emulator()), sched_cls(**kw),
+                                       vae=AutoencoderKL(MINI_VAE, Pv, _test_backend=Emulator()))
+        seen = []
+        out = pipe(pe, ne, num_inference_steps=steps, guidance_scale=gs, image=image, strength=strength,
+                   generator=torch.Generator().manual_seed(11),
+                   callback_on_step_end=lambda p, i, t, kw: (seen.append(float(t)), kw)[1])
+        # oracle: same draws in the same order (posterior noise, then the forward-process noise)
+        gg = torch.Generator().manual_seed(11)
+        n1 = torch.randn(1, 4, 8, 8, generator=gg)
+        n2 = torch.randn(2, 4, 8, 8, generator=gg)
+        _, _, z = V.encode(Pvb, MINI_VAE, image, n1)
+        init = torch.cat([z * sf] * 2).numpy()
+        sch = ref_cls(**kw)
+        sch.set_timesteps(steps)
+        kept = sch.timesteps[steps - int(steps * strength):]
+        assert len(kept) == 6 and seen == [float(t) for t in kept]
+        x = sch.add_noise(init, n2.numpy(), kept[0] if ref_cls is S.DDIMRef else np.repeat(kept[:1], 2))
+        emb = torch.cat([ne, pe])
+        for t in kept:
+            xin = np.concatenate([x, x])
+            if hasattr(sch, "scale_model_input"):
+                xin = sch.scale_model_input(xin, t)
+            eps = U.unet_forward(Pb, cfg, torch.from_numpy(np.asarray(xin, dtype=np.float32)), float(t), emb).numpy()
+            x = sch.step(eps[:2] + gs * (eps[2:] - eps[:2]), t, x)
+        rel = np.linalg.norm(out.numpy() - x) / np.linalg.norm(x)
+        assert out.shape == (2, 4, 8, 8) and rel < 5e-2, (sched_cls.__name__, rel)
+        # the unfused (generic scheduler.step) path walks the same kept steps
+        slow = pipe(pe, ne, num_inference_steps=steps, guidance_scale=gs, image=image, strength=strength,
+                    generator=torch.Generator().manual_seed(11), fused_update=False)
+        assert np.linalg.norm(slow.numpy() - out.numpy()) / np.linalg.norm(out.numpy()) < 2e-2
+    # latents passed as `image` skip the encoder (:635-636); strength bounds and the zero-step case raise
+    lat = torch.randn(2, 4, 8, 8, generator=g)
+    assert pipe(pe, ne, num_inference_steps=4, guidance_scale=gs, image=lat, strength=0.5).shape == (2, 4, 8, 8)
+    with pytest.raises(ValueError):
+        pipe(pe, ne, num_inference_steps=4, image=image, strength=1.5)
+    with pytest.raises(ValueError):
+        pipe(pe, ne, num_inference_steps=4, image=image, strength=0.1)      # int(4 * 0.1) = 0 steps
+    with pytest.raises(ValueError):
+        pipe(pe[:1].repeat(3, 1, 1), ne[:1].repeat(3, 1, 1), num_inference_steps=4, image=torch.cat([image, image]), strength=0.5)
