@@ -395,3 +395,41 @@ class DPMSolverMultistepRef:
             self.lower += 1
         self.idx += 1
         return x.astype(np.float32)
+
+
+class LCMRef:
+    """LCMScheduler (scheduling_lcm.py: schedule :362-464, boundary scalings :468-474, step :513-566), numpy float64 state,
+    epsilon prediction, no clipping. ``step`` takes the re-noising draw explicitly (None on the last step)."""
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                 original_inference_steps=50, set_alpha_to_one=True, timestep_scaling=10.0, **_unused):
+        self.n_train, self.original, self.scaling = num_train_timesteps, original_inference_steps, timestep_scaling
+        if beta_schedule == "scaled_linear":
+            betas = np.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=np.float32) ** 2
+        else:
+            betas = np.linspace(beta_start, beta_end, num_train_timesteps, dtype=np.float32)
+        self.alphas_cumprod = np.cumprod(1.0 - betas, dtype=np.float32)
+        self.final_alpha_cumprod = 1.0 if set_alpha_to_one else float(self.alphas_cumprod[0])
+        self.init_noise_sigma = 1.0
+        self.timesteps = None
+
+    def set_timesteps(self, n, strength=1.0):
+        k = self.n_train // self.original
+        origin = [i * k - 1 for i in range(1, int(self.original * strength) + 1)][::-1]
+        self.timesteps = np.array([origin[int(np.floor(j * len(origin) / n))] for j in range(n)], dtype=np.int64)
+        self._i = 0
+
+    def step(self, eps, t, x, noise=None):
+        t = int(t)
+        last = self._i == len(self.timesteps) - 1
+        prev_t = t if last else int(self.timesteps[self._i + 1])
+        a_t = float(self.alphas_cumprod[t])
+        a_prev = float(self.alphas_cumprod[prev_t]) if prev_t >= 0 else self.final_alpha_cumprod
+        st = t * self.scaling
+        c_skip, c_out = 0.25 / (st * st + 0.25), st / np.sqrt(st * st + 0.25)
+        x0 = (x - np.sqrt(1 - a_t) * eps) / np.sqrt(a_t)
+        denoised = c_out * x0 + c_skip * x
+        self._i += 1
+        if last:
+            return denoised, denoised
+        return np.sqrt(a_prev) * denoised + np.sqrt(1 - a_prev) * noise, denoised

@@ -105,6 +105,20 @@ class StableDiffusionDenoiser:
             raise ValueError(f"Unexpected latents shape, got {tuple(latents.shape)}, expected {shape}")
         return latents * self.scheduler.init_noise_sigma  # pipeline_stable_diffusion.py:581-586
 
+    @staticmethod
+    def get_guidance_scale_embedding(w: torch.Tensor, embedding_dim: int = 512) -> torch.Tensor:
+        """sinusoidal embedding of (guidance_scale - 1) for guidance-distilled UNets (LCM; pipeline_stable_diffusion.py:588-616)
+        -> fp32 [len(w), embedding_dim], the UNet's ``timestep_cond``"""
+        if w.dim() != 1:
+            raise ValueError("w: expected a 1-D tensor of guidance scales")
+        half = embedding_dim // 2
+        freq = torch.exp(torch.arange(half, dtype=torch.float32, device=w.device) * -(np.log(10000.0) / (half - 1)))
+        emb = (w.to(torch.float32) * 1000.0)[:, None] * freq[None, :]
+        emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=1)
+        if embedding_dim % 2 == 1:
+            emb = torch.nn.functional.pad(emb, (0, 1))
+        return emb
+
     def get_timesteps(self, num_inference_steps: int, strength: float):
         """img2img: keep the last ``int(steps * strength)`` steps (pipeline_stable_diffusion_img2img.py:616-623)."""
         init_timestep = min(int(num_inference_steps * strength), num_inference_steps)
@@ -144,11 +158,13 @@ class StableDiffusionDenoiser:
                  negative_prompt_ids: Optional[torch.Tensor] = None, prompt_ids_2: Optional[torch.Tensor] = None,
                  negative_prompt_ids_2: Optional[torch.Tensor] = None, original_size=None,
                  crops_coords_top_left=(0, 0), target_size=None, fused_update: bool = True,
-                 image: Optional[torch.Tensor] = None, strength: float = 0.8):
+                 image: Optional[torch.Tensor] = None, strength: float = 0.8, eta: float = 0.0):
         """``image`` (extension of the text2img call = StableDiffusionImg2ImgPipeline.__call__,
         pipeline_stable_diffusion_img2img.py:735-1010): start from the encoded, re-noised image and run the last
         ``int(num_inference_steps * strength)`` steps."""
-        do_cfg = guidance_scale > 1.0
+        # guidance-distilled UNets (LCM) take the scale as an embedding instead of a doubled batch (:634-635, :846-852)
+        tc_dim = getattr(self.unet.config, "time_cond_proj_dim", None)
+        do_cfg = guidance_scale > 1.0 and tc_dim is None
         if image is not None and (strength < 0 or strength > 1):
             raise ValueError(f"The value of strength should in [0.0, 1.0] but is {strength}")
         if prompt_embeds is None:
@@ -194,7 +210,18 @@ class StableDiffusionDenoiser:
             latents = self.prepare_image_latents(image, timesteps[:1], B, generator)
         else:
             latents = self.prepare_latents(B, cfg.in_channels, h, w, torch.float32, generator, latents, prompt_embeds.device)
-        fused = self._fused_plan(guidance_rescale, latents.device) if fused_update else None
+        import inspect
+        step_params = inspect.signature(self.scheduler.step).parameters   # prepare_extra_step_kwargs (:520-535)
+        extra = {}
+        if "eta" in step_params:
+            extra["eta"] = eta
+        if "generator" in step_params:
+            extra["generator"] = generator
+        unet_kw = {}
+        if tc_dim is not None:
+            w = torch.full((B,), float(guidance_scale) - 1.0, device=latents.device)
+            unet_kw["timestep_cond"] = self.get_guidance_scale_embedding(w, embedding_dim=tc_dim)
+        fused = self._fused_plan(guidance_rescale, latents.device) if fused_update and not eta else None
         for i, t in enumerate(timesteps, start=first):
             latent_model_input = torch.cat([latents] * 2) if do_cfg else latents
             if fused is not None:
@@ -202,7 +229,7 @@ class StableDiffusionDenoiser:
                 # epsilon-prediction step of Euler / DDIM(eta=0) is prev = a*x + b*eps with per-step (a, b) kept in HBM
                 scales, coef, lib, stream = fused
                 noise_pred = self.unet(latent_model_input * scales[i], t, encoder_hidden_states=prompt_embeds,
-                                       added_cond_kwargs=added_cond_kwargs, return_dict=False)[0]
+                                       added_cond_kwargs=added_cond_kwargs, return_dict=False, **unet_kw)[0]
                 lat = latents.contiguous()
                 out = torch.empty_like(lat)
                 n, cp = lat.numel(), coef.data_ptr() + 8 * i
@@ -221,13 +248,13 @@ class StableDiffusionDenoiser:
                 continue
             latent_model_input = self.scheduler.scale_model_input(latent_model_input, t)
             noise_pred = self.unet(latent_model_input, t, encoder_hidden_states=prompt_embeds,
-                                   added_cond_kwargs=added_cond_kwargs, return_dict=False)[0]
+                                   added_cond_kwargs=added_cond_kwargs, return_dict=False, **unet_kw)[0]
             if do_cfg:
                 noise_uncond, noise_text = noise_pred.chunk(2)
                 noise_pred = noise_uncond + guidance_scale * (noise_text - noise_uncond)
                 if guidance_rescale > 0.0:
                     noise_pred = rescale_noise_cfg(noise_pred, noise_text, guidance_rescale)
-            latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
+            latents = self.scheduler.step(noise_pred, t, latents, return_dict=False, **extra)[0]
             if callback_on_step_end is not None:
                 out = callback_on_step_end(self, i, t, {"latents": latents})
                 latents = out.pop("latents", latents)

@@ -7,6 +7,7 @@ Mirrors the reference classes' public contract -- ``set_timesteps`` / ``scale_mo
   FlowMatchEulerDiscreteScheduler    scheduling_flow_match_euler_discrete.py:44 (step :187-283)
   PNDMScheduler                      scheduling_pndm.py:69 (set_timesteps :178-235, step_prk :260-320, step_plms :322-395)
   DPMSolverMultistepScheduler        scheduling_dpmsolver_multistep.py:66 (deterministic variants, orders 1-2; step :802-878)
+  LCMScheduler                       scheduling_lcm.py:140 (set_timesteps :330-466, step :476-566) -- 2-8 step latent-consistency sampling
 Schedule tables are float32 numpy like the reference's float32 tensors; ``step`` works on torch tensors of any device.
 
 For deterministic sampling every ``step`` is a linear map  prev = a*sample + b*model_output ; ``step_coefficients``
@@ -567,3 +568,126 @@ class FlowMatchEulerDiscreteScheduler:
         prev = (sample.to(torch.float32) + (s_next - s) * model_output.to(torch.float32)).to(model_output.dtype)
         self._step_index += 1
         return _out(prev, return_dict)
+
+
+class LCMScheduler:
+    """Multistep consistency sampling for latent-consistency models / LCM-LoRA (scheduling_lcm.py:140-631): the schedule is a
+    subset of the ``original_inference_steps`` distillation schedule, each step predicts x0, applies the boundary-condition
+    scalings (c_skip, c_out) and -- except on the last step -- re-noises to the next timestep with fresh noise."""
+    order = 1
+
+    def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.00085, beta_end: float = 0.012,
+                 beta_schedule: str = "scaled_linear", original_inference_steps: int = 50, clip_sample: bool = False,
+                 clip_sample_range: float = 1.0, set_alpha_to_one: bool = True, steps_offset: int = 0,
+                 prediction_type: str = "epsilon", timestep_spacing: str = "leading", timestep_scaling: float = 10.0):
+        self.config = SimpleNamespace(**{k: v for k, v in locals().items() if k != "self"})
+        betas = _make_betas(num_train_timesteps, beta_start, beta_end, beta_schedule)
+        self.alphas_cumprod = np.cumprod(1.0 - betas, dtype=np.float32)
+        self.final_alpha_cumprod = np.float32(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self.init_noise_sigma = 1.0
+        self.num_inference_steps = None
+        self.timesteps = np.arange(0, num_train_timesteps)[::-1].copy().astype(np.int64)
+        self.custom_timesteps = False
+        self._step_index: Optional[int] = None
+
+    @property
+    def step_index(self):
+        return self._step_index
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def set_timesteps(self, num_inference_steps: Optional[int] = None, original_inference_steps: Optional[int] = None,
+                      timesteps=None, strength: float = 1.0):
+        c = self.config
+        if num_inference_steps is None and timesteps is None:
+            raise ValueError("Must pass exactly one of `num_inference_steps` or `custom_timesteps`.")
+        if num_inference_steps is not None and timesteps is not None:
+            raise ValueError("Can only pass one of `num_inference_steps` or `custom_timesteps`.")
+        original_steps = original_inference_steps if original_inference_steps is not None else c.original_inference_steps
+        if original_steps > c.num_train_timesteps:
+            raise ValueError(f"`original_steps`: {original_steps} cannot be larger than `self.config.train_timesteps`: "
+                             f"{c.num_train_timesteps}")
+        k = c.num_train_timesteps // original_steps                        # the paper's skipping step
+        origin = np.arange(1, int(original_steps * strength) + 1) * k - 1    # distillation schedule, ascending
+        if timesteps is not None:
+            ts = np.array(timesteps, dtype=np.int64)
+            if np.any(ts[1:] >= ts[:-1]):
+                raise ValueError("`custom_timesteps` must be in descending order.")
+            if ts[0] >= c.num_train_timesteps:
+                raise ValueError(f"`timesteps` must start before `self.config.train_timesteps`: {c.num_train_timesteps}.")
+            self.num_inference_steps, self.custom_timesteps = len(ts), True
+            init = min(int(self.num_inference_steps * strength), self.num_inference_steps)
+            ts = ts[max(self.num_inference_steps - init, 0) * self.order:]
+        else:
+            if num_inference_steps > c.num_train_timesteps:
+                raise ValueError(f"`num_inference_steps`: {num_inference_steps} cannot be larger than "
+                                 f"`self.config.train_timesteps`: {c.num_train_timesteps}")
+            if len(origin) // num_inference_steps < 1:
+                raise ValueError(f"The combination of `original_steps x strength`: {original_steps} x {strength} is smaller "
+                                 f"than `num_inference_steps`: {num_inference_steps}.")
+            if num_inference_steps > original_steps:
+                raise ValueError(f"`num_inference_steps`: {num_inference_steps} cannot be larger than "
+                                 f"`original_inference_steps`: {original_steps}")
+            self.num_inference_steps, self.custom_timesteps = num_inference_steps, False
+            rev = origin[::-1]
+            idx = np.floor(np.linspace(0, len(rev), num=num_inference_steps, endpoint=False)).astype(np.int64)
+            ts = rev[idx]
+        self.timesteps = ts.astype(np.int64)
+        self._step_index = None
+
+    def _init_step_index(self, timestep):
+        idx = np.nonzero(self.timesteps == int(timestep))[0]
+        self._step_index = int(idx[1] if len(idx) > 1 else idx[0])
+
+    def get_scalings_for_boundary_condition_discrete(self, timestep):
+        sigma_data = 0.5
+        st = float(timestep) * self.config.timestep_scaling
+        return sigma_data ** 2 / (st ** 2 + sigma_data ** 2), st / (st ** 2 + sigma_data ** 2) ** 0.5
+
+    def step(self, model_output, timestep, sample, generator=None, return_dict: bool = True, *, noise=None):
+        """-> prev_sample (and ``denoised``, the x0 estimate the LCM pipeline decodes). ``noise`` (extension): the re-noising
+        draw, otherwise ``torch.randn`` from ``generator``."""
+        if self.num_inference_steps is None:
+            raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating "
+                             "the scheduler")
+        if self._step_index is None:
+            self._init_step_index(timestep)
+        c, t = self.config, int(timestep)
+        nxt = self._step_index + 1
+        prev_t = int(self.timesteps[nxt]) if nxt < len(self.timesteps) else t
+        a_t = float(self.alphas_cumprod[t])
+        a_prev = float(self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod)
+        c_skip, c_out = self.get_scalings_for_boundary_condition_discrete(t)
+        if c.prediction_type == "epsilon":
+            x0 = (sample - (1 - a_t) ** 0.5 * model_output) / a_t ** 0.5
+        elif c.prediction_type == "sample":
+            x0 = model_output
+        elif c.prediction_type == "v_prediction":
+            x0 = a_t ** 0.5 * sample - (1 - a_t) ** 0.5 * model_output
+        else:
+            raise ValueError(f"prediction_type given as {c.prediction_type} must be one of `epsilon`, `sample` or "
+                             "`v_prediction` for `LCMScheduler`.")
+        if c.clip_sample:
+            x0 = x0.clamp(-c.clip_sample_range, c.clip_sample_range)
+        denoised = c_out * x0 + c_skip * sample
+        if self._step_index != self.num_inference_steps - 1:
+            if noise is None:
+                noise = torch.randn(model_output.shape, generator=generator, device=model_output.device,
+                                    dtype=denoised.dtype)
+            prev = a_prev ** 0.5 * denoised + (1 - a_prev) ** 0.5 * noise
+        else:
+            prev = denoised
+        self._step_index += 1
+        if not return_dict:
+            return (prev, denoised)
+        return SimpleNamespace(prev_sample=prev, denoised=denoised)
+
+    def add_noise(self, original_samples, noise, timesteps):
+        a = torch.as_tensor(self.alphas_cumprod)[torch.as_tensor(timesteps).long().cpu()].to(original_samples.device)
+        while a.dim() < original_samples.dim():
+            a = a.unsqueeze(-1)
+        return a ** 0.5 * original_samples + (1 - a) ** 0.5 * noise
+
+    def __len__(self):
+        return self.config.num_train_timesteps

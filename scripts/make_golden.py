@@ -56,7 +56,8 @@ def loop_sums(fname):
 def main():
     data = dict(note="literals asserted by the reference's own tests (no Paddle RNG involved); harvested by scripts/make_golden.py",
                 sinusoid=sinusoid_slices(), ddim=loop_sums("test_scheduler_ddim.py"), euler=loop_sums("test_scheduler_euler.py"),
-                pndm=loop_sums("test_scheduler_pndm.py"), dpm_multi=loop_sums("test_scheduler_dpm_multi.py"))
+                pndm=loop_sums("test_scheduler_pndm.py"), dpm_multi=loop_sums("test_scheduler_dpm_multi.py"),
+                lcm=loop_sums("test_scheduler_lcm.py"))
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     with open(OUT, "w") as f:
         json.dump(data, f, indent=1, sort_keys=True)

@@ -287,3 +287,51 @@ def test_img2img_loop_matches_oracle_loop():
         pipe(pe, ne, num_inference_steps=4, image=image, strength=0.1)      # int(4 * 0.1) = 0 steps
     with pytest.raises(ValueError):
         pipe(pe[:1].repeat(3, 1, 1), ne[:1].repeat(3, 1, 1), num_inference_steps=4, image=torch.cat([image, image]), strength=0.5)
+
+
+def test_lcm_loop_matches_oracle_loop():
+    """Latent-consistency sampling through the SD loop: a guidance-distilled UNet (time_cond_proj_dim) takes the scale as
+    ``timestep_cond = get_guidance_scale_embedding(guidance_scale - 1)`` instead of a doubled batch
+    (pipeline_stable_diffusion.py:588-616, 634-635, 846-852) and LCMScheduler re-noises between its 4 steps with the
+    pipeline's generator (scheduling_lcm.py:545-552)."""
+    from paddlemix_amd.schedulers import LCMScheduler
+    cfg = dict(TINY, time_cond_proj_dim=32)
+    P = synth_unet_params(cfg, seed=1234)
+    Pb = {k: v.to(torch.bfloat16).float() if v.dim() > 1 else v for k, v in P.items()}
+    g = torch.Generator().manual_seed(0)
+    pe = torch.randn(2, 7, 64, generator=g)
+    lat0 = torch.randn(2, 4, 8, 8, generator=g)
+    steps, gs = 4, 8.0
+    kw = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear")
+    pipe = StableDiffusionDenoiser(UNet2DConditionModel(cfg, P, _test_backend=Emulator()), LCMScheduler(**kw))
+    # the embedding itself: sin | cos of 1000 * w over the 10000^(-i / (half - 1)) frequencies
+    emb = pipe.get_guidance_scale_embedding(torch.tensor([gs - 1.0, 0.0]), embedding_dim=32)
+    f = np.exp(-np.log(10000.0) * np.arange(16) / 15)
+    want = np.concatenate([np.sin(7000.0 * f), np.cos(7000.0 * f)])
+    assert emb.shape == (2, 32) and np.abs(emb[0].numpy() - want).max() < 2e-3     # fp32 sin/cos of arguments up to 7000
+    assert torch.equal(emb[1], torch.cat([torch.zeros(16), torch.ones(16)]))
+    assert pipe.get_guidance_scale_embedding(torch.tensor([1.0]), embedding_dim=33).shape == (1, 33)
+    seen = []
+    out = pipe(pe, num_inference_steps=steps, guidance_scale=gs, latents=lat0.clone(),
+               generator=torch.Generator().manual_seed(21),
+               callback_on_step_end=lambda p, i, t, kw: (seen.append(int(t)), kw)[1])
+    sch = S.LCMRef(**kw)
+    sch.set_timesteps(steps)
+    gg = torch.Generator().manual_seed(21)
+    x = lat0.numpy().astype(np.float64)
+    tc = torch.from_numpy(np.tile(want, (2, 1)).astype(np.float32))
+    for i, t in enumerate(sch.timesteps):
+        eps = U.unet_forward(Pb, cfg, torch.from_numpy(x.astype(np.float32)), int(t), pe, timestep_cond=tc).numpy()
+        nz = None if i == steps - 1 else torch.randn(lat0.shape, generator=gg).numpy()
+        x, _ = sch.step(eps, t, x, nz)
+    assert seen == [999, 759, 499, 259]
+    rel = np.linalg.norm(out.numpy() - x) / np.linalg.norm(x)
+    assert rel < 3e-2, rel
+    # DDIM eta > 0 goes through the generic step with the pipeline's generator (prepare_extra_step_kwargs, :520-535)
+    cfg0 = TINY
+    pipe0 = StableDiffusionDenoiser(UNet2DConditionModel(cfg0, synth_unet_params(cfg0, seed=1234), _test_backend=Emulator()),
+                                    DDIMScheduler(clip_sample=False, set_alpha_to_one=False, **SCHED))
+    a = pipe0(pe, num_inference_steps=3, guidance_scale=1.0, latents=lat0.clone(), eta=1.0, generator=torch.Generator().manual_seed(2))
+    b = pipe0(pe, num_inference_steps=3, guidance_scale=1.0, latents=lat0.clone(), eta=1.0, generator=torch.Generator().manual_seed(2))
+    c = pipe0(pe, num_inference_steps=3, guidance_scale=1.0, latents=lat0.clone())
+    assert torch.equal(a, b) and not torch.allclose(a, c)

@@ -214,3 +214,62 @@ def test_dpm_multistep_golden_and_oracle():
         DPMSolverMultistepScheduler(algorithm_type="sde-dpmsolver++")
     with pytest.raises(NotImplementedError):
         DPMSolverMultistepScheduler(solver_order=3)
+
+
+def test_lcm_golden_and_oracle():
+    """LCMScheduler: the reference's one-step full loop is RNG-free (no re-noising on the last step) and pins product and
+    oracle (test_scheduler_lcm.py:239-247, via tests/golden/); the multistep loop is checked product-vs-oracle with the
+    re-noising draws supplied (the reference's multistep known answer needs Paddle's generator)."""
+    import json
+    import os
+    from paddlemix_amd.schedulers import LCMScheduler
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_known_answers.json")) as f:
+        gold = json.load(f)["lcm"]["tests"]
+    cfg = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.0120, beta_schedule="scaled_linear",
+               prediction_type="epsilon")
+    one = gold["test_full_loop_onestep"]
+    sch, ref = LCMScheduler(**cfg), S.LCMRef(**cfg)
+    sch.set_timesteps(1)
+    ref.set_timesteps(1)
+    assert list(sch.timesteps) == [999] == list(ref.timesteps)
+    x = dummy_sample_deter()
+    out = sch.step(dummy_model(x, 999), 999, x)
+    assert torch.equal(out.prev_sample, out.denoised)
+    assert abs(out.prev_sample.abs().sum().item() - one["sum"]["value"]) < one["sum"]["tol"]
+    assert abs(out.prev_sample.abs().mean().item() - one["mean"]["value"]) < one["mean"]["tol"]
+    r, _ = ref.step(dummy_model(x, 999).numpy().astype(np.float64), 999, x.numpy().astype(np.float64))
+    assert abs(np.abs(r).sum() - one["sum"]["value"]) < one["sum"]["tol"]
+    # schedules: subsets of the 50-step distillation schedule (scheduling_lcm.py:376-379, 458-462)
+    for n, want in ((4, [999, 759, 499, 259]), (10, [999, 899, 799, 699, 599, 499, 399, 299, 199, 99]), (2, [999, 499])):
+        sch.set_timesteps(n)
+        ref.set_timesteps(n)
+        assert list(sch.timesteps) == want == list(ref.timesteps)
+    sch.set_timesteps(4, strength=0.5)                       # img2img: the schedule is built on original_steps * strength
+    assert list(sch.timesteps) == [499, 379, 259, 139]            # indices floor([0, 6.25, 12.5, 18.75]) of 499, 479, ... 19
+    sch.set_timesteps(timesteps=[999, 499, 259])
+    assert list(sch.timesteps) == [999, 499, 259] and sch.custom_timesteps
+    with pytest.raises(ValueError):
+        sch.set_timesteps(timesteps=[499, 999])
+    with pytest.raises(ValueError):
+        sch.set_timesteps(60)                                # more steps than the distillation schedule has
+    with pytest.raises(ValueError):
+        sch.set_timesteps(4, timesteps=[999])
+    # multistep: same draws -> same trajectory as the float64 oracle
+    g = torch.Generator().manual_seed(0)
+    sch.set_timesteps(10)
+    ref.set_timesteps(10)
+    x, xr = dummy_sample_deter(), dummy_sample_deter().numpy().astype(np.float64)
+    for i, t in enumerate(sch.timesteps):
+        nz = torch.randn(x.shape, generator=g)
+        out = sch.step(dummy_model(x, t), t, x, noise=nz)
+        xr, den = ref.step(dummy_model(torch.from_numpy(xr), t).numpy(), t, xr, None if i == 9 else nz.numpy().astype(np.float64))
+        x = out.prev_sample
+        assert np.abs(out.denoised.numpy() - den).max() < 1e-4
+    assert np.abs(x.numpy() - xr).max() < 1e-4
+    # the generator path draws the same noise as an explicit torch.randn with that generator
+    sch.set_timesteps(2)
+    a = sch.step(dummy_model(x, 999), 999, x, generator=torch.Generator().manual_seed(5), return_dict=False)[0]
+    sch.set_timesteps(2)
+    b = sch.step(dummy_model(x, 999), 999, x, noise=torch.randn(x.shape, generator=torch.Generator().manual_seed(5))).prev_sample
+    assert torch.equal(a, b)
+    assert sch.add_noise(x, torch.ones_like(x), torch.tensor([999])).shape == x.shape
