@@ -4,7 +4,9 @@ denoising loop, VAE decode), 512x512, batch 1, 50 steps, after a warm-up call. R
 architectures (no checkpoints offline), synthetic token ids. ORIENTATION ONLY next to BASELINE.md section 1 (other
 hardware, other metric than bench.py's); never used as `vs_baseline`.
 
-  python scripts/e2e_bench.py [--model sd15|sdxl|sd3] [--calls 5] [--steps 50] [--side 512]
+  python scripts/e2e_bench.py [--model sd15|sdxl|sd3|dit|lcm] [--img2img] [--calls 5] [--steps 50] [--side 512]
+(lcm: the SD-1.5 UNet with the guidance embedding of LCM-distilled checkpoints, LCMScheduler, 4 steps, no doubled batch;
+--img2img: VAE encode -> re-noise -> the last 75 % of the steps, pipeline_stable_diffusion_img2img.py)
 (sd3: the reference quotes seconds per image, ppdiffusers/deploy/sd3/README.md:27-31: 1.2 s Paddle-Inference on A100-40G)
 """
 import argparse
@@ -18,15 +20,16 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from paddlemix_amd.clip import CLIPTextModel, CLIPTextModelWithProjection, synth_clip_params  # noqa: E402
 from paddlemix_amd.pipeline import StableDiffusionDenoiser  # noqa: E402
-from paddlemix_amd.schedulers import DDIMScheduler, EulerDiscreteScheduler  # noqa: E402
+from paddlemix_amd.schedulers import DDIMScheduler, EulerDiscreteScheduler, LCMScheduler  # noqa: E402
 from paddlemix_amd.unet import UNet2DConditionModel, synth_unet_params  # noqa: E402
-from paddlemix_amd.vae import AutoencoderKL, synth_decoder_params  # noqa: E402
+from paddlemix_amd.vae import AutoencoderKL, synth_decoder_params, synth_vae_params  # noqa: E402
 from tests.configs import CLIP_BIGG, CLIP_L, SD15, SD_VAE, SDXL  # noqa: E402
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--model", default="sd15", choices=["sd15", "sdxl", "sd3", "dit"])
+    ap.add_argument("--model", default="sd15", choices=["sd15", "sdxl", "sd3", "dit", "lcm"])
+    ap.add_argument("--img2img", action="store_true", help="sd15 / sdxl / lcm: start from an encoded image, strength 0.75")
     ap.add_argument("--act-dtype", default="bf16", choices=["bf16", "fp8"], help="sd3 only: W8A8 block GEMMs")
     ap.add_argument("--calls", type=int, default=5)
     ap.add_argument("--steps", type=int, default=50)
@@ -39,10 +42,13 @@ def main():
     if a.model == "dit":
         return dit(a, dev)
     xl = a.model == "sdxl"
-    ucfg = SDXL if xl else SD15
+    lcm = a.model == "lcm"
+    ucfg = SDXL if xl else (dict(SD15, time_cond_proj_dim=256) if lcm else SD15)
+    if lcm and a.steps == 50:
+        a.steps = 4
     unet = UNet2DConditionModel(ucfg, synth_unet_params(ucfg, seed=1, device=dev), device=dev)
     vcfg = dict(SD_VAE, scaling_factor=0.13025) if xl else SD_VAE
-    vae = AutoencoderKL(vcfg, synth_decoder_params(vcfg, seed=2, device=dev), device=dev)
+    vae = AutoencoderKL(vcfg, (synth_vae_params if a.img2img else synth_decoder_params)(vcfg, seed=2, device=dev), device=dev)
     te = CLIPTextModel(CLIP_L, synth_clip_params(CLIP_L, seed=3, device=dev), device=dev)
     te2 = None
     if xl:
@@ -50,6 +56,8 @@ def main():
         te2 = CLIPTextModelWithProjection(c2, synth_clip_params(c2, seed=4, device=dev), device=dev)
         sched = EulerDiscreteScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
                                        timestep_spacing="leading", steps_offset=1)
+    elif lcm:
+        sched = LCMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear")
     else:
         sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
                               set_alpha_to_one=False, steps_offset=1)
@@ -63,6 +71,11 @@ def main():
               guidance_scale=7.5, output_type="pt", generator=g)
     if xl:
         kw.update(prompt_ids_2=ids, negative_prompt_ids_2=neg, guidance_scale=5.0)
+    if lcm:
+        kw.update(guidance_scale=8.0)
+    if a.img2img:
+        kw.update(image=torch.rand(1, 3, a.side, a.side, generator=g, device=dev) * 2 - 1, strength=0.75)
+    ran = int(a.steps * 0.75) if a.img2img else a.steps
     img = pipe(**kw)   # warm-up call (plans, graphs)
     torch.cuda.synchronize()
     ts = []
@@ -73,9 +86,10 @@ def main():
         ts.append(time.perf_counter() - t0)
     img = img[0] if isinstance(img, (tuple, list)) else getattr(img, "images", img)
     mean = sum(ts) / len(ts)
-    print(json.dumps({"what": f"{a.model} text2img end to end, {a.side}x{a.side}, bs 1, {a.steps} steps, CFG, "
-                              f"{'2 CLIP' if xl else 'CLIP'} + UNet + VAE decode, random-init weights",
-                      "it_per_s": a.steps / mean, "s_per_image": mean, "calls": a.calls,
+    print(json.dumps({"what": f"{a.model} {'img2img (strength 0.75)' if a.img2img else 'text2img'} end to end, {a.side}x{a.side}, bs 1, "
+                              f"{ran} UNet steps, {'guidance embedding (no doubled batch)' if lcm else 'CFG'}, "
+                              f"{'2 CLIP' if xl else 'CLIP'} + {'VAE encode + ' if a.img2img else ''}UNet + VAE decode, random-init weights",
+                      "it_per_s": ran / mean, "s_per_image": mean, "calls": a.calls,
                       "image_shape": list(img.shape), "finite": bool(torch.isfinite(img.float()).all()),
                       "orientation": "reference deploy README: SD15 47.22 / SDXL 31.98 it/s on A100-80G TensorRT fp16 "
                                      "(ppdiffusers/deploy/README.md:44,47); not the same hardware or weights"}))
