@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MI355X_SD_ABI_VERSION 7
+#define MI355X_SD_ABI_VERSION 8
 #define MI355X_SD_OK 0
 #define MI355X_SD_ERR_INVALID 1      /* bad argument (shape <= 0, null pointer ...)          */
 #define MI355X_SD_ERR_UNSUPPORTED 2  /* well-formed but outside the implemented configurations */
@@ -156,6 +156,14 @@ int mi355x_sd_sdpa(const void* q, const void* k, const void* v, const float* bia
                    int B, int H, int Sq, int Skv, int D,
                    int64_t q_bs, int q_ts, int64_t k_bs, int k_ts, int64_t v_bs, int v_ts, int64_t o_bs, int o_ts,
                    int64_t bias_bs, int64_t bias_hs, int64_t bias_qs, float scale, void* stream);
+
+/* out += out_scale * softmax(q k^T * scale + bias) v  -- same layouts as mi355x_sd_sdpa, `out` already holding the result of
+ * a first attention over another key set. IPAdapterAttnProcessor.__call__ (PPD/models/attention_processor.py:1819-1901):
+ * hidden = attn(q, to_k(text), to_v(text)) + self.scale * attn(q, to_k_ip(image tokens), to_v_ip(image tokens)) (:1871-1886). */
+int mi355x_sd_sdpa_accum(const void* q, const void* k, const void* v, const float* bias, void* out,
+                   int B, int H, int Sq, int Skv, int D,
+                   int64_t q_bs, int q_ts, int64_t k_bs, int k_ts, int64_t v_bs, int v_ts, int64_t o_bs, int o_ts,
+                   int64_t bias_bs, int64_t bias_hs, int64_t bias_qs, float scale, float out_scale, void* stream);
 
 /* GroupNorm statistics -> scale_shift[B][2][C] fp32 (scale = gamma*rstd, shift = beta - mean*scale); x is
  * [B][HW][ldx>=C].  `workspace` needs mi355x_sd_groupnorm_workspace_floats(B,HW,C) floats.

@@ -62,10 +62,13 @@ UNET_DEFAULTS = dict(
     time_cond_proj_dim=None,
     num_class_embeds=None,
     class_embeddings_concat=False,
+    encoder_hid_dim=None,
+    encoder_hid_dim_type=None,
+    ip_adapter_num_tokens=4,       # not a reference config field: ImageProjection's num_image_text_embeds, which the reference
+                                   # reads off the IP-Adapter checkpoint (loaders/unet.py _load_ip_adapter_weights)
 )
 
 _UNSUPPORTED_IF_SET = (
-    "encoder_hid_dim", "encoder_hid_dim_type",
     "time_embedding_dim", "time_embedding_act_fn", "timestep_post_act",
     "cross_attention_norm", "dual_cross_attention", "resnet_skip_time_act",
 )
@@ -80,6 +83,10 @@ def normalize_config(config: dict) -> dict:
     for k in _UNSUPPORTED_IF_SET:
         if cfg.get(k) not in (None, False):
             raise NotImplementedError(f"oracle: config field {k}={cfg[k]!r} is outside the restated hot path")
+    if cfg["encoder_hid_dim_type"] not in (None, "ip_image_proj"):
+        raise NotImplementedError(f"oracle: encoder_hid_dim_type={cfg['encoder_hid_dim_type']!r}")
+    if cfg["encoder_hid_dim_type"] is not None and cfg["encoder_hid_dim"] is None:
+        raise ValueError(f"`encoder_hid_dim` has to be defined when `encoder_hid_dim_type` is set to {cfg['encoder_hid_dim_type']}.")
     if cfg["time_embedding_type"] != "positional" or cfg["resnet_time_scale_shift"] != "default":
         raise NotImplementedError("oracle: only positional time embedding / default resnet time shift restated")
     if cfg["act_fn"] not in ("silu", "swish"):
@@ -225,7 +232,15 @@ def prepare_attention_mask(mask: Optional[Tensor], target_length: int, batch_siz
     return mask.reshape(batch_size, heads, -1, mask.shape[-1])
 
 
-def attention(P: Params, name: str, hidden: Tensor, heads: int, encoder_hidden: Optional[Tensor] = None,
+class EncWithIP:
+    """encoder_hidden_states with IP-Adapter image tokens appended (unet_2d_condition.py:1054-1061): what the
+    IPAdapterAttnProcessor of every cross-attention splits again (attention_processor.py:1857-1862)."""
+
+    def __init__(self, hidden: Tensor, num_tokens: int, scale: float):
+        self.hidden, self.num_tokens, self.scale = hidden, num_tokens, scale
+
+
+def attention(P: Params, name: str, hidden: Tensor, heads: int, encoder_hidden=None,
               attention_mask: Optional[Tensor] = None, processor: str = "math") -> Tensor:
     """Attention.forward through AttnProcessor.__call__ (attention_processor.py:673-735) for the
     3-D input / no group_norm / no norm_cross / residual_connection=False / rescale=1 case.
@@ -236,6 +251,11 @@ def attention(P: Params, name: str, hidden: Tensor, heads: int, encoder_hidden: 
     (tests/models/test_modeling_common.py:197-256).
     """
     B, Sq, _ = hidden.shape
+    ip = None
+    if isinstance(encoder_hidden, EncWithIP):           # IPAdapterAttnProcessor.__call__ (attention_processor.py:1819-1901)
+        ip = encoder_hidden
+        end = ip.hidden.shape[1] - ip.num_tokens
+        encoder_hidden, ip_tokens = ip.hidden[:, :end], ip.hidden[:, end:]
     ctx = hidden if encoder_hidden is None else encoder_hidden
     Skv = ctx.shape[1]
     q = linear(P, name + ".to_q", hidden)
@@ -259,6 +279,12 @@ def attention(P: Params, name: str, hidden: Tensor, heads: int, encoder_hidden: 
                       attn_mask=mask4, scale=scale).reshape(B, Sq, inner)
     else:
         raise ValueError(processor)
+    if ip is not None:                                   # + scale * softmax(q k_ip^T) v_ip, no mask (:1876-1886)
+        ki = (ip_tokens @ P[name + ".processor.to_k_ip.weight"]).reshape(B, -1, heads, d).permute(0, 2, 1, 3)
+        vi = (ip_tokens @ P[name + ".processor.to_v_ip.weight"]).reshape(B, -1, heads, d).permute(0, 2, 1, 3)
+        qh = q.reshape(B, Sq, heads, d).permute(0, 2, 1, 3)
+        pi = torch.softmax((qh @ ki.transpose(-1, -2)) * scale, dim=-1)
+        o = o + ip.scale * (pi @ vi).permute(0, 2, 1, 3).reshape(B, Sq, inner)
     return linear(P, name + ".to_out.0", o)
 
 
@@ -349,7 +375,7 @@ def unet_forward(P: Params, config: dict, sample: Tensor, timestep, encoder_hidd
                  encoder_attention_mask: Optional[Tensor] = None, processor: str = "math",
                  taps: Optional[dict] = None, down_block_additional_residuals=None,
                  mid_block_additional_residual: Optional[Tensor] = None, class_labels=None,
-                 timestep_cond: Optional[Tensor] = None) -> Tensor:
+                 timestep_cond: Optional[Tensor] = None, ip_adapter_scale: float = 1.0) -> Tensor:
     """Returns the noise prediction [B, out_channels, H, W] (the ``(sample,)`` tuple's first element).
 
     ``taps``: optional dict that receives named intermediate activations (for layer-wise parity tests).
@@ -399,6 +425,16 @@ def unet_forward(P: Params, config: dict, sample: Tensor, timestep, encoder_hidd
         taps["emb"] = emb
 
     enc = encoder_hidden_states.to(dtype)
+    if cfg["encoder_hid_dim_type"] == "ip_image_proj":   # ImageProjection (embeddings.py:507-527) + concat (:1054-1061)
+        if not added_cond_kwargs or "image_embeds" not in added_cond_kwargs:
+            raise ValueError("UNet2DConditionModel has the config param `encoder_hid_dim_type` set to 'ip_image_proj' which "
+                             "requires the keyword argument `image_embeds` to be passed in  `added_conditions`")
+        if encoder_attention_mask is not None:
+            raise NotImplementedError("oracle: encoder_attention_mask together with IP-Adapter tokens")
+        T = cfg["ip_adapter_num_tokens"]
+        img = linear(P, "encoder_hid_proj.image_embeds", added_cond_kwargs["image_embeds"].to(dtype))
+        img = layer_norm(P, "encoder_hid_proj.norm", img.reshape(B, T, enc.shape[-1]))
+        enc = EncWithIP(torch.cat([enc, img], dim=1), T, ip_adapter_scale)
     x = conv2d(P, "conv_in", sample)
     if taps is not None:
         taps["conv_in"] = x
@@ -504,11 +540,16 @@ def unet_param_shapes(config: dict) -> Dict[str, tuple]:
         if cin != cout:
             conv(name + ".conv_shortcut", cin, cout, 1)
 
+    ip = cfg["encoder_hid_dim_type"] == "ip_image_proj"
+
     def attn(name, dim, cross):
         lin(name + ".to_q", dim, dim, bias=False)
         lin(name + ".to_k", cross, dim, bias=False)
         lin(name + ".to_v", cross, dim, bias=False)
         lin(name + ".to_out.0", dim, dim)
+        if ip and name.endswith(".attn2"):             # IPAdapterAttnProcessor sublayer (attention_processor.py:1816-1817)
+            lin(name + ".processor.to_k_ip", cross, dim, bias=False)
+            lin(name + ".processor.to_v_ip", cross, dim, bias=False)
 
     def transformer(name, c, layers, cross):
         norm(name + ".norm", c)
@@ -578,6 +619,10 @@ def unet_param_shapes(config: dict) -> Dict[str, tuple]:
 
     norm("conv_norm_out", boc[0])
     conv("conv_out", boc[0], cfg["out_channels"], 3)
+    if ip:   # ImageProjection (embeddings.py:507-518); listed last so the other parameters keep their synthetic draws
+        dx = cfg["cross_attention_dim"][0]
+        lin("encoder_hid_proj.image_embeds", cfg["encoder_hid_dim"], cfg["ip_adapter_num_tokens"] * dx)
+        norm("encoder_hid_proj.norm", dx)
     return S
 
 

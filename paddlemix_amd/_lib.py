@@ -17,7 +17,7 @@ if ELEM_NAME not in _BUILDS:
     raise ValueError(f"MI355X_SD_DTYPE must be one of {sorted(_BUILDS)}, got {ELEM_NAME!r}")
 LIB_PATH = os.path.join(_HERE, _BUILDS[ELEM_NAME][0])
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 GEGLU, OUT_F32, SILU, GELU_TANH, PAD_BR = 1, 2, 4, 8, 16
 
 # name -> (restype, argtypes); must list every symbol include/mi355x_sd.h declares (tests/test_abi.py checks)
@@ -51,6 +51,9 @@ SIGNATURES = {
     "mi355x_sd_sdpa": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                c_int64, c_int, c_int64, c_int, c_int64, c_int, c_int64, c_int, c_int64, c_int64,
                                c_int64, c_float, c_void_p]),
+    "mi355x_sd_sdpa_accum": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                     c_int64, c_int, c_int64, c_int, c_int64, c_int, c_int64, c_int, c_int64, c_int64,
+                                     c_int64, c_float, c_float, c_void_p]),
     "mi355x_sd_groupnorm_workspace_floats": (c_int, [c_int, c_int, c_int]),
     "mi355x_sd_groupnorm_stats": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_void_p]),

@@ -292,8 +292,16 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_ker
         for (int c = 0; c < 4; ++c) {
           const int d = db * 32 + 8 * c + 4 * hi;
           if (d < p.D) {
-            u32x2 pk = {pack_bf16(o[db][4 * c + 0] * inv_l, o[db][4 * c + 1] * inv_l),
-                        pack_bf16(o[db][4 * c + 2] * inv_l, o[db][4 * c + 3] * inv_l)};
+            float v0 = o[db][4 * c + 0] * inv_l, v1 = o[db][4 * c + 1] * inv_l;
+            float v2 = o[db][4 * c + 2] * inv_l, v3 = o[db][4 * c + 3] * inv_l;
+            if (p.accum != 0.f) {   // launch-uniform: add to what the first attention call left in O
+              const bf16x4 old = __builtin_bit_cast(bf16x4, *reinterpret_cast<const u32x2*>(orow + d));
+              v0 = (float)old[0] + p.accum * v0;
+              v1 = (float)old[1] + p.accum * v1;
+              v2 = (float)old[2] + p.accum * v2;
+              v3 = (float)old[3] + p.accum * v3;
+            }
+            u32x2 pk = {pack_bf16(v0, v1), pack_bf16(v2, v3)};
             *reinterpret_cast<u32x2*>(orow + d) = pk;
           }
         }

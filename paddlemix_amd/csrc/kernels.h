@@ -71,6 +71,7 @@ struct AttnArgs {
   const float* bias;             // optional additive mask, indexed b*bias_bs + h*bias_hs + q*bias_qs + kv
   long bias_bs, bias_hs, bias_qs;
   float scale;
+  float accum;   // != 0: O += accum * attention(...) instead of O = attention(...) (IP-Adapter's second key set)
   int dbg;   // ablation switches (MI355X_SD_ATTN_DBG; 0 in production)
 };
 int launch_attention(const AttnArgs& a, hipStream_t stream);

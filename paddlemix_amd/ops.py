@@ -143,7 +143,7 @@ def latent_dist(moments: Tensor, B: int, L: int, noise: Optional[Tensor] = None,
 
 
 def sdpa(q: Tensor, k: Tensor, v: Tensor, bias: Optional[Tensor] = None, scale: Optional[float] = None,
-         out: Optional[Tensor] = None) -> Tensor:
+         out: Optional[Tensor] = None, accum: Optional[float] = None) -> Tensor:
     """q [B,Sq,H,D], k/v [B,Skv,H,D] (head-contiguous token rows, arbitrary token/batch strides) -> [B,Sq,H,D].
     bias: optional fp32 additive mask broadcastable to [B,H,Sq,Skv] with unit inner stride."""
     lib = _lib.load()
@@ -163,9 +163,13 @@ def sdpa(q: Tensor, k: Tensor, v: Tensor, bias: Optional[Tensor] = None, scale: 
         bb = bias.stride(0) if bias.shape[0] > 1 else 0
         bh = bias.stride(1) if bias.shape[1] > 1 else 0
         bq = bias.stride(2) if bias.shape[2] > 1 else 0
-    check(lib.mi355x_sd_sdpa(q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(bias), out.data_ptr(), B, H, Sq, Skv, D,
-                             q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
-                             out.stride(0), out.stride(1), bb, bh, bq, float(scale), _stream()))
+    args = (q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(bias), out.data_ptr(), B, H, Sq, Skv, D,
+            q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+            out.stride(0), out.stride(1), bb, bh, bq, float(scale))
+    if accum is None:
+        check(lib.mi355x_sd_sdpa(*args, _stream()))
+    else:   # out += accum * attention (`out` given and already holding a first attention's result)
+        check(lib.mi355x_sd_sdpa_accum(*args, float(accum), _stream()))
     return out
 
 

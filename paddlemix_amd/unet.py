@@ -45,9 +45,11 @@ UNET_DEFAULTS = dict(
     addition_time_embed_dim=None, upcast_attention=False, resnet_time_scale_shift="default",
     resnet_out_scale_factor=1.0, time_embedding_type="positional", projection_class_embeddings_input_dim=None,
     time_cond_proj_dim=None, class_embed_type=None, num_class_embeds=None, class_embeddings_concat=False,
+    encoder_hid_dim=None, encoder_hid_dim_type=None,
+    ip_adapter_num_tokens=4,   # extension: ImageProjection.num_image_text_embeds, which the reference reads off the IP-Adapter
+                               # checkpoint instead of the config (loaders/unet.py _load_ip_adapter_weights)
 )
-_UNSUPPORTED_IF_SET = ("encoder_hid_dim", "encoder_hid_dim_type",
-                       "time_embedding_dim", "time_embedding_act_fn", "timestep_post_act",
+_UNSUPPORTED_IF_SET = ("time_embedding_dim", "time_embedding_act_fn", "timestep_post_act",
                        "cross_attention_norm", "dual_cross_attention", "resnet_skip_time_act")
 
 
@@ -58,6 +60,15 @@ def normalize_config(config: Mapping) -> dict:
     for k in _UNSUPPORTED_IF_SET:
         if cfg.get(k) not in (None, False):
             raise NotImplementedError(f"UNet2DConditionModel(mi355x): config {k}={cfg[k]!r} is not implemented")
+    # encoder_hid_proj (unet_2d_condition.py:300-335): the IP-Adapter image projection is built, text_proj / image_proj are not
+    if cfg["encoder_hid_dim_type"] not in (None, "ip_image_proj"):
+        raise NotImplementedError(f"UNet2DConditionModel(mi355x): encoder_hid_dim_type={cfg['encoder_hid_dim_type']!r} "
+                                  "is not implemented")
+    if cfg["encoder_hid_dim_type"] is not None and cfg["encoder_hid_dim"] is None:
+        raise ValueError(f"`encoder_hid_dim` has to be defined when `encoder_hid_dim_type` is set to "
+                         f"{cfg['encoder_hid_dim_type']}.")
+    if cfg["encoder_hid_dim_type"] is None and cfg["encoder_hid_dim"] is not None:
+        raise NotImplementedError("UNet2DConditionModel(mi355x): encoder_hid_dim without a type (text_proj) is not implemented")
     if cfg["time_embedding_type"] != "positional" or cfg["resnet_time_scale_shift"] != "default":
         raise NotImplementedError("only positional time embedding / default resnet time shift are implemented")
     if cfg["act_fn"] not in ("silu", "swish"):
@@ -206,6 +217,9 @@ def unet_param_shapes(config: Mapping) -> Dict[str, tuple]:
                     lin(b + a + ".to_out.0", c, c)
                     if a == ".attn1":
                         norm(b + ".norm2", c)
+                    elif cfg["encoder_hid_dim_type"] == "ip_image_proj":   # IPAdapterAttnProcessor (attention_processor.py:1816-1817)
+                        lin(b + a + ".processor.to_k_ip", kd, c, bias=False)
+                        lin(b + a + ".processor.to_v_ip", kd, c, bias=False)
                 norm(b + ".norm3", c)
                 lin(b + ".ff.net.0.proj", c, 8 * c)
                 lin(b + ".ff.net.2", 4 * c, c)
@@ -217,6 +231,10 @@ def unet_param_shapes(config: Mapping) -> Dict[str, tuple]:
             conv(d[1], d[2], d[2], 3)
     norm("conv_norm_out", boc[0])
     conv("conv_out", boc[0], cfg["out_channels"], 3)
+    if cfg["encoder_hid_dim_type"] == "ip_image_proj":   # ImageProjection (embeddings.py:507-518); last, so other draws keep their order
+        dx = cfg["cross_attention_dim"][0]
+        lin("encoder_hid_proj.image_embeds", cfg["encoder_hid_dim"], cfg["ip_adapter_num_tokens"] * dx)
+        norm("encoder_hid_proj.norm", dx)
     return S
 
 
@@ -333,6 +351,12 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
         temb_w, temb_b = [], []
         self._temb_off: Dict[str, int] = {}
         off = 0
+        self._ip = cfg["encoder_hid_dim_type"] == "ip_image_proj"
+        self.ip_adapter_scale = 1.0
+        if self._ip:
+            put_lin("encoder_hid_proj.image_embeds", "encoder_hid_proj.image_embeds")
+            put_norm("encoder_hid_proj.norm", "encoder_hid_proj.norm")
+        kvip_w: List[Tensor] = []          # ... and every IPAdapterAttnProcessor's to_k_ip / to_v_ip, same column offsets
         kv_w: List[Tensor] = []            # every cross-attention to_k / to_v, batched into one GEMM per step
         self._kv_off: Dict[str, int] = {}
         kv_off = 0
@@ -373,6 +397,9 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
                     if any(x != cfg["cross_attention_dim"][0] for x in cfg["cross_attention_dim"]):
                         raise NotImplementedError("per-block cross_attention_dim")
                     kv_w.append(bf(torch.cat([lin_w(b + ".attn2.to_k"), lin_w(b + ".attn2.to_v")], 0)))
+                    if self._ip:
+                        kvip_w.append(bf(torch.cat([lin_w(b + ".attn2.processor.to_k_ip"),
+                                                    lin_w(b + ".attn2.processor.to_v_ip")], 0)))
                     self._kv_off[b] = kv_off
                     kv_off += 2 * c
                     put_lin(b + ".attn2.out", b + ".attn2.to_out.0")
@@ -393,7 +420,9 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
             elif d[0] in ("down", "up"):
                 put_conv(d[1], d[1])
         W["kv_all.w"] = torch.cat(kv_w, 0).contiguous()
-        del kv_w
+        if self._ip:
+            W["kvip_all.w"] = torch.cat(kvip_w, 0).contiguous()
+        del kv_w, kvip_w
         self._kv_total = kv_off
         W["temb_all.w"] = bf(torch.cat(temb_w, 0))
         W["temb_all.b"] = torch.cat(temb_b, 0).contiguous()
@@ -478,13 +507,17 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
                                            wp(wkey + ".b"), flags, stream), "gemm", 2.0 * x.rows * N * K,
                  f"{x.rows}x{N}x{K}" + ("g" if flags & GEGLU else ""))
 
-        def attention(q: _V, k: _V, v: _V, out: _V, heads, sq, skv, bias=None):
+        def attention(q: _V, k: _V, v: _V, out: _V, heads, sq, skv, bias=None, accum: Optional[float] = None):
             d = q.C // heads
             # bias: additive encoder mask [B, skv] broadcast over heads and queries (unet_2d_condition.py:921-927)
-            emit(lib.mi355x_sd_sdpa, (q.p, k.p, v.p, bias, out.p, B, heads, sq, skv, d, sq * q.ld, q.ld, skv * k.ld,
-                                      k.ld, skv * v.ld, v.ld, sq * out.ld, out.ld, skv if bias else 0, 0, 0,
-                                      d ** -0.5, stream),
-                 "attn", 4.0 * B * heads * sq * skv * d, f"{B}x{heads}x{sq}x{skv}x{d}")
+            args = (q.p, k.p, v.p, bias, out.p, B, heads, sq, skv, d, sq * q.ld, q.ld, skv * k.ld, k.ld, skv * v.ld, v.ld,
+                    sq * out.ld, out.ld, skv if bias else 0, 0, 0, d ** -0.5)
+            if accum is None:
+                emit(lib.mi355x_sd_sdpa, args + (stream,), "attn", 4.0 * B * heads * sq * skv * d,
+                     f"{B}x{heads}x{sq}x{skv}x{d}")
+            else:   # out += accum * attention (the image-token half of IPAdapterAttnProcessor)
+                emit(lib.mi355x_sd_sdpa_accum, args + (float(accum), stream), "attn", 4.0 * B * heads * sq * skv * d,
+                     f"{B}x{heads}x{sq}x{skv}x{d}+")
 
         # ---- inputs (static buffers; staged by __call__) ----
         plan.sample = persist((B, cfg["in_channels"], H, Wd), torch.float32)
@@ -573,6 +606,20 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
         kv_all_t = persist((B * L, self._kv_total), _lib.elem_dtype())
         kv_all = _V(kv_all_t.data_ptr(), B * L, self._kv_total)
         linear(enc, "kv_all", kv_all, bias=False)
+        # IP-Adapter (unet_2d_condition.py:1054-1061): image_embeds -> ImageProjection (Linear, view [B*T, Dx], LayerNorm) -> the
+        # image tokens' K/V for every cross-attention in one GEMM. The reference appends the tokens to encoder_hidden_states
+        # and each IPAdapterAttnProcessor splits them off again; here they never join the text rows.
+        plan.image_embeds = None
+        kvip_all, T = None, cfg["ip_adapter_num_tokens"]
+        if self._ip:
+            E = cfg["encoder_hid_dim"]
+            plan.image_embeds = persist((B, E), _lib.elem_dtype())
+            raw = _V(persist((B, T * dx), _lib.elem_dtype()).data_ptr(), B, T * dx)
+            linear(_V(plan.image_embeds.data_ptr(), B, E), "encoder_hid_proj.image_embeds", raw)
+            tok = _V(persist((B * T, dx), _lib.elem_dtype()).data_ptr(), B * T, dx)
+            lnorm(_V(raw.p, B * T, dx), "encoder_hid_proj.norm", tok)
+            kvip_all = _V(persist((B * T, self._kv_total), _lib.elem_dtype()).data_ptr(), B * T, self._kv_total)
+            linear(tok, "kvip_all", kvip_all, bias=False)
 
         # ---- skip / concat buffers: pre-walk ----
         S = _structure(cfg)
@@ -650,6 +697,9 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
                     linear(ln, b + ".attn2.q", q2, bias=False)
                 ko = self._kv_off[b]
                 attention(q2, kv_all.cols(ko, c), kv_all.cols(ko + c, c), ao, heads, hw, L, bias=enc_bias)
+                if kvip_all is not None and self.ip_adapter_scale != 0.0:
+                    attention(q2, kvip_all.cols(ko, c), kvip_all.cols(ko + c, c), ao, heads, hw, T,
+                              accum=self.ip_adapter_scale)
                 linear(ao, b + ".attn2.out", hid, R=hid)
                 if self.fold_ln:
                     ln_linear(hid, b + ".ff1", ff, flags=GEGLU)
@@ -764,8 +814,18 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
                self._stream_ptr), "misc", 0.0)
         plan.prog.insert(plan._add_emit_index, op)
 
+    def set_ip_adapter_scale(self, scale: float) -> None:
+        """weight of the image prompt in every cross-attention (IPAdapterAttnProcessor.scale; the pipelines'
+        ``set_ip_adapter_scale``, loaders/ip_adapter.py). The scale is a launch constant: plans are per scale; 0 drops the
+        image-token attention launches altogether."""
+        if not self._ip:
+            raise ValueError("this UNet has no IP-Adapter (config encoder_hid_dim_type != 'ip_image_proj')")
+        self.ip_adapter_scale = float(scale)
+
     def _get_plan(self, B, H, W, L, masked: bool = False, controlnet: bool = False) -> _Plan:
-        key = (B, H, W, L, masked, controlnet)
+        if masked and self._ip:
+            raise NotImplementedError("encoder_attention_mask together with IP-Adapter image tokens")
+        key = (B, H, W, L, masked, controlnet, self.ip_adapter_scale)
         if key not in self._plans:
             self._plans[key] = self._build_plan(B, H, W, L, masked, controlnet)
         return self._plans[key]
@@ -817,6 +877,14 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
         if in_scale is not None:
             plan.in_scale.fill_(float(in_scale))
         plan.enc.copy_(encoder_hidden_states.reshape(plan.B * plan.L, -1), non_blocking=True)
+        if plan.image_embeds is not None:
+            if added_cond_kwargs is None or "image_embeds" not in added_cond_kwargs:
+                raise ValueError(f"{self.__class__} has the config param `encoder_hid_dim_type` set to 'ip_image_proj' which "
+                                 "requires the keyword argument `image_embeds` to be passed in  `added_conditions`")
+            ie = added_cond_kwargs["image_embeds"]
+            if tuple(ie.shape) != tuple(plan.image_embeds.shape):
+                raise ValueError(f"image_embeds of shape {tuple(ie.shape)}, expected {tuple(plan.image_embeds.shape)}")
+            plan.image_embeds.copy_(ie, non_blocking=True)
         if cfg["addition_embed_type"] == "text_time":
             if added_cond_kwargs is None or "text_embeds" not in added_cond_kwargs:
                 raise ValueError(f"{self.__class__} has the config param `addition_embed_type` set to 'text_time' which "

@@ -254,8 +254,13 @@ class Emulator:
         self._epilogue(acc, Cout, bias, rowbias, Ho * Wo, ld_rb, R, ldr, out_scale, flags, C, ldc)
         return 0
 
+    def mi355x_sd_sdpa_accum(self, q, k, v, bias, out, B, H, Sq, Skv, D, q_bs, q_ts, k_bs, k_ts, v_bs, v_ts, o_bs, o_ts,
+                             bias_bs, bias_hs, bias_qs, scale, out_scale, stream):
+        return self.mi355x_sd_sdpa(q, k, v, bias, out, B, H, Sq, Skv, D, q_bs, q_ts, k_bs, k_ts, v_bs, v_ts, o_bs, o_ts,
+                                   bias_bs, bias_hs, bias_qs, scale, stream, _accum=out_scale)
+
     def mi355x_sd_sdpa(self, q, k, v, bias, out, B, H, Sq, Skv, D, q_bs, q_ts, k_bs, k_ts, v_bs, v_ts, o_bs, o_ts,
-                       bias_bs, bias_hs, bias_qs, scale, stream):
+                       bias_bs, bias_hs, bias_qs, scale, stream, _accum=None):
         self.calls.append("sdpa")
 
         def view(p, S, bs, ts):
@@ -270,6 +275,8 @@ class Emulator:
             s = s + _flat(bias, n, torch.float32).as_strided((B, H, Sq, Skv), (bias_bs, bias_hs, bias_qs, 1))
         p = torch.softmax(s, -1)
         o = torch.einsum("bhqk,bkhd->bqhd", p, vv)
+        if _accum is not None:   # out += out_scale * attention, on the 16-bit values already in `out`
+            o = view(out, Sq, o_bs, o_ts).float() + _accum * o
         view(out, Sq, o_bs, o_ts).copy_(o.to(_lib.elem_dtype()))
         return 0
 

@@ -328,6 +328,24 @@ def test_sdpa(ops, B, H, Sq, Skv, D):
     check(out, ref, rel=5e-3, what=f"sdpa {B,H,Sq,Skv,D}")
 
 
+@pytest.mark.parametrize("B,H,Sq,Skv,T,D,scale", [(2, 8, 1024, 77, 4, 64, 1.0), (1, 10, 4096, 77, 4, 64, 0.6),
+                                                   (2, 8, 256, 77, 16, 40, 0.35), (1, 8, 64, 77, 4, 160, 1.0)])
+def test_sdpa_accum_ip_adapter_tokens(ops, B, H, Sq, Skv, T, D, scale):
+    """mi355x_sd_sdpa_accum: out = attn(q, k_text, v_text) + scale * attn(q, k_ip, v_ip), the arithmetic of
+    IPAdapterAttnProcessor.__call__ (attention_processor.py:1871-1886) with T image tokens as a second, tiny key set."""
+    g = torch.Generator().manual_seed(Sq + T + D)
+    q = bfr(torch.randn(B, Sq, H, D, generator=g))
+    k, v = (bfr(torch.randn(B, Skv, H, D, generator=g)) for _ in range(2))
+    ki, vi = (bfr(torch.randn(B, T, H, D, generator=g)) for _ in range(2))
+    ref = U.sdpa_math(q, k, v) + scale * U.sdpa_math(q, ki, vi)
+    out = ops.sdpa(dev(q), dev(k), dev(v))
+    first = out.clone()
+    ops.sdpa(dev(q), dev(ki), dev(vi), out=out, accum=scale)
+    check(out, ref, rel=6e-3, what=f"sdpa_accum {B,H,Sq,Skv,T,D}")   # two bf16 roundings of the text half
+    ops.sdpa(dev(q), dev(ki), dev(vi), out=first, accum=0.0)          # out += 0 * attention leaves it alone
+    assert torch.equal(first, ops.sdpa(dev(q), dev(k), dev(v)))
+
+
 def test_sdpa_fused_qkv_strides_and_spike(ops):
     """q/k/v consumed in place from a fused [rows, 3C] projection buffer; plus a spiked key that forces the
     online-softmax rescale at a late tile (cdna guide 5.4 rule 26)."""

@@ -212,3 +212,31 @@ def test_timestep_cond_on_device():
     assert _rel(out, U.unet_forward(P, cfg, sample, 200, enc, timestep_cond=w)) < 2e-2
     out0 = model(_cuda(sample), 200, _cuda(enc)).sample.cpu()
     assert _rel(out0, U.unet_forward(P, cfg, sample, 200, enc)) < 2e-2 and not torch.equal(out0, out)
+
+
+@pytest.mark.parametrize("base", ["TINY", "MINI_XL"])
+def test_ip_adapter_on_device(base):
+    """IP-Adapter (encoder_hid_dim_type="ip_image_proj", unet_2d_condition.py:1054-1061; IPAdapterAttnProcessor,
+    attention_processor.py:1793-1901): image_embeds -> ImageProjection -> per-block K/V of the image tokens -> a second,
+    accumulating attention launch in every cross-attention"""
+    from paddlemix_amd.unet import UNet2DConditionModel
+    from tests import configs
+    cfg = dict(getattr(configs, base), encoder_hid_dim_type="ip_image_proj", encoder_hid_dim=96)
+    P = _bf16_params(cfg, "cpu")
+    sample, enc, added = _inputs(cfg, 2, 16, 16, 7 if base == "TINY" else 77)
+    img = torch.randn(2, 96, generator=torch.Generator().manual_seed(9))
+    kw = dict(added or {}, image_embeds=img)
+    ckw = {k: v.cuda() for k, v in kw.items()}
+    model = UNet2DConditionModel(cfg, P)
+    outs = {}
+    for sc in (1.0, 0.5, 0.0):
+        model.set_ip_adapter_scale(sc)
+        out = model(_cuda(sample), 400, _cuda(enc), added_cond_kwargs=ckw, return_dict=False)[0].cpu()
+        ref = U.unet_forward(P, cfg, sample, 400, enc, added_cond_kwargs=kw, ip_adapter_scale=sc)
+        r = _rel(out, ref)
+        print(f"ip-adapter {base} scale {sc}: rel-L2 vs oracle {r:.3e}")
+        assert r < 2e-2, (sc, r)
+        outs[sc] = out
+    assert not torch.equal(outs[1.0], outs[0.0])
+    with pytest.raises(ValueError, match="image_embeds"):
+        model(_cuda(sample), 400, _cuda(enc), added_cond_kwargs={k: v for k, v in ckw.items() if k != "image_embeds"} or None)

@@ -117,6 +117,47 @@ def test_timestep_cond_matches_oracle():
         UNet2DConditionModel(TINY, synth_unet_params(TINY, seed=9), _test_backend=Emulator())(sample, 200, enc, timestep_cond=w)
 
 
+def test_ip_adapter_matches_oracle():
+    """encoder_hid_dim_type="ip_image_proj": ImageProjection of `image_embeds` (embeddings.py:507-527, unet_2d_condition.py:
+    1054-1061) and the image-token half of every cross-attention (IPAdapterAttnProcessor, attention_processor.py:1793-1901)"""
+    cfg = dict(TINY, encoder_hid_dim_type="ip_image_proj", encoder_hid_dim=48)
+    assert list(unet_param_shapes(cfg).items()) == list(U.unet_param_shapes(cfg).items())
+    P = synth_unet_params(cfg, seed=3)
+    b = "down_blocks.1.attentions.0.transformer_blocks.0.attn2.processor"
+    assert P[b + ".to_k_ip.weight"].shape == P[b.replace(".processor", "") + ".to_k.weight"].shape and (b + ".to_k_ip.bias") not in P       # Paddle [cross, C], no bias
+    assert P["encoder_hid_proj.image_embeds.weight"].shape == (48, 4 * 64) and P["encoder_hid_proj.norm.weight"].shape == (64,)
+    Pb = {k: v.to(torch.bfloat16).float() if v.dim() > 1 else v for k, v in P.items()}
+    sample, enc, _ = _inputs(cfg, 2, 16, 16, 7)
+    g = torch.Generator().manual_seed(2)
+    img, img2 = torch.randn(2, 48, generator=g), torch.randn(2, 48, generator=g)
+    model = UNet2DConditionModel(cfg, P, _test_backend=Emulator())
+    outs = {}
+    for sc in (1.0, 0.6, 0.0):
+        model.set_ip_adapter_scale(sc)
+        outs[sc] = model(sample, 10, enc, added_cond_kwargs={"image_embeds": img}).sample
+        ref = U.unet_forward(Pb, cfg, sample, 10, enc, added_cond_kwargs={"image_embeds": img}, ip_adapter_scale=sc)
+        assert _rel(outs[sc], ref) < 2e-2, (sc, _rel(outs[sc], ref))
+    # scale 0 launches no image-token attention: exactly the UNet without the adapter on the same weights
+    base = UNet2DConditionModel(TINY, {k: v for k, v in P.items() if "_ip." not in k and "encoder_hid_proj" not in k},
+                                _test_backend=Emulator())
+    assert torch.equal(outs[0.0], base(sample, 10, enc).sample)
+    assert _rel(outs[1.0], outs[0.0]) > 1e-2                     # the image prompt matters ...
+    model.set_ip_adapter_scale(1.0)
+    assert not torch.equal(model(sample, 10, enc, added_cond_kwargs={"image_embeds": img2}).sample, outs[1.0])   # ... and which one
+    with pytest.raises(ValueError, match="image_embeds"):
+        model(sample, 10, enc)
+    with pytest.raises(ValueError, match="image_embeds of shape"):
+        model(sample, 10, enc, added_cond_kwargs={"image_embeds": img[:, :40]})
+    with pytest.raises(NotImplementedError):
+        model(sample, 10, enc, added_cond_kwargs={"image_embeds": img}, encoder_attention_mask=torch.ones(2, 7))
+    with pytest.raises(ValueError):
+        base.set_ip_adapter_scale(0.5)
+    with pytest.raises(ValueError, match="encoder_hid_dim"):
+        unet_param_shapes(dict(TINY, encoder_hid_dim_type="ip_image_proj"))
+    with pytest.raises(NotImplementedError):
+        unet_param_shapes(dict(TINY, encoder_hid_dim_type="text_proj", encoder_hid_dim=32))
+
+
 def test_param_inventory_matches_oracle():
     for cfg in (TINY, MINI_XL, SD15, SDXL):
         a, b = unet_param_shapes(cfg), U.unet_param_shapes(cfg)
