@@ -119,6 +119,51 @@ class StableDiffusionDenoiser:
             emb = torch.nn.functional.pad(emb, (0, 1))
         return emb
 
+    def _encode_image(self, image: torch.Tensor, generator) -> torch.Tensor:
+        """``_encode_vae_image`` (pipeline_stable_diffusion_inpaint.py:746-758): posterior sample * scaling_factor"""
+        if self.vae is None:
+            raise ValueError("an image input needs a `vae` with encoder parameters")
+        return self.vae.encode(image.to(torch.float32)).latent_dist.sample(generator, out_scale=self.vae.config.scaling_factor)
+
+    def prepare_inpaint(self, image, mask_image, masked_image_latents, timesteps, batch_size: int, generator,
+                        is_strength_max: bool, do_cfg: bool):
+        """``prepare_latents`` + ``prepare_mask_latents`` of the inpaint pipeline (pipeline_stable_diffusion_inpaint.py:689-803),
+        in the reference's order of random draws: image posterior, initial noise, masked-image posterior."""
+        lc = self.vae.config.latent_channels if self.vae is not None else 4
+        four = self.unet.config.in_channels == lc
+        if not torch.is_tensor(image) or image.dim() != 4 or not torch.is_tensor(mask_image) or mask_image.dim() != 4:
+            raise ValueError("`image` and `mask_image` have to be [B, C, H, W] tensors")
+        image = image.to(torch.float32)
+        f = 2 ** (len(self.vae.config.block_out_channels) - 1) if self.vae is not None else 8     # vae_scale_factor
+        hl, wl = (image.shape[-2], image.shape[-1]) if image.shape[1] == lc else (image.shape[-2] // f, image.shape[-1] // f)
+        image_latents = None
+        if four or not is_strength_max:
+            image_latents = image if image.shape[1] == lc else self._encode_image(image, generator)
+            image_latents = image_latents.repeat(batch_size // image_latents.shape[0], 1, 1, 1)
+        noise = torch.randn((batch_size, lc, hl, wl), generator=generator, dtype=torch.float32, device=image.device)
+        if is_strength_max:
+            latents = noise * self.scheduler.init_noise_sigma
+        else:
+            ts = torch.as_tensor(np.asarray(timesteps[:1]).reshape(-1)).repeat(batch_size)
+            latents = self.scheduler.add_noise(image_latents, noise, ts)
+        mask_px = (mask_image.to(torch.float32) >= 0.5).to(torch.float32)          # mask_processor: do_binarize
+        mask = torch.nn.functional.interpolate(mask_px, size=(hl, wl))              # nearest, like the reference (:766-768)
+        if masked_image_latents is None:
+            if image.shape[1] == lc:
+                raise ValueError("latents passed as `image` need `masked_image_latents`")
+            masked_image_latents = self._encode_image(image * (mask_px < 0.5).to(image.dtype), generator)   # (:1134)
+        for nm, t in (("masks", mask), ("images", masked_image_latents)):
+            if batch_size % t.shape[0]:
+                raise ValueError(f"The passed {nm} and the required batch size don't match: {t.shape[0]} vs {batch_size}.")
+        mask = mask.repeat(batch_size // mask.shape[0], 1, 1, 1)
+        mil = masked_image_latents.to(torch.float32).repeat(batch_size // masked_image_latents.shape[0], 1, 1, 1)
+        if not four and lc + mask.shape[1] + mil.shape[1] != self.unet.config.in_channels:
+            raise ValueError(f"Incorrect configuration settings! The config of `pipeline.unet` expects "
+                             f"{self.unet.config.in_channels} but received `num_channels_latents`: {lc} + `num_channels_mask`: "
+                             f"{mask.shape[1]} + `num_channels_masked_image`: {mil.shape[1]}")
+        rep2 = (lambda t: torch.cat([t] * 2)) if do_cfg else (lambda t: t)
+        return latents, dict(mask=mask, noise=noise, image_latents=image_latents, mask_in=rep2(mask), masked_in=rep2(mil))
+
     def get_timesteps(self, num_inference_steps: int, strength: float):
         """img2img: keep the last ``int(steps * strength)`` steps (pipeline_stable_diffusion_img2img.py:616-623)."""
         init_timestep = min(int(num_inference_steps * strength), num_inference_steps)
@@ -158,10 +203,21 @@ class StableDiffusionDenoiser:
                  negative_prompt_ids: Optional[torch.Tensor] = None, prompt_ids_2: Optional[torch.Tensor] = None,
                  negative_prompt_ids_2: Optional[torch.Tensor] = None, original_size=None,
                  crops_coords_top_left=(0, 0), target_size=None, fused_update: bool = True,
-                 image: Optional[torch.Tensor] = None, strength: float = 0.8, eta: float = 0.0):
+                 image: Optional[torch.Tensor] = None, strength: Optional[float] = None, eta: float = 0.0,
+                 mask_image: Optional[torch.Tensor] = None, masked_image_latents: Optional[torch.Tensor] = None):
         """``image`` (extension of the text2img call = StableDiffusionImg2ImgPipeline.__call__,
         pipeline_stable_diffusion_img2img.py:735-1010): start from the encoded, re-noised image and run the last
-        ``int(num_inference_steps * strength)`` steps."""
+        ``int(num_inference_steps * strength)`` steps (strength defaults to 0.8).
+
+        ``image`` + ``mask_image`` [B|1, 1, H, W] in [0, 1], 1 = repaint (= StableDiffusionInpaintPipeline.__call__,
+        pipeline_stable_diffusion_inpaint.py:1094-1236; strength defaults to 1.0): a 9-channel UNet gets
+        ``[latents | mask | masked-image latents]`` every step, a 4-channel UNet has the kept region re-imposed after every
+        step from the re-noised image latents."""
+        inpaint = mask_image is not None
+        if inpaint and image is None:
+            raise ValueError("`mask_image` needs `image`")
+        if strength is None:
+            strength = 1.0 if inpaint else 0.8
         # guidance-distilled UNets (LCM) take the scale as an embedding instead of a doubled batch (:634-635, :846-852)
         tc_dim = getattr(self.unet.config, "time_cond_proj_dim", None)
         do_cfg = guidance_scale > 1.0 and tc_dim is None
@@ -201,13 +257,17 @@ class StableDiffusionDenoiser:
                 neg = negative_added_cond_kwargs or added_cond_kwargs
                 added_cond_kwargs = {k: torch.cat([neg[k], v]) for k, v in added_cond_kwargs.items()}
         self.scheduler.set_timesteps(num_inference_steps)
-        timesteps, first = self.scheduler.timesteps, 0
+        timesteps, first, inp = self.scheduler.timesteps, 0, None
         if image is not None:
             timesteps, _, first = self.get_timesteps(num_inference_steps, strength)
             if len(timesteps) < 1:
                 raise ValueError(f"After adjusting the num_inference_steps by strength parameter: {strength}, the number of "
                                  "pipeline steps is 0 which is < 1 and not appropriate for this pipeline.")
-            latents = self.prepare_image_latents(image, timesteps[:1], B, generator)
+            if inpaint:
+                latents, inp = self.prepare_inpaint(image, mask_image, masked_image_latents, timesteps, B, generator,
+                                                    strength == 1.0, do_cfg)
+            else:
+                latents = self.prepare_image_latents(image, timesteps[:1], B, generator)
         else:
             latents = self.prepare_latents(B, cfg.in_channels, h, w, torch.float32, generator, latents, prompt_embeds.device)
         import inspect
@@ -222,13 +282,27 @@ class StableDiffusionDenoiser:
             w = torch.full((B,), float(guidance_scale) - 1.0, device=latents.device)
             unet_kw["timestep_cond"] = self.get_guidance_scale_embedding(w, embedding_dim=tc_dim)
         fused = self._fused_plan(guidance_rescale, latents.device) if fused_update and not eta else None
+        nine = inp is not None and cfg.in_channels != latents.shape[1]
+
+        def extend(x):   # 9-channel inpainting UNet: [scaled latents | mask | masked-image latents] (:1194-1198)
+            return torch.cat([x, inp["mask_in"], inp["masked_in"]], dim=1) if nine else x
+
+        def reimpose(lat, step_no):   # 4-channel UNet: keep the unmasked region on the re-noised image latents (:1218-1231)
+            if inp is None or nine:
+                return lat
+            proper = inp["image_latents"]
+            if step_no < len(timesteps) - 1:
+                nt = torch.as_tensor(np.asarray(timesteps[step_no + 1]).reshape(1)).repeat(proper.shape[0])
+                proper = self.scheduler.add_noise(proper, inp["noise"], nt)
+            return (1 - inp["mask"]) * proper + inp["mask"] * lat
+
         for i, t in enumerate(timesteps, start=first):
             latent_model_input = torch.cat([latents] * 2) if do_cfg else latents
             if fused is not None:
                 # guidance combine + scheduler update as ONE device pass over the latents (mi355x_sd_cfg_axpby): the
                 # epsilon-prediction step of Euler / DDIM(eta=0) is prev = a*x + b*eps with per-step (a, b) kept in HBM
                 scales, coef, lib, stream = fused
-                noise_pred = self.unet(latent_model_input * scales[i], t, encoder_hidden_states=prompt_embeds,
+                noise_pred = self.unet(extend(latent_model_input * scales[i]), t, encoder_hidden_states=prompt_embeds,
                                        added_cond_kwargs=added_cond_kwargs, return_dict=False, **unet_kw)[0]
                 lat = latents.contiguous()
                 out = torch.empty_like(lat)
@@ -241,20 +315,20 @@ class StableDiffusionDenoiser:
                 if rc:
                     from . import _lib
                     _lib.check(rc)
-                latents = out
+                latents = reimpose(out, i - first)
                 if callback_on_step_end is not None:
                     cb = callback_on_step_end(self, i, t, {"latents": latents})
                     latents = cb.pop("latents", latents)
                 continue
             latent_model_input = self.scheduler.scale_model_input(latent_model_input, t)
-            noise_pred = self.unet(latent_model_input, t, encoder_hidden_states=prompt_embeds,
+            noise_pred = self.unet(extend(latent_model_input), t, encoder_hidden_states=prompt_embeds,
                                    added_cond_kwargs=added_cond_kwargs, return_dict=False, **unet_kw)[0]
             if do_cfg:
                 noise_uncond, noise_text = noise_pred.chunk(2)
                 noise_pred = noise_uncond + guidance_scale * (noise_text - noise_uncond)
                 if guidance_rescale > 0.0:
                     noise_pred = rescale_noise_cfg(noise_pred, noise_text, guidance_rescale)
-            latents = self.scheduler.step(noise_pred, t, latents, return_dict=False, **extra)[0]
+            latents = reimpose(self.scheduler.step(noise_pred, t, latents, return_dict=False, **extra)[0], i - first)
             if callback_on_step_end is not None:
                 out = callback_on_step_end(self, i, t, {"latents": latents})
                 latents = out.pop("latents", latents)

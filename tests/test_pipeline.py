@@ -335,3 +335,88 @@ def test_lcm_loop_matches_oracle_loop():
     b = pipe0(pe, num_inference_steps=3, guidance_scale=1.0, latents=lat0.clone(), eta=1.0, generator=torch.Generator().manual_seed(2))
     c = pipe0(pe, num_inference_steps=3, guidance_scale=1.0, latents=lat0.clone())
     assert torch.equal(a, b) and not torch.allclose(a, c)
+
+
+def test_inpaint_loops_match_oracle_loops():
+    """StableDiffusionInpaintPipeline semantics (pipeline_stable_diffusion_inpaint.py:689-803, 1094-1236): a 4-channel UNet
+    has the kept region re-imposed after every step from the re-noised image latents; a 9-channel UNet is fed
+    [latents | mask | masked-image latents]."""
+    import pytest
+    import torch.nn.functional as F
+    from oracle import vae_ref as V
+    from paddlemix_amd.vae import AutoencoderKL, synth_vae_params
+    from tests.configs import MINI_VAE
+    sf = MINI_VAE["scaling_factor"]
+    Pv = synth_vae_params(MINI_VAE, seed=6)
+    Pvb = {k: (v.to(torch.bfloat16).float() if v.dim() > 1 else v) for k, v in Pv.items()}
+    g = torch.Generator().manual_seed(8)
+    pe, ne = torch.randn(1, 7, 64, generator=g), torch.randn(1, 7, 64, generator=g)
+    image = torch.rand(1, 3, 32, 32, generator=g) * 2 - 1
+    mask_px = torch.zeros(1, 1, 32, 32)
+    mask_px[:, :, 8:24, 12:32] = 0.9                     # binarised at 0.5 (mask_processor do_binarize)
+    m_lat = F.interpolate((mask_px >= 0.5).float(), size=(8, 8))
+    assert 0 < m_lat.sum() < 64
+
+    def enc(img, n):
+        return V.encode(Pvb, MINI_VAE, img, n)[2] * sf
+
+    # ---- (a) 4-channel UNet, strength 1.0 (pure noise start), DDIM + CFG ----
+    cfg = TINY
+    P = synth_unet_params(cfg, seed=1234)
+    Pb = {k: v.to(torch.bfloat16).float() if v.dim() > 1 else v for k, v in P.items()}
+    kw = dict(clip_sample=False, set_alpha_to_one=False, **SCHED)
+    vae = AutoencoderKL(MINI_VAE, Pv, _test_backend=Emulator())
+    pipe = StableDiffusionDenoiser(UNet2DConditionModel(cfg, P, _test_backend=Emulator()), DDIMScheduler(**kw), vae=vae)
+    steps, gs = 5, 4.0
+    out = pipe(pe, ne, num_inference_steps=steps, guidance_scale=gs, image=image, mask_image=mask_px,
+               generator=torch.Generator().manual_seed(31))
+    gg = torch.Generator().manual_seed(31)               # draws: image posterior, initial noise, masked-image posterior
+    n_img, noise, n_msk = (torch.randn(1, 4, 8, 8, generator=gg) for _ in range(3))
+    img_lat = enc(image, n_img).numpy()
+    sch = S.DDIMRef(**kw)
+    sch.set_timesteps(steps)
+    x = noise.numpy() * sch.init_noise_sigma
+    emb = torch.cat([ne, pe])
+    mk = m_lat.numpy()
+    for i, t in enumerate(sch.timesteps):
+        eps = U.unet_forward(Pb, cfg, torch.from_numpy(np.concatenate([x, x]).astype(np.float32)), int(t), emb).numpy()
+        x = sch.step(eps[:1] + gs * (eps[1:] - eps[:1]), t, x)
+        proper = img_lat if i == steps - 1 else sch.add_noise(img_lat, noise.numpy(), int(sch.timesteps[i + 1]))
+        x = (1 - mk) * proper + mk * x
+    rel = np.linalg.norm(out.numpy() - x) / np.linalg.norm(x)
+    assert rel < 5e-2, rel
+    keep = (mk == 0).repeat(4, axis=1)
+    assert np.abs(out.numpy() - img_lat)[keep].max() < 2e-2          # outside the mask the image latents come back
+    slow = pipe(pe, ne, num_inference_steps=steps, guidance_scale=gs, image=image, mask_image=mask_px,
+                generator=torch.Generator().manual_seed(31), fused_update=False)
+    assert np.linalg.norm(slow.numpy() - out.numpy()) / np.linalg.norm(out.numpy()) < 2e-2
+
+    # ---- (b) 9-channel inpainting UNet, strength 0.6 (image + noise start), Euler, no CFG ----
+    cfg9 = dict(TINY, in_channels=9)
+    P9 = synth_unet_params(cfg9, seed=77)
+    P9b = {k: v.to(torch.bfloat16).float() if v.dim() > 1 else v for k, v in P9.items()}
+    ekw = dict(timestep_spacing="leading", **SCHED)
+    pipe9 = StableDiffusionDenoiser(UNet2DConditionModel(cfg9, P9, _test_backend=Emulator()), EulerDiscreteScheduler(**ekw), vae=vae)
+    steps = 10
+    out9 = pipe9(pe, num_inference_steps=steps, guidance_scale=1.0, image=image, mask_image=mask_px, strength=0.6,
+                 generator=torch.Generator().manual_seed(32))
+    gg = torch.Generator().manual_seed(32)
+    n_img, noise, n_msk = (torch.randn(1, 4, 8, 8, generator=gg) for _ in range(3))
+    img_lat = enc(image, n_img).numpy()
+    mil = enc(image * (mask_px < 0.5).float(), n_msk).numpy()
+    sch = S.EulerRef(**ekw)
+    sch.set_timesteps(steps)
+    kept = sch.timesteps[steps - int(steps * 0.6):]
+    x = sch.add_noise(img_lat, noise.numpy(), kept[:1])
+    for t in kept:
+        xin = np.concatenate([sch.scale_model_input(x, t), mk, mil], axis=1).astype(np.float32)
+        x = sch.step(U.unet_forward(P9b, cfg9, torch.from_numpy(xin), float(t), pe).numpy(), t, x)
+    rel = np.linalg.norm(out9.numpy() - x) / np.linalg.norm(x)
+    assert out9.shape == (1, 4, 8, 8) and rel < 5e-2, rel
+    # errors: mask without image; a UNet whose channel count fits neither form
+    with pytest.raises(ValueError):
+        pipe(pe, ne, num_inference_steps=2, mask_image=mask_px)
+    bad = StableDiffusionDenoiser(UNet2DConditionModel(dict(TINY, in_channels=8), synth_unet_params(dict(TINY, in_channels=8), seed=1),
+                                                       _test_backend=Emulator()), DDIMScheduler(**kw), vae=vae)
+    with pytest.raises(ValueError, match="Incorrect configuration"):
+        bad(pe, num_inference_steps=2, guidance_scale=1.0, image=image, mask_image=mask_px)
