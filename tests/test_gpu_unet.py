@@ -240,3 +240,49 @@ def test_ip_adapter_on_device(base):
     assert not torch.equal(outs[1.0], outs[0.0])
     with pytest.raises(ValueError, match="image_embeds"):
         model(_cuda(sample), 400, _cuda(enc), added_cond_kwargs={k: v for k, v in ckw.items() if k != "image_embeds"} or None)
+
+
+def test_img2img_inpaint_lcm_pipelines_on_device():
+    """The image-conditioned entries of the SD loop with every tensor on the GPU (VAE encode -> posterior sample -> add_noise ->
+    loop -> decode): finite, generator-reproducible, and for the 4-channel inpaint form the kept region comes back. The
+    arithmetic of these loops is pinned against oracle loops in tests/test_pipeline.py (CPU, ABI emulator)."""
+    from paddlemix_amd.pipeline import StableDiffusionDenoiser
+    from paddlemix_amd.schedulers import DDIMScheduler, EulerDiscreteScheduler, LCMScheduler
+    from paddlemix_amd.unet import UNet2DConditionModel, synth_unet_params
+    from paddlemix_amd.vae import AutoencoderKL, synth_vae_params
+    from tests.configs import MINI_VAE
+    sk = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear")
+    vae = AutoencoderKL(MINI_VAE, synth_vae_params(MINI_VAE, seed=6))
+    g = torch.Generator().manual_seed(8)
+    pe, ne = torch.randn(2, 7, 64, generator=g).cuda(), torch.randn(2, 7, 64, generator=g).cuda()
+    image = (torch.rand(2, 3, 64, 64, generator=g) * 2 - 1).cuda()
+    mask = torch.zeros(2, 1, 64, 64, device="cuda")
+    mask[:, :, 16:48, 24:64] = 1.0
+    gen = lambda s: torch.Generator(device="cuda").manual_seed(s)  # noqa: E731
+
+    unet = UNet2DConditionModel(TINY, synth_unet_params(TINY, seed=1234))
+    pipe = StableDiffusionDenoiser(unet, DDIMScheduler(clip_sample=False, set_alpha_to_one=False, steps_offset=1, **sk), vae=vae)
+    a = pipe(pe, ne, num_inference_steps=6, guidance_scale=4.0, image=image, strength=0.5, generator=gen(1), output_type="pt")
+    b = pipe(pe, ne, num_inference_steps=6, guidance_scale=4.0, image=image, strength=0.5, generator=gen(1), output_type="pt")
+    assert a.shape == (2, 3, 64, 64) and torch.isfinite(a).all() and torch.equal(a, b)
+    lat = pipe(pe, ne, num_inference_steps=4, guidance_scale=4.0, image=image, mask_image=mask, generator=gen(2))
+    dist = vae.encode(image).latent_dist
+    keep = (torch.nn.functional.interpolate(mask, size=lat.shape[-2:]) == 0).expand_as(lat)
+    redo = pipe(pe, ne, num_inference_steps=4, guidance_scale=4.0, image=image, mask_image=mask, generator=gen(2))
+    assert torch.isfinite(lat).all() and torch.equal(lat, redo)
+    # kept region = the image posterior sample the call drew (mean +- a few std), not the noise it started from
+    z = (lat / MINI_VAE["scaling_factor"] - dist.mean) / dist.std
+    assert z[keep].abs().max() < 6.0 and z[~keep].abs().max() > z[keep].abs().max()
+
+    cfg9 = dict(TINY, in_channels=9)
+    pipe9 = StableDiffusionDenoiser(UNet2DConditionModel(cfg9, synth_unet_params(cfg9, seed=7)),
+                                    EulerDiscreteScheduler(timestep_spacing="leading", steps_offset=1, **sk), vae=vae)
+    img9 = pipe9(pe, num_inference_steps=8, guidance_scale=1.0, image=image, mask_image=mask, strength=0.75, generator=gen(3),
+                 output_type="pt")
+    assert img9.shape == (2, 3, 64, 64) and torch.isfinite(img9).all()
+
+    cfgl = dict(TINY, time_cond_proj_dim=32)
+    pipel = StableDiffusionDenoiser(UNet2DConditionModel(cfgl, synth_unet_params(cfgl, seed=5)), LCMScheduler(**sk), vae=vae)
+    il = pipel(pe, num_inference_steps=4, guidance_scale=8.0, height=64, width=64, vae_scale_factor=4, generator=gen(4), output_type="pt")
+    il2 = pipel(pe, num_inference_steps=4, guidance_scale=8.0, height=64, width=64, vae_scale_factor=4, generator=gen(4), output_type="pt")
+    assert il.shape == (2, 3, 64, 64) and torch.isfinite(il).all() and torch.equal(il, il2)
