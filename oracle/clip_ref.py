@@ -109,3 +109,64 @@ def clip_text_forward(P: Params, config: dict, input_ids: Tensor) -> dict:
     if cfg["with_projection"]:
         out["text_embeds"] = pooled @ P["text_projection.weight"]
     return out
+
+
+# --------------------------------------------------------------------------
+# vision tower: CLIPVisionModelWithProjection (the IP-Adapter image encoder)
+#   CLIPVisionEmbeddings modeling.py:162-196 (bias-free patch conv, class token, learned positions),
+#   CLIPVisionTransformer :896-953 (pre_layrnorm [sic] -> encoder (no mask) -> post_layernorm of the class-token row),
+#   CLIPVisionModelWithProjection :1300-1373 (visual_projection, no bias -> image_embeds)
+# --------------------------------------------------------------------------
+CLIP_VISION_DEFAULTS = dict(hidden_size=768, intermediate_size=3072, projection_dim=512, num_hidden_layers=12,
+                            num_attention_heads=12, num_channels=3, image_size=224, patch_size=32, hidden_act="quick_gelu",
+                            layer_norm_eps=1e-5)
+
+
+def clip_vision_param_shapes(config: dict) -> Dict[str, tuple]:
+    cfg = dict(CLIP_VISION_DEFAULTS, **{k: v for k, v in config.items() if not k.startswith("_")})
+    D, I, p = cfg["hidden_size"], cfg["intermediate_size"], cfg["patch_size"]
+    n_pos = (cfg["image_size"] // p) ** 2 + 1
+    S: Dict[str, tuple] = {"vision_model.embeddings.class_embedding": (D,),
+                           "vision_model.embeddings.patch_embedding.weight": (D, cfg["num_channels"], p, p),
+                           "vision_model.embeddings.position_embedding.weight": (n_pos, D),
+                           "vision_model.pre_layrnorm.weight": (D,), "vision_model.pre_layrnorm.bias": (D,)}
+    for i in range(cfg["num_hidden_layers"]):
+        b = f"vision_model.encoder.layers.{i}"
+        for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            S[f"{b}.self_attn.{nm}.weight"], S[f"{b}.self_attn.{nm}.bias"] = (D, D), (D,)
+        S[b + ".layer_norm1.weight"], S[b + ".layer_norm1.bias"] = (D,), (D,)
+        S[b + ".mlp.fc1.weight"], S[b + ".mlp.fc1.bias"] = (D, I), (I,)
+        S[b + ".mlp.fc2.weight"], S[b + ".mlp.fc2.bias"] = (I, D), (D,)
+        S[b + ".layer_norm2.weight"], S[b + ".layer_norm2.bias"] = (D,), (D,)
+    S["vision_model.post_layernorm.weight"], S["vision_model.post_layernorm.bias"] = (D,), (D,)
+    S["visual_projection.weight"] = (D, cfg["projection_dim"])
+    return S
+
+
+def clip_vision_forward(P: Params, config: dict, pixel_values: Tensor) -> dict:
+    cfg = dict(CLIP_VISION_DEFAULTS, **{k: v for k, v in config.items() if not k.startswith("_")})
+    D, H, eps = cfg["hidden_size"], cfg["num_attention_heads"], cfg["layer_norm_eps"]
+    d = D // H
+    B = pixel_values.shape[0]
+    lin = lambda n, x: x @ P[n + ".weight"] + P[n + ".bias"]  # noqa: E731
+    ln = lambda n, x: F.layer_norm(x, (D,), P[n + ".weight"], P[n + ".bias"], eps)  # noqa: E731
+    patches = F.conv2d(pixel_values.float(), P["vision_model.embeddings.patch_embedding.weight"], None,
+                       stride=cfg["patch_size"]).flatten(2).transpose(1, 2)
+    x = torch.cat([P["vision_model.embeddings.class_embedding"].expand(B, 1, D), patches], dim=1)
+    x = x + P["vision_model.embeddings.position_embedding.weight"][None]
+    x = ln("vision_model.pre_layrnorm", x)
+    S = x.shape[1]
+    hidden = [x]
+    for i in range(cfg["num_hidden_layers"]):
+        b = f"vision_model.encoder.layers.{i}"
+        h = ln(b + ".layer_norm1", x)
+        q = (lin(b + ".self_attn.q_proj", h) * d ** -0.5).reshape(B, S, H, d).transpose(1, 2)
+        k = lin(b + ".self_attn.k_proj", h).reshape(B, S, H, d).transpose(1, 2)
+        v = lin(b + ".self_attn.v_proj", h).reshape(B, S, H, d).transpose(1, 2)
+        o = (torch.softmax(q @ k.transpose(-1, -2), -1) @ v).transpose(1, 2).reshape(B, S, D)
+        x = x + lin(b + ".self_attn.out_proj", o)
+        x = x + lin(b + ".mlp.fc2", _act(cfg["hidden_act"], lin(b + ".mlp.fc1", ln(b + ".layer_norm2", x))))
+        hidden.append(x)
+    pooled = ln("vision_model.post_layernorm", x[:, 0])
+    return dict(last_hidden_state=x, pooler_output=pooled, hidden_states=tuple(hidden),
+                image_embeds=pooled @ P["visual_projection.weight"])

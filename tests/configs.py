@@ -72,3 +72,10 @@ MINI_DIT = dict(sample_size=16, num_layers=3, patch_size=2, attention_head_dim=3
                 out_channels=8, num_embeds_ada_norm=10)
 DIT_XL2 = dict(sample_size=32, num_layers=28, patch_size=2, attention_head_dim=72, num_attention_heads=16, in_channels=4,
                out_channels=8, num_embeds_ada_norm=1000)
+
+# CLIP vision towers (CLIPVisionModelWithProjection): a miniature with the awkward patch width of the real ones (3 * 14 * 14 = 588
+# input columns, not a multiple of 8) and OpenCLIP ViT-H/14, the image encoder the IP-Adapter checkpoints ship with
+MINI_CLIP_VISION = dict(hidden_size=64, intermediate_size=128, projection_dim=48, num_hidden_layers=2, num_attention_heads=2,
+                        num_channels=3, image_size=56, patch_size=14, hidden_act="quick_gelu")
+CLIP_VIT_H14 = dict(hidden_size=1280, intermediate_size=5120, projection_dim=1024, num_hidden_layers=32, num_attention_heads=16,
+                    num_channels=3, image_size=224, patch_size=14, hidden_act="gelu")

@@ -76,3 +76,36 @@ def test_with_projection_and_errors():
                                     _test_backend=Emulator())
     with pytest.raises(NotImplementedError):
         CLIPTextModel(dict(cfg, hidden_act="relu"), Pp, _test_backend=Emulator())
+
+
+def test_vision_tower_matches_oracle():
+    """CLIPVisionModelWithProjection (modeling.py:162-196, 896-953, 1300-1373): patch GEMM written in place into the token
+    buffer behind the constant class-token row, maskless encoder, post_layernorm of the class rows, visual_projection"""
+    from paddlemix_amd.clip import CLIPVisionModelWithProjection, clip_vision_param_shapes, synth_clip_vision_params
+    from tests.configs import CLIP_VIT_H14, MINI_CLIP_VISION
+    cfg = MINI_CLIP_VISION
+    assert clip_vision_param_shapes(cfg) == R.clip_vision_param_shapes(cfg)
+    assert list(clip_vision_param_shapes(cfg)) == list(R.clip_vision_param_shapes(cfg))
+    n = sum(torch.Size(v).numel() for v in clip_vision_param_shapes(CLIP_VIT_H14).values())
+    assert n == 632_076_800          # OpenCLIP ViT-H/14 vision tower + projection (the published 632 M)
+    P = synth_clip_vision_params(cfg, seed=4)
+    Pb = {k: (v.to(torch.bfloat16).float() if v.dim() > 1 else v) for k, v in P.items()}
+    Pb["vision_model.embeddings.class_embedding"] = P["vision_model.embeddings.class_embedding"]
+    x = torch.randn(2, 3, 56, 56, generator=torch.Generator().manual_seed(1))
+    model = CLIPVisionModelWithProjection(cfg, P, _test_backend=Emulator())
+    out = model(x, output_hidden_states=True)
+    ref = R.clip_vision_forward(Pb, cfg, x)
+    assert out.image_embeds.shape == (2, 48) and out.last_hidden_state.shape == (2, 17, 64)
+    assert _rel(out.image_embeds, ref["image_embeds"]) < 1.5e-2, _rel(out.image_embeds, ref["image_embeds"])
+    assert _rel(out.last_hidden_state, ref["last_hidden_state"]) < 1.5e-2
+    assert len(out.hidden_states) == 3 and _rel(out.hidden_states[0], ref["hidden_states"][0]) < 1e-2
+    assert torch.equal(model(x, return_dict=False)[0], out.image_embeds) and torch.equal(out[0], out.image_embeds)
+    # a second, different batch reuses the plan: the constant class-token rows and the zero pad columns survive
+    x2 = torch.randn(2, 3, 56, 56, generator=torch.Generator().manual_seed(2))
+    assert _rel(model(x2).image_embeds, R.clip_vision_forward(Pb, cfg, x2)["image_embeds"]) < 1.5e-2
+    with pytest.raises(ValueError):
+        model(torch.zeros(1, 3, 28, 28))
+    bad = dict(P)
+    bad.pop("visual_projection.weight")
+    with pytest.raises(KeyError):
+        CLIPVisionModelWithProjection(cfg, bad, _test_backend=Emulator())

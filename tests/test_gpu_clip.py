@@ -67,3 +67,44 @@ def test_clip_l_architecture():
     r = _rel(out.last_hidden_state, ref["last_hidden_state"])
     print(f"CLIP-L text encoder: rel-L2 vs oracle {r:.3e}")
     assert out.last_hidden_state.shape == (2, 77, 768) and r < 1.5e-2, r
+
+
+def _vision_params(cfg, seed):
+    from paddlemix_amd.clip import synth_clip_vision_params
+    return {k: (v.to(torch.bfloat16).float() if v.dim() > 1 else v) for k, v in synth_clip_vision_params(cfg, seed).items()}
+
+
+def test_mini_clip_vision_vs_oracle():
+    """CLIPVisionModelWithProjection: patch GEMM (588 -> 592 padded columns) written in place behind the constant class-token
+    row, maskless encoder, post_layernorm of the class rows, visual_projection"""
+    from paddlemix_amd.clip import CLIPVisionModelWithProjection
+    from tests.configs import MINI_CLIP_VISION
+    cfg = MINI_CLIP_VISION
+    P = _vision_params(cfg, 4)
+    x = torch.randn(2, 3, 56, 56, generator=torch.Generator().manual_seed(1))
+    model = CLIPVisionModelWithProjection(cfg, P)
+    out = model(x.cuda(), output_hidden_states=True)
+    ref = R.clip_vision_forward(P, cfg, x)
+    for name, a, b in (("embeddings", out.hidden_states[0], ref["hidden_states"][0]), ("last", out.last_hidden_state, ref["last_hidden_state"]),
+                       ("image_embeds", out.image_embeds, ref["image_embeds"])):
+        assert _rel(a, b) < 1.5e-2, (name, _rel(a, b))
+    x2 = torch.randn(2, 3, 56, 56, generator=torch.Generator().manual_seed(2))
+    assert _rel(model(x2.cuda()).image_embeds, R.clip_vision_forward(P, cfg, x2)["image_embeds"]) < 1.5e-2   # graph replay, new input
+    assert torch.equal(model(x.cuda()).image_embeds, out.image_embeds)
+    eager = CLIPVisionModelWithProjection(cfg, P, use_graph=False)(x.cuda())
+    assert torch.equal(eager.image_embeds, out.image_embeds)
+
+
+def test_clip_vit_h14_vision_architecture():
+    """OpenCLIP ViT-H/14 (32 layers, 1280 wide, 16 heads of 80, 257 tokens, 632 M parameters): the image encoder of the
+    IP-Adapter checkpoints; its image_embeds [B, 1024] are the UNet's added_cond_kwargs["image_embeds"]."""
+    from paddlemix_amd.clip import CLIPVisionModelWithProjection
+    from tests.configs import CLIP_VIT_H14
+    cfg = CLIP_VIT_H14
+    P = _vision_params(cfg, 11)
+    x = torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(3))
+    out = CLIPVisionModelWithProjection(cfg, P)(x.cuda())
+    ref = R.clip_vision_forward(P, cfg, x)
+    r, rl = _rel(out.image_embeds, ref["image_embeds"]), _rel(out.last_hidden_state, ref["last_hidden_state"])
+    print(f"CLIP ViT-H/14 vision tower: rel-L2 vs oracle image_embeds {r:.3e} last_hidden_state {rl:.3e}")
+    assert out.image_embeds.shape == (1, 1024) and torch.isfinite(out.image_embeds).all() and r < 2e-2 and rl < 2e-2, (r, rl)
