@@ -375,7 +375,8 @@ def unet_forward(P: Params, config: dict, sample: Tensor, timestep, encoder_hidd
                  encoder_attention_mask: Optional[Tensor] = None, processor: str = "math",
                  taps: Optional[dict] = None, down_block_additional_residuals=None,
                  mid_block_additional_residual: Optional[Tensor] = None, class_labels=None,
-                 timestep_cond: Optional[Tensor] = None, ip_adapter_scale: float = 1.0) -> Tensor:
+                 timestep_cond: Optional[Tensor] = None, ip_adapter_scale: float = 1.0,
+                 _controlnet_cond: Optional[Tensor] = None) -> Tensor:
     """Returns the noise prediction [B, out_channels, H, W] (the ``(sample,)`` tuple's first element).
 
     ``taps``: optional dict that receives named intermediate activations (for layer-wise parity tests).
@@ -436,6 +437,12 @@ def unet_forward(P: Params, config: dict, sample: Tensor, timestep, encoder_hidd
         img = layer_norm(P, "encoder_hid_proj.norm", img.reshape(B, T, enc.shape[-1]))
         enc = EncWithIP(torch.cat([enc, img], dim=1), T, ip_adapter_scale)
     x = conv2d(P, "conv_in", sample)
+    if _controlnet_cond is not None:   # ControlNetModel.forward (controlnet.py:806-811): + ControlNetConditioningEmbedding (:103-113)
+        e = F.silu(conv2d(P, "controlnet_cond_embedding.conv_in", _controlnet_cond.to(dtype)))
+        nb = sum(1 for k in P if k.startswith("controlnet_cond_embedding.blocks.") and k.endswith(".weight"))
+        for j in range(nb):
+            e = F.silu(conv2d(P, f"controlnet_cond_embedding.blocks.{j}", e, stride=2 if j % 2 else 1))
+        x = x + conv2d(P, "controlnet_cond_embedding.conv_out", e)
     if taps is not None:
         taps["conv_in"] = x
 
@@ -480,6 +487,9 @@ def unet_forward(P: Params, config: dict, sample: Tensor, timestep, encoder_hidd
         x = x + mid_block_additional_residual.to(dtype)   # (:1151-1155)
     if taps is not None:
         taps["mid"] = x
+    if _controlnet_cond is not None:   # zero convolutions on every skip and on the mid output (controlnet.py:842-852)
+        downs = tuple(conv2d(P, f"controlnet_down_blocks.{k}", s_, padding=0) for k, s_ in enumerate(skips))
+        return downs, conv2d(P, "controlnet_mid_block", x, padding=0)
 
     # up (:1158-1191)
     rev_heads = tuple(reversed(cfg["num_attention_heads"]))
@@ -644,3 +654,64 @@ def synth_unet_params(config: dict, seed: int = 1234, dtype=torch.float32) -> Pa
             t = torch.randn(shape, generator=g) / math.sqrt(fan_in)
         P[name] = t.to(dtype)
     return P
+
+
+# --------------------------------------------------------------------------
+# ControlNetModel  (PPD/models/controlnet.py:116-877): the UNet's conv_in / time embedding / down blocks / mid block with the
+# conditioning embedding added after conv_in and a 1x1 "zero convolution" on every skip tensor and on the mid output
+# --------------------------------------------------------------------------
+CONTROLNET_EXTRA_DEFAULTS = dict(conditioning_channels=3, conditioning_embedding_out_channels=(16, 32, 96, 256),
+                                 controlnet_conditioning_channel_order="rgb", global_pool_conditions=False)
+
+
+def _split_controlnet_config(config: dict):
+    extra = dict(CONTROLNET_EXTRA_DEFAULTS)
+    base = {}
+    for k, v in config.items():
+        (extra if k in CONTROLNET_EXTRA_DEFAULTS else base)[k] = v
+    extra["conditioning_embedding_out_channels"] = tuple(extra["conditioning_embedding_out_channels"])
+    return base, extra
+
+
+def controlnet_param_shapes(config: dict) -> Dict[str, tuple]:
+    """construction order of ControlNetModel.__init__ restricted to what forward reads: the UNet's encoder half, then the
+    conditioning embedding and the zero convolutions (controlnet.py:262-417)"""
+    base, extra = _split_controlnet_config(config)
+    cfg = normalize_config(base)
+    boc = cfg["block_out_channels"]
+    S = {k: v for k, v in unet_param_shapes(base).items()
+         if not k.startswith(("up_blocks.", "conv_norm_out.", "conv_out."))}
+    ch = extra["conditioning_embedding_out_channels"]
+    S["controlnet_cond_embedding.conv_in.weight"], S["controlnet_cond_embedding.conv_in.bias"] = (ch[0], extra["conditioning_channels"], 3, 3), (ch[0],)
+    for i in range(len(ch) - 1):
+        S[f"controlnet_cond_embedding.blocks.{2 * i}.weight"], S[f"controlnet_cond_embedding.blocks.{2 * i}.bias"] = (ch[i], ch[i], 3, 3), (ch[i],)
+        S[f"controlnet_cond_embedding.blocks.{2 * i + 1}.weight"], S[f"controlnet_cond_embedding.blocks.{2 * i + 1}.bias"] = (ch[i + 1], ch[i], 3, 3), (ch[i + 1],)
+    S["controlnet_cond_embedding.conv_out.weight"], S["controlnet_cond_embedding.conv_out.bias"] = (boc[0], ch[-1], 3, 3), (boc[0],)
+    k, c = 0, boc[0]
+    S[f"controlnet_down_blocks.{k}.weight"], S[f"controlnet_down_blocks.{k}.bias"] = (c, c, 1, 1), (c,)
+    for i in range(len(boc)):
+        c = boc[i]
+        for _ in range(cfg["layers_per_block"][i] + (1 if i != len(boc) - 1 else 0)):
+            k += 1
+            S[f"controlnet_down_blocks.{k}.weight"], S[f"controlnet_down_blocks.{k}.bias"] = (c, c, 1, 1), (c,)
+    S["controlnet_mid_block.weight"], S["controlnet_mid_block.bias"] = (boc[-1], boc[-1], 1, 1), (boc[-1],)
+    return S
+
+
+def controlnet_forward(P: Params, config: dict, sample: Tensor, timestep, encoder_hidden_states: Tensor,
+                       controlnet_cond: Tensor, conditioning_scale: float = 1.0, guess_mode: bool = False,
+                       added_cond_kwargs: Optional[dict] = None, class_labels=None):
+    """-> (down_block_res_samples tuple, mid_block_res_sample) (controlnet.py:671-877; scaling :854-869)"""
+    base, extra = _split_controlnet_config(config)
+    if extra["controlnet_conditioning_channel_order"] == "bgr":
+        controlnet_cond = torch.flip(controlnet_cond, dims=[1])
+    elif extra["controlnet_conditioning_channel_order"] != "rgb":
+        raise ValueError(f"unknown `controlnet_conditioning_channel_order`: {extra['controlnet_conditioning_channel_order']}")
+    if extra["global_pool_conditions"]:
+        raise NotImplementedError("oracle: global_pool_conditions")
+    downs, mid = unet_forward(P, base, sample, timestep, encoder_hidden_states, added_cond_kwargs=added_cond_kwargs,
+                              class_labels=class_labels, _controlnet_cond=controlnet_cond)
+    if guess_mode:
+        scales = torch.logspace(-1, 0, len(downs) + 1) * conditioning_scale
+        return tuple(d * sc for d, sc in zip(downs, scales)), mid * scales[-1]
+    return tuple(d * conditioning_scale for d in downs), mid * conditioning_scale

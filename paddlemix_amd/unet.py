@@ -106,7 +106,7 @@ def normalize_config(config: Mapping) -> dict:
 # ---------------------------------------------------------------------------------------------------------------
 # structure walk shared by the parameter inventory and the program builder
 # ---------------------------------------------------------------------------------------------------------------
-def _structure(cfg: dict) -> List[tuple]:
+def _structure(cfg: dict, encoder_only: bool = False) -> List[tuple]:
     """Layer descriptors in execution order.
     ('resnet', name, cin, cout, scale) | ('attn', name, C, heads, layers, cross) | ('skip',) |
     ('down', name, C) | ('up', name, C) | ('cat', skip_channels)"""
@@ -130,6 +130,8 @@ def _structure(cfg: dict) -> List[tuple]:
     L.append(("attn", "mid_block.attentions.0", boc[-1], cfg["num_attention_heads"][-1],
               cfg["transformer_layers_per_block"][-1], cfg["cross_attention_dim"][-1]))
     L.append(("resnet", "mid_block.resnets.1", boc[-1], boc[-1], ms))
+    if encoder_only:   # ControlNetModel: conv_in skip, down blocks, mid block
+        return L
     rboc = tuple(reversed(boc))
     rlayers = tuple(reversed(cfg["layers_per_block"]))
     rtl = tuple(reversed(cfg["transformer_layers_per_block"]))
@@ -286,10 +288,15 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
         self.config = SimpleNamespace(**pub)
         self._load_weights(params)
 
+    _encoder_only = False   # ControlNetModel: stop after the mid block
+
+    def _shapes(self) -> Dict[str, tuple]:
+        return unet_param_shapes(self.cfg)
+
     # ------------------------------------------------------------------ weights
     def _load_weights(self, params: Mapping[str, Tensor]) -> None:
         cfg, dev = self.cfg, self.device
-        shapes = unet_param_shapes(cfg)
+        shapes = self._shapes()
         missing = [k for k in shapes if k not in params]
         if missing:
             raise KeyError(f"missing parameters: {missing[:5]}{'...' if len(missing) > 5 else ''}")
@@ -360,7 +367,7 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
         kv_w: List[Tensor] = []            # every cross-attention to_k / to_v, batched into one GEMM per step
         self._kv_off: Dict[str, int] = {}
         kv_off = 0
-        for d in _structure(cfg):
+        for d in _structure(cfg, self._encoder_only):
             if d[0] == "resnet":
                 _, name, cin, cout, _ = d
                 put_norm(name + ".norm1", name + ".norm1")
@@ -427,6 +434,9 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
         W["temb_all.w"] = bf(torch.cat(temb_w, 0))
         W["temb_all.b"] = torch.cat(temb_b, 0).contiguous()
         self._temb_total = off
+        if self._encoder_only:
+            self._load_extra(get, bf, put_conv)
+            return
         put_norm("conv_norm_out", "conv_norm_out")
         w = get("conv_out.weight")
         W["conv_out.w"] = bf(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1))
@@ -470,7 +480,7 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
                   R.p if R else None, R.ld if R else 0, out_scale, flags, stream), "gemm", 2.0 * a.rows * N * K,
                  f"{a.rows}x{N}x{K}" + ("g" if flags & GEGLU else ""))
 
-        def conv3(x: _V, h, w_, wkey, out: _V, stride=1, up=0, rowbias=None, R: Optional[_V] = None, out_scale=1.0):
+        def conv3(x: _V, h, w_, wkey, out: _V, stride=1, up=0, rowbias=None, R: Optional[_V] = None, out_scale=1.0, flags=0):
             w = W[wkey + ".w"]
             Cout = w.shape[0]
             ho = ((h << up) + 2 - 3) // stride + 1
@@ -478,7 +488,7 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
             emit(lib.mi355x_sd_conv3x3,
                  (x.p, x.ld, B, h, w_, x.C, stride, up, w.data_ptr(), out.p, out.ld, Cout, W[wkey + ".b"].data_ptr(),
                   rowbias, self._temb_total if rowbias is not None else 0, R.p if R else None, R.ld if R else 0,
-                  out_scale, 0, stream), "conv", 2.0 * B * ho * wo * Cout * 9 * x.C,
+                  out_scale, flags, stream), "conv", 2.0 * B * ho * wo * Cout * 9 * x.C,
                  f"{B * ho * wo}x{Cout}x{9 * x.C}" + ("s2" if stride == 2 else "") + ("up" if up else ""))
 
         def gnorm(x: _V, hw, nkey, eps_, silu) -> _V:
@@ -622,7 +632,7 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
             linear(tok, "kvip_all", kvip_all, bias=False)
 
         # ---- skip / concat buffers: pre-walk ----
-        S = _structure(cfg)
+        S = _structure(cfg, self._encoder_only)
         skips: List[Tuple[int, int, int]] = []  # (C, h, w) in production order
         h, w_ = H, Wd
         c_cur = boc[0]
@@ -636,7 +646,9 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
             elif d[0] == "cat":
                 break
         ups = [d for d in S if d[0] == "resnet" and d[1].startswith("up_blocks.")]
-        assert len(ups) == len(skips)
+        assert len(ups) == len(skips) or self._encoder_only
+        own_skips = [_V(persist((B * hs * ws_, cs), _lib.elem_dtype()).data_ptr(), B * hs * ws_, cs)
+                     for cs, hs, ws_ in skips] if self._encoder_only else None   # no up path to host them
         cats: List[_V] = []
         cat_xc: List[int] = []
         for u, d in enumerate(ups):  # up resnet u consumes skip n-1-u
@@ -647,6 +659,8 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
             cat_xc.append(cx)
 
         def skip_slot(k: int) -> _V:  # where skip k is produced
+            if own_skips is not None:
+                return own_skips[k]
             u = len(skips) - 1 - k
             return cats[u].cols(cat_xc[u], cats[u].C - cat_xc[u])
 
@@ -717,6 +731,8 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
         emit(lib.mi355x_sd_conv_in3x3, (plan.sample.data_ptr(), plan.in_scale.data_ptr(), wp("conv_in.w"),
                                         wp("conv_in.b"), cur.p, B, cfg["in_channels"], H, Wd, boc[0], cur.ld, stream),
              "misc")
+        if self._encoder_only:
+            self._emit_pre(plan, cur, B, H, Wd, persist, emit, conv3)
         k = 1
         tmp_i = 0
 
@@ -775,12 +791,15 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
                 h, w_ = 2 * h, 2 * w_
                 cur = dst
             i += 1
-        assert k == len(skips) and u == len(ups) and (h, w_) == (H, Wd)
+        assert k == len(skips) and u == len(ups) and ((h, w_) == (H, Wd) or self._encoder_only)
 
-        # ---- post (unet_2d_condition.py:1193-1196) ----
-        g = gnorm(cur, H * Wd, "conv_norm_out", eps, True)
-        emit(lib.mi355x_sd_conv_out3x3, (g.p, g.ld, wp("conv_out.w"), wp("conv_out.b"), plan.out.data_ptr(), B, g.C, H,
-                                         Wd, cfg["out_channels"], stream), "misc")
+        if self._encoder_only:
+            self._emit_post(plan, [skip_slot(kk) for kk in range(len(skips))], skips, cur, h, w_, B, persist, emit, linear, sc)
+        else:
+            # ---- post (unet_2d_condition.py:1193-1196) ----
+            g = gnorm(cur, H * Wd, "conv_norm_out", eps, True)
+            emit(lib.mi355x_sd_conv_out3x3, (g.p, g.ld, wp("conv_out.w"), wp("conv_out.b"), plan.out.data_ptr(), B, g.C, H,
+                                             Wd, cfg["out_channels"], stream), "misc")
 
         # ---- allocate scratch, resolve addresses ----
         bufs = {n: persist((max(nb, 16),), torch.uint8) for n, nb in scratch.items()}
@@ -933,5 +952,200 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
         if not return_dict:
             return (out,)
         return UNet2DConditionOutput(sample=out)
+
+    __call__ = forward
+
+
+# ---------------------------------------------------------------------------------------------------------------- ControlNet
+CONTROLNET_EXTRA_DEFAULTS = dict(conditioning_channels=3, conditioning_embedding_out_channels=(16, 32, 96, 256),
+                                 controlnet_conditioning_channel_order="rgb", global_pool_conditions=False)
+
+
+def _split_controlnet_config(config: Mapping):
+    extra, base = dict(CONTROLNET_EXTRA_DEFAULTS), {}
+    for k, v in config.items():
+        if k.startswith("_"):
+            continue
+        (extra if k in CONTROLNET_EXTRA_DEFAULTS else base)[k] = v
+    extra["conditioning_embedding_out_channels"] = tuple(extra["conditioning_embedding_out_channels"])
+    if any(c % 8 for c in extra["conditioning_embedding_out_channels"]):
+        raise ValueError("conditioning_embedding_out_channels must be multiples of 8")
+    if extra["global_pool_conditions"]:
+        raise NotImplementedError("ControlNetModel(mi355x): global_pool_conditions is not implemented")
+    if extra["controlnet_conditioning_channel_order"] not in ("rgb", "bgr"):
+        raise ValueError(f"unknown `controlnet_conditioning_channel_order`: {extra['controlnet_conditioning_channel_order']}")
+    return base, extra
+
+
+def controlnet_param_shapes(config: Mapping) -> Dict[str, tuple]:
+    """name -> shape (Paddle layouts) of what ControlNetModel.forward reads (controlnet.py:262-417): the UNet's encoder half,
+    the conditioning embedding (:81-101) and one 1x1 "zero convolution" per skip tensor plus one for the mid output."""
+    base, extra = _split_controlnet_config(config)
+    cfg = normalize_config(base)
+    boc = cfg["block_out_channels"]
+    S = {k: v for k, v in unet_param_shapes(base).items() if not k.startswith(("up_blocks.", "conv_norm_out.", "conv_out."))}
+
+    def conv(name, i, o, k):
+        S[name + ".weight"], S[name + ".bias"] = (o, i, k, k), (o,)
+
+    ch = extra["conditioning_embedding_out_channels"]
+    conv("controlnet_cond_embedding.conv_in", extra["conditioning_channels"], ch[0], 3)
+    for i in range(len(ch) - 1):
+        conv(f"controlnet_cond_embedding.blocks.{2 * i}", ch[i], ch[i], 3)
+        conv(f"controlnet_cond_embedding.blocks.{2 * i + 1}", ch[i], ch[i + 1], 3)
+    conv("controlnet_cond_embedding.conv_out", ch[-1], boc[0], 3)
+    k = 0
+    conv("controlnet_down_blocks.0", boc[0], boc[0], 1)
+    for i, c in enumerate(boc):
+        for _ in range(cfg["layers_per_block"][i] + (1 if i != len(boc) - 1 else 0)):
+            k += 1
+            conv(f"controlnet_down_blocks.{k}", c, c, 1)
+    conv("controlnet_mid_block", boc[-1], boc[-1], 1)
+    return S
+
+
+def synth_controlnet_params(config: Mapping, seed: int = 1234, device="cpu") -> Dict[str, Tensor]:
+    """random init like synth_unet_params (a trained ControlNet's zero convolutions are no longer zero either)"""
+    g = torch.Generator(device=device).manual_seed(seed)
+    P: Dict[str, Tensor] = {}
+    for name, shape in controlnet_param_shapes(config).items():
+        r = torch.randn(shape, generator=g, device=device)
+        if name.endswith(".bias"):
+            t = r * 0.02
+        elif len(shape) == 1:
+            t = 1.0 + r * 0.02
+        elif len(shape) == 2:
+            t = r / shape[0] ** 0.5
+        else:
+            t = r / (shape[1] * shape[2] * shape[3]) ** 0.5
+        P[name] = t
+    return P
+
+
+class ControlNetOutput(SimpleNamespace):
+    """``down_block_res_samples`` (tuple) and ``mid_block_res_sample`` (controlnet.py:46-68)"""
+
+
+class ControlNetModel(UNet2DConditionModel):
+    """ControlNetModel.forward (PPD/models/controlnet.py:671-877) on the UNet's program: conv_in + conditioning embedding
+    (3x3 convs with SiLU epilogues, the last one adding onto conv_in's output in place), the down blocks and the mid block
+    exactly as in the UNet, then a 1x1 GEMM per skip tensor / mid output with ``conditioning_scale`` as its output scale,
+    returned as the fp32 NCHW tensors ``UNet2DConditionModel.forward`` takes as ``down_block_additional_residuals`` /
+    ``mid_block_additional_residual``."""
+    _encoder_only = True
+    _param_shapes = staticmethod(controlnet_param_shapes)
+
+    def __init__(self, config: Mapping, params: Mapping[str, Tensor], **kw):
+        base, self._extra = _split_controlnet_config(config)
+        self._full_config = {k: v for k, v in config.items() if not k.startswith("_")}
+        self._cn_key = (1.0, False)
+        super().__init__(base, params, **kw)
+        for k, v in self._extra.items():
+            setattr(self.config, k, v)
+
+    def _shapes(self) -> Dict[str, tuple]:
+        return controlnet_param_shapes(self._full_config)
+
+    def _load_extra(self, get, bf, put_conv) -> None:
+        W, ch = self.w, self._extra["conditioning_embedding_out_channels"]
+        w = get("controlnet_cond_embedding.conv_in.weight")           # -> [ky][kx][ci][O], the conv_in kernel's layout
+        if self._extra["controlnet_conditioning_channel_order"] == "bgr":
+            w = torch.flip(w, dims=[1])                               # flipping the input channels = flipping the weight's
+        W["cn.conv_in.w"] = bf(w.permute(2, 3, 1, 0).reshape(-1, w.shape[0]))
+        W["cn.conv_in.b"] = get("controlnet_cond_embedding.conv_in.bias").contiguous()
+        for j in range(2 * (len(ch) - 1)):
+            put_conv(f"cn.blocks.{j}", f"controlnet_cond_embedding.blocks.{j}")
+        put_conv("cn.conv_out", "controlnet_cond_embedding.conv_out")
+        k = 0
+        while f"controlnet_down_blocks.{k}.weight" in self._shapes():
+            put_conv(f"cn.down.{k}", f"controlnet_down_blocks.{k}")
+            k += 1
+        self._n_down = k
+        put_conv("cn.mid", "controlnet_mid_block")
+
+    def _emit_pre(self, plan, x0: _V, B, H, Wd, persist, emit, conv3) -> None:
+        """ControlNetConditioningEmbedding.forward (controlnet.py:103-113) + ``sample = conv_in(sample) + cond`` (:807-810)"""
+        lib, W, stream = self._lib, self.w, self._stream_ptr
+        ch = self._extra["conditioning_embedding_out_channels"]
+        f = 1 << (len(ch) - 1)
+        hc, wc = H * f, Wd * f
+        plan.cond = persist((B, self._extra["conditioning_channels"], hc, wc), torch.float32)
+        bufs = [persist((B * hc * wc * ch[0],), _lib.elem_dtype()), persist((B * hc * wc * ch[0],), _lib.elem_dtype())]
+        e = _V(bufs[0].data_ptr(), B * hc * wc, ch[0])
+        emit(lib.mi355x_sd_conv_in3x3, (plan.cond.data_ptr(), None, W["cn.conv_in.w"].data_ptr(), W["cn.conv_in.b"].data_ptr(),
+                                        e.p, B, self._extra["conditioning_channels"], hc, wc, ch[0], e.ld, stream), "misc")
+        emit(lib.mi355x_sd_silu, (e.p, e.p, B * hc * wc * ch[0], 0, 0, stream), "misc")
+        which = 0
+        for i in range(len(ch) - 1):
+            for j, (cout, stride) in enumerate(((ch[i], 1), (ch[i + 1], 2))):
+                ho, wo = (hc + 2 - 3) // stride + 1, (wc + 2 - 3) // stride + 1
+                which ^= 1
+                out = _V(bufs[which].data_ptr(), B * ho * wo, cout)
+                conv3(e, hc, wc, f"cn.blocks.{2 * i + j}", out, stride=stride, flags=SILU)
+                e, hc, wc = out, ho, wo
+        assert (hc, wc) == (H, Wd)
+        conv3(e, hc, wc, "cn.conv_out", x0, R=x0)
+
+    def _emit_post(self, plan, slots, skips, mid: _V, hm, wm, B, persist, emit, linear, sc) -> None:
+        """zero convolutions + scaling (controlnet.py:842-869) -> fp32 NCHW residuals"""
+        lib, stream = self._lib, self._stream_ptr
+        scale, guess = self._cn_key
+        n = len(slots)
+        if n != self._n_down:
+            raise ValueError(f"checkpoint has {self._n_down} controlnet_down_blocks, the configuration produces {n} skips")
+        scales = [scale] * (n + 1)
+        if guess:   # paddle.logspace(-1, 0, n + 1) * conditioning_scale (:855-859)
+            scales = [float(v) * scale for v in torch.logspace(-1, 0, n + 1)]
+        plan.ctrl_out = []
+        for k, (sl, (cs, hs, ws_)) in enumerate(list(zip(slots, skips)) + [(mid, (mid.C, hm, wm))]):
+            key = f"cn.down.{k}" if k < n else "cn.mid"
+            rows = _V(sc("cn_rows", 2 * sl.rows * cs), sl.rows, cs)
+            linear(sl, key, rows, out_scale=scales[k])
+            out = persist((B, cs, hs, ws_), torch.float32)
+            emit(lib.mi355x_sd_unpatchify, (rows.p, rows.ld, B, cs, hs, ws_, 1, out.data_ptr(), stream), "misc")
+            plan.ctrl_out.append(out)
+
+    def _get_plan(self, B, H, W, L, masked: bool = False, controlnet: bool = False) -> _Plan:
+        key = (B, H, W, L, masked) + self._cn_key
+        if key not in self._plans:
+            self._plans[key] = self._build_plan(B, H, W, L, masked, False)
+        return self._plans[key]
+
+    def forward(self, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale: float = 1.0,
+                class_labels=None, timestep_cond=None, attention_mask=None, added_cond_kwargs=None,
+                cross_attention_kwargs=None, guess_mode: bool = False, return_dict: bool = True,
+                encoder_attention_mask=None):
+        if attention_mask is not None or cross_attention_kwargs:
+            raise NotImplementedError("ControlNetModel(mi355x): attention_mask / cross_attention_kwargs are not implemented")
+        if not isinstance(conditioning_scale, (int, float)):
+            raise NotImplementedError("per-residual conditioning_scale lists are not implemented (a float is)")
+        if not self._emulated and not (sample.is_cuda and encoder_hidden_states.is_cuda and controlnet_cond.is_cuda):
+            raise _lib.MI355XError("inputs must be GPU tensors (no CPU fallback)")
+        B, _, H, W = sample.shape
+        self._cn_key = (float(conditioning_scale), bool(guess_mode))
+        plan = self._get_plan(B, H, W, encoder_hidden_states.shape[1], encoder_attention_mask is not None)
+        if tuple(controlnet_cond.shape) != tuple(plan.cond.shape):
+            raise ValueError(f"controlnet_cond of shape {tuple(controlnet_cond.shape)}, expected {tuple(plan.cond.shape)}")
+
+        def stage(nb):
+            self.stage_inputs(plan, sample, timestep, encoder_hidden_states, added_cond_kwargs,
+                              encoder_attention_mask=encoder_attention_mask, class_labels=class_labels,
+                              timestep_cond=timestep_cond)
+            plan.cond.copy_(controlnet_cond, non_blocking=nb)
+
+        if self._emulated:
+            stage(False)
+            self._run_eager(plan)
+        else:
+            cur = torch.cuda.current_stream(self.device)
+            self._stream.wait_stream(cur)
+            with torch.cuda.stream(self._stream):
+                stage(True)
+                self.run(plan)
+            cur.wait_stream(self._stream)
+        outs = [t.clone() for t in plan.ctrl_out]
+        if not return_dict:
+            return tuple(outs[:-1]), outs[-1]
+        return ControlNetOutput(down_block_res_samples=tuple(outs[:-1]), mid_block_res_sample=outs[-1])
 
     __call__ = forward

@@ -286,3 +286,37 @@ def test_img2img_inpaint_lcm_pipelines_on_device():
     il = pipel(pe, num_inference_steps=4, guidance_scale=8.0, height=64, width=64, vae_scale_factor=4, generator=gen(4), output_type="pt")
     il2 = pipel(pe, num_inference_steps=4, guidance_scale=8.0, height=64, width=64, vae_scale_factor=4, generator=gen(4), output_type="pt")
     assert il.shape == (2, 3, 64, 64) and torch.isfinite(il).all() and torch.equal(il, il2)
+
+
+@pytest.mark.parametrize("base", ["TINY", "MINI_XL"])
+def test_controlnet_on_device(base):
+    """ControlNetModel (controlnet.py:671-877) through the C ABI: SiLU-epilogue convs of the conditioning embedding, the
+    UNet's encoder half, zero-convolution GEMMs with conditioning_scale as output scale -> fp32 NCHW residuals; then the
+    residuals into the UNet (unet_2d_condition.py:1121-1155)."""
+    from paddlemix_amd.unet import ControlNetModel, UNet2DConditionModel, synth_controlnet_params
+    from tests import configs
+    cfg = getattr(configs, base)
+    P = {k: (v.to(torch.bfloat16).float() if v.dim() > 1 else v) for k, v in synth_controlnet_params(cfg, 3).items()}
+    sample, enc, added = _inputs(cfg, 2, 16, 16, 7 if base == "TINY" else 77)
+    cond = torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(4))
+    net = ControlNetModel(cfg, P)
+    worst = 0.0
+    for sc, gm in ((1.0, False), (0.6, True)):
+        out = net(_cuda(sample), 20, _cuda(enc), cond.cuda(), conditioning_scale=sc, guess_mode=gm, added_cond_kwargs=_cuda(added))
+        downs, mid = U.controlnet_forward(P, cfg, sample, 20, enc, cond, sc, gm, added_cond_kwargs=added)
+        for a, b in zip(out.down_block_res_samples + (out.mid_block_res_sample,), downs + (mid,)):
+            assert a.shape == b.shape and a.dtype == torch.float32
+            worst = max(worst, _rel(a.cpu(), b))
+    print(f"controlnet {base}: worst rel-L2 of a residual vs oracle {worst:.3e}")
+    assert worst < 2e-2, worst
+    d, m = net(_cuda(sample), 20, _cuda(enc), cond.cuda(), added_cond_kwargs=_cuda(added), return_dict=False)
+    d2, m2 = net(_cuda(sample), 20, _cuda(enc), cond.cuda(), added_cond_kwargs=_cuda(added), return_dict=False)
+    assert all(torch.equal(a, b) for a, b in zip(d + (m,), d2 + (m2,)))          # graph replay is deterministic
+    Pu = _bf16_params(cfg, "cpu")
+    unet = UNet2DConditionModel(cfg, Pu)
+    got = unet(_cuda(sample), 20, _cuda(enc), added_cond_kwargs=_cuda(added), down_block_additional_residuals=d,
+               mid_block_additional_residual=m).sample.cpu()
+    rd, rm = U.controlnet_forward(P, cfg, sample, 20, enc, cond, added_cond_kwargs=added)
+    ref = U.unet_forward(Pu, cfg, sample, 20, enc, added_cond_kwargs=added, down_block_additional_residuals=rd,
+                         mid_block_additional_residual=rm)
+    assert _rel(got, ref) < 2e-2, _rel(got, ref)

@@ -158,6 +158,47 @@ def test_ip_adapter_matches_oracle():
         unet_param_shapes(dict(TINY, encoder_hid_dim_type="text_proj", encoder_hid_dim=32))
 
 
+def test_controlnet_matches_oracle_and_feeds_the_unet():
+    """ControlNetModel.forward (controlnet.py:671-877): conditioning embedding + encoder half + zero convolutions, and its
+    outputs as the UNet's down_block_additional_residuals / mid_block_additional_residual (unet_2d_condition.py:1121-1155)"""
+    from paddlemix_amd.unet import ControlNetModel, controlnet_param_shapes, synth_controlnet_params
+    for cfg in (TINY, MINI_XL):
+        assert list(controlnet_param_shapes(cfg).items()) == list(U.controlnet_param_shapes(cfg).items())
+    # SD-1.5 ControlNet: 361 279 120 parameters (the published sd-controlnet checkpoints)
+    assert sum(torch.Size(v).numel() for v in controlnet_param_shapes(SD15).values()) == 361_279_120
+    cfg = dict(TINY, controlnet_conditioning_channel_order="bgr")
+    P = synth_controlnet_params(cfg, seed=3)
+    Pb = {k: v.to(torch.bfloat16).float() if v.dim() > 1 else v for k, v in P.items()}
+    sample, enc, _ = _inputs(TINY, 2, 16, 16, 7)
+    cond = torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(4))
+    net = ControlNetModel(cfg, P, _test_backend=Emulator())
+    assert net.config.conditioning_embedding_out_channels == (16, 32, 96, 256) and net.config.in_channels == 4
+    for sc, gm in ((1.0, False), (0.6, True)):
+        out = net(sample, 20, enc, cond, conditioning_scale=sc, guess_mode=gm)
+        downs, mid = U.controlnet_forward(Pb, cfg, sample, 20, enc, cond, sc, gm)
+        assert len(out.down_block_res_samples) == len(downs) == 6
+        for a, b in zip(out.down_block_res_samples + (out.mid_block_res_sample,), downs + (mid,)):
+            assert a.shape == b.shape and a.dtype == torch.float32 and _rel(a, b) < 2e-2, _rel(a, b)
+    d2, m2 = net(sample, 20, enc, cond, return_dict=False)
+    Pu = synth_unet_params(TINY, seed=9)
+    unet = UNet2DConditionModel(TINY, Pu, _test_backend=Emulator())
+    got = unet(sample, 20, enc, down_block_additional_residuals=d2, mid_block_additional_residual=m2).sample
+    Pub = {k: v.to(torch.bfloat16).float() if v.dim() > 1 else v for k, v in Pu.items()}
+    rd, rm = U.controlnet_forward(Pb, cfg, sample, 20, enc, cond)
+    ref = U.unet_forward(Pub, TINY, sample, 20, enc, down_block_additional_residuals=rd, mid_block_additional_residual=rm)
+    assert _rel(got, ref) < 2e-2 and _rel(got, unet(sample, 20, enc).sample) > 1e-2
+    with pytest.raises(ValueError, match="controlnet_cond of shape"):
+        net(sample, 20, enc, cond[:, :, :64, :64])
+    with pytest.raises(NotImplementedError):
+        net(sample, 20, enc, cond, conditioning_scale=[1.0] * 7)
+    with pytest.raises(NotImplementedError):
+        ControlNetModel(dict(TINY, global_pool_conditions=True), P, _test_backend=Emulator())
+    bad = dict(P)
+    bad.pop("controlnet_mid_block.weight")
+    with pytest.raises(KeyError):
+        ControlNetModel(cfg, bad, _test_backend=Emulator())
+
+
 def test_param_inventory_matches_oracle():
     for cfg in (TINY, MINI_XL, SD15, SDXL):
         a, b = unet_param_shapes(cfg), U.unet_param_shapes(cfg)
