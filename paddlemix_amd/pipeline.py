@@ -28,9 +28,10 @@ def rescale_noise_cfg(noise_cfg, noise_pred_text, guidance_rescale=0.0):
 class StableDiffusionDenoiser:
     """``pipe = StableDiffusionDenoiser(unet, scheduler); latents = pipe(prompt_embeds=..., ...)``"""
 
-    def __init__(self, unet, scheduler, vae=None, text_encoder=None, text_encoder_2=None):
+    def __init__(self, unet, scheduler, vae=None, text_encoder=None, text_encoder_2=None, controlnet=None):
         self.unet, self.scheduler, self.vae = unet, scheduler, vae
         self.text_encoder, self.text_encoder_2 = text_encoder, text_encoder_2
+        self.controlnet = controlnet   # ControlNetModel: StableDiffusionControlNetPipeline (controlnet/pipeline_controlnet.py)
 
     def encode_prompt(self, input_ids: torch.Tensor, input_ids_2: Optional[torch.Tensor] = None,
                       clip_skip: Optional[int] = None):
@@ -204,7 +205,9 @@ class StableDiffusionDenoiser:
                  negative_prompt_ids_2: Optional[torch.Tensor] = None, original_size=None,
                  crops_coords_top_left=(0, 0), target_size=None, fused_update: bool = True,
                  image: Optional[torch.Tensor] = None, strength: Optional[float] = None, eta: float = 0.0,
-                 mask_image: Optional[torch.Tensor] = None, masked_image_latents: Optional[torch.Tensor] = None):
+                 mask_image: Optional[torch.Tensor] = None, masked_image_latents: Optional[torch.Tensor] = None,
+                 control_image: Optional[torch.Tensor] = None, controlnet_conditioning_scale: float = 1.0,
+                 guess_mode: bool = False):
         """``image`` (extension of the text2img call = StableDiffusionImg2ImgPipeline.__call__,
         pipeline_stable_diffusion_img2img.py:735-1010): start from the encoded, re-noised image and run the last
         ``int(num_inference_steps * strength)`` steps (strength defaults to 0.8).
@@ -284,6 +287,24 @@ class StableDiffusionDenoiser:
         fused = self._fused_plan(guidance_rescale, latents.device) if fused_update and not eta else None
         nine = inp is not None and cfg.in_channels != latents.shape[1]
 
+        def control(x_in, t):
+            """ControlNet residuals of this step (pipeline_controlnet.py:1148-1192): the ControlNet sees the UNet's input batch
+            -- or, in guess mode under CFG, only the conditional half, the unconditional half getting zero residuals"""
+            if control_image is None:
+                return {}
+            if self.controlnet is None:
+                raise ValueError("`control_image` needs a `controlnet`")
+            half = guess_mode and do_cfg
+            pick = (lambda v: v.chunk(2)[1]) if half else (lambda v: v)
+            img = control_image if (half or not do_cfg) else torch.cat([control_image] * 2)
+            added = None if added_cond_kwargs is None else {k: pick(v) for k, v in added_cond_kwargs.items()}
+            d, m = self.controlnet(pick(x_in)[:, :latents.shape[1]], t, encoder_hidden_states=pick(prompt_embeds),
+                                   controlnet_cond=img, conditioning_scale=controlnet_conditioning_scale,
+                                   guess_mode=guess_mode, added_cond_kwargs=added, return_dict=False)
+            if half:
+                d, m = tuple(torch.cat([torch.zeros_like(x), x]) for x in d), torch.cat([torch.zeros_like(m), m])
+            return dict(down_block_additional_residuals=d, mid_block_additional_residual=m)
+
         def extend(x):   # 9-channel inpainting UNet: [scaled latents | mask | masked-image latents] (:1194-1198)
             return torch.cat([x, inp["mask_in"], inp["masked_in"]], dim=1) if nine else x
 
@@ -302,8 +323,9 @@ class StableDiffusionDenoiser:
                 # guidance combine + scheduler update as ONE device pass over the latents (mi355x_sd_cfg_axpby): the
                 # epsilon-prediction step of Euler / DDIM(eta=0) is prev = a*x + b*eps with per-step (a, b) kept in HBM
                 scales, coef, lib, stream = fused
-                noise_pred = self.unet(extend(latent_model_input * scales[i]), t, encoder_hidden_states=prompt_embeds,
-                                       added_cond_kwargs=added_cond_kwargs, return_dict=False, **unet_kw)[0]
+                scaled = latent_model_input * scales[i]
+                noise_pred = self.unet(extend(scaled), t, encoder_hidden_states=prompt_embeds,
+                                       added_cond_kwargs=added_cond_kwargs, return_dict=False, **unet_kw, **control(scaled, t))[0]
                 lat = latents.contiguous()
                 out = torch.empty_like(lat)
                 n, cp = lat.numel(), coef.data_ptr() + 8 * i
@@ -322,7 +344,8 @@ class StableDiffusionDenoiser:
                 continue
             latent_model_input = self.scheduler.scale_model_input(latent_model_input, t)
             noise_pred = self.unet(extend(latent_model_input), t, encoder_hidden_states=prompt_embeds,
-                                   added_cond_kwargs=added_cond_kwargs, return_dict=False, **unet_kw)[0]
+                                   added_cond_kwargs=added_cond_kwargs, return_dict=False, **unet_kw,
+                                   **control(latent_model_input, t))[0]
             if do_cfg:
                 noise_uncond, noise_text = noise_pred.chunk(2)
                 noise_pred = noise_uncond + guidance_scale * (noise_text - noise_uncond)

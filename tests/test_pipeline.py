@@ -420,3 +420,47 @@ def test_inpaint_loops_match_oracle_loops():
                                                        _test_backend=Emulator()), DDIMScheduler(**kw), vae=vae)
     with pytest.raises(ValueError, match="Incorrect configuration"):
         bad(pe, num_inference_steps=2, guidance_scale=1.0, image=image, mask_image=mask_px)
+
+
+def test_controlnet_loop_matches_oracle_loop():
+    """StableDiffusionControlNetPipeline's loop (controlnet/pipeline_controlnet.py:1148-1192): every step the ControlNet sees
+    the UNet's scaled input batch and its residuals enter the UNet; guess mode under CFG runs it on the conditional half only
+    and gives the unconditional half zero residuals."""
+    from paddlemix_amd.unet import ControlNetModel, synth_controlnet_params
+    cfg = TINY
+    P = synth_unet_params(cfg, seed=1234)
+    Pc = synth_controlnet_params(cfg, seed=8)
+    bfp = lambda d: {k: v.to(torch.bfloat16).float() if v.dim() > 1 else v for k, v in d.items()}  # noqa: E731
+    Pb, Pcb = bfp(P), bfp(Pc)
+    g = torch.Generator().manual_seed(0)
+    pe, ne = torch.randn(1, 7, 64, generator=g), torch.randn(1, 7, 64, generator=g)
+    lat0 = torch.randn(1, 4, 8, 8, generator=g)
+    hint = torch.rand(1, 3, 64, 64, generator=g)
+    kw = dict(clip_sample=False, set_alpha_to_one=False, **SCHED)
+    pipe = StableDiffusionDenoiser(UNet2DConditionModel(cfg, P, _test_backend=Emulator()), DDIMScheduler(**kw),
+                                   controlnet=ControlNetModel(cfg, Pc, _test_backend=Emulator()))
+    steps, gs = 3, 5.0
+    for guess, sc in ((False, 0.8), (True, 1.0)):
+        out = pipe(pe, ne, num_inference_steps=steps, guidance_scale=gs, latents=lat0.clone(), control_image=hint,
+                   controlnet_conditioning_scale=sc, guess_mode=guess)
+        sch = S.DDIMRef(**kw)
+        sch.set_timesteps(steps)
+        x = lat0.numpy() * sch.init_noise_sigma
+        emb = torch.cat([ne, pe])
+        for t in sch.timesteps:
+            xin = torch.from_numpy(np.concatenate([x, x]).astype(np.float32))
+            if guess:
+                d, m = U.controlnet_forward(Pcb, cfg, xin[1:], int(t), pe, hint, sc, True)
+                d, m = tuple(torch.cat([torch.zeros_like(v), v]) for v in d), torch.cat([torch.zeros_like(m), m])
+            else:
+                d, m = U.controlnet_forward(Pcb, cfg, xin, int(t), emb, torch.cat([hint, hint]), sc, False)
+            eps = U.unet_forward(Pb, cfg, xin, int(t), emb, down_block_additional_residuals=d,
+                                 mid_block_additional_residual=m).numpy()
+            x = sch.step(eps[:1] + gs * (eps[1:] - eps[:1]), t, x)
+        rel = np.linalg.norm(out.numpy() - x) / np.linalg.norm(x)
+        assert rel < 5e-2, (guess, rel)
+    plain = pipe(pe, ne, num_inference_steps=steps, guidance_scale=gs, latents=lat0.clone())
+    assert np.linalg.norm(plain.numpy() - out.numpy()) / np.linalg.norm(out.numpy()) > 1e-2     # the hint matters
+    import pytest
+    with pytest.raises(ValueError, match="controlnet"):
+        StableDiffusionDenoiser(pipe.unet, pipe.scheduler)(pe, ne, num_inference_steps=1, latents=lat0.clone(), control_image=hint)
