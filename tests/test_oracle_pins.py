@@ -196,3 +196,24 @@ def test_golden_fixture_scheduler_loops():
     # (|x| sums to 5.7e4 in fp32: 0.1 is 2 ulp-per-element accumulation noise; the reference's own message quotes 57062.9297)
     assert abs(np.abs(x).sum() - w["sum"]["value"]) < 0.1 and abs(np.abs(x).mean() - w["mean"]["value"]) < w["mean"]["tol"]
     assert len(d) == 5 and len(e) == 5   # every full-loop known answer of the two scheduler test files is in the fixture
+
+
+# --- architecture tables against the published checkpoints' parameter totals -------------------------------------------
+def test_parameter_tables_match_published_totals():
+    """No checkpoint can be downloaded here, but the *totals* of the released models are public knowledge; a parameter table
+    (names + shapes, shared by product and oracle: tests/test_*host_logic.py assert they are equal) that reproduces them
+    exactly has every layer of the architecture with the right width. Structure is pinned this way, numerics are not."""
+    import torch
+    from oracle import unet_ref as U
+    from oracle import clip_ref as C
+    from oracle import vae_ref as V
+    from tests.configs import CLIP_BIGG, CLIP_L, CLIP_VIT_H14, SD15, SD_VAE, SDXL
+    n = lambda s: sum(torch.Size(v).numel() for v in s.values())  # noqa: E731
+    assert n(U.unet_param_shapes(SD15)) == 859_520_964                      # runwayml/stable-diffusion-v1-5 unet
+    assert n(U.unet_param_shapes(SDXL)) == 2_567_463_684                    # stabilityai/stable-diffusion-xl-base-1.0 unet
+    assert n(U.controlnet_param_shapes(SD15)) == 361_279_120                # lllyasviel/sd-controlnet-*
+    assert n(C.clip_param_shapes(CLIP_L)) == 123_060_480                    # openai/clip-vit-large-patch14 text model
+    assert n(C.clip_param_shapes(dict(CLIP_BIGG, with_projection=True))) == 694_659_840   # SDXL text_encoder_2
+    assert n(C.clip_vision_param_shapes(CLIP_VIT_H14)) == 632_076_800       # IP-Adapter image encoder (OpenCLIP ViT-H/14)
+    full = dict(SD_VAE)
+    assert n(V.encoder_param_shapes(full)) + n(V.decoder_param_shapes(full)) == 83_653_863   # SD / SDXL AutoencoderKL
