@@ -215,5 +215,8 @@ def test_parameter_tables_match_published_totals():
     assert n(C.clip_param_shapes(CLIP_L)) == 123_060_480                    # openai/clip-vit-large-patch14 text model
     assert n(C.clip_param_shapes(dict(CLIP_BIGG, with_projection=True))) == 694_659_840   # SDXL text_encoder_2
     assert n(C.clip_vision_param_shapes(CLIP_VIT_H14)) == 632_076_800       # IP-Adapter image encoder (OpenCLIP ViT-H/14)
+    from oracle import t5_ref as T
+    from tests.configs import T5_XXL
+    assert n(T.t5_param_shapes(T5_XXL)) == 4_762_310_656                    # T5 v1.1 XXL encoder (SD3 text_encoder_3)
     full = dict(SD_VAE)
     assert n(V.encoder_param_shapes(full)) + n(V.decoder_param_shapes(full)) == 83_653_863   # SD / SDXL AutoencoderKL
