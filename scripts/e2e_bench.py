@@ -29,6 +29,7 @@ from tests.configs import CLIP_BIGG, CLIP_L, SD15, SD_VAE, SDXL  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="sd15", choices=["sd15", "sdxl", "sd3", "dit", "lcm"])
+    ap.add_argument("--controlnet", action="store_true", help="sd15: ControlNet residuals every step (512^2 hint image)")
     ap.add_argument("--img2img", action="store_true", help="sd15 / sdxl / lcm: start from an encoded image, strength 0.75")
     ap.add_argument("--act-dtype", default="bf16", choices=["bf16", "fp8"], help="sd3 only: W8A8 block GEMMs")
     ap.add_argument("--calls", type=int, default=5)
@@ -61,7 +62,11 @@ def main():
     else:
         sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
                               set_alpha_to_one=False, steps_offset=1)
-    pipe = StableDiffusionDenoiser(unet, sched, vae=vae, text_encoder=te, text_encoder_2=te2)
+    cn = None
+    if a.controlnet:
+        from paddlemix_amd.unet import ControlNetModel, synth_controlnet_params
+        cn = ControlNetModel(ucfg, synth_controlnet_params(ucfg, seed=9, device=dev), device=dev)
+    pipe = StableDiffusionDenoiser(unet, sched, vae=vae, text_encoder=te, text_encoder_2=te2, controlnet=cn)
     g = torch.Generator(device=dev).manual_seed(0)
     ids = torch.randint(3, 40000, (1, 77), generator=g, device=dev)
     ids[:, 0], ids[:, 20:] = 49406, 49407
@@ -75,6 +80,8 @@ def main():
         kw.update(guidance_scale=8.0)
     if a.img2img:
         kw.update(image=torch.rand(1, 3, a.side, a.side, generator=g, device=dev) * 2 - 1, strength=0.75)
+    if a.controlnet:
+        kw.update(control_image=torch.rand(1, 3, a.side, a.side, generator=g, device=dev))
     ran = int(a.steps * 0.75) if a.img2img else a.steps
     img = pipe(**kw)   # warm-up call (plans, graphs)
     torch.cuda.synchronize()
@@ -88,7 +95,7 @@ def main():
     mean = sum(ts) / len(ts)
     print(json.dumps({"what": f"{a.model} {'img2img (strength 0.75)' if a.img2img else 'text2img'} end to end, {a.side}x{a.side}, bs 1, "
                               f"{ran} UNet steps, {'guidance embedding (no doubled batch)' if lcm else 'CFG'}, "
-                              f"{'2 CLIP' if xl else 'CLIP'} + {'VAE encode + ' if a.img2img else ''}UNet + VAE decode, random-init weights",
+                              f"{'2 CLIP' if xl else 'CLIP'} + {'VAE encode + ' if a.img2img else ''}{'ControlNet + ' if a.controlnet else ''}UNet + VAE decode, random-init weights",
                       "it_per_s": ran / mean, "s_per_image": mean, "calls": a.calls,
                       "image_shape": list(img.shape), "finite": bool(torch.isfinite(img.float()).all()),
                       "orientation": "reference deploy README: SD15 47.22 / SDXL 31.98 it/s on A100-80G TensorRT fp16 "
