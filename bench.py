@@ -29,6 +29,10 @@ SD15 = dict(block_out_channels=(320, 640, 1280, 1280), cross_attention_dim=768, 
 SD3_MEDIUM = dict(sample_size=128, patch_size=2, in_channels=16, num_layers=24, attention_head_dim=64,
                   num_attention_heads=24, caption_projection_dim=1536, joint_attention_dim=4096,
                   pooled_projection_dim=2048, out_channels=16, pos_embed_max_size=192)
+CLIP_L = dict(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12,
+              max_position_embeddings=77, hidden_act="quick_gelu", projection_dim=768, eos_token_id=2)
+CLIP_BIGG = dict(vocab_size=49408, hidden_size=1280, intermediate_size=5120, num_hidden_layers=32, num_attention_heads=20,
+                 max_position_embeddings=77, hidden_act="gelu", projection_dim=1280, eos_token_id=2)
 WORKLOADS = {
     "sdxl-1024-bs8": dict(cfg=SDXL, B=8, H=128, W=128, L=77, gflop_step=54089.8),
     "sd15-512-bs1": dict(cfg=SD15, B=1, H=64, W=64, L=77, gflop_step=803.3),
@@ -46,43 +50,28 @@ PEAK_FP8_TFLOPS = 5000.0   # dense MFMA fp8 (the W8A8 workload's block GEMMs)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=30)    # 3 warm-up + >= 30 timed steps (one Euler schedule)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="sdxl-1024-bs8", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--residual", default="16", choices=["16", "fp32"],
+                    help="storage type of the residual stream (fp32: tighter parity, more HBM traffic; DESIGN.md section 4)")
+    ap.add_argument("--text-encoders", action="store_true",
+                    help="also build the two SDXL text encoders from broadcast weights and encode the prompts on every rank "
+                         "(default for --gpus > 1: north_star's 'RCCL broadcast of text-encoder/UNet weights')")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"],
                     help="16-bit element type = which build of the library runs (bf16: BASELINE.json's configurations; "
                          "fp16: same MFMA rate, ~6x tighter parity)")
     return ap.parse_args()
 
 
-def broadcast_params(P, rank, world):
-    """RCCL broadcast of the weights from rank 0 (bucketed, ~256 MB per collective: xGMI rings are per-link bound)."""
-    import torch.distributed as dist
-    bucket, size = [], 0
-    names = list(P)
-
-    def flush():
-        nonlocal bucket, size
-        if not bucket:
-            return
-        flat = torch.cat([P[n].reshape(-1) for n in bucket])
-        dist.broadcast(flat, src=0)
-        off = 0
-        for n in bucket:
-            k = P[n].numel()
-            P[n].copy_(flat[off:off + k].view_as(P[n]))
-            off += k
-        bucket, size = [], 0
-
-    for n in names:
-        bucket.append(n)
-        size += P[n].numel() * 4
-        if size >= 256 << 20:
-            flush()
-    flush()
+def broadcast_params(P, rank=None, world=None):
+    """RCCL broadcast of rank 0's weights (paddlemix_amd/dist.py: 16-bit matrices on the wire, big tensors in place, small ones
+    bucketed)."""
+    from paddlemix_amd.dist import broadcast_params as _b
+    return _b(P, src=0)
 
 
 def main():
@@ -112,23 +101,33 @@ def main():
     wl = WORKLOADS[args.workload]
     cfg, B, H, W, L = wl["cfg"], wl["B"], wl["H"], wl["W"], wl["L"]
 
-    # ---- weights: rank 0 draws them, everyone else receives them over RCCL ----
-    t_w0 = time.time()
+    # ---- weights: rank 0 draws them, everyone else receives them over RCCL, as the 16-bit matrices the kernels consume ----
+    from paddlemix_amd.dist import empty_wire_params, gather_latents, wire_params
+    ed = _lib.elem_dtype()
+    with_te = (args.text_encoders or world > 1) and not is_sd3 and args.workload.startswith("sdxl")
+    te_cfgs = {}
+    if with_te:
+        from paddlemix_amd.clip import CLIPTextModel, CLIPTextModelWithProjection, clip_param_shapes, synth_clip_params
+        te_cfgs = {"text_encoder": (CLIP_L, CLIPTextModel), "text_encoder_2": (CLIP_BIGG, CLIPTextModelWithProjection)}
     if rank == 0:
-        P = synth_unet_params(cfg, seed=1234, device=dev)
+        P = wire_params(synth_unet_params(cfg, seed=1234, device=dev), ed)
+        PT = {k: wire_params(synth_clip_params(c, seed=77 + i, device=dev), ed) for i, (k, (c, _)) in enumerate(te_cfgs.items())}
     else:
-        P = {n: torch.empty(s, device=dev) for n, s in unet_param_shapes(cfg).items()}
-    bcast_s = None
+        P = empty_wire_params(unet_param_shapes(cfg), ed, dev)
+        PT = {k: empty_wire_params(clip_param_shapes(c), ed, dev) for k, (c, _) in te_cfgs.items()}
+    bcast_s = bcast_bytes = None
     if world > 1:
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.time()
-        broadcast_params(P, rank, world)
+        bcast_bytes = broadcast_params(P) + sum(broadcast_params(v) for v in PT.values())
         torch.cuda.synchronize()
         bcast_s = time.time() - t0
     kw = {"weight_dtype": "fp8"} if WORKLOADS[args.workload].get("fp8") else {}
     if WORKLOADS[args.workload].get("a8"):
         kw["act_dtype"] = "fp8"
+    if args.residual == "fp32":
+        kw["residual_dtype"] = "fp32"
     model = UNet2DConditionModel(cfg, P, device=dev, use_graph=not args.no_graph, **kw)
     P_cpu_needed = rank == 0 and world == 1 and not args.no_cpu_baseline and not is_sd3
     if not P_cpu_needed:
@@ -153,6 +152,25 @@ def main():
         td = cfg["projection_class_embeddings_input_dim"] - 6 * cfg["addition_time_embed_dim"]
         added = dict(text_embeds=torch.randn(B, td, generator=g, device=dev),
                      time_ids=torch.tensor([[1024., 1024., 0., 0., 1024., 1024.]], device=dev).repeat(B, 1))
+    te_s = None
+    if with_te:
+        # every rank encodes ITS prompts (synthetic token ids, its own seed) with the broadcast text encoders, once, outside the
+        # timed region: encode_prompt of the SDXL pipeline (pipeline_stable_diffusion_xl.py:283-470) = hidden_states[-2] of both
+        # encoders concatenated on the feature axis + the second encoder's pooled projection
+        t0 = time.time()
+        ids = torch.randint(3, 49000, (B, L), generator=g, device=dev)
+        ids[:, 0], ids[:, -1] = 49406, 49407   # BOS ... EOS (the pooled row is the arg-max id's, modeling.py:470-480)
+        te1 = te_cfgs["text_encoder"][1](CLIP_L, PT["text_encoder"], device=dev)
+        te2 = te_cfgs["text_encoder_2"][1](CLIP_BIGG, PT["text_encoder_2"], device=dev)
+        o1 = te1(ids, output_hidden_states=True)
+        o2 = te2(ids, output_hidden_states=True)
+        enc = torch.cat([o1.hidden_states[-2], o2.hidden_states[-2]], -1).float()
+        added["text_embeds"] = o2.text_embeds.float()
+        assert enc.shape == (B, L, cfg["cross_attention_dim"]) and added["text_embeds"].shape == (B, td)
+        torch.cuda.synchronize()
+        te_s = time.time() - t0
+        del te1, te2, o1, o2, PT
+        torch.cuda.empty_cache()
     plan = model._get_plan(B, H, W, L)
     if wl["gflop_step"] is None:
         wl = dict(wl, gflop_step=sum(fl for _, _, _, fl in plan.prog) / 1e9)
@@ -205,10 +223,17 @@ def main():
         elapsed = time.perf_counter() - t0
     if not torch.isfinite(latents).all():
         raise SystemExit("non-finite latents")
+    per_rank_ms = [1e3 * elapsed / args.steps]
+    gathered_shape = None
     if dist is not None:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = tmax.item()
+        tall = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(tall, torch.tensor([elapsed], device=dev, dtype=torch.float64))
+        per_rank_ms = [1e3 * t.item() / args.steps for t in tall]
+        elapsed = max(t.item() for t in tall)
+        allz = gather_latents(latents)      # the only other collective of the job: the ranks' results, once
+        gathered_shape = list(allz.shape)
+        if not torch.isfinite(allz).all():
+            raise SystemExit("non-finite latents on some rank")
 
     res = {
         "metric": {"sdxl-1024-bs8": "UNet denoising steps/sec (SD-XL 1024^2, bs=8)",
@@ -229,6 +254,22 @@ def main():
     }
     if bcast_s is not None:
         res["weight_broadcast_s"] = bcast_s
+        res["weight_broadcast_gb"] = bcast_bytes / 1e9
+        res["per_rank_ms_per_step"] = [round(v, 3) for v in per_rank_ms]
+        res["gathered_latents"] = gathered_shape
+    if te_s is not None:
+        res["text_encode_s"] = te_s
+    res["config"]["residual_stream"] = args.residual
+    # measured parity of this dtype / residual mode against the oracle (scripts/parity_report.py on the GPU box), when committed
+    import glob as _glob
+    pc = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*_parity.json")))
+    if pc and not is_sd3:
+        pj = json.load(open(pc[-1])).get(args.dtype, {})
+        key = "resid_" + args.residual
+        res["parity"] = {"source": os.path.relpath(pc[-1], ROOT), "target_rel_l2": 1e-3,
+                         "forward_rel_l2": {k: v.get(key) for k, v in pj.get("forward", {}).items()},
+                         "euler30_end_latents_rel_l2": {k: v.get(key, {}).get("end_latents_rel") for k, v in pj.get("loop", {}).items()},
+                         "oracle": "torch-CPU restatement of ppdiffusers (Paddle unavailable: unpinned)"}
 
     # ---- roofline of the dominant kernel: per-launch HIP-event timing on the launch stream, one eager step ----
     if rank == 0 and not args.no_roofline:
@@ -287,15 +328,16 @@ def main():
         res["eager_step_ms_sum_of_kernels"] = total_ms
 
     # ---- CPU baseline: the torch-CPU oracle on a bounded sample of the same workload (rank 0, N=1 only) ----
+    # ONE of the step's B prompts at the full latent geometry (exact attention cost; prompts are independent, so the step is
+    # B such forwards), timed once after a small page-in call: ~10-30 s of CPU work. The full-batch measurement (2 timed
+    # bs-B steps) is scripts/cpu_baseline.py -> profiles/r*_cpu_baseline_<workload>.json, attached when committed.
     if P_cpu_needed:
         from oracle import unet_ref as U
         threads = torch.get_num_threads()
-        frac_hw = 4  # 1 prompt at 1/4 of the latent side: (B*H*W) / (1*(H/4)*(W/4)) fewer positions
-        hb, wb = max(H // frac_hw, 8), max(W // frac_hw, 8)
         Pc = {k: v.float().cpu() for k, v in P.items()}
         del P
         gs = torch.Generator().manual_seed(0)
-        s = torch.randn(1, 4, hb, wb, generator=gs)
+        s = torch.randn(1, 4, H, W, generator=gs)
         e = torch.randn(1, L, cfg["cross_attention_dim"], generator=gs)
         ad = None
         if added is not None:
@@ -305,14 +347,15 @@ def main():
             t0 = time.perf_counter()
             U.unet_forward(Pc, cfg, s, 500, e, added_cond_kwargs=ad)
             cpu_s = time.perf_counter() - t0
-        positions_ratio = (B * H * W) / (hb * wb)
         res["cpu_baseline"] = {
-            "value": 1.0 / (cpu_s * positions_ratio), "unit": "steps/s", "cores": threads, "kind": "port",
-            "sample": f"torch-CPU fp32 restatement of ppdiffusers (Paddle unavailable): 1 UNet forward, 1 prompt at "
-                      f"{hb}x{wb} latents = 1/{positions_ratio:.0f} of the bs-{B} {H}x{W} step's positions, "
-                      f"{cpu_s:.2f} s on {threads} threads; scaled linearly in positions (optimistic for CPU: "
-                      f"self-attention grows quadratically)",
+            "value": 1.0 / (cpu_s * B), "unit": "steps/s", "cores": threads, "kind": "port",
+            "sample": f"torch-CPU fp32 restatement of ppdiffusers (Paddle unavailable): 1 UNet forward of 1 of the step's {B} "
+                      f"prompts at the full {H}x{W} latents, {cpu_s:.2f} s on {threads} threads; a step is {B} such forwards "
+                      f"(prompts do not interact), value = 1 / ({B} x {cpu_s:.2f} s)",
         }
+        cb = sorted(_glob.glob(os.path.join(ROOT, "profiles", f"r*_cpu_baseline_{args.workload}.json")))
+        if cb:
+            res["cpu_baseline"]["full_batch_measured"] = dict(json.load(open(cb[-1])), source=os.path.relpath(cb[-1], ROOT))
     if rank == 0:
         print(json.dumps(res))
     if dist is not None:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MI355X_SD_ABI_VERSION 8
+#define MI355X_SD_ABI_VERSION 9
 #define MI355X_SD_OK 0
 #define MI355X_SD_ERR_INVALID 1      /* bad argument (shape <= 0, null pointer ...)          */
 #define MI355X_SD_ERR_UNSUPPORTED 2  /* well-formed but outside the implemented configurations */
@@ -58,6 +58,9 @@ int mi355x_sd_set_workspace(void* ptr, size_t bytes);
 #define MI355X_SD_OUT_F32 2  /* C is fp32 */
 #define MI355X_SD_GELU_TANH 8 /* tanh-GELU applied to the final value (FeedForward "gelu-approximate", PPD/models/attention.py:648-649) */
 #define MI355X_SD_SILU 4     /* SiLU applied to the final value (TimestepEmbedding.act, PPD/models/embeddings.py:283-295) */
+#define MI355X_SD_R_F32 32   /* R is fp32 rows (ldr in fp32 elements): the fp32 residual-stream mode, where the tensors the reference
+                              * adds onto (`hidden_states + input_tensor` resnet.py:806, `attn_output + hidden_states` attention.py:430,
+                              * 455, 487, transformer_2d.py:467) never round to 16 bits; combine with MI355X_SD_OUT_F32 */
 #define MI355X_SD_PAD_BR 16  /* conv3x3, stride 2 only: zero padding is one row / column at the bottom / right instead of all round
                               * (Downsample2D with padding=0: F.pad (0,1,0,1) then an unpadded conv, PPD/models/resnet.py:277-279 --
                               * the VAE encoder's downsamplers, vae.py:113) */
@@ -178,6 +181,18 @@ int mi355x_sd_scale_shift_act(const void* x, int B, int HW, int C, int ldx, cons
 /* Row LayerNorm with optional affine (PPD/models/attention.py:397,442,463). C <= 2560. */
 int mi355x_sd_layernorm(const void* x, int rows, int C, int ldx, const float* gamma, const float* beta, float eps,
                         void* y, int ldy, void* stream);
+/* The same three with x_f32 != 0: x is fp32 rows (ldx in fp32 elements) -- the norms are where the fp32 residual stream
+ * becomes a 16-bit MFMA operand. scale_shift_act_ex can also emit raw16 (NULL: none) = the 16-bit rounding of the raw x
+ * rows in the same pass: the operand of the resnet's conv_shortcut GEMM (resnet.py:797-798). */
+int mi355x_sd_groupnorm_stats_ex(const void* x, int B, int HW, int C, int ldx, int groups, float eps,
+                                 const float* gamma, const float* beta, float* workspace, float* scale_shift,
+                                 int x_f32, void* stream);
+int mi355x_sd_scale_shift_act_ex(const void* x, int B, int HW, int C, int ldx, const float* scale_shift, int silu,
+                                 void* y, int ldy, int x_f32, void* raw16, int ld_raw, void* stream);
+int mi355x_sd_layernorm_ex(const void* x, int rows, int C, int ldx, const float* gamma, const float* beta, float eps,
+                           void* y, int ldy, int x_f32, void* stream);
+/* y (16-bit rows) = x (fp32 rows): operand copies of the fp32 residual stream (inputs of Downsample2D / Upsample2D convs). */
+int mi355x_sd_cast_rows(const float* x, int ldx, void* y, int ldy, int64_t rows, int C, void* stream);
 
 /* get_timestep_embedding (PPD/models/embeddings.py:26-64) in fp32, written as bf16 to
  * out[(i/group)*ldo + (i%group)*dim + j] for i < n, timestep t[i % t_count] (device fp32). */
@@ -189,6 +204,9 @@ int mi355x_sd_silu(const void* x, void* y, int64_t n, int in_f32, int out_f32, v
  * scale_model_input), w [9*Cin][Cout] bf16, y NHWC bf16. */
 int mi355x_sd_conv_in3x3(const float* x_nchw, const float* in_scale, const void* w, const float* bias, void* y,
                          int B, int Cin, int H, int W, int Cout, int ldy, void* stream);
+/* out_f32 != 0: y is NHWC fp32 (start of the fp32 residual stream) */
+int mi355x_sd_conv_in3x3_ex(const float* x_nchw, const float* in_scale, const void* w, const float* bias, void* y,
+                            int B, int Cin, int H, int W, int Cout, int ldy, int out_f32, void* stream);
 /* conv_out (unet_2d_condition.py:1196): x NHWC bf16, w [Cout<=4][3][3][Cin] bf16, y NCHW fp32. */
 int mi355x_sd_conv_out3x3(const void* x, int ldx, const void* w, const float* bias, float* y_nchw,
                           int B, int Cin, int H, int W, int Cout, void* stream);
@@ -198,6 +216,7 @@ int mi355x_sd_copy_rows(const void* x, int ldx, void* y, int ldy, int64_t rows, 
  * mid_block_additional_residual, PPD/models/unet_2d_condition.py:1121-1132, 1151-1155): x[b*HW + p][c] += r[b][c][p] in place
  * on a bf16 NHWC row view (row stride ldx; C % 8 == 0), r NCHW fp32 as the reference passes it. */
 int mi355x_sd_add_nchw(void* x, int ldx, const float* r_nchw, int B, int C, int64_t HW, void* stream);
+int mi355x_sd_add_nchw_ex(void* x, int ldx, const float* r_nchw, int B, int C, int64_t HW, int x_f32, void* stream);
 
 /* DiagonalGaussianDistribution (PPD/models/vae.py:744-763, built by AutoencoderKL.encode, autoencoder_kl.py:266-283) from
  * the encoder's moments held as fp32 rows [B*HW][ld >= 2L] (channels mean_0..L-1, logvar_0..L-1): writes NCHW fp32

@@ -17,8 +17,8 @@ if ELEM_NAME not in _BUILDS:
     raise ValueError(f"MI355X_SD_DTYPE must be one of {sorted(_BUILDS)}, got {ELEM_NAME!r}")
 LIB_PATH = os.path.join(_HERE, _BUILDS[ELEM_NAME][0])
 
-ABI_VERSION = 8
-GEGLU, OUT_F32, SILU, GELU_TANH, PAD_BR = 1, 2, 4, 8, 16
+ABI_VERSION = 9
+GEGLU, OUT_F32, SILU, GELU_TANH, PAD_BR, R_F32 = 1, 2, 4, 8, 16, 32
 
 # name -> (restype, argtypes); must list every symbol include/mi355x_sd.h declares (tests/test_abi.py checks)
 SIGNATURES = {
@@ -61,6 +61,17 @@ SIGNATURES = {
                                           c_void_p]),
     "mi355x_sd_layernorm": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int,
                                     c_void_p]),
+    # fp32-residual-stream forms (x_f32 = 1: the input rows are fp32)
+    "mi355x_sd_groupnorm_stats_ex": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
+                                             c_void_p, c_void_p, c_int, c_void_p]),
+    "mi355x_sd_scale_shift_act_ex": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
+                                             c_int, c_void_p, c_int, c_void_p]),
+    "mi355x_sd_layernorm_ex": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int,
+                                       c_int, c_void_p]),
+    "mi355x_sd_cast_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p]),
+    "mi355x_sd_conv_in3x3_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                        c_int, c_int, c_int, c_void_p]),
+    "mi355x_sd_add_nchw_ex": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int64, c_int, c_void_p]),
     "mi355x_sd_timestep_embedding": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float,
                                              c_void_p, c_int, c_void_p]),
     "mi355x_sd_silu": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),

@@ -32,7 +32,15 @@ CONFIG_NAME = "config.json"
 PADDLE_SAFETENSORS_WEIGHTS_NAME = "diffusion_paddle_model.safetensors"
 TORCH_SAFETENSORS_WEIGHTS_NAME = "diffusion_pytorch_model.safetensors"
 PADDLE_WEIGHTS_NAME = "model_state.pdparams"
-_CANDIDATES = (PADDLE_SAFETENSORS_WEIGHTS_NAME, TORCH_SAFETENSORS_WEIGHTS_NAME, PADDLE_WEIGHTS_NAME)
+# transformers-style text encoders (CLIP / T5 sub-folders of a pipeline) name their single file model.safetensors / model_state.pdparams
+_CANDIDATES = (PADDLE_SAFETENSORS_WEIGHTS_NAME, TORCH_SAFETENSORS_WEIGHTS_NAME, PADDLE_WEIGHTS_NAME, "model.safetensors")
+
+
+class Table(tuple):
+    """Shape of a 2-D parameter that is NOT an nn.Linear weight (nn.Embedding tables, T5's relative-attention bias): the
+    reference transposes only nn.Linear weights between the torch and Paddle layouts
+    (convert_pytorch_state_dict_to_paddle, modeling_pytorch_paddle_utils.py:27-47), so these keep their [num, dim] shape in
+    both formats. The *_param_shapes tables mark them with this type; it is a plain tuple everywhere else."""
 
 Tensor = torch.Tensor
 
@@ -95,7 +103,7 @@ def to_paddle_layout(state: Mapping[str, Tensor], shapes: Mapping[str, tuple], d
             missing.append(name)
             continue
         t = state[name]
-        if data_format == "pt" and t.dim() == 2 and len(shape) == 2:   # nn.Linear: torch keeps [out, in]
+        if data_format == "pt" and t.dim() == 2 and len(shape) == 2 and not isinstance(shape, Table):   # nn.Linear: torch keeps [out, in]
             t = t.t()
         if tuple(t.shape) != tuple(shape):
             bad.append(f"{name}: checkpoint {tuple(t.shape)} vs model {tuple(shape)}")
@@ -108,14 +116,19 @@ def to_paddle_layout(state: Mapping[str, Tensor], shapes: Mapping[str, tuple], d
     return out
 
 
-def from_paddle_layout(params: Mapping[str, Tensor], data_format: str) -> Dict[str, Tensor]:
-    """Inverse of `to_paddle_layout` for writing a checkpoint in torch layouts (format "pt")."""
+def from_paddle_layout(params: Mapping[str, Tensor], data_format: str,
+                       shapes: Optional[Mapping[str, tuple]] = None) -> Dict[str, Tensor]:
+    """Inverse of `to_paddle_layout` for writing a checkpoint in torch layouts (format "pt"). `shapes` (the model's parameter
+    table) tells nn.Linear weights from embedding tables; without it every 2-D tensor is taken for a Linear weight, which
+    is only right for models without tables (the UNet without class embeddings, the VAE)."""
     if data_format == "pt":
-        return {k: (v.t().contiguous() if v.dim() == 2 else v.contiguous()) for k, v in params.items()}
+        lin = lambda k, v: v.dim() == 2 and not (shapes is not None and isinstance(shapes.get(k), Table))  # noqa: E731
+        return {k: (v.t().contiguous() if lin(k, v) else v.contiguous()) for k, v in params.items()}
     return {k: v.contiguous() for k, v in params.items()}
 
 
-def save_pretrained(model_dir: str, config: Mapping, params: Mapping[str, Tensor], data_format: str = "pd") -> str:
+def save_pretrained(model_dir: str, config: Mapping, params: Mapping[str, Tensor], data_format: str = "pd",
+                    shapes: Optional[Mapping[str, tuple]] = None) -> str:
     """Write ``config.json`` + one safetensors file the way ppdiffusers lays a model directory out."""
     from safetensors.torch import save_file
     if data_format not in ("pd", "pt"):
@@ -125,7 +138,7 @@ def save_pretrained(model_dir: str, config: Mapping, params: Mapping[str, Tensor
         json.dump({k: (list(v) if isinstance(v, tuple) else v) for k, v in config.items()}, fh, indent=2)
     name = PADDLE_SAFETENSORS_WEIGHTS_NAME if data_format == "pd" else TORCH_SAFETENSORS_WEIGHTS_NAME
     path = os.path.join(model_dir, name)
-    save_file(from_paddle_layout({k: v.detach().cpu() for k, v in params.items()}, data_format), path,
+    save_file(from_paddle_layout({k: v.detach().cpu() for k, v in params.items()}, data_format, shapes), path,
               metadata={"format": data_format})
     return path
 

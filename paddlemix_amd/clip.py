@@ -23,7 +23,7 @@ from typing import Dict, List, Mapping, Optional
 import torch
 
 from . import _lib
-from .checkpoint import PretrainedMixin
+from .checkpoint import PretrainedMixin, Table
 from .program import DeviceProgram, _Plan, _Ref, _V
 
 Tensor = torch.Tensor
@@ -49,8 +49,8 @@ def clip_param_shapes(config: Mapping) -> Dict[str, tuple]:
     """name -> shape in Paddle layouts (Linear [in, out]); names as in the reference checkpoints."""
     cfg = normalize_config(config)
     D, I = cfg["hidden_size"], cfg["intermediate_size"]
-    S: Dict[str, tuple] = {"text_model.embeddings.token_embedding.weight": (cfg["vocab_size"], D),
-                           "text_model.embeddings.position_embedding.weight": (cfg["max_position_embeddings"], D)}
+    S: Dict[str, tuple] = {"text_model.embeddings.token_embedding.weight": Table((cfg["vocab_size"], D)),
+                           "text_model.embeddings.position_embedding.weight": Table((cfg["max_position_embeddings"], D))}
     _encoder_layer_shapes(S, "text_model", cfg["num_hidden_layers"], D, I)
     S["text_model.final_layer_norm.weight"], S["text_model.final_layer_norm.bias"] = (D,), (D,)
     if cfg["with_projection"]:
@@ -310,7 +310,7 @@ def clip_vision_param_shapes(config: Mapping) -> Dict[str, tuple]:
     D, I, p = cfg["hidden_size"], cfg["intermediate_size"], cfg["patch_size"]
     S: Dict[str, tuple] = {"vision_model.embeddings.class_embedding": (D,),
                            "vision_model.embeddings.patch_embedding.weight": (D, cfg["num_channels"], p, p),
-                           "vision_model.embeddings.position_embedding.weight": ((cfg["image_size"] // p) ** 2 + 1, D),
+                           "vision_model.embeddings.position_embedding.weight": Table(((cfg["image_size"] // p) ** 2 + 1, D)),
                            "vision_model.pre_layrnorm.weight": (D,), "vision_model.pre_layrnorm.bias": (D,)}
     _encoder_layer_shapes(S, "vision_model", cfg["num_hidden_layers"], D, I)
     S["vision_model.post_layernorm.weight"], S["vision_model.post_layernorm.bias"] = (D,), (D,)

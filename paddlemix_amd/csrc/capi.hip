@@ -105,6 +105,7 @@ int mi355x_sd_linear(const void* A, int lda, const void* W, void* C, int ldc, in
   g.R = (const bf16*)R; g.ldr = ldr; g.out_scale = out_scale;
   g.geglu = (flags & MI355X_SD_GEGLU) ? 1 : 0;
   g.out_f32 = (flags & MI355X_SD_OUT_F32) ? 1 : 0;
+  g.r_f32 = (flags & MI355X_SD_R_F32) ? 1 : 0;
   g.silu = (flags & MI355X_SD_SILU) ? 1 : 0;
   return finish(launch_gemm(g, S(stream)), "mi355x_sd_linear");
 }
@@ -127,6 +128,7 @@ int mi355x_sd_linear_ex(const void* A, int lda, int a_rows_per_batch, int64_t a_
   g.R = (const bf16*)R; g.ldr = ldr; g.out_scale = out_scale;
   g.geglu = (flags & MI355X_SD_GEGLU) ? 1 : 0;
   g.out_f32 = (flags & MI355X_SD_OUT_F32) ? 1 : 0;
+  g.r_f32 = (flags & MI355X_SD_R_F32) ? 1 : 0;
   g.silu = (flags & MI355X_SD_SILU) ? 1 : 0;
   g.gelu_tanh = (flags & MI355X_SD_GELU_TANH) ? 1 : 0;
   return finish(launch_gemm(g, S(stream)), "mi355x_sd_linear_ex");
@@ -148,6 +150,7 @@ int mi355x_sd_linear_ln(const void* A, int lda, const float* row_stats, const vo
   g.bias = bias; g.out_scale = 1.0f;
   g.geglu = (flags & MI355X_SD_GEGLU) ? 1 : 0;
   g.out_f32 = (flags & MI355X_SD_OUT_F32) ? 1 : 0;
+  g.r_f32 = (flags & MI355X_SD_R_F32) ? 1 : 0;
   g.silu = (flags & MI355X_SD_SILU) ? 1 : 0;
   g.gelu_tanh = (flags & MI355X_SD_GELU_TANH) ? 1 : 0;
   return finish(launch_gemm(g, S(stream)), "mi355x_sd_linear_ln");
@@ -242,6 +245,7 @@ int mi355x_sd_conv3x3(const void* X, int ldx, int B, int Hs, int Ws, int Cin, in
   g.bias = bias; g.rowbias = rowbias; g.rows_per_batch = g.Ho * g.Wo; g.ld_rowbias = ld_rowbias;
   g.R = (const bf16*)R; g.ldr = ldr; g.out_scale = out_scale;
   g.out_f32 = (flags & MI355X_SD_OUT_F32) ? 1 : 0;
+  g.r_f32 = (flags & MI355X_SD_R_F32) ? 1 : 0;
   g.silu = (flags & MI355X_SD_SILU) ? 1 : 0;
   return finish(launch_gemm(g, S(stream)), "mi355x_sd_conv3x3");
 }
@@ -286,23 +290,45 @@ int mi355x_sd_groupnorm_stats(const void* x, int B, int HW, int C, int ldx, int 
                               const float* beta, float* workspace, float* scale_shift, void* stream) {
   if (!x || !gamma || !beta || !workspace || !scale_shift)
     return fail(SD_ERR_INVALID, "mi355x_sd_groupnorm_stats: null pointer");
-  return finish(launch_groupnorm_stats((const bf16*)x, B, HW, C, ldx, groups, eps, gamma, beta, workspace, scale_shift,
-                                       S(stream)),
+  return finish(launch_groupnorm_stats(x, 0, B, HW, C, ldx, groups, eps, gamma, beta, workspace, scale_shift, S(stream)),
                 "mi355x_sd_groupnorm_stats");
+}
+
+int mi355x_sd_groupnorm_stats_ex(const void* x, int B, int HW, int C, int ldx, int groups, float eps, const float* gamma,
+                                 const float* beta, float* workspace, float* scale_shift, int x_f32, void* stream) {
+  if (!x || !gamma || !beta || !workspace || !scale_shift)
+    return fail(SD_ERR_INVALID, "mi355x_sd_groupnorm_stats_ex: null pointer");
+  return finish(launch_groupnorm_stats(x, x_f32, B, HW, C, ldx, groups, eps, gamma, beta, workspace, scale_shift, S(stream)),
+                "mi355x_sd_groupnorm_stats_ex");
 }
 
 int mi355x_sd_scale_shift_act(const void* x, int B, int HW, int C, int ldx, const float* scale_shift, int silu, void* y,
                               int ldy, void* stream) {
   if (!x || !scale_shift || !y) return fail(SD_ERR_INVALID, "mi355x_sd_scale_shift_act: null pointer");
-  return finish(launch_scale_shift_act((const bf16*)x, B, HW, C, ldx, scale_shift, silu, (bf16*)y, ldy, S(stream)),
+  return finish(launch_scale_shift_act(x, 0, B, HW, C, ldx, scale_shift, silu, (bf16*)y, ldy, nullptr, 0, S(stream)),
                 "mi355x_sd_scale_shift_act");
+}
+
+int mi355x_sd_scale_shift_act_ex(const void* x, int B, int HW, int C, int ldx, const float* scale_shift, int silu, void* y,
+                                 int ldy, int x_f32, void* raw16, int ld_raw, void* stream) {
+  if (!x || !scale_shift || !y) return fail(SD_ERR_INVALID, "mi355x_sd_scale_shift_act_ex: null pointer");
+  return finish(launch_scale_shift_act(x, x_f32, B, HW, C, ldx, scale_shift, silu, (bf16*)y, ldy, (bf16*)raw16, ld_raw,
+                                       S(stream)),
+                "mi355x_sd_scale_shift_act_ex");
 }
 
 int mi355x_sd_layernorm(const void* x, int rows, int C, int ldx, const float* gamma, const float* beta, float eps,
                         void* y, int ldy, void* stream) {
   if (!x || !y) return fail(SD_ERR_INVALID, "mi355x_sd_layernorm: null pointer");
-  return finish(launch_layernorm((const bf16*)x, rows, C, ldx, gamma, beta, eps, (bf16*)y, ldy, S(stream)),
+  return finish(launch_layernorm(x, 0, rows, C, ldx, gamma, beta, eps, (bf16*)y, ldy, S(stream)),
                 "mi355x_sd_layernorm");
+}
+
+int mi355x_sd_layernorm_ex(const void* x, int rows, int C, int ldx, const float* gamma, const float* beta, float eps,
+                           void* y, int ldy, int x_f32, void* stream) {
+  if (!x || !y) return fail(SD_ERR_INVALID, "mi355x_sd_layernorm_ex: null pointer");
+  return finish(launch_layernorm(x, x_f32, rows, C, ldx, gamma, beta, eps, (bf16*)y, ldy, S(stream)),
+                "mi355x_sd_layernorm_ex");
 }
 
 int mi355x_sd_timestep_embedding(const float* t, int t_count, int n, int dim, int group, int flip_sin_to_cos,
@@ -321,8 +347,20 @@ int mi355x_sd_silu(const void* x, void* y, int64_t n, int in_f32, int out_f32, v
 int mi355x_sd_conv_in3x3(const float* x_nchw, const float* in_scale, const void* w, const float* bias, void* y, int B,
                          int Cin, int H, int W, int Cout, int ldy, void* stream) {
   if (!x_nchw || !w || !y) return fail(SD_ERR_INVALID, "mi355x_sd_conv_in3x3: null pointer");
-  return finish(launch_conv_in3x3(x_nchw, in_scale, (const bf16*)w, bias, (bf16*)y, B, Cin, H, W, Cout, ldy, S(stream)),
+  return finish(launch_conv_in3x3(x_nchw, in_scale, (const bf16*)w, bias, y, 0, B, Cin, H, W, Cout, ldy, S(stream)),
                 "mi355x_sd_conv_in3x3");
+}
+
+int mi355x_sd_conv_in3x3_ex(const float* x_nchw, const float* in_scale, const void* w, const float* bias, void* y, int B,
+                            int Cin, int H, int W, int Cout, int ldy, int out_f32, void* stream) {
+  if (!x_nchw || !w || !y) return fail(SD_ERR_INVALID, "mi355x_sd_conv_in3x3_ex: null pointer");
+  return finish(launch_conv_in3x3(x_nchw, in_scale, (const bf16*)w, bias, y, out_f32, B, Cin, H, W, Cout, ldy, S(stream)),
+                "mi355x_sd_conv_in3x3_ex");
+}
+
+int mi355x_sd_cast_rows(const float* x, int ldx, void* y, int ldy, int64_t rows, int C, void* stream) {
+  if (!x || !y) return fail(SD_ERR_INVALID, "mi355x_sd_cast_rows: null pointer");
+  return finish(launch_cast_rows(x, ldx, (bf16*)y, ldy, (long)rows, C, S(stream)), "mi355x_sd_cast_rows");
 }
 
 int mi355x_sd_conv_out3x3(const void* x, int ldx, const void* w, const float* bias, float* y_nchw, int B, int Cin, int H,
@@ -339,7 +377,12 @@ int mi355x_sd_copy_rows(const void* x, int ldx, void* y, int ldy, int64_t rows, 
 
 int mi355x_sd_add_nchw(void* x, int ldx, const float* r_nchw, int B, int C, int64_t HW, void* stream) {
   if (!x || !r_nchw) return fail(SD_ERR_INVALID, "mi355x_sd_add_nchw: null pointer");
-  return finish(launch_add_nchw((bf16*)x, ldx, r_nchw, B, C, (long)HW, S(stream)), "mi355x_sd_add_nchw");
+  return finish(launch_add_nchw(x, 0, ldx, r_nchw, B, C, (long)HW, S(stream)), "mi355x_sd_add_nchw");
+}
+
+int mi355x_sd_add_nchw_ex(void* x, int ldx, const float* r_nchw, int B, int C, int64_t HW, int x_f32, void* stream) {
+  if (!x || !r_nchw) return fail(SD_ERR_INVALID, "mi355x_sd_add_nchw_ex: null pointer");
+  return finish(launch_add_nchw(x, x_f32, ldx, r_nchw, B, C, (long)HW, S(stream)), "mi355x_sd_add_nchw_ex");
 }
 
 int mi355x_sd_latent_dist(const float* moments, int ld, int B, int L, int64_t HW, const float* noise_nchw, float out_scale,

@@ -64,11 +64,15 @@ __device__ __forceinline__ f32x4 epi4(const GemmArgs& p, f32x4 v, int m, int n, 
   if (rb) v += *reinterpret_cast<const f32x4*>(rb + n);
   if (gt) v *= *reinterpret_cast<const f32x4*>(gt + n);
   if (p.R) {
-    const bf16x4 r4 = *reinterpret_cast<const bf16x4*>(p.R + (size_t)m * p.ldr + n);
-    v[0] += (float)r4[0];
-    v[1] += (float)r4[1];
-    v[2] += (float)r4[2];
-    v[3] += (float)r4[3];
+    if (p.r_f32) {
+      v += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.R) + (size_t)m * p.ldr + n);
+    } else {
+      const bf16x4 r4 = *reinterpret_cast<const bf16x4*>(p.R + (size_t)m * p.ldr + n);
+      v[0] += (float)r4[0];
+      v[1] += (float)r4[1];
+      v[2] += (float)r4[2];
+      v[3] += (float)r4[3];
+    }
   }
   return act4(p, v * p.out_scale);
 }

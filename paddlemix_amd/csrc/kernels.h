@@ -24,8 +24,9 @@ struct GemmArgs {
   const float* rowbias;   // [M / rows_per_batch][ld_rowbias] broadcast over rows of one batch item
   int rows_per_batch;
   int ld_rowbias;
-  const bf16* R;          // residual rows x ldr
+  const bf16* R;          // residual rows x ldr (fp32 rows when r_f32: the fp32 residual stream, MI355X_SD_R_F32)
   int ldr;
+  int r_f32;
   float out_scale;        // multiplies (acc + bias + rowbias + R)
   int geglu;              // W/bias rows interleaved [16 value | 16 gate]; writes N/2 columns value*gelu(gate)
   int out_f32;
@@ -77,11 +78,11 @@ struct AttnArgs {
 int launch_attention(const AttnArgs& a, hipStream_t stream);
 
 // GroupNorm over NHWC rows: stats -> per-(batch, channel) scale/shift, then fused normalise(+SiLU)
-int launch_groupnorm_stats(const bf16* x, int B, int HW, int C, int ldx, int groups, float eps, const float* gamma,
+int launch_groupnorm_stats(const void* x, int x_f32, int B, int HW, int C, int ldx, int groups, float eps, const float* gamma,
                            const float* beta, float* partial, float* scale_shift, hipStream_t stream);
 int groupnorm_partial_floats(int B, int HW, int C);
-int launch_scale_shift_act(const bf16* x, int B, int HW, int C, int ldx, const float* scale_shift, int silu, bf16* y,
-                           int ldy, hipStream_t stream);
+int launch_scale_shift_act(const void* x, int x_f32, int B, int HW, int C, int ldx, const float* scale_shift, int silu, bf16* y,
+                           int ldy, bf16* raw16, int ld_raw, hipStream_t stream);
 // y = LN(x) * (1 + scale[b]) + shift[b]  (no affine; b = row / rows_per_batch): AdaLayerNormZero / Continuous
 int launch_adaln(const bf16* x, int rows, int C, int ldx, const float* scale, const float* shift, int ld_mod,
                  int rows_per_batch, float eps, bf16* y, int ldy, hipStream_t stream);
@@ -92,18 +93,19 @@ int launch_quantize_rows(const bf16* x, long rows, int C, int ldx, int x_rpb, lo
 int launch_patchify(const float* x_nchw, int B, int C, int H, int W, int p, bf16* out, int ldo, hipStream_t stream);
 int launch_unpatchify(const bf16* x, int ldx, int B, int C, int H, int W, int p, float* out_nchw, hipStream_t stream);
 int launch_row_stats(const bf16* x, int rows, int C, int ldx, float eps, float* stats, hipStream_t stream);
-int launch_layernorm(const bf16* x, int rows, int C, int ldx, const float* gamma, const float* beta, float eps, bf16* y,
+int launch_layernorm(const void* x, int x_f32, int rows, int C, int ldx, const float* gamma, const float* beta, float eps, bf16* y,
                      int ldy, hipStream_t stream);
 
 // small ops
 int launch_timestep_embedding(const float* t, int t_count, int n, int dim, int group, int flip_sin_to_cos,
                               float freq_shift, float scale, float max_period, bf16* out, int ldo, hipStream_t stream);
 int launch_silu(const void* x, void* y, long n, int in_f32, int out_f32, hipStream_t stream);
-int launch_conv_in3x3(const float* x_nchw, const float* in_scale, const bf16* w, const float* bias, bf16* y, int B,
+int launch_conv_in3x3(const float* x_nchw, const float* in_scale, const bf16* w, const float* bias, void* y, int out_f32, int B,
                       int Cin, int H, int W, int Cout, int ldy, hipStream_t stream);
 int launch_conv_out3x3(const bf16* x, int ldx, const bf16* w, const float* bias, float* y_nchw, int B, int Cin, int H,
                        int W, int Cout, hipStream_t stream);
-int launch_add_nchw(bf16* x, int ldx, const float* r, int B, int C, long HW, hipStream_t stream);
+int launch_cast_rows(const float* x, int ldx, bf16* y, int ldy, long rows, int C, hipStream_t stream);
+int launch_add_nchw(void* x, int x_f32, int ldx, const float* r, int B, int C, long HW, hipStream_t stream);
 int launch_latent_dist(const float* m, int ld, int B, int L, long HW, const float* noise, float out_scale, float* mean,
                        float* logvar, float* sample, hipStream_t stream);
 int launch_embed_tokens(const int* ids, long n_tokens, int seq_len, const bf16* tok, const bf16* pos, int D, bf16* out,

@@ -76,8 +76,9 @@ int launch_silu(const void* x, void* y, long n, int in_f32, int out_f32, hipStre
 // conv_in: x NCHW fp32 [B,Cin,H,W] (optionally multiplied by *in_scale: the scheduler's scale_model_input folded in),
 // rounded to bf16 like the reference's sample.cast(self.dtype); w packed [9*Cin][Cout] bf16, k = (ky*3+kx)*Cin + ci.
 // One thread = one pixel x 8 output channels.
+template <bool OUT_F32>
 __global__ void conv_in3x3_kernel(const float* __restrict__ x, const float* __restrict__ in_scale,
-                                  const bf16* __restrict__ w, const float* __restrict__ bias, bf16* __restrict__ y,
+                                  const bf16* __restrict__ w, const float* __restrict__ bias, void* __restrict__ y,
                                   int B, int Cin, int H, int W, int Cout, int ldy) {
   const int cv = Cout >> 3;
   const long total = (long)B * H * W * cv;
@@ -106,21 +107,31 @@ __global__ void conv_in3x3_kernel(const float* __restrict__ x, const float* __re
         }
       }
     }
-    u32x4 pk = {pack_bf16(acc[0], acc[1]), pack_bf16(acc[2], acc[3]), pack_bf16(acc[4], acc[5]),
-                pack_bf16(acc[6], acc[7])};
-    *reinterpret_cast<u32x4*>(y + (size_t)pix * ldy + cc * 8) = pk;
+    if constexpr (OUT_F32) {   // fp32 residual-stream mode: the stream starts unrounded
+      float* yr = reinterpret_cast<float*>(y) + (size_t)pix * ldy + cc * 8;
+      *reinterpret_cast<f32x4*>(yr) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+      *reinterpret_cast<f32x4*>(yr + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+    } else {
+      u32x4 pk = {pack_bf16(acc[0], acc[1]), pack_bf16(acc[2], acc[3]), pack_bf16(acc[4], acc[5]),
+                  pack_bf16(acc[6], acc[7])};
+      *reinterpret_cast<u32x4*>(reinterpret_cast<bf16*>(y) + (size_t)pix * ldy + cc * 8) = pk;
+    }
   }
 }
 
-int launch_conv_in3x3(const float* x_nchw, const float* in_scale, const bf16* w, const float* bias, bf16* y, int B,
+int launch_conv_in3x3(const float* x_nchw, const float* in_scale, const bf16* w, const float* bias, void* y, int out_f32, int B,
                       int Cin, int H, int W, int Cout, int ldy, hipStream_t stream) {
   if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return SD_ERR_INVALID;
   if ((Cout & 7) || (ldy & 7)) return SD_ERR_UNSUPPORTED;
   const long total = (long)B * H * W * (Cout >> 3);
   long nb = (total + 255) / 256;
   if (nb > 8192) nb = 8192;
-  hipLaunchKernelGGL(conv_in3x3_kernel, dim3((unsigned)nb), dim3(256), 0, stream, x_nchw, in_scale, w, bias, y, B, Cin,
-                     H, W, Cout, ldy);
+  if (out_f32)
+    hipLaunchKernelGGL(conv_in3x3_kernel<true>, dim3((unsigned)nb), dim3(256), 0, stream, x_nchw, in_scale, w, bias, y, B, Cin,
+                       H, W, Cout, ldy);
+  else
+    hipLaunchKernelGGL(conv_in3x3_kernel<false>, dim3((unsigned)nb), dim3(256), 0, stream, x_nchw, in_scale, w, bias, y, B, Cin,
+                       H, W, Cout, ldy);
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
 
@@ -191,7 +202,8 @@ int launch_conv_out3x3(const bf16* x, int ldx, const bf16* w, const float* bias,
 // unet_2d_condition.py:1121-1132, 1151-1155) added in place to a bf16 NHWC row view (row stride ldx, so it can be a
 // channel slice of a concat buffer). 64 pixels x 64 channels per block through LDS: the fp32 reads run along pixels,
 // the bf16 read-modify-write along channels.
-__global__ __launch_bounds__(256) void add_nchw_kernel(bf16* __restrict__ x, int ldx, const float* __restrict__ r, int C,
+template <bool XF32>
+__global__ __launch_bounds__(256) void add_nchw_kernel(void* __restrict__ xv, int ldx, const float* __restrict__ r, int C,
                                                        long HW) {
   __shared__ float tile[64][65];
   const long p0 = (long)blockIdx.x * 64;
@@ -207,21 +219,37 @@ __global__ __launch_bounds__(256) void add_nchw_kernel(bf16* __restrict__ x, int
     const long p = p0 + pp;
     const int c = c0 + cg * 8;
     if (p >= HW || c >= C) continue;
-    bf16* xr = x + ((size_t)b * HW + p) * ldx + c;
-    const u32x4 raw = *reinterpret_cast<const u32x4*>(xr);
-    const bf16x8 v = *reinterpret_cast<const bf16x8*>(&raw);
-    float o[8];
+    if constexpr (XF32) {   // fp32 residual-stream rows
+      float* xr = reinterpret_cast<float*>(xv) + ((size_t)b * HW + p) * ldx + c;
+      f32x4 a = *reinterpret_cast<const f32x4*>(xr), d = *reinterpret_cast<const f32x4*>(xr + 4);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (float)v[j] + tile[cg * 8 + j][pp];
-    u32x4 pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7])};
-    *reinterpret_cast<u32x4*>(xr) = pk;
+      for (int j = 0; j < 4; ++j) {
+        a[j] += tile[cg * 8 + j][pp];
+        d[j] += tile[cg * 8 + 4 + j][pp];
+      }
+      *reinterpret_cast<f32x4*>(xr) = a;
+      *reinterpret_cast<f32x4*>(xr + 4) = d;
+    } else {
+      bf16* xr = reinterpret_cast<bf16*>(xv) + ((size_t)b * HW + p) * ldx + c;
+      const u32x4 raw = *reinterpret_cast<const u32x4*>(xr);
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(&raw);
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (float)v[j] + tile[cg * 8 + j][pp];
+      u32x4 pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7])};
+      *reinterpret_cast<u32x4*>(xr) = pk;
+    }
   }
 }
 
-int launch_add_nchw(bf16* x, int ldx, const float* r, int B, int C, long HW, hipStream_t stream) {
+int launch_add_nchw(void* x, int x_f32, int ldx, const float* r, int B, int C, long HW, hipStream_t stream) {
   if (B <= 0 || C <= 0 || HW <= 0) return SD_ERR_INVALID;
   if ((C & 7) || (ldx & 7) || B > 65535 || (C + 63) / 64 > 65535) return SD_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(add_nchw_kernel, dim3((unsigned)((HW + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)B), dim3(256), 0,
+  if (x_f32)
+    hipLaunchKernelGGL(add_nchw_kernel<true>, dim3((unsigned)((HW + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)B), dim3(256), 0,
+                       stream, x, ldx, r, C, HW);
+  else
+  hipLaunchKernelGGL(add_nchw_kernel<false>, dim3((unsigned)((HW + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)B), dim3(256), 0,
                      stream, x, ldx, r, C, HW);
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
@@ -403,6 +431,29 @@ __global__ void copy_rows_kernel(const bf16* __restrict__ x, int ldx, bf16* __re
     const int cc = (int)(id - r * cv);
     *reinterpret_cast<u32x4*>(y + (size_t)r * ldy + cc * 8) = *reinterpret_cast<const u32x4*>(x + (size_t)r * ldx + cc * 8);
   }
+}
+
+// fp32 rows -> 16-bit rows (the operand copies of the fp32 residual-stream mode: inputs of the down / upsampling convs)
+__global__ void cast_rows_kernel(const float* __restrict__ x, int ldx, bf16* __restrict__ y, int ldy, long rows, int cv) {
+  const long total = rows * cv;
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long)gridDim.x * blockDim.x) {
+    const long r = id / cv;
+    const int cc = (int)(id - r * cv);
+    const float* xr = x + (size_t)r * ldx + cc * 8;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(xr), b = *reinterpret_cast<const f32x4*>(xr + 4);
+    u32x4 pk = {pack_bf16(a[0], a[1]), pack_bf16(a[2], a[3]), pack_bf16(b[0], b[1]), pack_bf16(b[2], b[3])};
+    *reinterpret_cast<u32x4*>(y + (size_t)r * ldy + cc * 8) = pk;
+  }
+}
+
+int launch_cast_rows(const float* x, int ldx, bf16* y, int ldy, long rows, int C, hipStream_t stream) {
+  if (rows <= 0 || C <= 0) return SD_ERR_INVALID;
+  if ((C & 7) || (ldx & 3) || (ldy & 7)) return SD_ERR_UNSUPPORTED;
+  const long total = rows * (C >> 3);
+  long nb = (total + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(cast_rows_kernel, dim3((unsigned)nb), dim3(256), 0, stream, x, ldx, y, ldy, rows, C >> 3);
+  return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
 
 int launch_copy_rows(const bf16* x, int ldx, bf16* y, int ldy, long rows, int C, hipStream_t stream) {

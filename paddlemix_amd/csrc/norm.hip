@@ -20,6 +20,23 @@ namespace sd {
 
 static int ln_grid(int rows, int rows_per_block);
 
+// 8 consecutive channels of a row as fp32: from the build's 16-bit elements (one 16-byte load) or, in the fp32
+// residual-stream mode (XF32), from fp32 rows (two 16-byte loads). `x` is the row base in ELEMENTS of its own type.
+template <bool XF32>
+__device__ __forceinline__ void load8f(const void* x, size_t elem_off, float (&f)[8]) {
+  if constexpr (XF32) {
+    const float* p = reinterpret_cast<const float*>(x) + elem_off;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f[j] = a[j]; f[4 + j] = b[j]; }
+  } else {
+    const u32x4 raw = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16*>(x) + elem_off);
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(&raw);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (float)v[j];
+  }
+}
+
 constexpr int GN_ITERS = 16;      // pixels per thread-slot per block
 constexpr int GN_MAXC = 4096;
 
@@ -42,7 +59,8 @@ static GnGeom gn_geom(int HW, int C) {
   return g;
 }
 
-__global__ void gn_partial_kernel(const bf16* __restrict__ x, int HW, int C, int ldx, int groups, int cv, int ppp,
+template <bool XF32>
+__global__ void gn_partial_kernel(const void* __restrict__ x, int HW, int C, int ldx, int groups, int cv, int ppp,
                                   int nthreads, int ppb, float* __restrict__ partial) {
   // Deterministic (fixed-order) reduction: per-thread channel partials -> LDS -> per-channel -> per-group.
   extern __shared__ __attribute__((aligned(16))) float gsm[];
@@ -58,15 +76,14 @@ __global__ void gn_partial_kernel(const bf16* __restrict__ x, int HW, int C, int
     float s[8], q[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
-    const bf16* xb = x + (size_t)b * HW * ldx + cc * 8;
+    const size_t xb = (size_t)b * HW * ldx + cc * 8;
     for (int pix = p_begin + pl; pix < p_end; pix += ppp) {
-      const u32x4 raw = *reinterpret_cast<const u32x4*>(xb + (size_t)pix * ldx);
-      const bf16x8 v = *reinterpret_cast<const bf16x8*>(&raw);
+      float v[8];
+      load8f<XF32>(x, xb + (size_t)pix * ldx, v);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float f = (float)v[j];
-        s[j] += f;
-        q[j] = __builtin_fmaf(f, f, q[j]);
+        s[j] += v[j];
+        q[j] = __builtin_fmaf(v[j], v[j], q[j]);
       }
     }
     float* ts = t_sum + (size_t)pl * C + cc * 8;
@@ -151,38 +168,49 @@ int groupnorm_partial_floats(int B, int HW, int C) {
   return B * g.nblk * 2 * 64;
 }
 
-int launch_groupnorm_stats(const bf16* x, int B, int HW, int C, int ldx, int groups, float eps, const float* gamma,
+int launch_groupnorm_stats(const void* x, int x_f32, int B, int HW, int C, int ldx, int groups, float eps, const float* gamma,
                            const float* beta, float* partial, float* scale_shift, hipStream_t stream) {
   if (B <= 0 || HW <= 0 || C <= 0) return SD_ERR_INVALID;
   if ((C & 7) || (ldx & 7) || C > GN_MAXC || groups <= 0 || groups > 64 || C % groups) return SD_ERR_UNSUPPORTED;
   const GnGeom g = gn_geom(HW, C);
   if (g.block > 1024) return SD_ERR_UNSUPPORTED;
   const size_t lds = (size_t)(2 * g.ppp + 2) * C * sizeof(float);
-  hipLaunchKernelGGL(gn_partial_kernel, dim3(g.nblk, B), dim3(g.block), lds, stream, x, HW, C, ldx, groups, g.cv,
-                     g.ppp, g.threads, g.ppb, partial);
+  if (x_f32)
+    hipLaunchKernelGGL(gn_partial_kernel<true>, dim3(g.nblk, B), dim3(g.block), lds, stream, x, HW, C, ldx, groups, g.cv,
+                       g.ppp, g.threads, g.ppb, partial);
+  else
+    hipLaunchKernelGGL(gn_partial_kernel<false>, dim3(g.nblk, B), dim3(g.block), lds, stream, x, HW, C, ldx, groups, g.cv,
+                       g.ppp, g.threads, g.ppb, partial);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(512), 0, stream, partial, g.nblk, HW, C, groups, eps, gamma,
                      beta, scale_shift);
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
 
-template <bool SILU>
-__global__ void scale_shift_act_kernel(const bf16* __restrict__ x, long total_chunks, int HW, int C, int ldx,
-                                       const float* __restrict__ scale_shift, bf16* __restrict__ y, int ldy) {
+// XF32: x rows are fp32 (residual-stream mode); raw16 (optional, XF32 only) receives the 16-bit rounding of the raw rows
+// in the same pass -- the operand of the resnet's conv_shortcut GEMM (resnet.py:797-798), which must not read fp32.
+template <bool SILU, bool XF32>
+__global__ void scale_shift_act_kernel(const void* __restrict__ x, long total_chunks, int HW, int C, int ldx,
+                                       const float* __restrict__ scale_shift, bf16* __restrict__ y, int ldy,
+                                       bf16* __restrict__ raw16, int ld_raw) {
   const int cv = C >> 3;
   for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total_chunks; id += (long)gridDim.x * blockDim.x) {
     const long pix = id / cv;
     const int cc = (int)(id - pix * cv);
     const int b = (int)(pix / HW);
-    const u32x4 raw = *reinterpret_cast<const u32x4*>(x + (size_t)pix * ldx + cc * 8);
-    const bf16x8 v = *reinterpret_cast<const bf16x8*>(&raw);
+    float v[8];
+    load8f<XF32>(x, (size_t)pix * ldx + cc * 8, v);
+    if (XF32 && raw16) {
+      u32x4 rk = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+      *reinterpret_cast<u32x4*>(raw16 + (size_t)pix * ld_raw + cc * 8) = rk;
+    }
     const float* sc = scale_shift + (size_t)b * 2 * C + cc * 8;
     const f32x4 a0 = *reinterpret_cast<const f32x4*>(sc), a1 = *reinterpret_cast<const f32x4*>(sc + 4);
     const f32x4 b0 = *reinterpret_cast<const f32x4*>(sc + C), b1 = *reinterpret_cast<const f32x4*>(sc + C + 4);
     float o[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      o[j] = __builtin_fmaf((float)v[j], a0[j], b0[j]);
-      o[4 + j] = __builtin_fmaf((float)v[4 + j], a1[j], b1[j]);
+      o[j] = __builtin_fmaf(v[j], a0[j], b0[j]);
+      o[4 + j] = __builtin_fmaf(v[4 + j], a1[j], b1[j]);
     }
     if (SILU) {
 #pragma unroll
@@ -193,20 +221,21 @@ __global__ void scale_shift_act_kernel(const bf16* __restrict__ x, long total_ch
   }
 }
 
-int launch_scale_shift_act(const bf16* x, int B, int HW, int C, int ldx, const float* scale_shift, int silu, bf16* y,
-                           int ldy, hipStream_t stream) {
+int launch_scale_shift_act(const void* x, int x_f32, int B, int HW, int C, int ldx, const float* scale_shift, int silu, bf16* y,
+                           int ldy, bf16* raw16, int ld_raw, hipStream_t stream) {
   if (B <= 0 || HW <= 0 || C <= 0) return SD_ERR_INVALID;
   if ((C & 7) || (ldx & 7) || (ldy & 7)) return SD_ERR_UNSUPPORTED;
+  if (raw16 && (!x_f32 || (ld_raw & 7))) return SD_ERR_UNSUPPORTED;
   const long total = (long)B * HW * (C >> 3);
   const int block = 256;
   long nb = (total + block - 1) / block;
   if (nb > 256 * 16) nb = 256 * 16;
-  if (silu)
-    hipLaunchKernelGGL(scale_shift_act_kernel<true>, dim3((unsigned)nb), dim3(block), 0, stream, x, total, HW, C, ldx,
-                       scale_shift, y, ldy);
-  else
-    hipLaunchKernelGGL(scale_shift_act_kernel<false>, dim3((unsigned)nb), dim3(block), 0, stream, x, total, HW, C, ldx,
-                       scale_shift, y, ldy);
+#define SD_SSA(S_, F_) \
+  hipLaunchKernelGGL((scale_shift_act_kernel<S_, F_>), dim3((unsigned)nb), dim3(block), 0, stream, x, total, HW, C, ldx, \
+                     scale_shift, y, ldy, raw16, ld_raw)
+  if (silu) { if (x_f32) SD_SSA(true, true); else SD_SSA(true, false); }
+  else      { if (x_f32) SD_SSA(false, true); else SD_SSA(false, false); }
+#undef SD_SSA
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
 
@@ -214,8 +243,8 @@ int launch_scale_shift_act(const bf16* x, int B, int HW, int C, int ldx, const f
 // (ROWS at a time: all loads issued up front, the ROWS reduction chains interleave), so the per-row traffic is
 // exactly one read and one write of the row. Statistics in one pass over data shifted by the row's first element
 // (sum(x-K), sum((x-K)^2): no cancellation for the O(1..10) activations here), fp32.
-template <int NCH, int ROWS>
-__global__ __launch_bounds__(256) void layernorm_kernel(const bf16* __restrict__ x, int rows, int C, int ldx,
+template <int NCH, int ROWS, bool XF32 = false>
+__global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__ x, int rows, int C, int ldx,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float eps, bf16* __restrict__ y, int ldy) {
   const int lane = threadIdx.x & 63;
@@ -238,15 +267,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16* __restrict__
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
       const int row = min(row0 + r, rows - 1);
-      const bf16* xr = x + (size_t)row * ldx;
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
         const int cc = lane + 64 * i;
-        u32x4 raw = {0u, 0u, 0u, 0u};
-        if (cc < cv) raw = *reinterpret_cast<const u32x4*>(xr + cc * 8);
-        const bf16x8 t = *reinterpret_cast<const bf16x8*>(&raw);
+        if (cc < cv) {
+          load8f<XF32>(x, (size_t)row * ldx + cc * 8, v[r][i]);
+        } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[r][i][j] = (float)t[j];
+          for (int j = 0; j < 8; ++j) v[r][i][j] = 0.f;
+        }
       }
     }
     float mean[ROWS], rstd[ROWS], s1[ROWS], s2[ROWS];
@@ -314,7 +343,7 @@ static int ln_grid(int rows, int rows_per_block) {
   return blocks < needed ? blocks : needed;
 }
 
-int launch_layernorm(const bf16* x, int rows, int C, int ldx, const float* gamma, const float* beta, float eps, bf16* y,
+int launch_layernorm(const void* x, int x_f32, int rows, int C, int ldx, const float* gamma, const float* beta, float eps, bf16* y,
                      int ldy, hipStream_t stream) {
   if (rows <= 0 || C <= 0) return SD_ERR_INVALID;
   if ((C & 7) || (ldx & 7) || (ldy & 7) || C > 2560) return SD_ERR_UNSUPPORTED;
@@ -322,11 +351,17 @@ int launch_layernorm(const bf16* x, int rows, int C, int ldx, const float* gamma
   const int cv = C >> 3;
   constexpr int R = 4;   // measured: 4 rows in flight per wave beats 2 (4.6 vs 5.2 ms per SDXL step)
   const int blocks = ln_grid(rows, wpb * R);
-#define SD_LN_LAUNCH(NCH) \
-  hipLaunchKernelGGL((layernorm_kernel<NCH, R>), dim3(blocks), dim3(64 * wpb), 0, stream, x, rows, C, ldx, gamma, beta, eps, y, ldy)
-  if (cv <= 128) SD_LN_LAUNCH(2);
-  else if (cv <= 192) SD_LN_LAUNCH(3);
-  else hipLaunchKernelGGL((layernorm_kernel<5, 2>), dim3(blocks), dim3(64 * wpb), 0, stream, x, rows, C, ldx, gamma, beta, eps, y, ldy);
+#define SD_LN_LAUNCH(NCH, R_, F_) \
+  hipLaunchKernelGGL((layernorm_kernel<NCH, R_, F_>), dim3(blocks), dim3(64 * wpb), 0, stream, x, rows, C, ldx, gamma, beta, eps, y, ldy)
+  if (x_f32) {
+    if (cv <= 128) SD_LN_LAUNCH(2, R, true);
+    else if (cv <= 192) SD_LN_LAUNCH(3, R, true);
+    else SD_LN_LAUNCH(5, 2, true);
+  } else {
+    if (cv <= 128) SD_LN_LAUNCH(2, R, false);
+    else if (cv <= 192) SD_LN_LAUNCH(3, R, false);
+    else SD_LN_LAUNCH(5, 2, false);
+  }
 #undef SD_LN_LAUNCH
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }

@@ -25,7 +25,7 @@ import torch
 
 from . import _lib
 from ._lib import GELU_TANH, OUT_F32, SILU
-from .checkpoint import PretrainedMixin
+from .checkpoint import PretrainedMixin, Table
 from .program import DeviceProgram, _Plan, _Ref, _V
 from .sd3 import Transformer2DModelOutput
 
@@ -71,7 +71,7 @@ def dit_param_shapes(config: Mapping) -> Dict[str, tuple]:
         b = f"transformer_blocks.{i}"
         lin(b + ".norm1.emb.timestep_embedder.linear_1", 256, D)
         lin(b + ".norm1.emb.timestep_embedder.linear_2", D, D)
-        S[b + ".norm1.emb.class_embedder.embedding_table.weight"] = (cfg["num_embeds_ada_norm"] + 1, D)
+        S[b + ".norm1.emb.class_embedder.embedding_table.weight"] = Table((cfg["num_embeds_ada_norm"] + 1, D))
         lin(b + ".norm1.linear", D, 6 * D)
         for nm in ("to_q", "to_k", "to_v", "to_out.0"):
             lin(b + ".attn1." + nm, D, D)

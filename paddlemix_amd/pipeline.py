@@ -232,7 +232,13 @@ class StableDiffusionDenoiser:
             prompt_embeds, pooled = self.encode_prompt(prompt_ids, prompt_ids_2)
             neg_pooled = None
             if do_cfg and negative_prompt_embeds is None:
-                if negative_prompt_ids is None:   # force_zeros_for_empty_prompt (pipeline_stable_diffusion_xl.py:378-381)
+                if negative_prompt_ids is None:
+                    # SDXL only: force_zeros_for_empty_prompt (pipeline_stable_diffusion_xl.py:378-381). The single-encoder
+                    # pipelines encode the empty prompt "" through the text encoder instead (pipeline_stable_diffusion.py:409-441),
+                    # and the tokenizer is not part of this path -> the caller must pass its token ids.
+                    if self.text_encoder_2 is None:
+                        raise ValueError("classifier-free guidance on a single-encoder pipeline needs `negative_prompt_ids` "
+                                         "(the tokenised \"\" of the reference) or `negative_prompt_embeds`")
                     negative_prompt_embeds = torch.zeros_like(prompt_embeds)
                     neg_pooled = None if pooled is None else torch.zeros_like(pooled)
                 else:
@@ -259,10 +265,19 @@ class StableDiffusionDenoiser:
             if added_cond_kwargs is not None:
                 neg = negative_added_cond_kwargs or added_cond_kwargs
                 added_cond_kwargs = {k: torch.cat([neg[k], v]) for k, v in added_cond_kwargs.items()}
-        self.scheduler.set_timesteps(num_inference_steps)
+        import inspect
+        # LatentConsistencyModelImg2ImgPipeline (pipeline_latent_consistency_img2img.py:760-764): a scheduler whose
+        # set_timesteps takes `strength` (LCMScheduler) shortens its own distillation schedule and ALL num_inference_steps of it
+        # run; every other scheduler keeps the SD img2img rule (the last int(steps * strength) entries, get_timesteps)
+        lcm_strength = image is not None and "strength" in inspect.signature(self.scheduler.set_timesteps).parameters
+        if lcm_strength:
+            self.scheduler.set_timesteps(num_inference_steps, strength=strength)
+        else:
+            self.scheduler.set_timesteps(num_inference_steps)
         timesteps, first, inp = self.scheduler.timesteps, 0, None
         if image is not None:
-            timesteps, _, first = self.get_timesteps(num_inference_steps, strength)
+            if not lcm_strength:
+                timesteps, _, first = self.get_timesteps(num_inference_steps, strength)
             if len(timesteps) < 1:
                 raise ValueError(f"After adjusting the num_inference_steps by strength parameter: {strength}, the number of "
                                  "pipeline steps is 0 which is < 1 and not appropriate for this pipeline.")
@@ -273,7 +288,6 @@ class StableDiffusionDenoiser:
                 latents = self.prepare_image_latents(image, timesteps[:1], B, generator)
         else:
             latents = self.prepare_latents(B, cfg.in_channels, h, w, torch.float32, generator, latents, prompt_embeds.device)
-        import inspect
         step_params = inspect.signature(self.scheduler.step).parameters   # prepare_extra_step_kwargs (:520-535)
         extra = {}
         if "eta" in step_params:

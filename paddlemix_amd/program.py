@@ -24,14 +24,15 @@ class _Ref:
 
 
 class _V:
-    """Row view: `rows` rows of `C` bf16 channels, row stride `ld` elements, at address `p` (int or _Ref)."""
-    __slots__ = ("p", "rows", "C", "ld")
+    """Row view: `rows` rows of `C` channels of `es` bytes each (2 = the build's 16-bit element, 4 = fp32: the residual
+    stream of the fp32-residual mode), row stride `ld` elements, at address `p` (int or _Ref)."""
+    __slots__ = ("p", "rows", "C", "ld", "es")
 
-    def __init__(self, p, rows, C, ld=None):
-        self.p, self.rows, self.C, self.ld = p, rows, C, (C if ld is None else ld)
+    def __init__(self, p, rows, C, ld=None, es=2):
+        self.p, self.rows, self.C, self.ld, self.es = p, rows, C, (C if ld is None else ld), es
 
     def cols(self, off: int, C: int) -> "_V":
-        return _V(self.p + 2 * off, self.rows, C, self.ld)
+        return _V(self.p + self.es * off, self.rows, C, self.ld, self.es)
 
 
 class _Plan:

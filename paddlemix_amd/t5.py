@@ -17,7 +17,7 @@ from typing import Dict, List, Mapping, Optional
 import torch
 
 from . import _lib
-from .checkpoint import PretrainedMixin
+from .checkpoint import PretrainedMixin, Table
 from .program import DeviceProgram, _Plan
 
 Tensor = torch.Tensor
@@ -41,15 +41,15 @@ def t5_param_shapes(config: Mapping) -> Dict[str, tuple]:
     """name -> shape (Paddle layouts) of the encoder's parameters; names as in the reference checkpoints."""
     cfg = normalize_config(config)
     D, inner, Fd = cfg["d_model"], cfg["num_heads"] * cfg["d_kv"], cfg["d_ff"]
-    S: Dict[str, tuple] = {"shared.weight": (cfg["vocab_size"], D)}
+    S: Dict[str, tuple] = {"shared.weight": Table((cfg["vocab_size"], D))}
     for i in range(cfg["num_layers"]):
         b = f"encoder.block.{i}"
         for n in ("q", "k", "v"):
             S[f"{b}.layer.0.SelfAttention.{n}.weight"] = (D, inner)
         S[f"{b}.layer.0.SelfAttention.o.weight"] = (inner, D)
         if i == 0:
-            S[f"{b}.layer.0.SelfAttention.relative_attention_bias.weight"] = (cfg["relative_attention_num_buckets"],
-                                                                               cfg["num_heads"])
+            S[f"{b}.layer.0.SelfAttention.relative_attention_bias.weight"] = Table((cfg["relative_attention_num_buckets"],
+                                                                                     cfg["num_heads"]))   # nn.Embedding
         S[f"{b}.layer.0.layer_norm.weight"] = (D,)
         S[f"{b}.layer.1.DenseReluDense.wi_0.weight"] = (D, Fd)
         S[f"{b}.layer.1.DenseReluDense.wi_1.weight"] = (D, Fd)

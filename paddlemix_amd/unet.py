@@ -28,8 +28,8 @@ from typing import Dict, List, Mapping, Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import GEGLU, OUT_F32, SILU
-from .checkpoint import PretrainedMixin
+from ._lib import GEGLU, OUT_F32, R_F32, SILU
+from .checkpoint import PretrainedMixin, Table
 from .program import DeviceProgram, _Plan, _Ref, _V
 
 Tensor = torch.Tensor
@@ -49,6 +49,10 @@ UNET_DEFAULTS = dict(
     ip_adapter_num_tokens=4,   # extension: ImageProjection.num_image_text_embeds, which the reference reads off the IP-Adapter
                                # checkpoint instead of the config (loaders/unet.py _load_ip_adapter_weights)
 )
+_ONLY_DEFAULT = dict(attention_type="default", conv_in_kernel=3, conv_out_kernel=3, dropout=(0.0, 0), data_format="NCHW",
+                     mid_block_only_cross_attention=(None, False), reverse_transformer_layers_per_block=None,
+                     resnet_out_scale_factor=(1.0, 1), resnet_pre_temb_non_linearity=(None, False),
+                     addition_embed_type_num_heads=64)
 _UNSUPPORTED_IF_SET = ("time_embedding_dim", "time_embedding_act_fn", "timestep_post_act",
                        "cross_attention_norm", "dual_cross_attention", "resnet_skip_time_act")
 
@@ -60,6 +64,12 @@ def normalize_config(config: Mapping) -> dict:
     for k in _UNSUPPORTED_IF_SET:
         if cfg.get(k) not in (None, False):
             raise NotImplementedError(f"UNet2DConditionModel(mi355x): config {k}={cfg[k]!r} is not implemented")
+    # ctor arguments of the reference (unet_2d_condition.py:172-226) that change the arithmetic and are built only at their
+    # default value: a checkpoint whose config sets them differently must not load silently
+    for k, default in _ONLY_DEFAULT.items():
+        if k in cfg and cfg[k] not in (default if isinstance(default, tuple) else (default,)):
+            raise NotImplementedError(f"UNet2DConditionModel(mi355x): config {k}={cfg[k]!r} is not implemented "
+                                      f"(only {default!r})")
     # encoder_hid_proj (unet_2d_condition.py:300-335): the IP-Adapter image projection is built, text_proj / image_proj are not
     if cfg["encoder_hid_dim_type"] not in (None, "ip_image_proj"):
         raise NotImplementedError(f"UNet2DConditionModel(mi355x): encoder_hid_dim_type={cfg['encoder_hid_dim_type']!r} "
@@ -182,7 +192,7 @@ def unet_param_shapes(config: Mapping) -> Dict[str, tuple]:
     lin("time_embedding.linear_2", ted, ted)
     ct, pdim = cfg["class_embed_type"], cfg["projection_class_embeddings_input_dim"]
     if ct is None and cfg["num_class_embeds"] is not None:
-        S["class_embedding.weight"] = (cfg["num_class_embeds"], ted)          # nn.Embedding
+        S["class_embedding.weight"] = Table((cfg["num_class_embeds"], ted))   # nn.Embedding: never transposed
     elif ct in ("timestep", "projection"):                                     # TimestepEmbedding
         lin("class_embedding.linear_1", boc[0] if ct == "timestep" else pdim, ted)
         lin("class_embedding.linear_2", ted, ted)
@@ -270,7 +280,8 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
     _param_shapes = staticmethod(unet_param_shapes)
 
     def __init__(self, config: Mapping, params: Mapping[str, Tensor], device="cuda", use_graph: bool = True,
-                 profile: bool = False, fold_layernorm: Optional[bool] = None, _test_backend=None):
+                 profile: bool = False, fold_layernorm: Optional[bool] = None, residual_dtype: Optional[str] = None,
+                 _test_backend=None):
         """``_test_backend``: test-only injection point (tests/abi_emulator.py interprets the emitted C-ABI
         program on host memory to check the sequencing / packing logic without a GPU).  It is never selected by
         product code: without it the model needs the built HIP library and a GPU, and raises otherwise."""
@@ -281,6 +292,16 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
         # activations and run 6-12 % slower (operand-dependent MFMA power), a wash end to end
         # (profiles/r01_lnfold_ab.txt). MI355X_SD_LNFOLD=1 or fold_layernorm=True turns it on.
         self.fold_ln = (os.environ.get("MI355X_SD_LNFOLD") is not None) if fold_layernorm is None else bool(fold_layernorm)
+        # residual_dtype="fp32" (or MI355X_SD_RESID=fp32): the residual stream -- resnet outputs, the transformer blocks' hidden
+        # state, every skip / concat slot -- is stored in fp32; 16-bit values exist only as MFMA operands (the outputs of
+        # GroupNorm / LayerNorm / GEGLU / attention, which feed exactly one contraction each). Each branch then rounds once
+        # instead of the stream re-rounding after every one of its ~50-200 sequential adds.
+        rd = os.environ.get("MI355X_SD_RESID", "") if residual_dtype is None else residual_dtype
+        if rd not in ("", None, "fp32", "16"):
+            raise ValueError(f"residual_dtype must be None | '16' | 'fp32', got {rd!r}")
+        self.resid_f32 = rd == "fp32"
+        if self.resid_f32 and (self.fold_ln or self._encoder_only):
+            raise NotImplementedError("residual_dtype='fp32' with fold_layernorm / ControlNetModel")
         self.cfg = normalize_config(config)
         # .config shows the constructor arguments as given (register_to_config), not the per-block expansion
         pub = dict(UNET_DEFAULTS)
@@ -475,6 +496,8 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
             N, K = w.shape
             assert K == a.C, (wkey, K, a.C)
             b = (W[bkey] if bkey else W[wkey + ".b"]).data_ptr() if bias else None
+            assert a.es == 2, (wkey, "fp32 rows cannot be an MFMA operand")
+            flags |= (OUT_F32 if out.es == 4 else 0) | (R_F32 if (R is not None and R.es == 4) else 0)
             emit(lib.mi355x_sd_linear,
                  (a.p, a.ld, w.data_ptr(), out.p, out.ld, a.rows, N, K, b, rowbias, rpb, ld_rb,
                   R.p if R else None, R.ld if R else 0, out_scale, flags, stream), "gemm", 2.0 * a.rows * N * K,
@@ -485,26 +508,50 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
             Cout = w.shape[0]
             ho = ((h << up) + 2 - 3) // stride + 1
             wo = ((w_ << up) + 2 - 3) // stride + 1
+            assert x.es == 2, (wkey, "fp32 rows cannot be an MFMA operand")
+            flags |= (OUT_F32 if out.es == 4 else 0) | (R_F32 if (R is not None and R.es == 4) else 0)
             emit(lib.mi355x_sd_conv3x3,
                  (x.p, x.ld, B, h, w_, x.C, stride, up, w.data_ptr(), out.p, out.ld, Cout, W[wkey + ".b"].data_ptr(),
                   rowbias, self._temb_total if rowbias is not None else 0, R.p if R else None, R.ld if R else 0,
                   out_scale, flags, stream), "conv", 2.0 * B * ho * wo * Cout * 9 * x.C,
                  f"{B * ho * wo}x{Cout}x{9 * x.C}" + ("s2" if stride == 2 else "") + ("up" if up else ""))
 
-        def gnorm(x: _V, hw, nkey, eps_, silu) -> _V:
+        def gnorm(x: _V, hw, nkey, eps_, silu, raw16: Optional[_V] = None) -> _V:
+            """GroupNorm (+SiLU) of x -> 16-bit rows. fp32-residual mode: x is fp32; `raw16` (optional) receives the 16-bit
+            rounding of the raw x rows in the same pass (the operand of a conv_shortcut GEMM)."""
             nws = lib.mi355x_sd_groupnorm_workspace_floats(B, hw, x.C)
             ws = sc("gn_ws", 4 * nws)
             ss = sc("gn_ss", 4 * B * 2 * x.C)
             y = _V(sc("gn", 2 * x.rows * x.C), x.rows, x.C)
-            emit(lib.mi355x_sd_groupnorm_stats, (x.p, B, hw, x.C, x.ld, groups, eps_, wp(nkey + ".g"), wp(nkey + ".b"),
-                                                 ws, ss, stream), "gn_stats")
-            emit(lib.mi355x_sd_scale_shift_act, (x.p, B, hw, x.C, x.ld, ss, 1 if silu else 0, y.p, y.ld, stream),
-                 "gn_apply")
+            if x.es == 2:
+                assert raw16 is None
+                emit(lib.mi355x_sd_groupnorm_stats, (x.p, B, hw, x.C, x.ld, groups, eps_, wp(nkey + ".g"), wp(nkey + ".b"),
+                                                     ws, ss, stream), "gn_stats")
+                emit(lib.mi355x_sd_scale_shift_act, (x.p, B, hw, x.C, x.ld, ss, 1 if silu else 0, y.p, y.ld, stream),
+                     "gn_apply")
+            else:
+                emit(lib.mi355x_sd_groupnorm_stats_ex, (x.p, B, hw, x.C, x.ld, groups, eps_, wp(nkey + ".g"),
+                                                        wp(nkey + ".b"), ws, ss, 1, stream), "gn_stats")
+                emit(lib.mi355x_sd_scale_shift_act_ex, (x.p, B, hw, x.C, x.ld, ss, 1 if silu else 0, y.p, y.ld, 1,
+                                                        raw16.p if raw16 else None, raw16.ld if raw16 else 0, stream),
+                     "gn_apply")
+            return y
+
+        def cast16(x: _V, name: str) -> _V:
+            """16-bit copy of fp32 rows (operand of the down / upsampling convs in the fp32-residual mode)"""
+            if x.es == 2:
+                return x
+            y = _V(sc(name, 2 * x.rows * x.C), x.rows, x.C)
+            emit(lib.mi355x_sd_cast_rows, (x.p, x.ld, y.p, y.ld, x.rows, x.C, stream), "misc")
             return y
 
         def lnorm(x: _V, nkey, out: _V):
-            emit(lib.mi355x_sd_layernorm, (x.p, x.rows, x.C, x.ld, wp(nkey + ".g"), wp(nkey + ".b"), 1e-5, out.p,
-                                           out.ld, stream), "ln")
+            if x.es == 2:
+                emit(lib.mi355x_sd_layernorm, (x.p, x.rows, x.C, x.ld, wp(nkey + ".g"), wp(nkey + ".b"), 1e-5, out.p,
+                                               out.ld, stream), "ln")
+            else:
+                emit(lib.mi355x_sd_layernorm_ex, (x.p, x.rows, x.C, x.ld, wp(nkey + ".g"), wp(nkey + ".b"), 1e-5, out.p,
+                                                  out.ld, 1, stream), "ln")
 
         def ln_linear(x: _V, wkey: str, out: _V, flags=0):
             """LayerNorm(eps 1e-5, attention.py:318-331) folded into the projection: statistics pass + raw-row GEMM"""
@@ -647,6 +694,8 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
                 break
         ups = [d for d in S if d[0] == "resnet" and d[1].startswith("up_blocks.")]
         assert len(ups) == len(skips) or self._encoder_only
+        RES = 4 if self.resid_f32 else 2                       # bytes per element of the residual stream
+        res_dt = torch.float32 if self.resid_f32 else _lib.elem_dtype()
         own_skips = [_V(persist((B * hs * ws_, cs), _lib.elem_dtype()).data_ptr(), B * hs * ws_, cs)
                      for cs, hs, ws_ in skips] if self._encoder_only else None   # no up path to host them
         cats: List[_V] = []
@@ -654,8 +703,8 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
         for u, d in enumerate(ups):  # up resnet u consumes skip n-1-u
             cs, hs, ws_ = skips[len(skips) - 1 - u]
             cx = d[2] - cs
-            t = persist((B * hs * ws_, cx + cs), _lib.elem_dtype())
-            cats.append(_V(t.data_ptr(), B * hs * ws_, cx + cs))
+            t = persist((B * hs * ws_, cx + cs), res_dt)
+            cats.append(_V(t.data_ptr(), B * hs * ws_, cx + cs, es=RES))
             cat_xc.append(cx)
 
         def skip_slot(k: int) -> _V:  # where skip k is produced
@@ -667,18 +716,25 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
         def x_slot(u: int) -> _V:
             return cats[u].cols(0, cat_xc[u])
 
+        def add_nchw(dst: _V, r: Tensor, c, hw):
+            if dst.es == 2:
+                return lib.mi355x_sd_add_nchw, (dst.p, dst.ld, r.data_ptr(), B, c, hw, stream)
+            return lib.mi355x_sd_add_nchw_ex, (dst.p, dst.ld, r.data_ptr(), B, c, hw, 1, stream)
+
         # ---- layer emitters ----
         def resnet(name, x: _V, h, w_, cout, scale, out: _V):
             hw = h * w_
             rows = B * hw
-            g1 = gnorm(x, hw, name + ".norm1", eps, True)
-            h1 = _V(sc("h1", 2 * rows * cout), rows, cout)
+            need_short = x.C != cout
+            x16 = _V(sc("x16", 2 * rows * x.C), rows, x.C) if (need_short and x.es == 4) else None
+            g1 = gnorm(x, hw, name + ".norm1", eps, True, raw16=x16)
+            h1 = _V(sc("h1", RES * rows * cout), rows, cout, es=RES)   # fp32 mode: GroupNorm 2 reads the unrounded conv1 output
             rb = temb_all.data_ptr() + 4 * self._temb_off[name]
             conv3(g1, h, w_, name + ".conv1", h1, rowbias=rb)
             g2 = gnorm(h1, hw, name + ".norm2", eps, True)
-            if x.C != cout:
-                short = _V(sc("short", 2 * rows * cout), rows, cout)
-                linear(x, name + ".conv_shortcut", short)
+            if need_short:
+                short = _V(sc("short", RES * rows * cout), rows, cout, es=RES)
+                linear(x16 if x16 is not None else x, name + ".conv_shortcut", short)
             else:
                 short = x
             conv3(g2, h, w_, name + ".conv2", out, R=short, out_scale=1.0 / scale)
@@ -688,7 +744,8 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
             rows = B * hw
             c = x.C
             g = gnorm(x, hw, name + ".norm", 1e-6, False)
-            hid = _V(sc("t_h", 2 * rows * c), rows, c)
+            hid = _V(sc("t_h", RES * rows * c), rows, c, es=RES)
+            hid16 = _V(sc("t_h16", 2 * rows * c), rows, c) if RES == 4 else hid   # proj_out's operand: the last FF2 writes it
             linear(g, name + ".proj_in", hid)
             ln = None if self.fold_ln else _V(sc("t_ln", 2 * rows * c), rows, c)
             qkv = _V(sc("t_qkv", 2 * rows * 3 * c), rows, 3 * c)
@@ -720,17 +777,22 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
                 else:
                     lnorm(hid, b + ".norm3", ln)
                     linear(ln, b + ".ff1", ff, flags=GEGLU)
-                linear(ff, b + ".ff2", hid, R=hid)
-            linear(hid, name + ".proj_out", out, R=x)
+                linear(ff, b + ".ff2", hid16 if l == layers - 1 else hid, R=hid)
+            linear(hid16, name + ".proj_out", out, R=x)
 
         # ---- body ----
         h, w_ = H, Wd
         k = 0            # next skip index to produce
         u = 0            # next up resnet index
         cur = skip_slot(0)
-        emit(lib.mi355x_sd_conv_in3x3, (plan.sample.data_ptr(), plan.in_scale.data_ptr(), wp("conv_in.w"),
-                                        wp("conv_in.b"), cur.p, B, cfg["in_channels"], H, Wd, boc[0], cur.ld, stream),
-             "misc")
+        if cur.es == 2:
+            emit(lib.mi355x_sd_conv_in3x3, (plan.sample.data_ptr(), plan.in_scale.data_ptr(), wp("conv_in.w"),
+                                            wp("conv_in.b"), cur.p, B, cfg["in_channels"], H, Wd, boc[0], cur.ld, stream),
+                 "misc")
+        else:
+            emit(lib.mi355x_sd_conv_in3x3_ex, (plan.sample.data_ptr(), plan.in_scale.data_ptr(), wp("conv_in.w"),
+                                               wp("conv_in.b"), cur.p, B, cfg["in_channels"], H, Wd, boc[0], cur.ld, 1,
+                                               stream), "misc")
         if self._encoder_only:
             self._emit_pre(plan, cur, B, H, Wd, persist, emit, conv3)
         k = 1
@@ -739,7 +801,7 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
         def tmp(rows, c) -> _V:
             nonlocal tmp_i
             tmp_i ^= 1
-            return _V(sc(f"x{tmp_i}", 2 * rows * c), rows, c)
+            return _V(sc(f"x{tmp_i}", RES * rows * c), rows, c, es=RES)
 
         i = 1  # S[0] is the conv_in skip
         n_layers = len(S)
@@ -768,7 +830,7 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
             elif d[0] == "down":
                 ho, wo = (h + 2 - 3) // 2 + 1, (w_ + 2 - 3) // 2 + 1
                 dst = skip_slot(k)
-                conv3(cur, h, w_, d[1], dst, stride=2)
+                conv3(cast16(cur, "xc16"), h, w_, d[1], dst, stride=2)
                 h, w_ = ho, wo
                 cur = dst
             elif d[0] == "cat":
@@ -780,14 +842,14 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
                         rt = persist((B, cs, hs, ws_), torch.float32)
                         plan.ctrl_down.append(rt)
                         sl = skip_slot(kk)
-                        emit(lib.mi355x_sd_add_nchw, (sl.p, sl.ld, rt.data_ptr(), B, cs, hs * ws_, stream), "misc")
+                        emit(*add_nchw(sl, rt, cs, hs * ws_), "misc")
                     plan.ctrl_mid = persist((B, cur.C, h, w_), torch.float32)
-                    emit(lib.mi355x_sd_add_nchw, (cur.p, cur.ld, plan.ctrl_mid.data_ptr(), B, cur.C, h * w_, stream), "misc")
+                    emit(*add_nchw(cur, plan.ctrl_mid, cur.C, h * w_), "misc")
                 cur = cats[u]
                 u += 1
             elif d[0] == "up":
                 dst = x_slot(u)
-                conv3(cur, h, w_, d[1], dst, up=1)
+                conv3(cast16(cur, "xc16"), h, w_, d[1], dst, up=1)
                 h, w_ = 2 * h, 2 * w_
                 cur = dst
             i += 1

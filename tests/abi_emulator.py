@@ -18,7 +18,7 @@ import torch.nn.functional as F
 
 from paddlemix_amd import _lib
 
-GEGLU, OUT_F32, SILU, GELU_TANH = 1, 2, 4, 8
+GEGLU, OUT_F32, SILU, GELU_TANH, R_F32 = 1, 2, 4, 8, 32
 _ES = {torch.bfloat16: 2, torch.float16: 2, torch.float32: 4}
 
 
@@ -65,7 +65,7 @@ class Emulator:
                 rb = _rows(rowbias, nb, N, ld_rb, torch.float32)
                 acc = acc + rb.repeat_interleave(rpb, 0)[:M]
             if R:
-                acc = acc + _rows(R, M, N, ldr).float()
+                acc = acc + _rows(R, M, N, ldr, torch.float32 if flags & R_F32 else None).float()
             acc = acc * out_scale
             if flags & SILU:
                 acc = F.silu(acc)
@@ -281,9 +281,25 @@ class Emulator:
         return 0
 
     # ---- norms ----
-    def mi355x_sd_groupnorm_stats(self, x, B, HW, C, ldx, groups, eps, gamma, beta, ws, ss, stream):
+    def mi355x_sd_groupnorm_stats_ex(self, x, B, HW, C, ldx, groups, eps, gamma, beta, ws, ss, x_f32, stream):
+        return self.mi355x_sd_groupnorm_stats(x, B, HW, C, ldx, groups, eps, gamma, beta, ws, ss, stream, _f32=bool(x_f32))
+
+    def mi355x_sd_scale_shift_act_ex(self, x, B, HW, C, ldx, ss, silu, y, ldy, x_f32, raw16, ld_raw, stream):
+        if raw16:
+            _rows(raw16, B * HW, C, ld_raw).copy_(_rows(x, B * HW, C, ldx, torch.float32 if x_f32 else None).to(_lib.elem_dtype()))
+        return self.mi355x_sd_scale_shift_act(x, B, HW, C, ldx, ss, silu, y, ldy, stream, _f32=bool(x_f32))
+
+    def mi355x_sd_layernorm_ex(self, x, rows, C, ldx, gamma, beta, eps, y, ldy, x_f32, stream):
+        return self.mi355x_sd_layernorm(x, rows, C, ldx, gamma, beta, eps, y, ldy, stream, _f32=bool(x_f32))
+
+    def mi355x_sd_cast_rows(self, x, ldx, y, ldy, rows, C, stream):
+        self.calls.append("cast_rows")
+        _rows(y, rows, C, ldy).copy_(_rows(x, rows, C, ldx, torch.float32).to(_lib.elem_dtype()))
+        return 0
+
+    def mi355x_sd_groupnorm_stats(self, x, B, HW, C, ldx, groups, eps, gamma, beta, ws, ss, stream, _f32=False):
         self.calls.append("gn_stats")
-        xv = _rows(x, B * HW, C, ldx).float().reshape(B, HW, groups, C // groups)
+        xv = _rows(x, B * HW, C, ldx, torch.float32 if _f32 else None).float().reshape(B, HW, groups, C // groups)
         mean = xv.mean(dim=(1, 3))
         var = xv.var(dim=(1, 3), unbiased=False)
         rstd = (var + eps).rsqrt()
@@ -294,9 +310,9 @@ class Emulator:
         _flat(ss, B * 2 * C, torch.float32).reshape(B, 2, C).copy_(torch.stack([scale, shift], 1))
         return 0
 
-    def mi355x_sd_scale_shift_act(self, x, B, HW, C, ldx, ss, silu, y, ldy, stream):
+    def mi355x_sd_scale_shift_act(self, x, B, HW, C, ldx, ss, silu, y, ldy, stream, _f32=False):
         self.calls.append("scale_shift_act")
-        xv = _rows(x, B * HW, C, ldx).float().reshape(B, HW, C)
+        xv = _rows(x, B * HW, C, ldx, torch.float32 if _f32 else None).float().reshape(B, HW, C)
         s = _flat(ss, B * 2 * C, torch.float32).reshape(B, 2, C)
         o = xv * s[:, 0:1] + s[:, 1:2]
         if silu:
@@ -304,11 +320,11 @@ class Emulator:
         _rows(y, B * HW, C, ldy).copy_(o.reshape(B * HW, C).to(_lib.elem_dtype()))
         return 0
 
-    def mi355x_sd_layernorm(self, x, rows, C, ldx, gamma, beta, eps, y, ldy, stream):
+    def mi355x_sd_layernorm(self, x, rows, C, ldx, gamma, beta, eps, y, ldy, stream, _f32=False):
         self.calls.append("layernorm")
         g = _flat(gamma, C, torch.float32) if gamma else None
         b = _flat(beta, C, torch.float32) if beta else None
-        o = F.layer_norm(_rows(x, rows, C, ldx).float(), (C,), g, b, eps)
+        o = F.layer_norm(_rows(x, rows, C, ldx, torch.float32 if _f32 else None).float(), (C,), g, b, eps)
         _rows(y, rows, C, ldy).copy_(o.to(_lib.elem_dtype()))
         return 0
 
@@ -333,7 +349,10 @@ class Emulator:
         _flat(y, n, torch.float32 if out_f32 else _lib.elem_dtype()).copy_(F.silu(xi))
         return 0
 
-    def mi355x_sd_conv_in3x3(self, x, in_scale, w, bias, y, B, Cin, H, W, Cout, ldy, stream):
+    def mi355x_sd_conv_in3x3_ex(self, x, in_scale, w, bias, y, B, Cin, H, W, Cout, ldy, out_f32, stream):
+        return self.mi355x_sd_conv_in3x3(x, in_scale, w, bias, y, B, Cin, H, W, Cout, ldy, stream, _f32=bool(out_f32))
+
+    def mi355x_sd_conv_in3x3(self, x, in_scale, w, bias, y, B, Cin, H, W, Cout, ldy, stream, _f32=False):
         self.calls.append("conv_in")
         xs = _flat(x, B * Cin * H * W, torch.float32).reshape(B, Cin, H, W)
         if in_scale:
@@ -341,7 +360,8 @@ class Emulator:
         xs = xs.to(_lib.elem_dtype()).float()
         wt = _flat(w, 9 * Cin * Cout, _lib.elem_dtype()).float().reshape(3, 3, Cin, Cout).permute(3, 2, 0, 1)
         o = F.conv2d(xs, wt, _flat(bias, Cout, torch.float32) if bias else None, padding=1)
-        _rows(y, B * H * W, Cout, ldy).copy_(o.permute(0, 2, 3, 1).reshape(B * H * W, Cout).to(_lib.elem_dtype()))
+        dt = torch.float32 if _f32 else _lib.elem_dtype()
+        _rows(y, B * H * W, Cout, ldy, dt).copy_(o.permute(0, 2, 3, 1).reshape(B * H * W, Cout).to(dt))
         return 0
 
     def mi355x_sd_conv_out3x3(self, x, ldx, w, bias, y, B, Cin, H, W, Cout, stream):
@@ -352,10 +372,13 @@ class Emulator:
         _flat(y, B * Cout * H * W, torch.float32).reshape(B, Cout, H, W).copy_(o)
         return 0
 
-    def mi355x_sd_add_nchw(self, x, ldx, r, B, C, HW, stream):
-        xv = _rows(x, B * HW, C, ldx)
+    def mi355x_sd_add_nchw_ex(self, x, ldx, r, B, C, HW, x_f32, stream):
+        return self.mi355x_sd_add_nchw(x, ldx, r, B, C, HW, stream, _f32=bool(x_f32))
+
+    def mi355x_sd_add_nchw(self, x, ldx, r, B, C, HW, stream, _f32=False):
+        xv = _rows(x, B * HW, C, ldx, torch.float32 if _f32 else None)
         rv = _flat(r, B * C * HW, torch.float32).reshape(B, C, HW).permute(0, 2, 1).reshape(B * HW, C)
-        xv.copy_((xv.float() + rv).to(_lib.elem_dtype()))
+        xv.copy_((xv.float() + rv).to(xv.dtype))
         return 0
 
     def mi355x_sd_latent_dist(self, m, ld, B, L, HW, noise, out_scale, mean, logvar, sample, stream):

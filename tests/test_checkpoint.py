@@ -147,3 +147,43 @@ def test_fuse_lora_matches_the_unfused_branch():
         fuse_lora(P, {"unet.nope.lora.down.weight": torch.zeros(4, 4), "unet.nope.lora.up.weight": torch.zeros(4, 4)})
     with pytest.raises(KeyError):
         fuse_lora(P, {"unet." + lin + ".lora.down.weight": lora["unet." + lin + ".lora.down.weight"]})
+
+
+@pytest.mark.parametrize("which", ["clip", "dit", "t5", "unet-class-embedding"])
+def test_torch_layout_keeps_embedding_tables(tmp_path, which):
+    """convert_pytorch_state_dict_to_paddle (modeling_pytorch_paddle_utils.py:27-47) transposes nn.Linear weights ONLY: a
+    diffusers / transformers checkpoint stores nn.Embedding tables as [num, dim], exactly like Paddle. Build a torch-layout
+    state dict the way torch would (Linear [out, in], tables untouched) and load it."""
+    from safetensors.torch import save_file
+    from paddlemix_amd.checkpoint import Table
+    if which == "clip":
+        from paddlemix_amd.clip import clip_param_shapes as shapes_fn, synth_clip_params as synth
+        from tests.configs import MINI_CLIP as cfg
+        fname = "model.safetensors"          # the text-encoder sub-folders' file name
+    elif which == "dit":
+        from paddlemix_amd.dit import dit_param_shapes as shapes_fn, synth_dit_params as synth
+        from tests.configs import MINI_DIT as cfg
+        fname = C.TORCH_SAFETENSORS_WEIGHTS_NAME
+    elif which == "t5":
+        from paddlemix_amd.t5 import synth_t5_params as synth, t5_param_shapes as shapes_fn
+        from tests.configs import MINI_T5 as cfg
+        fname = "model.safetensors"
+    else:
+        shapes_fn, synth, cfg, fname = unet_param_shapes, synth_unet_params, dict(TINY, num_class_embeds=10), C.TORCH_SAFETENSORS_WEIGHTS_NAME
+    P = synth(cfg, seed=2)
+    shapes = shapes_fn(cfg)
+    tables = [k for k, s in shapes.items() if isinstance(s, Table)]
+    assert tables and all(len(shapes[k]) == 2 for k in tables)
+    torch_sd = {k: (v.t().contiguous() if (v.dim() == 2 and k not in tables) else v.contiguous()) for k, v in P.items()}
+    for k in tables:                         # [num, dim] as torch / diffusers store them
+        assert tuple(torch_sd[k].shape) == tuple(shapes[k])
+    d = tmp_path / "m"
+    d.mkdir()
+    (d / "config.json").write_text(json.dumps({k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.items()}))
+    save_file(torch_sd, str(d / fname), metadata={"format": "pt"})
+    _, params = C.load_pretrained(str(d), shapes_fn)
+    assert all(torch.equal(params[k], P[k].float()) for k in P)
+    # and our own writer emits the same torch layout when it knows the table
+    C.save_pretrained(str(tmp_path / "w"), cfg, P, data_format="pt", shapes=shapes)
+    state, fmt = C.load_state_dict(str(tmp_path / "w" / C.TORCH_SAFETENSORS_WEIGHTS_NAME))
+    assert fmt == "pt" and all(torch.equal(state[k], torch_sd[k]) for k in torch_sd)

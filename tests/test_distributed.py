@@ -17,41 +17,52 @@ def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import bench
-    from oracle import unet_ref as U
+    from paddlemix_amd import _lib
+    from paddlemix_amd.dist import empty_wire_params, gather_latents, wire_params
     from paddlemix_amd.unet import UNet2DConditionModel, synth_unet_params, unet_param_shapes
     from tests.abi_emulator import Emulator
     from tests.configs import TINY as cfg
+    ed = _lib.elem_dtype()
     torch.manual_seed(100 + rank)
     if rank == 0:
-        P = synth_unet_params(cfg, seed=1234)
+        P = wire_params(synth_unet_params(cfg, seed=1234), ed)
     else:
-        P = {n: torch.randn(s) for n, s in unet_param_shapes(cfg).items()}  # garbage until the broadcast
-    bench.broadcast_params(P, rank, world)
-    ref_P = synth_unet_params(cfg, seed=1234)
-    same = all(torch.equal(P[k], ref_P[k]) for k in ref_P)
-    # prompt sharding: global batch 4 -> 2 per rank
-    g = torch.Generator().manual_seed(0)
-    sample = torch.randn(4, 4, 8, 8, generator=g)
-    enc = torch.randn(4, 7, cfg["cross_attention_dim"], generator=g)
-    sl = slice(2 * rank, 2 * rank + 2)
+        P = empty_wire_params(unet_param_shapes(cfg), ed, "cpu")
+        for t in P.values():
+            t.normal_()   # garbage until the broadcast
+    nbytes = bench.broadcast_params(P)
+    ref_P = wire_params(synth_unet_params(cfg, seed=1234), ed)
+    same = all(torch.equal(P[k], ref_P[k]) and P[k].dtype == ref_P[k].dtype for k in ref_P)
+    # matrices travel as 16-bit elements, 1-D parameters as fp32
+    expect = sum(v.numel() * (2 if v.dim() > 1 else 4) for v in ref_P.values())
+    # prompt sharding with per-rank seeds: global batch 2 * world, every rank draws ITS prompts / latents from its own generator
+    g = torch.Generator().manual_seed(1000 + rank)
+    sample = torch.randn(2, 4, 8, 8, generator=g)
+    enc = torch.randn(2, 7, cfg["cross_attention_dim"], generator=g)
     model = UNet2DConditionModel(cfg, P, _test_backend=Emulator())
-    out = model(sample[sl], 321, enc[sl]).sample
-    gathered = [torch.empty_like(out) for _ in range(world)]
-    dist.all_gather(gathered, out)
+    out = model(sample, 321, enc).sample
+    allz = gather_latents(out)                      # the job's only other collective
+    ok = True
     if rank == 0:
-        full = UNet2DConditionModel(cfg, ref_P, _test_backend=Emulator())(sample, 321, enc).sample
-        q.put((same, torch.allclose(torch.cat(gathered), full, atol=1e-5, rtol=1e-5)))
-    else:
-        q.put((same, True))
+        full_s, full_e = [], []
+        for r in range(world):
+            gr = torch.Generator().manual_seed(1000 + r)
+            full_s.append(torch.randn(2, 4, 8, 8, generator=gr))
+            full_e.append(torch.randn(2, 7, cfg["cross_attention_dim"], generator=gr))
+        full = UNet2DConditionModel(cfg, ref_P, _test_backend=Emulator())(torch.cat(full_s), 321, torch.cat(full_e)).sample
+        ok = allz.shape == full.shape and torch.allclose(allz, full, atol=1e-5, rtol=1e-5)
+        ok = ok and not torch.allclose(allz[:2], allz[2:4])      # the ranks really worked on different prompts
+    q.put((same and nbytes == expect, ok))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_broadcast_and_prompt_sharding_world2():
+@pytest.mark.parametrize("world", [2, 4])
+def test_broadcast_and_prompt_sharding(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29650 + (os.getpid() % 200)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29650 + (os.getpid() % 200) + world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]

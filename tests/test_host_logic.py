@@ -52,6 +52,26 @@ def test_program_matches_oracle(cfg, B, H, W, L):
     assert "linear_ln" in emu2.calls and _rel(out3, ref) < 2e-2
 
 
+@pytest.mark.parametrize("cfg,B,H,W,L", [(TINY, 2, 16, 16, 7), (MINI_XL, 1, 16, 16, 77)])
+def test_fp32_residual_stream_program(cfg, B, H, W, L):
+    """residual_dtype="fp32": resnet outputs / transformer hidden state / skip slots are fp32 rows, 16-bit values exist only
+    as MFMA operands. Same program semantics, fewer rounding points: closer to the oracle than the 16-bit stream, and no
+    fp32 row is ever handed to a GEMM / conv as an operand (the builder asserts it)."""
+    P = synth_unet_params(cfg, seed=1234)
+    Pb = {k: v.to(torch.bfloat16).float() if v.dim() > 1 else v for k, v in P.items()}
+    sample, enc, added = _inputs(cfg, B, H, W, L)
+    ref = U.unet_forward(Pb, cfg, sample, 501, enc, added_cond_kwargs=added)
+    e16, e32 = Emulator(), Emulator()
+    o16 = UNet2DConditionModel(cfg, P, _test_backend=e16)(sample, 501, enc, added_cond_kwargs=added).sample
+    o32 = UNet2DConditionModel(cfg, P, residual_dtype="fp32", _test_backend=e32)(sample, 501, enc, added_cond_kwargs=added).sample
+    r16, r32 = _rel(o16, ref), _rel(o32, ref)
+    assert r32 < 0.8 * r16 and r32 < 1e-2, (r16, r32)
+    # same number of contractions; the extra launches are the operand casts in front of the down / upsampling convs
+    assert [c for c in e32.calls if c != "cast_rows"] == e16.calls and "cast_rows" in e32.calls
+    with pytest.raises(NotImplementedError):
+        UNet2DConditionModel(cfg, P, residual_dtype="fp32", fold_layernorm=True, _test_backend=Emulator())
+
+
 @pytest.mark.parametrize("name", sorted(UNET_VARIANTS))
 def test_config_variants_match_oracle(name):
     """the configuration switches the reference's model tests flip (tests/configs.py UNET_VARIANTS)"""
@@ -314,3 +334,13 @@ def test_controlnet_residual_inputs(cfg):
     with pytest.raises(ValueError):
         model(sample, 300, enc, added_cond_kwargs=added, down_block_additional_residuals=down[:-1],
               mid_block_additional_residual=mid)
+
+
+@pytest.mark.parametrize("key,val", [("attention_type", "gated"), ("conv_in_kernel", 5), ("conv_out_kernel", 1), ("dropout", 0.1),
+                                     ("mid_block_only_cross_attention", True), ("resnet_out_scale_factor", 2.0)])
+def test_semantics_changing_config_keys_are_refused(key, val):
+    """ctor arguments of the reference that change the arithmetic (unet_2d_condition.py:172-226) and are only built at their
+    default must not be accepted silently"""
+    with pytest.raises(NotImplementedError, match=key):
+        unet_param_shapes(dict(TINY, **{key: val}))
+    unet_param_shapes(dict(TINY, attention_type="default", conv_in_kernel=3, dropout=0.0))   # defaults spelled out are fine

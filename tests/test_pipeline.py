@@ -337,6 +337,35 @@ def test_lcm_loop_matches_oracle_loop():
     assert torch.equal(a, b) and not torch.allclose(a, c)
 
 
+def test_lcm_img2img_runs_all_steps_of_the_shortened_schedule():
+    """LatentConsistencyModelImg2ImgPipeline (pipeline_latent_consistency_img2img.py:760-764): `strength` goes INTO
+    LCMScheduler.set_timesteps and all num_inference_steps steps of the shortened distillation schedule run -- 4 steps at
+    strength 0.5 are [499, 379, 259, 139], not the SD img2img rule's last two of [999, 759, 499, 259]."""
+    import pytest
+    from paddlemix_amd.schedulers import LCMScheduler
+    cfg = dict(TINY, time_cond_proj_dim=32)
+    P = synth_unet_params(cfg, seed=1234)
+    g = torch.Generator().manual_seed(0)
+    pe = torch.randn(1, 7, 64, generator=g)
+    img_lat = torch.randn(1, 4, 8, 8, generator=g)      # already latent-sized: no VAE needed (img2img prepare_latents, :640-643)
+    kw = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear")
+    pipe = StableDiffusionDenoiser(UNet2DConditionModel(cfg, P, _test_backend=Emulator()), LCMScheduler(**kw))
+    seen = []
+    out = pipe(pe, num_inference_steps=4, guidance_scale=8.0, image=img_lat, strength=0.5,
+               generator=torch.Generator().manual_seed(3), callback_on_step_end=lambda p, i, t, k: (seen.append(int(t)), k)[1])
+    assert seen == [499, 379, 259, 139] and torch.isfinite(out).all()
+    # single-encoder pipeline, CFG on, prompt given as ids, no negative ids: the reference encodes "" -- zeros would be a
+    # different image, so the call must refuse (ADVICE r1)
+    from paddlemix_amd.clip import CLIPTextModel, synth_clip_params
+    from tests.configs import MINI_CLIP
+    te = CLIPTextModel(MINI_CLIP, synth_clip_params(MINI_CLIP, seed=1), _test_backend=Emulator())
+    pipe2 = StableDiffusionDenoiser(UNet2DConditionModel(TINY, synth_unet_params(TINY, seed=1), _test_backend=Emulator()),
+                                    DDIMScheduler(clip_sample=False, set_alpha_to_one=False, **SCHED), text_encoder=te)
+    ids = torch.randint(3, 900, (1, 7))
+    with pytest.raises(ValueError, match="negative_prompt_ids"):
+        pipe2(prompt_ids=ids, num_inference_steps=2, guidance_scale=7.5, latents=torch.randn(1, 4, 8, 8))
+
+
 def test_inpaint_loops_match_oracle_loops():
     """StableDiffusionInpaintPipeline semantics (pipeline_stable_diffusion_inpaint.py:689-803, 1094-1236): a 4-channel UNet
     has the kept region re-imposed after every step from the re-noised image latents; a 9-channel UNet is fed
