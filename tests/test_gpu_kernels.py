@@ -486,3 +486,64 @@ def test_errors_are_loud(ops):
         ops.linear(a, w)  # K not a multiple of 8
     with pytest.raises(MI355XError):
         ops.linear(torch.zeros(8, 16, dtype=torch.bfloat16), torch.zeros(16, 16, dtype=torch.bfloat16))  # CPU tensors
+
+
+@pytest.mark.parametrize("B,H,Sq,Skv,D", [(2, 5, 256, 77, 64), (1, 4, 128, 130, 64), (1, 8, 64, 77, 40)])
+def test_sdpa_ragged_kv_tail_ignores_what_follows_the_tensor(ops, B, H, Sq, Skv, D):
+    """The ragged last K/V tile must not read its out-of-range rows from memory: K and V live inside one allocation whose
+    bytes right behind each batch item's Skv rows (the next batch item / the padding after the last one) are NaN patterns.
+    A kernel that fetched them would multiply NaN by P = 0 in the P.V MFMA and return NaN (the tile offset goes
+    through the buffer descriptor's soffset, whose range check is not architecturally promised)."""
+    g = torch.Generator().manual_seed(Skv + D)
+    q = bfr(torch.randn(B, Sq, H, D, generator=g))
+    k = bfr(torch.randn(B, Skv, H, D, generator=g))
+    v = bfr(torch.randn(B, Skv, H, D, generator=g))
+    ref = U.sdpa_math(q, k, v)
+    pad = 200   # rows of NaN behind every batch item's keys / values
+    kbuf = torch.full((B, Skv + pad, H, D), float("nan"), dtype=torch.bfloat16, device="cuda")
+    vbuf = torch.full((B, Skv + pad, H, D), float("nan"), dtype=torch.bfloat16, device="cuda")
+    kbuf[:, :Skv] = dev(k)
+    vbuf[:, :Skv] = dev(v)
+    out = ops.sdpa(dev(q), kbuf[:, :Skv], vbuf[:, :Skv])      # views: batch stride (Skv + pad) * H * D
+    check(out, ref, rel=5e-3, what=f"sdpa NaN-guard {B,H,Sq,Skv,D}")
+
+
+@pytest.mark.parametrize("rows,C", [(300, 64), (1000, 640), (77, 1280)])
+def test_fp32_residual_forms_of_the_norms(ops, rows, C):
+    """x_f32 forms (ABI v9): LayerNorm / GroupNorm(+SiLU) reading fp32 rows, the raw16 side output, cast_rows, and the
+    R_F32 | OUT_F32 GEMM epilogue -- against fp32 torch math on the same fp32 inputs."""
+    import torch.nn.functional as F
+    from paddlemix_amd import _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(rows + C)
+    x = (torch.randn(rows, C, generator=g) * 3 + 0.5).cuda()
+    gam, bet = (1 + 0.1 * torch.randn(C, generator=g)).cuda(), (0.1 * torch.randn(C, generator=g)).cuda()
+    y = torch.empty(rows, C, dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.mi355x_sd_layernorm_ex(x.data_ptr(), rows, C, C, gam.data_ptr(), bet.data_ptr(), 1e-5, y.data_ptr(), C, 1, st))
+    check(y, F.layer_norm(x, (C,), gam, bet, 1e-5).cpu(), what="layernorm_ex fp32 in")
+    # GroupNorm over [B=1][HW=rows][C] + SiLU, with the raw 16-bit copy
+    ws = torch.empty(max(1, lib.mi355x_sd_groupnorm_workspace_floats(1, rows, C)), device="cuda")
+    ss = torch.empty(2 * C, device="cuda")
+    raw = torch.empty(rows, C, dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.mi355x_sd_groupnorm_stats_ex(x.data_ptr(), 1, rows, C, C, 32, 1e-5, gam.data_ptr(), bet.data_ptr(),
+                                                ws.data_ptr(), ss.data_ptr(), 1, st))
+    _lib.check(lib.mi355x_sd_scale_shift_act_ex(x.data_ptr(), 1, rows, C, C, ss.data_ptr(), 1, y.data_ptr(), C, 1,
+                                                raw.data_ptr(), C, st))
+    ref = F.silu(F.group_norm(x.t()[None], 32, gam, bet, 1e-5))[0].t()
+    check(y, ref.cpu(), what="groupnorm_ex fp32 in")
+    assert torch.equal(raw, x.to(torch.bfloat16))
+    c16 = torch.empty_like(raw)
+    _lib.check(lib.mi355x_sd_cast_rows(x.data_ptr(), C, c16.data_ptr(), C, rows, C, st))
+    assert torch.equal(c16, raw)
+    # GEMM: out(fp32) = a @ w^T + bias + R(fp32)
+    N = 128
+    a = bfr(torch.randn(rows, C, generator=g)).cuda().to(torch.bfloat16)
+    w = bfr(torch.randn(N, C, generator=g) / C ** 0.5).cuda().to(torch.bfloat16)
+    R = torch.randn(rows, N, generator=g).cuda() * 7
+    bias = torch.randn(N, generator=g).cuda()
+    out = torch.empty(rows, N, device="cuda")
+    _lib.check(lib.mi355x_sd_linear(a.data_ptr(), C, w.data_ptr(), out.data_ptr(), N, rows, N, C, bias.data_ptr(), None, 0, 0,
+                                    R.data_ptr(), N, 1.0, _lib.OUT_F32 | _lib.R_F32, st))
+    want = a.float() @ w.float().t() + bias + R
+    assert (out - want).abs().max() < 2e-4 * want.abs().max()     # fp32 accumulation order only: no 16-bit rounding anywhere
