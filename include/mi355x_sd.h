@@ -53,6 +53,46 @@ int mi355x_sd_init(int device);
  * stream. ptr == NULL (the initial state) disables split-K. The library never allocates ("no hidden allocation"). */
 int mi355x_sd_set_workspace(void* ptr, size_t bytes);
 
+/* ---- seam B1: the whole UNet2DConditionModel behind one handle (paddlemix_amd/csrc/unet_exec.hip) ----------------------------
+ * What a compiled host (Paddle C++, a serving runtime) binds instead of the per-op entry points: the reference calls its UNet once
+ * per denoising step as `unet(sample, t, encoder_hidden_states, added_cond_kwargs=...)` (pipeline_stable_diffusion.py:866-879) and
+ * its deployment pipelines already treat it as an opaque predictor with named inputs (PaddleInferRuntimeModel.__call__,
+ * PPD/models/paddleinfer_runtime.py:47-126; input names PPD/../deploy/sd15/export_model.py:78-90). Life cycle:
+ *   create(config.json text) -> load_weight(name, host pointer) for every parameter (reference names, Paddle layouts: Linear
+ *   [in,out], conv OIHW; enumerate them with num_params / param_info) -> weight_bytes -> finalize_weights(caller's device buffer)
+ *   -> plan(B, H, W, L) -> bind_workspace(caller's device buffer) -> forward(...) per step -> destroy.
+ * The library never allocates device memory; all tensors of forward() are device pointers; split-K GEMMs use the workspace of
+ * mi355x_sd_set_workspace like the per-op calls. Built: the four SD block types, conv / linear projections, addition_embed_type
+ * None | "text_time"; anything else in the config is refused at create (MI355X_SD_ERR_UNSUPPORTED), never ignored. */
+#define MI355X_SD_DTYPE_F32 0
+#define MI355X_SD_DTYPE_BF16 1
+#define MI355X_SD_DTYPE_F16 2
+int mi355x_sd_unet_create(const char* config_json, void** handle);
+int mi355x_sd_unet_destroy(void* handle);
+/* options before plan(): "residual_f32" = 1 keeps the residual stream in fp32 (MI355X_SD_R_F32) */
+int mi355x_sd_unet_set_option(void* handle, const char* key, int value);
+int mi355x_sd_unet_num_params(void* handle);
+int mi355x_sd_unet_param_info(void* handle, int index, const char** name, int64_t* shape4, int* ndim);
+int mi355x_sd_unet_load_weight(void* handle, const char* name, const void* host_ptr, const int64_t* shape, int ndim, int dtype);
+int mi355x_sd_unet_weight_bytes(void* handle, size_t* bytes);
+int mi355x_sd_unet_finalize_weights(void* handle, void* device_buffer, size_t bytes, void* stream);
+/* finalize_weights in two halves for hosts that stage uploads themselves: the packed image into HOST memory, then the device
+ * address it was copied to. packed_tensor locates one packed tensor inside the image (keys as in paddlemix_amd/unet.py). */
+int mi355x_sd_unet_pack_weights(void* handle, void* host_buffer, size_t bytes);
+int mi355x_sd_unet_attach_weights(void* handle, void* device_buffer, size_t bytes);
+int mi355x_sd_unet_packed_tensor(void* handle, const char* key, size_t* offset, size_t* bytes, int* rows, int* cols);
+int mi355x_sd_unet_plan(void* handle, int B, int H, int W, int L, size_t* workspace_bytes);
+int mi355x_sd_unet_bind_workspace(void* handle, void* device_ptr, size_t bytes);
+int mi355x_sd_unet_num_launches(void* handle);
+/* All pointers are device memory, fp32: sample [B,Cin,H,W], timestep [1], encoder_hidden_states [B,L,D], text_embeds
+ * [B, projection_class_embeddings_input_dim - 6*addition_time_embed_dim] and time_ids [B,6] (text_time only, else NULL), in_scale
+ * optional scalar multiplied into the sample (scheduler.scale_model_input; NULL = 1), out [B,Cout,H,W]. Missing text_embeds /
+ * time_ids on a text_time model is MI355X_SD_ERR_INVALID (the reference's ValueError, unet_2d_condition.py:993-1001).
+ * use_graph != 0: the launches are captured into a hipGraph on the first call and replayed afterwards. */
+int mi355x_sd_unet_forward(void* handle, void* stream, const float* sample, const float* timestep,
+                           const float* encoder_hidden_states, const float* text_embeds, const float* time_ids,
+                           const float* in_scale, float* out, int use_graph);
+
 /* flags for mi355x_sd_linear / mi355x_sd_conv3x3 */
 #define MI355X_SD_GEGLU 1    /* W/bias rows interleaved [16 value | 16 gate]; writes N/2 columns value*gelu_erf(gate) */
 #define MI355X_SD_OUT_F32 2  /* C is fp32 */

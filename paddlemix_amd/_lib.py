@@ -92,6 +92,24 @@ SIGNATURES = {
     "mi355x_sd_softmax_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "mi355x_sd_axpby": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "mi355x_sd_cfg_axpby": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_void_p]),
+    # seam B1: the whole UNet behind a handle (csrc/unet_exec.hip)
+    "mi355x_sd_unet_create": (c_int, [c_char_p, POINTER(c_void_p)]),
+    "mi355x_sd_unet_destroy": (c_int, [c_void_p]),
+    "mi355x_sd_unet_set_option": (c_int, [c_void_p, c_char_p, c_int]),
+    "mi355x_sd_unet_num_params": (c_int, [c_void_p]),
+    "mi355x_sd_unet_param_info": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(c_int64), POINTER(c_int)]),
+    "mi355x_sd_unet_load_weight": (c_int, [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int, c_int]),
+    "mi355x_sd_unet_weight_bytes": (c_int, [c_void_p, POINTER(ctypes.c_size_t)]),
+    "mi355x_sd_unet_finalize_weights": (c_int, [c_void_p, c_void_p, ctypes.c_size_t, c_void_p]),
+    "mi355x_sd_unet_pack_weights": (c_int, [c_void_p, c_void_p, ctypes.c_size_t]),
+    "mi355x_sd_unet_attach_weights": (c_int, [c_void_p, c_void_p, ctypes.c_size_t]),
+    "mi355x_sd_unet_packed_tensor": (c_int, [c_void_p, c_char_p, POINTER(ctypes.c_size_t), POINTER(ctypes.c_size_t), POINTER(c_int),
+                                             POINTER(c_int)]),
+    "mi355x_sd_unet_plan": (c_int, [c_void_p, c_int, c_int, c_int, c_int, POINTER(ctypes.c_size_t)]),
+    "mi355x_sd_unet_bind_workspace": (c_int, [c_void_p, c_void_p, ctypes.c_size_t]),
+    "mi355x_sd_unet_num_launches": (c_int, [c_void_p]),
+    "mi355x_sd_unet_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_int]),
     "mi355x_sd_graph_begin": (c_int, [c_void_p]),
     "mi355x_sd_graph_end": (c_int, [c_void_p, POINTER(c_void_p)]),
     "mi355x_sd_graph_launch": (c_int, [c_void_p, c_void_p]),

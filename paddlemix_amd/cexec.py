@@ -1,0 +1,155 @@
+"""Thin Python wrapper over seam B1 of the C ABI (``mi355x_sd_unet_*``, csrc/unet_exec.hip): the whole UNet behind one handle.
+
+The program builder, the weight packing and the execution live in the C library; this class only marshals: config -> JSON text,
+parameters -> host pointers, two caller-owned device buffers (weights, workspace) as torch tensors, and device pointers per
+call. It presents the reference's call contract (``unet(sample, t, encoder_hidden_states, added_cond_kwargs=...,
+return_dict=False) -> (noise_pred,)``, unet_2d_condition.py:809-1207) like ``paddlemix_amd.unet.UNet2DConditionModel`` does --
+the latter emits the same launches from Python and remains the form with every optional input (class labels, IP-Adapter,
+ControlNet residuals, masks); the handle form is what a compiled host binds.
+"""
+from __future__ import annotations
+
+import ctypes
+import json
+from types import SimpleNamespace
+from typing import Dict, Mapping, Optional
+
+import torch
+
+from . import _lib
+from .program import WORKSPACE_BYTES
+
+_DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+
+
+class UNetHandle:
+    """owns the C handle; usable without a GPU up to `pack()` (host logic), which the CPU tests exercise"""
+
+    def __init__(self, config: Mapping, residual_dtype: Optional[str] = None):
+        self.lib = _lib.load()
+        self.config_dict = {k: (list(v) if isinstance(v, tuple) else v) for k, v in config.items() if not k.startswith("_")}
+        self.h = ctypes.c_void_p()
+        _lib.check(self.lib.mi355x_sd_unet_create(json.dumps(self.config_dict).encode(), ctypes.byref(self.h)))
+        if residual_dtype == "fp32":
+            _lib.check(self.lib.mi355x_sd_unet_set_option(self.h, b"residual_f32", 1))
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None) and self.h.value:
+                self.lib.mi355x_sd_unet_destroy(self.h)
+                self.h = ctypes.c_void_p()
+        except Exception:   # interpreter shutdown
+            pass
+
+    def param_shapes(self) -> Dict[str, tuple]:
+        out = {}
+        name, shape, nd = ctypes.c_char_p(), (ctypes.c_int64 * 4)(), ctypes.c_int()
+        for i in range(self.lib.mi355x_sd_unet_num_params(self.h)):
+            _lib.check(self.lib.mi355x_sd_unet_param_info(self.h, i, ctypes.byref(name), shape, ctypes.byref(nd)))
+            out[name.value.decode()] = tuple(int(shape[j]) for j in range(nd.value))
+        return out
+
+    def load(self, params: Mapping[str, torch.Tensor]) -> None:
+        for name in self.param_shapes():
+            if name not in params:
+                raise KeyError(f"missing parameter {name}")
+            t = params[name].detach().cpu().contiguous()
+            if t.dtype not in _DT:
+                t = t.float()
+            shp = (ctypes.c_int64 * t.dim())(*t.shape)
+            _lib.check(self.lib.mi355x_sd_unet_load_weight(self.h, name.encode(), t.data_ptr(), shp, t.dim(), _DT[t.dtype]))
+
+    def weight_bytes(self) -> int:
+        n = ctypes.c_size_t()
+        _lib.check(self.lib.mi355x_sd_unet_weight_bytes(self.h, ctypes.byref(n)))
+        return n.value
+
+    def pack(self) -> torch.Tensor:
+        """the packed weight image in host memory (uint8)"""
+        n = self.weight_bytes()
+        raw = torch.empty(n + 256, dtype=torch.uint8)
+        skip = (-raw.data_ptr()) % 256          # the image is addressed in 256-byte units
+        buf = raw[skip:skip + n]
+        _lib.check(self.lib.mi355x_sd_unet_pack_weights(self.h, buf.data_ptr(), buf.numel()))
+        return buf
+
+    def packed_tensor(self, image: torch.Tensor, key: str) -> torch.Tensor:
+        off, nb, rows, cols = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_int(), ctypes.c_int()
+        _lib.check(self.lib.mi355x_sd_unet_packed_tensor(self.h, key.encode(), ctypes.byref(off), ctypes.byref(nb), ctypes.byref(rows),
+                                                          ctypes.byref(cols)))
+        raw = image[off.value:off.value + nb.value]
+        if nb.value == rows.value * cols.value * 2:
+            return raw.view(_lib.elem_dtype()).reshape(rows.value, cols.value)
+        return raw.view(torch.float32).reshape(-1)
+
+    def attach(self, device_or_host_buffer: torch.Tensor) -> None:
+        _lib.check(self.lib.mi355x_sd_unet_attach_weights(self.h, device_or_host_buffer.data_ptr(), device_or_host_buffer.numel()))
+
+    def plan(self, B: int, H: int, W: int, L: int) -> int:
+        n = ctypes.c_size_t()
+        _lib.check(self.lib.mi355x_sd_unet_plan(self.h, B, H, W, L, ctypes.byref(n)))
+        return n.value
+
+    def num_launches(self) -> int:
+        return self.lib.mi355x_sd_unet_num_launches(self.h)
+
+
+class CUNet2DConditionModel:
+    """``UNet2DConditionModel`` on the handle API. Buffers (weights, workspace, split-K scratch) are torch tensors owned here --
+    i.e. by the caller of the C ABI."""
+
+    def __init__(self, config: Mapping, params: Mapping[str, torch.Tensor], device="cuda", use_graph: bool = True,
+                 residual_dtype: Optional[str] = None):
+        if not torch.cuda.is_available():
+            raise _lib.MI355XError("CUNet2DConditionModel(mi355x) needs a GPU; there is no CPU fallback")
+        self.device = torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.hd = UNetHandle(config, residual_dtype)
+        _lib.check(self.hd.lib.mi355x_sd_init(self.device.index))
+        self.config = SimpleNamespace(**self.hd.config_dict)
+        self.dtype = _lib.elem_dtype()
+        self.use_graph = use_graph
+        self._stream = torch.cuda.Stream(device=self.device)
+        self.hd.load(params)
+        self._weights = torch.empty(self.hd.weight_bytes(), device=self.device, dtype=torch.uint8)
+        _lib.check(self.hd.lib.mi355x_sd_unet_finalize_weights(self.hd.h, self._weights.data_ptr(), self._weights.numel(),
+                                                                self._stream.cuda_stream))
+        self._splitk = torch.empty(WORKSPACE_BYTES, device=self.device, dtype=torch.uint8)
+        self._geom = None
+        self._workspace = None
+
+    def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None, return_dict: bool = True, in_scale=None):
+        lib, h = self.hd.lib, self.hd.h
+        B, _, H, W = sample.shape
+        L = encoder_hidden_states.shape[1]
+        if self._geom != (B, H, W, L):
+            nbytes = self.hd.plan(B, H, W, L)
+            self._workspace = torch.empty(nbytes, device=self.device, dtype=torch.uint8)
+            _lib.check(lib.mi355x_sd_unet_bind_workspace(h, self._workspace.data_ptr(), nbytes))
+            self._geom = (B, H, W, L)
+        f32 = lambda t: t.to(device=self.device, dtype=torch.float32).contiguous()  # noqa: E731
+        t = timestep if torch.is_tensor(timestep) else torch.tensor([float(timestep)])
+        te = ti = None
+        if added_cond_kwargs is not None:
+            te = f32(added_cond_kwargs["text_embeds"]) if "text_embeds" in added_cond_kwargs else None
+            ti = f32(added_cond_kwargs["time_ids"]) if "time_ids" in added_cond_kwargs else None
+        cur = torch.cuda.current_stream(self.device)
+        self._stream.wait_stream(cur)
+        with torch.cuda.stream(self._stream):
+            s, tt, e = f32(sample), f32(t.reshape(-1)[:1]), f32(encoder_hidden_states)
+            sc = None if in_scale is None else f32(torch.tensor([float(in_scale)]))
+            out = torch.empty((B, self.config.__dict__.get("out_channels", 4), H, W), device=self.device, dtype=torch.float32)
+            _lib.check(lib.mi355x_sd_set_workspace(self._splitk.data_ptr(), self._splitk.numel()))
+            p = lambda x: None if x is None else x.data_ptr()  # noqa: E731
+            _lib.check(lib.mi355x_sd_unet_forward(h, self._stream.cuda_stream, p(s), p(tt), p(e), p(te), p(ti), p(sc), p(out),
+                                                  1 if self.use_graph else 0))
+        cur.wait_stream(self._stream)
+        for x in (s, tt, e, te, ti, sc):     # keep the staging tensors alive until the stream has consumed them
+            if x is not None:
+                x.record_stream(self._stream)
+        if not return_dict:
+            return (out,)
+        return SimpleNamespace(sample=out)
+
+    __call__ = forward

@@ -24,6 +24,8 @@
 
 namespace sd {
 
+constexpr int ATTN8_DEFAULT_MODE = -1;   // set from measurements (profiles/r02_attention8.txt)
+constexpr int ATTN8_MIN_SKV = 256;       // short-KV (cross-attention) launches stay on the four-wave, two-query-tile path
 constexpr int ATT_WAVES = 4;
 constexpr int ATT_THREADS = ATT_WAVES * 64;
 constexpr int QROWS = 32;                   // per wave
@@ -336,6 +338,17 @@ static int launch_dp(const AttnArgs& a0, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
 
+// MI355X_SD_ATTN8: -1 = four-wave kernel everywhere; 0..3 = mode bits of the eight-wave kernel (attention8.hip) for its shapes
+static int attn8_mode() {
+  static const bool dyn = getenv("MI355X_SD_ATTN8_DYN") != nullptr;   // probes flip the variable between launches
+  static int cached = -2;
+  if (cached == -2 || dyn) {
+    const char* e = getenv("MI355X_SD_ATTN8");
+    cached = e ? atoi(e) : ATTN8_DEFAULT_MODE;
+  }
+  return cached;
+}
+
 int launch_attention(const AttnArgs& a, hipStream_t stream) {
   if (a.B <= 0 || a.H <= 0 || a.Sq <= 0 || a.Skv <= 0 || a.D <= 0) return SD_ERR_INVALID;
   if ((a.D & 7) || a.D > 160) return SD_ERR_UNSUPPORTED;
@@ -343,6 +356,11 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
       (a.o_bs & 3))
     return SD_ERR_UNSUPPORTED;
   if (!(a.scale > 0.f)) return SD_ERR_INVALID;
+  const int m8 = attn8_mode();
+  if (m8 >= 0 && a.D == 64 && !a.bias && a.Skv >= ((m8 & 4) ? 1 : ATTN8_MIN_SKV)) {
+    const int rc = launch_attention8(a, m8, stream);
+    if (rc != SD_ERR_UNSUPPORTED) return rc;
+  }
   if (a.D <= 64) return launch_dp<64>(a, stream);
   if (a.D <= 96) return launch_dp<96>(a, stream);
   return launch_dp<160>(a, stream);

@@ -28,6 +28,10 @@ int finish(int rc, const char* what) {
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 }  // namespace
 
+namespace sd {
+void set_last_error(const char* msg) { snprintf(g_err, sizeof(g_err), "%s", msg ? msg : ""); }
+}  // namespace sd
+
 using namespace sd;
 
 // ---- layout probe (tests/test_gpu_probe.py) -------------------------------------------------------------------

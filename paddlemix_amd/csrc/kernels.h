@@ -57,6 +57,7 @@ struct GemmArgs {
 };
 // caller-owned scratch for split-K partial sums (mi355x_sd_set_workspace); no workspace -> no split-K
 void set_workspace(void* ptr, size_t bytes);
+void set_last_error(const char* msg);   // text behind mi355x_sd_last_error() (capi.hip), for the entry points defined elsewhere
 int launch_gemm(const GemmArgs& a, hipStream_t stream);
 int launch_gemm256(const GemmArgs& a, hipStream_t stream);
 int launch_gemm_f8(const GemmArgs& a, hipStream_t stream);   // W8A8 (gemm256.hip); validates
@@ -76,6 +77,7 @@ struct AttnArgs {
   int dbg;   // ablation switches (MI355X_SD_ATTN_DBG; 0 in production)
 };
 int launch_attention(const AttnArgs& a, hipStream_t stream);
+int launch_attention8(const AttnArgs& a, int mode, hipStream_t stream);   // attention8.hip: D == 64, no mask; SD_ERR_UNSUPPORTED otherwise
 
 // GroupNorm over NHWC rows: stats -> per-(batch, channel) scale/shift, then fused normalise(+SiLU)
 int launch_groupnorm_stats(const void* x, int x_f32, int B, int HW, int C, int ldx, int groups, float eps, const float* gamma,

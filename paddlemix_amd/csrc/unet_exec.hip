@@ -1,0 +1,1274 @@
+// Seam B1 in the C ABI: UNet2DConditionModel as an opaque handle -- config in, weights in, one call per denoising step.
+//
+//   mi355x_sd_unet_create(config_json, &h)            parse the reference's config.json, build the layer list
+//   mi355x_sd_unet_load_weight(h, name, ptr, ...)     reference parameter names, Paddle layouts (Linear [in,out], conv OIHW), host memory
+//   mi355x_sd_unet_weight_bytes / _finalize_weights   pack once (transposes, fused QKV, batched K/V and time projections, GEGLU
+//                                                     interleave) into a CALLER-OWNED device buffer
+//   mi355x_sd_unet_plan(h, B, H, W, L, &bytes)        static program + workspace layout for one input geometry
+//   mi355x_sd_unet_bind_workspace(h, ptr, bytes)      caller-owned device arena; nothing is allocated on the device by the library
+//   mi355x_sd_unet_forward(h, stream, ...)            stage inputs + replay the program (optionally as a hipGraph)
+//
+// It is the C++ form of paddlemix_amd/unet.py (same op sequence, same packing -> bit-identical results, tested) for the
+// configurations of the hot path: the four SD block types, mid cross-attention block, conv or linear projections,
+// addition_embed_type None | "text_time", 16-bit or fp32 residual stream. Reference: UNet2DConditionModel.forward
+// (ppdiffusers/ppdiffusers/models/unet_2d_condition.py:809-1207); the opaque-predictor precedent for this seam is
+// PaddleInferRuntimeModel.__call__ (ppdiffusers/ppdiffusers/models/paddleinfer_runtime.py:47-126) with the named inputs of
+// ppdiffusers/deploy/sd15/export_model.py:78-90 (sample, timestep, encoder_hidden_states [+ text_embeds, time_ids]).
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/mi355x_sd.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+using sd::bf16;
+
+// ---------------------------------------------------------------------------------------------------------------- errors
+struct ExecError {
+  int code;
+  std::string msg;
+};
+[[noreturn]] void die(int code, const std::string& m) { throw ExecError{code, m}; }
+
+// ---------------------------------------------------------------------------------------------------------------- tiny JSON
+struct JVal {
+  enum Kind { NUL, BOOL, NUM, STR, ARR, OBJ } kind = NUL;
+  bool b = false;
+  double num = 0.0;
+  std::string str;
+  std::vector<JVal> arr;
+  std::vector<std::pair<std::string, JVal>> obj;
+  const JVal* get(const std::string& k) const {
+    for (auto& kv : obj)
+      if (kv.first == k) return &kv.second;
+    return nullptr;
+  }
+};
+struct JParser {
+  const char* p;
+  explicit JParser(const char* s) : p(s) {}
+  void ws() {
+    while (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r') ++p;
+  }
+  JVal parse() {
+    ws();
+    JVal v;
+    if (*p == '{') {
+      v.kind = JVal::OBJ;
+      ++p;
+      ws();
+      if (*p == '}') { ++p; return v; }
+      for (;;) {
+        ws();
+        JVal k = parse();
+        if (k.kind != JVal::STR) die(MI355X_SD_ERR_INVALID, "config_json: object key is not a string");
+        ws();
+        if (*p != ':') die(MI355X_SD_ERR_INVALID, "config_json: expected ':'");
+        ++p;
+        v.obj.emplace_back(k.str, parse());
+        ws();
+        if (*p == ',') { ++p; continue; }
+        if (*p == '}') { ++p; return v; }
+        die(MI355X_SD_ERR_INVALID, "config_json: expected ',' or '}'");
+      }
+    }
+    if (*p == '[') {
+      v.kind = JVal::ARR;
+      ++p;
+      ws();
+      if (*p == ']') { ++p; return v; }
+      for (;;) {
+        v.arr.push_back(parse());
+        ws();
+        if (*p == ',') { ++p; continue; }
+        if (*p == ']') { ++p; return v; }
+        die(MI355X_SD_ERR_INVALID, "config_json: expected ',' or ']'");
+      }
+    }
+    if (*p == '"') {
+      v.kind = JVal::STR;
+      ++p;
+      while (*p && *p != '"') {
+        if (*p == '\\' && p[1]) ++p;
+        v.str.push_back(*p++);
+      }
+      if (*p != '"') die(MI355X_SD_ERR_INVALID, "config_json: unterminated string");
+      ++p;
+      return v;
+    }
+    if (!strncmp(p, "true", 4)) { p += 4; v.kind = JVal::BOOL; v.b = true; return v; }
+    if (!strncmp(p, "false", 5)) { p += 5; v.kind = JVal::BOOL; v.b = false; return v; }
+    if (!strncmp(p, "null", 4)) { p += 4; return v; }
+    char* end = nullptr;
+    v.num = strtod(p, &end);
+    if (end == p) die(MI355X_SD_ERR_INVALID, "config_json: unexpected character");
+    p = end;
+    v.kind = JVal::NUM;
+    return v;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------- config
+struct Cfg {
+  int in_channels = 4, out_channels = 4;
+  bool flip_sin_to_cos = true;
+  double freq_shift = 0.0;
+  std::vector<std::string> down = {"CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"};
+  std::vector<std::string> up = {"UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"};
+  std::vector<int> boc = {320, 640, 1280, 1280};
+  std::vector<int> layers_per_block, tlayers, heads;
+  int cross_dim = 1280;
+  double mid_scale = 1.0;
+  int groups = 32;
+  double norm_eps = 1e-5;
+  bool linear_proj = false;
+  bool text_time = false;
+  int atd = 0, pdim = 0;
+};
+
+std::vector<int> int_or_list(const JVal* v, size_t n, int dflt, const char* key) {
+  std::vector<int> out(n, dflt);
+  if (!v || v->kind == JVal::NUL) return out;
+  if (v->kind == JVal::NUM) return std::vector<int>(n, (int)v->num);
+  if (v->kind != JVal::ARR || v->arr.size() != n) die(MI355X_SD_ERR_INVALID, std::string("config ") + key + ": expected an int or one int per block");
+  for (size_t i = 0; i < n; ++i) {
+    if (v->arr[i].kind != JVal::NUM) die(MI355X_SD_ERR_UNSUPPORTED, std::string("config ") + key + ": nested lists are not implemented");
+    out[i] = (int)v->arr[i].num;
+  }
+  return out;
+}
+
+Cfg parse_config(const char* json) {
+  JParser jp(json);
+  const JVal root = jp.parse();
+  if (root.kind != JVal::OBJ) die(MI355X_SD_ERR_INVALID, "config_json: expected an object");
+  Cfg c;
+  auto num = [&](const char* k, double d) {
+    const JVal* v = root.get(k);
+    return (v && v->kind == JVal::NUM) ? v->num : d;
+  };
+  auto boolean = [&](const char* k, bool d) {
+    const JVal* v = root.get(k);
+    return (v && v->kind == JVal::BOOL) ? v->b : d;
+  };
+  auto strs = [&](const char* k, std::vector<std::string> d) {
+    const JVal* v = root.get(k);
+    if (!v || v->kind != JVal::ARR) return d;
+    std::vector<std::string> o;
+    for (auto& e : v->arr) o.push_back(e.str);
+    return o;
+  };
+  // what this executor does not build must not load silently (same refusals as paddlemix_amd/unet.py normalize_config)
+  static const char* must_be_null[] = {"class_embed_type", "num_class_embeds", "time_cond_proj_dim", "encoder_hid_dim", "encoder_hid_dim_type",
+                                       "time_embedding_dim", "time_embedding_act_fn", "timestep_post_act", "cross_attention_norm",
+                                       "mid_block_only_cross_attention", "reverse_transformer_layers_per_block", "num_attention_heads"};
+  for (const char* k : must_be_null) {
+    const JVal* v = root.get(k);
+    if (v && !(v->kind == JVal::NUL || (v->kind == JVal::BOOL && !v->b)))
+      die(MI355X_SD_ERR_UNSUPPORTED, std::string("mi355x_sd_unet_create: config ") + k + " is not implemented by the C executor");
+  }
+  static const char* must_be_false[] = {"center_input_sample", "dual_cross_attention", "only_cross_attention", "resnet_skip_time_act",
+                                        "class_embeddings_concat"};
+  for (const char* k : must_be_false)
+    if (boolean(k, false)) die(MI355X_SD_ERR_UNSUPPORTED, std::string("mi355x_sd_unet_create: config ") + k + "=true is not implemented");
+  auto str_is = [&](const char* k, const char* want) {
+    const JVal* v = root.get(k);
+    if (v && v->kind == JVal::STR && v->str != want)
+      die(MI355X_SD_ERR_UNSUPPORTED, std::string("mi355x_sd_unet_create: config ") + k + "=" + v->str + " is not implemented");
+  };
+  str_is("act_fn", "silu");
+  str_is("time_embedding_type", "positional");
+  str_is("resnet_time_scale_shift", "default");
+  str_is("attention_type", "default");
+  str_is("mid_block_type", "UNetMidBlock2DCrossAttn");
+  if (num("downsample_padding", 1) != 1 || num("conv_in_kernel", 3) != 3 || num("conv_out_kernel", 3) != 3 ||
+      num("resnet_out_scale_factor", 1.0) != 1.0 || num("dropout", 0.0) != 0.0)
+    die(MI355X_SD_ERR_UNSUPPORTED, "mi355x_sd_unet_create: downsample_padding / conv kernels / resnet_out_scale_factor / dropout off default");
+
+  c.in_channels = (int)num("in_channels", 4);
+  c.out_channels = (int)num("out_channels", 4);
+  c.flip_sin_to_cos = boolean("flip_sin_to_cos", true);
+  c.freq_shift = num("freq_shift", 0);
+  c.down = strs("down_block_types", c.down);
+  c.up = strs("up_block_types", c.up);
+  if (const JVal* v = root.get("block_out_channels")) {
+    if (v->kind != JVal::ARR) die(MI355X_SD_ERR_INVALID, "config block_out_channels: expected a list");
+    c.boc.clear();
+    for (auto& e : v->arr) c.boc.push_back((int)e.num);
+  }
+  const size_t n = c.down.size();
+  if (c.boc.size() != n || c.up.size() != n || n < 1) die(MI355X_SD_ERR_INVALID, "config: block lists must have one entry per level");
+  for (auto& bt : c.down)
+    if (bt != "CrossAttnDownBlock2D" && bt != "DownBlock2D") die(MI355X_SD_ERR_UNSUPPORTED, "block type " + bt + " is not implemented");
+  for (auto& bt : c.up)
+    if (bt != "CrossAttnUpBlock2D" && bt != "UpBlock2D") die(MI355X_SD_ERR_UNSUPPORTED, "block type " + bt + " is not implemented");
+  c.layers_per_block = int_or_list(root.get("layers_per_block"), n, 2, "layers_per_block");
+  c.tlayers = int_or_list(root.get("transformer_layers_per_block"), n, 1, "transformer_layers_per_block");
+  c.heads = int_or_list(root.get("attention_head_dim"), n, 8, "attention_head_dim");   // the naming quirk at unet_2d_condition.py:245
+  std::vector<int> cross = int_or_list(root.get("cross_attention_dim"), n, 1280, "cross_attention_dim");
+  for (int x : cross)
+    if (x != cross[0]) die(MI355X_SD_ERR_UNSUPPORTED, "per-block cross_attention_dim is not implemented");
+  c.cross_dim = cross[0];
+  c.mid_scale = num("mid_block_scale_factor", 1.0);
+  c.groups = (int)num("norm_num_groups", 32);
+  c.norm_eps = num("norm_eps", 1e-5);
+  c.linear_proj = boolean("use_linear_projection", false);
+  if (const JVal* v = root.get("addition_embed_type")) {
+    if (v->kind == JVal::STR) {
+      if (v->str != "text_time") die(MI355X_SD_ERR_UNSUPPORTED, "addition_embed_type=" + v->str + " is not implemented");
+      c.text_time = true;
+      c.atd = (int)num("addition_time_embed_dim", 0);
+      c.pdim = (int)num("projection_class_embeddings_input_dim", 0);
+      if (c.atd <= 0 || c.pdim <= 0) die(MI355X_SD_ERR_INVALID, "text_time needs addition_time_embed_dim and projection_class_embeddings_input_dim");
+    }
+  }
+  if (c.out_channels > 4) die(MI355X_SD_ERR_UNSUPPORTED, "out_channels > 4");
+  return c;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- structure
+struct Layer {
+  enum Kind { SKIP, RESNET, ATTN, DOWN, UP, CAT } kind;
+  std::string name;
+  int cin = 0, cout = 0;   // RESNET: cin -> cout; ATTN / DOWN / UP: channels in cout; CAT: skip channels in cout
+  double scale = 1.0;
+  int heads = 0, layers = 0;
+};
+
+std::vector<Layer> structure(const Cfg& c) {   // == paddlemix_amd/unet.py:_structure
+  std::vector<Layer> L;
+  const int n = (int)c.boc.size();
+  auto S = [](int v) { return std::to_string(v); };
+  L.push_back({Layer::SKIP});
+  int out_c = c.boc[0];
+  for (int i = 0; i < n; ++i) {
+    const int in_c = out_c;
+    out_c = c.boc[i];
+    for (int j = 0; j < c.layers_per_block[i]; ++j) {
+      L.push_back({Layer::RESNET, "down_blocks." + S(i) + ".resnets." + S(j), j == 0 ? in_c : out_c, out_c, 1.0});
+      if (c.down[i] == "CrossAttnDownBlock2D")
+        L.push_back({Layer::ATTN, "down_blocks." + S(i) + ".attentions." + S(j), 0, out_c, 1.0, c.heads[i], c.tlayers[i]});
+      L.push_back({Layer::SKIP});
+    }
+    if (i != n - 1) {
+      L.push_back({Layer::DOWN, "down_blocks." + S(i) + ".downsamplers.0.conv", 0, out_c});
+      L.push_back({Layer::SKIP});
+    }
+  }
+  L.push_back({Layer::RESNET, "mid_block.resnets.0", c.boc[n - 1], c.boc[n - 1], c.mid_scale});
+  L.push_back({Layer::ATTN, "mid_block.attentions.0", 0, c.boc[n - 1], 1.0, c.heads[n - 1], c.tlayers[n - 1]});
+  L.push_back({Layer::RESNET, "mid_block.resnets.1", c.boc[n - 1], c.boc[n - 1], c.mid_scale});
+  out_c = c.boc[n - 1];
+  for (int i = 0; i < n; ++i) {
+    const int ri = n - 1 - i;
+    const int prev_out = out_c;
+    out_c = c.boc[ri];
+    const int in_c = c.boc[n - 1 - std::min(i + 1, n - 1)];
+    const int nl = c.layers_per_block[ri] + 1;
+    for (int j = 0; j < nl; ++j) {
+      const int skip_c = (j == nl - 1) ? in_c : out_c;
+      const int rin = (j == 0) ? prev_out : out_c;
+      L.push_back({Layer::CAT, "", 0, skip_c});
+      L.push_back({Layer::RESNET, "up_blocks." + S(i) + ".resnets." + S(j), rin + skip_c, out_c, 1.0});
+      if (c.up[i] == "CrossAttnUpBlock2D")
+        L.push_back({Layer::ATTN, "up_blocks." + S(i) + ".attentions." + S(j), 0, out_c, 1.0, c.heads[ri], c.tlayers[ri]});
+    }
+    if (i != n - 1) L.push_back({Layer::UP, "up_blocks." + S(i) + ".upsamplers.0.conv", 0, out_c});
+  }
+  return L;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- weights
+struct HostT {
+  std::vector<int64_t> shape;
+  std::vector<float> v;
+  bool loaded = false;
+  int64_t numel() const {
+    int64_t n = 1;
+    for (auto d : shape) n *= d;
+    return n;
+  }
+};
+
+float bf16_bits_to_f32(uint16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+float f16_bits_to_f32(uint16_t h) {
+  _Float16 x;
+  memcpy(&x, &h, 2);
+  return (float)x;
+}
+// fp32 -> the build's 16-bit element, round to nearest even (what torch's .to(bfloat16 / float16) does)
+uint16_t to_elem16(float f) {
+#ifdef MI355X_SD_F16
+  _Float16 x = (_Float16)f;
+  uint16_t h;
+  memcpy(&h, &x, 2);
+  return h;
+#else
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+#endif
+}
+
+struct Packed {   // one packed device tensor: offset into the weight buffer
+  size_t off = 0, bytes = 0;
+  int rows = 0, cols = 0;   // [N][K] for matrices
+};
+
+// symbolic workspace address
+struct Ref {
+  int buf = -1;   // index into Exec::bufs; -1: absolute (weights / null)
+  size_t off = 0;
+  const void* abs = nullptr;
+};
+struct View {   // rows x C elements of `es` bytes, row stride ld elements
+  Ref p;
+  int rows = 0, C = 0, ld = 0, es = 2;
+  View cols(int off, int c) const {
+    View v = *this;
+    v.p.off += (size_t)off * es;
+    v.C = c;
+    return v;
+  }
+};
+
+struct Exec {
+  Cfg cfg;
+  std::vector<Layer> layers;
+  std::map<std::string, HostT> params;            // expected parameters (reference names, Paddle layouts)
+  std::vector<std::string> order;                 // construction order
+  bool resid_f32 = false;
+  // packed weights
+  std::map<std::string, Packed> w;
+  std::vector<unsigned char> host_pack;
+  size_t weight_bytes = 0;
+  unsigned char* dev_w = nullptr;
+  std::map<std::string, int> temb_off, kv_off;
+  int temb_total = 0, kv_total = 0;
+  // plan
+  int B = 0, H = 0, W = 0, L = 0;
+  struct Buf {
+    std::string name;
+    size_t bytes = 0, off = 0;
+  };
+  std::vector<Buf> bufs;
+  std::map<std::string, int> buf_index;
+  size_t workspace_bytes = 0;
+  unsigned char* ws = nullptr;
+  std::vector<std::function<int(void*)>> prog_sym;   // built at plan time, read `ws` at run time
+  Ref in_sample, in_t, in_scale, in_enc, in_addin, in_tids, out;
+  int text_dim = 0, n_ids = 0;
+  bool planned = false, consts_set = false;
+  hipGraphExec_t graph = nullptr;
+  void* graph_stream = nullptr;
+
+  void* at(const Ref& r) const { return r.buf < 0 ? const_cast<void*>(r.abs) : (void*)(ws + bufs[r.buf].off + r.off); }
+};
+
+void expect(Exec& e, const std::string& name, std::vector<int64_t> shape) {
+  e.params[name].shape = std::move(shape);
+  e.order.push_back(name);
+}
+
+void build_param_table(Exec& e) {   // == unet_param_shapes for the supported configs
+  const Cfg& c = e.cfg;
+  const int ted = c.boc[0] * 4;
+  auto lin = [&](const std::string& n, int i, int o, bool bias = true) {
+    expect(e, n + ".weight", {i, o});
+    if (bias) expect(e, n + ".bias", {o});
+  };
+  auto conv = [&](const std::string& n, int i, int o, int k) {
+    expect(e, n + ".weight", {o, i, k, k});
+    expect(e, n + ".bias", {o});
+  };
+  auto norm = [&](const std::string& n, int ch) {
+    expect(e, n + ".weight", {ch});
+    expect(e, n + ".bias", {ch});
+  };
+  conv("conv_in", c.in_channels, c.boc[0], 3);
+  lin("time_embedding.linear_1", c.boc[0], ted);
+  lin("time_embedding.linear_2", ted, ted);
+  if (c.text_time) {
+    lin("add_embedding.linear_1", c.pdim, ted);
+    lin("add_embedding.linear_2", ted, ted);
+  }
+  for (auto& d : e.layers) {
+    if (d.kind == Layer::RESNET) {
+      norm(d.name + ".norm1", d.cin);
+      conv(d.name + ".conv1", d.cin, d.cout, 3);
+      lin(d.name + ".time_emb_proj", ted, d.cout);
+      norm(d.name + ".norm2", d.cout);
+      conv(d.name + ".conv2", d.cout, d.cout, 3);
+      if (d.cin != d.cout) conv(d.name + ".conv_shortcut", d.cin, d.cout, 1);
+    } else if (d.kind == Layer::ATTN) {
+      const int ch = d.cout;
+      norm(d.name + ".norm", ch);
+      if (c.linear_proj) lin(d.name + ".proj_in", ch, ch);
+      else conv(d.name + ".proj_in", ch, ch, 1);
+      for (int l = 0; l < d.layers; ++l) {
+        const std::string b = d.name + ".transformer_blocks." + std::to_string(l);
+        norm(b + ".norm1", ch);
+        for (int a = 0; a < 2; ++a) {
+          const std::string an = b + (a == 0 ? ".attn1" : ".attn2");
+          const int kd = a == 0 ? ch : c.cross_dim;
+          lin(an + ".to_q", ch, ch, false);
+          lin(an + ".to_k", kd, ch, false);
+          lin(an + ".to_v", kd, ch, false);
+          lin(an + ".to_out.0", ch, ch);
+          if (a == 0) norm(b + ".norm2", ch);
+        }
+        norm(b + ".norm3", ch);
+        lin(b + ".ff.net.0.proj", ch, 8 * ch);
+        lin(b + ".ff.net.2", 4 * ch, ch);
+      }
+      if (c.linear_proj) lin(d.name + ".proj_out", ch, ch);
+      else conv(d.name + ".proj_out", ch, ch, 1);
+    } else if (d.kind == Layer::DOWN || d.kind == Layer::UP) {
+      conv(d.name, d.cout, d.cout, 3);
+    }
+  }
+  norm("conv_norm_out", c.boc[0]);
+  conv("conv_out", c.boc[0], c.out_channels, 3);
+}
+
+// ---- packing (== UNet2DConditionModel._load_weights) ----
+struct Packer {
+  Exec& e;
+  explicit Packer(Exec& ex) : e(ex) {}
+  const HostT& get(const std::string& n) {
+    auto it = e.params.find(n);
+    if (it == e.params.end() || !it->second.loaded) die(MI355X_SD_ERR_INVALID, "missing parameter " + n);
+    return it->second;
+  }
+  // every packed tensor is staged in its own buffer (pointers stay valid while others are added) and laid out at the end
+  std::map<std::string, std::vector<unsigned char>> staged;
+  std::vector<std::string> staged_order;
+  unsigned char* reserve(const std::string& key, size_t bytes, int rows, int cols) {
+    if (staged.count(key)) die(MI355X_SD_ERR_INVALID, "internal: packed tensor " + key + " defined twice");
+    std::vector<unsigned char>& v = staged[key];
+    v.resize(bytes);
+    staged_order.push_back(key);
+    e.w[key] = Packed{0, bytes, rows, cols};
+    return v.data();
+  }
+  uint16_t* m16(const std::string& key, int rows, int cols) {
+    return reinterpret_cast<uint16_t*>(reserve(key, (size_t)rows * cols * 2, rows, cols));
+  }
+  float* f32(const std::string& key, int n) { return reinterpret_cast<float*>(reserve(key, (size_t)n * 4, 1, n)); }
+  // Paddle Linear [in, out] -> rows [out][in] appended at row r0 of dst (row length in)
+  static void lin_rows(const HostT& t, uint16_t* dst, int r0) {
+    const int in = (int)t.shape[0], out = (int)t.shape[1];
+    for (int o = 0; o < out; ++o)
+      for (int i = 0; i < in; ++i) dst[(size_t)(r0 + o) * in + i] = to_elem16(t.v[(size_t)i * out + o]);
+  }
+  void put_vec(const std::string& key, const std::string& name) {
+    const HostT& t = get(name);
+    memcpy(f32(key, (int)t.numel()), t.v.data(), t.numel() * 4);
+  }
+  void put_lin(const std::string& key, const std::string& name, bool bias = true) {
+    const HostT& t = get(name + ".weight");
+    lin_rows(t, m16(key + ".w", (int)t.shape[1], (int)t.shape[0]), 0);
+    if (bias) put_vec(key + ".b", name + ".bias");
+  }
+  void put_conv(const std::string& key, const std::string& name) {   // OIHW -> [O][kh][kw][I]
+    const HostT& t = get(name + ".weight");
+    const int O = (int)t.shape[0], I = (int)t.shape[1], kh = (int)t.shape[2], kw = (int)t.shape[3];
+    uint16_t* d = m16(key + ".w", O, kh * kw * I);
+    for (int o = 0; o < O; ++o)
+      for (int i = 0; i < I; ++i)
+        for (int y = 0; y < kh; ++y)
+          for (int x = 0; x < kw; ++x)
+            d[(((size_t)o * kh + y) * kw + x) * I + i] = to_elem16(t.v[(((size_t)o * I + i) * kh + y) * kw + x]);
+    put_vec(key + ".b", name + ".bias");
+  }
+  void put_norm(const std::string& key, const std::string& name) {
+    put_vec(key + ".g", name + ".weight");
+    put_vec(key + ".b", name + ".bias");
+  }
+  void run() {
+    const Cfg& c = e.cfg;
+    {   // conv_in: -> [ky][kx][ci][O]
+      const HostT& t = get("conv_in.weight");
+      const int O = (int)t.shape[0], I = (int)t.shape[1];
+      uint16_t* d = m16("conv_in.w", 9 * I, O);
+      for (int o = 0; o < O; ++o)
+        for (int i = 0; i < I; ++i)
+          for (int y = 0; y < 3; ++y)
+            for (int x = 0; x < 3; ++x) d[(((size_t)y * 3 + x) * I + i) * O + o] = to_elem16(t.v[(((size_t)o * I + i) * 3 + y) * 3 + x]);
+      put_vec("conv_in.b", "conv_in.bias");
+    }
+    put_lin("time_embedding.linear_1", "time_embedding.linear_1");
+    put_lin("time_embedding.linear_2", "time_embedding.linear_2");
+    if (c.text_time) {
+      put_lin("add_embedding.linear_1", "add_embedding.linear_1");
+      put_lin("add_embedding.linear_2", "add_embedding.linear_2");
+    }
+    // sizes of the batched matrices first
+    const int ted = c.boc[0] * 4;
+    int toff = 0, koff = 0;
+    for (auto& d : e.layers) {
+      if (d.kind == Layer::RESNET) {
+        e.temb_off[d.name] = toff;
+        toff += d.cout;
+      } else if (d.kind == Layer::ATTN) {
+        for (int l = 0; l < d.layers; ++l) {
+          e.kv_off[d.name + ".transformer_blocks." + std::to_string(l)] = koff;
+          koff += 2 * d.cout;
+        }
+      }
+    }
+    e.temb_total = toff;
+    e.kv_total = koff;
+    for (auto& d : e.layers) {
+      if (d.kind == Layer::RESNET) {
+        put_norm(d.name + ".norm1", d.name + ".norm1");
+        put_conv(d.name + ".conv1", d.name + ".conv1");
+        put_norm(d.name + ".norm2", d.name + ".norm2");
+        put_conv(d.name + ".conv2", d.name + ".conv2");
+        if (d.cin != d.cout) put_conv(d.name + ".conv_shortcut", d.name + ".conv_shortcut");
+      } else if (d.kind == Layer::ATTN) {
+        const int ch = d.cout;
+        put_norm(d.name + ".norm", d.name + ".norm");
+        if (c.linear_proj) {
+          put_lin(d.name + ".proj_in", d.name + ".proj_in");
+          put_lin(d.name + ".proj_out", d.name + ".proj_out");
+        } else {
+          put_conv(d.name + ".proj_in", d.name + ".proj_in");
+          put_conv(d.name + ".proj_out", d.name + ".proj_out");
+        }
+        for (int l = 0; l < d.layers; ++l) {
+          const std::string b = d.name + ".transformer_blocks." + std::to_string(l);
+          for (const char* nm : {".norm1", ".norm2", ".norm3"}) put_norm(b + nm, b + nm);
+          uint16_t* q = m16(b + ".attn1.qkv.w", 3 * ch, ch);
+          lin_rows(get(b + ".attn1.to_q.weight"), q, 0);
+          lin_rows(get(b + ".attn1.to_k.weight"), q, ch);
+          lin_rows(get(b + ".attn1.to_v.weight"), q, 2 * ch);
+          lin_rows(get(b + ".attn2.to_q.weight"), m16(b + ".attn2.q.w", ch, ch), 0);
+          put_lin(b + ".attn1.out", b + ".attn1.to_out.0");
+          put_lin(b + ".attn2.out", b + ".attn2.to_out.0");
+          {   // GEGLU: rows interleaved [16 value | 16 gate]
+            const HostT& t = get(b + ".ff.net.0.proj.weight");   // [c, 8c]
+            const HostT& tb = get(b + ".ff.net.0.proj.bias");
+            const int in = (int)t.shape[0], out = (int)t.shape[1], half = out / 2;
+            uint16_t* d1 = m16(b + ".ff1.w", out, in);
+            float* b1 = f32(b + ".ff1.b", out);
+            for (int o = 0; o < out; ++o) {
+              const int src = o < half ? o : o - half;            // value rows come from [0, half), gate rows from [half, out)
+              const int grp = src / 16, r = src % 16;
+              const int dst = grp * 32 + (o < half ? 0 : 16) + r;
+              for (int i = 0; i < in; ++i) d1[(size_t)dst * in + i] = to_elem16(t.v[(size_t)i * out + o]);
+              b1[dst] = tb.v[o];
+            }
+          }
+          put_lin(b + ".ff2", b + ".ff.net.2");
+        }
+      } else if (d.kind == Layer::DOWN || d.kind == Layer::UP) {
+        put_conv(d.name, d.name);
+      }
+    }
+    {   // every cross-attention to_k / to_v in one matrix
+      uint16_t* kv = m16("kv_all.w", e.kv_total, c.cross_dim);
+      for (auto& d : e.layers)
+        if (d.kind == Layer::ATTN)
+          for (int l = 0; l < d.layers; ++l) {
+            const std::string b = d.name + ".transformer_blocks." + std::to_string(l);
+            const int r0 = e.kv_off[b];
+            lin_rows(get(b + ".attn2.to_k.weight"), kv, r0);
+            lin_rows(get(b + ".attn2.to_v.weight"), kv, r0 + d.cout);
+          }
+    }
+    {   // every resnet time_emb_proj in one matrix
+      uint16_t* tw = m16("temb_all.w", e.temb_total, ted);
+      float* tb = f32("temb_all.b", e.temb_total);
+      for (auto& d : e.layers)
+        if (d.kind == Layer::RESNET) {
+          const int r0 = e.temb_off[d.name];
+          lin_rows(get(d.name + ".time_emb_proj.weight"), tw, r0);
+          const HostT& bb = get(d.name + ".time_emb_proj.bias");
+          memcpy(tb + r0, bb.v.data(), bb.numel() * 4);
+        }
+    }
+    put_norm("conv_norm_out", "conv_norm_out");
+    put_conv("conv_out", "conv_out");
+    size_t off = 0;
+    for (auto& key : staged_order) {
+      e.w[key].off = off;
+      off += (staged[key].size() + 255) & ~(size_t)255;
+    }
+    e.weight_bytes = off;
+    e.host_pack.assign(off, 0);
+    for (auto& key : staged_order) {
+      memcpy(e.host_pack.data() + e.w[key].off, staged[key].data(), staged[key].size());
+      std::vector<unsigned char>().swap(staged[key]);
+    }
+    for (auto& kv : e.params) {   // the fp32 host copies are no longer needed
+      std::vector<float>().swap(kv.second.v);
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------- plan
+struct Planner {
+  Exec& e;
+  const Cfg& c;
+  int B, H, W, L;
+  const int RES;   // bytes per element of the residual stream
+  explicit Planner(Exec& ex) : e(ex), c(ex.cfg), B(ex.B), H(ex.H), W(ex.W), L(ex.L), RES(ex.resid_f32 ? 4 : 2) {}
+
+  Ref sc(const std::string& name, size_t bytes) {   // named scratch, sized to its maximum use
+    auto it = e.buf_index.find(name);
+    int idx;
+    if (it == e.buf_index.end()) {
+      idx = (int)e.bufs.size();
+      e.bufs.push_back({name, 0, 0});
+      e.buf_index[name] = idx;
+    } else {
+      idx = it->second;
+    }
+    if (bytes > e.bufs[idx].bytes) e.bufs[idx].bytes = bytes;
+    Ref r;
+    r.buf = idx;
+    return r;
+  }
+  int persist_n = 0;
+  Ref persist(size_t bytes) { return sc("persist." + std::to_string(persist_n++), bytes < 16 ? 16 : bytes); }
+  Ref wref(const std::string& key) {
+    auto it = e.w.find(key);
+    if (it == e.w.end()) die(MI355X_SD_ERR_INVALID, "internal: packed weight " + key + " missing");
+    Ref r;
+    r.abs = e.dev_w + it->second.off;
+    return r;
+  }
+  const Packed& wp(const std::string& key) { return e.w.at(key); }
+  View view(Ref p, int rows, int C, int es = 2) {
+    View v;
+    v.p = p;
+    v.rows = rows;
+    v.C = C;
+    v.ld = C;
+    v.es = es;
+    return v;
+  }
+  void emit(std::function<int(void*)> f) { e.prog_sym.push_back(std::move(f)); }
+
+  void linear(const View& a, const std::string& wkey, const View& out, bool bias = true, const View* R = nullptr, int flags = 0,
+              float out_scale = 1.0f, Ref rowbias = Ref(), int rpb = 0, int ld_rb = 0) {
+    const Packed& w = wp(wkey + ".w");
+    const int N = w.rows, K = w.cols;
+    if (K != a.C || a.es != 2) die(MI355X_SD_ERR_INVALID, "internal: linear " + wkey + " operand mismatch");
+    flags |= (out.es == 4 ? MI355X_SD_OUT_F32 : 0) | ((R && R->es == 4) ? MI355X_SD_R_F32 : 0);
+    Exec* ex = &e;
+    const Ref wr = wref(wkey + ".w");
+    Ref br;
+    if (bias) br = wref(wkey + ".b");
+    const bool has_rb = rowbias.buf >= 0 || rowbias.abs;
+    const bool has_R = R != nullptr;
+    const View Rv = R ? *R : View();
+    emit([=](void* st) {
+      return mi355x_sd_linear(ex->at(a.p), a.ld, ex->at(wr), ex->at(out.p), out.ld, a.rows, N, K, bias ? (const float*)ex->at(br) : nullptr,
+                              has_rb ? (const float*)ex->at(rowbias) : nullptr, rpb, ld_rb, has_R ? ex->at(Rv.p) : nullptr, has_R ? Rv.ld : 0,
+                              out_scale, flags, st);
+    });
+  }
+  void conv3(const View& x, int h, int w_, const std::string& wkey, const View& out, int stride = 1, int up = 0, Ref rowbias = Ref(),
+             const View* R = nullptr, float out_scale = 1.0f) {
+    const Packed& w = wp(wkey + ".w");
+    const int Cout = w.rows;
+    if (x.es != 2) die(MI355X_SD_ERR_INVALID, "internal: conv operand is fp32");
+    const int flags = (out.es == 4 ? MI355X_SD_OUT_F32 : 0) | ((R && R->es == 4) ? MI355X_SD_R_F32 : 0);
+    Exec* ex = &e;
+    const Ref wr = wref(wkey + ".w"), br = wref(wkey + ".b");
+    const bool has_rb = rowbias.buf >= 0 || rowbias.abs;
+    const bool has_R = R != nullptr;
+    const View Rv = R ? *R : View();
+    const int Bc = B, tt = e.temb_total;
+    emit([=](void* st) {
+      return mi355x_sd_conv3x3(ex->at(x.p), x.ld, Bc, h, w_, x.C, stride, up, ex->at(wr), ex->at(out.p), out.ld, Cout, (const float*)ex->at(br),
+                               has_rb ? (const float*)ex->at(rowbias) : nullptr, has_rb ? tt : 0, has_R ? ex->at(Rv.p) : nullptr,
+                               has_R ? Rv.ld : 0, out_scale, flags, st);
+    });
+  }
+  View gnorm(const View& x, int hw, const std::string& nkey, float eps, bool silu, const View* raw16 = nullptr) {
+    const int nws = mi355x_sd_groupnorm_workspace_floats(B, hw, x.C);
+    const Ref ws = sc("gn_ws", (size_t)4 * nws), ss = sc("gn_ss", (size_t)4 * B * 2 * x.C);
+    View y = view(sc("gn", (size_t)2 * x.rows * x.C), x.rows, x.C);
+    Exec* ex = &e;
+    const Ref g = wref(nkey + ".g"), bt = wref(nkey + ".b");
+    const int Bc = B, groups = c.groups, f32 = x.es == 4;
+    const bool has_raw = raw16 != nullptr;
+    const View rv = raw16 ? *raw16 : View();
+    emit([=](void* st) {
+      return mi355x_sd_groupnorm_stats_ex(ex->at(x.p), Bc, hw, x.C, x.ld, groups, eps, (const float*)ex->at(g), (const float*)ex->at(bt),
+                                          (float*)ex->at(ws), (float*)ex->at(ss), f32, st);
+    });
+    emit([=](void* st) {
+      return mi355x_sd_scale_shift_act_ex(ex->at(x.p), Bc, hw, x.C, x.ld, (const float*)ex->at(ss), silu ? 1 : 0, ex->at(y.p), y.ld, f32,
+                                          has_raw ? ex->at(rv.p) : nullptr, has_raw ? rv.ld : 0, st);
+    });
+    return y;
+  }
+  void lnorm(const View& x, const std::string& nkey, const View& out) {
+    Exec* ex = &e;
+    const Ref g = wref(nkey + ".g"), bt = wref(nkey + ".b");
+    const int f32 = x.es == 4;
+    emit([=](void* st) {
+      return mi355x_sd_layernorm_ex(ex->at(x.p), x.rows, x.C, x.ld, (const float*)ex->at(g), (const float*)ex->at(bt), 1e-5f, ex->at(out.p),
+                                    out.ld, f32, st);
+    });
+  }
+  View cast16(const View& x, const std::string& name) {
+    if (x.es == 2) return x;
+    View y = view(sc(name, (size_t)2 * x.rows * x.C), x.rows, x.C);
+    Exec* ex = &e;
+    emit([=](void* st) { return mi355x_sd_cast_rows((const float*)ex->at(x.p), x.ld, ex->at(y.p), y.ld, x.rows, x.C, st); });
+    return y;
+  }
+  void attention(const View& q, const View& k, const View& v, const View& out, int heads, int sq, int skv) {
+    const int d = q.C / heads;
+    Exec* ex = &e;
+    const int Bc = B;
+    const float scale = (float)pow((double)d, -0.5);   // == Python d ** -0.5 rounded to fp32
+    emit([=](void* st) {
+      return mi355x_sd_sdpa(ex->at(q.p), ex->at(k.p), ex->at(v.p), nullptr, ex->at(out.p), Bc, heads, sq, skv, d, (int64_t)sq * q.ld, q.ld,
+                            (int64_t)skv * k.ld, k.ld, (int64_t)skv * v.ld, v.ld, (int64_t)sq * out.ld, out.ld, 0, 0, 0, scale, st);
+    });
+  }
+
+  void build() {
+    const int ted = c.boc[0] * 4;
+    const int dx = c.cross_dim;
+    Exec* ex = &e;
+    // ---- inputs ----
+    e.in_sample = persist((size_t)4 * B * c.in_channels * H * W);
+    e.in_t = persist(4);
+    e.in_scale = persist(4);
+    e.in_enc = persist((size_t)2 * B * L * dx);
+    const View enc = view(e.in_enc, B * L, dx);
+    e.out = persist((size_t)4 * B * c.out_channels * H * W);
+    // ---- time / added-condition embedding (unet_2d_condition.py:933-1030) ----
+    const View t0 = view(persist((size_t)2 * B * c.boc[0]), B, c.boc[0]);
+    {
+      const Ref tin = e.in_t;
+      const int Bc = B, dim = c.boc[0], flip = c.flip_sin_to_cos ? 1 : 0;
+      const float fs = (float)c.freq_shift;
+      emit([=](void* st) {
+        return mi355x_sd_timestep_embedding((const float*)ex->at(tin), 1, Bc, dim, 1, flip, fs, 1.0f, 10000.0f, ex->at(t0.p), dim, st);
+      });
+    }
+    const View e1 = view(persist((size_t)2 * B * ted), B, ted);
+    const View emb = view(persist((size_t)2 * B * ted), B, ted);
+    linear(t0, "time_embedding.linear_1", e1, true, nullptr, MI355X_SD_SILU);
+    linear(e1, "time_embedding.linear_2", emb);
+    if (c.text_time) {
+      e.text_dim = c.pdim - 6 * c.atd;
+      e.n_ids = 6;
+      if (e.text_dim <= 0 || (e.text_dim & 7)) die(MI355X_SD_ERR_UNSUPPORTED, "text_time: text_embeds width must be a positive multiple of 8");
+      e.in_addin = persist((size_t)2 * B * c.pdim);
+      e.in_tids = persist((size_t)4 * B * e.n_ids);
+      const View a1 = view(persist((size_t)2 * B * ted), B, ted);
+      {
+        const Ref tids = e.in_tids, addin = e.in_addin;
+        const int n = B * e.n_ids, atd = c.atd, nid = e.n_ids, flip = c.flip_sin_to_cos ? 1 : 0, pdim = c.pdim, td = e.text_dim;
+        const float fs = (float)c.freq_shift;
+        emit([=](void* st) {
+          return mi355x_sd_timestep_embedding((const float*)ex->at(tids), n, n, atd, nid, flip, fs, 1.0f, 10000.0f,
+                                              (unsigned char*)ex->at(addin) + 2 * td, pdim, st);
+        });
+      }
+      linear(view(e.in_addin, B, c.pdim), "add_embedding.linear_1", a1, true, nullptr, MI355X_SD_SILU);
+      linear(a1, "add_embedding.linear_2", emb, true, &emb);
+    }
+    const View semb = view(persist((size_t)2 * B * ted), B, ted);
+    {
+      const int n = B * ted;
+      emit([=](void* st) { return mi355x_sd_silu(ex->at(emb.p), ex->at(semb.p), n, 0, 0, st); });
+    }
+    const Ref temb_all = persist((size_t)4 * B * e.temb_total);
+    {
+      View ta = view(temb_all, B, e.temb_total, 4);
+      linear(semb, "temb_all", ta);
+    }
+    const View kv_all = view(persist((size_t)2 * B * L * e.kv_total), B * L, e.kv_total);
+    linear(enc, "kv_all", kv_all, false);
+
+    // ---- skip / concat buffers: pre-walk ----
+    struct Sk { int C, h, w; };
+    std::vector<Sk> skips;
+    {
+      int h = H, w_ = W, c_cur = c.boc[0];
+      for (auto& d : e.layers) {
+        if (d.kind == Layer::RESNET) c_cur = d.cout;
+        else if (d.kind == Layer::DOWN) { h = (h + 2 - 3) / 2 + 1; w_ = (w_ + 2 - 3) / 2 + 1; }
+        else if (d.kind == Layer::SKIP) skips.push_back({c_cur, h, w_});
+        else if (d.kind == Layer::CAT) break;
+      }
+    }
+    std::vector<const Layer*> ups;
+    for (auto& d : e.layers)
+      if (d.kind == Layer::RESNET && d.name.rfind("up_blocks.", 0) == 0) ups.push_back(&d);
+    if (ups.size() != skips.size()) die(MI355X_SD_ERR_INVALID, "internal: skip / up-resnet count mismatch");
+    std::vector<View> cats;
+    std::vector<int> cat_xc;
+    for (size_t u = 0; u < ups.size(); ++u) {
+      const Sk& s = skips[skips.size() - 1 - u];
+      const int cx = ups[u]->cin - s.C;
+      cats.push_back(view(persist((size_t)RES * B * s.h * s.w * (cx + s.C)), B * s.h * s.w, cx + s.C, RES));
+      cat_xc.push_back(cx);
+    }
+    auto skip_slot = [&](int k) {
+      const size_t u = skips.size() - 1 - k;
+      return cats[u].cols(cat_xc[u], cats[u].C - cat_xc[u]);
+    };
+    auto x_slot = [&](int u) { return cats[u].cols(0, cat_xc[u]); };
+
+    // ---- layer emitters ----
+    auto resnet = [&](const Layer& d, const View& x, int h, int w_, const View& out) {
+      const int hw = h * w_, rows = B * hw, cout = d.cout;
+      const bool need_short = x.C != cout;
+      View x16;
+      const bool has_x16 = need_short && x.es == 4;
+      if (has_x16) x16 = view(sc("x16", (size_t)2 * rows * x.C), rows, x.C);
+      const View g1 = gnorm(x, hw, d.name + ".norm1", (float)c.norm_eps, true, has_x16 ? &x16 : nullptr);
+      const View h1 = view(sc("h1", (size_t)RES * rows * cout), rows, cout, RES);
+      Ref rb = temb_all;
+      rb.off += (size_t)4 * e.temb_off[d.name];
+      conv3(g1, h, w_, d.name + ".conv1", h1, 1, 0, rb);
+      const View g2 = gnorm(h1, hw, d.name + ".norm2", (float)c.norm_eps, true);
+      View shortv = x;
+      if (need_short) {
+        shortv = view(sc("short", (size_t)RES * rows * cout), rows, cout, RES);
+        linear(has_x16 ? x16 : x, d.name + ".conv_shortcut", shortv);
+      }
+      conv3(g2, h, w_, d.name + ".conv2", out, 1, 0, Ref(), &shortv, (float)(1.0 / d.scale));
+    };
+    auto transformer = [&](const Layer& d, const View& x, int h, int w_, const View& out) {
+      const int hw = h * w_, rows = B * hw, ch = x.C;
+      const View g = gnorm(x, hw, d.name + ".norm", 1e-6f, false);
+      const View hid = view(sc("t_h", (size_t)RES * rows * ch), rows, ch, RES);
+      const View hid16 = RES == 4 ? view(sc("t_h16", (size_t)2 * rows * ch), rows, ch) : hid;
+      linear(g, d.name + ".proj_in", hid);
+      const View ln = view(sc("t_ln", (size_t)2 * rows * ch), rows, ch);
+      const View qkv = view(sc("t_qkv", (size_t)2 * rows * 3 * ch), rows, 3 * ch);
+      const View ao = view(sc("t_ao", (size_t)2 * rows * ch), rows, ch);
+      const View ff = view(sc("t_ff", (size_t)2 * rows * 4 * ch), rows, 4 * ch);
+      for (int l = 0; l < d.layers; ++l) {
+        const std::string b = d.name + ".transformer_blocks." + std::to_string(l);
+        View q2 = view(qkv.p, rows, ch);
+        lnorm(hid, b + ".norm1", ln);
+        linear(ln, b + ".attn1.qkv", qkv, false);
+        attention(qkv.cols(0, ch), qkv.cols(ch, ch), qkv.cols(2 * ch, ch), ao, d.heads, hw, hw);
+        linear(ao, b + ".attn1.out", hid, true, &hid);
+        lnorm(hid, b + ".norm2", ln);
+        linear(ln, b + ".attn2.q", q2, false);
+        const int ko = e.kv_off[b];
+        attention(q2, kv_all.cols(ko, ch), kv_all.cols(ko + ch, ch), ao, d.heads, hw, L);
+        linear(ao, b + ".attn2.out", hid, true, &hid);
+        lnorm(hid, b + ".norm3", ln);
+        linear(ln, b + ".ff1", ff, true, nullptr, MI355X_SD_GEGLU);
+        linear(ff, b + ".ff2", l == d.layers - 1 ? hid16 : hid, true, &hid);
+      }
+      linear(hid16, d.name + ".proj_out", out, true, &x);
+    };
+
+    // ---- body ----
+    int h = H, w_ = W, k = 0, u = 0;
+    View cur = skip_slot(0);
+    {
+      const Ref smp = e.in_sample, scl = e.in_scale, wr = wref("conv_in.w"), br = wref("conv_in.b");
+      const int Bc = B, ci = c.in_channels, Hc = H, Wc = W, co = c.boc[0], f32 = cur.es == 4;
+      const View cv = cur;
+      emit([=](void* st) {
+        return mi355x_sd_conv_in3x3_ex((const float*)ex->at(smp), (const float*)ex->at(scl), ex->at(wr), (const float*)ex->at(br), ex->at(cv.p),
+                                       Bc, ci, Hc, Wc, co, cv.ld, f32, st);
+      });
+    }
+    k = 1;
+    int tmp_i = 0;
+    auto tmp = [&](int rows, int ch) {
+      tmp_i ^= 1;
+      return view(sc(std::string("x") + std::to_string(tmp_i), (size_t)RES * rows * ch), rows, ch, RES);
+    };
+    const size_t nl = e.layers.size();
+    for (size_t i = 1; i < nl; ++i) {
+      const Layer& d = e.layers[i];
+      const Layer::Kind nxt = i + 1 < nl ? e.layers[i + 1].kind : Layer::SKIP;
+      const bool last = i + 1 >= nl;
+      const int rows = B * h * w_;
+      if (d.kind == Layer::RESNET || d.kind == Layer::ATTN) {
+        const int cout = d.cout;
+        View dst;
+        if (!last && nxt == Layer::ATTN) dst = tmp(rows, cout);
+        else if (!last && nxt == Layer::SKIP) dst = skip_slot(k);
+        else if (!last && nxt == Layer::CAT) dst = x_slot(u);
+        else dst = tmp(rows, cout);
+        if (d.kind == Layer::RESNET) resnet(d, cur, h, w_, dst);
+        else transformer(d, cur, h, w_, dst);
+        cur = dst;
+      } else if (d.kind == Layer::SKIP) {
+        ++k;
+      } else if (d.kind == Layer::DOWN) {
+        const int ho = (h + 2 - 3) / 2 + 1, wo = (w_ + 2 - 3) / 2 + 1;
+        const View dst = skip_slot(k);
+        conv3(cast16(cur, "xc16"), h, w_, d.name, dst, 2);
+        h = ho;
+        w_ = wo;
+        cur = dst;
+      } else if (d.kind == Layer::CAT) {
+        cur = cats[u];
+        ++u;
+      } else if (d.kind == Layer::UP) {
+        const View dst = x_slot(u);
+        conv3(cast16(cur, "xc16"), h, w_, d.name, dst, 1, 1);
+        h *= 2;
+        w_ *= 2;
+        cur = dst;
+      }
+    }
+    if (k != (int)skips.size() || u != (int)ups.size() || h != H || w_ != W) die(MI355X_SD_ERR_INVALID, "internal: plan walk mismatch");
+    // ---- post (unet_2d_condition.py:1193-1196) ----
+    {
+      const View g = gnorm(cur, H * W, "conv_norm_out", (float)c.norm_eps, true);
+      const Ref wr = wref("conv_out.w"), br = wref("conv_out.b"), o = e.out;
+      const int Bc = B, Hc = H, Wc = W, co = c.out_channels;
+      emit([=](void* st) {
+        return mi355x_sd_conv_out3x3(ex->at(g.p), g.ld, ex->at(wr), (const float*)ex->at(br), (float*)ex->at(o), Bc, g.C, Hc, Wc, co, st);
+      });
+    }
+    // ---- workspace layout ----
+    size_t off = 0;
+    for (auto& b : e.bufs) {
+      b.off = off;
+      off += (b.bytes + 255) & ~(size_t)255;
+    }
+    e.workspace_bytes = off;
+  }
+};
+
+thread_local std::string g_exec_err;
+int report(const ExecError& x) {
+  sd::set_last_error(x.msg.c_str());
+  return x.code;
+}
+Exec* H_(void* h) { return reinterpret_cast<Exec*>(h); }
+
+}  // namespace
+
+extern "C" {
+
+int mi355x_sd_unet_create(const char* config_json, void** handle) {
+  if (!config_json || !handle) {
+    sd::set_last_error("mi355x_sd_unet_create: null pointer");
+    return MI355X_SD_ERR_INVALID;
+  }
+  try {
+    std::unique_ptr<Exec> e(new Exec);
+    e->cfg = parse_config(config_json);
+    e->layers = structure(e->cfg);
+    build_param_table(*e);
+    *handle = e.release();
+    return MI355X_SD_OK;
+  } catch (const ExecError& x) {
+    return report(x);
+  }
+}
+
+int mi355x_sd_unet_destroy(void* handle) {
+  if (!handle) return MI355X_SD_OK;
+  Exec* e = H_(handle);
+  if (e->graph) (void)hipGraphExecDestroy(e->graph);
+  delete e;
+  return MI355X_SD_OK;
+}
+
+int mi355x_sd_unet_set_option(void* handle, const char* key, int value) {
+  if (!handle || !key) {
+    sd::set_last_error("mi355x_sd_unet_set_option: null pointer");
+    return MI355X_SD_ERR_INVALID;
+  }
+  Exec* e = H_(handle);
+  if (!strcmp(key, "residual_f32")) {
+    if (e->planned) {
+      sd::set_last_error("mi355x_sd_unet_set_option: residual_f32 must be set before mi355x_sd_unet_plan");
+      return MI355X_SD_ERR_INVALID;
+    }
+    e->resid_f32 = value != 0;
+    return MI355X_SD_OK;
+  }
+  sd::set_last_error("mi355x_sd_unet_set_option: unknown option");
+  return MI355X_SD_ERR_INVALID;
+}
+
+int mi355x_sd_unet_num_params(void* handle) { return handle ? (int)H_(handle)->order.size() : -1; }
+
+int mi355x_sd_unet_param_info(void* handle, int index, const char** name, int64_t* shape4, int* ndim) {
+  if (!handle || index < 0 || index >= (int)H_(handle)->order.size() || !name || !shape4 || !ndim) {
+    sd::set_last_error("mi355x_sd_unet_param_info: bad argument");
+    return MI355X_SD_ERR_INVALID;
+  }
+  Exec* e = H_(handle);
+  const std::string& n = e->order[index];
+  const HostT& t = e->params[n];
+  *name = n.c_str();
+  *ndim = (int)t.shape.size();
+  for (int i = 0; i < 4; ++i) shape4[i] = i < *ndim ? t.shape[i] : 1;
+  return MI355X_SD_OK;
+}
+
+int mi355x_sd_unet_load_weight(void* handle, const char* name, const void* host_ptr, const int64_t* shape, int ndim, int dtype) {
+  if (!handle || !name || !host_ptr || !shape) {
+    sd::set_last_error("mi355x_sd_unet_load_weight: null pointer");
+    return MI355X_SD_ERR_INVALID;
+  }
+  try {
+    Exec* e = H_(handle);
+    if (e->dev_w) die(MI355X_SD_ERR_INVALID, "mi355x_sd_unet_load_weight: weights are already finalized");
+    auto it = e->params.find(name);
+    if (it == e->params.end()) die(MI355X_SD_ERR_INVALID, std::string("mi355x_sd_unet_load_weight: the configured UNet has no parameter ") + name);
+    HostT& t = it->second;
+    bool same = (int)t.shape.size() == ndim;
+    for (int i = 0; same && i < ndim; ++i) same = t.shape[i] == shape[i];
+    if (!same) die(MI355X_SD_ERR_INVALID, std::string("mi355x_sd_unet_load_weight: ") + name + ": shape differs from the configured model (Paddle layouts expected)");
+    const int64_t n = t.numel();
+    t.v.resize(n);
+    if (dtype == MI355X_SD_DTYPE_F32) {
+      memcpy(t.v.data(), host_ptr, n * 4);
+    } else if (dtype == MI355X_SD_DTYPE_BF16) {
+      const uint16_t* s = (const uint16_t*)host_ptr;
+      for (int64_t i = 0; i < n; ++i) t.v[i] = bf16_bits_to_f32(s[i]);
+    } else if (dtype == MI355X_SD_DTYPE_F16) {
+      const uint16_t* s = (const uint16_t*)host_ptr;
+      for (int64_t i = 0; i < n; ++i) t.v[i] = f16_bits_to_f32(s[i]);
+    } else {
+      die(MI355X_SD_ERR_INVALID, "mi355x_sd_unet_load_weight: dtype must be MI355X_SD_DTYPE_F32 / _BF16 / _F16");
+    }
+    t.loaded = true;
+    return MI355X_SD_OK;
+  } catch (const ExecError& x) {
+    return report(x);
+  }
+}
+
+int mi355x_sd_unet_weight_bytes(void* handle, size_t* bytes) {
+  if (!handle || !bytes) {
+    sd::set_last_error("mi355x_sd_unet_weight_bytes: null pointer");
+    return MI355X_SD_ERR_INVALID;
+  }
+  try {
+    Exec* e = H_(handle);
+    if (e->host_pack.empty()) {
+      for (auto& n : e->order)
+        if (!e->params[n].loaded) die(MI355X_SD_ERR_INVALID, "mi355x_sd_unet_weight_bytes: parameter " + n + " was never loaded");
+      Packer(*e).run();
+    }
+    *bytes = e->weight_bytes;
+    return MI355X_SD_OK;
+  } catch (const ExecError& x) {
+    return report(x);
+  }
+}
+
+int mi355x_sd_unet_pack_weights(void* handle, void* host_buffer, size_t bytes) {
+  size_t need = 0;
+  const int rc = mi355x_sd_unet_weight_bytes(handle, &need);
+  if (rc) return rc;
+  Exec* e = H_(handle);
+  if (!host_buffer || bytes < need || e->host_pack.empty()) {
+    sd::set_last_error("mi355x_sd_unet_pack_weights: buffer missing / too small, or the packed image was already released");
+    return MI355X_SD_ERR_INVALID;
+  }
+  memcpy(host_buffer, e->host_pack.data(), need);
+  return MI355X_SD_OK;
+}
+
+int mi355x_sd_unet_attach_weights(void* handle, void* device_buffer, size_t bytes) {
+  size_t need = 0;
+  const int rc = mi355x_sd_unet_weight_bytes(handle, &need);
+  if (rc) return rc;
+  Exec* e = H_(handle);
+  if (!device_buffer || bytes < need || (reinterpret_cast<uintptr_t>(device_buffer) & 255)) {
+    sd::set_last_error("mi355x_sd_unet_attach_weights: device buffer missing, too small or not 256-byte aligned");
+    return MI355X_SD_ERR_INVALID;
+  }
+  e->dev_w = (unsigned char*)device_buffer;
+  std::vector<unsigned char>().swap(e->host_pack);
+  return MI355X_SD_OK;
+}
+
+int mi355x_sd_unet_packed_tensor(void* handle, const char* key, size_t* offset, size_t* bytes, int* rows, int* cols) {
+  Exec* e = H_(handle);
+  if (!handle || !key || !offset || !bytes || !rows || !cols || e->w.find(key) == e->w.end()) {
+    sd::set_last_error("mi355x_sd_unet_packed_tensor: unknown key (pack the weights first)");
+    return MI355X_SD_ERR_INVALID;
+  }
+  const Packed& p = e->w[key];
+  *offset = p.off; *bytes = p.bytes; *rows = p.rows; *cols = p.cols;
+  return MI355X_SD_OK;
+}
+
+int mi355x_sd_unet_finalize_weights(void* handle, void* device_buffer, size_t bytes, void* stream) {
+  size_t need = 0;
+  const int rc = mi355x_sd_unet_weight_bytes(handle, &need);
+  if (rc) return rc;
+  Exec* e = H_(handle);
+  if (!device_buffer || bytes < need || (reinterpret_cast<uintptr_t>(device_buffer) & 255) || e->host_pack.empty()) {
+    sd::set_last_error("mi355x_sd_unet_finalize_weights: device buffer missing, too small or not 256-byte aligned");
+    return MI355X_SD_ERR_INVALID;
+  }
+  if (hipMemcpyAsync(device_buffer, e->host_pack.data(), need, hipMemcpyHostToDevice, reinterpret_cast<hipStream_t>(stream)) != hipSuccess ||
+      hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)) != hipSuccess) {
+    sd::set_last_error("mi355x_sd_unet_finalize_weights: host-to-device copy failed");
+    return MI355X_SD_ERR_HIP;
+  }
+  return mi355x_sd_unet_attach_weights(handle, device_buffer, bytes);
+}
+
+int mi355x_sd_unet_plan(void* handle, int B, int H, int W, int L, size_t* workspace_bytes) {
+  if (!handle || !workspace_bytes || B <= 0 || H <= 0 || W <= 0 || L <= 0) {
+    sd::set_last_error("mi355x_sd_unet_plan: bad argument");
+    return MI355X_SD_ERR_INVALID;
+  }
+  try {
+    Exec* e = H_(handle);
+    if (!e->dev_w) die(MI355X_SD_ERR_INVALID, "mi355x_sd_unet_plan: call mi355x_sd_unet_finalize_weights first");
+    if (e->graph) {
+      (void)hipGraphExecDestroy(e->graph);
+      e->graph = nullptr;
+    }
+    e->B = B; e->H = H; e->W = W; e->L = L;
+    e->bufs.clear();
+    e->buf_index.clear();
+    e->prog_sym.clear();
+    e->ws = nullptr;
+    e->consts_set = false;
+    Planner(*e).build();
+    e->planned = true;
+    *workspace_bytes = e->workspace_bytes;
+    return MI355X_SD_OK;
+  } catch (const ExecError& x) {
+    return report(x);
+  }
+}
+
+int mi355x_sd_unet_bind_workspace(void* handle, void* device_ptr, size_t bytes) {
+  Exec* e = H_(handle);
+  if (!handle || !e->planned || !device_ptr || bytes < e->workspace_bytes || (reinterpret_cast<uintptr_t>(device_ptr) & 255)) {
+    sd::set_last_error("mi355x_sd_unet_bind_workspace: no plan, or buffer missing / too small / not 256-byte aligned");
+    return MI355X_SD_ERR_INVALID;
+  }
+  if (e->graph) {
+    (void)hipGraphExecDestroy(e->graph);
+    e->graph = nullptr;
+  }
+  e->ws = (unsigned char*)device_ptr;
+  e->consts_set = false;
+  return MI355X_SD_OK;
+}
+
+int mi355x_sd_unet_num_launches(void* handle) { return handle ? (int)H_(handle)->prog_sym.size() : -1; }
+
+// sample [B,Cin,H,W] fp32 NCHW, timestep: one fp32, encoder_hidden_states [B,L,D] fp32, text_embeds [B,text_dim] fp32, time_ids
+// [B,6] fp32, out [B,Cout,H,W] fp32 -- all DEVICE pointers (the boundary never touches host memory per step); in_scale: optional
+// device scalar multiplied into the sample (the scheduler's scale_model_input), NULL = 1. use_graph != 0: the program is captured
+// into a hipGraph on first use with this stream and replayed afterwards.
+int mi355x_sd_unet_forward(void* handle, void* stream, const float* sample, const float* timestep, const float* encoder_hidden_states,
+                           const float* text_embeds, const float* time_ids, const float* in_scale, float* out, int use_graph) {
+  Exec* e = H_(handle);
+  if (!handle || !e->planned || !e->ws) {
+    sd::set_last_error("mi355x_sd_unet_forward: plan and bind a workspace first");
+    return MI355X_SD_ERR_INVALID;
+  }
+  if (!sample || !timestep || !encoder_hidden_states || !out) {
+    sd::set_last_error("mi355x_sd_unet_forward: null pointer");
+    return MI355X_SD_ERR_INVALID;
+  }
+  if (e->cfg.text_time && (!text_embeds || !time_ids)) {
+    // the reference raises ValueError here (unet_2d_condition.py:993-1001)
+    sd::set_last_error("mi355x_sd_unet_forward: addition_embed_type 'text_time' requires text_embeds and time_ids");
+    return MI355X_SD_ERR_INVALID;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const Cfg& c = e->cfg;
+  const int B = e->B, H = e->H, W = e->W, L = e->L;
+  // ---- stage inputs into the plan's static buffers (device-to-device, stream ordered) ----
+  bool ok = hipMemcpyAsync(e->at(e->in_sample), sample, (size_t)4 * B * c.in_channels * H * W, hipMemcpyDeviceToDevice, st) == hipSuccess;
+  ok = ok && hipMemcpyAsync(e->at(e->in_t), timestep, 4, hipMemcpyDeviceToDevice, st) == hipSuccess;
+  if (in_scale) {
+    ok = ok && hipMemcpyAsync(e->at(e->in_scale), in_scale, 4, hipMemcpyDeviceToDevice, st) == hipSuccess;
+    e->consts_set = false;
+  } else if (!e->consts_set) {
+    static const float one = 1.0f;
+    ok = ok && hipMemcpyAsync(e->at(e->in_scale), &one, 4, hipMemcpyHostToDevice, st) == hipSuccess;
+    e->consts_set = true;
+  }
+  if (!ok) {
+    sd::set_last_error("mi355x_sd_unet_forward: staging copy failed");
+    return MI355X_SD_ERR_HIP;
+  }
+  int rc = mi355x_sd_cast_rows(encoder_hidden_states, c.cross_dim, e->at(e->in_enc), c.cross_dim, (int64_t)B * L, c.cross_dim, stream);
+  if (rc) return rc;
+  if (c.text_time) {
+    rc = mi355x_sd_cast_rows(text_embeds, e->text_dim, e->at(e->in_addin), c.pdim, B, e->text_dim, stream);
+    if (rc) return rc;
+    if (hipMemcpyAsync(e->at(e->in_tids), time_ids, (size_t)4 * B * e->n_ids, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+      sd::set_last_error("mi355x_sd_unet_forward: staging copy failed");
+      return MI355X_SD_ERR_HIP;
+    }
+  }
+  // ---- the program ----
+  auto run_eager = [&]() {
+    for (auto& f : e->prog_sym) {
+      const int r = f(stream);
+      if (r) return r;
+    }
+    return (int)MI355X_SD_OK;
+  };
+  if (use_graph) {
+    if (!e->graph || e->graph_stream != stream) {
+      if (e->graph) {
+        (void)hipGraphExecDestroy(e->graph);
+        e->graph = nullptr;
+      }
+      rc = run_eager();   // warm-up outside capture (lazy module loading), also this call's result
+      if (rc) return rc;
+      rc = mi355x_sd_graph_begin(stream);
+      if (rc) return rc;
+      const int rprog = run_eager();
+      void* exec = nullptr;
+      rc = mi355x_sd_graph_end(stream, &exec);
+      if (rprog) return rprog;
+      if (rc) return rc;
+      e->graph = reinterpret_cast<hipGraphExec_t>(exec);
+      e->graph_stream = stream;
+    } else {
+      rc = mi355x_sd_graph_launch(e->graph, stream);
+      if (rc) return rc;
+    }
+  } else {
+    rc = run_eager();
+    if (rc) return rc;
+  }
+  if (hipMemcpyAsync(out, e->at(e->out), (size_t)4 * B * c.out_channels * H * W, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+    sd::set_last_error("mi355x_sd_unet_forward: output copy failed");
+    return MI355X_SD_ERR_HIP;
+  }
+  return MI355X_SD_OK;
+}
+
+}  // extern "C"

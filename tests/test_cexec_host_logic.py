@@ -1,0 +1,68 @@
+"""CPU: host logic of seam B1 in the C ABI (csrc/unet_exec.hip) -- config parsing, parameter table, weight packing and the plan
+-- against the Python builder (paddlemix_amd/unet.py), without launching anything. The packed image must equal the Python
+model's packed tensors bit for bit, the parameter table must equal unet_param_shapes, the program must have the same number of
+launches. (The launches themselves are compared on the GPU: tests/test_gpu_cexec.py.)"""
+import ctypes
+
+import pytest
+import torch
+
+from paddlemix_amd import _lib
+from paddlemix_amd.cexec import UNetHandle
+from paddlemix_amd.unet import UNet2DConditionModel, synth_unet_params, unet_param_shapes
+from tests.abi_emulator import Emulator
+from tests.configs import MINI_XL, SD15, SDXL, TINY
+
+
+@pytest.mark.parametrize("cfg", [TINY, MINI_XL, SD15, SDXL], ids=["tiny", "mini-xl", "sd15", "sdxl"])
+def test_parameter_table_equals_python_table(cfg):
+    hd = UNetHandle(cfg)
+    got = hd.param_shapes()
+    want = unet_param_shapes(cfg)
+    assert list(got) == list(want)                      # names AND construction order
+    assert all(tuple(got[k]) == tuple(want[k]) for k in want)
+
+
+@pytest.mark.parametrize("cfg,rd", [(TINY, None), (MINI_XL, None), (MINI_XL, "fp32")], ids=["tiny", "mini-xl", "mini-xl-f32resid"])
+def test_packed_weights_and_plan_equal_python_builder(cfg, rd):
+    P = synth_unet_params(cfg, seed=5)
+    hd = UNetHandle(cfg, residual_dtype=rd)
+    hd.load(P)
+    image = hd.pack()
+    model = UNet2DConditionModel(cfg, P, residual_dtype=rd, _test_backend=Emulator())
+    checked = 0
+    for key, t in model.w.items():
+        got = hd.packed_tensor(image, key)
+        if t.dtype == torch.float32:
+            assert torch.equal(got, t.reshape(-1)), key
+        else:
+            assert got.shape == t.shape and torch.equal(got.view(torch.int16), t.view(torch.int16)), key
+        checked += 1
+    assert checked == len(model.w) and checked > 30
+    # plan: same number of kernel launches as the Python program for the same geometry (the Python plan inserts the
+    # time_ids sinusoid at its first call; the handle knows the widths from the config)
+    B, H, W, L = 2, 16, 16, 7
+    hd.attach(image)             # planning reads no device memory: a host image is enough to lay the program out
+    nbytes = hd.plan(B, H, W, L)
+    plan = model._get_plan(B, H, W, L)
+    n_py = len(plan.prog) + (1 if cfg.get("addition_embed_type") == "text_time" else 0)
+    assert hd.num_launches() == n_py
+    assert nbytes > 0 and nbytes % 256 == 0
+
+
+def test_refusals_are_loud():
+    lib = _lib.load()
+    for bad in (dict(TINY, class_embed_type="timestep"), dict(TINY, time_cond_proj_dim=32), dict(TINY, attention_type="gated"),
+                dict(TINY, down_block_types=("DownBlock2D", "AttnDownBlock2D")), dict(TINY, encoder_hid_dim_type="ip_image_proj", encoder_hid_dim=8)):
+        with pytest.raises(_lib.MI355XError):
+            UNetHandle(bad)
+    hd = UNetHandle(TINY)
+    with pytest.raises(_lib.MI355XError, match="never loaded"):
+        hd.weight_bytes()
+    w = torch.zeros(3, 3)
+    shp = (ctypes.c_int64 * 2)(3, 3)
+    assert lib.mi355x_sd_unet_load_weight(hd.h, b"conv_in.weight", w.data_ptr(), shp, 2, 0) != 0
+    assert b"shape" in lib.mi355x_sd_last_error()
+    assert lib.mi355x_sd_unet_load_weight(hd.h, b"no.such.weight", w.data_ptr(), shp, 2, 0) != 0
+    n = ctypes.c_size_t()
+    assert lib.mi355x_sd_unet_plan(hd.h, 1, 8, 8, 7, ctypes.byref(n)) != 0      # weights not finalized
