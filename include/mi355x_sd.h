@@ -101,6 +101,9 @@ int mi355x_sd_unet_forward(void* handle, void* stream, const float* sample, cons
 #define MI355X_SD_R_F32 32   /* R is fp32 rows (ldr in fp32 elements): the fp32 residual-stream mode, where the tensors the reference
                               * adds onto (`hidden_states + input_tensor` resnet.py:806, `attn_output + hidden_states` attention.py:430,
                               * 455, 487, transformer_2d.py:467) never round to 16 bits; combine with MI355X_SD_OUT_F32 */
+#define MI355X_SD_CONV_KB64 64 /* conv3x3, Cin % 64 == 0: W is packed [O][Cin/64][3][3][64] instead of [O][3][3][Cin] -- the K loop then walks the 9
+                              * taps of one 64-channel block back to back, so the eight re-reads of a [pixels x 64 channels] region hit the XCD's
+                              * L2 (32 KB per block) instead of coming back through the fabric a full channel sweep later */
 #define MI355X_SD_PAD_BR 16  /* conv3x3, stride 2 only: zero padding is one row / column at the bottom / right instead of all round
                               * (Downsample2D with padding=0: F.pad (0,1,0,1) then an unpadded conv, PPD/models/resnet.py:277-279 --
                               * the VAE encoder's downsamplers, vae.py:113) */

@@ -18,7 +18,7 @@ if ELEM_NAME not in _BUILDS:
 LIB_PATH = os.path.join(_HERE, _BUILDS[ELEM_NAME][0])
 
 ABI_VERSION = 9
-GEGLU, OUT_F32, SILU, GELU_TANH, PAD_BR, R_F32 = 1, 2, 4, 8, 16, 32
+GEGLU, OUT_F32, SILU, GELU_TANH, PAD_BR, R_F32, CONV_KB64 = 1, 2, 4, 8, 16, 32, 64
 
 # name -> (restype, argtypes); must list every symbol include/mi355x_sd.h declares (tests/test_abi.py checks)
 SIGNATURES = {

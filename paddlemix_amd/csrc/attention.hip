@@ -67,9 +67,11 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_ker
   const bf16* Vp = p.V + (size_t)b * p.v_bs + (size_t)h * p.D;
   bf16* Op = p.O + (size_t)b * p.o_bs + (size_t)h * p.D;
 
-  // ---- K/V tile loader: thread owns CHUNKS 16-B chunks of the K tile and of the V tile.  Buffer (SRD) loads: a
-  // per-lane 32-bit byte offset that never changes + a scalar per-tile offset; rows past Skv fall outside the
-  // descriptor's range and read as zero in hardware (no branches, no 64-bit address arithmetic in the loop). ----
+  // ---- K/V tile loader: thread owns CHUNKS 16-B chunks of the K tile and of the V tile.  Buffer (SRD) loads with a
+  // per-lane 32-bit byte offset = lane part (never changes) + tile part; rows past Skv fall outside the descriptor's
+  // range and read as zero in hardware (no branches, no 64-bit address arithmetic in the loop). The tile part is added
+  // to the PER-LANE offset, not passed as soffset: the descriptor's range check covers voffset + inst_offset only, so a
+  // scalar offset past the end would fetch whatever follows the tensor (NaN there -> NaN out through P.V with P = 0). ----
   u32x4 rk[L::CHUNKS], rv[L::CHUNKS];
   const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<bf16*>(Kp), 0, (unsigned)(((size_t)(p.Skv - 1) * p.k_ts + p.D) * 2), 0x00020000);
@@ -85,11 +87,14 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_ker
     v_off[i] = col_ok ? (unsigned)((row * p.v_ts + ch * 8) * 2) : 0xFFFFFFF0u;
   }
   auto load_kv = [&](int kv0) {
-    const int ks_off = kv0 * p.k_ts * 2, vs_off = kv0 * p.v_ts * 2;
+    const unsigned ks_off = (unsigned)(kv0 * p.k_ts * 2), vs_off = (unsigned)(kv0 * p.v_ts * 2);
 #pragma unroll
     for (int i = 0; i < L::CHUNKS; ++i) {
-      rk[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_off[i], ks_off, 0));
-      rv[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, v_off[i], vs_off, 0));
+      // (padded head-dim columns carry the out-of-range marker: keep it out of range)
+      const unsigned ko = (k_off[i] != 0xFFFFFFF0u) ? k_off[i] + ks_off : 0xFFFFFFF0u;
+      const unsigned vo = (v_off[i] != 0xFFFFFFF0u) ? v_off[i] + vs_off : 0xFFFFFFF0u;
+      rk[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, ko, 0, 0));
+      rv[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, vo, 0, 0));
     }
   };
   auto store_kv = [&](int buf) {

@@ -240,6 +240,8 @@ int mi355x_sd_conv3x3(const void* X, int ldx, int B, int Hs, int Ws, int Cin, in
   g.A = (const bf16*)X; g.W = (const bf16*)W; g.C = C;
   g.conv = 1; g.Hs = Hs; g.Ws = Ws; g.Cin = Cin; g.stride = stride; g.up = upsample;
   g.pad = (flags & MI355X_SD_PAD_BR) ? 0 : 1;
+  g.kb64 = (flags & MI355X_SD_CONV_KB64) ? 1 : 0;
+  if (g.kb64 && (Cin & 63)) return fail(SD_ERR_UNSUPPORTED, "mi355x_sd_conv3x3: MI355X_SD_CONV_KB64 needs Cin % 64 == 0");
   if (!g.pad && (stride != 2 || upsample))
     return fail(SD_ERR_UNSUPPORTED, "mi355x_sd_conv3x3: MI355X_SD_PAD_BR is the stride-2 downsampler's padding");
   const int Hin = Hs << upsample, Win = Ws << upsample;

@@ -103,6 +103,34 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return base + idx;
 }
 
+// Implicit-GEMM conv: (tap, first channel) of the 64-wide K tile number kt, and the step to the next K tile, for the two K
+// orders (GemmArgs::kb64). cg8 = this lane's channel offset inside the K tile.
+__device__ __forceinline__ void conv_k_init(int kb64, int kt, int cg8, int Cin, int& tap, int& ch) {
+  if (kb64) {
+    const int cb = kt / 9;
+    tap = kt - cb * 9;
+    ch = cb * 64 + cg8;
+  } else {
+    ch = kt * 64 + cg8;
+    tap = ch / Cin;
+    ch -= tap * Cin;
+  }
+}
+__device__ __forceinline__ void conv_k_next(int kb64, int Cin, int& tap, int& ch) {
+  if (kb64) {
+    if (++tap == 9) {
+      tap = 0;
+      ch += 64;
+    }
+  } else {
+    ch += 64;
+    while (ch >= Cin) {
+      ch -= Cin;
+      ++tap;
+    }
+  }
+}
+
 // Logical tile id -> (tile_m, tile_n), "grouped" order: ids sweep GM row-tiles first, then the column, so the
 // tiles an XCD runs concurrently (a contiguous id range after xcd_remap) form a compact 2-D patch that shares
 // A row-panels and W column-panels in that XCD's L2.

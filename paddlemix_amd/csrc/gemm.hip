@@ -103,10 +103,7 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_bf16_kernel(const GemmAr
     t1 = min(nt_all, t0 + p.kc);
   }
   int gtap = 0, gcch = t0 * BK + g_cg * 8;   // conv: running (tap, channel) of this lane's chunk
-  if (CONV) {
-    gtap = gcch / p.Cin;
-    gcch -= gtap * p.Cin;
-  }
+  if (CONV) conv_k_init(p.kb64, t0, g_cg * 8, p.Cin, gtap, gcch);
   const bf16* zsrc = reinterpret_cast<const bf16*>(g_zero16);
 
   auto issue_tile = [&](int k0, int buf) {
@@ -126,11 +123,7 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_bf16_kernel(const GemmAr
         if (CFG::A_TOTAL % CFG::NW == 0 || wave + i * CFG::NW < CFG::A_TOTAL)
           __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(a + i * (CFG::NW * 1024)), 16, 0, 0);
       }
-      gcch += BK;
-      while (gcch >= p.Cin) {
-        gcch -= p.Cin;
-        ++gtap;
-      }
+      conv_k_next(p.kb64, p.Cin, gtap, gcch);
     } else {
 #pragma unroll
       for (int i = 0; i < CFG::A_PIECES; ++i) {

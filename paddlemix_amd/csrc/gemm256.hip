@@ -115,8 +115,9 @@ __global__ __launch_bounds__(g256::THREADS, 2) void gemm256_kernel(const GemmArg
   int kA[2] = {0, 0}, kB[2] = {0, 0};              // next K offset (elements) of each half-tile stream
   int tapA[2] = {0, 0}, chA[2] = {cg * 8, cg * 8}; // conv: running (tap, channel) per A stream
   if (CONV) {
-    tapA[0] = tapA[1] = (cg * 8) / p.Cin;
-    chA[0] = chA[1] = cg * 8 - tapA[0] * p.Cin;
+    conv_k_init(p.kb64, 0, cg * 8, p.Cin, tapA[0], chA[0]);
+    tapA[1] = tapA[0];
+    chA[1] = chA[0];
   }
 
   auto issue_A = [&](const int h, int buf) {
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(g256::THREADS, 2) void gemm256_kernel(const GemmArg
     if (CONV) {
       const int ky = tapA[h] / 3, kx = tapA[h] - ky * 3;
       const int Hin = p.Hs << p.up, Win = p.Ws << p.up;
-      const bool k_ok = tapA[h] < 9;
+      const bool k_ok = p.kb64 ? chA[h] < p.Cin : tapA[h] < 9;   // run-out tiles past K
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int i = h * 2 + j;
@@ -135,11 +136,7 @@ __global__ __launch_bounds__(g256::THREADS, 2) void gemm256_kernel(const GemmArg
         const unsigned off = a_img[i] + (unsigned)(((iy >> p.up) * p.Ws + (ix >> p.up)) * p.lda + chA[h]) * 2u;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lptr_t)(dst + j * 1024), 16, ok ? off : OOB, 0, 0, 0);
       }
-      chA[h] += BK;
-      while (chA[h] >= p.Cin) {
-        chA[h] -= p.Cin;
-        ++tapA[h];
-      }
+      conv_k_next(p.kb64, p.Cin, tapA[h], chA[h]);
     } else {
       const int soff = (kA[h] < p.K) ? kA[h] * ES : (int)0x7FFFFFF0;   // run-out tiles: out of range -> zeros
 #pragma unroll

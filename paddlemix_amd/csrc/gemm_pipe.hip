@@ -107,10 +107,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES) void gemm_pipe_kernel
   for (int i = 0; i < WP; ++i) mine += (wave + i * NW < CFG::W_TOTAL) ? 1 : 0;
 
   int gtap = 0, gcch = t0 * BK + cg * 8;   // conv: running (tap, channel) of this lane's chunk
-  if (CONV) {
-    gtap = gcch / p.Cin;
-    gcch -= gtap * p.Cin;
-  }
+  if (CONV) conv_k_init(p.kb64, t0, cg * 8, p.Cin, gtap, gcch);
   int kiss = t0 * BK;   // K offset of the next tile to stage
 
   auto issue_tile = [&](const int stage) {
@@ -127,11 +124,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES) void gemm_pipe_kernel
         const unsigned off = a_off[i] + (unsigned)(((iy >> p.up) * p.Ws + (ix >> p.up)) * p.lda + gcch) * 2u;
         if (CFG::A_TOTAL % NW == 0 || wave + i * NW < CFG::A_TOTAL) dma(a_rsrc, a + i * (NW * 1024), ok ? off : OOB, 0);
       }
-      gcch += BK;
-      while (gcch >= p.Cin) {
-        gcch -= p.Cin;
-        ++gtap;
-      }
+      conv_k_next(p.kb64, p.Cin, gtap, gcch);
     } else {
 #pragma unroll
       for (int i = 0; i < AP; ++i)

@@ -19,6 +19,7 @@ struct GemmArgs {
   int stride;      // 1 | 2
   int up;          // 1: nearest-2x upsample of the source folded into the gather
   int pad;         // 1: zero padding all round; 0: one row / column at the bottom / right only (MI355X_SD_PAD_BR)
+  int kb64;        // conv K order: 0: k = tap*Cin + c ([O][3][3][Cin] weights); 1: k = ((c/64)*9 + tap)*64 + c%64 (MI355X_SD_CONV_KB64)
   // epilogue
   const float* bias;      // [N]
   const float* rowbias;   // [M / rows_per_batch][ld_rowbias] broadcast over rows of one batch item

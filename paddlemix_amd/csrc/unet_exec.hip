@@ -22,6 +22,7 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -361,6 +362,7 @@ struct Exec {
   size_t weight_bytes = 0;
   unsigned char* dev_w = nullptr;
   std::map<std::string, int> temb_off, kv_off;
+  std::set<std::string> kb64;                     // 3x3 convs whose weights are packed in 64-channel blocks
   int temb_total = 0, kv_total = 0;
   // plan
   int B = 0, H = 0, W = 0, L = 0;
@@ -487,15 +489,21 @@ struct Packer {
     lin_rows(t, m16(key + ".w", (int)t.shape[1], (int)t.shape[0]), 0);
     if (bias) put_vec(key + ".b", name + ".bias");
   }
-  void put_conv(const std::string& key, const std::string& name) {   // OIHW -> [O][kh][kw][I]
+  // OIHW -> [O][kh][kw][I]; 3x3 with I % 64 == 0 -> [O][I/64][kh][kw][64] (MI355X_SD_CONV_KB64: taps innermost per 64-channel block)
+  void put_conv(const std::string& key, const std::string& name) {
     const HostT& t = get(name + ".weight");
     const int O = (int)t.shape[0], I = (int)t.shape[1], kh = (int)t.shape[2], kw = (int)t.shape[3];
+    const bool kb64 = kh == 3 && (I % 64) == 0 && !getenv("MI355X_SD_NO_KB64");
+    if (kb64) e.kb64.insert(key);
     uint16_t* d = m16(key + ".w", O, kh * kw * I);
     for (int o = 0; o < O; ++o)
       for (int i = 0; i < I; ++i)
         for (int y = 0; y < kh; ++y)
-          for (int x = 0; x < kw; ++x)
-            d[(((size_t)o * kh + y) * kw + x) * I + i] = to_elem16(t.v[(((size_t)o * I + i) * kh + y) * kw + x]);
+          for (int x = 0; x < kw; ++x) {
+            const size_t dst = kb64 ? ((((size_t)o * (I / 64) + i / 64) * kh + y) * kw + x) * 64 + i % 64
+                                    : (((size_t)o * kh + y) * kw + x) * I + i;
+            d[dst] = to_elem16(t.v[(((size_t)o * I + i) * kh + y) * kw + x]);
+          }
     put_vec(key + ".b", name + ".bias");
   }
   void put_norm(const std::string& key, const std::string& name) {
@@ -692,7 +700,8 @@ struct Planner {
     const Packed& w = wp(wkey + ".w");
     const int Cout = w.rows;
     if (x.es != 2) die(MI355X_SD_ERR_INVALID, "internal: conv operand is fp32");
-    const int flags = (out.es == 4 ? MI355X_SD_OUT_F32 : 0) | ((R && R->es == 4) ? MI355X_SD_R_F32 : 0);
+    const int flags = (out.es == 4 ? MI355X_SD_OUT_F32 : 0) | ((R && R->es == 4) ? MI355X_SD_R_F32 : 0) |
+                      (e.kb64.count(wkey) ? MI355X_SD_CONV_KB64 : 0);
     Exec* ex = &e;
     const Ref wr = wref(wkey + ".w"), br = wref(wkey + ".b");
     const bool has_rb = rowbias.buf >= 0 || rowbias.abs;

@@ -92,9 +92,10 @@ def linear(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, rowbias: Opti
 
 def conv3x3(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, stride: int = 1, upsample: bool = False,
             rowbias: Optional[Tensor] = None, residual: Optional[Tensor] = None, out: Optional[Tensor] = None,
-            out_scale: float = 1.0, pad_br: bool = False) -> Tensor:
+            out_scale: float = 1.0, pad_br: bool = False, kb64: bool = False) -> Tensor:
     """x NHWC view [B,H,W,C] (pixel stride >= C), w [Cout, 9*Cin] -> rows [B*Ho*Wo, Cout]. ``pad_br`` (stride 2): zero
-    padding at the bottom / right only -- Downsample2D(padding=0), resnet.py:277-279."""
+    padding at the bottom / right only -- Downsample2D(padding=0), resnet.py:277-279. ``kb64``: w is packed
+    [Cout][Cin/64][3][3][64] (MI355X_SD_CONV_KB64) instead of [Cout][3][3][Cin]."""
     lib = _lib.load()
     _bind_workspace(x.device)
     if x.dim() != 4 or x.dtype != _lib.elem_dtype() or x.stride(3) != 1 or not x.is_cuda:
@@ -118,7 +119,7 @@ def conv3x3(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, stride: int 
     ld_rb = rowbias.stride(0) if rowbias is not None else 0
     check(lib.mi355x_sd_conv3x3(x.data_ptr(), ldx, B, H, W, C, stride, up, w.data_ptr(), out.data_ptr(), ldc, Cout,
                                 _p(_vec(bias, Cout, "bias")), _p(rowbias), ld_rb, _p(residual), ldr, float(out_scale),
-                                _lib.PAD_BR if pad_br else 0, _stream()))
+                                (_lib.PAD_BR if pad_br else 0) | (_lib.CONV_KB64 if kb64 else 0), _stream()))
     return out
 
 

@@ -28,7 +28,7 @@ from typing import Dict, List, Mapping, Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import GEGLU, OUT_F32, R_F32, SILU
+from ._lib import CONV_KB64, GEGLU, OUT_F32, R_F32, SILU
 from .checkpoint import PretrainedMixin, Table
 from .program import DeviceProgram, _Plan, _Ref, _V
 
@@ -339,9 +339,16 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
             if bias:
                 W[key + ".b"] = get(name + ".bias").contiguous()
 
-        def put_conv(key, name):  # OIHW -> [O][kh][kw][I]
+        self._kb64 = set()
+
+        def put_conv(key, name):  # OIHW -> [O][kh][kw][I]; 3x3 with Cin % 64 == 0 -> [O][I/64][kh][kw][64] (MI355X_SD_CONV_KB64)
             w = get(name + ".weight")
-            W[key + ".w"] = bf(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1))
+            O, I, kh, kw = w.shape
+            if kh == 3 and I % 64 == 0 and not os.environ.get("MI355X_SD_NO_KB64"):
+                W[key + ".w"] = bf(w.reshape(O, I // 64, 64, kh, kw).permute(0, 1, 3, 4, 2).reshape(O, -1))
+                self._kb64.add(key)
+            else:
+                W[key + ".w"] = bf(w.permute(0, 2, 3, 1).reshape(O, -1))
             W[key + ".b"] = get(name + ".bias").contiguous()
 
         def put_norm(key, name):
@@ -510,6 +517,7 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
             wo = ((w_ << up) + 2 - 3) // stride + 1
             assert x.es == 2, (wkey, "fp32 rows cannot be an MFMA operand")
             flags |= (OUT_F32 if out.es == 4 else 0) | (R_F32 if (R is not None and R.es == 4) else 0)
+            flags |= CONV_KB64 if wkey in self._kb64 else 0
             emit(lib.mi355x_sd_conv3x3,
                  (x.p, x.ld, B, h, w_, x.C, stride, up, w.data_ptr(), out.p, out.ld, Cout, W[wkey + ".b"].data_ptr(),
                   rowbias, self._temb_total if rowbias is not None else 0, R.p if R else None, R.ld if R else 0,

@@ -243,7 +243,11 @@ class Emulator:
         x = _rows(X, B * Hs * Ws, Cin, ldx).float().reshape(B, Hs, Ws, Cin).permute(0, 3, 1, 2)
         if up:
             x = F.interpolate(x, scale_factor=2.0, mode="nearest")
-        w = _rows(W, Cout, 9 * Cin, 9 * Cin).float().reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+        if flags & 64:   # MI355X_SD_CONV_KB64: [O][Cin/64][3][3][64]
+            assert Cin % 64 == 0
+            w = _rows(W, Cout, 9 * Cin, 9 * Cin).float().reshape(Cout, Cin // 64, 3, 3, 64).permute(0, 1, 4, 2, 3).reshape(Cout, Cin, 3, 3)
+        else:
+            w = _rows(W, Cout, 9 * Cin, 9 * Cin).float().reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
         if flags & 16:   # MI355X_SD_PAD_BR
             assert stride == 2 and not up
             y = F.conv2d(F.pad(x, (0, 1, 0, 1)), w, None, stride=2, padding=0)

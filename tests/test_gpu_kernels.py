@@ -547,3 +547,28 @@ def test_fp32_residual_forms_of_the_norms(ops, rows, C):
                                     R.data_ptr(), N, 1.0, _lib.OUT_F32 | _lib.R_F32, st))
     want = a.float() @ w.float().t() + bias + R
     assert (out - want).abs().max() < 2e-4 * want.abs().max()     # fp32 accumulation order only: no 16-bit rounding anywhere
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,up", [(2, 16, 16, 64, 128, 1, False), (1, 32, 32, 320, 320, 1, False),
+                                                      (2, 17, 15, 128, 160, 2, False), (1, 8, 8, 640, 96, 1, True),
+                                                      (1, 8, 8, 1280, 1280, 1, False), (8, 32, 32, 640, 640, 1, False)])
+def test_conv3x3_kb64_weight_order(ops, B, H, W, Cin, Cout, stride, up):
+    """MI355X_SD_CONV_KB64: weights packed [O][Cin/64][3][3][64], K loop tap-innermost per 64-channel block -- same result as
+    the [O][3][3][Cin] packing bit for bit? No: the fp32 accumulation order over K differs, so to rounding; both against the
+    oracle. Covers every conv kernel (generic, pipelined 128 / 256x160, phased 256, split-K)."""
+    g = torch.Generator().manual_seed(B * H + Cin + Cout + stride + 1)
+    x = bfr(torch.randn(B, Cin, H, W, generator=g))
+    w = bfr(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin))
+    bias = torch.randn(Cout, generator=g) * 0.1
+    P = {"c.conv.weight": w, "c.conv.bias": bias}
+    ref = U.upsample(P, "c", x) if up else (U.downsample(P, "c", x) if stride == 2 else U.conv2d(P, "c.conv", x))
+    x_nhwc = dev(x.permute(0, 2, 3, 1).contiguous())
+    wk = dev(w.reshape(Cout, Cin // 64, 64, 3, 3).permute(0, 1, 3, 4, 2).reshape(Cout, -1).contiguous())
+    out = ops.conv3x3(x_nhwc, wk, dev(bias, torch.float32), stride=stride, upsample=up, kb64=True)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    check(out.reshape(B, Ho, Wo, Cout).permute(0, 3, 1, 2), ref, what=f"conv3x3 kb64 {B,H,W,Cin,Cout,stride,up}")
+    w0 = dev(w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous())
+    out0 = ops.conv3x3(x_nhwc, w0, dev(bias, torch.float32), stride=stride, upsample=up)
+    assert (out.float() - out0.float()).abs().max() <= 2 * 2 ** -8 * ref.abs().max()
+    with pytest.raises(Exception):
+        ops.conv3x3(dev(torch.zeros(1, 4, 4, 40)), dev(torch.zeros(8, 360)), None, kb64=True)      # Cin % 64 != 0
