@@ -32,7 +32,7 @@ SD3_MEDIUM = dict(sample_size=128, patch_size=2, in_channels=16, num_layers=24, 
 CLIP_L = dict(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12,
               max_position_embeddings=77, hidden_act="quick_gelu", projection_dim=768, eos_token_id=2)
 CLIP_BIGG = dict(vocab_size=49408, hidden_size=1280, intermediate_size=5120, num_hidden_layers=32, num_attention_heads=20,
-                 max_position_embeddings=77, hidden_act="gelu", projection_dim=1280, eos_token_id=2)
+                 max_position_embeddings=77, hidden_act="gelu", projection_dim=1280, eos_token_id=2, with_projection=True)
 WORKLOADS = {
     "sdxl-1024-bs8": dict(cfg=SDXL, B=8, H=128, W=128, L=77, gflop_step=54089.8),
     "sd15-512-bs1": dict(cfg=SD15, B=1, H=64, W=64, L=77, gflop_step=803.3),

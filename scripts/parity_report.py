@@ -49,9 +49,12 @@ def child(elem: str, quick: bool) -> dict:
         P = synth_unet_params(cfg, seed=1234)
         return {k: (v.to(ed).float() if v.dim() > 1 else v) for k, v in P.items()}   # what the device holds
 
+    # (the CPU oracle needs ~40 s per SDXL prompt at 128x128 on the GPU box's 128 threads: keep the list short)
     cases = [("tiny", TINY, 2, 16, 16, 7, True), ("mini_xl", MINI_XL, 2, 32, 32, 77, True)]
     if not quick:
         cases += [("sd15_1x4x64x64", SD15, 1, 64, 64, 77, False), ("sdxl_1x4x128x128", SDXL, 1, 128, 128, 77, False)]
+    if os.environ.get("PARITY_SKIP_SD15"):
+        cases = [c for c in cases if not c[0].startswith("sd15")]
     for name, cfg, B, H, W, L, small in cases:
         P = params(cfg)
         sample, enc, added = _inputs(cfg, B, H, W, L)
@@ -78,7 +81,7 @@ def child(elem: str, quick: bool) -> dict:
 
     # ---- 30 Euler steps (teacher-forced per-step epsilon error + free-running end latents), float64 oracle loop ----
     loops = [("mini_xl_2x4x32x32", MINI_XL, 2, 32, 32, 77)]
-    if not quick:
+    if os.environ.get("PARITY_SDXL_LOOP"):   # float64 oracle of the full SDXL parameter set: ~minutes per step on the CPU
         loops.append(("sdxl_arch_1x4x32x32", SDXL, 1, 32, 32, 77))
     for name, cfg, B, H, W, L in loops:
         P = params(cfg)
@@ -130,14 +133,20 @@ def main():
     for elem in ("bf16", "fp16"):
         env = dict(os.environ, MI355X_SD_DTYPE=elem)
         env.pop("MI355X_SD_RESID", None)
-        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", elem] + (["--quick"] if a.quick else []),
-                           env=env, capture_output=True, text=True)
-        sys.stdout.write(p.stdout)
-        if p.returncode != 0:
-            sys.stderr.write(p.stderr[-4000:])
+        # stream the child's lines through (a run cut short by a time limit still leaves its finished cases in the log)
+        p = subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__), "--child", elem] + (["--quick"] if a.quick else []),
+                             env=env, stdout=subprocess.PIPE, text=True)
+        line = None
+        for ln in p.stdout:
+            sys.stdout.write(ln)
+            sys.stdout.flush()
+            if ln.startswith("PARITY_JSON "):
+                line = ln
+        if p.wait() != 0 or line is None:
             raise SystemExit(f"child {elem} failed")
-        line = [ln for ln in p.stdout.splitlines() if ln.startswith("PARITY_JSON ")][-1]
         res[elem] = json.loads(line[len("PARITY_JSON "):])
+        with open(a.out + ".partial", "w") as f:
+            json.dump(res, f, indent=1)
     res["note"] = ("rel-L2 vs the torch-CPU oracle (restatement of ppdiffusers; Paddle unavailable -> unpinned) on identical "
                    "16-bit-representable synthetic weights; north_star target 1e-3 on latents")
     os.makedirs(os.path.dirname(a.out), exist_ok=True)

@@ -11,10 +11,13 @@ from tests.configs import MINI_XL, SD15, SDXL, TINY, UNET_VARIANTS
 
 pytestmark = pytest.mark.gpu
 
-# Whole-UNet bars = 1.5 x the value measured on the MI355X by scripts/parity_report.py (profiles/r02_parity.json), bf16 build.
-# north_star asks for 1e-3 on latents; what 16-bit MFMA operands give on this random-init network is stated in DESIGN.md 4.
-BAR_16 = 2e-2        # 16-bit residual stream (the throughput headline)
-BAR_F32 = 1.5e-2     # fp32 residual stream
+# Whole-UNet bars = 1.5 x the value MEASURED on the MI355X (bf16 build; profiles/r02_parity.json, gpurun_out/r02a/tests_new.log):
+# rel-L2 of one noise prediction vs the oracle, (16-bit residual stream, fp32 residual stream). north_star asks for 1e-3 on
+# LATENTS; the 30-step loop test below measures that quantity (1.9e-3 / 1.2e-3 in bf16). DESIGN.md section 4 has the full table.
+MEASURED = {"tiny": (9.04e-3, 6.23e-3), "mini-xl": (1.289e-2, 8.67e-3), "sd15-1x4x64x64": (1.280e-2, 8.10e-3),
+            "sdxl-1x4x128x128": (1.523e-2, 9.53e-3), "euler30-eps": (1.347e-2, 8.48e-3), "euler30-latents": (1.915e-3, 1.229e-3)}
+BARS = {k: (1.5 * a, 1.5 * b) for k, (a, b) in MEASURED.items()}
+BAR_16 = 2e-2        # other whole-model tests of this file (16-bit stream, small configurations)
 
 
 def _rel(a, b):
@@ -340,7 +343,7 @@ def test_fp32_residual_stream_on_device(name, cfg, B, H, W, L):
     o32 = m32(_cuda(sample), 501, _cuda(enc), added_cond_kwargs=_cuda(added)).sample
     r16, r32 = _rel(o16.cpu(), ref), _rel(o32.cpu(), ref)
     print(f"{name}: rel-L2 vs oracle, 16-bit stream {r16:.3e}, fp32 stream {r32:.3e}")
-    assert r32 < r16 and r32 < BAR_F32, (r16, r32)
+    assert r32 < r16 and r16 < BARS[name][0] and r32 < BARS[name][1], (r16, r32)
     g32 = UNet2DConditionModel(cfg, P, residual_dtype="fp32", use_graph=True)
     a = g32(_cuda(sample), 501, _cuda(enc), added_cond_kwargs=_cuda(added)).sample
     b = g32(_cuda(sample), 501, _cuda(enc), added_cond_kwargs=_cuda(added)).sample
@@ -368,7 +371,7 @@ def test_headline_geometry_vs_oracle(name, cfg, H, W):
     r16, r32 = _rel(o16, ref), _rel(o32, ref)
     print(f"{name}: rel-L2 vs oracle, 16-bit stream {r16:.3e}, fp32 stream {r32:.3e}")
     assert torch.isfinite(o16).all() and torch.isfinite(o32).all()
-    assert r16 < BAR_16 and r32 < BAR_F32, (r16, r32)
+    assert r16 < BARS[name][0] and r32 < BARS[name][1], (r16, r32)
 
 
 def test_euler30_latents_vs_float64_oracle_loop():
@@ -387,7 +390,8 @@ def test_euler30_latents_vs_float64_oracle_loop():
     sch.set_timesteps(30)
     sig = sch.sigmas.astype(np.float64)
     res = {}
-    for rd, bar_eps, bar_lat in (("16", BAR_16, BAR_16), ("fp32", BAR_F32, BAR_F32)):
+    for rd, bar_eps, bar_lat in (("16", BARS["euler30-eps"][0], BARS["euler30-latents"][0]),
+                                 ("fp32", BARS["euler30-eps"][1], BARS["euler30-latents"][1])):
         model = UNet2DConditionModel(cfg, P, residual_dtype=rd)
         x_ref = sample.double() * float(sch.init_noise_sigma)
         x_dev = x_ref.clone()
