@@ -69,7 +69,8 @@ int mi355x_sd_set_workspace(void* ptr, size_t bytes);
 #define MI355X_SD_DTYPE_F16 2
 int mi355x_sd_unet_create(const char* config_json, void** handle);
 int mi355x_sd_unet_destroy(void* handle);
-/* options before plan(): "residual_f32" = 1 keeps the residual stream in fp32 (MI355X_SD_R_F32) */
+/* options: "residual_f32" = 1 (before plan) keeps the residual stream in fp32 (MI355X_SD_R_F32); "fold_softmax_scale" = 1 (before the
+ * weights are packed) folds head_dim^-0.5 * log2(e) into the self-attention to_q weights and runs those attentions as MI355X_SD_SDPA_LOG2 */
 int mi355x_sd_unet_set_option(void* handle, const char* key, int value);
 int mi355x_sd_unet_num_params(void* handle);
 int mi355x_sd_unet_param_info(void* handle, int index, const char** name, int64_t* shape4, int* ndim);
@@ -206,6 +207,13 @@ int mi355x_sd_sdpa(const void* q, const void* k, const void* v, const float* bia
 /* out += out_scale * softmax(q k^T * scale + bias) v  -- same layouts as mi355x_sd_sdpa, `out` already holding the result of
  * a first attention over another key set. IPAdapterAttnProcessor.__call__ (PPD/models/attention_processor.py:1819-1901):
  * hidden = attn(q, to_k(text), to_v(text)) + self.scale * attn(q, to_k_ip(image tokens), to_v_ip(image tokens)) (:1871-1886). */
+/* mi355x_sd_sdpa with flags. MI355X_SD_SDPA_LOG2: the caller has folded scale * log2(e) into the queries (e.g. into the to_q
+ * weights), so q.k IS the base-2 exponent: out = softmax_2(q k^T) v with softmax_2(x) = 2^x / sum 2^x; `scale` is ignored, no mask,
+ * D == 64. Saves the multiply-add per score in front of every exponential. */
+#define MI355X_SD_SDPA_LOG2 1
+int mi355x_sd_sdpa_ex(const void* q, const void* k, const void* v, const float* bias, void* out, int B, int H, int Sq, int Skv, int D,
+                      int64_t q_bs, int q_ts, int64_t k_bs, int k_ts, int64_t v_bs, int v_ts, int64_t o_bs, int o_ts,
+                      int64_t bias_bs, int64_t bias_hs, int64_t bias_qs, float scale, int flags, void* stream);
 int mi355x_sd_sdpa_accum(const void* q, const void* k, const void* v, const float* bias, void* out,
                    int B, int H, int Sq, int Skv, int D,
                    int64_t q_bs, int q_ts, int64_t k_bs, int k_ts, int64_t v_bs, int v_ts, int64_t o_bs, int o_ts,

@@ -19,6 +19,7 @@ LIB_PATH = os.path.join(_HERE, _BUILDS[ELEM_NAME][0])
 
 ABI_VERSION = 9
 GEGLU, OUT_F32, SILU, GELU_TANH, PAD_BR, R_F32, CONV_KB64 = 1, 2, 4, 8, 16, 32, 64
+SDPA_LOG2 = 1
 
 # name -> (restype, argtypes); must list every symbol include/mi355x_sd.h declares (tests/test_abi.py checks)
 SIGNATURES = {
@@ -51,6 +52,9 @@ SIGNATURES = {
     "mi355x_sd_sdpa": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                c_int64, c_int, c_int64, c_int, c_int64, c_int, c_int64, c_int, c_int64, c_int64,
                                c_int64, c_float, c_void_p]),
+    "mi355x_sd_sdpa_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                  c_int64, c_int, c_int64, c_int, c_int64, c_int, c_int64, c_int, c_int64, c_int64,
+                                  c_int64, c_float, c_int, c_void_p]),
     "mi355x_sd_sdpa_accum": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                      c_int64, c_int, c_int64, c_int, c_int64, c_int, c_int64, c_int, c_int64, c_int64,
                                      c_int64, c_float, c_float, c_void_p]),

@@ -24,6 +24,7 @@
 
 namespace sd {
 
+constexpr int ATTN_LAZY_DEFAULT = 1;
 constexpr int ATTN8_DEFAULT_MODE = -1;   // set from measurements (profiles/r02_attention8.txt)
 constexpr int ATTN8_MIN_SKV = 256;       // short-KV (cross-attention) launches stay on the four-wave, two-query-tile path
 constexpr int ATT_WAVES = 4;
@@ -42,8 +43,17 @@ struct AttLds {
 };
 
 // QT: query tiles per block (1; 2 for the short-KV cross-attention launches, see the query-tile loop at the bottom)
-template <int DP, bool HAS_BIAS, int QT = 1>
+// FL bit 0 (LAZY): the tile's scores are exponentiated against the RUNNING row maximum without first searching the tile's own
+//   maximum (~20 of the ~135 VALU instructions of a tile); the reference only has to keep exp2 inside the fp32 range -- P and
+//   the accumulators are floating point, a stale reference costs no precision -- so the exact path (maximum, rescale,
+//   exponentiate again from the intact scores) runs on the first tile and whenever a lane's partial row sum leaves [0, 2^60].
+// FL bit 1 (LOG2, needs LAZY, no mask): the caller folded scale * log2(e) into the queries (the UNet builder folds it into
+//   the to_q weights), so a score IS the exponent: the S^T accumulators start at -reference instead of 0 (a persistent
+//   16-register C operand, rewritten only at a rescale) and exp2 needs no multiply-add per score.
+template <int DP, bool HAS_BIAS, int QT = 1, int FL = 0>
 __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_kernel(const AttnArgs p) {
+  constexpr bool LAZY = (FL & 1) != 0, LOG2 = (FL & 2) != 0;
+  static_assert(!LOG2 || (LAZY && !HAS_BIAS), "LOG2 builds on the lazy reference and has no additive mask");
   using L = AttLds<DP>;
   constexpr int NBUF = (DP <= 96) ? 2 : 1;
   constexpr int KS = DP / 16;   // k-steps of QK^T
@@ -117,7 +127,10 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_ker
   f32x16 o[DB];
   float m_run = -INFINITY;   // running max of raw scores (q . k [+ bias/scale]), both half-waves agree
   float l_run = 0.f;         // this half-wave's partial row sum
-  const float c2 = p.scale * 1.4426950408889634f;  // exp(x*scale) = exp2(x*c2)
+  const float c2 = LOG2 ? 1.0f : p.scale * 1.4426950408889634f;  // exp(x*scale) = exp2(x*c2); LOG2: scores are exponents already
+  f32x16 sinit;              // LOG2: -reference in every element (C operand of the first MFMA of each S^T chain)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sinit[r] = 0.f;
 
   // Q fragments (MFMA B operand) of query tile qt: lane (q = lq, hi) holds d = ks*16 + hi*8 .. +8
   auto load_q = [&](const int qt, bf16x8 (&dst)[KS]) {
@@ -161,12 +174,19 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_ker
     const unsigned char* ks_ = smem + buf * (L::KBYTES + L::VBYTES);
     const unsigned char* vs_ = ks_ + L::KBYTES;
 
-    // ---- S^T = K Q^T : two 32-key blocks ----
+    // ---- S^T = K Q^T : two 32-key blocks (+ mask / bias). A lambda: the lazy softmax overwrites the scores in place and, in
+    // the rare case its overflow guard fires, simply computes them again (the K tile is still in LDS) ----
     f32x16 s[2];
+    const int kv0 = t * KVBLK;
+    auto compute_scores = [&]() {
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb) {
+      if (LOG2) {
+        s[sb] = sinit;
+      } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[sb][r] = 0.f;
+        for (int r = 0; r < 16; ++r) s[sb][r] = 0.f;
+      }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks_ + (sb * 32 + lq) * L::KRS + (ks * 2 + hi) * 16);
@@ -175,7 +195,6 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_ker
     }
 
     // ---- mask / bias; s[sb][r] is key kv0 + sb*32 + (r&3) + 8*(r>>2) + 4*hi for query lq ----
-    const int kv0 = t * KVBLK;
     if (HAS_BIAS) {
       const float inv = 1.0f / p.scale;
       const float* bp = p.bias + (size_t)b * p.bias_bs + (size_t)h * p.bias_hs + (size_t)(q_ok ? q_row : 0) * p.bias_qs;
@@ -196,46 +215,86 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_ker
           if (kv >= p.Skv) s[sb][r] = -INFINITY;
         }
     }
+    };
+    compute_scores();
 
     // ---- online softmax (one query per lane column) ----
     // 3-input max tree (v_max3_f32).  This file is built with -fno-honor-nans: otherwise hipcc canonicalises every MFMA
     // result before fmaxf (one extra v_max per score).  No inline asm here: an asm reader of MFMA results would need
     // its own MFMA->VALU wait states (cdna guide 5.7).
     auto max3 = [](float a, float b, float c) { return fmaxf(fmaxf(a, b), c); };
-    float mx[10];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) mx[i] = max3(s[(3 * i) >> 4][(3 * i) & 15], s[(3 * i + 1) >> 4][(3 * i + 1) & 15],
-                                              s[(3 * i + 2) >> 4][(3 * i + 2) & 15]);
-    float mloc = max3(max3(mx[0], mx[1], mx[2]), max3(mx[3], mx[4], mx[5]), max3(mx[6], mx[7], mx[8]));
-    mloc = max3(mloc, mx[9], fmaxf(s[1][14], s[1][15]));
-    mloc = xhalf_max(mloc);
-    // defer the rescale while the running max is still a good reference for every row of the wave
-    if (!__all((mloc - m_run) * c2 <= RESCALE_THR)) {
-      asm volatile("; online-softmax rescale (rare; asm volatile keeps it from being speculated)");
-      const float m_new = fmaxf(m_run, mloc);
-      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * c2);  // m_run = -inf -> 0
-      l_run *= alpha;
-      m_run = m_use;
-#pragma unroll
-      for (int i = 0; i < DB; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-    }
-    const float mc = m_run * c2;
+    // LOG2: s holds (score - reference) in exponent units; otherwise raw scores against m_run
+    bool exact = true;
     float psum = 0.f;
     bf16x8 pf[4];
-    if (p.dbg & 2) {   // ablation: no exp / conversions
+    if (LAZY && t > 0 && !(p.dbg & 2)) {
+      const float mc0 = m_run * c2;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) pf[i] = bf16x8{};
-    } else
-#pragma unroll
-    for (int sb = 0; sb < 2; ++sb) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sb][r], c2, -mc));
+      for (int i = 0; i < 32; ++i) {
+        const float e = LOG2 ? __builtin_amdgcn_exp2f(s[i >> 4][i & 15]) : __builtin_amdgcn_exp2f(__builtin_fmaf(s[i >> 4][i & 15], c2, -mc0));
         psum += e;
-        pf[sb * 2 + (r >> 3)][r & 7] = (bf16)e;
+        pf[i >> 3][i & 7] = (bf16)e;
+      }
+      exact = __any(!(psum <= 0x1p60f));   // overflow (or NaN): redo the tile the exact way
+      if (exact) {
+        asm volatile("; lazy-maximum overflow guard fired: scores again, exact path");
+        compute_scores();
+      }
+    }
+    if (exact) {
+      if (LAZY) asm volatile("; exact softmax path (first tile / overflow guard)");
+      float mx[10];
+#pragma unroll
+      for (int i = 0; i < 10; ++i) mx[i] = max3(s[(3 * i) >> 4][(3 * i) & 15], s[(3 * i + 1) >> 4][(3 * i + 1) & 15],
+                                                s[(3 * i + 2) >> 4][(3 * i + 2) & 15]);
+      float mloc = max3(max3(mx[0], mx[1], mx[2]), max3(mx[3], mx[4], mx[5]), max3(mx[6], mx[7], mx[8]));
+      mloc = max3(mloc, mx[9], fmaxf(s[1][14], s[1][15]));
+      mloc = xhalf_max(mloc);
+      float shift = 0.f;   // LOG2: what still has to come off the scores of this tile (they are relative to the OLD reference)
+      if (LOG2) {
+        // mloc is relative to the reference m_run (0 on the first tile, where m_run is still -inf and o = l = 0)
+        const bool first = t == 0;
+        if (first || !__all(mloc <= RESCALE_THR)) {
+          asm volatile("; online-softmax rescale (rare)");
+          const float mfin = (mloc == -INFINITY) ? 0.f : mloc;
+          const float delta = first ? mfin : fmaxf(mfin, 0.f);
+          const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);   // first tile: o = l = 0, nothing to rescale
+          l_run *= alpha;
+          m_run = (first ? 0.f : m_run) + delta;
+          shift = delta;
+#pragma unroll
+          for (int i = 0; i < DB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sinit[r] = -m_run;
+        }
+      } else if (!__all((mloc - m_run) * c2 <= RESCALE_THR)) {
+        asm volatile("; online-softmax rescale (rare; asm volatile keeps it from being speculated)");
+        const float m_new = fmaxf(m_run, mloc);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * c2);  // m_run = -inf -> 0
+        l_run *= alpha;
+        m_run = m_use;
+#pragma unroll
+        for (int i = 0; i < DB; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+      }
+      const float mc = LOG2 ? shift : m_run * c2;
+      psum = 0.f;
+      if (p.dbg & 2) {   // ablation: no exp / conversions
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pf[i] = bf16x8{};
+      } else
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sb][r], c2, -mc));
+          psum += e;
+          pf[sb * 2 + (r >> 3)][r & 7] = (bf16)e;
+        }
       }
     }
     l_run += psum;
@@ -284,6 +343,8 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_ker
       for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
     m_run = -INFINITY;
     l_run = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sinit[r] = 0.f;
 
     for (int t = 0; t < nfull; ++t) tile_body(t, std::false_type{});
     if (nfull < ntiles) tile_body(nfull, std::true_type{});
@@ -316,6 +377,17 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_ker
   }
 }
 
+// lazy row maximum: MI355X_SD_ATTN_LAZY=0 turns it off (default on: profiles/r02_attention.txt)
+static bool attn_lazy() {
+  static const bool dyn = getenv("MI355X_SD_ATTN8_DYN") != nullptr;   // probes flip the variables between launches
+  static int cached = -1;
+  if (cached < 0 || dyn) {
+    const char* e = getenv("MI355X_SD_ATTN_LAZY");
+    cached = e ? (atoi(e) != 0) : ATTN_LAZY_DEFAULT;
+  }
+  return cached != 0;
+}
+
 template <int DP>
 static int launch_dp(const AttnArgs& a0, hipStream_t stream) {
   static const int dbg = [] {
@@ -324,22 +396,34 @@ static int launch_dp(const AttnArgs& a0, hipStream_t stream) {
   }();
   AttnArgs a = a0;
   a.dbg = dbg;
+  // lazy only where it costs no occupancy step: the d <= 64 kernel without mask (158 / 168 VGPRs: still 3 waves per SIMD)
+  const bool lazy = DP == 64 && !a.bias && (attn_lazy() || a.log2);
+  if (a.log2 && (DP != 64 || a.bias)) return SD_ERR_UNSUPPORTED;
   // short KV (both tiles stay resident in the two LDS buffers) and enough query tiles to keep every CU busy: two query
   // tiles per block
   static const bool no_qt = getenv("MI355X_SD_ATTN_NO_QT") != nullptr;
   const long qtiles = (long)((a.Sq + QBLK - 1) / QBLK) * a.B * a.H;
   if (DP == 64 && a.Skv <= 2 * KVBLK && qtiles >= 1024 && !a.bias && !no_qt) {
     constexpr int QT = 2;
+    constexpr int Q = (DP == 64 ? QT : 1);
     const int nqb = (a.Sq + QBLK * QT - 1) / (QBLK * QT);
-    hipLaunchKernelGGL((attention_kernel<DP, false, (DP == 64 ? QT : 1)>), dim3(nqb * a.B * a.H), dim3(ATT_THREADS), 0, stream, a);
+    dim3 grid(nqb * a.B * a.H), block(ATT_THREADS);
+    // (the two-query-tile kernel keeps the exact maximum: lazy would cost it an occupancy step, 168 -> 199 VGPRs)
+    if (DP == 64 && a.log2) hipLaunchKernelGGL((attention_kernel<DP, false, Q, (DP == 64 ? 3 : 0)>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((attention_kernel<DP, false, Q, 0>), grid, block, 0, stream, a);
     return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
   }
   const int nqb = (a.Sq + QBLK - 1) / QBLK;
   dim3 grid(nqb * a.B * a.H), block(ATT_THREADS);
-  if (a.bias)
-    hipLaunchKernelGGL((attention_kernel<DP, true>), grid, block, 0, stream, a);
-  else
-    hipLaunchKernelGGL((attention_kernel<DP, false>), grid, block, 0, stream, a);
+  if (a.bias) {
+    hipLaunchKernelGGL((attention_kernel<DP, true, 1, 0>), grid, block, 0, stream, a);
+  } else if (DP == 64 && a.log2) {
+    hipLaunchKernelGGL((attention_kernel<DP, false, 1, (DP == 64 ? 3 : 0)>), grid, block, 0, stream, a);
+  } else if (lazy) {
+    hipLaunchKernelGGL((attention_kernel<DP, false, 1, (DP == 64 ? 1 : 0)>), grid, block, 0, stream, a);
+  } else {
+    hipLaunchKernelGGL((attention_kernel<DP, false, 1, 0>), grid, block, 0, stream, a);
+  }
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
 

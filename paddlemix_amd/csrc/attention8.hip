@@ -56,8 +56,11 @@ __device__ __forceinline__ void a8_dma(__amdgpu_buffer_rsrc_t rsrc, unsigned cha
 // own maximum first (that search is ~20 of the ~135 VALU instructions of a tile); the running maximum only has to keep
 // exp2 inside the fp32 range, so the exact path (maximum, rescale, exponentiate again) runs on the first tile and whenever a
 // lane's partial row sum leaves [0, 2^60] -- P and the accumulators are floating point, a stale reference costs no precision
+// bit 4 (needs bit 3): scores are base-2 exponents already (AttnArgs::log2, see attention.hip FL bit 1)
 template <int MODE>
 __global__ __launch_bounds__(A8_THREADS, 2) void attention8_kernel(const AttnArgs p) {
+  constexpr bool LOG2 = (MODE & 16) != 0;
+  static_assert(!LOG2 || (MODE & 8), "LOG2 builds on the lazy reference");
   __shared__ __attribute__((aligned(16))) unsigned char smem[A8_STAGES * A8_STAGE];
   constexpr int KS = 4;   // k-steps of K.Q^T (d = 64)
   constexpr int DB = 2;   // 32-row blocks of O^T
@@ -123,8 +126,11 @@ __global__ __launch_bounds__(A8_THREADS, 2) void attention8_kernel(const AttnArg
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
   float m_run = -INFINITY;   // running max of raw scores, both half-waves agree
   float l_run = 0.f;         // this half-wave's partial row sum
-  const float c2 = p.scale * 1.4426950408889634f;
+  const float c2 = LOG2 ? 1.0f : p.scale * 1.4426950408889634f;
   constexpr float RESCALE_THR = 4.0f;
+  f32x16 sinit;              // LOG2: -reference in every element
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sinit[r] = 0.f;
 
   // fragment-read geometry
   //   K: lane (lq, hi) reads row sb*32 + lq, chunk ks*2 + hi at slot chunk ^ ((row>>1)&7)        (row>>1 = sb*16 + (lq>>1))
@@ -160,8 +166,12 @@ __global__ __launch_bounds__(A8_THREADS, 2) void attention8_kernel(const AttnArg
     const unsigned char* ks_ = smem + (t & (A8_STAGES - 1)) * A8_STAGE;
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb) {
+      if (LOG2) {
+        s[sb] = sinit;
+      } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[sb][r] = 0.f;
+        for (int r = 0; r < 16; ++r) s[sb][r] = 0.f;
+      }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks_ + sb * 4096 + k_row_off + (((ks * 2 + hi) ^ k_sw) << 4));
@@ -172,7 +182,7 @@ __global__ __launch_bounds__(A8_THREADS, 2) void attention8_kernel(const AttnArg
 
   auto softmax = [&](const int t, auto mask_tag) {
     constexpr bool MASK = decltype(mask_tag)::value;
-    if (MASK) {
+    auto apply_mask = [&]() {
       const int kv0 = t * A8_KV;
 #pragma unroll
       for (int sb = 0; sb < 2; ++sb)
@@ -181,21 +191,23 @@ __global__ __launch_bounds__(A8_THREADS, 2) void attention8_kernel(const AttnArg
           const int kv = kv0 + sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
           if (kv >= p.Skv) s[sb][r] = -INFINITY;
         }
-    }
+    };
+    if (MASK) apply_mask();
     const float mc0 = m_run * c2;
     bool exact = true;
     float psum = 0.f;
     if ((MODE & 8) && t > 0) {   // lazy: exponentiate against the running maximum, verify afterwards
-      float e[32];
 #pragma unroll
       for (int i = 0; i < 32; ++i) {
-        e[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i >> 4][i & 15], c2, -mc0));
-        psum += e[i];
+        const float e = LOG2 ? __builtin_amdgcn_exp2f(s[i >> 4][i & 15]) : __builtin_amdgcn_exp2f(__builtin_fmaf(s[i >> 4][i & 15], c2, -mc0));
+        psum += e;
+        pf[i >> 3][i & 7] = (bf16)e;
       }
-      exact = __any(!(psum <= 0x1p60f));   // overflow (or NaN): redo the tile the exact way, s is still intact
-      if (!exact) {
-#pragma unroll
-        for (int i = 0; i < 32; ++i) pf[i >> 3][i & 7] = (bf16)e[i];
+      exact = __any(!(psum <= 0x1p60f));   // overflow (or NaN): scores again (the K tile is still staged), exact path
+      if (exact) {
+        asm volatile("; lazy-maximum overflow guard fired");
+        qk(t);
+        if (MASK) apply_mask();
       }
     }
     if (exact) {
@@ -207,7 +219,25 @@ __global__ __launch_bounds__(A8_THREADS, 2) void attention8_kernel(const AttnArg
       float mloc = max3(max3(mx[0], mx[1], mx[2]), max3(mx[3], mx[4], mx[5]), max3(mx[6], mx[7], mx[8]));
       mloc = max3(mloc, mx[9], fmaxf(s[1][14], s[1][15]));
       mloc = xhalf_max(mloc);
-      if (!__all((mloc - m_run) * c2 <= RESCALE_THR)) {
+      float shift = 0.f;
+      if (LOG2) {   // scores are relative to the reference m_run (0 on the first tile)
+        const bool first = t == 0;
+        if (first || !__all(mloc <= RESCALE_THR)) {
+          asm volatile("; online-softmax rescale (rare)");
+          const float mfin = (mloc == -INFINITY) ? 0.f : mloc;
+          const float delta = first ? mfin : fmaxf(mfin, 0.f);
+          const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+          l_run *= alpha;
+          m_run = (first ? 0.f : m_run) + delta;
+          shift = delta;
+#pragma unroll
+          for (int i = 0; i < DB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sinit[r] = -m_run;
+        }
+      } else if (!__all((mloc - m_run) * c2 <= RESCALE_THR)) {
         asm volatile("; online-softmax rescale (rare)");
         const float m_new = fmaxf(m_run, mloc);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
@@ -219,7 +249,7 @@ __global__ __launch_bounds__(A8_THREADS, 2) void attention8_kernel(const AttnArg
 #pragma unroll
           for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
       }
-      const float mc = m_run * c2;
+      const float mc = LOG2 ? shift : m_run * c2;
       psum = 0.f;
 #pragma unroll
       for (int sb = 0; sb < 2; ++sb) {
@@ -297,6 +327,7 @@ __global__ __launch_bounds__(A8_THREADS, 2) void attention8_kernel(const AttnArg
 // D == 64, no additive mask, 16-byte aligned K / V rows (the LDS-DMA moves 16-byte chunks). mode: MI355X_SD_ATTN8 (see launch_attention)
 int launch_attention8(const AttnArgs& a, int mode, hipStream_t stream) {
   if (a.D != 64 || a.bias) return SD_ERR_UNSUPPORTED;
+  if (a.log2) mode |= 8 | 16;
   if ((a.k_ts & 7) || (a.v_ts & 7) || (a.k_bs & 7) || (a.v_bs & 7) || (reinterpret_cast<uintptr_t>(a.K) & 15) ||
       (reinterpret_cast<uintptr_t>(a.V) & 15))
     return SD_ERR_UNSUPPORTED;
@@ -304,6 +335,11 @@ int launch_attention8(const AttnArgs& a, int mode, hipStream_t stream) {
     return SD_ERR_UNSUPPORTED;   // 32-bit buffer offsets
   const int nqb = (a.Sq + A8_QBLK - 1) / A8_QBLK;
   dim3 grid(nqb * a.B * a.H), block(A8_THREADS);
+  if (mode & 16) {
+    if (mode & 1) hipLaunchKernelGGL(attention8_kernel<25>, grid, block, 0, stream, a);
+    else hipLaunchKernelGGL(attention8_kernel<24>, grid, block, 0, stream, a);
+    return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+  }
   switch (mode & 11) {
     case 0: hipLaunchKernelGGL(attention8_kernel<0>, grid, block, 0, stream, a); break;
     case 1: hipLaunchKernelGGL(attention8_kernel<1>, grid, block, 0, stream, a); break;

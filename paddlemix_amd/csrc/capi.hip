@@ -272,6 +272,25 @@ int mi355x_sd_sdpa(const void* q, const void* k, const void* v, const float* bia
   return finish(launch_attention(a, S(stream)), "mi355x_sd_sdpa");
 }
 
+int mi355x_sd_sdpa_ex(const void* q, const void* k, const void* v, const float* bias, void* out, int B, int H, int Sq,
+                      int Skv, int D, int64_t q_bs, int q_ts, int64_t k_bs, int k_ts, int64_t v_bs, int v_ts,
+                      int64_t o_bs, int o_ts, int64_t bias_bs, int64_t bias_hs, int64_t bias_qs, float scale, int flags,
+                      void* stream) {
+  if (!q || !k || !v || !out) return fail(SD_ERR_INVALID, "mi355x_sd_sdpa_ex: null pointer");
+  if ((flags & MI355X_SD_SDPA_LOG2) && (bias || D != 64))
+    return fail(SD_ERR_UNSUPPORTED, "mi355x_sd_sdpa_ex: MI355X_SD_SDPA_LOG2 needs D == 64 and no mask");
+  AttnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.Q = (const bf16*)q; a.K = (const bf16*)k; a.V = (const bf16*)v; a.O = (bf16*)out;
+  a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.D = D;
+  a.q_bs = q_bs; a.k_bs = k_bs; a.v_bs = v_bs; a.o_bs = o_bs;
+  a.q_ts = q_ts; a.k_ts = k_ts; a.v_ts = v_ts; a.o_ts = o_ts;
+  a.bias = bias; a.bias_bs = bias_bs; a.bias_hs = bias_hs; a.bias_qs = bias_qs;
+  a.log2 = (flags & MI355X_SD_SDPA_LOG2) ? 1 : 0;
+  a.scale = a.log2 ? 1.0f : scale;
+  return finish(launch_attention(a, S(stream)), "mi355x_sd_sdpa_ex");
+}
+
 int mi355x_sd_sdpa_accum(const void* q, const void* k, const void* v, const float* bias, void* out, int B, int H, int Sq,
                          int Skv, int D, int64_t q_bs, int q_ts, int64_t k_bs, int k_ts, int64_t v_bs, int v_ts,
                          int64_t o_bs, int o_ts, int64_t bias_bs, int64_t bias_hs, int64_t bias_qs, float scale,

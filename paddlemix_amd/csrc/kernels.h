@@ -75,6 +75,7 @@ struct AttnArgs {
   long bias_bs, bias_hs, bias_qs;
   float scale;
   float accum;   // != 0: O += accum * attention(...) instead of O = attention(...) (IP-Adapter's second key set)
+  int log2;      // MI355X_SD_SDPA_LOG2: q already carries scale * log2(e) -- scores are base-2 exponents (D == 64, no mask)
   int dbg;   // ablation switches (MI355X_SD_ATTN_DBG; 0 in production)
 };
 int launch_attention(const AttnArgs& a, hipStream_t stream);

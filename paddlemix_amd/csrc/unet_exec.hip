@@ -356,6 +356,8 @@ struct Exec {
   std::map<std::string, HostT> params;            // expected parameters (reference names, Paddle layouts)
   std::vector<std::string> order;                 // construction order
   bool resid_f32 = false;
+  bool fold_scale = false;                        // head_dim^-0.5 * log2(e) folded into the self-attention to_q weights (head_dim 64)
+  std::set<std::string> log2_blocks;
   // packed weights
   std::map<std::string, Packed> w;
   std::vector<unsigned char> host_pack;
@@ -474,11 +476,11 @@ struct Packer {
     return reinterpret_cast<uint16_t*>(reserve(key, (size_t)rows * cols * 2, rows, cols));
   }
   float* f32(const std::string& key, int n) { return reinterpret_cast<float*>(reserve(key, (size_t)n * 4, 1, n)); }
-  // Paddle Linear [in, out] -> rows [out][in] appended at row r0 of dst (row length in)
-  static void lin_rows(const HostT& t, uint16_t* dst, int r0) {
+  // Paddle Linear [in, out] -> rows [out][in] appended at row r0 of dst (row length in); mul: fp32 factor applied before rounding
+  static void lin_rows(const HostT& t, uint16_t* dst, int r0, float mul = 1.0f) {
     const int in = (int)t.shape[0], out = (int)t.shape[1];
     for (int o = 0; o < out; ++o)
-      for (int i = 0; i < in; ++i) dst[(size_t)(r0 + o) * in + i] = to_elem16(t.v[(size_t)i * out + o]);
+      for (int i = 0; i < in; ++i) dst[(size_t)(r0 + o) * in + i] = to_elem16(mul == 1.0f ? t.v[(size_t)i * out + o] : t.v[(size_t)i * out + o] * mul);
   }
   void put_vec(const std::string& key, const std::string& name) {
     const HostT& t = get(name);
@@ -565,7 +567,12 @@ struct Packer {
           const std::string b = d.name + ".transformer_blocks." + std::to_string(l);
           for (const char* nm : {".norm1", ".norm2", ".norm3"}) put_norm(b + nm, b + nm);
           uint16_t* q = m16(b + ".attn1.qkv.w", 3 * ch, ch);
-          lin_rows(get(b + ".attn1.to_q.weight"), q, 0);
+          float qmul = 1.0f;
+          if (e.fold_scale && ch / d.heads == 64) {
+            qmul = (float)(pow((double)(ch / d.heads), -0.5) * 1.4426950408889634);
+            e.log2_blocks.insert(b);
+          }
+          lin_rows(get(b + ".attn1.to_q.weight"), q, 0, qmul);
           lin_rows(get(b + ".attn1.to_k.weight"), q, ch);
           lin_rows(get(b + ".attn1.to_v.weight"), q, 2 * ch);
           lin_rows(get(b + ".attn2.to_q.weight"), m16(b + ".attn2.q.w", ch, ch), 0);
@@ -749,10 +756,18 @@ struct Planner {
     emit([=](void* st) { return mi355x_sd_cast_rows((const float*)ex->at(x.p), x.ld, ex->at(y.p), y.ld, x.rows, x.C, st); });
     return y;
   }
-  void attention(const View& q, const View& k, const View& v, const View& out, int heads, int sq, int skv) {
+  void attention(const View& q, const View& k, const View& v, const View& out, int heads, int sq, int skv, bool log2 = false) {
     const int d = q.C / heads;
     Exec* ex = &e;
     const int Bc = B;
+    if (log2) {
+      emit([=](void* st) {
+        return mi355x_sd_sdpa_ex(ex->at(q.p), ex->at(k.p), ex->at(v.p), nullptr, ex->at(out.p), Bc, heads, sq, skv, d, (int64_t)sq * q.ld, q.ld,
+                                 (int64_t)skv * k.ld, k.ld, (int64_t)skv * v.ld, v.ld, (int64_t)sq * out.ld, out.ld, 0, 0, 0, 1.0f,
+                                 MI355X_SD_SDPA_LOG2, st);
+      });
+      return;
+    }
     const float scale = (float)pow((double)d, -0.5);   // == Python d ** -0.5 rounded to fp32
     emit([=](void* st) {
       return mi355x_sd_sdpa(ex->at(q.p), ex->at(k.p), ex->at(v.p), nullptr, ex->at(out.p), Bc, heads, sq, skv, d, (int64_t)sq * q.ld, q.ld,
@@ -882,7 +897,7 @@ struct Planner {
         View q2 = view(qkv.p, rows, ch);
         lnorm(hid, b + ".norm1", ln);
         linear(ln, b + ".attn1.qkv", qkv, false);
-        attention(qkv.cols(0, ch), qkv.cols(ch, ch), qkv.cols(2 * ch, ch), ao, d.heads, hw, hw);
+        attention(qkv.cols(0, ch), qkv.cols(ch, ch), qkv.cols(2 * ch, ch), ao, d.heads, hw, hw, e.log2_blocks.count(b) != 0);
         linear(ao, b + ".attn1.out", hid, true, &hid);
         lnorm(hid, b + ".norm2", ln);
         linear(ln, b + ".attn2.q", q2, false);
@@ -1018,6 +1033,14 @@ int mi355x_sd_unet_set_option(void* handle, const char* key, int value) {
       return MI355X_SD_ERR_INVALID;
     }
     e->resid_f32 = value != 0;
+    return MI355X_SD_OK;
+  }
+  if (!strcmp(key, "fold_softmax_scale")) {
+    if (!e->host_pack.empty() || e->dev_w) {
+      sd::set_last_error("mi355x_sd_unet_set_option: fold_softmax_scale must be set before the weights are packed");
+      return MI355X_SD_ERR_INVALID;
+    }
+    e->fold_scale = value != 0;
     return MI355X_SD_OK;
   }
   sd::set_last_error("mi355x_sd_unet_set_option: unknown option");

@@ -144,9 +144,10 @@ def latent_dist(moments: Tensor, B: int, L: int, noise: Optional[Tensor] = None,
 
 
 def sdpa(q: Tensor, k: Tensor, v: Tensor, bias: Optional[Tensor] = None, scale: Optional[float] = None,
-         out: Optional[Tensor] = None, accum: Optional[float] = None) -> Tensor:
+         out: Optional[Tensor] = None, accum: Optional[float] = None, log2: bool = False) -> Tensor:
     """q [B,Sq,H,D], k/v [B,Skv,H,D] (head-contiguous token rows, arbitrary token/batch strides) -> [B,Sq,H,D].
-    bias: optional fp32 additive mask broadcastable to [B,H,Sq,Skv] with unit inner stride."""
+    bias: optional fp32 additive mask broadcastable to [B,H,Sq,Skv] with unit inner stride. log2: q already carries
+    scale * log2(e) (MI355X_SD_SDPA_LOG2): out = softmax_2(q k^T) v."""
     lib = _lib.load()
     for name, t in (("q", q), ("k", k), ("v", v)):
         if t.dim() != 4 or t.dtype != _lib.elem_dtype() or not t.is_cuda or t.stride(3) != 1 or t.stride(2) != t.shape[3]:
@@ -167,7 +168,11 @@ def sdpa(q: Tensor, k: Tensor, v: Tensor, bias: Optional[Tensor] = None, scale: 
     args = (q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(bias), out.data_ptr(), B, H, Sq, Skv, D,
             q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
             out.stride(0), out.stride(1), bb, bh, bq, float(scale))
-    if accum is None:
+    if log2:
+        if accum is not None:
+            raise ValueError("log2 and accum cannot be combined")
+        check(lib.mi355x_sd_sdpa_ex(*args, _lib.SDPA_LOG2, _stream()))
+    elif accum is None:
         check(lib.mi355x_sd_sdpa(*args, _stream()))
     else:   # out += accum * attention (`out` given and already holding a first attention's result)
         check(lib.mi355x_sd_sdpa_accum(*args, float(accum), _stream()))

@@ -281,7 +281,7 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
 
     def __init__(self, config: Mapping, params: Mapping[str, Tensor], device="cuda", use_graph: bool = True,
                  profile: bool = False, fold_layernorm: Optional[bool] = None, residual_dtype: Optional[str] = None,
-                 _test_backend=None):
+                 fold_softmax_scale: Optional[bool] = None, _test_backend=None):
         """``_test_backend``: test-only injection point (tests/abi_emulator.py interprets the emitted C-ABI
         program on host memory to check the sequencing / packing logic without a GPU).  It is never selected by
         product code: without it the model needs the built HIP library and a GPU, and raises otherwise."""
@@ -296,6 +296,11 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
         # state, every skip / concat slot -- is stored in fp32; 16-bit values exist only as MFMA operands (the outputs of
         # GroupNorm / LayerNorm / GEGLU / attention, which feed exactly one contraction each). Each branch then rounds once
         # instead of the stream re-rounding after every one of its ~50-200 sequential adds.
+        # fold_softmax_scale (MI355X_SD_FOLD_SCALE=1): head_dim^-0.5 * log2(e) is multiplied into the self-attention to_q weights
+        # at load (fp32, before the one rounding to 16 bits), so q.k IS the base-2 exponent of the softmax and the attention
+        # kernel runs its MI355X_SD_SDPA_LOG2 form (no multiply-add per score). Same function, slightly different rounding of
+        # the to_q weights (they are rounded after the scaling instead of before); self-attention with head_dim 64 only.
+        self.fold_scale = (os.environ.get("MI355X_SD_FOLD_SCALE", "0") == "1") if fold_softmax_scale is None else bool(fold_softmax_scale)
         rd = os.environ.get("MI355X_SD_RESID", "") if residual_dtype is None else residual_dtype
         if rd not in ("", None, "fp32", "16"):
             raise ValueError(f"residual_dtype must be None | '16' | 'fp32', got {rd!r}")
@@ -340,6 +345,7 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
                 W[key + ".b"] = get(name + ".bias").contiguous()
 
         self._kb64 = set()
+        self._log2_blocks = set()   # transformer blocks whose self-attention scores are base-2 exponents (fold_softmax_scale)
 
         def put_conv(key, name):  # OIHW -> [O][kh][kw][I]; 3x3 with Cin % 64 == 0 -> [O][I/64][kh][kw][64] (MI355X_SD_CONV_KB64)
             w = get(name + ".weight")
@@ -419,7 +425,11 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
                     put_conv(name + ".proj_out", name + ".proj_out")
                 for l in range(layers):
                     b = f"{name}.transformer_blocks.{l}"
-                    wqkv = torch.cat([lin_w(b + ".attn1.to_q"), lin_w(b + ".attn1.to_k"), lin_w(b + ".attn1.to_v")], 0)
+                    wq = lin_w(b + ".attn1.to_q")
+                    if self.fold_scale and c // heads == 64:
+                        wq = wq * ((c // heads) ** -0.5 * 1.4426950408889634)
+                        self._log2_blocks.add(b)
+                    wqkv = torch.cat([wq, lin_w(b + ".attn1.to_k"), lin_w(b + ".attn1.to_v")], 0)
                     if self.fold_ln:
                         put_ln_lin(b + ".attn1.qkv", wqkv, None, b + ".norm1")
                         put_ln_lin(b + ".attn2.q", lin_w(b + ".attn2.to_q"), None, b + ".norm2")
@@ -572,8 +582,14 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
                                            wp(wkey + ".b"), flags, stream), "gemm", 2.0 * x.rows * N * K,
                  f"{x.rows}x{N}x{K}" + ("g" if flags & GEGLU else ""))
 
-        def attention(q: _V, k: _V, v: _V, out: _V, heads, sq, skv, bias=None, accum: Optional[float] = None):
+        def attention(q: _V, k: _V, v: _V, out: _V, heads, sq, skv, bias=None, accum: Optional[float] = None, log2=False):
             d = q.C // heads
+            if log2:
+                assert bias is None and accum is None and d == 64
+                emit(lib.mi355x_sd_sdpa_ex, (q.p, k.p, v.p, None, out.p, B, heads, sq, skv, d, sq * q.ld, q.ld, skv * k.ld, k.ld,
+                                             skv * v.ld, v.ld, sq * out.ld, out.ld, 0, 0, 0, 1.0, _lib.SDPA_LOG2, stream), "attn",
+                     4.0 * B * heads * sq * skv * d, f"{B}x{heads}x{sq}x{skv}x{d}")
+                return
             # bias: additive encoder mask [B, skv] broadcast over heads and queries (unet_2d_condition.py:921-927)
             args = (q.p, k.p, v.p, bias, out.p, B, heads, sq, skv, d, sq * q.ld, q.ld, skv * k.ld, k.ld, skv * v.ld, v.ld,
                     sq * out.ld, out.ld, skv if bias else 0, 0, 0, d ** -0.5)
@@ -767,7 +783,7 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
                 else:
                     lnorm(hid, b + ".norm1", ln)
                     linear(ln, b + ".attn1.qkv", qkv, bias=False)
-                attention(qkv.cols(0, c), qkv.cols(c, c), qkv.cols(2 * c, c), ao, heads, hw, hw)
+                attention(qkv.cols(0, c), qkv.cols(c, c), qkv.cols(2 * c, c), ao, heads, hw, hw, log2=b in self._log2_blocks)
                 linear(ao, b + ".attn1.out", hid, R=hid)
                 if self.fold_ln:
                     ln_linear(hid, b + ".attn2.q", q2)

@@ -1,7 +1,10 @@
-"""Probe of the attention kernels on the GPU box: the four-wave kernel (attention.hip) against the modes of the eight-wave
-LDS-DMA kernel (attention8.hip) -- parity against fp32 torch math on a subsample and against each other, and time per launch.
+"""Probe of the attention kernels on the GPU box: the four-wave kernel (attention.hip; exact / lazy row maximum / lazy + base-2
+scores) against the modes of the eight-wave LDS-DMA kernel (attention8.hip) -- parity against fp32 torch math on one
+(batch, head) pair and against the first variant over the whole tensor, and time per launch.
 
-    MI355X_SD_ATTN8_DYN=1 python scripts/attn8_probe.py [--iters 20]
+    python scripts/attn8_probe.py [--iters 10]
+
+variant = (MI355X_SD_ATTN8 mode or -1 for the four-wave kernel, MI355X_SD_ATTN_LAZY, log2 flag)
 """
 import argparse
 import json
@@ -15,68 +18,82 @@ import torch  # noqa: E402
 
 from paddlemix_amd import ops  # noqa: E402
 
+VARIANTS = [("4w-exact", -1, 0, False), ("4w-lazy", -1, 1, False), ("4w-lazy-log2", -1, 1, True),
+            ("8w-prio", 1, 0, False), ("8w-prio-lazy", 9, 0, False), ("8w-prio-lazy-log2", 9, 0, True)]
+C2 = 0.125 * 1.4426950408889634
+
+
+def run(name, mode, lazy, log2, q, k, v, q2, out=None):
+    os.environ["MI355X_SD_ATTN8"] = str(mode if mode < 0 else (mode | 4))   # bit 2: also take short-KV launches
+    os.environ["MI355X_SD_ATTN_LAZY"] = str(lazy)
+    return ops.sdpa(q2 if log2 else q, k, v, out=out, log2=log2)
+
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--modes", default="-1,0,1,2,3,8,9")
+    ap.add_argument("--iters", type=int, default=10)
     a = ap.parse_args()
     ops.init(0)
-    shapes = [(8, 10, 4096, 4096), (8, 20, 1024, 1024), (8, 24, 4250, 4250), (2, 10, 4096, 4000), (8, 20, 1024, 77), (8, 10, 4096, 77)]
-    modes = [int(m) for m in a.modes.split(",")]
+    shapes = [(8, 10, 4096, 4096), (8, 20, 1024, 1024), (8, 24, 4250, 4250), (8, 20, 1024, 77)]
     rows = []
     for (B, H, Sq, Skv) in shapes:
         g = torch.Generator(device="cuda").manual_seed(Sq + Skv)
         C = H * 64
-        # self-attention reads q/k/v in place from the fused projection buffer [rows, 3C]; cross-attention from separate buffers
-        if Sq == Skv:
+        if Sq == Skv:   # self-attention reads q/k/v in place from the fused projection buffer [rows, 3C]
             qkv = torch.randn(B, Sq, 3 * C, generator=g, device="cuda").to(torch.bfloat16)
             q, k, v = (qkv[..., i * C:(i + 1) * C].unflatten(-1, (H, 64)) for i in range(3))
+            qkv2 = qkv.clone()
+            qkv2[..., :C] = (qkv[..., :C].float() * C2).to(torch.bfloat16)      # what a to_q with the scale folded in produces
+            q2 = qkv2[..., :C].unflatten(-1, (H, 64))
+            k2, v2 = (qkv2[..., i * C:(i + 1) * C].unflatten(-1, (H, 64)) for i in (1, 2))
         else:
             q = torch.randn(B, Sq, H, 64, generator=g, device="cuda").to(torch.bfloat16)
             k = torch.randn(B, Skv, H, 64, generator=g, device="cuda").to(torch.bfloat16)
             v = torch.randn(B, Skv, H, 64, generator=g, device="cuda").to(torch.bfloat16)
-        # fp32 reference on one (batch, head) pair, every query
-        qs, ks, vs = q[0, :, 0].float(), k[0, :, 0].float(), v[0, :, 0].float()
-        ref = torch.softmax(qs @ ks.t() * 0.125, -1) @ vs
+            q2, k2, v2 = (q.float() * C2).to(torch.bfloat16), k, v
+        ks, vs = k[0, :, 0].float(), v[0, :, 0].float()
+        ref = torch.softmax(q[0, :, 0].float() @ ks.t() * 0.125, -1) @ vs
+        ref2 = torch.softmax(q2[0, :, 0].float() @ ks.t() * 0.6931471805599453, -1) @ vs     # base-2 softmax of the folded scores
         base = None
-        for m in modes:
-            os.environ["MI355X_SD_ATTN8"] = str(m if m < 0 else (m | 4))   # bit 2: also take short-KV launches
-            out = ops.sdpa(q, k, v)
+        for (name, mode, lazy, log2) in VARIANTS:
+            kk, vv = (k2, v2) if log2 else (k, v)
+            out = run(name, mode, lazy, log2, q, kk, vv, q2)
             torch.cuda.synchronize()
-            rel = ((out[0, :, 0].float() - ref).norm() / ref.norm()).item()
+            rel = ((out[0, :, 0].float() - (ref2 if log2 else ref)).norm() / ref.norm()).item()
+            rel_plain = ((out[0, :, 0].float() - ref).norm() / ref.norm()).item()     # what folding the scale into q costs
             finite = bool(torch.isfinite(out.float()).all())
             if base is None:
                 base = out.clone()
             dmax = (out.float() - base.float()).abs().max().item()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             for _ in range(3):
-                ops.sdpa(q, k, v, out=out)
+                run(name, mode, lazy, log2, q, kk, vv, q2, out=out)
             e0.record()
             for _ in range(a.iters):
-                ops.sdpa(q, k, v, out=out)
+                run(name, mode, lazy, log2, q, kk, vv, q2, out=out)
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / a.iters
             tf = 4.0 * B * H * Sq * Skv * 64 / us / 1e6
-            rows.append(dict(shape=[B, H, Sq, Skv, 64], mode=m, us=round(us, 1), tflops=round(tf, 1), rel_vs_fp32=rel,
-                             max_abs_vs_first_mode=dmax, finite=finite))
+            rows.append(dict(shape=[B, H, Sq, Skv, 64], variant=name, us=round(us, 1), tflops=round(tf, 1), rel_vs_own_fp32_ref=rel,
+                             rel_vs_unfolded_fp32_ref=rel_plain, max_abs_vs_first=dmax, finite=finite))
             print(rows[-1], flush=True)
-    # overflow guard of the lazy-maximum modes: late keys 40x larger -> exp2 against the stale running maximum overflows fp32,
-    # the exact path must take over (and the deferred-rescale path of the other modes fires as well)
+    # overflow guard of the lazy variants: late keys 40x larger -> exp2 against the stale running maximum overflows fp32, the exact
+    # path must take over (and the deferred-rescale path of the exact variants fires as well)
     g = torch.Generator(device="cuda").manual_seed(5)
     q = torch.randn(1, 512, 2, 64, generator=g, device="cuda").to(torch.bfloat16)
     k = torch.randn(1, 512, 2, 64, generator=g, device="cuda")
     k[:, 300:] *= 40.0
     k = k.to(torch.bfloat16)
     v = torch.randn(1, 512, 2, 64, generator=g, device="cuda").to(torch.bfloat16)
-    ref = torch.softmax(torch.einsum("bqhd,bkhd->bhqk", q.double(), k.double()) * 0.125, -1)
-    ref = torch.einsum("bhqk,bkhd->bqhd", ref, v.double())
-    for m in modes:
-        os.environ["MI355X_SD_ATTN8"] = str(m if m < 0 else (m | 4))
-        out = ops.sdpa(q, k, v)
-        rel = ((out.double() - ref).norm() / ref.norm()).item()
-        rows.append(dict(shape="spike(1,2,512,512,64)", mode=m, rel_vs_fp64=rel, finite=bool(torch.isfinite(out.float()).all())))
+    q2 = (q.float() * C2).to(torch.bfloat16)
+    sm = lambda qq, f: torch.einsum("bhqk,bkhd->bqhd", torch.softmax(torch.einsum("bqhd,bkhd->bhqk", qq.double(), k.double()) * f, -1), v.double())  # noqa: E731
+    ref, ref2 = sm(q, 0.125), sm(q2, 0.6931471805599453)
+    for (name, mode, lazy, log2) in VARIANTS:
+        out = run(name, mode, lazy, log2, q, k, v, q2)
+        r = ref2 if log2 else ref
+        rows.append(dict(shape="spike(1,2,512,512,64)", variant=name, rel_vs_fp64=((out.double() - r).norm() / r.norm()).item(),
+                         finite=bool(torch.isfinite(out.float()).all())))
         print(rows[-1], flush=True)
     print("ATTN8_JSON " + json.dumps(rows))
 

@@ -22,6 +22,61 @@ from tests.configs import MINI_XL, TINY  # noqa: E402
 from tests.test_host_logic import _inputs, _rel  # noqa: E402
 
 
+def fp32_residual_cases(make_model, dev, headline: bool):
+    """fp16 elements + fp32 residual stream: single forwards, 30 Euler steps on the SDXL-structured mini UNet against a float64
+    oracle loop, and (GPU only) the full SDXL parameter set at the headline geometry 1x4x128x128"""
+    import numpy as np
+    from oracle import schedulers_ref as S
+    from tests.configs import SDXL
+    out = {}
+    mv = (lambda t: t.to(dev)) if dev else (lambda t: t)
+    mvd = lambda d: None if d is None else {k: mv(v) for k, v in d.items()}  # noqa: E731
+    cases = [("tiny", TINY, 2, 16, 16, 7), ("mini_xl", MINI_XL, 2 if dev else 1, 32 if dev else 16, 32 if dev else 16, 77)]
+    if headline:
+        cases.append(("sdxl_1x4x128x128", SDXL, 1, 128, 128, 77))
+    for name, cfg, B, H, W, L in cases:
+        P = synth_unet_params(cfg, seed=1234)
+        Ph = {k: v.to(torch.float16).float() if v.dim() > 1 else v for k, v in P.items()}
+        sample, enc, added = _inputs(cfg, B, H, W, L)
+        ref = U.unet_forward(Ph, cfg, sample, 501, enc, added_cond_kwargs=added)
+        r = {}
+        for rd in ("16", "fp32"):
+            model = make_model(cfg, P, rd)
+            got = model(mv(sample), 501, mv(enc), added_cond_kwargs=mvd(added), return_dict=False)[0].float().cpu()
+            r["resid_" + rd] = _rel(got, ref)
+            del model
+        out[name] = r
+    # 30 Euler steps, float64 oracle loop (the quantity north_star's 1e-3 is stated on: the latents)
+    cfg, B, H, W, L = MINI_XL, 2, (32 if dev else 16), (32 if dev else 16), 77
+    P = synth_unet_params(cfg, seed=1234)
+    Ph = {k: v.to(torch.float16).float() if v.dim() > 1 else v for k, v in P.items()}
+    P64 = {k: v.double() for k, v in Ph.items()}
+    sample, enc, added = _inputs(cfg, B, H, W, L)
+    added64 = {k: v.double() for k, v in added.items()}
+    sch = S.EulerRef(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", timestep_spacing="leading", steps_offset=1)
+    sch.set_timesteps(30 if dev else 6)
+    sig = sch.sigmas.astype(np.float64)
+    loop = {}
+    for rd in ("16", "fp32"):
+        model = make_model(cfg, P, rd)
+        x_ref = sample.double() * float(sch.init_noise_sigma)
+        x_dev = x_ref.clone()
+        worst = 0.0
+        for i, t in enumerate(sch.timesteps):
+            s = sig[i]
+            xin = x_ref / (s * s + 1.0) ** 0.5
+            e_ref = U.unet_forward(P64, cfg, xin, int(t), enc.double(), added_cond_kwargs=added64)
+            e_tf = model(mv(xin.float()), int(t), mv(enc), added_cond_kwargs=mvd(added), return_dict=False)[0].cpu().double()
+            worst = max(worst, _rel(e_tf, e_ref))
+            e_fr = model(mv((x_dev / (s * s + 1.0) ** 0.5).float()), int(t), mv(enc), added_cond_kwargs=mvd(added), return_dict=False)[0]
+            x_ref = x_ref + e_ref * (sig[i + 1] - s)
+            x_dev = x_dev + e_fr.cpu().double() * (sig[i + 1] - s)
+        loop["resid_" + rd] = dict(eps_worst=worst, end_latents=_rel(x_dev, x_ref), steps=len(sch.timesteps))
+        del model
+    out["euler_loop_mini_xl"] = loop
+    return out
+
+
 def unet_cases(make_model, dev):
     out = {}
     for name, cfg, B, H, W, L in (("tiny", TINY, 2, 16, 16, 7), ("mini_xl", MINI_XL, 1, 16, 16, 77)):
@@ -90,6 +145,8 @@ def main(mode):
         lib = _lib.load()   # dlopen works without a GPU: every declared symbol present, element type matches
         res["elem_dtype_symbol"] = lib.mi355x_sd_elem_dtype()
         res["unet"] = unet_cases(lambda cfg, P: UNet2DConditionModel(cfg, P, _test_backend=Emulator()), None)
+        res["fp32_residual"] = fp32_residual_cases(
+            lambda cfg, P, rd: UNet2DConditionModel(cfg, P, residual_dtype=rd, _test_backend=Emulator()), None, False)
         res["models"] = other_models(dict(_test_backend=Emulator()), None)
     else:
         from paddlemix_amd import ops
@@ -117,6 +174,8 @@ def main(mode):
         ref = F.silu(F.group_norm(xg.float().permute(0, 2, 1), 32, gam, bet, 1e-5)).permute(0, 2, 1)
         res["group_norm_silu"] = _rel(got, ref)
         res["unet"] = unet_cases(lambda cfg, P: UNet2DConditionModel(cfg, P, device="cuda:0"), "cuda:0")
+        res["fp32_residual"] = fp32_residual_cases(
+            lambda cfg, P, rd: UNet2DConditionModel(cfg, P, device="cuda:0", residual_dtype=rd), "cuda:0", True)
         res["models"] = other_models(dict(device="cuda:0"), "cuda:0")
     print(json.dumps(res))
 
