@@ -25,6 +25,8 @@
 
 namespace sd {
 
+constexpr int GEMM_LOADERS_DEFAULT = 0;   // set from measurements (profiles/r02_gemm_loaders.txt)
+
 #define SD_PIPE_BARRIER()                 \
   do {                                    \
     __builtin_amdgcn_sched_barrier(0);    \
@@ -39,10 +41,18 @@ __device__ __forceinline__ void dma(__amdgpu_buffer_rsrc_t rsrc, unsigned char* 
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)lds, 16, voff, soff, 0, 0);
 }
 
-template <bool CONV, class CFG, bool LN>
-__global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES) void gemm_pipe_kernel(const GemmArgs p) {
+// LW > 0: LW extra LOADER waves per block issue every LDS-DMA piece; the NW compute waves never touch VMEM inside the K loop.
+// Why: an in-order wave pays ~60 cycles of issue per LDS-DMA piece among bare MFMAs and 100-185 in a phase that also carries
+// ds_read_b128s (MI355X_MICROARCH.md constants; measured here: 9 pieces per wave per K-tile = 1600-3300 cycles per SIMD next to
+// ~2600 cycles of MFMA) -- cycles in which it cannot issue MFMAs. A loader wave has nothing else to do; one per SIMD (LW = 4)
+// moves a K-tile's pieces in about the time the two compute waves of that SIMD need for its MFMAs. Same LDS image, same barriers
+// (loaders take part in them), same hazards argument: the loader issues tile t+AHEAD after the barrier at which every compute wave
+// retired its reads of the stage it overwrites, and waits for its pieces of tile t+1 before the barrier that publishes them.
+template <bool CONV, class CFG, bool LN, int LW = 0>
+__global__ __launch_bounds__(CFG::THREADS + LW * 64, (LW ? 3 : CFG::MIN_WAVES)) void gemm_pipe_kernel(const GemmArgs p) {
   constexpr int BM = CFG::BM, BN = CFG::BN, TM = CFG::TM, TN = CFG::TN, ST = CFG::STAGES, NW = CFG::NW;
-  constexpr int AP = CFG::A_PIECES, WP = CFG::W_PIECES;
+  constexpr int PW = LW ? LW : NW;                       // waves that own LDS-DMA pieces
+  constexpr int AP = (CFG::A_TOTAL + PW - 1) / PW, WP = (CFG::W_TOTAL + PW - 1) / PW;
   constexpr int STAGE_A = BM * BK * 2, STAGE_W = BN * BK * 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* As = smem;                 // [ST][BM][128 B]
@@ -51,6 +61,8 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES) void gemm_pipe_kernel
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = LW > 0 && wave >= NW;              // wave-uniform
+  const int pw = LW ? (loader ? wave - NW : 0) : wave;   // piece-owner index of this wave
   const int wm = wave / CFG::WAVES_N, wn = wave % CFG::WAVES_N;
 
   const int ntn = (p.N + BN - 1) / BN;
@@ -79,7 +91,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES) void gemm_pipe_kernel
   bool a_ok[AP];
 #pragma unroll
   for (int i = 0; i < AP; ++i) {
-    const int m = m0 + (wave + i * NW) * 8 + sub;
+    const int m = m0 + (pw + i * PW) * 8 + sub;
     a_ok[i] = m < p.M;
     const int mm = a_ok[i] ? m : 0;
     if (CONV) {
@@ -97,22 +109,22 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES) void gemm_pipe_kernel
   }
 #pragma unroll
   for (int i = 0; i < WP; ++i) {
-    const int n = n0 + w_row_of_lds_row<TN>((wave + i * NW) * 8 + sub, p.geglu);   // epilogue-friendly channel order
+    const int n = n0 + w_row_of_lds_row<TN>((pw + i * PW) * 8 + sub, p.geglu);   // epilogue-friendly channel order
     w_off[i] = (n < p.N) ? (unsigned)(((size_t)n * p.K + cg * 8) * 2) : OOB;
   }
   int mine = 0;   // LDS-DMA instructions this wave issues per K-tile (the last waves may own one piece fewer)
 #pragma unroll
-  for (int i = 0; i < AP; ++i) mine += (wave + i * NW < CFG::A_TOTAL) ? 1 : 0;
+  for (int i = 0; i < AP; ++i) mine += (pw + i * PW < CFG::A_TOTAL) ? 1 : 0;
 #pragma unroll
-  for (int i = 0; i < WP; ++i) mine += (wave + i * NW < CFG::W_TOTAL) ? 1 : 0;
+  for (int i = 0; i < WP; ++i) mine += (pw + i * PW < CFG::W_TOTAL) ? 1 : 0;
 
   int gtap = 0, gcch = t0 * BK + cg * 8;   // conv: running (tap, channel) of this lane's chunk
   if (CONV) conv_k_init(p.kb64, t0, cg * 8, p.Cin, gtap, gcch);
   int kiss = t0 * BK;   // K offset of the next tile to stage
 
   auto issue_tile = [&](const int stage) {
-    unsigned char* a = As + stage * STAGE_A + wave * 1024;
-    unsigned char* w = Ws + stage * STAGE_W + wave * 1024;
+    unsigned char* a = As + stage * STAGE_A + pw * 1024;
+    unsigned char* w = Ws + stage * STAGE_W + pw * 1024;
     if (CONV) {
       const int ky = gtap / 3, kx = gtap - ky * 3;
       const int Hin = p.Hs << p.up, Win = p.Ws << p.up;
@@ -122,17 +134,17 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES) void gemm_pipe_kernel
         const int ix = ox[i] * p.stride + kx - p.pad;
         const bool ok = a_ok[i] && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
         const unsigned off = a_off[i] + (unsigned)(((iy >> p.up) * p.Ws + (ix >> p.up)) * p.lda + gcch) * 2u;
-        if (CFG::A_TOTAL % NW == 0 || wave + i * NW < CFG::A_TOTAL) dma(a_rsrc, a + i * (NW * 1024), ok ? off : OOB, 0);
+        if (CFG::A_TOTAL % PW == 0 || pw + i * PW < CFG::A_TOTAL) dma(a_rsrc, a + i * (PW * 1024), ok ? off : OOB, 0);
       }
       conv_k_next(p.kb64, p.Cin, gtap, gcch);
     } else {
 #pragma unroll
       for (int i = 0; i < AP; ++i)
-        if (CFG::A_TOTAL % NW == 0 || wave + i * NW < CFG::A_TOTAL) dma(a_rsrc, a + i * (NW * 1024), a_off[i], kiss * 2);
+        if (CFG::A_TOTAL % PW == 0 || pw + i * PW < CFG::A_TOTAL) dma(a_rsrc, a + i * (PW * 1024), a_off[i], kiss * 2);
     }
 #pragma unroll
     for (int i = 0; i < WP; ++i)
-      if (CFG::W_TOTAL % NW == 0 || wave + i * NW < CFG::W_TOTAL) dma(w_rsrc, w + i * (NW * 1024), w_off[i], kiss * 2);
+      if (CFG::W_TOTAL % PW == 0 || pw + i * PW < CFG::W_TOTAL) dma(w_rsrc, w + i * (PW * 1024), w_off[i], kiss * 2);
     kiss += BK;
   };
   // this wave's pieces of the newest staged tile may stay in flight, everything older has landed
@@ -143,6 +155,46 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES) void gemm_pipe_kernel
     else wait_vmcnt_imm<(PMAX > 2 ? PMAX - 2 : 0)>();
   };
 
+  constexpr bool STREAM = (TM + TN) > 10;   // two full fragment sets would not fit next to the accumulators
+  if (LW > 0 && loader) {
+    // ---- loader waves: the K loop's DMA side, barrier for barrier what the compute waves below execute ----
+    if constexpr (!STREAM) {
+      constexpr int AHEAD = ST - 1;
+      issue_tile(0);
+      if (AHEAD == 2 && t0 + 1 < t1) {
+        issue_tile(1);
+        wait_all_but_newest();
+      } else {
+        wait_vmcnt_imm<0>();
+      }
+      SD_PIPE_BARRIER();
+      int stage = 0;
+      for (int t = t0; t < t1; ++t) {
+        const int s1 = stage == ST - 1 ? 0 : stage + 1;
+        const int s_new = ST == 3 ? (stage == 0 ? 2 : stage - 1) : s1;
+        if (t + AHEAD < t1) issue_tile(s_new);
+        if (t + 1 < t1) {
+          if (AHEAD == 2 && t + 2 < t1) wait_all_but_newest();
+          else wait_vmcnt_imm<0>();
+          SD_PIPE_BARRIER();
+        }
+        stage = s1;
+      }
+    } else {
+      issue_tile(0);
+      wait_vmcnt_imm<0>();
+      SD_PIPE_BARRIER();
+      for (int t = t0; t < t1; ++t) {
+        if (t + 1 < t1) {
+          issue_tile(((t - t0) & 1) ^ 1);
+          wait_vmcnt_imm<0>();
+          SD_PIPE_BARRIER();
+        }
+      }
+    }
+    return;
+  }
+
   f32x4 acc[TN][TM];
 #pragma unroll
   for (int i = 0; i < TN; ++i)
@@ -152,7 +204,6 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES) void gemm_pipe_kernel
   const int frow = lane & 15, fkc = lane >> 4, rsw = frow & 7;
   const int a_row = (wm * (TM * 16) + frow) * 128, w_row = (wn * (TN * 16) + frow) * 128;
   const int c0 = ((0 * 4 + fkc) ^ rsw) << 4, c1 = ((1 * 4 + fkc) ^ rsw) << 4;
-  constexpr bool STREAM = (TM + TN) > 10;   // two full fragment sets would not fit next to the accumulators
 
   if constexpr (!STREAM) {
   // ---- fragments: two register sets (k-step 0 / 1 of a K-tile) ----
@@ -178,12 +229,14 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES) void gemm_pipe_kernel
   // insertion sees them and therefore emits no conservative lgkmcnt(0) in front of the MFMA batches (checked in the ISA:
   // barrier, 9 ds_read, 20 MFMA, lgkmcnt(0), 7 DMA, 9 ds_read, 20 MFMA, waits, barrier).
   constexpr int AHEAD = ST - 1;
-  issue_tile(0);
-  if (AHEAD == 2 && t0 + 1 < t1) {
-    issue_tile(1);
-    wait_all_but_newest();
-  } else {
-    wait_vmcnt_imm<0>();
+  if constexpr (LW == 0) {
+    issue_tile(0);
+    if (AHEAD == 2 && t0 + 1 < t1) {
+      issue_tile(1);
+      wait_all_but_newest();
+    } else {
+      wait_vmcnt_imm<0>();
+    }
   }
   SD_PIPE_BARRIER();
   read_frag(0, 0);
@@ -193,15 +246,19 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES) void gemm_pipe_kernel
     const int s_new = ST == 3 ? (stage == 0 ? 2 : stage - 1) : s1;   // stage the tile t+AHEAD goes to
     __builtin_amdgcn_s_waitcnt(0xC07F);        // k-step-0 fragments of tile t (issued under the previous MFMA batch)
     // re-staged stage: last read as tile t-1 (ST = 3) / t-1 (ST = 2), retired before the mid barrier of iteration t-1
-    if (t + AHEAD < t1) issue_tile(s_new);
+    if constexpr (LW == 0) {
+      if (t + AHEAD < t1) issue_tile(s_new);
+    }
     read_frag(1, stage);
     __builtin_amdgcn_sched_barrier(0);
     mma(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(0xC07F);        // k-step-1 fragments (issued TM*TN MFMAs ago): every read of tile t retired
     if (t + 1 < t1) {
-      if (AHEAD == 2 && t + 2 < t1) wait_all_but_newest();   // own pieces of tile t+1 landed, t+2 may stay in flight
-      else wait_vmcnt_imm<0>();
+      if constexpr (LW == 0) {
+        if (AHEAD == 2 && t + 2 < t1) wait_all_but_newest();   // own pieces of tile t+1 landed, t+2 may stay in flight
+        else wait_vmcnt_imm<0>();
+      }
       SD_PIPE_BARRIER();                       // publishes tile t+1; every wave is done reading tile t
       read_frag(0, s1);
     }
@@ -232,8 +289,10 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES) void gemm_pipe_kernel
     qf[slot] = *reinterpret_cast<const bf16x8*>(b + s * 16 * 128);
   };
 
-  issue_tile(0);
-  wait_vmcnt_imm<0>();
+  if constexpr (LW == 0) {
+    issue_tile(0);
+    wait_vmcnt_imm<0>();
+  }
   SD_PIPE_BARRIER();
   read_hold(0, 0);
 #pragma unroll
@@ -241,13 +300,15 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES) void gemm_pipe_kernel
   for (int t = t0; t < t1; ++t) {
     const int cur = (t - t0) & 1, nxt = cur ^ 1;
     const bool more = t + 1 < t1;
-    if (more) issue_tile(nxt);   // stage of tile t-1: every wave passed the roll-over barrier of iteration t-1
+    if constexpr (LW == 0) {
+      if (more) issue_tile(nxt);   // stage of tile t-1: every wave passed the roll-over barrier of iteration t-1
+    }
 #pragma unroll
     for (int j = 0; j < STEPS; ++j) {
       const int ks = j / SN, s = j % SN;
       if (j == 0) read_hold(1, cur);
       if (j == STEPS - Q && more) {
-        wait_vmcnt_imm<0>();                    // own pieces of tile t+1 (issued STEPS - Q steps ago)
+        if constexpr (LW == 0) wait_vmcnt_imm<0>();   // own pieces of tile t+1 (issued STEPS - Q steps ago)
         __builtin_amdgcn_s_waitcnt(0xC07F);     // every read of tile t retired
         SD_PIPE_BARRIER();
         read_hold(0, nxt);
@@ -285,8 +346,36 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES) void gemm_pipe_kernel
   else gemm_epilogue<TM, TN>(p, acc, m_w, n_w, lane);
 }
 
+// loader waves (template LW): MI355X_SD_GEMM_LOADERS=0 | 4 (eight-wave tiles only; the four-wave 128x128 tile keeps LW = 0)
+static int gemm_loaders() {
+  static const int v = [] {
+    const char* e = getenv("MI355X_SD_GEMM_LOADERS");
+    return e ? atoi(e) : GEMM_LOADERS_DEFAULT;
+  }();
+  return v;
+}
+
+template <bool CONV, class CFG, bool LN, int LW>
+static int launch_pipe_lw(const GemmArgs& a, hipStream_t stream) {
+  static const bool attr_ok = [] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<CONV, CFG, LN, LW>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES) == hipSuccess;
+  }();
+  if (!attr_ok) return SD_ERR_HIP;
+  const int ntm = (a.M + CFG::BM - 1) / CFG::BM, ntn = (a.N + CFG::BN - 1) / CFG::BN;
+  const int ny = a.splitk > 1 ? a.splitk : 1;
+  hipLaunchKernelGGL((gemm_pipe_kernel<CONV, CFG, LN, LW>), dim3(ntm * ntn, ny), dim3(CFG::THREADS + LW * 64), CFG::LDS_BYTES, stream, a);
+  if (a.splitk > 1) launch_splitk_reduce(a, stream);
+  return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+}
+
 template <bool CONV, class CFG, bool LN>
 static int launch_pipe(const GemmArgs& a, hipStream_t stream) {
+  // only the 256x160 three-stage tile leaves room for 12 waves per CU (166 VGPRs <= the 168 of three waves per SIMD); the larger
+  // register tiles (196-246 VGPRs) would spill into their K loops
+  if constexpr (CFG::NW == 8 && !LN && CFG::BN == 160 && CFG::STAGES == 3) {
+    if (gemm_loaders() == 4) return launch_pipe_lw<CONV, CFG, LN, 4>(a, stream);
+  }
   static const bool attr_ok = [] {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<CONV, CFG, LN>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES) == hipSuccess;
