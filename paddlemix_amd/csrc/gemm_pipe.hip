@@ -48,7 +48,21 @@ __device__ __forceinline__ void dma(__amdgpu_buffer_rsrc_t rsrc, unsigned char* 
 // moves a K-tile's pieces in about the time the two compute waves of that SIMD need for its MFMAs. Same LDS image, same barriers
 // (loaders take part in them), same hazards argument: the loader issues tile t+AHEAD after the barrier at which every compute wave
 // retired its reads of the stage it overwrites, and waits for its pieces of tile t+1 before the barrier that publishes them.
-template <bool CONV, class CFG, bool LN, int LW = 0>
+// SG (with LW > 0): the compute waves' fragment reads are INTERLEAVED with the MFMAs of the other fragment set
+// (sched_group_barrier: one ds_read_b128 per two MFMAs) instead of issued as a burst in front of them -- the read's issue slot
+// then sits in the shadow of a 16-cycle MFMA, and with the DMA gone from these waves a half-iteration is straight-line code.
+template <int NREAD, int NMFMA>
+__device__ __forceinline__ void sgb_reads_under_mfmas() {
+  constexpr int PER = NMFMA / NREAD;
+#pragma unroll
+  for (int i = 0; i < NREAD; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // 1 DS read
+    __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);   // PER MFMAs
+  }
+  if constexpr (NMFMA - PER * NREAD > 0) __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - PER * NREAD, 0);
+}
+
+template <bool CONV, class CFG, bool LN, int LW = 0, int SG = 0>
 __global__ __launch_bounds__(CFG::THREADS + LW * 64, (LW ? 3 : CFG::MIN_WAVES)) void gemm_pipe_kernel(const GemmArgs p) {
   constexpr int BM = CFG::BM, BN = CFG::BN, TM = CFG::TM, TN = CFG::TN, ST = CFG::STAGES, NW = CFG::NW;
   constexpr int PW = LW ? LW : NW;                       // waves that own LDS-DMA pieces
@@ -241,6 +255,31 @@ __global__ __launch_bounds__(CFG::THREADS + LW * 64, (LW ? 3 : CFG::MIN_WAVES)) 
   SD_PIPE_BARRIER();
   read_frag(0, 0);
   int stage = 0;
+  if constexpr (LW > 0 && SG) {
+    // compute waves with loader waves beside them: no VMEM, no conditionals inside a half-iteration -> reads interleaved
+    for (int t = t0; t < t1 - 1; ++t) {
+      const int s1 = stage == ST - 1 ? 0 : stage + 1;
+      __builtin_amdgcn_s_waitcnt(0xC07F);      // k-step-0 fragments of tile t
+      read_frag(1, stage);
+      mma(0);
+      sgb_reads_under_mfmas<TM + TN, TM * TN>();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0xC07F);      // k-step-1 fragments: every read of tile t retired
+      SD_PIPE_BARRIER();                       // the loaders published tile t+1
+      read_frag(0, s1);
+      mma(1);
+      sgb_reads_under_mfmas<TM + TN, TM * TN>();
+      __builtin_amdgcn_sched_barrier(0);
+      stage = s1;
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    read_frag(1, stage);
+    mma(0);
+    sgb_reads_under_mfmas<TM + TN, TM * TN>();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    mma(1);
+  } else
   for (int t = t0; t < t1; ++t) {
     const int s1 = stage == ST - 1 ? 0 : stage + 1;          // stage of tile t+1
     const int s_new = ST == 3 ? (stage == 0 ? 2 : stage - 1) : s1;   // stage the tile t+AHEAD goes to
@@ -346,7 +385,7 @@ __global__ __launch_bounds__(CFG::THREADS + LW * 64, (LW ? 3 : CFG::MIN_WAVES)) 
   else gemm_epilogue<TM, TN>(p, acc, m_w, n_w, lane);
 }
 
-// loader waves (template LW): MI355X_SD_GEMM_LOADERS=0 | 4 (eight-wave tiles only; the four-wave 128x128 tile keeps LW = 0)
+// loader waves (template LW): MI355X_SD_GEMM_LOADERS=0 | 4 | 5 (5 = 4 loaders + interleaved fragment reads, template SG)
 static int gemm_loaders() {
   static const int v = [] {
     const char* e = getenv("MI355X_SD_GEMM_LOADERS");
@@ -355,16 +394,16 @@ static int gemm_loaders() {
   return v;
 }
 
-template <bool CONV, class CFG, bool LN, int LW>
+template <bool CONV, class CFG, bool LN, int LW, int SG = 0>
 static int launch_pipe_lw(const GemmArgs& a, hipStream_t stream) {
   static const bool attr_ok = [] {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<CONV, CFG, LN, LW>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<CONV, CFG, LN, LW, SG>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES) == hipSuccess;
   }();
   if (!attr_ok) return SD_ERR_HIP;
   const int ntm = (a.M + CFG::BM - 1) / CFG::BM, ntn = (a.N + CFG::BN - 1) / CFG::BN;
   const int ny = a.splitk > 1 ? a.splitk : 1;
-  hipLaunchKernelGGL((gemm_pipe_kernel<CONV, CFG, LN, LW>), dim3(ntm * ntn, ny), dim3(CFG::THREADS + LW * 64), CFG::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL((gemm_pipe_kernel<CONV, CFG, LN, LW, SG>), dim3(ntm * ntn, ny), dim3(CFG::THREADS + LW * 64), CFG::LDS_BYTES, stream, a);
   if (a.splitk > 1) launch_splitk_reduce(a, stream);
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
@@ -375,6 +414,7 @@ static int launch_pipe(const GemmArgs& a, hipStream_t stream) {
   // register tiles (196-246 VGPRs) would spill into their K loops
   if constexpr (CFG::NW == 8 && !LN && CFG::BN == 160 && CFG::STAGES == 3) {
     if (gemm_loaders() == 4) return launch_pipe_lw<CONV, CFG, LN, 4>(a, stream);
+    if (gemm_loaders() == 5) return launch_pipe_lw<CONV, CFG, LN, 4, 1>(a, stream);   // + interleaved fragment reads
   }
   static const bool attr_ok = [] {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<CONV, CFG, LN>),
