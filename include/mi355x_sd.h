@@ -69,8 +69,9 @@ int mi355x_sd_set_workspace(void* ptr, size_t bytes);
 #define MI355X_SD_DTYPE_F16 2
 int mi355x_sd_unet_create(const char* config_json, void** handle);
 int mi355x_sd_unet_destroy(void* handle);
-/* options: "residual_f32" = 1 (before plan) keeps the residual stream in fp32 (MI355X_SD_R_F32); "fold_softmax_scale" = 1 (before the
- * weights are packed) folds head_dim^-0.5 * log2(e) into the self-attention to_q weights and runs those attentions as MI355X_SD_SDPA_LOG2 */
+/* options: "residual_f32" = 1 (before plan) keeps the residual stream in fp32 (MI355X_SD_R_F32); "fold_softmax_scale" = 0 | 1 (default 1;
+ * before the weights are packed): head_dim^-0.5 * log2(e) is folded into the self-attention to_q weights (head_dim 64) and those attentions
+ * run as MI355X_SD_SDPA_LOG2 */
 int mi355x_sd_unet_set_option(void* handle, const char* key, int value);
 int mi355x_sd_unet_num_params(void* handle);
 int mi355x_sd_unet_param_info(void* handle, int index, const char** name, int64_t* shape4, int* ndim);

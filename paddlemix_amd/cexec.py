@@ -25,15 +25,14 @@ _DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 class UNetHandle:
     """owns the C handle; usable without a GPU up to `pack()` (host logic), which the CPU tests exercise"""
 
-    def __init__(self, config: Mapping, residual_dtype: Optional[str] = None, fold_softmax_scale: bool = False):
+    def __init__(self, config: Mapping, residual_dtype: Optional[str] = None, fold_softmax_scale: bool = True):
         self.lib = _lib.load()
         self.config_dict = {k: (list(v) if isinstance(v, tuple) else v) for k, v in config.items() if not k.startswith("_")}
         self.h = ctypes.c_void_p()
         _lib.check(self.lib.mi355x_sd_unet_create(json.dumps(self.config_dict).encode(), ctypes.byref(self.h)))
         if residual_dtype == "fp32":
             _lib.check(self.lib.mi355x_sd_unet_set_option(self.h, b"residual_f32", 1))
-        if fold_softmax_scale:
-            _lib.check(self.lib.mi355x_sd_unet_set_option(self.h, b"fold_softmax_scale", 1))
+        _lib.check(self.lib.mi355x_sd_unet_set_option(self.h, b"fold_softmax_scale", 1 if fold_softmax_scale else 0))
 
     def __del__(self):
         try:
@@ -101,7 +100,7 @@ class CUNet2DConditionModel:
     i.e. by the caller of the C ABI."""
 
     def __init__(self, config: Mapping, params: Mapping[str, torch.Tensor], device="cuda", use_graph: bool = True,
-                 residual_dtype: Optional[str] = None, fold_softmax_scale: bool = False):
+                 residual_dtype: Optional[str] = None, fold_softmax_scale: bool = True):
         if not torch.cuda.is_available():
             raise _lib.MI355XError("CUNet2DConditionModel(mi355x) needs a GPU; there is no CPU fallback")
         self.device = torch.device(device)

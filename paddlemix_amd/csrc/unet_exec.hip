@@ -356,7 +356,7 @@ struct Exec {
   std::map<std::string, HostT> params;            // expected parameters (reference names, Paddle layouts)
   std::vector<std::string> order;                 // construction order
   bool resid_f32 = false;
-  bool fold_scale = false;                        // head_dim^-0.5 * log2(e) folded into the self-attention to_q weights (head_dim 64)
+  bool fold_scale = true;                         // head_dim^-0.5 * log2(e) folded into the self-attention to_q weights (head_dim 64)
   std::set<std::string> log2_blocks;
   // packed weights
   std::map<std::string, Packed> w;

@@ -296,11 +296,11 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
         # state, every skip / concat slot -- is stored in fp32; 16-bit values exist only as MFMA operands (the outputs of
         # GroupNorm / LayerNorm / GEGLU / attention, which feed exactly one contraction each). Each branch then rounds once
         # instead of the stream re-rounding after every one of its ~50-200 sequential adds.
-        # fold_softmax_scale (MI355X_SD_FOLD_SCALE=1): head_dim^-0.5 * log2(e) is multiplied into the self-attention to_q weights
+        # fold_softmax_scale (default on; MI355X_SD_FOLD_SCALE=0 turns it off): head_dim^-0.5 * log2(e) is multiplied into the self-attention to_q weights
         # at load (fp32, before the one rounding to 16 bits), so q.k IS the base-2 exponent of the softmax and the attention
         # kernel runs its MI355X_SD_SDPA_LOG2 form (no multiply-add per score). Same function, slightly different rounding of
         # the to_q weights (they are rounded after the scaling instead of before); self-attention with head_dim 64 only.
-        self.fold_scale = (os.environ.get("MI355X_SD_FOLD_SCALE", "0") == "1") if fold_softmax_scale is None else bool(fold_softmax_scale)
+        self.fold_scale = (os.environ.get("MI355X_SD_FOLD_SCALE", "1") == "1") if fold_softmax_scale is None else bool(fold_softmax_scale)
         rd = os.environ.get("MI355X_SD_RESID", "") if residual_dtype is None else residual_dtype
         if rd not in ("", None, "fp32", "16"):
             raise ValueError(f"residual_dtype must be None | '16' | 'fp32', got {rd!r}")
