@@ -40,7 +40,6 @@ def child(elem: str, quick: bool) -> dict:
 
     ed = _lib.elem_dtype()
     assert (elem == "fp16") == (ed == torch.float16)
-    torch.set_num_threads(os.cpu_count() or 8)
     rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm()).item()  # noqa: E731
     cuda = lambda x: None if x is None else ({k: v.cuda() for k, v in x.items()} if isinstance(x, dict) else x.cuda())  # noqa: E731
     out = {"elem": elem, "threads": torch.get_num_threads(), "forward": {}, "loop": {}}
@@ -55,6 +54,8 @@ def child(elem: str, quick: bool) -> dict:
         cases += [("sd15_1x4x64x64", SD15, 1, 64, 64, 77, False), ("sdxl_1x4x128x128", SDXL, 1, 128, 128, 77, False)]
     if os.environ.get("PARITY_SKIP_SD15"):
         cases = [c for c in cases if not c[0].startswith("sd15")]
+    if os.environ.get("PARITY_ONLY_SDXL_LOOP"):
+        cases = []
     for name, cfg, B, H, W, L, small in cases:
         P = params(cfg)
         sample, enc, added = _inputs(cfg, B, H, W, L)
@@ -80,19 +81,23 @@ def child(elem: str, quick: bool) -> dict:
         print(elem, name, r, flush=True)
 
     # ---- 30 Euler steps (teacher-forced per-step epsilon error + free-running end latents), float64 oracle loop ----
-    loops = [("mini_xl_2x4x32x32", MINI_XL, 2, 32, 32, 77)]
-    if os.environ.get("PARITY_SDXL_LOOP"):   # float64 oracle of the full SDXL parameter set: ~minutes per step on the CPU
-        loops.append(("sdxl_arch_1x4x32x32", SDXL, 1, 32, 32, 77))
-    for name, cfg, B, H, W, L in loops:
+    # (mini: float64 oracle loop; the full SDXL parameter set at 32x32 latents: the fp32 oracle -- a float64 forward of 2.6 B
+    # parameters takes minutes per step on the CPU, and the fp32 oracle sits 1e-6 from the float64 one, see oracle_f32_vs_f64)
+    loops = [("mini_xl_2x4x32x32", MINI_XL, 2, 32, 32, 77, torch.float64)]
+    if os.environ.get("PARITY_SDXL_LOOP") or os.environ.get("PARITY_ONLY_SDXL_LOOP"):
+        loops.append(("sdxl_arch_1x4x32x32", SDXL, 1, 32, 32, 77, torch.float32))
+    if os.environ.get("PARITY_ONLY_SDXL_LOOP"):
+        loops = loops[1:]
+    for name, cfg, B, H, W, L, odt in loops:
         P = params(cfg)
-        P64 = {k: v.double() for k, v in P.items()}
+        P64 = {k: v.to(odt) for k, v in P.items()}
         sch = S.EulerRef(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", timestep_spacing="leading",
                          steps_offset=1)
         sch.set_timesteps(30)
         sig = sch.sigmas.astype(np.float64)
         ts = sch.timesteps
         sample, enc, added = _inputs(cfg, B, H, W, L)
-        added64 = None if added is None else {k: v.double() for k, v in added.items()}
+        added64 = None if added is None else {k: v.to(odt) for k, v in added.items()}
         r = {}
         for rd in ("16", "fp32"):
             model = UNet2DConditionModel(cfg, P, residual_dtype=rd)
@@ -102,7 +107,7 @@ def child(elem: str, quick: bool) -> dict:
             for i, t in enumerate(ts):
                 s = sig[i]
                 xin = x_ref / (s * s + 1.0) ** 0.5
-                eps_ref = U.unet_forward(P64, cfg, xin, int(t), enc.double(), added_cond_kwargs=added64)
+                eps_ref = U.unet_forward(P64, cfg, xin.to(odt), int(t), enc.to(odt), added_cond_kwargs=added64).double()
                 # teacher forced: the device sees the oracle's latents of this step
                 e_tf = model(cuda(xin.float()), int(t), cuda(enc), added_cond_kwargs=cuda(added), return_dict=False)[0]
                 eps_err.append(rel(e_tf.cpu(), eps_ref))
@@ -111,6 +116,7 @@ def child(elem: str, quick: bool) -> dict:
                 e_fr = model(cuda(xin_d.float()), int(t), cuda(enc), added_cond_kwargs=cuda(added), return_dict=False)[0]
                 x_ref = x_ref + eps_ref * (sig[i + 1] - s)
                 x_dev = x_dev + e_fr.cpu().double() * (sig[i + 1] - s)
+            r["oracle_dtype"] = str(odt)
             r["resid_" + rd] = {"eps_rel_per_step_max": max(eps_err), "eps_rel_per_step_mean": sum(eps_err) / len(eps_err),
                                 "eps_rel_first_last": [eps_err[0], eps_err[-1]], "end_latents_rel": rel(x_dev, x_ref)}
             del model
