@@ -246,6 +246,20 @@ int mi355x_sd_layernorm_ex(const void* x, int rows, int C, int ldx, const float*
 /* y (16-bit rows) = x (fp32 rows): operand copies of the fp32 residual stream (inputs of Downsample2D / Upsample2D convs). */
 int mi355x_sd_cast_rows(const float* x, int ldx, void* y, int ldy, int64_t rows, int C, void* stream);
 
+/* ---- the reference's fused custom ops, with THEIR signatures (seam B4; paddlemix/triton_ops/triton_ops.py) ----
+ * fused_adaLN_scale_residual(x, mha_out, gate_msa, scale_mlp, shift_mlp, weight, bias, epsilon) -> (resi_out, adaLN_out)
+ * (triton_ops.py:758-920; unfused definition :842-847): resi_out = mha_out * gate[b] + x, adaLN_out = layer_norm(resi_out, weight,
+ * bias, eps) * (1 + scale[b]) + shift[b], b = row / rows_per_batch. x, mha_out, resi_out, adaLN_out: 16-bit rows [rows][ld >= C];
+ * gate / scale / shift: fp32 [rows / rows_per_batch][ld_mod >= C]; weight / bias fp32 [C] or NULL. C % 8 == 0, C <= 4096. */
+int mi355x_sd_fused_adaln_scale_residual(const void* x, int ldx, const void* mha_out, int ld_mha, const float* gate_msa,
+                                         const float* scale_mlp, const float* shift_mlp, int ld_mod, int rows_per_batch,
+                                         const float* weight, const float* bias, float epsilon, int rows, int C,
+                                         void* resi_out, int ld_resi, void* adaln_out, int ld_out, void* stream);
+/* split_concat(x [B,S1,3C], y [B,S2,3C]) -> q, k, v, each [B, S1+S2, C]: chunk i of x followed by chunk i of y along the sequence
+ * (triton_ops.py:1692-1752); dense 16-bit tensors, C % 8 == 0. */
+int mi355x_sd_split_concat(const void* x, const void* y, void* q_out, void* k_out, void* v_out, int B, int S1, int S2, int C,
+                           void* stream);
+
 /* get_timestep_embedding (PPD/models/embeddings.py:26-64) in fp32, written as bf16 to
  * out[(i/group)*ldo + (i%group)*dim + j] for i < n, timestep t[i % t_count] (device fp32). */
 int mi355x_sd_timestep_embedding(const float* t, int t_count, int n, int dim, int group, int flip_sin_to_cos,

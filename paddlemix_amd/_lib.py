@@ -76,6 +76,10 @@ SIGNATURES = {
     "mi355x_sd_conv_in3x3_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                         c_int, c_int, c_int, c_void_p]),
     "mi355x_sd_add_nchw_ex": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int64, c_int, c_void_p]),
+    "mi355x_sd_fused_adaln_scale_residual": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                                     c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
+                                                     c_void_p]),
+    "mi355x_sd_split_concat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "mi355x_sd_timestep_embedding": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float,
                                              c_void_p, c_int, c_void_p]),
     "mi355x_sd_silu": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),

@@ -356,6 +356,25 @@ int mi355x_sd_layernorm_ex(const void* x, int rows, int C, int ldx, const float*
                 "mi355x_sd_layernorm_ex");
 }
 
+int mi355x_sd_fused_adaln_scale_residual(const void* x, int ldx, const void* mha_out, int ld_mha, const float* gate_msa,
+                                         const float* scale_mlp, const float* shift_mlp, int ld_mod, int rows_per_batch,
+                                         const float* weight, const float* bias, float epsilon, int rows, int C, void* resi_out,
+                                         int ld_resi, void* adaln_out, int ld_out, void* stream) {
+  if (!x || !mha_out || !gate_msa || !scale_mlp || !shift_mlp || !resi_out || !adaln_out)
+    return fail(SD_ERR_INVALID, "mi355x_sd_fused_adaln_scale_residual: null pointer");
+  return finish(launch_fused_adaln_scale_residual((const bf16*)x, ldx, (const bf16*)mha_out, ld_mha, gate_msa, scale_mlp, shift_mlp,
+                                                  ld_mod, rows_per_batch, weight, bias, epsilon, rows, C, (bf16*)resi_out, ld_resi,
+                                                  (bf16*)adaln_out, ld_out, S(stream)),
+                "mi355x_sd_fused_adaln_scale_residual");
+}
+
+int mi355x_sd_split_concat(const void* x, const void* y, void* q_out, void* k_out, void* v_out, int B, int S1, int S2, int C,
+                           void* stream) {
+  if (!x || !y || !q_out || !k_out || !v_out) return fail(SD_ERR_INVALID, "mi355x_sd_split_concat: null pointer");
+  return finish(launch_split_concat((const bf16*)x, (const bf16*)y, (bf16*)q_out, (bf16*)k_out, (bf16*)v_out, B, S1, S2, C, S(stream)),
+                "mi355x_sd_split_concat");
+}
+
 int mi355x_sd_timestep_embedding(const float* t, int t_count, int n, int dim, int group, int flip_sin_to_cos,
                                  float freq_shift, float scale, float max_period, void* out, int ldo, void* stream) {
   if (!t || !out) return fail(SD_ERR_INVALID, "mi355x_sd_timestep_embedding: null pointer");

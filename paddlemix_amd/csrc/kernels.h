@@ -94,6 +94,11 @@ int launch_adaln_f8(const bf16* x, int rows, int C, int ldx, const float* scale,
                     int rows_per_batch, float eps, unsigned char* y8, int ldy, float* yscale, float* yl2, hipStream_t stream);
 int launch_quantize_rows(const bf16* x, long rows, int C, int ldx, int x_rpb, long x_bstride, unsigned char* y8, int ldy,
                          float* yscale, hipStream_t stream);
+// the reference's fused custom ops with their own signatures (fused_ops.hip; triton_ops.py:758-920, 1692-1752)
+int launch_fused_adaln_scale_residual(const bf16* x, int ldx, const bf16* mha, int ldm, const float* gate, const float* scale,
+                                      const float* shift, int ld_mod, int rows_per_batch, const float* weight, const float* bias,
+                                      float eps, int rows, int C, bf16* resi, int ldr, bf16* out, int ldo, hipStream_t stream);
+int launch_split_concat(const bf16* x, const bf16* y, bf16* o0, bf16* o1, bf16* o2, int B, int S1, int S2, int C, hipStream_t stream);
 int launch_patchify(const float* x_nchw, int B, int C, int H, int W, int p, bf16* out, int ldo, hipStream_t stream);
 int launch_unpatchify(const bf16* x, int ldx, int B, int C, int H, int W, int p, float* out_nchw, hipStream_t stream);
 int launch_row_stats(const bf16* x, int rows, int C, int ldx, float eps, float* stats, hipStream_t stream);

@@ -510,3 +510,48 @@ def linear_f8(a8: Tensor, a_scale: Tensor, w8: Tensor, w_scale: Tensor, bias: Op
                                   _p(residual), _rows(residual, "residual") if residual is not None else 0,
                                   GELU_TANH if gelu_tanh else 0, _stream()))
     return out
+
+
+def fused_adaLN_scale_residual(x: Tensor, mha_out: Tensor, gate_msa: Tensor, scale_mlp: Tensor, shift_mlp: Tensor,
+                               weight: Optional[Tensor] = None, bias: Optional[Tensor] = None, epsilon: float = 1e-05):
+    """The reference's fused op with its own signature and shape checks (paddlemix/triton_ops/triton_ops.py:758-920):
+    ``resi_out = mha_out * gate_msa[:, None] + x``; ``adaLN_out = layer_norm(resi_out, weight, bias, epsilon) * (1 + scale_mlp[:, None])
+    + shift_mlp[:, None]`` -> ``(resi_out, adaLN_out)``. x / mha_out [B, S, C] in the build's 16-bit type; gate / scale / shift [B, C]."""
+    assert x.shape == mha_out.shape, "x and mha_out should have same shape"
+    assert gate_msa.shape == scale_mlp.shape == shift_mlp.shape, "gate_msa, scale_mlp and shift_mlp should have same shape"
+    assert x.dim() == 3, "x should be 3-dim [batch_size, seq_size, feature_dim]"
+    B, S, C = x.shape
+    if weight is not None:
+        assert weight.dim() == 1 and weight.shape[-1] == C, "x and weight should have same shape[-1] == feature_dim"
+    if bias is not None:
+        assert bias.dim() == 1 and bias.shape[-1] == C, "x and bias should have same shape[-1] == feature_dim"
+    assert scale_mlp.dim() == 2 and shift_mlp.dim() == 2, "scale and shift should be 2-dim [batch_size, feature_dim]"
+    assert scale_mlp.shape[0] == B and scale_mlp.shape[1] == C, "x, scale and shift should have same batch_size / feature_dim"
+    ed = _lib.elem_dtype()
+    if x.dtype != ed or mha_out.dtype != ed or not x.is_cuda:
+        raise ValueError(f"x / mha_out: expected {ed} cuda tensors")
+    xx, mm = x.contiguous(), mha_out.contiguous()
+    f32 = lambda t: None if t is None else t.to(device=x.device, dtype=torch.float32).contiguous()  # noqa: E731
+    g, sc, sh, w, b = f32(gate_msa), f32(scale_mlp), f32(shift_mlp), f32(weight), f32(bias)
+    resi, out = torch.empty_like(xx), torch.empty_like(xx)
+    check(_lib.load().mi355x_sd_fused_adaln_scale_residual(xx.data_ptr(), C, mm.data_ptr(), C, g.data_ptr(), sc.data_ptr(), sh.data_ptr(),
+                                                           C, S, _p(w), _p(b), float(epsilon), B * S, C, resi.data_ptr(), C,
+                                                           out.data_ptr(), C, _stream()))
+    return resi, out
+
+
+def split_concat(x: Tensor, y: Tensor):
+    """The reference's ``split_concat(x [B,S1,3C], y [B,S2,3C]) -> (q, k, v)`` each [B, S1+S2, C] (triton_ops.py:1692-1752): what
+    JointAttnProcessor does with the fused image / context QKV projections before attention (simplified_sd3.py:96-113)."""
+    assert x.dim() == 3 and y.dim() == 3
+    assert x.shape[0] == y.shape[0] and x.shape[2] == y.shape[2]
+    B, S1, H3 = x.shape
+    S2, C = y.shape[1], H3 // 3
+    ed = _lib.elem_dtype()
+    if x.dtype != ed or y.dtype != ed or not x.is_cuda or H3 % 3:
+        raise ValueError(f"x / y: expected {ed} cuda tensors [B, S, 3C]")
+    xx, yy = x.contiguous(), y.contiguous()
+    outs = [torch.empty((B, S1 + S2, C), device=x.device, dtype=ed) for _ in range(3)]
+    check(_lib.load().mi355x_sd_split_concat(xx.data_ptr(), yy.data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(),
+                                             B, S1, S2, C, _stream()))
+    return tuple(outs)

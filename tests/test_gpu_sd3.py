@@ -260,3 +260,42 @@ def test_mini_sd3_w8a8_vs_fake_quant_oracle():
     assert r < 3e-2, r
     eager, _ = _run(cfg, 2, 32, 32, 154, P, use_graph=False, weight_dtype="fp8", act_dtype="fp8")
     assert torch.equal(eager, out)
+
+
+@pytest.mark.parametrize("B,S,C,affine", [(2, 300, 1536, True), (1, 77, 64, False), (3, 1025, 1152, True), (2, 154, 4096, False)])
+def test_fused_adaln_scale_residual_reference_signature(B, S, C, affine):
+    """paddlemix.triton_ops.fused_adaLN_scale_residual with the reference's signature and TWO outputs (triton_ops.py:758-920),
+    against its own unfused definition (:842-847) -- the check the reference's docstring example performs."""
+    import torch.nn.functional as F
+    from paddlemix_amd import _lib, ops
+    ops.init(0)
+    ed = _lib.elem_dtype()
+    g = torch.Generator().manual_seed(B * S + C)
+    x, mha = (torch.randn(B, S, C, generator=g) * 2).to(ed), torch.randn(B, S, C, generator=g).to(ed)
+    gate, scale, shift = (torch.randn(B, C, generator=g) * 0.5 for _ in range(3))
+    w = (1 + 0.1 * torch.randn(C, generator=g)) if affine else None
+    b = (0.1 * torch.randn(C, generator=g)) if affine else None
+    resi, out = ops.fused_adaLN_scale_residual(x.cuda(), mha.cuda(), gate.cuda(), scale.cuda(), shift.cuda(),
+                                               None if w is None else w.cuda(), None if b is None else b.cuda(), 1e-5)
+    resi_ref = (mha.float() * gate[:, None] + x.float())
+    assert resi.shape == x.shape and out.shape == x.shape and resi.dtype == ed
+    assert torch.equal(resi.cpu(), resi_ref.to(ed))                          # one fp32 fma, one rounding
+    ln = F.layer_norm(resi_ref.to(ed).float(), (C,), w, b, 1e-5)             # the LayerNorm of the unfused op sees the 16-bit tensor
+    ref = ln * (1 + scale[:, None]) + shift[:, None]
+    err = ((out.float().cpu() - ref).norm() / ref.norm()).item()
+    assert err < 4e-3, err
+    with pytest.raises(AssertionError):
+        ops.fused_adaLN_scale_residual(x.cuda(), mha[:, :-1].cuda(), gate.cuda(), scale.cuda(), shift.cuda())
+
+
+@pytest.mark.parametrize("B,S1,S2,C", [(2, 1024, 154, 1536), (1, 5, 3, 64), (3, 4096, 77, 1152)])
+def test_split_concat_reference_signature(B, S1, S2, C):
+    """paddlemix.triton_ops.split_concat (triton_ops.py:1692-1752): q / k / v = concat(x.chunk(3)[i], y.chunk(3)[i], axis=1), exact."""
+    from paddlemix_amd import _lib, ops
+    ops.init(0)
+    ed = _lib.elem_dtype()
+    g = torch.Generator().manual_seed(S1 + S2 + C)
+    x, y = torch.randn(B, S1, 3 * C, generator=g).to(ed), torch.randn(B, S2, 3 * C, generator=g).to(ed)
+    q, k, v = ops.split_concat(x.cuda(), y.cuda())
+    for got, xc, yc in zip((q, k, v), x.chunk(3, -1), y.chunk(3, -1)):
+        assert torch.equal(got.cpu(), torch.cat([xc, yc], 1))
