@@ -51,6 +51,18 @@ __device__ __forceinline__ f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
 #endif
 }
 
+// fp32 += the dot product of two packed element pairs (v_dot2c_f32_bf16 / v_dot2c_f32_f16): the VALU form of a short
+// contraction for the few outputs that are not worth an MFMA tile (conv_out's 4 channels) -- no unpack / convert per element
+__device__ __forceinline__ float dot2_acc(uint32_t a, uint32_t b, float c) {
+#ifdef MI355X_SD_F16
+  typedef __attribute__((ext_vector_type(2))) _Float16 pair_t;
+  return __builtin_amdgcn_fdot2(__builtin_bit_cast(pair_t, a), __builtin_bit_cast(pair_t, b), c, false);
+#else
+  typedef __attribute__((ext_vector_type(2))) __bf16 pair_t;
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(pair_t, a), __builtin_bit_cast(pair_t, b), c, false);
+#endif
+}
+
 __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
 __device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }  // RNE; lowers to v_cvt_pk_bf16_f32
 

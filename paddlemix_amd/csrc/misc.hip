@@ -75,69 +75,143 @@ int launch_silu(const void* x, void* y, long n, int in_f32, int out_f32, hipStre
 
 // conv_in: x NCHW fp32 [B,Cin,H,W] (optionally multiplied by *in_scale: the scheduler's scale_model_input folded in),
 // rounded to bf16 like the reference's sample.cast(self.dtype); w packed [9*Cin][Cout] bf16, k = (ky*3+kx)*Cin + ci.
-// One thread = one pixel x 8 output channels.
-template <bool OUT_F32>
-__global__ void conv_in3x3_kernel(const float* __restrict__ x, const float* __restrict__ in_scale,
+// One thread = CI_PX horizontally adjacent pixels x 8 output channels: one weight chunk (load + 8 converts) feeds CI_PX x 8
+// fmas, the image row comes from blockIdx.y (no 64-bit index arithmetic). Per output the taps are accumulated in the order
+// (ky, kx, ci) with padding taps contributing exact zeros. (First version: one pixel per thread and four 64-bit divisions per
+// 16 output bytes -- ~1300 VALU instructions per chunk, 192 us for the SDXL bs-8 launch whose 84 MB need ~20 us of HBM.)
+constexpr int CI_PX = 4;
+// CIN > 0: Cin is a compile-time constant (4 = the SD latents): per kernel row the thread's CIN x (CI_PX + 2) input patch and
+// its 3 x CIN weight chunks are loaded in ONE batch and the (kx, ci) loop unrolls, so a thread waits out 3 L2 round trips
+// instead of 36 (the fully rolled loop was latency-bound at 127 us; fully unrolled it needs ~400 registers). CIN == 0: runtime
+// Cin, rolled loop.
+template <bool OUT_F32, int CIN>
+__global__ __launch_bounds__(256) void conv_in3x3_kernel(const float* __restrict__ x, const float* __restrict__ in_scale,
                                   const bf16* __restrict__ w, const float* __restrict__ bias, void* __restrict__ y,
                                   int B, int Cin, int H, int W, int Cout, int ldy) {
   const int cv = Cout >> 3;
-  const long total = (long)B * H * W * cv;
+  const int ngrp = (W + CI_PX - 1) / CI_PX;
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= ngrp * cv) return;
+  const int grp = id / cv, cc = id - grp * cv;
+  const int px0 = grp * CI_PX;
   const float xs = in_scale ? *in_scale : 1.0f;
-  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long)gridDim.x * blockDim.x) {
-    const long pix = id / cv;
-    const int cc = (int)(id - pix * cv);
-    const int px = (int)(pix % W);
-    const int py = (int)((pix / W) % H);
-    const int b = (int)(pix / ((long)W * H));
-    float acc[8];
+  for (int row = blockIdx.y; row < B * H; row += gridDim.y) {   // row = b * H + py
+  const int b = row / H, py = row - b * H;
+  float acc[CI_PX][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = bias ? bias[cc * 8 + j] : 0.f;
-    for (int ky = 0; ky < 3; ++ky) {
+  for (int j = 0; j < 8; ++j) {
+    const float bj = bias ? bias[cc * 8 + j] : 0.f;
+#pragma unroll
+    for (int p = 0; p < CI_PX; ++p) acc[p][j] = bj;
+  }
+  if constexpr (CIN > 0) {
+#pragma unroll 1
+    for (int ky = 0; ky < 3; ++ky) {   // rolled on purpose: one batch of loads (CIN x 6 inputs + 3 x CIN weight chunks) per kernel row
       const int iy = py + ky - 1;
       if ((unsigned)iy >= (unsigned)H) continue;
-      for (int kx = 0; kx < 3; ++kx) {
-        const int ix = px + kx - 1;
-        if ((unsigned)ix >= (unsigned)W) continue;
-        for (int ci = 0; ci < Cin; ++ci) {
-          const float xv = (float)(bf16)(x[(((size_t)b * Cin + ci) * H + iy) * W + ix] * xs);
-          const u32x4 raw = *reinterpret_cast<const u32x4*>(w + (size_t)((ky * 3 + kx) * Cin + ci) * Cout + cc * 8);
-          const bf16x8 wv = *reinterpret_cast<const bf16x8*>(&raw);
+      float xp[CIN][CI_PX + 2];
+      u32x4 wr[3][CIN];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(xv, (float)wv[j], acc[j]);
+      for (int ci = 0; ci < CIN; ++ci) {
+        const float* xr = x + (((size_t)b * CIN + ci) * H + iy) * W;
+#pragma unroll
+        for (int t = 0; t < CI_PX + 2; ++t) {
+          const int ix = px0 + t - 1;
+          float v = 0.f;
+          if ((unsigned)ix < (unsigned)W) v = xr[ix];
+          xp[ci][t] = v;
+        }
+      }
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci)
+          wr[kx][ci] = *reinterpret_cast<const u32x4*>(w + (size_t)((ky * 3 + kx) * CIN + ci) * Cout + cc * 8);
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+        for (int t = 0; t < CI_PX + 2; ++t) xp[ci][t] = (float)(bf16)(xp[ci][t] * xs);
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) {
+          const bf16x8 wv = *reinterpret_cast<const bf16x8*>(&wr[kx][ci]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float wj = (float)wv[j];
+#pragma unroll
+            for (int p = 0; p < CI_PX; ++p) acc[p][j] = __builtin_fmaf(xp[ci][p + kx], wj, acc[p][j]);
+          }
         }
       }
     }
-    if constexpr (OUT_F32) {   // fp32 residual-stream mode: the stream starts unrounded
-      float* yr = reinterpret_cast<float*>(y) + (size_t)pix * ldy + cc * 8;
-      *reinterpret_cast<f32x4*>(yr) = f32x4{acc[0], acc[1], acc[2], acc[3]};
-      *reinterpret_cast<f32x4*>(yr + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
-    } else {
-      u32x4 pk = {pack_bf16(acc[0], acc[1]), pack_bf16(acc[2], acc[3]), pack_bf16(acc[4], acc[5]),
-                  pack_bf16(acc[6], acc[7])};
-      *reinterpret_cast<u32x4*>(reinterpret_cast<bf16*>(y) + (size_t)pix * ldy + cc * 8) = pk;
+  } else {
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = py + ky - 1;
+    if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      for (int ci = 0; ci < Cin; ++ci) {
+        const float* xr = x + (((size_t)b * Cin + ci) * H + iy) * W;
+        float xv[CI_PX];
+#pragma unroll
+        for (int p = 0; p < CI_PX; ++p) {
+          const int ix = px0 + p + kx - 1;
+          xv[p] = ((unsigned)ix < (unsigned)W) ? (float)(bf16)(xr[ix] * xs) : 0.f;
+        }
+        const u32x4 raw = *reinterpret_cast<const u32x4*>(w + (size_t)((ky * 3 + kx) * Cin + ci) * Cout + cc * 8);
+        const bf16x8 wv = *reinterpret_cast<const bf16x8*>(&raw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float wj = (float)wv[j];
+#pragma unroll
+          for (int p = 0; p < CI_PX; ++p) acc[p][j] = __builtin_fmaf(xv[p], wj, acc[p][j]);
+        }
+      }
     }
+  }
+  }
+#pragma unroll
+  for (int p = 0; p < CI_PX; ++p) {
+    if (px0 + p >= W) break;
+    const size_t pix = (size_t)row * W + px0 + p;
+    if constexpr (OUT_F32) {   // fp32 residual-stream mode: the stream starts unrounded
+      float* yr = reinterpret_cast<float*>(y) + pix * ldy + cc * 8;
+      *reinterpret_cast<f32x4*>(yr) = f32x4{acc[p][0], acc[p][1], acc[p][2], acc[p][3]};
+      *reinterpret_cast<f32x4*>(yr + 4) = f32x4{acc[p][4], acc[p][5], acc[p][6], acc[p][7]};
+    } else {
+      u32x4 pk = {pack_bf16(acc[p][0], acc[p][1]), pack_bf16(acc[p][2], acc[p][3]), pack_bf16(acc[p][4], acc[p][5]),
+                  pack_bf16(acc[p][6], acc[p][7])};
+      *reinterpret_cast<u32x4*>(reinterpret_cast<bf16*>(y) + pix * ldy + cc * 8) = pk;
+    }
+  }
   }
 }
 
 int launch_conv_in3x3(const float* x_nchw, const float* in_scale, const bf16* w, const float* bias, void* y, int out_f32, int B,
                       int Cin, int H, int W, int Cout, int ldy, hipStream_t stream) {
   if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return SD_ERR_INVALID;
-  if ((Cout & 7) || (ldy & 7)) return SD_ERR_UNSUPPORTED;
-  const long total = (long)B * H * W * (Cout >> 3);
-  long nb = (total + 255) / 256;
-  if (nb > 8192) nb = 8192;
-  if (out_f32)
-    hipLaunchKernelGGL(conv_in3x3_kernel<true>, dim3((unsigned)nb), dim3(256), 0, stream, x_nchw, in_scale, w, bias, y, B, Cin,
-                       H, W, Cout, ldy);
-  else
-    hipLaunchKernelGGL(conv_in3x3_kernel<false>, dim3((unsigned)nb), dim3(256), 0, stream, x_nchw, in_scale, w, bias, y, B, Cin,
-                       H, W, Cout, ldy);
+  if ((Cout & 7) || (ldy & 7) || (long)B * H >= (1L << 31)) return SD_ERR_UNSUPPORTED;
+  const int per_row = ((W + CI_PX - 1) / CI_PX) * (Cout >> 3);
+  const dim3 grid((per_row + 255) / 256, B * H < 65535 ? B * H : 65535);
+#define SD_CI(F_, C_) \
+  hipLaunchKernelGGL((conv_in3x3_kernel<F_, C_>), grid, dim3(256), 0, stream, x_nchw, in_scale, w, bias, y, B, Cin, H, W, Cout, ldy)
+  if (Cin == 4) { if (out_f32) SD_CI(true, 4); else SD_CI(false, 4); }
+  else          { if (out_f32) SD_CI(true, 0); else SD_CI(false, 0); }
+#undef SD_CI
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
 
 // conv_out: x NHWC bf16 (already GroupNorm+SiLU'd) -> y NCHW fp32 [B,Cout<=4,H,W]; w [Cout][9][Cin] bf16 in LDS.
-// One wave per output pixel: lanes split the 9*Cin reduction in 16-B chunks, then a wave reduction.
+// One wave per output pixel: lanes split the 9*Cin reduction in 16-B chunks, every chunk is 4 packed-pair dot products
+// (v_dot2c) per output channel, then a wave reduction. (First version: 8 converts + 8 fmas per chunk and channel plus an
+// integer division per trip -- 177 us for the 84 MB of the SDXL bs-8 launch; with dot products and no division: 137 us.)
 constexpr int CO_MAX = 4;
+// NI = chunks per lane = ceil(9 * Cin / 8 / 64), compile-time: the (tap, chunk) of lane's i-th chunk is the same for every
+// pixel and lives in registers, and ALL of a pixel's input loads are issued before the first dot product (the rolled loop
+// waited out one L2 round trip per chunk: 6 per pixel at Cin = 320 -- latency-bound at 137 us). Chunks past 9*Cin/8 and
+// padding taps contribute zeros.
+template <int NI>
 __global__ void conv_out3x3_kernel(const bf16* __restrict__ x, int ldx, const bf16* __restrict__ w,
                                    const float* __restrict__ bias, float* __restrict__ y, int B, int Cin, int H, int W,
                                    int Cout) {
@@ -150,36 +224,53 @@ __global__ void conv_out3x3_kernel(const bf16* __restrict__ x, int ldx, const bf
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
   const int cvin = Cin >> 3;
-  const long npix = (long)B * H * W;
-  for (long pix = (long)blockIdx.x * wpb + (threadIdx.x >> 6); pix < npix; pix += (long)gridDim.x * wpb) {
-    const int px = (int)(pix % W);
-    const int py = (int)((pix / W) % H);
-    const int b = (int)(pix / ((long)W * H));
+  const int nch = 9 * cvin;
+  int dy[NI], dx[NI], woff[NI], coff[NI];
+  bool valid[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int ch = lane + 64 * i;
+    valid[i] = ch < nch;
+    const int tap = valid[i] ? ch / cvin : 0;
+    const int cc = valid[i] ? ch - tap * cvin : 0;
+    const int ky = (tap * 11) >> 5;   // tap / 3 for tap < 9
+    dy[i] = ky - 1;
+    dx[i] = tap - ky * 3 - 1;
+    woff[i] = tap * Cin + cc * 8;
+    coff[i] = cc * 8;
+  }
+  const int HWp = H * W;
+  const int npix = B * HWp;
+  for (int pix = blockIdx.x * wpb + (threadIdx.x >> 6); pix < npix; pix += gridDim.x * wpb) {
+    const int b = pix / HWp;
+    const int rem = pix - b * HWp;
+    const int py = rem / W, px = rem - py * W;
+    u32x4 xv[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int iy = py + dy[i], ix = px + dx[i];
+      xv[i] = u32x4{0u, 0u, 0u, 0u};
+      if (valid[i] && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+        xv[i] = *reinterpret_cast<const u32x4*>(x + (((size_t)b * H + iy) * W + ix) * ldx + coff[i]);
+    }
     float acc[CO_MAX] = {0.f, 0.f, 0.f, 0.f};
-    for (int ch = lane; ch < 9 * cvin; ch += 64) {
-      const int tap = ch / cvin, cc = ch - tap * cvin;
-      const int ky = tap / 3, kx = tap - ky * 3;
-      const int iy = py + ky - 1, ix = px + kx - 1;
-      if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) continue;
-      const u32x4 raw = *reinterpret_cast<const u32x4*>(x + (((size_t)b * H + iy) * W + ix) * ldx + cc * 8);
-      const bf16x8 xv = *reinterpret_cast<const bf16x8*>(&raw);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
 #pragma unroll
       for (int co = 0; co < CO_MAX; ++co) {
         if (co < Cout) {
-          const bf16x8 wv = *reinterpret_cast<const bf16x8*>(ws + (size_t)co * K + tap * Cin + cc * 8);
+          const u32x4 wv = *reinterpret_cast<const u32x4*>(ws + (size_t)co * K + woff[i]);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc[co] = __builtin_fmaf((float)xv[j], (float)wv[j], acc[co]);
+          for (int j = 0; j < 4; ++j) acc[co] = dot2_acc(xv[i][j], wv[j], acc[co]);
         }
       }
     }
 #pragma unroll
     for (int co = 0; co < CO_MAX; ++co) acc[co] = wave_sum(acc[co]);
-    if (lane < Cout) {
-      float v = acc[0];
-      if (lane == 1) v = acc[1];
-      if (lane == 2) v = acc[2];
-      if (lane == 3) v = acc[3];
-      y[(((size_t)b * Cout + lane) * H + py) * W + px] = v + (bias ? bias[lane] : 0.f);
+    if (lane == 0) {   // (statically indexed: a lane-indexed pick of acc[] goes through scratch memory)
+#pragma unroll
+      for (int co = 0; co < CO_MAX; ++co)
+        if (co < Cout) y[(((size_t)b * Cout + co) * H + py) * W + px] = acc[co] + (bias ? bias[co] : 0.f);
     }
   }
 }
@@ -191,10 +282,23 @@ int launch_conv_out3x3(const bf16* x, int ldx, const bf16* w, const float* bias,
   const size_t lds = (size_t)Cout * 9 * Cin * 2;
   if (lds > 64 * 1024) return SD_ERR_UNSUPPORTED;
   const long npix = (long)B * H * W;
+  if (npix >= (1L << 31)) return SD_ERR_UNSUPPORTED;
   long nb = (npix + 3) / 4;
   if (nb > 2048) nb = 2048;
-  hipLaunchKernelGGL(conv_out3x3_kernel, dim3((unsigned)nb), dim3(256), lds, stream, x, ldx, w, bias, y_nchw, B, Cin, H,
-                     W, Cout);
+  const int ni = (9 * (Cin >> 3) + 63) / 64;
+#define SD_CO(NI_) \
+  hipLaunchKernelGGL(conv_out3x3_kernel<NI_>, dim3((unsigned)nb), dim3(256), lds, stream, x, ldx, w, bias, y_nchw, B, Cin, H, W, Cout)
+  switch (ni) {
+    case 1: SD_CO(1); break;
+    case 2: SD_CO(2); break;
+    case 3: SD_CO(3); break;
+    case 4: SD_CO(4); break;
+    case 5: case 6: SD_CO(6); break;
+    case 7: case 8: case 9: SD_CO(9); break;
+    case 10: case 11: case 12: SD_CO(12); break;
+    default: return SD_ERR_UNSUPPORTED;   // Cin > 680 (lds caps Cin at 904 anyway)
+  }
+#undef SD_CO
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
 

@@ -22,15 +22,22 @@ static int ln_grid(int rows, int rows_per_block);
 
 // 8 consecutive channels of a row as fp32: from the build's 16-bit elements (one 16-byte load) or, in the fp32
 // residual-stream mode (XF32), from fp32 rows (two 16-byte loads). `x` is the row base in ELEMENTS of its own type.
+// `ok == false` yields zeros. Only the raw load sits under the predicate (the conversion does not), so that the compiler
+// issues the loads of an unrolled caller back to back instead of one branch + s_waitcnt per chunk.
 template <bool XF32>
-__device__ __forceinline__ void load8f(const void* x, size_t elem_off, float (&f)[8]) {
+__device__ __forceinline__ void load8f(const void* x, size_t elem_off, float (&f)[8], bool ok = true) {
   if constexpr (XF32) {
     const float* p = reinterpret_cast<const float*>(x) + elem_off;
-    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+      a = *reinterpret_cast<const f32x4*>(p);
+      b = *reinterpret_cast<const f32x4*>(p + 4);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) { f[j] = a[j]; f[4 + j] = b[j]; }
   } else {
-    const u32x4 raw = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16*>(x) + elem_off);
+    u32x4 raw = {0u, 0u, 0u, 0u};
+    if (ok) raw = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16*>(x) + elem_off);
     const bf16x8 v = *reinterpret_cast<const bf16x8*>(&raw);
 #pragma unroll
     for (int j = 0; j < 8; ++j) f[j] = (float)v[j];
@@ -77,7 +84,23 @@ __global__ void gn_partial_kernel(const void* __restrict__ x, int HW, int C, int
 #pragma unroll
     for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
     const size_t xb = (size_t)b * HW * ldx + cc * 8;
-    for (int pix = p_begin + pl; pix < p_end; pix += ppp) {
+    // four pixels' loads in flight per thread (one 16-B load per trip left the kernel latency-bound at ~1.7 TB/s); the
+    // accumulation order is the pixel order either way, so the partials do not depend on the unrolling
+    int pix = p_begin + pl;
+    for (; pix + 3 * ppp < p_end; pix += 4 * ppp) {
+      float v[4][8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) load8f<XF32>(x, xb + (size_t)(pix + u * ppp) * ldx, v[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          s[j] += v[u][j];
+          q[j] = __builtin_fmaf(v[u][j], v[u][j], q[j]);
+        }
+      }
+    }
+    for (; pix < p_end; pix += ppp) {
       float v[8];
       load8f<XF32>(x, xb + (size_t)pix * ldx, v);
 #pragma unroll
@@ -189,23 +212,27 @@ int launch_groupnorm_stats(const void* x, int x_f32, int B, int HW, int C, int l
 // XF32: x rows are fp32 (residual-stream mode); raw16 (optional, XF32 only) receives the 16-bit rounding of the raw rows
 // in the same pass -- the operand of the resnet's conv_shortcut GEMM (resnet.py:797-798), which must not read fp32.
 template <bool SILU, bool XF32>
-__global__ void scale_shift_act_kernel(const void* __restrict__ x, long total_chunks, int HW, int C, int ldx,
+__global__ void scale_shift_act_kernel(const void* __restrict__ x, int HW, int C, int ldx, int cv, int ppp, int nthreads, int ppb,
                                        const float* __restrict__ scale_shift, bf16* __restrict__ y, int ldy,
                                        bf16* __restrict__ raw16, int ld_raw) {
-  const int cv = C >> 3;
-  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total_chunks; id += (long)gridDim.x * blockDim.x) {
-    const long pix = id / cv;
-    const int cc = (int)(id - pix * cv);
-    const int b = (int)(pix / HW);
-    float v[8];
-    load8f<XF32>(x, (size_t)pix * ldx + cc * 8, v);
+  // Same block geometry as gn_partial_kernel: a thread owns ONE 8-channel chunk (its scale / shift stay in registers) and
+  // walks pixels, four loads in flight. (The first version decomposed a flat 64-bit chunk id with two divisions per
+  // 16 bytes and re-read scale / shift every trip: ~350 VALU instructions per chunk, VALU-bound at 1.4 TB/s.)
+  const int tid = threadIdx.x;
+  if (tid >= nthreads) return;
+  const int b = blockIdx.y;
+  const int cc = tid % cv, pl = tid / cv;
+  const int p_begin = blockIdx.x * ppb;
+  const int p_end = min(p_begin + ppb, HW);
+  const float* sc = scale_shift + (size_t)b * 2 * C + cc * 8;
+  const f32x4 a0 = *reinterpret_cast<const f32x4*>(sc), a1 = *reinterpret_cast<const f32x4*>(sc + 4);
+  const f32x4 b0 = *reinterpret_cast<const f32x4*>(sc + C), b1 = *reinterpret_cast<const f32x4*>(sc + C + 4);
+  const size_t row0 = (size_t)b * HW;
+  auto emit = [&](size_t row, const float (&v)[8]) {
     if (XF32 && raw16) {
       u32x4 rk = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
-      *reinterpret_cast<u32x4*>(raw16 + (size_t)pix * ld_raw + cc * 8) = rk;
+      *reinterpret_cast<u32x4*>(raw16 + row * ld_raw + cc * 8) = rk;
     }
-    const float* sc = scale_shift + (size_t)b * 2 * C + cc * 8;
-    const f32x4 a0 = *reinterpret_cast<const f32x4*>(sc), a1 = *reinterpret_cast<const f32x4*>(sc + 4);
-    const f32x4 b0 = *reinterpret_cast<const f32x4*>(sc + C), b1 = *reinterpret_cast<const f32x4*>(sc + C + 4);
     float o[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -217,7 +244,20 @@ __global__ void scale_shift_act_kernel(const void* __restrict__ x, long total_ch
       for (int j = 0; j < 8; ++j) o[j] = silu_f(o[j]);
     }
     u32x4 pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7])};
-    *reinterpret_cast<u32x4*>(y + (size_t)pix * ldy + cc * 8) = pk;
+    *reinterpret_cast<u32x4*>(y + row * ldy + cc * 8) = pk;
+  };
+  int pix = p_begin + pl;
+  for (; pix + 3 * ppp < p_end; pix += 4 * ppp) {
+    float v[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) load8f<XF32>(x, (row0 + pix + u * ppp) * ldx + cc * 8, v[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) emit(row0 + pix + u * ppp, v[u]);
+  }
+  for (; pix < p_end; pix += ppp) {
+    float v[8];
+    load8f<XF32>(x, (row0 + pix) * ldx + cc * 8, v);
+    emit(row0 + pix, v);
   }
 }
 
@@ -226,13 +266,11 @@ int launch_scale_shift_act(const void* x, int x_f32, int B, int HW, int C, int l
   if (B <= 0 || HW <= 0 || C <= 0) return SD_ERR_INVALID;
   if ((C & 7) || (ldx & 7) || (ldy & 7)) return SD_ERR_UNSUPPORTED;
   if (raw16 && (!x_f32 || (ld_raw & 7))) return SD_ERR_UNSUPPORTED;
-  const long total = (long)B * HW * (C >> 3);
-  const int block = 256;
-  long nb = (total + block - 1) / block;
-  if (nb > 256 * 16) nb = 256 * 16;
+  const GnGeom g = gn_geom(HW, C);
+  if (g.block > 1024 || B > 65535) return SD_ERR_UNSUPPORTED;
 #define SD_SSA(S_, F_) \
-  hipLaunchKernelGGL((scale_shift_act_kernel<S_, F_>), dim3((unsigned)nb), dim3(block), 0, stream, x, total, HW, C, ldx, \
-                     scale_shift, y, ldy, raw16, ld_raw)
+  hipLaunchKernelGGL((scale_shift_act_kernel<S_, F_>), dim3(g.nblk, B), dim3(g.block), 0, stream, x, HW, C, ldx, g.cv, g.ppp, \
+                     g.threads, g.ppb, scale_shift, y, ldy, raw16, ld_raw)
   if (silu) { if (x_f32) SD_SSA(true, true); else SD_SSA(true, false); }
   else      { if (x_f32) SD_SSA(false, true); else SD_SSA(false, false); }
 #undef SD_SSA
@@ -255,10 +293,22 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int cc = lane + 64 * i;
+    // two 16-byte loads per vector under ONE predicate each (element-wise selects compile to a branch + dword load per element)
+    f32x4 ga = {1.f, 1.f, 1.f, 1.f}, gb = ga, ba = {0.f, 0.f, 0.f, 0.f}, bb = ba;
+    if (gamma && cc < cv) {
+      ga = *reinterpret_cast<const f32x4*>(gamma + cc * 8);
+      gb = *reinterpret_cast<const f32x4*>(gamma + cc * 8 + 4);
+    }
+    if (beta && cc < cv) {
+      ba = *reinterpret_cast<const f32x4*>(beta + cc * 8);
+      bb = *reinterpret_cast<const f32x4*>(beta + cc * 8 + 4);
+    }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      g[i][j] = (gamma && cc < cv) ? gamma[cc * 8 + j] : 1.f;
-      bt[i][j] = (beta && cc < cv) ? beta[cc * 8 + j] : 0.f;
+    for (int j = 0; j < 4; ++j) {
+      g[i][j] = ga[j];
+      g[i][4 + j] = gb[j];
+      bt[i][j] = ba[j];
+      bt[i][4 + j] = bb[j];
     }
   }
   const float invC = 1.0f / (float)C;
@@ -270,12 +320,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
         const int cc = lane + 64 * i;
-        if (cc < cv) {
-          load8f<XF32>(x, (size_t)row * ldx + cc * 8, v[r][i]);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[r][i][j] = 0.f;
-        }
+        load8f<XF32>(x, (size_t)row * ldx + cc * 8, v[r][i], cc < cv);
       }
     }
     float mean[ROWS], rstd[ROWS], s1[ROWS], s2[ROWS];
