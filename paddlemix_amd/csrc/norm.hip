@@ -11,6 +11,7 @@
 //      gn_finalize_kernel: mean / rstd per (batch, group) -> scale[b][c] = gamma*rstd, shift[b][c] = beta - mean*scale
 //   2. scale_shift_act_kernel: y = act(x*scale + shift)                                    (reads x once, writes y once)
 // All loads/stores are 16-byte (8 x bf16) per lane.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "common.h"
@@ -44,7 +45,11 @@ __device__ __forceinline__ void load8f(const void* x, size_t elem_off, float (&f
   }
 }
 
-constexpr int GN_ITERS = 16;      // pixels per thread-slot per block
+// pixels per thread-slot per block: statistics pass / apply pass (measured inside the SDXL step, profiles/r02_l_norm_knobs.txt:
+// statistics 8 / 16 / 32 -> 1.20 / 1.01 / 0.94 ms, apply 0.90 / 0.93 / 0.99 ms; the statistics pass stays at 16 because its
+// block partition is part of the result's summation order)
+constexpr int GN_ITERS_STATS = 16;
+constexpr int GN_ITERS_APPLY = 8;
 constexpr int GN_MAXC = 4096;
 
 struct GnGeom {
@@ -55,13 +60,13 @@ struct GnGeom {
   int ppb;       // pixels per block
   int nblk;      // blocks per batch item
 };
-static GnGeom gn_geom(int HW, int C) {
+static GnGeom gn_geom(int HW, int C, int iters = GN_ITERS_STATS) {
   GnGeom g;
   g.cv = C / 8;
   g.ppp = g.cv <= 256 ? 256 / g.cv : 1;
   g.threads = g.ppp * g.cv;
   g.block = (g.threads + 63) / 64 * 64;
-  g.ppb = g.ppp * GN_ITERS;
+  g.ppb = g.ppp * iters;
   g.nblk = (HW + g.ppb - 1) / g.ppb;
   return g;
 }
@@ -266,7 +271,7 @@ int launch_scale_shift_act(const void* x, int x_f32, int B, int HW, int C, int l
   if (B <= 0 || HW <= 0 || C <= 0) return SD_ERR_INVALID;
   if ((C & 7) || (ldx & 7) || (ldy & 7)) return SD_ERR_UNSUPPORTED;
   if (raw16 && (!x_f32 || (ld_raw & 7))) return SD_ERR_UNSUPPORTED;
-  const GnGeom g = gn_geom(HW, C);
+  const GnGeom g = gn_geom(HW, C, GN_ITERS_APPLY);
   if (g.block > 1024 || B > 65535) return SD_ERR_UNSUPPORTED;
 #define SD_SSA(S_, F_) \
   hipLaunchKernelGGL((scale_shift_act_kernel<S_, F_>), dim3(g.nblk, B), dim3(g.block), 0, stream, x, HW, C, ldx, g.cv, g.ppp, \
@@ -377,14 +382,27 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
   }
 }
 
-// Grid of the row-normalisation kernels. With every row group resident at once all waves load, then all waves store,
-// and the two phases never overlap; 1-2 blocks per CU whose waves walk 2-4 row groups each overlap them
-// (scripts/ln_probe.py: 8192 x 1280 15.7 -> 13.6 us at 256 blocks, 32768 x 640 26.8 -> 21.2 us at 512 blocks).
+// Grid of the row-normalisation kernels: blocks = clamp(needed / div, min, max). Round 1 measured, back to back in isolation,
+// that waves walking 2-4 row groups beat one group per wave (scripts/ln_probe.py: 8192 x 1280 15.7 -> 13.6 us at 256 blocks) and
+// used div = 2; inside the SDXL step, and with the per-wave prologue now 12 vector loads instead of 48 branches, one trip per
+// wave wins (LayerNorm class 3.07 -> 2.79 ms per step, profiles/r02_k_ln_grid.txt): div = 1, at most 1024 blocks.
+// MI355X_SD_LN_GRID="div,min,max" overrides the three constants (experiments only).
 static int ln_grid(int rows, int rows_per_block) {
+  static int cfg[3] = {0, 0, 0};
+  if (!cfg[0]) {
+    int d = 1, lo = 256, hi = 1024;
+    if (const char* e = getenv("MI355X_SD_LN_GRID")) {
+      int a = 0, b = 0, c = 0;
+      if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a > 0 && b > 0 && c >= b) { d = a; lo = b; hi = c; }
+    }
+    cfg[1] = lo;
+    cfg[2] = hi;
+    cfg[0] = d;
+  }
   const int needed = (rows + rows_per_block - 1) / rows_per_block;
-  int blocks = needed / 2;
-  if (blocks < 256) blocks = 256;
-  if (blocks > 512) blocks = 512;
+  int blocks = needed / cfg[0];
+  if (blocks < cfg[1]) blocks = cfg[1];
+  if (blocks > cfg[2]) blocks = cfg[2];
   return blocks < needed ? blocks : needed;
 }
 
@@ -394,11 +412,22 @@ int launch_layernorm(const void* x, int x_f32, int rows, int C, int ldx, const f
   if ((C & 7) || (ldx & 7) || (ldy & 7) || C > 2560) return SD_ERR_UNSUPPORTED;
   const int wpb = 4;
   const int cv = C >> 3;
-  constexpr int R = 4;   // measured: 4 rows in flight per wave beats 2 (4.6 vs 5.2 ms per SDXL step)
-  const int blocks = ln_grid(rows, wpb * R);
+  // rows per wave: round 1 measured 4 better than 2 (4.6 vs 5.2 ms per SDXL step) when every wave paid a 48-branch prologue; with
+  // the vector prologue and one trip per wave, 2 rows (twice the waves, ~110 instead of 200 registers) is ahead again: class
+  // 2.80 -> 2.65 ms per step (profiles/r02_l_norm_knobs.txt). MI355X_SD_LN_ROWS=4 selects the old shape (experiments only).
+  constexpr int R = 4;
+  static int rows_env = -1;
+  if (rows_env < 0) {
+    const char* e = getenv("MI355X_SD_LN_ROWS");
+    rows_env = (e && atoi(e) == 4) ? 4 : 2;
+  }
+  const int blocks = ln_grid(rows, wpb * (cv <= 192 ? rows_env : 2));
 #define SD_LN_LAUNCH(NCH, R_, F_) \
   hipLaunchKernelGGL((layernorm_kernel<NCH, R_, F_>), dim3(blocks), dim3(64 * wpb), 0, stream, x, rows, C, ldx, gamma, beta, eps, y, ldy)
-  if (x_f32) {
+  if (rows_env == 2 && cv <= 192) {
+    if (x_f32) { if (cv <= 128) SD_LN_LAUNCH(2, 2, true); else SD_LN_LAUNCH(3, 2, true); }
+    else       { if (cv <= 128) SD_LN_LAUNCH(2, 2, false); else SD_LN_LAUNCH(3, 2, false); }
+  } else if (x_f32) {
     if (cv <= 128) SD_LN_LAUNCH(2, R, true);
     else if (cv <= 192) SD_LN_LAUNCH(3, R, true);
     else SD_LN_LAUNCH(5, 2, true);
