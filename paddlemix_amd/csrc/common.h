@@ -145,16 +145,28 @@ __device__ __forceinline__ void conv_k_next(int kb64, int Cin, int& tap, int& ch
 
 // Logical tile id -> (tile_m, tile_n), "grouped" order: ids sweep GM row-tiles first, then the column, so the
 // tiles an XCD runs concurrently (a contiguous id range after xcd_remap) form a compact 2-D patch that shares
-// A row-panels and W column-panels in that XCD's L2.
-__device__ __forceinline__ void tile_coords(int lid, int ntm, int ntn, int& tile_m, int& tile_n) {
-  constexpr int GM = 8;
-  const int per_group = GM * ntn;
-  const int g = lid / per_group;
-  const int first_m = g * GM;
-  const int gsz = min(ntm - first_m, GM);
-  const int r = lid - g * per_group;
-  tile_n = r / gsz;
-  tile_m = first_m + (r - tile_n * gsz);
+// A row-panels and W column-panels in that XCD's L2. gm > 0: groups of gm row-tiles (round 1: 8); gm < 0: the transposed
+// order, groups of -gm column-tiles swept over the rows (production: -4, gemm.hip GEMM_GM_DEFAULT; MI355X_SD_GEMM_GM overrides).
+__device__ __forceinline__ void tile_coords(int lid, int ntm, int ntn, int gm, int& tile_m, int& tile_n) {
+  if (gm == 0) gm = -4;
+  if (gm > 0) {
+    const int per_group = gm * ntn;
+    const int g = lid / per_group;
+    const int first_m = g * gm;
+    const int gsz = min(ntm - first_m, gm);
+    const int r = lid - g * per_group;
+    tile_n = r / gsz;
+    tile_m = first_m + (r - tile_n * gsz);
+  } else {
+    const int gn = -gm;
+    const int per_group = gn * ntm;
+    const int g = lid / per_group;
+    const int first_n = g * gn;
+    const int gsz = min(ntn - first_n, gn);
+    const int r = lid - g * per_group;
+    tile_m = r / gsz;
+    tile_n = first_n + (r - tile_m * gsz);
+  }
 }
 
 }  // namespace sd

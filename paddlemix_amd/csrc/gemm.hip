@@ -58,7 +58,7 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_bf16_kernel(const GemmAr
   const int ntm = (p.M + BM - 1) / BM;
   const int lid = xcd_remap(blockIdx.x, ntm * ntn);
   int tile_m, tile_n;
-  tile_coords(lid, ntm, ntn, tile_m, tile_n);
+  tile_coords(lid, ntm, ntn, p.gm, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // ---- LDS-DMA loader geometry: wave w fills pieces w*PIECES .. of A and of W (piece = 8 rows x 128 B) ----
@@ -313,9 +313,24 @@ static int pick_tile(const GemmArgs& a) {
   return best;
 }
 
+// Tile rasterisation (common.h tile_coords), measured inside the SDXL bs-8 step (profiles/r02_o_gemm_gm.txt, one box, ms per
+// step): row groups of 2 / 4 / 8 / 16 / 32: 60.98 / 61.48 / 61.19-61.50 / 61.92 / 64.72; column groups of 2 / 4 / 8: 61.11 /
+// 60.37 / 60.47. Column groups of 4: an XCD's concurrently running tiles keep the same 4 W column-panels (the small operand)
+// hot in its L2 while the A row-panels stream through once.
+constexpr int GEMM_GM_DEFAULT = -4;
+int gemm_gm() {
+  static const int v = [] {
+    const char* e = getenv("MI355X_SD_GEMM_GM");   // experiments only
+    const int n = e ? atoi(e) : 0;
+    return (n != 0 && n >= -64 && n <= 64) ? n : GEMM_GM_DEFAULT;
+  }();
+  return v;
+}
+
 int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
   GemmArgs a = a_in;
   a.splitk = 0;
+  a.gm = gemm_gm();
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return SD_ERR_INVALID;
   if ((a.K & 7) || (a.N & 3) || (a.lda & 7) || (a.ldc & 3)) return SD_ERR_UNSUPPORTED;
   if (a.R && (a.ldr & 3)) return SD_ERR_UNSUPPORTED;

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(g256::THREADS, 2) void gemm256_kernel(const GemmArg
   const int ntm = (p.M + BM - 1) / BM;
   const int lid = xcd_remap(blockIdx.x, ntm * ntn);
   int tile_m, tile_n;
-  tile_coords(lid, ntm, ntn, tile_m, tile_n);
+  tile_coords(lid, ntm, ntn, p.gm, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // ---- LDS-DMA geometry: a half-tile is 16 pieces of 1 KiB (8 rows x 128 B); wave w issues pieces 2w, 2w+1 ----
@@ -306,6 +306,7 @@ int launch_gemm256(const GemmArgs& a, hipStream_t stream) {
 
 int launch_gemm_f8(const GemmArgs& a_in, hipStream_t stream) {
   GemmArgs a = a_in;
+  a.gm = gemm_gm();
   a.c_wide = !a.out_f8 && !(reinterpret_cast<uintptr_t>(a.C) & 15) && !(a.ldc & 7) && !(a.c_bstride & 7);
   if (a.out_f8 && ((a.ldc & 7) || a.c_rpb || a.R || a.gate)) return SD_ERR_UNSUPPORTED;   // 8-byte e4m3 stores
   if (a.M <= 0 || a.N <= 0 || a.K <= 0 || !a.ascale || !a.wscale) return SD_ERR_INVALID;

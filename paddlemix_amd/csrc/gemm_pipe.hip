@@ -83,7 +83,7 @@ __global__ __launch_bounds__(CFG::THREADS + LW * 64, (LW ? 3 : CFG::MIN_WAVES)) 
   const int ntm = (p.M + BM - 1) / BM;
   const int lid = xcd_remap(blockIdx.x, ntm * ntn);
   int tile_m, tile_n;
-  tile_coords(lid, ntm, ntn, tile_m, tile_n);
+  tile_coords(lid, ntm, ntn, p.gm, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const int nt_all = p.K / BK;   // K % 64 == 0 on this path
