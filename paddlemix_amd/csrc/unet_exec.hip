@@ -1010,6 +1010,9 @@ int mi355x_sd_unet_create(const char* config_json, void** handle) {
     return MI355X_SD_OK;
   } catch (const ExecError& x) {
     return report(x);
+  } catch (const std::exception& x) {   // bad_alloc, a malformed number in the config ...: never across the C boundary
+    sd::set_last_error((std::string("mi355x_sd_unet: ") + x.what()).c_str());
+    return MI355X_SD_ERR_INVALID;
   }
 }
 
@@ -1094,6 +1097,9 @@ int mi355x_sd_unet_load_weight(void* handle, const char* name, const void* host_
     return MI355X_SD_OK;
   } catch (const ExecError& x) {
     return report(x);
+  } catch (const std::exception& x) {   // bad_alloc, a malformed number in the config ...: never across the C boundary
+    sd::set_last_error((std::string("mi355x_sd_unet: ") + x.what()).c_str());
+    return MI355X_SD_ERR_INVALID;
   }
 }
 
@@ -1113,6 +1119,9 @@ int mi355x_sd_unet_weight_bytes(void* handle, size_t* bytes) {
     return MI355X_SD_OK;
   } catch (const ExecError& x) {
     return report(x);
+  } catch (const std::exception& x) {   // bad_alloc, a malformed number in the config ...: never across the C boundary
+    sd::set_last_error((std::string("mi355x_sd_unet: ") + x.what()).c_str());
+    return MI355X_SD_ERR_INVALID;
   }
 }
 
@@ -1195,6 +1204,9 @@ int mi355x_sd_unet_plan(void* handle, int B, int H, int W, int L, size_t* worksp
     return MI355X_SD_OK;
   } catch (const ExecError& x) {
     return report(x);
+  } catch (const std::exception& x) {   // bad_alloc, a malformed number in the config ...: never across the C boundary
+    sd::set_last_error((std::string("mi355x_sd_unet: ") + x.what()).c_str());
+    return MI355X_SD_ERR_INVALID;
   }
 }
 
@@ -1284,8 +1296,10 @@ int mi355x_sd_unet_forward(void* handle, void* stream, const float* sample, cons
       const int rprog = run_eager();
       void* exec = nullptr;
       rc = mi355x_sd_graph_end(stream, &exec);
-      if (rprog) return rprog;
-      if (rc) return rc;
+      if (rprog || rc) {   // a launch failed inside the capture: do not keep (or leak) the partial graph
+        if (exec) (void)hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(exec));
+        return rprog ? rprog : rc;
+      }
       e->graph = reinterpret_cast<hipGraphExec_t>(exec);
       e->graph_stream = stream;
     } else {

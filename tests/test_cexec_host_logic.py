@@ -56,6 +56,10 @@ def test_refusals_are_loud():
                 dict(TINY, down_block_types=("DownBlock2D", "AttnDownBlock2D")), dict(TINY, encoder_hid_dim_type="ip_image_proj", encoder_hid_dim=8)):
         with pytest.raises(_lib.MI355XError):
             UNetHandle(bad)
+    for bad in (b"{not json", b"", b"[]", b'{"block_out_channels": "x"}', b'{"a": {"b": [1,2,',
+                b'{"block_out_channels": [32, 64], "layers_per_block": 99999999999999999999}'):
+        h = ctypes.c_void_p()      # malformed config text: an error code and a message, never an exception across the C boundary
+        assert lib.mi355x_sd_unet_create(bad, ctypes.byref(h)) != 0 and not h.value and lib.mi355x_sd_last_error()
     hd = UNetHandle(TINY)
     with pytest.raises(_lib.MI355XError, match="never loaded"):
         hd.weight_bytes()
