@@ -219,17 +219,19 @@ def main():
         t0 = time.perf_counter()
         for i in range(args.steps):
             step(args.warmup + i)
+        torch.cuda.synchronize()
+        local_elapsed = time.perf_counter() - t0   # this rank's own K steps (reported per rank; not the metric)
         sync_all()
-        elapsed = time.perf_counter() - t0
+        elapsed = time.perf_counter() - t0         # the metric's clock: barrier + synchronize on both sides
     if not torch.isfinite(latents).all():
         raise SystemExit("non-finite latents")
-    per_rank_ms = [1e3 * elapsed / args.steps]
+    per_rank_ms = [1e3 * local_elapsed / args.steps]
     gathered_shape = None
     if dist is not None:
-        tall = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
-        dist.all_gather(tall, torch.tensor([elapsed], device=dev, dtype=torch.float64))
-        per_rank_ms = [1e3 * t.item() / args.steps for t in tall]
-        elapsed = max(t.item() for t in tall)
+        tall = [torch.zeros(2, device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(tall, torch.tensor([elapsed, local_elapsed], device=dev, dtype=torch.float64))
+        per_rank_ms = [1e3 * t[1].item() / args.steps for t in tall]
+        elapsed = max(t[0].item() for t in tall)   # max over ranks
         allz = gather_latents(latents)      # the only other collective of the job: the ranks' results, once
         gathered_shape = list(allz.shape)
         if not torch.isfinite(allz).all():
@@ -359,6 +361,7 @@ def main():
     if rank == 0:
         print(json.dumps(res))
     if dist is not None:
+        dist.barrier()   # rank 0 ran the roofline pass meanwhile: tear the communicator down together
         dist.destroy_process_group()
 
 

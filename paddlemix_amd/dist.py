@@ -39,8 +39,13 @@ def broadcast_params(P: Dict[str, torch.Tensor], src: int = 0) -> int:
     for n in P:     # dict order is the construction order on every rank
         t = P[n]
         total += t.numel() * t.element_size()
-        if t.numel() >= BIG and t.is_contiguous():
-            dist.broadcast(t, src=src)
+        if t.numel() >= BIG:   # (decided by SIZE only: every rank must issue the same sequence of collectives)
+            if t.is_contiguous():
+                dist.broadcast(t, src=src)
+            else:
+                c = t.contiguous()
+                dist.broadcast(c, src=src)
+                t.copy_(c)
         else:
             small.setdefault(t.dtype, []).append(n)
 

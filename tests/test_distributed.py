@@ -70,3 +70,38 @@ def test_broadcast_and_prompt_sharding(world):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(a and b for a, b in res), res
+
+
+def test_receiver_tables_match_the_sender_for_every_broadcast_model():
+    """The receivers allocate from the *shape tables*, rank 0 sends what the *generators* produce: the broadcast pairs tensors by
+    position in the dict, so names, order and shapes must agree for every model bench.py broadcasts (UNet + both text encoders)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from paddlemix_amd.clip import clip_param_shapes, synth_clip_params
+    from paddlemix_amd.unet import synth_unet_params, unet_param_shapes
+    from tests.configs import MINI_XL, TINY
+    pairs = [(synth_unet_params(c, seed=1), unet_param_shapes(c)) for c in (TINY, MINI_XL)]
+    pairs += [(synth_clip_params(c, seed=1), clip_param_shapes(c))
+              for c in (dict(bench.CLIP_L, num_hidden_layers=2), dict(bench.CLIP_BIGG, num_hidden_layers=2))]
+    for P, S in pairs:
+        assert list(P) == list(S)
+        assert all(tuple(P[k].shape) == tuple(S[k]) for k in S)
+    # the SDXL configuration of the headline itself, names and order only (the shape table needs no memory)
+    S = unet_param_shapes(bench.SDXL)
+    assert len(S) > 1000 and sum(int(torch.tensor(s).prod()) for s in S.values()) == 2_567_463_684
+
+
+def test_broadcast_sequence_does_not_depend_on_strides(monkeypatch):
+    """Which tensors go out on their own and which in buckets is decided by size alone: a rank holding a non-contiguous view of a
+    big tensor must issue the same collectives (count and sizes) as the ranks holding contiguous ones."""
+    from paddlemix_amd import dist as D
+    calls = []
+    monkeypatch.setattr(dist, "broadcast", lambda t, src=0: calls.append((t.numel(), t.dtype, t.is_contiguous())))
+    big = torch.zeros(2048, 2049)                      # >= BIG elements
+    P_contig = {"a.weight": big.clone(), "a.bias": torch.zeros(7), "b.weight": torch.zeros(3, 5, dtype=torch.bfloat16)}
+    P_view = dict(P_contig, **{"a.weight": torch.zeros(2049, 2048).t()})
+    assert not P_view["a.weight"].is_contiguous() and P_view["a.weight"].numel() >= D.BIG
+    n1 = D.broadcast_params(P_contig)
+    seq1, calls[:] = list(calls), []
+    n2 = D.broadcast_params(P_view)
+    assert n1 == n2 and [c[:2] for c in calls] == [c[:2] for c in seq1] and all(c[2] for c in calls)
