@@ -14,7 +14,11 @@ import os
 import sys
 import time
 
-import torch
+# the host driver only supports dmabuf IPC: without this RCCL's peer buffers fail with hipIpcGetMemHandle "invalid argument"
+# (read by the HSA runtime when the first HIP call initialises it, so it has to be in the environment before that)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

@@ -455,6 +455,10 @@ int launch_gemm_pipe(const GemmArgs& a, int tile, void* stream_) {
     return a.conv ? launch_pipe<true, Cfg256, false>(a, stream) : launch_pipe<false, Cfg256, false>(a, stream);
   }
   if (tile == 320) {
+    {   // experiment, off unless MI355X_SD_GEMM_PERSIST=1: one persistent block per CU walking its tiles (gemm_persist.hip)
+      const int rc = launch_gemm_persist(a, tile, stream_);
+      if (rc != SD_ERR_UNSUPPORTED) return rc;
+    }
     if (a.geglu) return ln ? launch_pipe<false, Cfg256x320g, true>(a, stream) : launch_pipe<false, Cfg256x320g, false>(a, stream);
     if (ln) return launch_pipe<false, Cfg256x320, true>(a, stream);
     return a.conv ? launch_pipe<true, Cfg256x320, false>(a, stream) : launch_pipe<false, Cfg256x320, false>(a, stream);
