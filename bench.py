@@ -9,8 +9,10 @@ over xGMI, every rank then denoises its own shard of 8 prompts with no per-step 
 Prints ONE JSON line (see the field notes in DESIGN.md "Measurement").
 """
 import argparse
+import contextlib
 import json
 import os
+import socket
 import sys
 import time
 
@@ -68,7 +70,30 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"],
                     help="16-bit element type = which build of the library runs (bf16: BASELINE.json's configurations; "
                          "fp16: same MFMA rate, ~6x tighter parity)")
+    ap.add_argument("--no-parity-mode", action="store_true",
+                    help="skip the second short timed loop in the configuration that meets the 1e-3 latents bar (fp16 + fp32 stream)")
+    # test plumbing (tests/test_distributed.py): the launcher, the rendezvous, the barrier / max-over-ranks timing protocol and
+    # the one-JSON-line contract on CPU ranks (gloo) with the C-ABI interpreter of tests/abi_emulator.py standing in for the
+    # library on the tiny test UNet. The line it prints says "selftest": it is never a measurement.
+    ap.add_argument("--selftest-cpu", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args) -> None:
+    """`python bench.py --gpus N` outside a launcher: become `python -m torch.distributed.run ... bench.py <same flags>` (one
+    process per GPU on this node, rendezvous on 127.0.0.1). stdout is inherited, so rank 0's JSON line is this process's."""
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
 
 
 def broadcast_params(P, rank=None, world=None):
@@ -82,26 +107,43 @@ def main():
     args = parse()
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)   # does not return
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    cpu = args.selftest_cpu
+    if cpu:
+        dev = torch.device("cpu")
+        args.workload, args.no_cpu_baseline, args.no_roofline, args.no_parity_mode = "tiny-selftest", True, True, True
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if cpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+
+    def dev_sync():
+        if not cpu:
+            torch.cuda.synchronize()
 
     from paddlemix_amd import _lib
     _lib.set_elem_dtype(args.dtype)   # before anything loads the library
     from paddlemix_amd.schedulers import EulerDiscreteScheduler, FlowMatchEulerDiscreteScheduler
     from paddlemix_amd.unet import UNet2DConditionModel, synth_unet_params, unet_param_shapes
-    is_sd3 = bool(WORKLOADS[args.workload].get("sd3"))
+    is_sd3 = bool(WORKLOADS.get(args.workload, {}).get("sd3"))
     if is_sd3:
         from paddlemix_amd.sd3 import SD3Transformer2DModel as UNet2DConditionModel  # same program interface
         from paddlemix_amd.sd3 import sd3_param_shapes as unet_param_shapes, synth_sd3_params as synth_unet_params
 
+    if cpu:
+        from tests.configs import TINY
+        WORKLOADS["tiny-selftest"] = dict(cfg=TINY, B=2, H=8, W=8, L=7, gflop_step=0.0)
     wl = WORKLOADS[args.workload]
     cfg, B, H, W, L = wl["cfg"], wl["B"], wl["H"], wl["W"], wl["L"]
 
@@ -121,22 +163,26 @@ def main():
         PT = {k: empty_wire_params(clip_param_shapes(c), ed, dev) for k, (c, _) in te_cfgs.items()}
     bcast_s = bcast_bytes = None
     if world > 1:
-        torch.cuda.synchronize()
+        dev_sync()
         dist.barrier()
         t0 = time.time()
         bcast_bytes = broadcast_params(P) + sum(broadcast_params(v) for v in PT.values())
-        torch.cuda.synchronize()
+        dev_sync()
         bcast_s = time.time() - t0
-    kw = {"weight_dtype": "fp8"} if WORKLOADS[args.workload].get("fp8") else {}
-    if WORKLOADS[args.workload].get("a8"):
+    kw = {"weight_dtype": "fp8"} if wl.get("fp8") else {}
+    if wl.get("a8"):
         kw["act_dtype"] = "fp8"
     if args.residual == "fp32":
         kw["residual_dtype"] = "fp32"
+    if cpu:
+        from tests.abi_emulator import Emulator   # test plumbing only (see --selftest-cpu above)
+        kw["_test_backend"] = Emulator()
     model = UNet2DConditionModel(cfg, P, device=dev, use_graph=not args.no_graph, **kw)
     P_cpu_needed = rank == 0 and world == 1 and not args.no_cpu_baseline and not is_sd3
     if not P_cpu_needed:
         del P
-    torch.cuda.empty_cache()
+    if not cpu:
+        torch.cuda.empty_cache()
 
     # ---- synthetic inputs, resident in HBM ----
     g = torch.Generator(device=dev).manual_seed(rank)
@@ -171,7 +217,7 @@ def main():
         enc = torch.cat([o1.hidden_states[-2], o2.hidden_states[-2]], -1).float()
         added["text_embeds"] = o2.text_embeds.float()
         assert enc.shape == (B, L, cfg["cross_attention_dim"]) and added["text_embeds"].shape == (B, td)
-        torch.cuda.synchronize()
+        dev_sync()
         te_s = time.time() - t0
         del te1, te2, o1, o2, PT
         torch.cuda.empty_cache()
@@ -189,8 +235,9 @@ def main():
             coef_host.append(tuple(float(v) for v in sched.step_coefficients(sched.timesteps[k])))
         sched._step_index = None
     coef_all = torch.tensor(coef_host, device=dev, dtype=torch.float32).contiguous()
-    lib = _lib.load()
+    lib = model._lib   # the loaded library (the C-ABI interpreter in the CPU self-test)
     stream = model._stream
+    stream_ptr = model._stream_ptr
     lat0 = latents.clone()
 
     def step(i):
@@ -208,22 +255,22 @@ def main():
             model.stage_inputs(plan, latents, float(t), enc, added, in_scale=scale)
         eps = model.run(plan)
         _lib.check(lib.mi355x_sd_axpby(latents.data_ptr(), eps.data_ptr(), latents.data_ptr(),
-                                       coef_all.data_ptr() + 8 * k, latents.numel(), stream.cuda_stream))
+                                       coef_all.data_ptr() + 8 * k, latents.numel(), stream_ptr))
 
     def sync_all():
-        torch.cuda.synchronize()
+        dev_sync()
         if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize()
+            dev_sync()
 
-    with torch.cuda.stream(stream):
+    with (contextlib.nullcontext() if cpu else torch.cuda.stream(stream)):
         for i in range(args.warmup):
             step(i)
         sync_all()
         t0 = time.perf_counter()
         for i in range(args.steps):
             step(args.warmup + i)
-        torch.cuda.synchronize()
+        dev_sync()
         local_elapsed = time.perf_counter() - t0   # this rank's own K steps (reported per rank; not the metric)
         sync_all()
         elapsed = time.perf_counter() - t0         # the metric's clock: barrier + synchronize on both sides
@@ -240,22 +287,26 @@ def main():
         gathered_shape = list(allz.shape)
         if not torch.isfinite(allz).all():
             raise SystemExit("non-finite latents on some rank")
+        if cpu and rank == 0:   # self-test: the ranks drew different prompts (per-rank seed) and the gather is rank-major
+            assert torch.equal(allz[:B], latents) and not torch.allclose(allz[:B], allz[B:2 * B])
 
     res = {
         "metric": {"sdxl-1024-bs8": "UNet denoising steps/sec (SD-XL 1024^2, bs=8)",
                    "sd15-512-bs1": "UNet denoising steps/sec (SD-1.5 512^2, bs=1)",
                    "sd3-1024-bs8": "MMDiT denoising steps/sec (SD3-medium 1024^2, bs=8, bf16 weights)",
                    "sd3-1024-bs8-fp8w": "MMDiT denoising steps/sec (SD3-medium 1024^2, bs=8, fp8 weights)",
-                   "sd3-1024-bs8-w8a8": "MMDiT denoising steps/sec (SD3-medium 1024^2, bs=8, fp8 weights + activations, fp8 MFMA)"}[args.workload],
+                   "sd3-1024-bs8-w8a8": "MMDiT denoising steps/sec (SD3-medium 1024^2, bs=8, fp8 weights + activations, fp8 MFMA)",
+                   "tiny-selftest": "launcher self-test (no measurement)"}[args.workload],
         "value": world * args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None,
+        "vs_baseline": None, **({"selftest": "CPU ranks + C-ABI interpreter on the tiny test UNet: launcher / rendezvous / timing "
+                                              "protocol only, NOT a measurement"} if cpu else {}),
         "dtype": ("fp8 e4m3 (block GEMM operands) + " + args.dtype) if wl.get("a8") else args.dtype, "data": "synthetic",
         "config": {"workload": args.workload, "latents": [B, cfg["in_channels"] if is_sd3 else 4, H, W], "text": [B, L, cfg["joint_attention_dim" if is_sd3 else "cross_attention_dim"]],
                    "batch_per_gpu": B, "global_batch": B * world, "scheduler": "FlowMatchEuler/28" if is_sd3 else "EulerDiscrete/30",
                    "weights": f"random-init {args.dtype} (N(0,1/fan_in)), RCCL-broadcast from rank 0" if world > 1
                    else f"random-init {args.dtype} (N(0,1/fan_in))",
-                   "parallelism": f"prompt-sharded dp{world}, no per-step collective", "hipgraph": not args.no_graph},
+                   "parallelism": f"prompt-sharded dp{world}, no per-step collective", "hipgraph": bool(model.use_graph)},
         "tflops_effective": world * args.steps * wl["gflop_step"] / 1e3 / elapsed,
     }
     if bcast_s is not None:
@@ -269,7 +320,7 @@ def main():
     # measured parity of this dtype / residual mode against the oracle (scripts/parity_report.py on the GPU box), when committed
     import glob as _glob
     pc = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*_parity.json")))
-    if pc and not is_sd3:
+    if pc and not is_sd3 and not cpu:
         pj = json.load(open(pc[-1])).get(args.dtype, {})
         key = "resid_" + args.residual
         res["parity"] = {"source": os.path.relpath(pc[-1], ROOT), "target_rel_l2": 1e-3,

@@ -1,0 +1,182 @@
+"""Full-depth denoising-loop parity cases (BASELINE.json configs 2, 3, 5) shared by the fixture generator
+(scripts/make_parity_golden.py, run HERE on the CPU: the oracle loops take minutes) and the GPU tests / reports that replay
+the same loops on the device and compare with the committed oracle trajectories under tests/golden/parity/.
+
+Weights: the seeded synthetic parameter sets of SURVEY.md 8(d), made representable in BOTH 16-bit element types (bf16 rounding,
+then magnitudes below fp16's smallest normal 2^-14 set to zero): the bf16 build, the fp16 build and the fp32 oracle multiply
+by identical numbers, so one oracle trajectory serves every device mode.  Latent state and scheduler arithmetic: float64 on
+the host for oracle and device alike, so what is compared is the accumulated error of the noise predictions only.
+
+The oracle is the torch-CPU restatement of ppdiffusers (Paddle cannot be installed here): parity against it is "unpinned"
+against Paddle itself (oracle/__init__.py).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+from tests.configs import SD15, SD3_MEDIUM, SDXL
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "parity")
+
+# name -> model family, config, latent geometry, text length, scheduler, steps, which steps' (x_in, eps) pairs are stored for the
+# teacher-forced per-step check ("all" or a list), and the reference pipeline settings the loop follows
+CASES = {
+    # BASELINE config 3 at full depth, small latents: every step stored (north_star's 1e-3 is stated on the end latents)
+    "sdxl_1x4x32x32_euler30": dict(kind="unet", cfg=SDXL, B=1, C=4, H=32, W=32, L=77, sched="euler", steps=30, keep="all"),
+    # one prompt of the headline geometry, 10 Euler steps
+    "sdxl_1x4x128x128_euler10": dict(kind="unet", cfg=SDXL, B=1, C=4, H=128, W=128, L=77, sched="euler", steps=10, keep=[0, 9]),
+    # BASELINE config 2: SD-1.5, 50 DDIM steps
+    "sd15_1x4x64x64_ddim50": dict(kind="unet", cfg=SD15, B=1, C=4, H=64, W=64, L=77, sched="ddim", steps=50, keep=[0, 25, 49]),
+    # BASELINE config 5: SD3-medium MMDiT, 28 flow-matching Euler steps (512^2 image = 64x64 latents: the CPU oracle at 128x128
+    # needs ~1.5 min per step here)
+    "sd3_1x16x64x64_flow28": dict(kind="sd3", cfg=SD3_MEDIUM, B=1, C=16, H=64, W=64, L=154, sched="flow", steps=28, keep=[0, 14, 27]),
+}
+
+
+def dual16(P):
+    """matrices / conv kernels -> values exact in bf16 AND fp16; 1-D parameters stay fp32 (the device keeps them in fp32)"""
+    out = {}
+    for k, v in P.items():
+        if v.dim() > 1:
+            w = v.to(torch.bfloat16).float()
+            w = torch.where(w.abs() < 2.0 ** -14, torch.zeros_like(w), w)
+            assert torch.equal(w.to(torch.float16).float(), w)
+            out[k] = w
+        else:
+            out[k] = v.float()
+    return out
+
+
+def case_params(case):
+    if case["kind"] == "sd3":
+        from oracle.sd3_ref import synth_sd3_params
+        return dual16(synth_sd3_params(case["cfg"], seed=1234))
+    from oracle.unet_ref import synth_unet_params
+    return dual16(synth_unet_params(case["cfg"], seed=1234))
+
+
+def case_inputs(case):
+    """(initial noise [B,C,H,W], text states [B,L,D], extra conditioning) -- fp32, seeded"""
+    g = torch.Generator().manual_seed(0)
+    cfg, B = case["cfg"], case["B"]
+    x = torch.randn(B, case["C"], case["H"], case["W"], generator=g)
+    if case["kind"] == "sd3":
+        enc = torch.randn(B, case["L"], cfg["joint_attention_dim"], generator=g)
+        return x, enc, torch.randn(B, cfg["pooled_projection_dim"], generator=g)
+    enc = torch.randn(B, case["L"], cfg["cross_attention_dim"], generator=g)
+    added = None
+    if cfg.get("addition_embed_type") == "text_time":
+        td = cfg["projection_class_embeddings_input_dim"] - 6 * cfg["addition_time_embed_dim"]
+        added = dict(text_embeds=torch.randn(B, td, generator=g),
+                     time_ids=torch.tensor([[1024., 1024., 0., 0., 1024., 1024.]]).repeat(B, 1))
+    return x, enc, added
+
+
+def schedule(case):
+    """-> (x0_scale, [(model timestep, input scale, a, b)]): step i feeds the model x * input_scale and updates
+    x <- a * x + b * prediction (the three schedulers are linear in (x, prediction) for epsilon models with eta = 0)."""
+    from oracle import schedulers_ref as S
+    n = case["steps"]
+    if case["sched"] == "euler":
+        # the reference's SDXL test scheduler (ppdiffusers/tests/pipelines/stable_diffusion_xl/test_stable_diffusion_xl.py:84-90)
+        sch = S.EulerRef(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", timestep_spacing="leading", steps_offset=1)
+        sch.set_timesteps(n)
+        sig = sch.sigmas.astype(np.float64)
+        rows = [(float(sch.timesteps[i]), float(1.0 / (sig[i] ** 2 + 1.0) ** 0.5), 1.0, float(sig[i + 1] - sig[i])) for i in range(n)]
+        return float(sch.init_noise_sigma), rows
+    if case["sched"] == "ddim":
+        # the SD test scheduler (ppdiffusers/tests/pipelines/stable_diffusion/test_stable_diffusion.py:122-128)
+        sch = S.DDIMRef(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
+                        set_alpha_to_one=False, steps_offset=1)
+        sch.set_timesteps(n)
+        rows = []
+        for t in sch.timesteps:
+            t = int(t)
+            prev = t - sch.T // n
+            a_t = float(sch.alphas_cumprod[t])
+            a_p = float(sch.alphas_cumprod[prev]) if prev >= 0 else float(sch.final_alpha_cumprod)
+            # x0 = (x - sqrt(1-a_t) e) / sqrt(a_t);  x' = sqrt(a_p) x0 + sqrt(1-a_p) e
+            ca = (a_p / a_t) ** 0.5
+            rows.append((float(t), 1.0, ca, (1 - a_p) ** 0.5 - ca * (1 - a_t) ** 0.5))
+        return 1.0, rows
+    if case["sched"] == "flow":
+        sch = S.FlowMatchEulerRef(shift=3.0)
+        sch.set_timesteps(n)
+        sig = sch.sigmas.astype(np.float64)
+        return 1.0, [(float(sch.timesteps[i]), 1.0, 1.0, float(sig[i + 1] - sig[i])) for i in range(n)]
+    raise ValueError(case["sched"])
+
+
+def kept_steps(case):
+    return list(range(case["steps"])) if case["keep"] == "all" else list(case["keep"])
+
+
+def run_loop(case, predict, x_init, on_step=None):
+    """free-running loop: predict(x_in fp32, timestep, step index) -> prediction tensor; float64 state. Returns end latents."""
+    s0, rows = schedule(case)
+    x = x_init.double() * s0
+    for i, (t, cin, a, b) in enumerate(rows):
+        x_in = (x * cin).float()
+        pred = predict(x_in, t, i).double().cpu()
+        if on_step is not None:
+            on_step(i, x_in, pred)
+        x = a * x + b * pred
+    return x
+
+
+def oracle_predictor(case, P, enc, extra):
+    if case["kind"] == "sd3":
+        from oracle.sd3_ref import sd3_forward
+        return lambda x_in, t, i: sd3_forward(P, case["cfg"], x_in, enc, extra, float(t))
+    from oracle.unet_ref import unet_forward
+    return lambda x_in, t, i: unet_forward(P, case["cfg"], x_in, int(t), enc, added_cond_kwargs=extra)
+
+
+def golden_path(name):
+    return os.path.join(GOLDEN_DIR, name + ".npz")
+
+
+def load_golden(name):
+    z = np.load(golden_path(name))
+    return {k: z[k] for k in z.files}
+
+
+def rel_l2(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return ((a - b).norm() / b.norm()).item()
+
+
+def device_report(case_name, make_model, dev="cuda"):
+    """Replay one case on the device: free-running end latents and teacher-forced per-step predictions vs the committed oracle
+    trajectory. ``make_model(case, P)`` -> object with the product's forward signature (UNet2DConditionModel /
+    SD3Transformer2DModel)."""
+    case = CASES[case_name]
+    gold = load_golden(case_name)
+    P = case_params(case)
+    x0, enc, extra = case_inputs(case)
+    model = make_model(case, P)
+    del P
+    enc_d = enc.to(dev)
+    if case["kind"] == "sd3":
+        extra_d = extra.to(dev)
+
+        def predict(x_in, t, i):
+            return model(x_in.to(dev), enc_d, extra_d, torch.tensor([float(t)], device=dev), return_dict=False)[0].float()
+    else:
+        extra_d = None if extra is None else {k: v.to(dev) for k, v in extra.items()}
+
+        def predict(x_in, t, i):
+            return model(x_in.to(dev), int(t), enc_d, added_cond_kwargs=extra_d, return_dict=False)[0].float()
+    x_end = run_loop(case, predict, x0)
+    out = {"end_latents_rel": rel_l2(x_end, gold["x_end"]), "steps": case["steps"]}
+    errs = []
+    for j, i in enumerate(gold["kept"].tolist()):
+        t = schedule(case)[1][i][0]
+        e = predict(torch.from_numpy(gold["x_in"][j]), t, i).cpu()
+        errs.append(rel_l2(e, gold["pred"][j]))
+    out["pred_rel_teacher_forced_max"] = max(errs)
+    out["pred_rel_teacher_forced_first_last"] = [errs[0], errs[-1]]
+    return out

@@ -72,6 +72,37 @@ def test_broadcast_and_prompt_sharding(world):
     assert all(a and b for a, b in res), res
 
 
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` exactly as the driver invokes it for N > 1 without a launcher (no WORLD_SIZE in the
+    environment): bench.py becomes torch.distributed.run with one process per rank, and rank 0 prints ONE JSON line carrying the
+    whole-job value, the per-rank step times and the gathered latents. CPU ranks (gloo) + the C-ABI interpreter stand in for the
+    GPUs (--selftest-cpu); the line says so."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--selftest-cpu"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    # (the gloo transport of the CPU stand-in announces its connections on stdout; RCCL does not)
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip() and "[Gloo]" not in ln and "peer ranks" not in ln]
+    assert len(lines) == 1, p.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 2 and r["warmup"] == 1 and r["scaling"] == "weak" and "selftest" in r
+    assert len(r["per_rank_ms_per_step"]) == 2 and r["gathered_latents"] == [4, 4, 8, 8]
+    assert r["config"]["global_batch"] == 2 * r["config"]["batch_per_gpu"]
+    # value = the units all ranks processed / the max-over-ranks time of the K timed steps
+    assert abs(r["value"] - 2 * 2 / (r["ms_per_step"] * 2 / 1e3)) < 1e-6 * r["value"]
+    assert r["ms_per_step"] >= max(r["per_rank_ms_per_step"]) * 0.999
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-cpu"], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in (p.stderr + p.stdout)
+
+
 def test_receiver_tables_match_the_sender_for_every_broadcast_model():
     """The receivers allocate from the *shape tables*, rank 0 sends what the *generators* produce: the broadcast pairs tensors by
     position in the dict, so names, order and shapes must agree for every model bench.py broadcasts (UNet + both text encoders)."""
