@@ -178,6 +178,15 @@ int mi355x_sd_quantize_rows(const void* x, int64_t rows, int C, int ldx, int x_r
  * adaptive_layer_norm (paddlemix/triton_ops/triton_ops.py:981-1139). */
 int mi355x_sd_adaln(const void* x, int rows, int C, int ldx, const float* scale, const float* shift, int ld_mod,
                     int rows_per_batch, float eps, void* y, int ldy, void* stream);
+/* Element type of the modulation (gate / scale / shift) and affine (weight / bias) vectors of the _ex forms below.
+ * MI355X_SD_MOD_ELEM = the build's 16-bit element type: what the REFERENCE's ops receive -- gate_msa / scale_mlp / shift_mlp are
+ * chunks of a 16-bit linear output and weight / bias 16-bit parameters, all of x.dtype (paddlemix/triton_ops/triton_ops.py:777-786,
+ * call sites PPD/models/simplified_sd3.py:62-76); ld_mod % 8 == 0 and 16-byte aligned vectors then. MI355X_SD_MOD_F32: fp32
+ * vectors (ld_mod % 4 == 0), what this library's own SD3 / DiT programs keep them in. */
+#define MI355X_SD_MOD_F32 0
+#define MI355X_SD_MOD_ELEM 1
+int mi355x_sd_adaln_ex(const void* x, int rows, int C, int ldx, const void* scale, const void* shift, int ld_mod, int mod_dtype,
+                       int rows_per_batch, float eps, void* y, int ldy, void* stream);
 /* PatchEmbed.proj operand (PPD/models/embeddings.py:148-155, 209-219): NCHW fp32 -> rows [B*(H/p)*(W/p), C*p*p] bf16,
  * columns ordered (c, py, px) like the flattened conv weight; and the inverse at the output (transformer_sd3.py:349-356):
  * rows [B*h*w, p*p*C] ordered (py, px, c) -> NCHW fp32. */
@@ -250,11 +259,18 @@ int mi355x_sd_cast_rows(const float* x, int ldx, void* y, int ldy, int64_t rows,
  * fused_adaLN_scale_residual(x, mha_out, gate_msa, scale_mlp, shift_mlp, weight, bias, epsilon) -> (resi_out, adaLN_out)
  * (triton_ops.py:758-920; unfused definition :842-847): resi_out = mha_out * gate[b] + x, adaLN_out = layer_norm(resi_out, weight,
  * bias, eps) * (1 + scale[b]) + shift[b], b = row / rows_per_batch. x, mha_out, resi_out, adaLN_out: 16-bit rows [rows][ld >= C];
- * gate / scale / shift: fp32 [rows / rows_per_batch][ld_mod >= C]; weight / bias fp32 [C] or NULL. C % 8 == 0, C <= 4096. */
+ * gate / scale / shift: fp32 [rows / rows_per_batch][ld_mod >= C]; weight / bias fp32 [C] or NULL. C % 8 == 0, C <= 4096.
+ * (fp32 vectors: this library's own convention; the reference passes them in x.dtype -- use the _ex form below for a one-for-one swap) */
 int mi355x_sd_fused_adaln_scale_residual(const void* x, int ldx, const void* mha_out, int ld_mha, const float* gate_msa,
                                          const float* scale_mlp, const float* shift_mlp, int ld_mod, int rows_per_batch,
                                          const float* weight, const float* bias, float epsilon, int rows, int C,
                                          void* resi_out, int ld_resi, void* adaln_out, int ld_out, void* stream);
+/* The one-for-one form: gate / scale / shift / weight / bias in mod_dtype (MI355X_SD_MOD_ELEM = the tensors exactly as the reference
+ * hands them to fused_adaLN_scale_residual: all of x.dtype). Arithmetic in fp32 either way. */
+int mi355x_sd_fused_adaln_scale_residual_ex(const void* x, int ldx, const void* mha_out, int ld_mha, const void* gate_msa,
+                                            const void* scale_mlp, const void* shift_mlp, int ld_mod, int mod_dtype,
+                                            int rows_per_batch, const void* weight, const void* bias, float epsilon, int rows,
+                                            int C, void* resi_out, int ld_resi, void* adaln_out, int ld_out, void* stream);
 /* split_concat(x [B,S1,3C], y [B,S2,3C]) -> q, k, v, each [B, S1+S2, C]: chunk i of x followed by chunk i of y along the sequence
  * (triton_ops.py:1692-1752); dense 16-bit tensors, C % 8 == 0. */
 int mi355x_sd_split_concat(const void* x, const void* y, void* q_out, void* k_out, void* v_out, int B, int S1, int S2, int C,

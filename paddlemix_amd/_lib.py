@@ -20,6 +20,7 @@ LIB_PATH = os.path.join(_HERE, _BUILDS[ELEM_NAME][0])
 ABI_VERSION = 9
 GEGLU, OUT_F32, SILU, GELU_TANH, PAD_BR, R_F32, CONV_KB64 = 1, 2, 4, 8, 16, 32, 64
 SDPA_LOG2 = 1
+MOD_F32, MOD_ELEM = 0, 1
 
 # name -> (restype, argtypes); must list every symbol include/mi355x_sd.h declares (tests/test_abi.py checks)
 SIGNATURES = {
@@ -45,6 +46,8 @@ SIGNATURES = {
     "mi355x_sd_quantize_rows": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int64, c_void_p, c_int, c_void_p, c_void_p]),
     "mi355x_sd_adaln": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_int,
                                 c_void_p]),
+    "mi355x_sd_adaln_ex": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int,
+                                   c_void_p]),
     "mi355x_sd_patchify": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "mi355x_sd_unpatchify": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mi355x_sd_conv3x3": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
@@ -79,6 +82,9 @@ SIGNATURES = {
     "mi355x_sd_fused_adaln_scale_residual": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                                      c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
                                                      c_void_p]),
+    "mi355x_sd_fused_adaln_scale_residual_ex": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                                        c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
+                                                        c_void_p]),
     "mi355x_sd_split_concat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "mi355x_sd_timestep_embedding": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float,
                                              c_void_p, c_int, c_void_p]),

@@ -122,8 +122,30 @@ class CUNet2DConditionModel:
 
     def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None, return_dict: bool = True, in_scale=None):
         lib, h = self.hd.lib, self.hd.h
+        cfgd = self.hd.config_dict
+        if sample.dim() != 4 or sample.shape[1] != cfgd.get("in_channels", 4):
+            raise ValueError(f"sample: expected [B, {cfgd.get('in_channels', 4)}, H, W], got {tuple(sample.shape)}")
         B, _, H, W = sample.shape
+        cross = cfgd.get("cross_attention_dim", 1280)
+        cross = cross[0] if isinstance(cross, (list, tuple)) else cross
+        if encoder_hidden_states.dim() != 3 or encoder_hidden_states.shape[0] != B or encoder_hidden_states.shape[2] != cross:
+            # the C side reads B * L * cross_attention_dim floats whatever it is handed
+            raise ValueError(f"encoder_hidden_states: expected [{B}, L, {cross}], got {tuple(encoder_hidden_states.shape)}")
         L = encoder_hidden_states.shape[1]
+        if torch.is_tensor(timestep) and timestep.numel() > 1:
+            tv = timestep.reshape(-1)
+            if tv.numel() != B or not bool((tv == tv[0]).all()):
+                # the program reads ONE timestep (the pipelines' call form, pipeline_stable_diffusion.py:866-879); the reference
+                # would broadcast a [B] tensor per sample (unet_2d_condition.py:946)
+                raise ValueError("timestep: per-sample timesteps are not implemented (pass one value, or B equal values)")
+        if cfgd.get("addition_embed_type") == "text_time":
+            for key, width in (("text_embeds", cfgd["projection_class_embeddings_input_dim"] - 6 * cfgd["addition_time_embed_dim"]),
+                               ("time_ids", 6)):
+                if added_cond_kwargs is None or key not in added_cond_kwargs:
+                    raise ValueError(f"{self.__class__} has the config param `addition_embed_type` set to 'text_time' which requires "
+                                     f"the keyword argument `{key}` to be passed in `added_cond_kwargs`")
+                if tuple(added_cond_kwargs[key].shape) != (B, width):
+                    raise ValueError(f"{key}: expected [{B}, {width}], got {tuple(added_cond_kwargs[key].shape)}")
         if self._geom != (B, H, W, L):
             nbytes = self.hd.plan(B, H, W, L)
             self._workspace = torch.empty(nbytes, device=self.device, dtype=torch.uint8)

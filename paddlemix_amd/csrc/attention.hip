@@ -25,8 +25,15 @@
 namespace sd {
 
 constexpr int ATTN_LAZY_DEFAULT = 1;
-constexpr int ATTN8_DEFAULT_MODE = -1;   // set from measurements (profiles/r02_attention8.txt)
-constexpr int ATTN8_MIN_SKV = 256;       // short-KV (cross-attention) launches stay on the four-wave, two-query-tile path
+// Lazy-maximum guard (FL bit 0): a lane's partial row sum of the freshly exponentiated tile must stay below this, else the tile
+// is redone the exact way. Every P value of the lane is <= that sum, and P is stored in the build's 16-bit type: bf16 shares
+// fp32's exponent range (any finite value converts), IEEE half tops out at 65504 -- a score more than ~16 log2 units above the
+// stale reference would become +inf in P and NaN in O. 2^15 keeps P finite in the half build with a 2x margin.
+#ifdef MI355X_SD_F16
+constexpr float LAZY_PSUM_LIMIT = 0x1p15f;
+#else
+constexpr float LAZY_PSUM_LIMIT = 0x1p60f;
+#endif
 constexpr int ATT_WAVES = 4;
 constexpr int ATT_THREADS = ATT_WAVES * 64;
 constexpr int QROWS = 32;                   // per wave
@@ -46,7 +53,8 @@ struct AttLds {
 // FL bit 0 (LAZY): the tile's scores are exponentiated against the RUNNING row maximum without first searching the tile's own
 //   maximum (~20 of the ~135 VALU instructions of a tile); the reference only has to keep exp2 inside the fp32 range -- P and
 //   the accumulators are floating point, a stale reference costs no precision -- so the exact path (maximum, rescale,
-//   exponentiate again from the intact scores) runs on the first tile and whenever a lane's partial row sum leaves [0, 2^60].
+//   exponentiate again from the intact scores) runs on the first tile and whenever a lane's partial row sum leaves
+//   [0, LAZY_PSUM_LIMIT] (2^60; 2^15 in the IEEE-half build, whose P cannot hold more than 65504).
 // FL bit 1 (LOG2, needs LAZY, no mask): the caller folded scale * log2(e) into the queries (the UNet builder folds it into
 //   the to_q weights), so a score IS the exponent: the S^T accumulators start at -reference instead of 0 (a persistent
 //   16-register C operand, rewritten only at a rescale) and exp2 needs no multiply-add per score.
@@ -235,7 +243,9 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_ker
         psum += e;
         pf[i >> 3][i & 7] = (bf16)e;
       }
-      exact = __any(!(psum <= 0x1p60f));   // overflow (or NaN): redo the tile the exact way
+      // psum >= 0, so its bit pattern orders like its value and +inf / NaN patterns sit above every finite limit: an integer
+      // compare cannot be folded away by -fno-honor-nans (this file's build flag) the way !(psum <= limit) could
+      exact = __any(__float_as_uint(psum) > __float_as_uint(LAZY_PSUM_LIMIT));   // too large for P's type / overflow / NaN
       if (exact) {
         asm volatile("; lazy-maximum overflow guard fired: scores again, exact path");
         compute_scores();
@@ -379,7 +389,7 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_ker
 
 // lazy row maximum: MI355X_SD_ATTN_LAZY=0 turns it off (default on: profiles/r02_attention.txt)
 static bool attn_lazy() {
-  static const bool dyn = getenv("MI355X_SD_ATTN8_DYN") != nullptr;   // probes flip the variables between launches
+  static const bool dyn = getenv("MI355X_SD_ATTN_DYN") != nullptr;   // probes flip the variable between launches
   static int cached = -1;
   if (cached < 0 || dyn) {
     const char* e = getenv("MI355X_SD_ATTN_LAZY");
@@ -427,17 +437,6 @@ static int launch_dp(const AttnArgs& a0, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
 
-// MI355X_SD_ATTN8: -1 = four-wave kernel everywhere; 0..3 = mode bits of the eight-wave kernel (attention8.hip) for its shapes
-static int attn8_mode() {
-  static const bool dyn = getenv("MI355X_SD_ATTN8_DYN") != nullptr;   // probes flip the variable between launches
-  static int cached = -2;
-  if (cached == -2 || dyn) {
-    const char* e = getenv("MI355X_SD_ATTN8");
-    cached = e ? atoi(e) : ATTN8_DEFAULT_MODE;
-  }
-  return cached;
-}
-
 int launch_attention(const AttnArgs& a, hipStream_t stream) {
   if (a.B <= 0 || a.H <= 0 || a.Sq <= 0 || a.Skv <= 0 || a.D <= 0) return SD_ERR_INVALID;
   if ((a.D & 7) || a.D > 160) return SD_ERR_UNSUPPORTED;
@@ -445,11 +444,6 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
       (a.o_bs & 3))
     return SD_ERR_UNSUPPORTED;
   if (!(a.scale > 0.f)) return SD_ERR_INVALID;
-  const int m8 = attn8_mode();
-  if (m8 >= 0 && a.D == 64 && !a.bias && a.Skv >= ((m8 & 4) ? 1 : ATTN8_MIN_SKV)) {
-    const int rc = launch_attention8(a, m8, stream);
-    if (rc != SD_ERR_UNSUPPORTED) return rc;
-  }
   if (a.D <= 64) return launch_dp<64>(a, stream);
   if (a.D <= 96) return launch_dp<96>(a, stream);
   return launch_dp<160>(a, stream);

@@ -212,9 +212,19 @@ int mi355x_sd_quantize_rows(const void* x, int64_t rows, int C, int ldx, int x_r
 int mi355x_sd_adaln(const void* x, int rows, int C, int ldx, const float* scale, const float* shift, int ld_mod,
                     int rows_per_batch, float eps, void* y, int ldy, void* stream) {
   if (!x || !scale || !shift || !y) return fail(SD_ERR_INVALID, "mi355x_sd_adaln: null pointer");
-  return finish(launch_adaln((const bf16*)x, rows, C, ldx, scale, shift, ld_mod, rows_per_batch, eps, (bf16*)y, ldy,
+  return finish(launch_adaln((const bf16*)x, rows, C, ldx, scale, shift, ld_mod, 0, rows_per_batch, eps, (bf16*)y, ldy,
                              S(stream)),
                 "mi355x_sd_adaln");
+}
+
+int mi355x_sd_adaln_ex(const void* x, int rows, int C, int ldx, const void* scale, const void* shift, int ld_mod, int mod_dtype,
+                       int rows_per_batch, float eps, void* y, int ldy, void* stream) {
+  if (!x || !scale || !shift || !y) return fail(SD_ERR_INVALID, "mi355x_sd_adaln_ex: null pointer");
+  if (mod_dtype != MI355X_SD_MOD_F32 && mod_dtype != MI355X_SD_MOD_ELEM)
+    return fail(SD_ERR_INVALID, "mi355x_sd_adaln_ex: mod_dtype must be MI355X_SD_MOD_F32 or MI355X_SD_MOD_ELEM");
+  return finish(launch_adaln((const bf16*)x, rows, C, ldx, scale, shift, ld_mod, mod_dtype == MI355X_SD_MOD_ELEM, rows_per_batch, eps,
+                             (bf16*)y, ldy, S(stream)),
+                "mi355x_sd_adaln_ex");
 }
 
 int mi355x_sd_patchify(const float* x_nchw, int B, int C, int H, int W, int patch, void* out, int ldo, void* stream) {
@@ -363,9 +373,23 @@ int mi355x_sd_fused_adaln_scale_residual(const void* x, int ldx, const void* mha
   if (!x || !mha_out || !gate_msa || !scale_mlp || !shift_mlp || !resi_out || !adaln_out)
     return fail(SD_ERR_INVALID, "mi355x_sd_fused_adaln_scale_residual: null pointer");
   return finish(launch_fused_adaln_scale_residual((const bf16*)x, ldx, (const bf16*)mha_out, ld_mha, gate_msa, scale_mlp, shift_mlp,
-                                                  ld_mod, rows_per_batch, weight, bias, epsilon, rows, C, (bf16*)resi_out, ld_resi,
+                                                  ld_mod, 0, rows_per_batch, weight, bias, epsilon, rows, C, (bf16*)resi_out, ld_resi,
                                                   (bf16*)adaln_out, ld_out, S(stream)),
                 "mi355x_sd_fused_adaln_scale_residual");
+}
+
+int mi355x_sd_fused_adaln_scale_residual_ex(const void* x, int ldx, const void* mha_out, int ld_mha, const void* gate_msa,
+                                            const void* scale_mlp, const void* shift_mlp, int ld_mod, int mod_dtype,
+                                            int rows_per_batch, const void* weight, const void* bias, float epsilon, int rows, int C,
+                                            void* resi_out, int ld_resi, void* adaln_out, int ld_out, void* stream) {
+  if (!x || !mha_out || !gate_msa || !scale_mlp || !shift_mlp || !resi_out || !adaln_out)
+    return fail(SD_ERR_INVALID, "mi355x_sd_fused_adaln_scale_residual_ex: null pointer");
+  if (mod_dtype != MI355X_SD_MOD_F32 && mod_dtype != MI355X_SD_MOD_ELEM)
+    return fail(SD_ERR_INVALID, "mi355x_sd_fused_adaln_scale_residual_ex: mod_dtype must be MI355X_SD_MOD_F32 or MI355X_SD_MOD_ELEM");
+  return finish(launch_fused_adaln_scale_residual((const bf16*)x, ldx, (const bf16*)mha_out, ld_mha, gate_msa, scale_mlp, shift_mlp,
+                                                  ld_mod, mod_dtype == MI355X_SD_MOD_ELEM, rows_per_batch, weight, bias, epsilon, rows,
+                                                  C, (bf16*)resi_out, ld_resi, (bf16*)adaln_out, ld_out, S(stream)),
+                "mi355x_sd_fused_adaln_scale_residual_ex");
 }
 
 int mi355x_sd_split_concat(const void* x, const void* y, void* q_out, void* k_out, void* v_out, int B, int S1, int S2, int C,

@@ -95,6 +95,27 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));
 }
 
+// 8 consecutive values of a modulation / affine vector: fp32 (M16 = false: this library's own programs keep them in fp32) or the
+// build's 16-bit element type (M16 = true: what the reference's fused ops receive -- gate / scale / shift are chunks of a 16-bit
+// linear output, weight / bias are 16-bit parameters; paddlemix/triton_ops/triton_ops.py:777-786)
+template <bool M16>
+__device__ __forceinline__ void load_mod8(const void* base, size_t idx, float (&o)[8]) {
+  if constexpr (M16) {
+    const u32x4 raw = *reinterpret_cast<const u32x4*>(static_cast<const bf16*>(base) + idx);
+    const bf16x8 t = *reinterpret_cast<const bf16x8*>(&raw);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (float)t[j];
+  } else {
+    const float* f = static_cast<const float*>(base) + idx;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(f), b = *reinterpret_cast<const f32x4*>(f + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o[j] = a[j];
+      o[4 + j] = b[j];
+    }
+  }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

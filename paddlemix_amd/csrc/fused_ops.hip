@@ -13,11 +13,12 @@
 
 namespace sd {
 
-template <int NCH>
+// M16: gate / scale / shift / weight / bias are the build's 16-bit element type (what the reference passes) instead of fp32
+template <int NCH, bool M16>
 __global__ __launch_bounds__(256) void fused_adaln_scale_residual_kernel(
-    const bf16* __restrict__ x, int ldx, const bf16* __restrict__ mha, int ldm, const float* __restrict__ gate,
-    const float* __restrict__ scale, const float* __restrict__ shift, int ld_mod, int rows_per_batch,
-    const float* __restrict__ weight, const float* __restrict__ bias, float eps, int rows, int C, bf16* __restrict__ resi,
+    const bf16* __restrict__ x, int ldx, const bf16* __restrict__ mha, int ldm, const void* __restrict__ gate,
+    const void* __restrict__ scale, const void* __restrict__ shift, int ld_mod, int rows_per_batch,
+    const void* __restrict__ weight, const void* __restrict__ bias, float eps, int rows, int C, bf16* __restrict__ resi,
     int ldr, bf16* __restrict__ out, int ldo) {
   const int lane = threadIdx.x & 63;
   const int wave_g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -34,11 +35,10 @@ __global__ __launch_bounds__(256) void fused_adaln_scale_residual_kernel(
         const u32x4 rx = *reinterpret_cast<const u32x4*>(x + (size_t)row * ldx + cc * 8);
         const u32x4 rm = *reinterpret_cast<const u32x4*>(mha + (size_t)row * ldm + cc * 8);
         const bf16x8 tx = *reinterpret_cast<const bf16x8*>(&rx), tm = *reinterpret_cast<const bf16x8*>(&rm);
-        const float* g = gate + mrow + cc * 8;
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(g), g1 = *reinterpret_cast<const f32x4*>(g + 4);
-        float r8[8];
+        float g8[8], r8[8];
+        load_mod8<M16>(gate, mrow + cc * 8, g8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r8[j] = __builtin_fmaf((float)tm[j], j < 4 ? g0[j] : g1[j - 4], (float)tx[j]);
+        for (int j = 0; j < 8; ++j) r8[j] = __builtin_fmaf((float)tm[j], g8[j], (float)tx[j]);
         // the residual leaves as a 16-bit tensor; the LayerNorm of the unfused definition sees THAT tensor
         const u32x4 pk = {pack_bf16(r8[0], r8[1]), pack_bf16(r8[2], r8[3]), pack_bf16(r8[4], r8[5]), pack_bf16(r8[6], r8[7])};
         *reinterpret_cast<u32x4*>(resi + (size_t)row * ldr + cc * 8) = pk;
@@ -71,14 +71,16 @@ __global__ __launch_bounds__(256) void fused_adaln_scale_residual_kernel(
     for (int i = 0; i < NCH; ++i) {
       const int cc = lane + 64 * i;
       if (cc < cv) {
-        const float* sc = scale + mrow + cc * 8;
-        const float* sh = shift + mrow + cc * 8;
-        float o[8];
+        float sc[8], sh[8], wv[8], bv[8], o[8];
+        load_mod8<M16>(scale, mrow + cc * 8, sc);
+        load_mod8<M16>(shift, mrow + cc * 8, sh);
+        if (weight) load_mod8<M16>(weight, (size_t)cc * 8, wv);
+        if (bias) load_mod8<M16>(bias, (size_t)cc * 8, bv);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           float y = (v[i][j] - mean) * rstd;
-          if (weight) y *= weight[cc * 8 + j];
-          if (bias) y += bias[cc * 8 + j];
+          if (weight) y *= wv[j];
+          if (bias) y += bv[j];
           o[j] = __builtin_fmaf(y, 1.0f + sc[j], sh[j]);
         }
         const u32x4 pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7])};
@@ -88,20 +90,28 @@ __global__ __launch_bounds__(256) void fused_adaln_scale_residual_kernel(
   }
 }
 
-int launch_fused_adaln_scale_residual(const bf16* x, int ldx, const bf16* mha, int ldm, const float* gate, const float* scale,
-                                      const float* shift, int ld_mod, int rows_per_batch, const float* weight, const float* bias,
-                                      float eps, int rows, int C, bf16* resi, int ldr, bf16* out, int ldo, hipStream_t stream) {
+int launch_fused_adaln_scale_residual(const bf16* x, int ldx, const bf16* mha, int ldm, const void* gate, const void* scale,
+                                      const void* shift, int ld_mod, int mod16, int rows_per_batch, const void* weight,
+                                      const void* bias, float eps, int rows, int C, bf16* resi, int ldr, bf16* out, int ldo,
+                                      hipStream_t stream) {
   if (rows <= 0 || C <= 0 || rows_per_batch <= 0) return SD_ERR_INVALID;
-  if ((C & 7) || (ldx & 7) || (ldm & 7) || (ldr & 7) || (ldo & 7) || (ld_mod & 3) || C > 4096) return SD_ERR_UNSUPPORTED;
+  if ((C & 7) || (ldx & 7) || (ldm & 7) || (ldr & 7) || (ldo & 7) || (ld_mod & (mod16 ? 7 : 3)) || C > 4096) return SD_ERR_UNSUPPORTED;
+  if (mod16 && ((reinterpret_cast<uintptr_t>(weight) | reinterpret_cast<uintptr_t>(bias)) & 15)) return SD_ERR_UNSUPPORTED;
   const int cv = C >> 3;
   int blocks = (rows + 3) / 4;
   if (blocks > 2048) blocks = 2048;
-#define SD_FA_LAUNCH(NCH)                                                                                                   \
-  hipLaunchKernelGGL((fused_adaln_scale_residual_kernel<NCH>), dim3(blocks), dim3(256), 0, stream, x, ldx, mha, ldm, gate, scale, \
+#define SD_FA_LAUNCH(NCH, M16)                                                                                                     \
+  hipLaunchKernelGGL((fused_adaln_scale_residual_kernel<NCH, M16>), dim3(blocks), dim3(256), 0, stream, x, ldx, mha, ldm, gate, scale, \
                      shift, ld_mod, rows_per_batch, weight, bias, eps, rows, C, resi, ldr, out, ldo)
-  if (cv <= 128) SD_FA_LAUNCH(2);
-  else if (cv <= 256) SD_FA_LAUNCH(4);
-  else SD_FA_LAUNCH(8);
+  if (mod16) {
+    if (cv <= 128) SD_FA_LAUNCH(2, true);
+    else if (cv <= 256) SD_FA_LAUNCH(4, true);
+    else SD_FA_LAUNCH(8, true);
+  } else {
+    if (cv <= 128) SD_FA_LAUNCH(2, false);
+    else if (cv <= 256) SD_FA_LAUNCH(4, false);
+    else SD_FA_LAUNCH(8, false);
+  }
 #undef SD_FA_LAUNCH
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }

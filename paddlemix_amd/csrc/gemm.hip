@@ -343,6 +343,13 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
     if ((long)a.M % ((long)a.Ho * a.Wo) != 0) return SD_ERR_INVALID;
   }
   if (a.rowbias && a.rows_per_batch <= 0) return SD_ERR_INVALID;
+  {   // diagnostics only: a device buffer for per-block time stamps, handed over by scripts/gemm_timeline.py as an address
+    static unsigned long long* const ts = [] {
+      const char* e = getenv("MI355X_SD_GEMM_TSTAMP");
+      return e ? reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0)) : nullptr;
+    }();
+    a.ts = ts;
+  }
   a.c_wide = !a.out_f32 && !(reinterpret_cast<uintptr_t>(a.C) & 15) && !(a.ldc & 7) && !(a.c_bstride & 7);
   const int tile = pick_tile(a);
   if (tile == 128) plan_splitk(a, 128, 128);

@@ -34,6 +34,5 @@ __device__ __forceinline__ void wait_vmcnt_imm() {
 
 // Candidate tile ids of pick_tile (gemm.hip)
 int launch_gemm_pipe(const struct GemmArgs& a, int tile, void* stream);   // SD_ERR_UNSUPPORTED: caller falls back
-int launch_gemm_persist(const struct GemmArgs& a, int tile, void* stream);   // gemm_persist.hip (experiment, env-gated)
 
 }  // namespace sd

@@ -25,7 +25,9 @@
 
 namespace sd {
 
-constexpr int GEMM_LOADERS_DEFAULT = 0;   // set from measurements (profiles/r02_gemm_loaders.txt)
+// loader waves chosen by shape (K >= 4096): -0.45 ms per SDXL bs-8 step in two A/B pairs (profiles/r03_s1_step_ab.txt), after the
+// isolated -10 % / -16 % on FF2 / the 11520-deep convs of round 2 (profiles/r02_gemm_loaders.txt)
+constexpr int GEMM_LOADERS_DEFAULT = -1;
 
 #define SD_PIPE_BARRIER()                 \
   do {                                    \
@@ -75,6 +77,11 @@ __global__ __launch_bounds__(CFG::THREADS + LW * 64, (LW ? 3 : CFG::MIN_WAVES)) 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // timeline diagnostics (p.ts != NULL only under scripts/gemm_timeline.py): thread 0 of each block stamps the 100-MHz wall clock
+  auto stamp = [&](const int slot) {
+    if (p.ts && tid == 0) p.ts[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 6 + slot] = wall_clock64();
+  };
+  stamp(0);
   const bool loader = LW > 0 && wave >= NW;              // wave-uniform
   const int pw = LW ? (loader ? wave - NW : 0) : wave;   // piece-owner index of this wave
   const int wm = wave / CFG::WAVES_N, wn = wave % CFG::WAVES_N;
@@ -253,6 +260,7 @@ __global__ __launch_bounds__(CFG::THREADS + LW * 64, (LW ? 3 : CFG::MIN_WAVES)) 
     }
   }
   SD_PIPE_BARRIER();
+  stamp(1);
   read_frag(0, 0);
   int stage = 0;
   if constexpr (LW > 0 && SG) {
@@ -333,6 +341,7 @@ __global__ __launch_bounds__(CFG::THREADS + LW * 64, (LW ? 3 : CFG::MIN_WAVES)) 
     wait_vmcnt_imm<0>();
   }
   SD_PIPE_BARRIER();
+  stamp(1);
   read_hold(0, 0);
 #pragma unroll
   for (int j = 0; j < Q; ++j) read_stream(j % QN, 0, j / SN, j % SN);
@@ -367,6 +376,10 @@ __global__ __launch_bounds__(CFG::THREADS + LW * 64, (LW ? 3 : CFG::MIN_WAVES)) 
   }
 
   const int m_w = m0 + wm * (TM * 16), n_w = n0 + wn * (TN * 16);
+  if (p.ts) {   // (the stamp must not be taken before the accumulators are final: touch one)
+    asm volatile("" ::"v"(acc[TN - 1][TM - 1][0]));
+    stamp(2);
+  }
   if (p.splitk > 1) {   // raw partial sums -> ws[split][m][n]; the epilogue runs in splitk_reduce_kernel (gemm.hip)
     float* ws = p.ws + (size_t)blockIdx.y * p.M * p.N;
 #pragma unroll
@@ -383,9 +396,21 @@ __global__ __launch_bounds__(CFG::THREADS + LW * 64, (LW ? 3 : CFG::MIN_WAVES)) 
   }
   if constexpr (LN) gemm_epilogue_ln<TM, TN>(p, acc, m_w, n_w, lane);
   else gemm_epilogue<TM, TN>(p, acc, m_w, n_w, lane);
+  if (p.ts) {
+    stamp(3);                                   // stores issued (not yet drained)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(4);                                   // this wave's stores written back
+    if (tid == 0) {
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      p.ts[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 6 + 5] = ((unsigned long long)(xcc & 15) << 32) | (unsigned)blockIdx.x;
+    }
+  }
 }
 
-// loader waves (template LW): MI355X_SD_GEMM_LOADERS=0 | 4 | 5 (5 = 4 loaders + interleaved fragment reads, template SG)
+// loader waves (template LW): MI355X_SD_GEMM_LOADERS=0 | 4 | 5 (5 = 4 loaders + interleaved fragment reads, template SG) for every
+// 256x160 launch; -1 = by shape: 4 loaders + interleaved reads where they measured a gain in isolation (K >= 4096: FF2 -10 %, the
+// 11520-deep convs -16 %, profiles/r02_gemm_loaders.txt), none for the K = 1280 launches (no gain there)
 static int gemm_loaders() {
   static const int v = [] {
     const char* e = getenv("MI355X_SD_GEMM_LOADERS");
@@ -414,7 +439,8 @@ static int launch_pipe(const GemmArgs& a, hipStream_t stream) {
   // register tiles (196-246 VGPRs) would spill into their K loops
   if constexpr (CFG::NW == 8 && !LN && CFG::BN == 160 && CFG::STAGES == 3) {
     if (gemm_loaders() == 4) return launch_pipe_lw<CONV, CFG, LN, 4>(a, stream);
-    if (gemm_loaders() == 5) return launch_pipe_lw<CONV, CFG, LN, 4, 1>(a, stream);   // + interleaved fragment reads
+    if (gemm_loaders() == 5 || (gemm_loaders() == -1 && a.K >= 4096 && a.splitk <= 1))
+      return launch_pipe_lw<CONV, CFG, LN, 4, 1>(a, stream);   // + interleaved fragment reads
   }
   static const bool attr_ok = [] {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<CONV, CFG, LN>),
@@ -455,10 +481,6 @@ int launch_gemm_pipe(const GemmArgs& a, int tile, void* stream_) {
     return a.conv ? launch_pipe<true, Cfg256, false>(a, stream) : launch_pipe<false, Cfg256, false>(a, stream);
   }
   if (tile == 320) {
-    {   // experiment, off unless MI355X_SD_GEMM_PERSIST=1: one persistent block per CU walking its tiles (gemm_persist.hip)
-      const int rc = launch_gemm_persist(a, tile, stream_);
-      if (rc != SD_ERR_UNSUPPORTED) return rc;
-    }
     if (a.geglu) return ln ? launch_pipe<false, Cfg256x320g, true>(a, stream) : launch_pipe<false, Cfg256x320g, false>(a, stream);
     if (ln) return launch_pipe<false, Cfg256x320, true>(a, stream);
     return a.conv ? launch_pipe<true, Cfg256x320, false>(a, stream) : launch_pipe<false, Cfg256x320, false>(a, stream);

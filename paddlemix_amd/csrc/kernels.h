@@ -51,6 +51,8 @@ struct GemmArgs {
   int c_rpb;              // same remap for the C rows (joint text+image token buffers of the MMDiT attention)
   long c_bstride;
   int dbg;                // ablation switches of gemm256.hip (MI355X_SD_GEMM_DBG; 0 in production)
+  unsigned long long* ts; // diagnostics (scripts/gemm_timeline.py, MI355X_SD_GEMM_TSTAMP=<device address>): per block 4 x 100-MHz
+                          // wall-clock stamps (entry, first tile landed, K loop done, stores issued) + (XCC id, block id); NULL in production
   int gm;                 // tile rasterisation group (common.h tile_coords): set by the launchers (gemm_gm())
   // split-K (filled in by launch_gemm, callers leave 0): blockIdx.y owns k-tiles [y*kc, (y+1)*kc) and stores its raw
   // fp32 accumulators to ws[y][M][N]; splitk_reduce_kernel sums the slices in fixed order and runs the epilogue.
@@ -81,7 +83,6 @@ struct AttnArgs {
   int dbg;   // ablation switches (MI355X_SD_ATTN_DBG; 0 in production)
 };
 int launch_attention(const AttnArgs& a, hipStream_t stream);
-int launch_attention8(const AttnArgs& a, int mode, hipStream_t stream);   // attention8.hip: D == 64, no mask; SD_ERR_UNSUPPORTED otherwise
 
 // GroupNorm over NHWC rows: stats -> per-(batch, channel) scale/shift, then fused normalise(+SiLU)
 int launch_groupnorm_stats(const void* x, int x_f32, int B, int HW, int C, int ldx, int groups, float eps, const float* gamma,
@@ -90,16 +91,18 @@ int groupnorm_partial_floats(int B, int HW, int C);
 int launch_scale_shift_act(const void* x, int x_f32, int B, int HW, int C, int ldx, const float* scale_shift, int silu, bf16* y,
                            int ldy, bf16* raw16, int ld_raw, hipStream_t stream);
 // y = LN(x) * (1 + scale[b]) + shift[b]  (no affine; b = row / rows_per_batch): AdaLayerNormZero / Continuous
-int launch_adaln(const bf16* x, int rows, int C, int ldx, const float* scale, const float* shift, int ld_mod,
+// mod16 != 0: scale / shift (and gate / weight / bias below) are the build's 16-bit element type instead of fp32
+int launch_adaln(const bf16* x, int rows, int C, int ldx, const void* scale, const void* shift, int ld_mod, int mod16,
                  int rows_per_batch, float eps, bf16* y, int ldy, hipStream_t stream);
 int launch_adaln_f8(const bf16* x, int rows, int C, int ldx, const float* scale, const float* shift, int ld_mod,
                     int rows_per_batch, float eps, unsigned char* y8, int ldy, float* yscale, float* yl2, hipStream_t stream);
 int launch_quantize_rows(const bf16* x, long rows, int C, int ldx, int x_rpb, long x_bstride, unsigned char* y8, int ldy,
                          float* yscale, hipStream_t stream);
 // the reference's fused custom ops with their own signatures (fused_ops.hip; triton_ops.py:758-920, 1692-1752)
-int launch_fused_adaln_scale_residual(const bf16* x, int ldx, const bf16* mha, int ldm, const float* gate, const float* scale,
-                                      const float* shift, int ld_mod, int rows_per_batch, const float* weight, const float* bias,
-                                      float eps, int rows, int C, bf16* resi, int ldr, bf16* out, int ldo, hipStream_t stream);
+int launch_fused_adaln_scale_residual(const bf16* x, int ldx, const bf16* mha, int ldm, const void* gate, const void* scale,
+                                      const void* shift, int ld_mod, int mod16, int rows_per_batch, const void* weight,
+                                      const void* bias, float eps, int rows, int C, bf16* resi, int ldr, bf16* out, int ldo,
+                                      hipStream_t stream);
 int launch_split_concat(const bf16* x, const bf16* y, bf16* o0, bf16* o1, bf16* o2, int B, int S1, int S2, int C, hipStream_t stream);
 int launch_patchify(const float* x_nchw, int B, int C, int H, int W, int p, bf16* out, int ldo, hipStream_t stream);
 int launch_unpatchify(const bf16* x, int ldx, int B, int C, int H, int W, int p, float* out_nchw, hipStream_t stream);

@@ -595,9 +595,9 @@ int launch_rmsnorm(const bf16* x, int rows, int C, int ldx, const float* weight,
 // Reference: AdaLayerNormZero.forward (ppdiffusers/ppdiffusers/models/normalization.py:72-86), AdaLayerNormContinuous
 // (:190-202), the modulated norm2 of JointTransformerBlock (attention.py:184-185) and the fused Triton op
 // adaptive_layer_norm (paddlemix/triton_ops/triton_ops.py:981-1027).  Same wave layout as layernorm_kernel.
-template <int NCH, int ROWS>
+template <int NCH, int ROWS, bool M16 = false>
 __global__ __launch_bounds__(256) void adaln_kernel(const bf16* __restrict__ x, int rows, int C, int ldx,
-                                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                                    const void* __restrict__ scale, const void* __restrict__ shift,
                                                     int ld_mod, int rows_per_batch, float eps, bf16* __restrict__ y,
                                                     int ldy) {
   const int lane = threadIdx.x & 63;
@@ -659,21 +659,16 @@ __global__ __launch_bounds__(256) void adaln_kernel(const bf16* __restrict__ x, 
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
       if (row0 + r < rows) {
-        const int bidx = (row0 + r) / rows_per_batch;
-        const float* sc = scale + (size_t)bidx * ld_mod;
-        const float* sh = shift + (size_t)bidx * ld_mod;
+        const size_t mrow = (size_t)((row0 + r) / rows_per_batch) * ld_mod;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
           const int cc = lane + 64 * i;
           if (cc < cv) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(sc + cc * 8), a1 = *reinterpret_cast<const f32x4*>(sc + cc * 8 + 4);
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(sh + cc * 8), b1 = *reinterpret_cast<const f32x4*>(sh + cc * 8 + 4);
-            float o[8];
+            float sc[8], sh[8], o[8];
+            load_mod8<M16>(scale, mrow + cc * 8, sc);
+            load_mod8<M16>(shift, mrow + cc * 8, sh);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              o[j] = __builtin_fmaf((v[r][i][j] - mean[r]) * rstd[r], 1.0f + a0[j], b0[j]);
-              o[4 + j] = __builtin_fmaf((v[r][i][4 + j] - mean[r]) * rstd[r], 1.0f + a1[j], b1[j]);
-            }
+            for (int j = 0; j < 8; ++j) o[j] = __builtin_fmaf((v[r][i][j] - mean[r]) * rstd[r], 1.0f + sc[j], sh[j]);
             u32x4 pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7])};
             *reinterpret_cast<u32x4*>(y + (size_t)(row0 + r) * ldy + cc * 8) = pk;
           }
@@ -829,10 +824,10 @@ int launch_quantize_rows(const bf16* x, long rows, int C, int ldx, int x_rpb, lo
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
 
-int launch_adaln(const bf16* x, int rows, int C, int ldx, const float* scale, const float* shift, int ld_mod,
+int launch_adaln(const bf16* x, int rows, int C, int ldx, const void* scale, const void* shift, int ld_mod, int mod16,
                  int rows_per_batch, float eps, bf16* y, int ldy, hipStream_t stream) {
   if (rows <= 0 || C <= 0 || rows_per_batch <= 0) return SD_ERR_INVALID;
-  if ((C & 7) || (ldx & 7) || (ldy & 7) || (ld_mod & 3) || C > 2560) return SD_ERR_UNSUPPORTED;
+  if ((C & 7) || (ldx & 7) || (ldy & 7) || (ld_mod & (mod16 ? 7 : 3)) || C > 2560) return SD_ERR_UNSUPPORTED;
   const int wpb = 4;
   const int cv = C >> 3;
   constexpr int R = 4;
@@ -840,15 +835,19 @@ int launch_adaln(const bf16* x, int rows, int C, int ldx, const float* scale, co
   // the per-batch scale / shift vectors add a dependent load to every iteration)
   int blocks = (rows + wpb * R - 1) / (wpb * R);
   if (blocks > 256 * 8) blocks = 256 * 8;
-  if (cv <= 128)
-    hipLaunchKernelGGL((adaln_kernel<2, R>), dim3(blocks), dim3(64 * wpb), 0, stream, x, rows, C, ldx, scale, shift, ld_mod,
-                       rows_per_batch, eps, y, ldy);
-  else if (cv <= 192)
-    hipLaunchKernelGGL((adaln_kernel<3, R>), dim3(blocks), dim3(64 * wpb), 0, stream, x, rows, C, ldx, scale, shift, ld_mod,
-                       rows_per_batch, eps, y, ldy);
-  else
-    hipLaunchKernelGGL((adaln_kernel<5, 2>), dim3(blocks), dim3(64 * wpb), 0, stream, x, rows, C, ldx, scale, shift, ld_mod,
-                       rows_per_batch, eps, y, ldy);
+#define SD_ADALN_LAUNCH(NCH, RR, M16)                                                                                         \
+  hipLaunchKernelGGL((adaln_kernel<NCH, RR, M16>), dim3(blocks), dim3(64 * wpb), 0, stream, x, rows, C, ldx, scale, shift, ld_mod, \
+                     rows_per_batch, eps, y, ldy)
+  if (mod16) {   // 16-bit modulation vectors (the reference's own operand type)
+    if (cv <= 128) SD_ADALN_LAUNCH(2, R, true);
+    else if (cv <= 192) SD_ADALN_LAUNCH(3, R, true);
+    else SD_ADALN_LAUNCH(5, 2, true);
+  } else {
+    if (cv <= 128) SD_ADALN_LAUNCH(2, R, false);
+    else if (cv <= 192) SD_ADALN_LAUNCH(3, R, false);
+    else SD_ADALN_LAUNCH(5, 2, false);
+  }
+#undef SD_ADALN_LAUNCH
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
 

@@ -192,6 +192,10 @@ Cfg parse_config(const char* json) {
   str_is("resnet_time_scale_shift", "default");
   str_is("attention_type", "default");
   str_is("mid_block_type", "UNetMidBlock2DCrossAttn");
+  str_is("data_format", "NCHW");
+  if (const JVal* v = root.get("mid_block_type"))   // null = "no mid block" in the reference (unet_2d_condition.py:553-555)
+    if (v->kind == JVal::NUL) die(MI355X_SD_ERR_UNSUPPORTED, "mi355x_sd_unet_create: config mid_block_type=null (no mid block) is not implemented");
+  if (boolean("upcast_attention", false)) die(MI355X_SD_ERR_UNSUPPORTED, "mi355x_sd_unet_create: config upcast_attention=true is not implemented");
   if (num("downsample_padding", 1) != 1 || num("conv_in_kernel", 3) != 3 || num("conv_out_kernel", 3) != 3 ||
       num("resnet_out_scale_factor", 1.0) != 1.0 || num("dropout", 0.0) != 0.0)
     die(MI355X_SD_ERR_UNSUPPORTED, "mi355x_sd_unet_create: downsample_padding / conv kernels / resnet_out_scale_factor / dropout off default");
@@ -205,7 +209,10 @@ Cfg parse_config(const char* json) {
   if (const JVal* v = root.get("block_out_channels")) {
     if (v->kind != JVal::ARR) die(MI355X_SD_ERR_INVALID, "config block_out_channels: expected a list");
     c.boc.clear();
-    for (auto& e : v->arr) c.boc.push_back((int)e.num);
+    for (auto& e : v->arr) {
+      if (e.kind != JVal::NUM) die(MI355X_SD_ERR_INVALID, "config block_out_channels: expected integers");
+      c.boc.push_back((int)e.num);
+    }
   }
   const size_t n = c.down.size();
   if (c.boc.size() != n || c.up.size() != n || n < 1) die(MI355X_SD_ERR_INVALID, "config: block lists must have one entry per level");
@@ -234,6 +241,18 @@ Cfg parse_config(const char* json) {
     }
   }
   if (c.out_channels > 4) die(MI355X_SD_ERR_UNSUPPORTED, "out_channels > 4");
+  if (c.in_channels <= 0 || c.out_channels <= 0 || c.cross_dim <= 0 || (c.cross_dim & 7))
+    die(MI355X_SD_ERR_INVALID, "config: in_channels / out_channels / cross_attention_dim must be positive (cross_attention_dim a multiple of 8)");
+  if (c.groups <= 0) die(MI355X_SD_ERR_INVALID, "config norm_num_groups must be positive");
+  for (size_t i = 0; i < n; ++i) {
+    // GroupNorm groups of whole channels, 16-byte channel chunks in every kernel, and heads that divide the width
+    if (c.boc[i] <= 0 || c.boc[i] % c.groups || (c.boc[i] & 7))
+      die(MI355X_SD_ERR_INVALID, "config block_out_channels: every entry must be a positive multiple of norm_num_groups and of 8");
+    if (c.layers_per_block[i] <= 0 || c.tlayers[i] <= 0) die(MI355X_SD_ERR_INVALID, "config layers_per_block / transformer_layers_per_block must be positive");
+    if (c.heads[i] <= 0 || c.boc[i] % c.heads[i] || ((c.boc[i] / c.heads[i]) & 7) || c.boc[i] / c.heads[i] > 160)
+      die(MI355X_SD_ERR_INVALID, "config attention_head_dim: the head count must be positive and divide block_out_channels into head "
+                                 "dims that are multiples of 8 and at most 160");
+  }
   return c;
 }
 
@@ -361,6 +380,7 @@ struct Exec {
   // packed weights
   std::map<std::string, Packed> w;
   std::vector<unsigned char> host_pack;
+  bool packed = false;        // Packer ran (it consumes the loaded fp32 tensors: it must never run twice)
   size_t weight_bytes = 0;
   unsigned char* dev_w = nullptr;
   std::map<std::string, int> temb_off, kv_off;
@@ -1039,7 +1059,7 @@ int mi355x_sd_unet_set_option(void* handle, const char* key, int value) {
     return MI355X_SD_OK;
   }
   if (!strcmp(key, "fold_softmax_scale")) {
-    if (!e->host_pack.empty() || e->dev_w) {
+    if (e->packed || e->dev_w) {
       sd::set_last_error("mi355x_sd_unet_set_option: fold_softmax_scale must be set before the weights are packed");
       return MI355X_SD_ERR_INVALID;
     }
@@ -1073,7 +1093,7 @@ int mi355x_sd_unet_load_weight(void* handle, const char* name, const void* host_
   }
   try {
     Exec* e = H_(handle);
-    if (e->dev_w) die(MI355X_SD_ERR_INVALID, "mi355x_sd_unet_load_weight: weights are already finalized");
+    if (e->dev_w || e->packed) die(MI355X_SD_ERR_INVALID, "mi355x_sd_unet_load_weight: weights are already packed / finalized");
     auto it = e->params.find(name);
     if (it == e->params.end()) die(MI355X_SD_ERR_INVALID, std::string("mi355x_sd_unet_load_weight: the configured UNet has no parameter ") + name);
     HostT& t = it->second;
@@ -1110,10 +1130,11 @@ int mi355x_sd_unet_weight_bytes(void* handle, size_t* bytes) {
   }
   try {
     Exec* e = H_(handle);
-    if (e->host_pack.empty()) {
+    if (!e->packed) {   // (not "host_pack is empty": attach / finalize release the host image, the size stays known)
       for (auto& n : e->order)
         if (!e->params[n].loaded) die(MI355X_SD_ERR_INVALID, "mi355x_sd_unet_weight_bytes: parameter " + n + " was never loaded");
       Packer(*e).run();
+      e->packed = true;
     }
     *bytes = e->weight_bytes;
     return MI355X_SD_OK;
@@ -1130,8 +1151,12 @@ int mi355x_sd_unet_pack_weights(void* handle, void* host_buffer, size_t bytes) {
   const int rc = mi355x_sd_unet_weight_bytes(handle, &need);
   if (rc) return rc;
   Exec* e = H_(handle);
-  if (!host_buffer || bytes < need || e->host_pack.empty()) {
-    sd::set_last_error("mi355x_sd_unet_pack_weights: buffer missing / too small, or the packed image was already released");
+  if (e->host_pack.empty()) {
+    sd::set_last_error("mi355x_sd_unet_pack_weights: the packed host image was already released (attach / finalize ran)");
+    return MI355X_SD_ERR_INVALID;
+  }
+  if (!host_buffer || bytes < need) {
+    sd::set_last_error("mi355x_sd_unet_pack_weights: buffer missing or too small");
     return MI355X_SD_ERR_INVALID;
   }
   memcpy(host_buffer, e->host_pack.data(), need);
@@ -1146,6 +1171,16 @@ int mi355x_sd_unet_attach_weights(void* handle, void* device_buffer, size_t byte
   if (!device_buffer || bytes < need || (reinterpret_cast<uintptr_t>(device_buffer) & 255)) {
     sd::set_last_error("mi355x_sd_unet_attach_weights: device buffer missing, too small or not 256-byte aligned");
     return MI355X_SD_ERR_INVALID;
+  }
+  if (e->dev_w != (unsigned char*)device_buffer) {
+    // the plan's launch closures and a captured graph hold ABSOLUTE weight addresses: a moved weight buffer invalidates both
+    // (mi355x_sd_unet_plan + _bind_workspace have to run again before the next forward)
+    if (e->graph) {
+      (void)hipGraphExecDestroy(e->graph);
+      e->graph = nullptr;
+    }
+    e->planned = false;
+    e->prog_sym.clear();
   }
   e->dev_w = (unsigned char*)device_buffer;
   std::vector<unsigned char>().swap(e->host_pack);
@@ -1168,7 +1203,12 @@ int mi355x_sd_unet_finalize_weights(void* handle, void* device_buffer, size_t by
   const int rc = mi355x_sd_unet_weight_bytes(handle, &need);
   if (rc) return rc;
   Exec* e = H_(handle);
-  if (!device_buffer || bytes < need || (reinterpret_cast<uintptr_t>(device_buffer) & 255) || e->host_pack.empty()) {
+  if (e->host_pack.empty()) {
+    sd::set_last_error("mi355x_sd_unet_finalize_weights: the packed host image was already released (attach / finalize ran); "
+                       "use mi355x_sd_unet_attach_weights to move to a buffer that already holds the image");
+    return MI355X_SD_ERR_INVALID;
+  }
+  if (!device_buffer || bytes < need || (reinterpret_cast<uintptr_t>(device_buffer) & 255)) {
     sd::set_last_error("mi355x_sd_unet_finalize_weights: device buffer missing, too small or not 256-byte aligned");
     return MI355X_SD_ERR_INVALID;
   }

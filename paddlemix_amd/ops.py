@@ -315,18 +315,58 @@ def linear_ex(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, w_scale: O
     return out
 
 
+def _mod_vectors(device, *ts):
+    """Modulation / affine vectors as the C ABI takes them -> (tensors, ld_mod of the first 2-D group, mod_dtype). All in the build's
+    16-bit element type (the reference's case: chunks of a 16-bit linear output, possibly strided views of it) -> MOD_ELEM, passed
+    as they are when they share a row stride and sit on 16-byte boundaries; anything else -> contiguous fp32 copies, MOD_F32."""
+    ed = _lib.elem_dtype()
+    given = [t for t in ts if t is not None]
+    two_d = [t for t in given if t.dim() == 2]
+    if all(t.dtype == ed and t.is_cuda and t.stride(-1) == 1 and t.data_ptr() % 16 == 0 for t in given) and \
+            len({t.stride(0) for t in two_d}) <= 1 and all(t.stride(0) % 8 == 0 for t in two_d):
+        return list(ts), (two_d[0].stride(0) if two_d else 0), _lib.MOD_ELEM
+    conv = [None if t is None else t.to(device=device, dtype=torch.float32).contiguous() for t in ts]
+    two_d = [t for t in conv if t is not None and t.dim() == 2]
+    return conv, (two_d[0].stride(0) if two_d else 0), _lib.MOD_F32
+
+
 def adaln(x: Tensor, scale: Tensor, shift: Tensor, rows_per_batch: int, eps: float = 1e-6,
           out: Optional[Tensor] = None) -> Tensor:
-    """y = LN_noaffine(x) * (1 + scale[b]) + shift[b]; scale/shift fp32 [batches, C] rows sharing one row stride."""
+    """y = LN_noaffine(x) * (1 + scale[b]) + shift[b]; scale/shift [batches, C] rows sharing one row stride, fp32 or the build's
+    16-bit element type (mi355x_sd_adaln_ex)."""
     lib = _lib.load()
     ldx = _rows(x, "x")
     rows, C = x.shape
     if out is None:
         out = torch.empty((rows, C), device=x.device, dtype=_lib.elem_dtype())
-    assert scale.stride(0) == shift.stride(0) and scale.dtype == torch.float32
-    check(lib.mi355x_sd_adaln(x.data_ptr(), rows, C, ldx, scale.data_ptr(), shift.data_ptr(), scale.stride(0),
-                              rows_per_batch, float(eps), out.data_ptr(), _rows(out, "out"), _stream()))
+    if scale.dtype == torch.float32 and shift.dtype == torch.float32:
+        assert scale.stride(0) == shift.stride(0)
+        check(lib.mi355x_sd_adaln(x.data_ptr(), rows, C, ldx, scale.data_ptr(), shift.data_ptr(), scale.stride(0),
+                                  rows_per_batch, float(eps), out.data_ptr(), _rows(out, "out"), _stream()))
+        return out
+    (sc, sh), ld_mod, md = _mod_vectors(x.device, scale, shift)
+    check(lib.mi355x_sd_adaln_ex(x.data_ptr(), rows, C, ldx, sc.data_ptr(), sh.data_ptr(), ld_mod, md, rows_per_batch, float(eps),
+                                 out.data_ptr(), _rows(out, "out"), _stream()))
     return out
+
+
+def adaptive_layer_norm(x: Tensor, scale: Tensor, shift: Tensor, weight: Optional[Tensor] = None, bias: Optional[Tensor] = None,
+                        epsilon: float = 1e-05) -> Tensor:
+    """The reference's fused op with its own signature (paddlemix/triton_ops/triton_ops.py:1030-1139; unfused definition
+    :1084-1088): ``layer_norm(x, weight, bias, epsilon) * (1 + scale[:, None]) + shift[:, None]``; x [B, S, C] in the build's 16-bit
+    type, scale / shift [B, C] in x.dtype as the reference passes them (fp32 also accepted)."""
+    assert x.dim() == 3, "x should be 3-dim [batch_size, seq_size, feature_dim]"
+    assert scale.shape == shift.shape and scale.dim() == 2, "scale and shift should be 2-dim [batch_size, feature_dim]"
+    B, S, C = x.shape
+    assert scale.shape[0] == B and scale.shape[1] == C, "x, scale and shift should have same batch_size / feature_dim"
+    if x.dtype != _lib.elem_dtype() or not x.is_cuda:
+        raise ValueError(f"x: expected a {_lib.elem_dtype()} cuda tensor")
+    xx = x.contiguous()
+    if weight is None and bias is None:
+        return adaln(xx.view(B * S, C), scale, shift, S, epsilon).view(B, S, C)
+    # with an affine LayerNorm: the two-output op with a zero gate (resi_out = x is discarded)
+    zero = torch.zeros_like(scale)
+    return fused_adaLN_scale_residual(xx, xx, zero, scale, shift, weight, bias, epsilon)[1]
 
 
 def patchify(x_nchw: Tensor, patch: int) -> Tensor:
@@ -516,7 +556,8 @@ def fused_adaLN_scale_residual(x: Tensor, mha_out: Tensor, gate_msa: Tensor, sca
                                weight: Optional[Tensor] = None, bias: Optional[Tensor] = None, epsilon: float = 1e-05):
     """The reference's fused op with its own signature and shape checks (paddlemix/triton_ops/triton_ops.py:758-920):
     ``resi_out = mha_out * gate_msa[:, None] + x``; ``adaLN_out = layer_norm(resi_out, weight, bias, epsilon) * (1 + scale_mlp[:, None])
-    + shift_mlp[:, None]`` -> ``(resi_out, adaLN_out)``. x / mha_out [B, S, C] in the build's 16-bit type; gate / scale / shift [B, C]."""
+    + shift_mlp[:, None]`` -> ``(resi_out, adaLN_out)``. x / mha_out [B, S, C] in the build's 16-bit type; gate / scale / shift [B, C]
+    and weight / bias [C] in x.dtype as the reference passes them (:777-786) or fp32."""
     assert x.shape == mha_out.shape, "x and mha_out should have same shape"
     assert gate_msa.shape == scale_mlp.shape == shift_mlp.shape, "gate_msa, scale_mlp and shift_mlp should have same shape"
     assert x.dim() == 3, "x should be 3-dim [batch_size, seq_size, feature_dim]"
@@ -531,12 +572,13 @@ def fused_adaLN_scale_residual(x: Tensor, mha_out: Tensor, gate_msa: Tensor, sca
     if x.dtype != ed or mha_out.dtype != ed or not x.is_cuda:
         raise ValueError(f"x / mha_out: expected {ed} cuda tensors")
     xx, mm = x.contiguous(), mha_out.contiguous()
-    f32 = lambda t: None if t is None else t.to(device=x.device, dtype=torch.float32).contiguous()  # noqa: E731
-    g, sc, sh, w, b = f32(gate_msa), f32(scale_mlp), f32(shift_mlp), f32(weight), f32(bias)
+    # gate / scale / shift / weight / bias go down in the type they come in: x.dtype in the reference (chunks of a 16-bit linear
+    # output: strided views are passed as they are), fp32 from this library's own programs
+    (g, sc, sh, w, b), ld_mod, md = _mod_vectors(x.device, gate_msa, scale_mlp, shift_mlp, weight, bias)
     resi, out = torch.empty_like(xx), torch.empty_like(xx)
-    check(_lib.load().mi355x_sd_fused_adaln_scale_residual(xx.data_ptr(), C, mm.data_ptr(), C, g.data_ptr(), sc.data_ptr(), sh.data_ptr(),
-                                                           C, S, _p(w), _p(b), float(epsilon), B * S, C, resi.data_ptr(), C,
-                                                           out.data_ptr(), C, _stream()))
+    check(_lib.load().mi355x_sd_fused_adaln_scale_residual_ex(xx.data_ptr(), C, mm.data_ptr(), C, g.data_ptr(), sc.data_ptr(),
+                                                              sh.data_ptr(), ld_mod, md, S, _p(w), _p(b), float(epsilon), B * S, C,
+                                                              resi.data_ptr(), C, out.data_ptr(), C, _stream()))
     return resi, out
 
 

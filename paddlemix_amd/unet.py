@@ -481,7 +481,8 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
         W["conv_out.b"] = get("conv_out.bias").contiguous()
 
     # ------------------------------------------------------------------ plan
-    def _build_plan(self, B: int, H: int, Wd: int, L: int, masked: bool = False, controlnet: bool = False) -> _Plan:
+    def _build_plan(self, B: int, H: int, Wd: int, L: int, masked: bool = False, controlnet: bool = False,
+                    self_mask_len: int = 0) -> _Plan:
         cfg, lib, dev, W = self.cfg, self._lib, self.device, self.w
         stream = self._stream_ptr
         boc = cfg["block_out_channels"]
@@ -584,6 +585,14 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
 
         def attention(q: _V, k: _V, v: _V, out: _V, heads, sq, skv, bias=None, accum: Optional[float] = None, log2=False):
             d = q.C // heads
+            if log2 and bias is not None:
+                # q already carries head_dim^-0.5 * log2(e) (folded into to_q at load) but the masked kernel exponentiates
+                # exp2((q.k + bias / scale) * scale * log2(e)): scale = ln 2 makes that exp2(q.k + bias * log2(e)) -- the same softmax
+                assert accum is None
+                args = (q.p, k.p, v.p, bias, out.p, B, heads, sq, skv, d, sq * q.ld, q.ld, skv * k.ld, k.ld, skv * v.ld, v.ld,
+                        sq * out.ld, out.ld, skv, 0, 0, math.log(2.0))
+                emit(lib.mi355x_sd_sdpa, args + (stream,), "attn", 4.0 * B * heads * sq * skv * d, f"{B}x{heads}x{sq}x{skv}x{d}m")
+                return
             if log2:
                 assert bias is None and accum is None and d == 64
                 emit(lib.mi355x_sd_sdpa_ex, (q.p, k.p, v.p, None, out.p, B, heads, sq, skv, d, sq * q.ld, q.ld, skv * k.ld, k.ld,
@@ -611,6 +620,10 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
         plan.out = persist((B, cfg["out_channels"], H, Wd), torch.float32)
         plan.enc_bias = persist((B, L), torch.float32) if masked else None
         enc_bias = plan.enc_bias.data_ptr() if masked else None
+        # `attention_mask`: a key mask over the LATENT tokens, added to every self-attention (unet_2d_condition.py:916-923 ->
+        # BasicTransformerBlock.attn1, attention.py:417-423)
+        plan.self_bias = persist((B, self_mask_len), torch.float32) if self_mask_len else None
+        self_bias = plan.self_bias.data_ptr() if self_mask_len else None
 
         # ---- time / added-condition embedding (unet_2d_condition.py:933-1030) ----
         t0 = persist((B, boc[0]), _lib.elem_dtype())
@@ -783,7 +796,13 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
                 else:
                     lnorm(hid, b + ".norm1", ln)
                     linear(ln, b + ".attn1.qkv", qkv, bias=False)
-                attention(qkv.cols(0, c), qkv.cols(c, c), qkv.cols(2 * c, c), ao, heads, hw, hw, log2=b in self._log2_blocks)
+                if self_bias is not None and hw != self_mask_len:
+                    # the reference pads a mask of the wrong length by target_length zeros (Attention.prepare_attention_mask,
+                    # attention_processor.py:616-622) and the add onto the [.., hw, hw] scores then fails on the shapes
+                    raise ValueError(f"attention_mask has {self_mask_len} key tokens but {b}.attn1 attends over {hw} latent tokens "
+                                     "(the mask must match the token count of every attention level)")
+                attention(qkv.cols(0, c), qkv.cols(c, c), qkv.cols(2 * c, c), ao, heads, hw, hw, bias=self_bias,
+                          log2=b in self._log2_blocks)
                 linear(ao, b + ".attn1.out", hid, R=hid)
                 if self.fold_ln:
                     ln_linear(hid, b + ".attn2.q", q2)
@@ -927,19 +946,22 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
             raise ValueError("this UNet has no IP-Adapter (config encoder_hid_dim_type != 'ip_image_proj')")
         self.ip_adapter_scale = float(scale)
 
-    def _get_plan(self, B, H, W, L, masked: bool = False, controlnet: bool = False) -> _Plan:
+    def _get_plan(self, B, H, W, L, masked: bool = False, controlnet: bool = False, self_mask_len: int = 0) -> _Plan:
         if masked and self._ip:
             raise NotImplementedError("encoder_attention_mask together with IP-Adapter image tokens")
-        key = (B, H, W, L, masked, controlnet, self.ip_adapter_scale)
+        key = (B, H, W, L, masked, controlnet, self.ip_adapter_scale, self_mask_len)
         if key not in self._plans:
-            self._plans[key] = self._build_plan(B, H, W, L, masked, controlnet)
+            self._plans[key] = self._build_plan(B, H, W, L, masked, controlnet, self_mask_len)
         return self._plans[key]
 
     def stage_inputs(self, plan: _Plan, sample, timestep, encoder_hidden_states, added_cond_kwargs=None,
                      in_scale: Optional[float] = None, encoder_attention_mask=None,
                      down_block_additional_residuals=None, mid_block_additional_residual=None, class_labels=None,
-                     timestep_cond=None) -> None:
+                     timestep_cond=None, attention_mask=None) -> None:
         cfg = self.cfg
+        if getattr(plan, "self_bias", None) is not None:
+            # (1 - mask) * -10000 as an additive bias on the self-attention scores (unet_2d_condition.py:916-923)
+            plan.self_bias.copy_((1.0 - attention_mask.to(torch.float32)) * -10000.0, non_blocking=True)
         if plan.tcond is not None:
             if timestep_cond is None:
                 plan.tcond.zero_()   # cond_proj has no bias: a zero condition adds nothing, like the reference's `condition is None`
@@ -972,9 +994,19 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
             # (1 - mask) * -10000 as an additive bias (unet_2d_condition.py:921-927)
             plan.enc_bias.copy_((1.0 - encoder_attention_mask.to(torch.float32)) * -10000.0, non_blocking=True)
         if torch.is_tensor(timestep):
-            plan.t.copy_(timestep.reshape(-1)[:1].to(torch.float32), non_blocking=True)
+            tv = timestep.reshape(-1)
+            if tv.numel() > 1 and (tv.numel() != plan.B or not bool((tv == tv[0]).all())):
+                # the program reads ONE timestep (what the pipelines pass, pipeline_stable_diffusion.py:866-879); the reference would
+                # broadcast a [B] tensor per sample (unet_2d_condition.py:946)
+                raise ValueError("timestep: per-sample timesteps are not implemented (pass one value, or B equal values)")
+            plan.t.copy_(tv[:1].to(torch.float32), non_blocking=True)
         else:
             plan.t.fill_(float(timestep))
+        if tuple(sample.shape) != tuple(plan.sample.shape):
+            raise ValueError(f"sample of shape {tuple(sample.shape)}, expected {tuple(plan.sample.shape)}")
+        if encoder_hidden_states.dim() != 3 or encoder_hidden_states.shape[-1] != plan.enc.shape[1]:
+            raise ValueError(f"encoder_hidden_states of shape {tuple(encoder_hidden_states.shape)}, expected "
+                             f"[{plan.B}, {plan.L}, {plan.enc.shape[1]}]")
         s = sample.to(torch.float32)
         if cfg["center_input_sample"]:
             s = 2 * s - 1.0
@@ -1007,8 +1039,11 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
                 attention_mask=None, cross_attention_kwargs=None, added_cond_kwargs=None,
                 down_block_additional_residuals=None, mid_block_additional_residual=None,
                 encoder_attention_mask=None, return_dict: bool = True):
+        self_mask_len = 0
         if attention_mask is not None:
-            raise NotImplementedError("UNet2DConditionModel(mi355x): `attention_mask` is not implemented on this path")
+            if attention_mask.dim() != 2 or attention_mask.shape[0] != sample.shape[0]:
+                raise ValueError(f"attention_mask: expected [batch, key_tokens], got {tuple(attention_mask.shape)}")
+            self_mask_len = int(attention_mask.shape[1])
         # (class_labels without a class embedding are ignored, like unet_2d_condition.py:953)
         controlnet = down_block_additional_residuals is not None
         if controlnet != (mid_block_additional_residual is not None):
@@ -1016,12 +1051,12 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
                                       "`mid_block_additional_residual` (the T2I-adapter form is not implemented)")
         ctrl = dict(down_block_additional_residuals=down_block_additional_residuals,
                     mid_block_additional_residual=mid_block_additional_residual, class_labels=class_labels,
-                    timestep_cond=timestep_cond)
+                    timestep_cond=timestep_cond, attention_mask=attention_mask)
         if not self._emulated and (not sample.is_cuda or not encoder_hidden_states.is_cuda):
             raise _lib.MI355XError("inputs must be GPU tensors (no CPU fallback)")
         B, _, H, W = sample.shape
         L = encoder_hidden_states.shape[1]
-        plan = self._get_plan(B, H, W, L, encoder_attention_mask is not None, controlnet)
+        plan = self._get_plan(B, H, W, L, encoder_attention_mask is not None, controlnet, self_mask_len)
         if self._emulated:
             self.stage_inputs(plan, sample, timestep, encoder_hidden_states, added_cond_kwargs,
                               encoder_attention_mask=encoder_attention_mask, **ctrl)

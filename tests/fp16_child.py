@@ -3,6 +3,7 @@ per process) and prints one JSON line of parity numbers for the IEEE-half build 
 
   python tests/fp16_child.py cpu   -- host logic through the ABI emulator (fp32 math, fp16 stores)
   python tests/fp16_child.py gpu   -- the HIP kernels of libmi355x_sd_f16.so on cuda:0
+  python tests/fp16_child.py gpu-kernels   -- the kernel-level part of the above only
 """
 import json
 import math
@@ -168,11 +169,31 @@ def main(mode):
         got = ops.sdpa(q.cuda(), k.cuda(), v.cuda()).float().cpu()
         ref = F.scaled_dot_product_attention(*(t.float().permute(0, 2, 1, 3) for t in (q, k, v))).permute(0, 2, 1, 3)
         res["sdpa"] = _rel(got, ref)
+        # lazy row maximum in the half build: one LATE key (tile 3) scores 20-30 nats above everything the first
+        # tile holds for a few queries -- exponentiated against the stale tile-0 reference that is e^20+ > 65504, which P's
+        # fp16 cannot hold; the guard (LAZY_PSUM_LIMIT, attention.hip) must send those tiles down the exact path. Plain and
+        # base-2 (scale folded into q) flavours.
+        qs, ks_, vs = (torch.randn(2, 320, 5, 64, generator=g) for _ in range(3))
+        ks_ = ks_ * 0.3
+        ks_[:, 200] = 3.0 * qs[:, 17]            # score of query 17 against key 200: 3 |q|^2 / 8 ~ 24 nats
+        qs, ks_, vs = h(qs), h(ks_), h(vs)
+        ref = F.scaled_dot_product_attention(*(t.float().permute(0, 2, 1, 3) for t in (qs, ks_, vs))).permute(0, 2, 1, 3)
+        got = ops.sdpa(qs.cuda(), ks_.cuda(), vs.cuda()).float().cpu()
+        res["sdpa_late_spike"] = dict(finite=bool(torch.isfinite(got).all()), rel=_rel(got, ref),
+                                      spike_nats=float((qs[:, 17].float() * ks_[:, 200].float()).sum(-1).max() / 8.0))
+        q2 = h(qs.float() * (0.125 * 1.4426950408889634))    # what the UNet builder folds into to_q
+        ref2 = F.scaled_dot_product_attention(*(t.float().permute(0, 2, 1, 3) for t in (q2, ks_, vs)),
+                                              scale=0.6931471805599453).permute(0, 2, 1, 3)
+        got2 = ops.sdpa(q2.cuda(), ks_.cuda(), vs.cuda(), log2=True).float().cpu()
+        res["sdpa_late_spike_log2"] = dict(finite=bool(torch.isfinite(got2).all()), rel=_rel(got2, ref2))
         xg = h(torch.randn(2, 256, 128, generator=g) * 2 + 0.5)
         gam, bet = torch.randn(128, generator=g), torch.randn(128, generator=g)
         got = ops.group_norm(xg.cuda(), gam.cuda(), bet.cuda(), 32, 1e-5, True).float().cpu()
         ref = F.silu(F.group_norm(xg.float().permute(0, 2, 1), 32, gam, bet, 1e-5)).permute(0, 2, 1)
         res["group_norm_silu"] = _rel(got, ref)
+        if mode == "gpu-kernels":   # the kernel-level checks only (seconds)
+            print(json.dumps(res))
+            return
         res["unet"] = unet_cases(lambda cfg, P: UNet2DConditionModel(cfg, P, device="cuda:0"), "cuda:0")
         res["fp32_residual"] = fp32_residual_cases(
             lambda cfg, P, rd: UNet2DConditionModel(cfg, P, device="cuda:0", residual_dtype=rd), "cuda:0", True)

@@ -50,6 +50,55 @@ def test_packed_weights_and_plan_equal_python_builder(cfg, rd):
     assert nbytes > 0 and nbytes % 256 == 0
 
 
+def test_weight_life_cycle_after_the_host_image_is_released():
+    """attach / finalize release the packed host image; every later call has to work from the cached size, never repack
+    from the (consumed) fp32 tensors. pack -> attach -> weight_bytes / attach again / pack: sizes stay, pack says why it cannot,
+    a moved weight buffer drops the plan (its launches hold absolute weight addresses)."""
+    lib = _lib.load()
+    P = synth_unet_params(TINY, seed=5)
+    hd = UNetHandle(TINY)
+    hd.load(P)
+    n = hd.weight_bytes()
+    image = hd.pack()
+    hd.attach(image)
+    assert hd.weight_bytes() == n                       # (used to re-run the packer on emptied tensors: SIGSEGV)
+    hd.plan(2, 16, 16, 7)
+    assert hd.num_launches() > 50
+    hd.attach(image)                                    # same buffer again: the plan stays
+    assert hd.num_launches() > 50
+    raw = torch.empty(n + 256, dtype=torch.uint8)
+    image2 = raw[(-raw.data_ptr()) % 256:][:n]
+    image2.copy_(image)
+    hd.attach(image2)                                   # the buffer moved: plan (absolute addresses) and graph are dropped
+    assert hd.num_launches() == 0
+    ws = ctypes.c_size_t()
+    assert lib.mi355x_sd_unet_bind_workspace(hd.h, image2.data_ptr(), n) != 0 and b"no plan" in lib.mi355x_sd_last_error()
+    assert hd.plan(2, 16, 16, 7) > 0 and hd.num_launches() > 50
+    buf = torch.empty(n, dtype=torch.uint8)
+    assert lib.mi355x_sd_unet_pack_weights(hd.h, buf.data_ptr(), n) != 0 and b"already released" in lib.mi355x_sd_last_error()
+    assert lib.mi355x_sd_unet_finalize_weights(hd.h, image2.data_ptr(), n, None) != 0 and b"already released" in lib.mi355x_sd_last_error()
+    shp = (ctypes.c_int64 * 4)(*P["conv_in.weight"].shape)
+    assert lib.mi355x_sd_unet_load_weight(hd.h, b"conv_in.weight", P["conv_in.weight"].data_ptr(), shp, 4, 0) != 0   # too late
+    del ws
+
+
+def test_config_values_are_validated_at_create():
+    """what parse_config cannot build must fail at create with a message -- a zero head count used to be an integer
+    division by zero (SIGFPE) while packing, `mid_block_type: null` silently built a mid block."""
+    lib = _lib.load()
+    for bad, frag in ((dict(TINY, attention_head_dim=0), b"attention_head_dim"), (dict(TINY, attention_head_dim=3), b"attention_head_dim"),
+                      (dict(TINY, block_out_channels=(64, 100)), b"block_out_channels"), (dict(TINY, norm_num_groups=0), b"norm_num_groups"),
+                      (dict(TINY, mid_block_type=None), b"mid_block_type"), (dict(TINY, upcast_attention=True), b"upcast_attention"),
+                      (dict(TINY, data_format="NHWC"), b"data_format"), (dict(TINY, layers_per_block=0), b"layers_per_block"),
+                      (dict(TINY, cross_attention_dim=12), b"cross_attention_dim")):
+        with pytest.raises(_lib.MI355XError):
+            UNetHandle(bad)
+        assert frag in lib.mi355x_sd_last_error(), (bad, lib.mi355x_sd_last_error())
+    h = ctypes.c_void_p()
+    assert lib.mi355x_sd_unet_create(b'{"block_out_channels": [64, "128"], "down_block_types": ["DownBlock2D", "DownBlock2D"], '
+                                     b'"up_block_types": ["UpBlock2D", "UpBlock2D"]}', ctypes.byref(h)) != 0
+
+
 def test_refusals_are_loud():
     lib = _lib.load()
     for bad in (dict(TINY, class_embed_type="timestep"), dict(TINY, time_cond_proj_dim=32), dict(TINY, attention_type="gated"),

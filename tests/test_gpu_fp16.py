@@ -7,12 +7,24 @@ from tests.test_fp16_mode import run_child
 pytestmark = pytest.mark.gpu
 
 
-def test_fp16_build_kernels_and_unet_parity():
-    r = run_child("gpu")
+def _check_kernels(r):
     assert r["elem"] == "fp16" and r["elem_dtype_symbol"] == 1
     # fp32 accumulation, one fp16 rounding of the result: ~2^-11 relative
     assert r["linear"] < 6e-4 and r["conv3x3"] < 6e-4 and r["group_norm_silu"] < 6e-4, r
     assert r["sdpa"] < 1e-3, r     # + the fp16 rounding of the probabilities
+    # a late key >= 12 nats above the first tile's maximum: the lazy-maximum guard of the half build must fire (no inf in P)
+    assert r["sdpa_late_spike"]["spike_nats"] > 12, r["sdpa_late_spike"]
+    for key in ("sdpa_late_spike", "sdpa_late_spike_log2"):
+        assert r[key]["finite"] and r[key]["rel"] < 1.5e-3, (key, r[key])
+
+
+def test_fp16_build_kernels():
+    _check_kernels(run_child("gpu-kernels"))
+
+
+def test_fp16_build_kernels_and_unet_parity():
+    r = run_child("gpu")
+    _check_kernels(r)
     for name, c in r["unet"].items():
         assert c["finite"], name
         # north_star asks for 1e-3 of the CPU reference: with 16-bit weights the fp32 oracle itself moves by 0.7-1.2e-3

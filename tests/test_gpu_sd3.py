@@ -290,6 +290,42 @@ def test_fused_adaln_scale_residual_reference_signature(B, S, C, affine):
         ops.fused_adaLN_scale_residual(x.cuda(), mha[:, :-1].cuda(), gate.cuda(), scale.cuda(), shift.cuda())
 
 
+@pytest.mark.parametrize("B,S,C,affine", [(2, 300, 1536, True), (1, 77, 64, False), (3, 1025, 1152, False)])
+def test_fused_ops_take_the_reference_s_16bit_modulation_vectors(B, S, C, affine):
+    """gate / scale / shift exactly as the reference builds them (paddlemix/triton_ops/triton_ops.py:777-808, call sites
+    simplified_sd3.py:62-76): chunks of ONE 16-bit linear output [B, 6C] -- x.dtype tensors that are strided views -- and 16-bit
+    LayerNorm parameters. They go down to the kernels untouched (MI355X_SD_MOD_ELEM), for both fused ops."""
+    import torch.nn.functional as F
+    from paddlemix_amd import _lib, ops
+    ops.init(0)
+    ed = _lib.elem_dtype()
+    g = torch.Generator().manual_seed(7 * B + S + C)
+    x, mha = (torch.randn(B, S, C, generator=g) * 2).to(ed).cuda(), torch.randn(B, S, C, generator=g).to(ed).cuda()
+    mod = (torch.randn(B, 6 * C, generator=g) * 0.5).to(ed).cuda()            # linear1(silu(temb)) of the reference, x.dtype
+    shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = mod.chunk(6, dim=1)
+    assert not gate_msa.is_contiguous() and gate_msa.dtype == ed
+    w = (1 + 0.1 * torch.randn(C, generator=g)).to(ed).cuda() if affine else None
+    b = (0.1 * torch.randn(C, generator=g)).to(ed).cuda() if affine else None
+    resi, out = ops.fused_adaLN_scale_residual(x, mha, gate_msa, scale_mlp, shift_mlp, w, b, 1e-6)
+    f = lambda t: t.float().cpu()  # noqa: E731
+    resi_ref = (f(mha).double() * f(gate_msa).double()[:, None] + f(x).double()).float()
+    assert torch.equal(resi.cpu(), resi_ref.to(ed))
+    ln = F.layer_norm(resi_ref.to(ed).float(), (C,), None if w is None else f(w), None if b is None else f(b), 1e-6)
+    ref = ln * (1 + f(scale_mlp)[:, None]) + f(shift_mlp)[:, None]
+    assert ((f(out) - ref).norm() / ref.norm()).item() < 4e-3
+    # the same numbers handed over as fp32 copies give the same result bit for bit (fp32 arithmetic either way)
+    resi32, out32 = ops.fused_adaLN_scale_residual(x, mha, gate_msa.float(), scale_mlp.float(), shift_mlp.float(),
+                                                   None if w is None else w.float(), None if b is None else b.float(), 1e-6)
+    assert torch.equal(resi32, resi) and torch.equal(out32, out)
+    # adaptive_layer_norm(x, scale, shift[, weight, bias]) (triton_ops.py:1030-1139), same operand types
+    y = ops.adaptive_layer_norm(x, scale_msa, shift_msa, w, b, 1e-6)
+    ref = F.layer_norm(f(x), (C,), None if w is None else f(w), None if b is None else f(b), 1e-6) * (1 + f(scale_msa)[:, None]) \
+        + f(shift_msa)[:, None]
+    assert y.shape == x.shape and y.dtype == ed and ((f(y) - ref).norm() / ref.norm()).item() < 4e-3
+    if not affine:
+        assert torch.equal(y, ops.adaptive_layer_norm(x, scale_msa.float(), shift_msa.float(), None, None, 1e-6))
+
+
 @pytest.mark.parametrize("B,S1,S2,C", [(2, 1024, 154, 1536), (1, 5, 3, 64), (3, 4096, 77, 1152)])
 def test_split_concat_reference_signature(B, S1, S2, C):
     """paddlemix.triton_ops.split_concat (triton_ops.py:1692-1752): q / k / v = concat(x.chunk(3)[i], y.chunk(3)[i], axis=1), exact."""

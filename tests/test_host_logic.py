@@ -276,8 +276,43 @@ def test_encoder_attention_mask_semantics():
     assert torch.allclose(masked, trunc, rtol=1e-3, atol=1e-3)
     ref = U.unet_forward(Pb, cfg, sample, 10, enc, encoder_attention_mask=m)
     assert _rel(masked, ref) < 2e-2
-    with pytest.raises(NotImplementedError):
-        model(sample, 10, enc, attention_mask=torch.ones(2, 64))
+
+
+@pytest.mark.parametrize("head_dim64", [False, True], ids=["d16", "d64-folded-scale"])
+def test_self_attention_mask_semantics(head_dim64):
+    """`attention_mask` of UNet2DConditionModel.forward (unet_2d_condition.py:916-923): a keep/discard mask over the LATENT tokens,
+    turned into a -10000 bias and added to the scores of every self-attention (BasicTransformerBlock.attn1). It has to match the
+    token count of every attention level (Attention.prepare_attention_mask pads a wrong length by target_length and the add then
+    fails on the shapes, attention_processor.py:616-622): the reference's tiny test geometry, where all attention runs at one
+    resolution, is the usable case. head_dim 64: the softmax scale is folded into to_q and the mask goes in base-2 units."""
+    cfg = dict(TINY, attention_head_dim=2) if head_dim64 else TINY       # 128 channels / 2 heads = 64
+    P = synth_unet_params(cfg, seed=1234)
+    Pb = {k: v.to(torch.bfloat16).float() if v.dim() > 1 else v for k, v in P.items()}
+    sample, enc, _ = _inputs(cfg, 2, 16, 16, L=7)                        # attention at 8 x 8 = 64 latent tokens
+    model = UNet2DConditionModel(cfg, P, _test_backend=Emulator())
+    if head_dim64:
+        assert model._log2_blocks
+    none = model(sample, 10, enc).sample
+    keep = model(sample, 10, enc, attention_mask=torch.ones(2, 64)).sample
+    assert torch.allclose(none, keep, rtol=1e-3, atol=1e-4)
+    g = torch.Generator().manual_seed(3)
+    m = (torch.rand(2, 64, generator=g) > 0.4).float()
+    m[:, 0] = 1
+    masked = model(sample, 10, enc, attention_mask=m).sample
+    assert _rel(masked, none) > 1e-2                                       # the mask does something
+    ref = U.unet_forward(Pb, cfg, sample, 10, enc, attention_mask=m)
+    assert _rel(masked, ref) < 2e-2
+    both = model(sample, 10, enc, attention_mask=m, encoder_attention_mask=torch.ones(2, 7)).sample   # both masks together
+    assert torch.allclose(both, masked, rtol=1e-3, atol=1e-4)
+    with pytest.raises(ValueError, match="key tokens"):                   # wrong length: the reference fails on the shapes
+        model(sample, 10, enc, attention_mask=torch.ones(2, 63))
+    with pytest.raises(ValueError, match="batch"):
+        model(sample, 10, enc, attention_mask=torch.ones(64))
+    # a UNet with attention at several resolutions cannot take one mask length (SD-1.5 / SDXL: no pipeline passes it)
+    multi = UNet2DConditionModel(MINI_XL, synth_unet_params(MINI_XL, seed=1), _test_backend=Emulator())
+    s2, e2, a2 = _inputs(MINI_XL, 1, 16, 16, L=7)
+    with pytest.raises(ValueError, match="key tokens"):
+        multi(s2, 10, e2, added_cond_kwargs=a2, attention_mask=torch.ones(1, 64))
 
 
 def test_seam_objects_refuse_cpu_tensors():
