@@ -49,6 +49,7 @@ WORKLOADS = {
     # the same with fp8 activations into the block GEMMs: W8A8 on the fp8 matrix pipe (v_mfma_scale_f32_16x16x128_f8f6f4)
     "sd3-1024-bs8-w8a8": dict(cfg=SD3_MEDIUM, B=8, H=128, W=128, L=154, gflop_step=None, sd3=True, fp8=True, a8=True),
 }
+PARITY_CASE = "sdxl_1x4x32x32_euler30"   # tests/parity_cases.py: full SDXL parameter set, 30 Euler steps, committed oracle trajectory
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16 / fp16, MI355X_MICROARCH.md chip table
 PEAK_FP8_TFLOPS = 5000.0   # dense MFMA fp8 (the W8A8 workload's block GEMMs)
 
@@ -76,6 +77,10 @@ def parse():
     # the one-JSON-line contract on CPU ranks (gloo) with the C-ABI interpreter of tests/abi_emulator.py standing in for the
     # library on the tiny test UNet. The line it prints says "selftest": it is never a measurement.
     ap.add_argument("--selftest-cpu", action="store_true", help=argparse.SUPPRESS)
+    # the child process of the "parity_mode" leg (one element type per process): fp16 elements + fp32 residual stream on the seeded
+    # weights of tests/parity_cases.py, a short timed loop at the headline geometry, then the 30-Euler-step replay against the
+    # committed oracle trajectory
+    ap.add_argument("--parity-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -112,6 +117,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.parity_child:
+        args.dtype, args.residual, args.no_cpu_baseline, args.no_roofline, args.no_parity_mode = "fp16", "fp32", True, True, True
+        args.workload = "sdxl-1024-bs8"
     cpu = args.selftest_cpu
     if cpu:
         dev = torch.device("cpu")
@@ -155,7 +163,12 @@ def main():
     if with_te:
         from paddlemix_amd.clip import CLIPTextModel, CLIPTextModelWithProjection, clip_param_shapes, synth_clip_params
         te_cfgs = {"text_encoder": (CLIP_L, CLIPTextModel), "text_encoder_2": (CLIP_BIGG, CLIPTextModelWithProjection)}
-    if rank == 0:
+    if args.parity_child:
+        # the seeded CPU weights the committed oracle trajectory was computed with (exact in fp16 and bf16)
+        from tests import parity_cases as PC
+        P = wire_params({k: v.to(dev) for k, v in PC.case_params(PC.CASES[PARITY_CASE]).items()}, ed)
+        PT = {}
+    elif rank == 0:
         P = wire_params(synth_unet_params(cfg, seed=1234, device=dev), ed)
         PT = {k: wire_params(synth_clip_params(c, seed=77 + i, device=dev), ed) for i, (k, (c, _)) in enumerate(te_cfgs.items())}
     else:
@@ -323,10 +336,19 @@ def main():
     if pc and not is_sd3 and not cpu:
         pj = json.load(open(pc[-1])).get(args.dtype, {})
         key = "resid_" + args.residual
+        # (scripts/parity_loops.py on the GPU box: full-depth loops against the committed oracle trajectories)
         res["parity"] = {"source": os.path.relpath(pc[-1], ROOT), "target_rel_l2": 1e-3,
-                         "forward_rel_l2": {k: v.get(key) for k, v in pj.get("forward", {}).items()},
-                         "euler30_end_latents_rel_l2": {k: v.get(key, {}).get("end_latents_rel") for k, v in pj.get("loop", {}).items()},
+                         "end_latents_rel_l2": {c: m[key]["end_latents_rel"] for c, m in pj.items() if isinstance(m, dict) and key in m},
+                         "pred_rel_l2_teacher_forced_max": {c: m[key]["pred_rel_teacher_forced_max"] for c, m in pj.items()
+                                                            if isinstance(m, dict) and key in m},
                          "oracle": "torch-CPU restatement of ppdiffusers (Paddle unavailable: unpinned)"}
+
+    if args.parity_child:
+        # the SAME model object that was just timed replays the 30-step loop of the fixture (float64 latent state on the host)
+        from tests import parity_cases as PC
+        rep = PC.device_report(PARITY_CASE, model=model, dev=dev)
+        res["parity_live"] = dict(rep, case=PARITY_CASE, target_rel_l2=1e-3,
+                                  oracle="committed trajectory of the torch-CPU restatement of ppdiffusers (tests/golden/parity; unpinned)")
 
     # ---- roofline of the dominant kernel: per-launch HIP-event timing on the launch stream, one eager step ----
     if rank == 0 and not args.no_roofline:
@@ -413,6 +435,28 @@ def main():
         cb = sorted(_glob.glob(os.path.join(ROOT, "profiles", f"r*_cpu_baseline_{args.workload}.json")))
         if cb:
             res["cpu_baseline"]["full_batch_measured"] = dict(json.load(open(cb[-1])), source=os.path.relpath(cb[-1], ROOT))
+    # ---- the configuration that MEETS north_star's 1e-3 on the latents (fp16 elements + fp32 residual stream), measured by this
+    # run: a child process (the library is built per element type, one type per process) times a short loop of the same step and
+    # replays the full-depth 30-step loop against the committed oracle trajectory ----
+    if (rank == 0 and world == 1 and not cpu and not args.no_parity_mode and not args.parity_child
+            and args.workload == "sdxl-1024-bs8" and (args.dtype, args.residual) != ("fp16", "fp32")):
+        import subprocess
+        t0 = time.time()
+        try:
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--parity-child", "--steps", "10", "--warmup", "2"],
+                               capture_output=True, text=True, timeout=900, cwd=ROOT,
+                               env={k: v for k, v in os.environ.items() if k not in ("MI355X_SD_DTYPE", "MI355X_SD_RESID")})
+            line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+            if p.returncode != 0 or not line:
+                raise RuntimeError(p.stderr[-600:])
+            c = json.loads(line[-1])
+            res["parity_mode"] = {"dtype": "fp16", "residual": "fp32", "steps_per_s": c["value"], "ms_per_step": c["ms_per_step"],
+                                  "steps": c["steps"], "end_latents_rel_l2": c["parity_live"]["end_latents_rel"],
+                                  "pred_rel_l2_teacher_forced_max": c["parity_live"]["pred_rel_teacher_forced_max"],
+                                  "target_rel_l2": 1e-3, "case": c["parity_live"]["case"], "oracle": c["parity_live"]["oracle"],
+                                  "measured": "this run (child process, same box)", "seconds": round(time.time() - t0, 1)}
+        except Exception as e:   # the headline number stands on its own; say why the second leg is missing
+            res["parity_mode"] = {"error": str(e)[-600:]}
     if rank == 0:
         print(json.dumps(res))
     if dist is not None:

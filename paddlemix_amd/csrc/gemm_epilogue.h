@@ -159,6 +159,80 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TN
   }
 }
 
+// ---- epilogue operands fetched EARLY (gemm_pipe.hip, residual launches) ----------------------------------------------------------
+// scripts/gemm_timeline.py on the K = 1280 residual projections (8192 x 1280 x 1280 + R, 192 launches per SDXL step): K loop 21 us,
+// epilogue 12.7 us -- every CU leaves its K loop at the same moment and only THEN starts fetching its 80 KB of residual, 20 dependent
+// load -> wait -> add -> store rounds per wave with nothing else on the chip to overlap them. The residual (and bias) values a lane
+// needs are known from the start, so they are loaded into registers during the last 1.5 K iterations (after the loop's final LDS-DMA
+// wait: no interaction with the counted vmcnt of the DMA ring) and the epilogue starts with its operands in hand.
+// 8 consecutive channels per sub-tile pair = one 16-byte load; 40 (bf16 residual) + 20 (bias) registers per lane at TM x TN = 4 x 5.
+template <int TM, int TN>
+struct EpiPre {
+  u32x4 r8[TM][TN / 2 > 0 ? TN / 2 : 1];   // residual channels of the pair (acc[2h] | acc[2h+1]) of row-tile tm
+  u32x2 r4[TM];                            // the unpaired last sub-tile (TN odd)
+  f32x4 b[TN];                             // bias of this lane's 4 channels of sub-tile tn
+};
+
+template <int TM, int TN>
+__device__ __forceinline__ void epi_prefetch(const GemmArgs& p, EpiPre<TM, TN>& pre, int m_wave, int n_wave, int lane) {
+  const int lq = lane >> 4;
+  // bounds-checked buffer loads: rows >= M and channels >= N read as zero (the matching stores are skipped)
+  const __amdgpu_buffer_rsrc_t r_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.R), 0, (unsigned)(((size_t)(p.M - 1) * p.ldr + p.N) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.bias ? (unsigned)((size_t)p.N * 4) : 0u, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int n = n_wave + acc_col<TN>(tn, lq, false);
+    pre.b[tn] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, n < p.N ? (unsigned)n * 4u : OOB, 0, 0));
+  }
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int m = m_wave + tm * 16 + (lane & 15);
+    const unsigned row = (unsigned)((size_t)m * p.ldr * 2);
+#pragma unroll
+    for (int h = 0; h < TN / 2; ++h) {
+      const int n = n_wave + h * 32 + lq * 8;
+      pre.r8[tm][h] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, (m < p.M && n + 8 <= p.N) ? row + (unsigned)n * 2u : OOB, 0, 0));
+    }
+    if constexpr (TN & 1) {
+      const int n = n_wave + (TN - 1) * 16 + lq * 4;
+      pre.r4[tm] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r_rsrc, (m < p.M && n + 4 <= p.N) ? row + (unsigned)n * 2u : OOB, 0, 0));
+    }
+  }
+}
+
+// gemm_epilogue for a launch whose residual and bias sit in `pre` (bf16 residual, no GEGLU / fp8 scale / gate: gemm_pipe.hip checks)
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_pre(const GemmArgs& p, f32x4 (&acc)[TN][TM], const EpiPre<TM, TN>& pre, int m_wave,
+                                                  int n_wave, int lane) {
+  const int lq = lane >> 4;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int m = m_wave + tm * 16 + (lane & 15);
+    if (m >= p.M) continue;
+    const float* rb = p.rowbias ? p.rowbias + (size_t)(m / p.rows_per_batch) * p.ld_rowbias : nullptr;
+    const size_t crow = p.c_rpb ? (size_t)(m / p.c_rpb) * p.c_bstride + (size_t)(m % p.c_rpb) * p.ldc : (size_t)m * p.ldc;
+    store_row<TN>(p, crow, n_wave, lq, [&](int tn, int n) {
+      f32x4 v = acc[tn][tm] + pre.b[tn];        // (no bias: the descriptor was empty, the loads returned zeros)
+      if (rb) v += *reinterpret_cast<const f32x4*>(rb + n);
+      bf16x4 r4;
+      if ((TN & 1) && tn == TN - 1) {
+        r4 = __builtin_bit_cast(bf16x4, pre.r4[tm]);
+      } else {
+        const u32x4 q = pre.r8[tm][tn >> 1];
+        r4 = __builtin_bit_cast(bf16x4, (tn & 1) ? u32x2{q[2], q[3]} : u32x2{q[0], q[1]});
+      }
+      v[0] += (float)r4[0];
+      v[1] += (float)r4[1];
+      v[2] += (float)r4[2];
+      v[3] += (float)r4[3];
+      return act4(p, v * p.out_scale);
+    });
+  }
+}
+
 // Epilogue of the LayerNorm-folded projections (mi355x_sd_linear_ln): acc <- rstd[m] * acc - mean[m] * rstd[m] * wsum[n]
 // + bias[n], then GEGLU / SiLU / tanh-GELU and the store. A separate function (and separate kernel instantiations,
 // template parameter LN) so the register allocation of every other GEMM is unaffected. The row statistics of all TM

@@ -64,8 +64,12 @@ __device__ __forceinline__ void sgb_reads_under_mfmas() {
   if constexpr (NMFMA - PER * NREAD > 0) __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - PER * NREAD, 0);
 }
 
-template <bool CONV, class CFG, bool LN, int LW = 0, int SG = 0>
+// PRE: the epilogue's residual / bias operands are fetched during the last K iterations (gemm_epilogue.h EpiPre). Its own
+// instantiation, not a run-time branch: two alternative consumers of the accumulators make the register allocator split their
+// live ranges and spill inside the K loop (header of gemm_epilogue.h).
+template <bool CONV, class CFG, bool LN, int LW = 0, int SG = 0, bool PRE = false>
 __global__ __launch_bounds__(CFG::THREADS + LW * 64, (LW ? 3 : CFG::MIN_WAVES)) void gemm_pipe_kernel(const GemmArgs p) {
+  static_assert(!PRE || (LW == 0 && !LN && (CFG::TM + CFG::TN) <= 10), "early epilogue operands: register-pipelined tiles without loader waves");
   constexpr int BM = CFG::BM, BN = CFG::BN, TM = CFG::TM, TN = CFG::TN, ST = CFG::STAGES, NW = CFG::NW;
   constexpr int PW = LW ? LW : NW;                       // waves that own LDS-DMA pieces
   constexpr int AP = (CFG::A_TOTAL + PW - 1) / PW, WP = (CFG::W_TOTAL + PW - 1) / PW;
@@ -78,8 +82,11 @@ __global__ __launch_bounds__(CFG::THREADS + LW * 64, (LW ? 3 : CFG::MIN_WAVES)) 
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // timeline diagnostics (p.ts != NULL only under scripts/gemm_timeline.py): thread 0 of each block stamps the 100-MHz wall clock
+  // (not in the loader-wave kernels: they live on exactly the 168 registers of three waves per SIMD and the stamp costs one)
   auto stamp = [&](const int slot) {
-    if (p.ts && tid == 0) p.ts[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 6 + slot] = wall_clock64();
+    if constexpr (LW == 0) {
+      if (p.ts && tid == 0) p.ts[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 6 + slot] = wall_clock64();
+    }
   };
   stamp(0);
   const bool loader = LW > 0 && wave >= NW;              // wave-uniform
@@ -222,6 +229,11 @@ __global__ __launch_bounds__(CFG::THREADS + LW * 64, (LW ? 3 : CFG::MIN_WAVES)) 
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // early fetch of the epilogue's residual / bias (gemm_epilogue.h EpiPre): the register-pipelined tiles without loader waves
+  // (those are capped at 168 registers), plain bf16 residual launches only (launch_pipe decides)
+  EpiPre<PRE ? TM : 1, PRE ? TN : 1> pre;
+  const int m_pre = m0 + wm * (TM * 16), n_pre = n0 + wn * (TN * 16);
+
   const int frow = lane & 15, fkc = lane >> 4, rsw = frow & 7;
   const int a_row = (wm * (TM * 16) + frow) * 128, w_row = (wn * (TN * 16) + frow) * 128;
   const int c0 = ((0 * 4 + fkc) ^ rsw) << 4, c1 = ((1 * 4 + fkc) ^ rsw) << 4;
@@ -261,6 +273,9 @@ __global__ __launch_bounds__(CFG::THREADS + LW * 64, (LW ? 3 : CFG::MIN_WAVES)) 
   }
   SD_PIPE_BARRIER();
   stamp(1);
+  if constexpr (PRE) {
+    if (t1 - t0 == 1) epi_prefetch<TM, TN>(p, pre, m_pre, n_pre, lane);   // one K-tile: there is no later point
+  }
   read_frag(0, 0);
   int stage = 0;
   if constexpr (LW > 0 && SG) {
@@ -307,6 +322,11 @@ __global__ __launch_bounds__(CFG::THREADS + LW * 64, (LW ? 3 : CFG::MIN_WAVES)) 
         else wait_vmcnt_imm<0>();
       }
       SD_PIPE_BARRIER();                       // publishes tile t+1; every wave is done reading tile t
+      if constexpr (PRE) {
+        // the loop's LAST LDS-DMA wait is behind us (iteration t1 - 2): the epilogue's operands go in flight now and have the rest
+        // of this iteration and all of the last one to land
+        if (t == t1 - 2) epi_prefetch<TM, TN>(p, pre, m_pre, n_pre, lane);
+      }
       read_frag(0, s1);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -376,9 +396,11 @@ __global__ __launch_bounds__(CFG::THREADS + LW * 64, (LW ? 3 : CFG::MIN_WAVES)) 
   }
 
   const int m_w = m0 + wm * (TM * 16), n_w = n0 + wn * (TN * 16);
-  if (p.ts) {   // (the stamp must not be taken before the accumulators are final: touch one)
-    asm volatile("" ::"v"(acc[TN - 1][TM - 1][0]));
-    stamp(2);
+  if constexpr (LW == 0) {
+    if (p.ts) {   // (the stamp must not be taken before the accumulators are final: touch one)
+      asm volatile("" ::"v"(acc[TN - 1][TM - 1][0]));
+      stamp(2);
+    }
   }
   if (p.splitk > 1) {   // raw partial sums -> ws[split][m][n]; the epilogue runs in splitk_reduce_kernel (gemm.hip)
     float* ws = p.ws + (size_t)blockIdx.y * p.M * p.N;
@@ -394,9 +416,14 @@ __global__ __launch_bounds__(CFG::THREADS + LW * 64, (LW ? 3 : CFG::MIN_WAVES)) 
     }
     return;
   }
-  if constexpr (LN) gemm_epilogue_ln<TM, TN>(p, acc, m_w, n_w, lane);
-  else gemm_epilogue<TM, TN>(p, acc, m_w, n_w, lane);
-  if (p.ts) {
+  if constexpr (LN) {
+    gemm_epilogue_ln<TM, TN>(p, acc, m_w, n_w, lane);
+  } else if constexpr (PRE) {
+    gemm_epilogue_pre<TM, TN>(p, acc, pre, m_w, n_w, lane);
+  } else {
+    gemm_epilogue<TM, TN>(p, acc, m_w, n_w, lane);
+  }
+  if constexpr (LW == 0) if (p.ts) {
     stamp(3);                                   // stores issued (not yet drained)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp(4);                                   // this wave's stores written back
@@ -442,13 +469,29 @@ static int launch_pipe(const GemmArgs& a, hipStream_t stream) {
     if (gemm_loaders() == 5 || (gemm_loaders() == -1 && a.K >= 4096 && a.splitk <= 1))
       return launch_pipe_lw<CONV, CFG, LN, 4, 1>(a, stream);   // + interleaved fragment reads
   }
+  const int ntm = (a.M + CFG::BM - 1) / CFG::BM, ntn = (a.N + CFG::BN - 1) / CFG::BN;
+  const int ny = a.splitk > 1 ? a.splitk : 1;
+  if constexpr (!CONV && !LN && (CFG::TM + CFG::TN) <= 10) {
+    // residual launches (to_out, proj_out, the K < 4096 FF2s): epilogue operands fetched during the last K iterations. bf16
+    // residual rows addressed with 32-bit offsets, no GEGLU / gate / fp8 scale / split-K (those epilogues live elsewhere); not
+    // the implicit-GEMM convs (their gather state leaves no room: 256 registers + spills at 256x160)
+    static const bool pre_off = getenv("MI355X_SD_GEMM_NO_PRE") != nullptr;   // A/B switch
+    if (!pre_off && a.R && !a.r_f32 && !a.geglu && !a.gate && !a.wscale && a.splitk <= 1 &&
+        ((size_t)(a.M - 1) * a.ldr + a.N) * 2 < 0xFFFF0000ull) {
+      static const bool pre_ok = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<CONV, CFG, LN, 0, 0, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES) == hipSuccess;
+      }();
+      if (!pre_ok) return SD_ERR_HIP;
+      hipLaunchKernelGGL((gemm_pipe_kernel<CONV, CFG, LN, 0, 0, true>), dim3(ntm * ntn, ny), dim3(CFG::THREADS), CFG::LDS_BYTES, stream, a);
+      return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+    }
+  }
   static const bool attr_ok = [] {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<CONV, CFG, LN>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES) == hipSuccess;
   }();
   if (!attr_ok) return SD_ERR_HIP;
-  const int ntm = (a.M + CFG::BM - 1) / CFG::BM, ntn = (a.N + CFG::BN - 1) / CFG::BN;
-  const int ny = a.splitk > 1 ? a.splitk : 1;
   hipLaunchKernelGGL((gemm_pipe_kernel<CONV, CFG, LN>), dim3(ntm * ntn, ny), dim3(CFG::THREADS), CFG::LDS_BYTES, stream, a);
   if (a.splitk > 1) launch_splitk_reduce(a, stream);
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;

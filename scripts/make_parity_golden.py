@@ -2,8 +2,9 @@
 
 Run on the CPU (no GPU, no network):   python scripts/make_parity_golden.py [case ...]
 Each file holds the float64 end latents of the free-running fp32 oracle loop (x_end), and for the kept steps the model input
-(x_in, fp32), the oracle's prediction (pred, fp32) and their indices (kept) for the teacher-forced per-step check, plus the
-wall time and thread count of the run.  The GPU tests regenerate the same seeded weights / inputs and replay the loop on the
+(x_in, fp32), the oracle's prediction (pred, fp32) and their indices (kept) for the teacher-forced per-step check, the schedule
+the loop followed (x0_scale, sched rows: the device replay reads it from here, not from oracle/), plus the wall time and thread
+count of the run.  The GPU tests regenerate the same seeded weights / inputs and replay the loop on the
 device (tests/test_gpu_parity_loops.py, scripts/parity_loops.py).
 """
 import os
@@ -38,7 +39,9 @@ def main():
 
         with torch.no_grad():
             x_end = PC.run_loop(case, predict, x0, on_step)
-        np.savez(PC.golden_path(name), x_end=x_end.numpy(), kept=np.array(keep, dtype=np.int64),
+        s0, rows = PC.schedule(case)
+        np.savez(PC.golden_path(name), x_end=x_end.numpy(), kept=np.array(keep, dtype=np.int64), x0_scale=np.float64(s0),
+                 sched=np.array(rows, dtype=np.float64),   # per step: model timestep, input scale, a, b  (x <- a x + b pred)
                  x_in=np.stack([xin[i] for i in keep]), pred=np.stack([pred[i] for i in keep]),
                  seconds=np.float64(time.time() - t0), threads=np.int64(torch.get_num_threads()))
         print(f"{name}: wrote {PC.golden_path(name)} in {time.time() - t0:.0f} s", flush=True)

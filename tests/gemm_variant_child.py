@@ -1,0 +1,41 @@
+"""Child of tests/test_gpu_gemm_variants.py: runs a few GEMM / conv launches under the MI355X_SD_GEMM_* switches of its environment
+(read once per process) and prints one JSON line: sha256 of every output + rel-L2 against fp32 torch math."""
+import hashlib
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+from paddlemix_amd import _lib, ops  # noqa: E402
+
+ops.init(0)
+ed = _lib.elem_dtype()
+res = {}
+# the 256x160 three-stage tile (N = 1280 column tiles) with K on both sides of the loader-wave threshold, ragged M, residual
+for M, N, K, resid in ((8192, 1280, 5120, True), (1000, 1280, 4096, False), (8192, 1280, 1280, True), (777, 2560, 8192, False)):
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = torch.randn(M, K, device="cuda", generator=g).to(ed)
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(ed)
+    b = torch.randn(N, device="cuda", generator=g)
+    r = torch.randn(M, N, device="cuda", generator=g).to(ed) if resid else None
+    out = ops.linear(a, w, b, residual=r)
+    ref = a[:512].float() @ w.float().t() + b + (r[:512].float() if resid else 0)
+    res[f"gemm {M}x{N}x{K}{'+R' if resid else ''}"] = dict(
+        sha=hashlib.sha256(out.cpu().view(torch.int16).numpy().tobytes()).hexdigest()[:16],
+        rel=((out[:512].float() - ref).norm() / ref.norm()).item())
+for B, H, W, Cin, Cout in ((8, 32, 32, 1280, 1280), (2, 30, 34, 640, 1280)):      # 11520- / 5760-deep implicit-GEMM convs
+    g = torch.Generator(device="cuda").manual_seed(B + H + Cin)
+    x = torch.randn(B, H, W, Cin, device="cuda", generator=g).to(ed)
+    w = (torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) / (9 * Cin) ** 0.5).to(ed)
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
+    b = torch.randn(Cout, device="cuda", generator=g)
+    out = ops.conv3x3(x, wp, b)
+    ref = F.conv2d(x[:1].float().permute(0, 3, 1, 2), w.float(), b, padding=1).permute(0, 2, 3, 1).reshape(-1, Cout)
+    res[f"conv {B}x{H}x{W}x{Cin}->{Cout}"] = dict(
+        sha=hashlib.sha256(out.cpu().view(torch.int16).numpy().tobytes()).hexdigest()[:16],
+        rel=((out[:H * W].float() - ref).norm() / ref.norm()).item())
+print("VARIANT_JSON " + json.dumps(res))

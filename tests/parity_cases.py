@@ -51,10 +51,12 @@ def dual16(P):
 
 
 def case_params(case):
+    """the seeded synthetic parameter set of SURVEY.md 8(d) (the product's and the oracle's generators draw the same numbers:
+    tests/test_parity_cases.py), made exact in both 16-bit types"""
     if case["kind"] == "sd3":
-        from oracle.sd3_ref import synth_sd3_params
+        from paddlemix_amd.sd3 import synth_sd3_params
         return dual16(synth_sd3_params(case["cfg"], seed=1234))
-    from oracle.unet_ref import synth_unet_params
+    from paddlemix_amd.unet import synth_unet_params
     return dual16(synth_unet_params(case["cfg"], seed=1234))
 
 
@@ -114,9 +116,10 @@ def kept_steps(case):
     return list(range(case["steps"])) if case["keep"] == "all" else list(case["keep"])
 
 
-def run_loop(case, predict, x_init, on_step=None):
-    """free-running loop: predict(x_in fp32, timestep, step index) -> prediction tensor; float64 state. Returns end latents."""
-    s0, rows = schedule(case)
+def run_loop(case, predict, x_init, on_step=None, sched=None):
+    """free-running loop: predict(x_in fp32, timestep, step index) -> prediction tensor; float64 state. Returns end latents.
+    ``sched``: (x0_scale, rows) as stored in a fixture (the device replay takes the schedule from there, not from oracle/)."""
+    s0, rows = sched if sched is not None else schedule(case)
     x = x_init.double() * s0
     for i, (t, cin, a, b) in enumerate(rows):
         x_in = (x * cin).float()
@@ -149,16 +152,17 @@ def rel_l2(a, b):
     return ((a - b).norm() / b.norm()).item()
 
 
-def device_report(case_name, make_model, dev="cuda"):
+def device_report(case_name, make_model=None, dev="cuda", model=None):
     """Replay one case on the device: free-running end latents and teacher-forced per-step predictions vs the committed oracle
     trajectory. ``make_model(case, P)`` -> object with the product's forward signature (UNet2DConditionModel /
-    SD3Transformer2DModel)."""
+    SD3Transformer2DModel), or ``model``: one already built from ``case_params(case)``."""
     case = CASES[case_name]
     gold = load_golden(case_name)
-    P = case_params(case)
     x0, enc, extra = case_inputs(case)
-    model = make_model(case, P)
-    del P
+    if model is None:
+        P = case_params(case)
+        model = make_model(case, P)
+        del P
     enc_d = enc.to(dev)
     if case["kind"] == "sd3":
         extra_d = extra.to(dev)
@@ -170,11 +174,12 @@ def device_report(case_name, make_model, dev="cuda"):
 
         def predict(x_in, t, i):
             return model(x_in.to(dev), int(t), enc_d, added_cond_kwargs=extra_d, return_dict=False)[0].float()
-    x_end = run_loop(case, predict, x0)
+    sched = (float(gold["x0_scale"]), [tuple(float(v) for v in r) for r in gold["sched"]])
+    x_end = run_loop(case, predict, x0, sched=sched)
     out = {"end_latents_rel": rel_l2(x_end, gold["x_end"]), "steps": case["steps"]}
     errs = []
     for j, i in enumerate(gold["kept"].tolist()):
-        t = schedule(case)[1][i][0]
+        t = sched[1][i][0]
         e = predict(torch.from_numpy(gold["x_in"][j]), t, i).cpu()
         errs.append(rel_l2(e, gold["pred"][j]))
     out["pred_rel_teacher_forced_max"] = max(errs)

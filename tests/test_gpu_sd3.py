@@ -303,7 +303,7 @@ def test_fused_ops_take_the_reference_s_16bit_modulation_vectors(B, S, C, affine
     x, mha = (torch.randn(B, S, C, generator=g) * 2).to(ed).cuda(), torch.randn(B, S, C, generator=g).to(ed).cuda()
     mod = (torch.randn(B, 6 * C, generator=g) * 0.5).to(ed).cuda()            # linear1(silu(temb)) of the reference, x.dtype
     shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = mod.chunk(6, dim=1)
-    assert not gate_msa.is_contiguous() and gate_msa.dtype == ed
+    assert (B == 1 or not gate_msa.is_contiguous()) and gate_msa.dtype == ed and gate_msa.stride(0) == 6 * C
     w = (1 + 0.1 * torch.randn(C, generator=g)).to(ed).cuda() if affine else None
     b = (0.1 * torch.randn(C, generator=g)).to(ed).cuda() if affine else None
     resi, out = ops.fused_adaLN_scale_residual(x, mha, gate_msa, scale_mlp, shift_mlp, w, b, 1e-6)

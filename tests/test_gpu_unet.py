@@ -129,6 +129,29 @@ def test_encoder_attention_mask_on_device():
     assert _rel(masked.cpu(), ref) < 2e-2
 
 
+@pytest.mark.parametrize("head_dim64", [False, True], ids=["d16", "d64-folded-scale"])
+def test_self_attention_mask_on_device(head_dim64):
+    """`attention_mask` (unet_2d_condition.py:916-923: a key mask over the latent tokens, a -10000 bias on every self-attention)
+    through the HIP path, on the geometry where the reference can take it (all attention at one resolution); head_dim 64 runs the
+    masked kernel on queries that carry the folded softmax scale (bias in base-2 units)."""
+    from paddlemix_amd.unet import UNet2DConditionModel
+    cfg = dict(TINY, attention_head_dim=2) if head_dim64 else TINY
+    P = _bf16_params(cfg, "cpu")
+    model = UNet2DConditionModel(cfg, P)
+    sample, enc, _ = _inputs(cfg, 2, 16, 16, L=7)
+    none = model(sample.cuda(), 10, enc.cuda()).sample
+    keep = model(sample.cuda(), 10, enc.cuda(), attention_mask=torch.ones(2, 64, device="cuda")).sample
+    assert _rel(keep.cpu(), none.cpu()) < 5e-3        # same arithmetic up to the masked kernel's accumulation order
+    g = torch.Generator().manual_seed(3)
+    m = (torch.rand(2, 64, generator=g) > 0.4).float()
+    m[:, 0] = 1
+    masked = model(sample.cuda(), 10, enc.cuda(), attention_mask=m.cuda()).sample
+    ref = U.unet_forward(P, cfg, sample, 10, enc, attention_mask=m)
+    assert _rel(masked.cpu(), none.cpu()) > 1e-2 and _rel(masked.cpu(), ref) < 2e-2
+    with pytest.raises(ValueError, match="key tokens"):
+        model(sample.cuda(), 10, enc.cuda(), attention_mask=torch.ones(2, 63, device="cuda"))
+
+
 def test_controlnet_residuals_on_device():
     """down_block_additional_residuals / mid_block_additional_residual (unet_2d_condition.py:1121-1155) through the
     in-place NCHW-residual kernel on the concat-by-construction skip slots."""
