@@ -387,6 +387,178 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_ker
   }
 }
 
+// ---- short key sequences (cross-attention against 77 text tokens), head dim 64 ---------------------------------------------
+// The SDXL step runs 70 such launches (8x20x1024x77, 8x10x4096x77): 45-90 MB of Q in / O out against 20 KB of K/V per (batch,
+// head), i.e. a streaming problem -- which the flash kernel above turns into a chain of latencies: it walks 77 keys as two 64-key
+// tiles of an online softmax (128 key columns of MFMA and exp work for 77), fetches each query tile only after the previous one
+// is stored, and stores 8 bytes per lane. This kernel is cut for the shape instead:
+//   * all keys at once: NSB <= 4 blocks of 32 keys (77 -> 3) resident in LDS for the block's life, ONE exact softmax pass per
+//     query tile -- no running maximum, no rescale, no second tile;
+//   * a block walks `qtpb` query tiles of its (batch, head); the next tile's Q fragments are requested before the current tile's
+//     MFMAs, so the only exposed load latency is the first;
+//   * O leaves as 16-byte stores: the two half-waves hold adjacent 8-byte pieces of a row, one v_permlane32_swap per dword pairs
+//     them up (cdna guide T21) -- 4 store instructions per tile instead of 8.
+// Same operand layouts, LDS images and MFMA order as attention_kernel (S^T = K Q^T, O^T = V^T P^T); results differ from it only by
+// the softmax being exact in one pass (no deferred rescale).
+template <int NSB, bool LOG2>
+__global__ __launch_bounds__(ATT_THREADS, 2) void attention_short_kernel(const AttnArgs p, const int qtpb) {
+  using L = AttLds<64>;
+  constexpr int KS = 4, DB = 2, ROWS = NSB * 32;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[ROWS * (L::KRS + L::VRS)];
+  unsigned char* ks_ = smem;
+  unsigned char* vs_ = smem + ROWS * L::KRS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;
+  const int lq = lane & 31;
+
+  const int ntq = (p.Sq + QBLK - 1) / QBLK;          // query tiles per (batch, head)
+  const int nqb = (ntq + qtpb - 1) / qtpb;            // blocks per (batch, head)
+  const int lid = xcd_remap(blockIdx.x, nqb * p.B * p.H);
+  const int qb = lid % nqb;
+  const int bh = lid / nqb;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const bf16* Qp = p.Q + (size_t)b * p.q_bs + (size_t)h * 64;
+  const bf16* Kp = p.K + (size_t)b * p.k_bs + (size_t)h * 64;
+  const bf16* Vp = p.V + (size_t)b * p.v_bs + (size_t)h * 64;
+  bf16* Op = p.O + (size_t)b * p.o_bs + (size_t)h * 64;
+
+  // Q fragments (MFMA B operand) of query tile qt: lane (q = lq, hi) holds d = ks*16 + hi*8 .. +8. Rows past Sq: row 0 (never stored)
+  auto load_q = [&](const int qt, bf16x8 (&dst)[KS]) {
+    const int row = qt * QBLK + wave * QROWS + lq;
+    const bf16* qr = Qp + (size_t)(row < p.Sq ? row : 0) * p.q_ts + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) dst[ks] = *reinterpret_cast<const bf16x8*>(qr + ks * 16);
+  };
+  bf16x8 qf[KS], qn[KS];
+  const int qt0 = qb * qtpb;
+  load_q(qt0, qf);   // in flight together with K / V
+
+  // ---- K and V of this (batch, head): rows past Skv are outside the descriptor's range and read as zero ----
+  {
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16*>(Kp), 0, (unsigned)(((size_t)(p.Skv - 1) * p.k_ts + 64) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16*>(Vp), 0, (unsigned)(((size_t)(p.Skv - 1) * p.v_ts + 64) * 2), 0x00020000);
+    u32x4 rk[NSB], rv[NSB];
+#pragma unroll
+    for (int i = 0; i < NSB; ++i) {   // 16-byte chunk cid: row cid / 8, chunk cid % 8
+      const int cid = tid + ATT_THREADS * i;
+      const int row = cid >> 3, ch = cid & 7;
+      rk[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, (unsigned)((row * p.k_ts + ch * 8) * 2), 0, 0));
+      rv[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, (unsigned)((row * p.v_ts + ch * 8) * 2), 0, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < NSB; ++i) {
+      const int cid = tid + ATT_THREADS * i;
+      const int row = cid >> 3, ch = cid & 7;
+      *reinterpret_cast<u32x4*>(ks_ + row * L::KRS + ch * 16) = rk[i];
+      *reinterpret_cast<u32x4*>(vs_ + row * L::VRS + ch * 16) = rv[i];
+    }
+  }
+  __syncthreads();
+
+  const int i16 = lane & 15;
+  const int dh = (lane >> 4) & 1;
+  const int tr_row = (i16 >> 2);
+  const int tr_col = dh * 16 + (i16 & 3) * 4;
+  const float c2 = LOG2 ? 1.0f : p.scale * 1.4426950408889634f;
+  auto max3 = [](float a, float b, float c) { return fmaxf(fmaxf(a, b), c); };
+
+#pragma unroll 1
+  for (int qi = 0; qi < qtpb; ++qi) {
+    const int qt = qt0 + qi;
+    if (qt >= ntq) break;                              // block-uniform
+    const bool more = qi + 1 < qtpb && qt + 1 < ntq;
+    if (more) load_q(qt + 1, qn);                      // lands under this tile's MFMAs and exponentials
+
+    // ---- S^T = K Q^T: lane (lq, hi) gets key sb*32 + (r&3) + 8*(r>>2) + 4*hi of query lq in s[sb][r] ----
+    f32x16 s[NSB];
+#pragma unroll
+    for (int sb = 0; sb < NSB; ++sb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[sb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks_ + (sb * 32 + lq) * L::KRS + (ks * 2 + hi) * 16);
+        s[sb] = mfma_32x32x16(kf, qf[ks], s[sb]);
+      }
+    }
+    // keys past Skv (they sit in the last 32-key block only: the launcher picks NSB = ceil(Skv / 32))
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kv = (NSB - 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (kv >= p.Skv) s[NSB - 1][r] = -INFINITY;
+    }
+    // ---- exact softmax in one pass (key 0 always exists: the maximum is finite) ----
+    float mloc = s[0][0];
+#pragma unroll
+    for (int sb = 0; sb < NSB; ++sb) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) mloc = max3(mloc, s[sb][3 * i], max3(s[sb][3 * i + 1], s[sb][3 * i + 2], mloc));
+      mloc = fmaxf(mloc, s[sb][15]);
+    }
+    {
+      const unsigned u = __float_as_uint(mloc);
+      const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+      mloc = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    const float mc = mloc * c2;
+    float psum = 0.f;
+    bf16x8 pf[2 * NSB];
+#pragma unroll
+    for (int sb = 0; sb < NSB; ++sb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(LOG2 ? s[sb][r] - mc : __builtin_fmaf(s[sb][r], c2, -mc));
+        psum += e;
+        pf[sb * 2 + (r >> 3)][r & 7] = (bf16)e;
+      }
+    }
+    // ---- O^T = V^T P^T ----
+    f32x16 o[DB];
+#pragma unroll
+    for (int i = 0; i < DB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 2 * NSB; ++kk) {
+      const unsigned char* vrow = vs_ + (kk * 16 + 4 * hi + tr_row) * L::VRS + tr_col * 2;
+#pragma unroll
+      for (int db = 0; db < DB; ++db) {
+        const bf16x4 lo = ds_read_tr16((lds_bf16x4*)(vrow + db * 64));
+        const bf16x4 hi4 = ds_read_tr16((lds_bf16x4*)(vrow + 8 * L::VRS + db * 64));
+        const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+        o[db] = mfma_32x32x16(vf, pf[kk], o[db]);
+      }
+    }
+    // ---- O[q][d] = O^T[d][q] / l: lane holds d = db*32 + 8c + 4*hi .. +3; the half-waves' pieces paired into 16-byte stores ----
+    const float l_tot = psum + __shfl_xor(psum, 32, 64);
+    const float inv_l = 1.0f / l_tot;
+    const int q_row = qt * QBLK + wave * QROWS + lq;
+    bf16* orow = Op + (size_t)(q_row < p.Sq ? q_row : 0) * p.o_ts + hi * 8;
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int c = 0; c < 4; c += 2) {
+        unsigned a0 = pack_bf16(o[db][4 * c + 0] * inv_l, o[db][4 * c + 1] * inv_l), a1 = pack_bf16(o[db][4 * c + 2] * inv_l, o[db][4 * c + 3] * inv_l);
+        unsigned b0 = pack_bf16(o[db][4 * c + 4] * inv_l, o[db][4 * c + 5] * inv_l), b1 = pack_bf16(o[db][4 * c + 6] * inv_l, o[db][4 * c + 7] * inv_l);
+        // lower half keeps its piece c and takes the upper half's piece c (channels 8c .. 8c+7); the upper half takes the lower
+        // half's piece c+1 next to its own (channels 8c+8 .. 8c+15)
+        const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        const u32x4 pk = {r0[0], r1[0], r0[1], r1[1]};
+        if (q_row < p.Sq) *reinterpret_cast<u32x4*>(orow + db * 32 + c * 8) = pk;
+      }
+    if (more) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) qf[ks] = qn[ks];
+    }
+  }
+}
+
 // lazy row maximum: MI355X_SD_ATTN_LAZY=0 turns it off (default on: profiles/r02_attention.txt)
 static bool attn_lazy() {
   static const bool dyn = getenv("MI355X_SD_ATTN_DYN") != nullptr;   // probes flip the variable between launches
@@ -411,6 +583,33 @@ static int launch_dp(const AttnArgs& a0, hipStream_t stream) {
   if (a.log2 && (DP != 64 || a.bias)) return SD_ERR_UNSUPPORTED;
   // short KV (both tiles stay resident in the two LDS buffers) and enough query tiles to keep every CU busy: two query
   // tiles per block
+  // short key sequences at head dim 64: the single-pass streaming kernel (MI355X_SD_ATTN_NO_SHORT: A/B switch). 16-byte O stores
+  // need 16-byte-aligned rows; masks and the accumulating (IP-Adapter) form stay on the flash kernel
+  static const bool no_short = getenv("MI355X_SD_ATTN_NO_SHORT") != nullptr;
+  if (DP == 64 && a.D == 64 && a.Skv <= 128 && !a.bias && a.accum == 0.f && !no_short && !(a.o_ts & 7) && !(a.o_bs & 7) &&
+      !(reinterpret_cast<uintptr_t>(a.O) & 15)) {
+    const int ntq = (a.Sq + QBLK - 1) / QBLK;
+    // query tiles per block: ONE. Measured per launch at 8x20x1024x77 / 8x10x4096x77 (profiles/r03_s5_attn.txt): 1 / 2 / 4 / 8 tiles
+    // per block = 14.8 / 15.2 / 17.1 / 19.5 us and 21.3 / 22.3 / 22.5 / 26.3 us (flash kernel: 21.2 / 31.6 us) -- re-staging 20 KB
+    // of L2-resident K / V per tile costs less than the parallelism lost to longer blocks
+    int qtpb = 1;
+    static const int qt_forced = [] { const char* e = getenv("MI355X_SD_ATTN_SHORT_QT"); return e ? atoi(e) : 0; }();
+    if (qt_forced > 0) qtpb = qt_forced;
+    const int nqb = (ntq + qtpb - 1) / qtpb;
+    dim3 grid(nqb * a.B * a.H), block(ATT_THREADS);
+    const int nsb = (a.Skv + 31) / 32;
+#define SD_SHORT(N)                                                                                                  \
+    do {                                                                                                               \
+      if (a.log2) hipLaunchKernelGGL((attention_short_kernel<N, true>), grid, block, 0, stream, a, qtpb);              \
+      else hipLaunchKernelGGL((attention_short_kernel<N, false>), grid, block, 0, stream, a, qtpb);                    \
+    } while (0)
+    if (nsb == 1) SD_SHORT(1);
+    else if (nsb == 2) SD_SHORT(2);
+    else if (nsb == 3) SD_SHORT(3);
+    else SD_SHORT(4);
+#undef SD_SHORT
+    return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+  }
   static const bool no_qt = getenv("MI355X_SD_ATTN_NO_QT") != nullptr;
   const long qtiles = (long)((a.Sq + QBLK - 1) / QBLK) * a.B * a.H;
   if (DP == 64 && a.Skv <= 2 * KVBLK && qtiles >= 1024 && !a.bias && !no_qt) {

@@ -31,6 +31,9 @@
 
 #include "common.h"
 #include "gemm_cfg.h"
+#include <utility>
+#include <vector>
+
 #include "gemm_epilogue.h"
 #include "kernels.h"
 
@@ -286,12 +289,34 @@ static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
 // i.e. prefer the largest tile that still gives every CU work and leaves no mostly-empty last round.
 // MI355X_SD_GEMM_TILE forces a configuration for A/B measurements: 128 | 256 | 257 (phased 256x256) | 160 | 320.
 struct TileChoice { int id, bm, bn; };
+static int pick_tile_model(const GemmArgs& a);
 static int pick_tile(const GemmArgs& a) {
   static const int forced = [] {
     const char* e = getenv("MI355X_SD_GEMM_TILE");
     return e ? atoi(e) : 0;
   }();
   if (forced) return forced;
+  // MI355X_SD_GEMM_TILE_MAP="from:to,from:to" re-maps the model's choice per tile class (A/B measurements inside the step)
+  static const std::vector<std::pair<int, int>> remap = [] {
+    std::vector<std::pair<int, int>> v;
+    const char* e = getenv("MI355X_SD_GEMM_TILE_MAP");
+    while (e && *e) {
+      char* end = nullptr;
+      const long from = strtol(e, &end, 10);
+      if (!end || *end != ':') break;
+      const long to = strtol(end + 1, &end, 10);
+      v.emplace_back((int)from, (int)to);
+      e = (*end == ',') ? end + 1 : end;
+      if (*end != ',') break;
+    }
+    return v;
+  }();
+  const int chosen = pick_tile_model(a);
+  for (const auto& m : remap)
+    if (m.first == chosen && !(a.geglu && (m.second == 129 || m.second == 160)) && a.M >= 256) return m.second;
+  return chosen;
+}
+static int pick_tile_model(const GemmArgs& a) {
   if (a.M < 256) return 128;
   const bool wide_ok = (size_t)a.M * a.lda * 2 < (1ull << 31) && (size_t)a.N * a.K * 2 < (1ull << 31);
   const TileChoice cand[] = {{128, 128, 128}, {160, 256, 160}, {257, 256, 256}, {320, 256, 320}, {256, 256, 256}};
@@ -351,6 +376,9 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
     a.ts = ts;
   }
   a.c_wide = !a.out_f32 && !(reinterpret_cast<uintptr_t>(a.C) & 15) && !(a.ldc & 7) && !(a.c_bstride & 7);
+  static const bool epi_batch_off = getenv("MI355X_SD_GEMM_NO_EPI_BATCH") != nullptr;   // A/B switch (gemm_epilogue.h)
+  a.epi_batch = epi_batch_off ? 0 : 1;
+  a.bias_acc = 0;   // launch_gemm_pipe decides
   const int tile = pick_tile(a);
   if (tile == 128) plan_splitk(a, 128, 128);
   if (a.rowstat && (a.conv || a.wscale || a.a_rpb || a.c_rpb || a.R || a.rowbias || a.gate || !a.wsum))

@@ -6,15 +6,20 @@
 // contiguous bytes per store instruction (scripts/probes/store_probe.hip: 5.8 vs 3.75 TB/s for the 8-byte / 32-byte-
 // per-row pattern of the natural mapping). acc_col() is the single definition of the mapping; the DMA source rows
 // (w_row_of_lds_row), the split-K partial sums and the epilogues all derive from it.
-// Loads: each optional operand sits in its own uniform branch (load, wait, use) per 4-channel group. Batching them
-// (branch-free buffer loads through zero-sized descriptors for absent operands, 8-16 channels per lane in flight) was
-// built and measured (profiles/experiments/r01_gemm_epilogue_batched_loads.h.txt): no spills, parity green, but no
-// gain -- SDXL step 63.4 vs 63.5 ms (box noise), SD3 W8A8 68.0 vs 65.1 ms (slower): the eight waves of a block already
-// hide each other's epilogue latency, and the unconditional loads of absent operands are not free. Two lessons kept
-// from it: (1) never give the accumulators two alternative consumer loops (a fast path next to a general one, or an
-// e4m3 and a bf16 store loop) -- the register allocator then splits their live ranges and spills them INSIDE the K loop;
-// (2) per-channel operands folded into all accumulators up front pin the whole accumulator set in VGPRs.
+// Loads (round 3, scripts/gemm_timeline.py): with one dependent load -> wait -> use round per 4-channel group an epilogue costs
+// TM x TN memory round trips per wave with ~4 KB in flight per CU -- 12.6 us of the 39.6 us of an 8192 x 1280 x 1280 + R launch,
+// 35 us of 65 us at 32768 x 640 x 640 + R (TM x TN = 40), 8.4 us per FF1 tile for nothing but its bias (a load the compiler cannot
+// hoist over the stores). Now: (a) the bias is the INITIAL VALUE of the accumulators (GemmArgs::bias_acc, gemm_pipe.hip) -- no
+// epilogue load at all; (b) the residual of the register-pipelined tiles is fetched during the last K iterations (EpiPre below);
+// (c) everywhere else the operands of a whole row-tile (row bias, gate, residual: up to 3 x TN loads) are issued back to back in
+// front of its math (GemmArgs::epi_batch), TM round trips instead of TM x TN.
+// Round 1 had tried branch-free batching through zero-sized descriptors (profiles/experiments/r01_gemm_epilogue_batched_loads.h.txt)
+// and seen no gain in the step; two lessons kept from it: (1) never give the accumulators two alternative consumer loops (a fast
+// path next to a general one, or an e4m3 and a bf16 store loop) -- the register allocator then splits their live ranges and spills
+// them INSIDE the K loop; (2) per-channel operands folded into all accumulators up front pin the whole accumulator set in VGPRs.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -58,21 +63,40 @@ __device__ __forceinline__ f32x4 act4(const GemmArgs& p, f32x4 v) {
   }
   return v;
 }
-__device__ __forceinline__ f32x4 epi4(const GemmArgs& p, f32x4 v, int m, int n, const float* rb, const float* gt) {
+__device__ __forceinline__ f32x4 add_r16(f32x4 v, u32x2 raw) {
+  const bf16x4 r4 = __builtin_bit_cast(bf16x4, raw);
+  v[0] += (float)r4[0];
+  v[1] += (float)r4[1];
+  v[2] += (float)r4[2];
+  v[3] += (float)r4[3];
+  return v;
+}
+// Operands of one 4-channel group fetched ahead of the row-tile's math (GemmArgs::epi_batch). To keep the register cost at 6 per
+// group the fp32 operands share one slot: the gate when there is one, else the sum of row bias and fp32 residual; the two
+// combinations that would need a second fp32 slot (gate next to a row bias or an fp32 residual -- no program of this library
+// emits them) take the group-at-a-time path. 16-bit residuals are kept packed.
+struct Epi4Ops {
+  f32x4 x;     // gate, or row bias (+ fp32 residual)
+  u32x2 r16;   // 16-bit residual
+};
+__device__ __forceinline__ bool epi_batched(const GemmArgs& p) {
+  return p.epi_batch && !p.geglu && !(p.gate && (p.rowbias || (p.R && p.r_f32)));
+}
+__device__ __forceinline__ f32x4 epi4(const GemmArgs& p, f32x4 v, int m, int n, const float* rb, const float* gt, bool batched,
+                                      const Epi4Ops& o) {
   if (p.wscale) v *= *reinterpret_cast<const f32x4*>(p.wscale + n);
-  if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+  if (p.bias && !p.bias_acc) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+  if (batched) {
+    if (gt) v *= o.x;
+    else if (rb || (p.R && p.r_f32)) v += o.x;
+    if (p.R && !p.r_f32) v = add_r16(v, o.r16);
+    return act4(p, v * p.out_scale);
+  }
   if (rb) v += *reinterpret_cast<const f32x4*>(rb + n);
   if (gt) v *= *reinterpret_cast<const f32x4*>(gt + n);
   if (p.R) {
-    if (p.r_f32) {
-      v += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.R) + (size_t)m * p.ldr + n);
-    } else {
-      const bf16x4 r4 = *reinterpret_cast<const bf16x4*>(p.R + (size_t)m * p.ldr + n);
-      v[0] += (float)r4[0];
-      v[1] += (float)r4[1];
-      v[2] += (float)r4[2];
-      v[3] += (float)r4[3];
-    }
+    if (p.r_f32) v += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.R) + (size_t)m * p.ldr + n);
+    else v = add_r16(v, *reinterpret_cast<const u32x2*>(p.R + (size_t)m * p.ldr + n));
   }
   return act4(p, v * p.out_scale);
 }
@@ -149,88 +173,155 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TN
     const float* rb = p.rowbias ? p.rowbias + (size_t)(m / p.rows_per_batch) * p.ld_rowbias : nullptr;
     const float* gt = p.gate ? p.gate + (size_t)(m / p.rows_per_batch) * p.ld_gate : nullptr;
     const size_t crow = p.c_rpb ? (size_t)(m / p.c_rpb) * p.c_bstride + (size_t)(m % p.c_rpb) * p.ldc : (size_t)m * p.ldc;
+    // this row-tile's operands, all loads in flight before the first is used (channels past N: the group's address is clamped
+    // into the row, its stores are skipped). Tiles of more than 6 sub-tiles per wave are GEGLU-only (no such operands).
+    constexpr int TB = TN <= 6 ? TN : 1;
+    Epi4Ops ops[TB];
+    const bool batched = TN <= 6 && epi_batched(p);
+    if (TN <= 6 && batched) {
+      int nc[TB];
+#pragma unroll
+      for (int tn = 0; tn < TB; ++tn) nc[tn] = min(n_wave + acc_col<TN>(tn, lq, false), p.N - 4);
+      const bool r32 = p.R && p.r_f32;
+      if (gt) {
+#pragma unroll
+        for (int tn = 0; tn < TB; ++tn) ops[tn].x = *reinterpret_cast<const f32x4*>(gt + nc[tn]);
+      } else if (rb && r32) {
+        f32x4 t[TB];
+#pragma unroll
+        for (int tn = 0; tn < TB; ++tn) {
+          ops[tn].x = *reinterpret_cast<const f32x4*>(rb + nc[tn]);
+          t[tn] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.R) + (size_t)m * p.ldr + nc[tn]);
+        }
+#pragma unroll
+        for (int tn = 0; tn < TB; ++tn) ops[tn].x += t[tn];
+      } else if (rb) {
+#pragma unroll
+        for (int tn = 0; tn < TB; ++tn) ops[tn].x = *reinterpret_cast<const f32x4*>(rb + nc[tn]);
+      } else if (r32) {
+#pragma unroll
+        for (int tn = 0; tn < TB; ++tn) ops[tn].x = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.R) + (size_t)m * p.ldr + nc[tn]);
+      }
+      if (p.R && !p.r_f32) {
+#pragma unroll
+        for (int tn = 0; tn < TB; ++tn) ops[tn].r16 = *reinterpret_cast<const u32x2*>(p.R + (size_t)m * p.ldr + nc[tn]);
+      }
+    }
     store_row<TN>(p, crow, n_wave, lq, [&](int tn, int n) {
-      if (!p.geglu) return epi4(p, acc[tn][tm], m, n, rb, gt);
+      if (!p.geglu) return epi4(p, acc[tn][tm], m, n, rb, gt, batched, ops[TN <= 6 ? tn : 0]);
       f32x4 v = acc[tn][tm];   // GEGLU halves: fp8 scale and bias only (launch_gemm rejects the other operands)
       if (p.wscale) v *= *reinterpret_cast<const f32x4*>(p.wscale + n);
-      if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+      if (p.bias && !p.bias_acc) v += *reinterpret_cast<const f32x4*>(p.bias + n);
       return v;
     });
   }
 }
 
-// ---- epilogue operands fetched EARLY (gemm_pipe.hip, residual launches) ----------------------------------------------------------
-// scripts/gemm_timeline.py on the K = 1280 residual projections (8192 x 1280 x 1280 + R, 192 launches per SDXL step): K loop 21 us,
-// epilogue 12.7 us -- every CU leaves its K loop at the same moment and only THEN starts fetching its 80 KB of residual, 20 dependent
-// load -> wait -> add -> store rounds per wave with nothing else on the chip to overlap them. The residual (and bias) values a lane
-// needs are known from the start, so they are loaded into registers during the last 1.5 K iterations (after the loop's final LDS-DMA
-// wait: no interaction with the counted vmcnt of the DMA ring) and the epilogue starts with its operands in hand.
-// 8 consecutive channels per sub-tile pair = one 16-byte load; 40 (bf16 residual) + 20 (bias) registers per lane at TM x TN = 4 x 5.
+// ---- residual fetched EARLY (gemm_pipe.hip, residual launches of the register-pipelined tiles) ---------------------------------
+// scripts/gemm_timeline.py on the K = 1280 residual projections (8192 x 1280 x 1280 + R, 192 launches per SDXL step): K loop 22 us,
+// epilogue 12.6 us -- every CU leaves its K loop at the same moment and only THEN starts fetching its 80 KB of residual, 20 dependent
+// load -> wait -> add -> store rounds per wave with nothing else on the chip to overlap them. The residual values a lane needs are
+// known from the start, so they are requested during the last K iterations -- one row-tile per iteration, issued right after that
+// iteration's LDS-DMA so that the loop's counted vmcnt (gemm_pipe.hip) lets them stay in flight for two iterations -- and the
+// epilogue starts with its operands on chip (the bias is in the accumulators already, GemmArgs::bias_acc): 12.6 -> 4.1 us.
+// WHERE they land: in v216 .. v255, registers the compiler never allocates in these kernels (they are built with
+// amdgpu_num_vgpr(216); the clobber lists make the kernel's register count include them). Four other forms failed first: plain loads under the run-time row index came out as load -> s_waitcnt -> copy inside the loop (phis of the landing
+// registers are not coalesced); the row iterations peeled off the loop made the allocator spill the fresh values behind a
+// vmcnt(0); inline-asm loads tied to C variables ("+v") were COPIED right after issue -- to the compiler an asm output is ready
+// -- i.e. before the data arrived (NaN in the first hardware run); a-registers as the landing zone made hipcc split the register
+// budget 128 + 128 and shuttle the accumulators through v_accvgpr moves. Registers the allocator never sees have none of these
+// problems: the loads are asm with the registers named in the text, nothing touches them until gemm_epilogue_pre has waited,
+// then a v_mov per register moves each row-tile's 10 registers out right before use. 16 bits per value: 40 registers per lane at
+// TM x TN = 4 x 5.
+#define SD_PRE_CLOBBERS                                                                                                          \
+  "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231",   \
+      "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", \
+      "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
+constexpr int SD_PRE_BASE = 216;   // first landing register; the PRE kernels are compiled with amdgpu_num_vgpr(216)
 template <int TM, int TN>
 struct EpiPre {
-  u32x4 r8[TM][TN / 2 > 0 ? TN / 2 : 1];   // residual channels of the pair (acc[2h] | acc[2h+1]) of row-tile tm
-  u32x2 r4[TM];                            // the unpaired last sub-tile (TN odd)
-  f32x4 b[TN];                             // bias of this lane's 4 channels of sub-tile tn
+  static constexpr int PAIRS = TN / 2;
+  static constexpr int RPR = PAIRS * 4 + (TN & 1) * 2;   // a-registers per row-tile: pair h at 4h .. 4h+3, the unpaired sub-tile last
+  static constexpr int LOADS_PER_ROW = PAIRS + (TN & 1);
+  static_assert(TM * RPR <= 40, "the landing zone is v216 .. v255");
 };
 
-template <int TM, int TN>
-__device__ __forceinline__ void epi_prefetch(const GemmArgs& p, EpiPre<TM, TN>& pre, int m_wave, int n_wave, int lane) {
-  const int lq = lane >> 4;
-  // bounds-checked buffer loads: rows >= M and channels >= N read as zero (the matching stores are skipped)
-  const __amdgpu_buffer_rsrc_t r_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.R), 0, (unsigned)(((size_t)(p.M - 1) * p.ldr + p.N) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t b_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.bias ? (unsigned)((size_t)p.N * 4) : 0u, 0x00020000);
-  constexpr unsigned OOB = 0xFFFFFFF0u;
+// loads of row-tile TMI. One per-lane offset (the lane's row and first channel), the sub-tile pair as an immediate: rows >= M are
+// sent out of the descriptor's range and read as zero; channels past N in a ragged last column tile read whatever follows in the
+// row (never stored) or zero beyond the buffer's end.
+template <int TMI, int TM, int TN>
+__device__ __forceinline__ void epi_prefetch_row(const GemmArgs& p, u32x4 srd, int m_wave, int n_wave, int lane) {
+  using P = EpiPre<TM, TN>;
+  constexpr unsigned OOB = 0xFFFFF000u;
+  const int m = m_wave + TMI * 16 + (lane & 15);
+  const unsigned voff = m < p.M ? (unsigned)(((size_t)m * p.ldr + n_wave + (lane >> 4) * 8) * 2) : OOB;
 #pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
-    const int n = n_wave + acc_col<TN>(tn, lq, false);
-    pre.b[tn] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, n < p.N ? (unsigned)n * 4u : OOB, 0, 0));
-  }
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm) {
-    const int m = m_wave + tm * 16 + (lane & 15);
-    const unsigned row = (unsigned)((size_t)m * p.ldr * 2);
-#pragma unroll
-    for (int h = 0; h < TN / 2; ++h) {
-      const int n = n_wave + h * 32 + lq * 8;
-      pre.r8[tm][h] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, (m < p.M && n + 8 <= p.N) ? row + (unsigned)n * 2u : OOB, 0, 0));
-    }
-    if constexpr (TN & 1) {
-      const int n = n_wave + (TN - 1) * 16 + lq * 4;
-      pre.r4[tm] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r_rsrc, (m < p.M && n + 4 <= p.N) ? row + (unsigned)n * 2u : OOB, 0, 0));
-    }
+  for (int h = 0; h < P::PAIRS; ++h)
+    asm volatile("buffer_load_dwordx4 v[%c2:%c3], %0, %1, 0 offen offset:%c4"
+                 :
+                 : "v"(voff), "s"(srd), "n"(SD_PRE_BASE + TMI * P::RPR + 4 * h), "n"(SD_PRE_BASE + TMI * P::RPR + 4 * h + 3), "n"(h * 64)
+                 : "memory", SD_PRE_CLOBBERS);
+  if constexpr (TN & 1) {   // the unpaired sub-tile: 4 channels per lane group at (TN-1)*16 + lq*4 = the pair offset - lq*8 bytes
+    const unsigned v4 = m < p.M ? voff + (TN - 1) * 32 - (unsigned)(lane >> 4) * 8u : OOB;
+    asm volatile("buffer_load_dwordx2 v[%c2:%c3], %0, %1, 0 offen"
+                 :
+                 : "v"(v4), "s"(srd), "n"(SD_PRE_BASE + TMI * P::RPR + 4 * P::PAIRS), "n"(SD_PRE_BASE + TMI * P::RPR + 4 * P::PAIRS + 1)
+                 : "memory", SD_PRE_CLOBBERS);
   }
 }
+// the descriptor of the residual rows as four SGPR words (base, stride 0, bytes, raw-buffer flags) for the asm loads
+__device__ __forceinline__ u32x4 epi_r_srd(const GemmArgs& p) {
+  const unsigned long long base = reinterpret_cast<unsigned long long>(p.R);
+  return u32x4{(unsigned)__builtin_amdgcn_readfirstlane((unsigned)base), (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(base >> 32) & 0xFFFFu),
+               (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(((size_t)(p.M - 1) * p.ldr + p.N) * 2)), 0x00020000u};
+}
+template <int IDX>
+__device__ __forceinline__ unsigned epi_pre_read() {
+  unsigned v;
+  asm volatile("v_mov_b32 %0, v%c1" : "=v"(v) : "n"(SD_PRE_BASE + IDX));
+  return v;
+}
 
-// gemm_epilogue for a launch whose residual and bias sit in `pre` (bf16 residual, no GEGLU / fp8 scale / gate: gemm_pipe.hip checks)
+// gemm_epilogue for a launch whose residual sits in v216.. (bf16 residual, bias in the accumulators, no GEGLU / fp8 scale / gate:
+// launch_pipe checks)
 template <int TM, int TN>
-__device__ __forceinline__ void gemm_epilogue_pre(const GemmArgs& p, f32x4 (&acc)[TN][TM], const EpiPre<TM, TN>& pre, int m_wave,
-                                                  int n_wave, int lane) {
+__device__ __forceinline__ void gemm_epilogue_pre(const GemmArgs& p, f32x4 (&acc)[TN][TM], int m_wave, int n_wave, int lane) {
+  using P = EpiPre<TM, TN>;
   const int lq = lane >> 4;
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory", SD_PRE_CLOBBERS);   // every early load has landed (volatile asm keeps its order)
+  auto row = [&](auto tm_tag) {
+    constexpr int tm = decltype(tm_tag)::value;
+    // this row-tile's residual, 2 registers per 4-channel group (asm volatile: issued after the wait above, in order)
+    u32x2 r[TN];
+    auto rd = [&](auto tn_tag) {
+      constexpr int tn = decltype(tn_tag)::value;
+      constexpr int a = tm * P::RPR + ((TN & 1) && tn == TN - 1 ? 4 * P::PAIRS : 4 * (tn >> 1) + 2 * (tn & 1));
+      r[tn] = u32x2{epi_pre_read<a>(), epi_pre_read<a + 1>()};
+    };
+    rd(std::integral_constant<int, 0>{});
+    if constexpr (TN > 1) rd(std::integral_constant<int, (TN > 1 ? 1 : 0)>{});
+    if constexpr (TN > 2) rd(std::integral_constant<int, (TN > 2 ? 2 : 0)>{});
+    if constexpr (TN > 3) rd(std::integral_constant<int, (TN > 3 ? 3 : 0)>{});
+    if constexpr (TN > 4) rd(std::integral_constant<int, (TN > 4 ? 4 : 0)>{});
+    if constexpr (TN > 5) rd(std::integral_constant<int, (TN > 5 ? 5 : 0)>{});
+    static_assert(TN <= 6, "six sub-tiles per wave");
     const int m = m_wave + tm * 16 + (lane & 15);
-    if (m >= p.M) continue;
+    if (m >= p.M) return;
     const float* rb = p.rowbias ? p.rowbias + (size_t)(m / p.rows_per_batch) * p.ld_rowbias : nullptr;
     const size_t crow = p.c_rpb ? (size_t)(m / p.c_rpb) * p.c_bstride + (size_t)(m % p.c_rpb) * p.ldc : (size_t)m * p.ldc;
     store_row<TN>(p, crow, n_wave, lq, [&](int tn, int n) {
-      f32x4 v = acc[tn][tm] + pre.b[tn];        // (no bias: the descriptor was empty, the loads returned zeros)
+      f32x4 v = acc[tn][tm];
       if (rb) v += *reinterpret_cast<const f32x4*>(rb + n);
-      bf16x4 r4;
-      if ((TN & 1) && tn == TN - 1) {
-        r4 = __builtin_bit_cast(bf16x4, pre.r4[tm]);
-      } else {
-        const u32x4 q = pre.r8[tm][tn >> 1];
-        r4 = __builtin_bit_cast(bf16x4, (tn & 1) ? u32x2{q[2], q[3]} : u32x2{q[0], q[1]});
-      }
-      v[0] += (float)r4[0];
-      v[1] += (float)r4[1];
-      v[2] += (float)r4[2];
-      v[3] += (float)r4[3];
-      return act4(p, v * p.out_scale);
+      return act4(p, add_r16(v, r[tn]) * p.out_scale);
     });
-  }
+  };
+  row(std::integral_constant<int, 0>{});
+  if constexpr (TM > 1) row(std::integral_constant<int, (TM > 1 ? 1 : 0)>{});
+  if constexpr (TM > 2) row(std::integral_constant<int, (TM > 2 ? 2 : 0)>{});
+  if constexpr (TM > 3) row(std::integral_constant<int, (TM > 3 ? 3 : 0)>{});
+  if constexpr (TM > 4) row(std::integral_constant<int, (TM > 4 ? 4 : 0)>{});
+  if constexpr (TM > 5) row(std::integral_constant<int, (TM > 5 ? 5 : 0)>{});
+  static_assert(TM <= 6, "six row-tiles per wave");
 }
 
 // Epilogue of the LayerNorm-folded projections (mi355x_sd_linear_ln): acc <- rstd[m] * acc - mean[m] * rstd[m] * wsum[n]

@@ -67,8 +67,8 @@ __device__ __forceinline__ void sgb_reads_under_mfmas() {
 // PRE: the epilogue's residual / bias operands are fetched during the last K iterations (gemm_epilogue.h EpiPre). Its own
 // instantiation, not a run-time branch: two alternative consumers of the accumulators make the register allocator split their
 // live ranges and spill inside the K loop (header of gemm_epilogue.h).
-template <bool CONV, class CFG, bool LN, int LW = 0, int SG = 0, bool PRE = false>
-__global__ __launch_bounds__(CFG::THREADS + LW * 64, (LW ? 3 : CFG::MIN_WAVES)) void gemm_pipe_kernel(const GemmArgs p) {
+template <bool CONV, class CFG, bool LN, int LW, int SG, bool PRE>
+__device__ __forceinline__ void gemm_pipe_body(const GemmArgs& p) {
   static_assert(!PRE || (LW == 0 && !LN && (CFG::TM + CFG::TN) <= 10), "early epilogue operands: register-pipelined tiles without loader waves");
   constexpr int BM = CFG::BM, BN = CFG::BN, TM = CFG::TM, TN = CFG::TN, ST = CFG::STAGES, NW = CFG::NW;
   constexpr int PW = LW ? LW : NW;                       // waves that own LDS-DMA pieces
@@ -223,16 +223,52 @@ __global__ __launch_bounds__(CFG::THREADS + LW * 64, (LW ? 3 : CFG::MIN_WAVES)) 
     return;
   }
 
+  // The accumulators start at the bias of their channel (GemmArgs::bias_acc: plain bf16-weight launches without split-K): the
+  // loads go out here, ahead of the first LDS-DMA, and are consumed after the prologue's wait -- the epilogue then has no bias
+  // load (one dependent L2 round trip per 4-channel group before, gemm_epilogue.h). Channels past N read a clamped address; they
+  // are never stored.
   f32x4 acc[TN][TM];
+  f32x4 bias4[TN];
+  if (!LN && p.bias_acc) {
 #pragma unroll
-  for (int i = 0; i < TN; ++i)
+    for (int i = 0; i < TN; ++i)
+      bias4[i] = *reinterpret_cast<const f32x4*>(p.bias + min(n0 + wn * (TN * 16) + acc_col<TN>(i, lane >> 4, p.geglu), p.N - 4));
+  } else {
 #pragma unroll
-    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < TN; ++i) bias4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  auto init_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc[i][j] = bias4[i];
+  };
 
-  // early fetch of the epilogue's residual / bias (gemm_epilogue.h EpiPre): the register-pipelined tiles without loader waves
-  // (those are capped at 168 registers), plain bf16 residual launches only (launch_pipe decides)
-  EpiPre<PRE ? TM : 1, PRE ? TN : 1> pre;
+  // early fetch of the epilogue's residual (gemm_epilogue.h EpiPre): the register-pipelined tiles without loader waves (those
+  // are capped at 168 registers), plain bf16 residual launches of at least TM + 2 K-tiles only (launch_pipe decides).
+  // Row-tile j is requested in iteration t1 - 1 - TM + j, right after that iteration's LDS-DMA. At the wait of iteration t (which
+  // must see tile t+1, issued one iteration earlier in FRONT of that iteration's residual loads) the residual loads of iterations
+  // t-1 and t may stay in flight next to the DMA of tile t+2: two K iterations (~2 us) for each batch to land, all of it under
+  // MFMA work. The loads land in registers the compiler does not manage (gemm_epilogue.h tells why); it neither counts nor
+  // waits for them: the counted waits below include them and gemm_epilogue_pre starts with its own wait.
   const int m_pre = m0 + wm * (TM * 16), n_pre = n0 + wn * (TN * 16);
+  [[maybe_unused]] const u32x4 r_srd = PRE ? epi_r_srd(p) : u32x4{0u, 0u, 0u, 0u};
+  [[maybe_unused]] const int t_pre = t1 - 1 - TM;   // >= t0 + 1 (launch_pipe)
+  [[maybe_unused]] int rprev = 0;
+  auto prefetch_rows = [&](const int t) -> int {
+    if constexpr (PRE) {
+      const int j = t - t_pre;
+      if (j < 0 || j >= TM) return 0;
+      if (j == 0) epi_prefetch_row<0, TM, TN>(p, r_srd, m_pre, n_pre, lane);
+      if constexpr (TM > 1) if (j == 1) epi_prefetch_row<(TM > 1 ? 1 : 0), TM, TN>(p, r_srd, m_pre, n_pre, lane);
+      if constexpr (TM > 2) if (j == 2) epi_prefetch_row<(TM > 2 ? 2 : 0), TM, TN>(p, r_srd, m_pre, n_pre, lane);
+      if constexpr (TM > 3) if (j == 3) epi_prefetch_row<(TM > 3 ? 3 : 0), TM, TN>(p, r_srd, m_pre, n_pre, lane);
+      static_assert(!PRE || TM <= 4, "prefetch_rows enumerates four row-tiles");
+      return EpiPre<(PRE ? TM : 1), (PRE ? TN : 1)>::LOADS_PER_ROW;
+    } else {
+      return 0;
+    }
+  };
 
   const int frow = lane & 15, fkc = lane >> 4, rsw = frow & 7;
   const int a_row = (wm * (TM * 16) + frow) * 128, w_row = (wn * (TN * 16) + frow) * 128;
@@ -273,9 +309,7 @@ __global__ __launch_bounds__(CFG::THREADS + LW * 64, (LW ? 3 : CFG::MIN_WAVES)) 
   }
   SD_PIPE_BARRIER();
   stamp(1);
-  if constexpr (PRE) {
-    if (t1 - t0 == 1) epi_prefetch<TM, TN>(p, pre, m_pre, n_pre, lane);   // one K-tile: there is no later point
-  }
+  init_acc();
   read_frag(0, 0);
   int stage = 0;
   if constexpr (LW > 0 && SG) {
@@ -311,22 +345,29 @@ __global__ __launch_bounds__(CFG::THREADS + LW * 64, (LW ? 3 : CFG::MIN_WAVES)) 
     if constexpr (LW == 0) {
       if (t + AHEAD < t1) issue_tile(s_new);
     }
+    [[maybe_unused]] int rcur = 0;
+    if constexpr (PRE) {
+      __builtin_amdgcn_sched_barrier(0);       // the counted waits below rely on: DMA of this iteration, THEN these loads
+      rcur = prefetch_rows(t);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     read_frag(1, stage);
     __builtin_amdgcn_sched_barrier(0);
     mma(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(0xC07F);        // k-step-1 fragments (issued TM*TN MFMAs ago): every read of tile t retired
     if (t + 1 < t1) {
-      if constexpr (LW == 0) {
+      if constexpr (LW == 0 && PRE) {
+        // tile t+1 must have landed. Issued after it: (three stages) the residual loads of iteration t-1, the DMA of tile t+2
+        // and this iteration's residual loads; (two stages) only this iteration's residual loads
+        if (AHEAD == 2) wait_vmcnt_dyn((t + 2 < t1 ? mine : 0) + rprev + rcur);
+        else wait_vmcnt_dyn(rcur);
+        rprev = rcur;
+      } else if constexpr (LW == 0) {
         if (AHEAD == 2 && t + 2 < t1) wait_all_but_newest();   // own pieces of tile t+1 landed, t+2 may stay in flight
         else wait_vmcnt_imm<0>();
       }
       SD_PIPE_BARRIER();                       // publishes tile t+1; every wave is done reading tile t
-      if constexpr (PRE) {
-        // the loop's LAST LDS-DMA wait is behind us (iteration t1 - 2): the epilogue's operands go in flight now and have the rest
-        // of this iteration and all of the last one to land
-        if (t == t1 - 2) epi_prefetch<TM, TN>(p, pre, m_pre, n_pre, lane);
-      }
       read_frag(0, s1);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -362,6 +403,7 @@ __global__ __launch_bounds__(CFG::THREADS + LW * 64, (LW ? 3 : CFG::MIN_WAVES)) 
   }
   SD_PIPE_BARRIER();
   stamp(1);
+  init_acc();
   read_hold(0, 0);
 #pragma unroll
   for (int j = 0; j < Q; ++j) read_stream(j % QN, 0, j / SN, j % SN);
@@ -419,7 +461,7 @@ __global__ __launch_bounds__(CFG::THREADS + LW * 64, (LW ? 3 : CFG::MIN_WAVES)) 
   if constexpr (LN) {
     gemm_epilogue_ln<TM, TN>(p, acc, m_w, n_w, lane);
   } else if constexpr (PRE) {
-    gemm_epilogue_pre<TM, TN>(p, acc, pre, m_w, n_w, lane);
+    gemm_epilogue_pre<TM, TN>(p, acc, m_w, n_w, lane);
   } else {
     gemm_epilogue<TM, TN>(p, acc, m_w, n_w, lane);
   }
@@ -433,6 +475,17 @@ __global__ __launch_bounds__(CFG::THREADS + LW * 64, (LW ? 3 : CFG::MIN_WAVES)) 
       p.ts[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 6 + 5] = ((unsigned long long)(xcc & 15) << 32) | (unsigned)blockIdx.x;
     }
   }
+}
+
+template <bool CONV, class CFG, bool LN, int LW = 0, int SG = 0>
+__global__ __launch_bounds__(CFG::THREADS + LW * 64, (LW ? 3 : CFG::MIN_WAVES)) void gemm_pipe_kernel(const GemmArgs p) {
+  gemm_pipe_body<CONV, CFG, LN, LW, SG, false>(p);
+}
+// the early-residual form: the compiler allocates v0 .. v215 only, v216 .. v255 are the landing zone of the asm loads
+// (gemm_epilogue.h EpiPre; the attribute takes no template-dependent argument, hence the second entry point)
+template <bool CONV, class CFG>
+__global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES) __attribute__((amdgpu_num_vgpr(216))) void gemm_pipe_pre_kernel(const GemmArgs p) {
+  gemm_pipe_body<CONV, CFG, false, 0, 0, true>(p);
 }
 
 // loader waves (template LW): MI355X_SD_GEMM_LOADERS=0 | 4 | 5 (5 = 4 loaders + interleaved fragment reads, template SG) for every
@@ -460,30 +513,43 @@ static int launch_pipe_lw(const GemmArgs& a, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
 
+// early residual fetch (gemm_pipe_pre_kernel) applies: plain bf16 residual launches of the register-pipelined tiles
+template <bool CONV, class CFG, bool LN>
+static bool pre_applies(const GemmArgs& a) {
+  if constexpr (!CONV && !LN && (CFG::TM + CFG::TN) <= 10 && CFG::TM <= 4) {
+    static const bool pre_off = getenv("MI355X_SD_GEMM_NO_PRE") != nullptr;   // A/B switch
+    return !pre_off && a.R && !a.r_f32 && !a.geglu && !a.gate && !a.wscale && a.splitk <= 1 && (!a.bias || a.bias_acc) &&
+           a.K / BK >= CFG::TM + 2 && !(a.N & 7) && ((size_t)(a.M - 1) * a.ldr + a.N) * 2 < 0xFFFF0000ull;
+  } else {
+    return false;
+  }
+}
+
 template <bool CONV, class CFG, bool LN>
 static int launch_pipe(const GemmArgs& a, hipStream_t stream) {
   // only the 256x160 three-stage tile leaves room for 12 waves per CU (166 VGPRs <= the 168 of three waves per SIMD); the larger
-  // register tiles (196-246 VGPRs) would spill into their K loops
+  // register tiles (196-246 VGPRs) would spill into their K loops. By shape (-1): the long-K launches that cannot take the early
+  // residual fetch -- inside the step the K = 5120 FF2 runs better on that than on loader waves (GEMM class 39.2 vs 40.2 ms,
+  // profiles/r03_s5_step_ab.txt), the 11520-deep convs the other way round (conv class 10.4 vs 10.7 ms)
   if constexpr (CFG::NW == 8 && !LN && CFG::BN == 160 && CFG::STAGES == 3) {
     if (gemm_loaders() == 4) return launch_pipe_lw<CONV, CFG, LN, 4>(a, stream);
-    if (gemm_loaders() == 5 || (gemm_loaders() == -1 && a.K >= 4096 && a.splitk <= 1))
+    if (gemm_loaders() == 5 || (gemm_loaders() == -1 && a.K >= 4096 && a.splitk <= 1 && !pre_applies<CONV, CFG, LN>(a)))
       return launch_pipe_lw<CONV, CFG, LN, 4, 1>(a, stream);   // + interleaved fragment reads
   }
   const int ntm = (a.M + CFG::BM - 1) / CFG::BM, ntn = (a.N + CFG::BN - 1) / CFG::BN;
   const int ny = a.splitk > 1 ? a.splitk : 1;
-  if constexpr (!CONV && !LN && (CFG::TM + CFG::TN) <= 10) {
-    // residual launches (to_out, proj_out, the K < 4096 FF2s): epilogue operands fetched during the last K iterations. bf16
-    // residual rows addressed with 32-bit offsets, no GEGLU / gate / fp8 scale / split-K (those epilogues live elsewhere); not
-    // the implicit-GEMM convs (their gather state leaves no room: 256 registers + spills at 256x160)
-    static const bool pre_off = getenv("MI355X_SD_GEMM_NO_PRE") != nullptr;   // A/B switch
-    if (!pre_off && a.R && !a.r_f32 && !a.geglu && !a.gate && !a.wscale && a.splitk <= 1 &&
-        ((size_t)(a.M - 1) * a.ldr + a.N) * 2 < 0xFFFF0000ull) {
+  if constexpr (!CONV && !LN && (CFG::TM + CFG::TN) <= 10 && CFG::TM <= 4) {
+    // residual launches (to_out, proj_out, FF2): the residual is fetched during the last TM + 1 K iterations. bf16 residual rows
+    // addressed with 32-bit offsets, N % 8 == 0 (a 16-byte pair load never straddles the row's end), bias in the accumulators, no
+    // GEGLU / gate / fp8 scale / split-K (those epilogues live elsewhere); not the implicit-GEMM convs (their gather state leaves no
+    // room for the 40 landing registers)
+    if (pre_applies<CONV, CFG, LN>(a)) {
       static const bool pre_ok = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<CONV, CFG, LN, 0, 0, true>),
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_pre_kernel<CONV, CFG>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES) == hipSuccess;
       }();
       if (!pre_ok) return SD_ERR_HIP;
-      hipLaunchKernelGGL((gemm_pipe_kernel<CONV, CFG, LN, 0, 0, true>), dim3(ntm * ntn, ny), dim3(CFG::THREADS), CFG::LDS_BYTES, stream, a);
+      hipLaunchKernelGGL((gemm_pipe_pre_kernel<CONV, CFG>), dim3(ntm * ntn, ny), dim3(CFG::THREADS), CFG::LDS_BYTES, stream, a);
       return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
     }
   }
@@ -498,8 +564,11 @@ static int launch_pipe(const GemmArgs& a, hipStream_t stream) {
 }
 
 // tile: 128 | 160 (pick_tile ids). Returns SD_ERR_UNSUPPORTED when the fast path does not apply (caller falls back).
-int launch_gemm_pipe(const GemmArgs& a, int tile, void* stream_) {
+int launch_gemm_pipe(const GemmArgs& a_in, int tile, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  GemmArgs a = a_in;
+  static const bool bias_acc_off = getenv("MI355X_SD_GEMM_NO_BIAS_ACC") != nullptr;   // A/B switch
+  a.bias_acc = (a.bias && !a.wscale && a.splitk <= 1 && !a.rowstat && !bias_acc_off) ? 1 : 0;
   static const bool off = getenv("MI355X_SD_NO_PIPE") != nullptr;
   static const bool off128 = getenv("MI355X_SD_NO_PIPE128") != nullptr;   // A/B switch for the 128x128 variant
   if (tile == 128 && off128) return SD_ERR_UNSUPPORTED;
@@ -509,7 +578,8 @@ int launch_gemm_pipe(const GemmArgs& a, int tile, void* stream_) {
   if (tile == 320 && (off320 || (a.conv && a.geglu))) return SD_ERR_UNSUPPORTED;
   // 256x256: the phased kernel (gemm256.hip) stays the default where it can run (id 257); id 256 is what pick_tile
   // returns when it cannot (A row remap of the MMDiT output projections) and takes the pipelined loop here
-  if (tile != 128 && tile != 160 && tile != 320 && tile != 256 && !(on256 && tile == 257)) return SD_ERR_UNSUPPORTED;
+  if (tile != 128 && tile != 160 && tile != 320 && tile != 256 && tile != 129 && !(on256 && tile == 257)) return SD_ERR_UNSUPPORTED;
+  if (a.geglu && tile == 129) return SD_ERR_UNSUPPORTED;   // odd number of 16-column sub-tiles per wave
   if (a.conv && (a.Cin & 7)) return SD_ERR_UNSUPPORTED;
   // 32-bit buffer offsets: every addressed byte of A and W must sit below 4 GiB - 64 KiB
   const size_t lim = 0xFFFF0000ull;
@@ -528,6 +598,8 @@ int launch_gemm_pipe(const GemmArgs& a, int tile, void* stream_) {
     if (ln) return launch_pipe<false, Cfg256x320, true>(a, stream);
     return a.conv ? launch_pipe<true, Cfg256x320, false>(a, stream) : launch_pipe<false, Cfg256x320, false>(a, stream);
   }
+  if (tile == 129 && !ln) return a.conv ? launch_pipe<true, Cfg128x160, false>(a, stream) : launch_pipe<false, Cfg128x160, false>(a, stream);
+  if (tile == 129) return SD_ERR_UNSUPPORTED;
   if (tile == 160) {
     if (ln) return launch_pipe<false, Cfg256x160s3, true>(a, stream);
     return a.conv ? launch_pipe<true, Cfg256x160s3, false>(a, stream) : launch_pipe<false, Cfg256x160s3, false>(a, stream);

@@ -27,6 +27,43 @@ for M, N, K, resid in ((8192, 1280, 5120, True), (1000, 1280, 4096, False), (819
     res[f"gemm {M}x{N}x{K}{'+R' if resid else ''}"] = dict(
         sha=hashlib.sha256(out.cpu().view(torch.int16).numpy().tobytes()).hexdigest()[:16],
         rel=((out[:512].float() - ref).norm() / ref.norm()).item())
+# epilogue forms (round 3): residual rows inside a wider buffer and ragged M / N (early residual fetch and its fall-backs: N % 8 != 0,
+# fewer than TM + 2 K-tiles), no bias, out_scale, a 640-wide launch on the streaming 256x320 tile, GEGLU (bias in the accumulators)
+for M, N, K, kind in ((8200, 1280, 1280, "wide"), (300, 1288, 640, "wide"), (8200, 1284, 1280, "plain"), (515, 640, 256, "plain"),
+                      (32768, 640, 640, "nobias"), (4100, 640, 640, "scale"), (2048, 2560, 1280, "geglu"), (8192, 10240, 1280, "geglu")):
+    g = torch.Generator(device="cuda").manual_seed(M + N + K + 1)
+    a = torch.randn(M, K, device="cuda", generator=g).to(ed)
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(ed)
+    b = None if kind == "nobias" else torch.randn(N, device="cuda", generator=g)
+    if kind == "geglu":
+        out = ops.linear(a, w, b, geglu=True)
+        y = (a[:256].float() @ w.float().t() + b).reshape(256, N // 32, 2, 16)
+        ref = (y[:, :, 0] * F.gelu(y[:, :, 1])).reshape(256, N // 2)
+        got = out[:256].float()
+    else:
+        rbig = torch.randn(M, N + 24, device="cuda", generator=g).to(ed)
+        r = rbig[:, 8:8 + N] if kind == "wide" else rbig[:, :N].contiguous()
+        sc = 0.5 if kind == "scale" else 1.0
+        out = ops.linear(a, w, b, residual=r, out_scale=sc)
+        rows = slice(M - 256, M)
+        ref = (a[rows].float() @ w.float().t() + (b if b is not None else 0) + r[rows].float()) * sc
+        got = out[rows].float()
+    res[f"gemm {M}x{N}x{K} {kind}"] = dict(sha=hashlib.sha256(out.cpu().view(torch.int16).numpy().tobytes()).hexdigest()[:16],
+                                           rel=((got - ref).norm() / ref.norm()).item())
+# resnet convs: time-embedding row bias (conv1) and shortcut residual (conv2), the operands the batched epilogue fetches per row-tile
+for B, H, W, Cin, Cout in ((2, 32, 32, 640, 640), (1, 30, 34, 320, 640)):
+    g = torch.Generator(device="cuda").manual_seed(B + H + Cin + 7)
+    x = torch.randn(B, H, W, Cin, device="cuda", generator=g).to(ed)
+    w = (torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) / (9 * Cin) ** 0.5).to(ed)
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
+    b = torch.randn(Cout, device="cuda", generator=g)
+    rb = torch.randn(B, Cout, device="cuda", generator=g)
+    r = torch.randn(B * H * W, Cout, device="cuda", generator=g).to(ed)
+    out = ops.conv3x3(x, wp, b, rowbias=rb, residual=r, out_scale=0.7)
+    ref = (F.conv2d(x[:1].float().permute(0, 3, 1, 2), w.float(), b, padding=1).permute(0, 2, 3, 1).reshape(-1, Cout) + rb[0] + r[:H * W].float()) * 0.7
+    res[f"conv {B}x{H}x{W}x{Cin}->{Cout} +temb+R"] = dict(
+        sha=hashlib.sha256(out.cpu().view(torch.int16).numpy().tobytes()).hexdigest()[:16],
+        rel=((out[:H * W].float() - ref).norm() / ref.norm()).item())
 for B, H, W, Cin, Cout in ((8, 32, 32, 1280, 1280), (2, 30, 34, 640, 1280)):      # 11520- / 5760-deep implicit-GEMM convs
     g = torch.Generator(device="cuda").manual_seed(B + H + Cin)
     x = torch.randn(B, H, W, Cin, device="cuda", generator=g).to(ed)

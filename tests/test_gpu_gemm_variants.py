@@ -12,7 +12,17 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+_CACHE = {}
+
+
 def _run(env_extra):
+    key = tuple(sorted(env_extra.items()))
+    if key not in _CACHE:
+        _CACHE[key] = _run_child(env_extra)
+    return _CACHE[key]
+
+
+def _run_child(env_extra):
     env = dict(os.environ, **env_extra)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gemm_variant_child.py")], env=env, cwd=ROOT, capture_output=True,
                        text=True, timeout=600)
@@ -31,3 +41,34 @@ def test_loader_wave_variants_are_bit_identical():
     # and the library's default (no variable) is one of them
     dflt = _run({})
     assert all(dflt[k]["sha"] == base[k]["sha"] for k in base)
+
+
+def test_epilogue_operand_variants():
+    """Round-3 epilogue forms (csrc/gemm_epilogue.h): residual fetched during the last K iterations, a row-tile's operands fetched in
+    one batch, bias as the accumulators' initial value. The first two change WHEN operands are loaded, never the arithmetic:
+    bit-identical to the group-at-a-time epilogue. The bias moves from the end of the fp32 sum to its start: same tolerance."""
+    base = _run({})
+    for k, v in base.items():
+        assert v["rel"] < 4e-3, (k, v)
+    for env in ({"MI355X_SD_GEMM_NO_PRE": "1"}, {"MI355X_SD_GEMM_NO_EPI_BATCH": "1"},
+                {"MI355X_SD_GEMM_NO_PRE": "1", "MI355X_SD_GEMM_NO_EPI_BATCH": "1"}):
+        got = _run(env)
+        for k in base:
+            assert got[k]["sha"] == base[k]["sha"], (env, k, got[k], base[k])
+    got = _run({"MI355X_SD_GEMM_NO_BIAS_ACC": "1"})
+    for k, v in got.items():
+        assert v["rel"] < 4e-3, (k, v)
+
+
+@pytest.mark.parametrize("tile_map", ["160:129", "257:129,320:129"])
+def test_four_wave_tiles(tile_map):
+    """The four-wave tiles built for two co-resident blocks per CU (gemm_cfg.h: 128x160) substituted for the
+    picker's choice: every output element still accumulates its K products in the same order -> bit-identical."""
+    base = _run({})
+    got = _run({"MI355X_SD_GEMM_TILE_MAP": tile_map})
+    for k in base:
+        assert got[k]["rel"] < 4e-3, (tile_map, k, got[k])
+        # same loop, other tile: bit-identical. (Launches the picker gives to the phased 256x256 kernel, id 257, walk K in another
+        # order: equal within the tolerance only.)
+        if "257" not in tile_map:
+            assert got[k]["sha"] == base[k]["sha"], (tile_map, k, got[k], base[k])

@@ -372,13 +372,15 @@ def test_sdpa_additive_mask(ops):
     qd, kd, vd = dev(q), dev(k), dev(v)
     none = ops.sdpa(qd, kd, vd)
     keep = ops.sdpa(qd, kd, vd, bias=torch.zeros(B, 1, 1, Skv, device="cuda"))
-    assert torch.equal(none, keep)
+    # (two kernels since round 3: short key sequences without a mask take the single-pass kernel, a mask the flash kernel with
+    # its deferred rescale: the same softmax rounded at different points -- equal within the per-op bar, not bit for bit)
+    check(none, keep.float().cpu(), rel=5e-3, what="sdpa keep-all mask == no mask")
     m = torch.ones(B, Skv)
     m[:, -1] = 0
     bias = ((1 - m) * -10000.0)[:, None, None, :]
     masked = ops.sdpa(qd, kd, vd, bias=bias.cuda().contiguous())
     trunc = ops.sdpa(qd, kd[:, :-1], vd[:, :-1])
-    assert torch.allclose(masked.float(), trunc.float(), rtol=1e-3, atol=1e-5)
+    check(masked, trunc.float().cpu(), rel=5e-3, what="sdpa masked last key == truncated")
     full = torch.randn(B, H, Sq, Skv, generator=g)
     ref = U.sdpa_math(q, k, v, attn_mask=full)
     check(ops.sdpa(qd, kd, vd, bias=full.cuda()), ref, rel=5e-3, what="sdpa full bias")
