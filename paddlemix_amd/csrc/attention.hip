@@ -58,9 +58,13 @@ struct AttLds {
 // FL bit 1 (LOG2, needs LAZY, no mask): the caller folded scale * log2(e) into the queries (the UNet builder folds it into
 //   the to_q weights), so a score IS the exponent: the S^T accumulators start at -reference instead of 0 (a persistent
 //   16-register C operand, rewritten only at a rescale) and exp2 needs no multiply-add per score.
+// FL bit 2 (WIDE): O leaves as 16-byte stores (the launcher checked: rows 16-byte aligned, D % 16 == 0, no accumulation): the
+//   half-waves hold adjacent 8-byte pieces of a row, one v_permlane32_swap per dword pairs them up (cdna guide T21). Its own
+//   instantiation: next to the 8-byte store loop in one kernel it cost 3 registers = the occupancy step at 168.
 template <int DP, bool HAS_BIAS, int QT = 1, int FL = 0>
-__global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_kernel(const AttnArgs p) {
-  constexpr bool LAZY = (FL & 1) != 0, LOG2 = (FL & 2) != 0;
+__global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? ((FL & 4) ? 3 : 2) : 1) void attention_kernel(const AttnArgs p) {
+  constexpr bool LAZY = (FL & 1) != 0, LOG2 = (FL & 2) != 0, WIDE = (FL & 4) != 0;
+  static_assert(!WIDE || QT == 1, "wide stores: the one-query-tile form");
   static_assert(!LOG2 || (LAZY && !HAS_BIAS), "LOG2 builds on the lazy reference and has no additive mask");
   using L = AttLds<DP>;
   constexpr int NBUF = (DP <= 96) ? 2 : 1;
@@ -155,6 +159,11 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_ker
   };
 
   const int ntiles = (p.Skv + KVBLK - 1) / KVBLK;
+  if (p.dbg & 16) {   // experiment: the blocks that share a CU (ids 256 apart under round-robin placement) start a third of a tile apart
+    const int ph = (blockIdx.x >> 8) % 3;
+    if (ph == 1) __builtin_amdgcn_s_sleep(8);
+    if (ph == 2) __builtin_amdgcn_s_sleep(16);
+  }
   load_q(qb * QT, qf);   // in flight together with the first K/V tile
   load_kv(0);
   store_kv(0);
@@ -310,6 +319,7 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_ker
     l_run += psum;
 
     // ---- O^T += V^T P^T ----
+    if (p.dbg & 4) __builtin_amdgcn_s_setprio(1);   // experiment: the matrix interval outranks the co-resident blocks' VALU work
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       // B-operand element i of pf[kk] is key kk*16 + (i&3) + 8*(i>>2) + 4*hi -> the A operand must match
@@ -322,6 +332,7 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_ker
         o[db] = mfma_32x32x16(vf, pf[kk], o[db]);
       }
     }
+    if (p.dbg & 4) __builtin_amdgcn_s_setprio(0);
 
     if (NBUF == 2) {
       if (t + 1 < ntiles && stage_kv && !(p.dbg & 1)) store_kv(buf ^ 1);
@@ -362,7 +373,20 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? 2 : 1) void attention_ker
     // ---- finalize: O[q][d] = O^T[d][q] / l ; lane holds d = db*32 + (r&3) + 8*(r>>2) + 4*hi ----
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv_l = (l_tot > 0.f) ? 1.0f / l_tot : 0.f;
-    if (q_ok) {
+    if constexpr (WIDE) {
+      bf16* orow = Op + (size_t)(q_ok ? q_row : 0) * p.o_ts + hi * 8;
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int c = 0; c < 4; c += 2) {
+          const unsigned a0 = pack_bf16(o[db][4 * c + 0] * inv_l, o[db][4 * c + 1] * inv_l), a1 = pack_bf16(o[db][4 * c + 2] * inv_l, o[db][4 * c + 3] * inv_l);
+          const unsigned b0 = pack_bf16(o[db][4 * c + 4] * inv_l, o[db][4 * c + 5] * inv_l), b1 = pack_bf16(o[db][4 * c + 6] * inv_l, o[db][4 * c + 7] * inv_l);
+          const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+          const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+          const u32x4 pk = {r0[0], r1[0], r0[1], r1[1]};
+          if (q_ok && db * 32 + c * 8 + hi * 8 < p.D) *reinterpret_cast<u32x4*>(orow + db * 32 + c * 8) = pk;
+        }
+    } else if (q_ok) {
       bf16* orow = Op + (size_t)q_row * p.o_ts;
 #pragma unroll
       for (int db = 0; db < DB; ++db)
@@ -624,12 +648,16 @@ static int launch_dp(const AttnArgs& a0, hipStream_t stream) {
   }
   const int nqb = (a.Sq + QBLK - 1) / QBLK;
   dim3 grid(nqb * a.B * a.H), block(ATT_THREADS);
+  static const bool no_wide = getenv("MI355X_SD_ATTN_NO_WIDE") != nullptr;   // A/B switch
+  const bool wide = !no_wide && a.accum == 0.f && !(a.o_ts & 7) && !(a.o_bs & 7) && !(reinterpret_cast<uintptr_t>(a.O) & 15) && !(a.D & 15);
   if (a.bias) {
     hipLaunchKernelGGL((attention_kernel<DP, true, 1, 0>), grid, block, 0, stream, a);
   } else if (DP == 64 && a.log2) {
-    hipLaunchKernelGGL((attention_kernel<DP, false, 1, (DP == 64 ? 3 : 0)>), grid, block, 0, stream, a);
+    if (wide) hipLaunchKernelGGL((attention_kernel<DP, false, 1, (DP == 64 ? 7 : 0)>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((attention_kernel<DP, false, 1, (DP == 64 ? 3 : 0)>), grid, block, 0, stream, a);
   } else if (lazy) {
-    hipLaunchKernelGGL((attention_kernel<DP, false, 1, (DP == 64 ? 1 : 0)>), grid, block, 0, stream, a);
+    if (wide) hipLaunchKernelGGL((attention_kernel<DP, false, 1, (DP == 64 ? 5 : 0)>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((attention_kernel<DP, false, 1, (DP == 64 ? 1 : 0)>), grid, block, 0, stream, a);
   } else {
     hipLaunchKernelGGL((attention_kernel<DP, false, 1, 0>), grid, block, 0, stream, a);
   }

@@ -330,6 +330,18 @@ static int pick_tile_model(const GemmArgs& a) {
     const long per_cu = (tiles + 255) / 256;
     double cost = (double)per_cu * (c.bm + c.bn);
     if (c.id == 128) cost *= 0.95;   // two co-resident blocks hide each other's prologue / epilogue
+    // Short-K plain GEMMs (K <= 1536, no GEGLU, not a conv): the 256x160 tile is the best or within 2 % of the best of the five
+    // families on every such shape of the SDXL and SD3 steps (profiles/r03_s8_tile_sweep.txt: fused QKV 104.1 vs 105.8 us on
+    // 256x256 and 119.6 on 256x320, the 640-wide out-projections 50.1 vs 53.8, 32768 x 1920 x 640 125.0 vs 132.8, SD3's
+    // 32768 x 1536 x 1536 + R 175.0 vs 199.3) although the bytes-per-CU model below ranks the larger tiles first: its rounds are
+    // exact multiples of the chip there, its residual arrives early (gemm_pipe_pre_kernel), and with 20-24 K-tiles per output
+    // tile the per-tile fixed costs weigh as much as the loop. Long K keeps the model's choice (FF2 at K = 5120 / 6144, every conv).
+    if (c.id == 160 && !a.conv && !a.geglu && a.K <= 1536 && !a.wscale && !a.rowstat && !a.a_rpb && !a.c_rpb) cost *= 0.6;   // (measured forms only)
+    static const double p257 = [] {   // MI355X_SD_GEMM_P257: re-weights the phased 256x256 kernel (A/B measurements)
+      const char* e = getenv("MI355X_SD_GEMM_P257");
+      return e ? atof(e) : 1.0;
+    }();
+    if (c.id == 257) cost *= p257;
     if (cost < best_cost) {
       best_cost = cost;
       best = c.id;

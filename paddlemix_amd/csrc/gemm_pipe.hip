@@ -78,24 +78,35 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& p) {
   unsigned char* As = smem;                 // [ST][BM][128 B]
   unsigned char* Ws = smem + ST * STAGE_A;  // [ST][BN][128 B]
 
-  const int tid = threadIdx.x;
+  const int ntn = (p.N + BN - 1) / BN;
+  const int ntm = (p.M + BM - 1) / BM;
+  // Persistent blocks (round 3): launches of more tiles than the chip holds blocks start only that many blocks, block b walks the
+  // tiles b, b + gridDim.x, ... -- the tiles the dispatcher would have handed it anyway (same XCD, same L2 neighbourhood), without
+  // the ~3.4 us it takes to re-dispatch 256 blocks x 8 waves at every round boundary (scripts/gemm_timeline.py: FF1's second round
+  // starts 45 us after the first although a tile takes 41). The only cost: one barrier between the K loop and the epilogue, so
+  // that no wave's next prologue DMA overwrites a stage another wave still reads; a wave that is done with its stores goes
+  // straight on to the next tile's prologue while slower waves are still storing.
+  const int nvb = ntm * ntn;
+  const bool persist = (int)gridDim.x < nvb;             // launch-uniform
+  for (int vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+  // (the thread id is re-read through an opaque asm per tile: otherwise every per-lane constant of the prologue is hoisted out of
+  // this loop and kept alive across the K loop for the next tile -- 256 VGPRs and spills at the 256x320 tiles)
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // timeline diagnostics (p.ts != NULL only under scripts/gemm_timeline.py): thread 0 of each block stamps the 100-MHz wall clock
   // (not in the loader-wave kernels: they live on exactly the 168 registers of three waves per SIMD and the stamp costs one)
   auto stamp = [&](const int slot) {
     if constexpr (LW == 0) {
-      if (p.ts && tid == 0) p.ts[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 6 + slot] = wall_clock64();
+      if (p.ts && tid == 0) p.ts[(size_t)(blockIdx.y * nvb + vb) * 6 + slot] = wall_clock64();
     }
   };
-  stamp(0);
   const bool loader = LW > 0 && wave >= NW;              // wave-uniform
   const int pw = LW ? (loader ? wave - NW : 0) : wave;   // piece-owner index of this wave
   const int wm = wave / CFG::WAVES_N, wn = wave % CFG::WAVES_N;
-
-  const int ntn = (p.N + BN - 1) / BN;
-  const int ntm = (p.M + BM - 1) / BM;
-  const int lid = xcd_remap(blockIdx.x, ntm * ntn);
+  stamp(0);
+  const int lid = xcd_remap(vb, nvb);
   int tile_m, tile_n;
   tile_coords(lid, ntm, ntn, p.gm, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -220,7 +231,8 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& p) {
         }
       }
     }
-    return;
+    if (persist) SD_PIPE_BARRIER();   // (the compute waves' barrier between K loop and epilogue)
+    continue;
   }
 
   // The accumulators start at the bias of their channel (GemmArgs::bias_acc: plain bf16-weight launches without split-K): the
@@ -437,6 +449,7 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& p) {
   }
   }
 
+  if (persist) SD_PIPE_BARRIER();   // every wave has read its last fragments: the next tile's prologue may overwrite the stages
   const int m_w = m0 + wm * (TM * 16), n_w = n0 + wn * (TN * 16);
   if constexpr (LW == 0) {
     if (p.ts) {   // (the stamp must not be taken before the accumulators are final: touch one)
@@ -472,9 +485,10 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& p) {
     if (tid == 0) {
       unsigned xcc;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-      p.ts[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 6 + 5] = ((unsigned long long)(xcc & 15) << 32) | (unsigned)blockIdx.x;
+      p.ts[(size_t)(blockIdx.y * nvb + vb) * 6 + 5] = ((unsigned long long)(xcc & 15) << 32) | (unsigned)vb;
     }
   }
+  }   // tiles of this block
 }
 
 template <bool CONV, class CFG, bool LN, int LW = 0, int SG = 0>
@@ -486,6 +500,25 @@ __global__ __launch_bounds__(CFG::THREADS + LW * 64, (LW ? 3 : CFG::MIN_WAVES)) 
 template <bool CONV, class CFG>
 __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES) __attribute__((amdgpu_num_vgpr(216))) void gemm_pipe_pre_kernel(const GemmArgs p) {
   gemm_pipe_body<CONV, CFG, false, 0, 0, true>(p);
+}
+
+// Grid of a launch: one block per tile, capped at what the chip holds at once (persistent blocks, see the kernel) when there are
+// more tiles than that. MI355X_SD_GEMM_PERSIST=0: one block per tile always (A/B switch).
+template <class CFG, int LW>
+static int pipe_grid_x(int tiles, int ny) {
+  static const bool off = [] {
+    const char* e = getenv("MI355X_SD_GEMM_PERSIST");
+    return e && atoi(e) == 0;
+  }();
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
+  }();
+  // blocks per CU by LDS and registers: the eight-wave tiles (and anything with loader waves) own a CU, the four-wave ones share it
+  constexpr int bpc = (CFG::NW == 8 || LW > 0) ? 1 : 2;
+  const int cap = cus * bpc;
+  return (off || ny > 1 || tiles <= cap) ? tiles : cap;
 }
 
 // loader waves (template LW): MI355X_SD_GEMM_LOADERS=0 | 4 | 5 (5 = 4 loaders + interleaved fragment reads, template SG) for every
@@ -508,7 +541,7 @@ static int launch_pipe_lw(const GemmArgs& a, hipStream_t stream) {
   if (!attr_ok) return SD_ERR_HIP;
   const int ntm = (a.M + CFG::BM - 1) / CFG::BM, ntn = (a.N + CFG::BN - 1) / CFG::BN;
   const int ny = a.splitk > 1 ? a.splitk : 1;
-  hipLaunchKernelGGL((gemm_pipe_kernel<CONV, CFG, LN, LW, SG>), dim3(ntm * ntn, ny), dim3(CFG::THREADS + LW * 64), CFG::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL((gemm_pipe_kernel<CONV, CFG, LN, LW, SG>), dim3(pipe_grid_x<CFG, LW>(ntm * ntn, ny), ny), dim3(CFG::THREADS + LW * 64), CFG::LDS_BYTES, stream, a);
   if (a.splitk > 1) launch_splitk_reduce(a, stream);
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
@@ -549,7 +582,7 @@ static int launch_pipe(const GemmArgs& a, hipStream_t stream) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES) == hipSuccess;
       }();
       if (!pre_ok) return SD_ERR_HIP;
-      hipLaunchKernelGGL((gemm_pipe_pre_kernel<CONV, CFG>), dim3(ntm * ntn, ny), dim3(CFG::THREADS), CFG::LDS_BYTES, stream, a);
+      hipLaunchKernelGGL((gemm_pipe_pre_kernel<CONV, CFG>), dim3(pipe_grid_x<CFG, 0>(ntm * ntn, ny), ny), dim3(CFG::THREADS), CFG::LDS_BYTES, stream, a);
       return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
     }
   }
@@ -558,7 +591,7 @@ static int launch_pipe(const GemmArgs& a, hipStream_t stream) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES) == hipSuccess;
   }();
   if (!attr_ok) return SD_ERR_HIP;
-  hipLaunchKernelGGL((gemm_pipe_kernel<CONV, CFG, LN>), dim3(ntm * ntn, ny), dim3(CFG::THREADS), CFG::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL((gemm_pipe_kernel<CONV, CFG, LN>), dim3(pipe_grid_x<CFG, 0>(ntm * ntn, ny), ny), dim3(CFG::THREADS), CFG::LDS_BYTES, stream, a);
   if (a.splitk > 1) launch_splitk_reduce(a, stream);
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }

@@ -36,6 +36,13 @@ GEMMS = [("to_out", 8192, 1280, 1280, False, True, True, 192),
 CONVS = [("c1280", 8, 32, 32, 1280, 1280, True, False, 10),
          ("c320", 8, 128, 128, 320, 320, False, True, 7),
          ("c640", 8, 64, 64, 640, 640, True, False, 6)]
+if os.environ.get("GEMM_VARIANTS_ALL"):   # every distinct shape of the SDXL step (+ the SD3-medium block GEMMs): the tile sweep of round 3
+    GEMMS += [("g1280x2560", 8192, 1280, 2560, False, False, True, 2), ("g320x640", 131072, 320, 640, False, False, True, 2),
+              ("g640x1920", 32768, 640, 1920, False, False, True, 1), ("g320x960", 131072, 320, 960, False, False, True, 1),
+              ("sd3_qkv", 32768, 4608, 1536, False, False, True, 24), ("sd3_out", 32768, 1536, 1536, False, True, True, 24),
+              ("sd3_ff1", 32768, 6144, 1536, False, False, True, 24), ("sd3_ff2", 32768, 1536, 6144, False, True, True, 24)]
+    CONVS += [("c320x8640", 8, 128, 128, 960, 320, True, False, 1), ("c640x11520", 8, 64, 64, 1280, 640, True, False, 1),
+              ("c1280x23040", 8, 32, 32, 2560, 1280, True, False, 2), ("c640x17280", 8, 64, 64, 1920, 640, True, False, 1)]
 NSET = 4
 out = {}
 

@@ -51,7 +51,8 @@ def test_epilogue_operand_variants():
     for k, v in base.items():
         assert v["rel"] < 4e-3, (k, v)
     for env in ({"MI355X_SD_GEMM_NO_PRE": "1"}, {"MI355X_SD_GEMM_NO_EPI_BATCH": "1"},
-                {"MI355X_SD_GEMM_NO_PRE": "1", "MI355X_SD_GEMM_NO_EPI_BATCH": "1"}):
+                {"MI355X_SD_GEMM_NO_PRE": "1", "MI355X_SD_GEMM_NO_EPI_BATCH": "1"},
+                {"MI355X_SD_GEMM_PERSIST": "0"}):   # one block per tile instead of persistent blocks walking several
         got = _run(env)
         for k in base:
             assert got[k]["sha"] == base[k]["sha"], (env, k, got[k], base[k])
