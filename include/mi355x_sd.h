@@ -94,6 +94,33 @@ int mi355x_sd_unet_num_launches(void* handle);
 int mi355x_sd_unet_forward(void* handle, void* stream, const float* sample, const float* timestep,
                            const float* encoder_hidden_states, const float* text_embeds, const float* time_ids,
                            const float* in_scale, float* out, int use_graph);
+/* The optional inputs of UNet2DConditionModel.forward that change the PROGRAM are chosen at plan time (plan_ex flags), their
+ * tensors are handed over per call (forward_ex; a NULL / absent input whose flag was planned is MI355X_SD_ERR_INVALID, as is a
+ * non-NULL one that was not planned):
+ *   ENC_MASK   encoder_attention_mask [B, L], 1 = attend, 0 = masked: becomes the additive bias (1 - m) * -10000 of every
+ *              cross-attention (unet_2d_condition.py:925-927)
+ *   SELF_MASK  attention_mask [B, H*W]: the same for every self-attention (:916-923). Like the reference, this only works for a
+ *              UNet whose attention levels all see H*W tokens; a level with another token count fails the plan (the reference
+ *              fails on the shapes of the add)
+ *   CONTROLNET down_block_additional_residuals (one fp32 NCHW tensor per skip connection, in the order the down path produces
+ *              them: conv_in first) + mid_block_additional_residual (:1121-1132, 1151-1155), e.g. the outputs of
+ *              ControlNetModel; both or neither
+ * class_labels, timestep_cond and the IP-Adapter image_embeds are inputs of the Python-planned model only (paddlemix_amd/unet.py);
+ * a config that needs them is refused at create. */
+#define MI355X_SD_UNET_ENC_MASK 1
+#define MI355X_SD_UNET_SELF_MASK 2
+#define MI355X_SD_UNET_CONTROLNET 4
+int mi355x_sd_unet_plan_ex(void* handle, int B, int H, int W, int L, int flags, size_t* workspace_bytes);
+/* number of skip tensors = length of down_block_additional_residuals, and the [C, H, W] of skip i (i == count: the mid output) */
+int mi355x_sd_unet_num_skips(void* handle);
+int mi355x_sd_unet_skip_shape(void* handle, int index, int* C, int* H, int* W);
+int mi355x_sd_unet_forward_ex(void* handle, void* stream, const float* sample, const float* timestep,
+                              const float* encoder_hidden_states, const float* text_embeds, const float* time_ids,
+                              const float* in_scale, const float* encoder_attention_mask, const float* attention_mask,
+                              const float* const* down_block_additional_residuals, int num_down_residuals,
+                              const float* mid_block_additional_residual, float* out, int use_graph);
+/* bias[i] = (1 - mask[i]) * -10000: the additive form of a keep-mask (unet_2d_condition.py:921-927) */
+int mi355x_sd_mask_to_bias(const float* mask, float* bias, int64_t n, void* stream);
 
 /* flags for mi355x_sd_linear / mi355x_sd_conv3x3 */
 #define MI355X_SD_GEGLU 1    /* W/bias rows interleaved [16 value | 16 gate]; writes N/2 columns value*gelu_erf(gate) */

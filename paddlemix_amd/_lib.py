@@ -19,6 +19,7 @@ LIB_PATH = os.path.join(_HERE, _BUILDS[ELEM_NAME][0])
 
 ABI_VERSION = 9
 GEGLU, OUT_F32, SILU, GELU_TANH, PAD_BR, R_F32, CONV_KB64 = 1, 2, 4, 8, 16, 32, 64
+UNET_ENC_MASK, UNET_SELF_MASK, UNET_CONTROLNET = 1, 2, 4   # mi355x_sd_unet_plan_ex flags
 SDPA_LOG2 = 1
 MOD_F32, MOD_ELEM = 0, 1
 
@@ -105,6 +106,7 @@ SIGNATURES = {
                                          c_void_p]),
     "mi355x_sd_softmax_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "mi355x_sd_axpby": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mi355x_sd_mask_to_bias": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "mi355x_sd_cfg_axpby": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_void_p]),
     # seam B1: the whole UNet behind a handle (csrc/unet_exec.hip)
     "mi355x_sd_unet_create": (c_int, [c_char_p, POINTER(c_void_p)]),
@@ -124,6 +126,11 @@ SIGNATURES = {
     "mi355x_sd_unet_num_launches": (c_int, [c_void_p]),
     "mi355x_sd_unet_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_int]),
+    "mi355x_sd_unet_plan_ex": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(ctypes.c_size_t)]),
+    "mi355x_sd_unet_num_skips": (c_int, [c_void_p]),
+    "mi355x_sd_unet_skip_shape": (c_int, [c_void_p, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "mi355x_sd_unet_forward_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, POINTER(c_void_p), c_int, c_void_p, c_void_p, c_int]),
     "mi355x_sd_graph_begin": (c_int, [c_void_p]),
     "mi355x_sd_graph_end": (c_int, [c_void_p, POINTER(c_void_p)]),
     "mi355x_sd_graph_launch": (c_int, [c_void_p, c_void_p]),

@@ -86,10 +86,19 @@ class UNetHandle:
     def attach(self, device_or_host_buffer: torch.Tensor) -> None:
         _lib.check(self.lib.mi355x_sd_unet_attach_weights(self.h, device_or_host_buffer.data_ptr(), device_or_host_buffer.numel()))
 
-    def plan(self, B: int, H: int, W: int, L: int) -> int:
+    def plan(self, B: int, H: int, W: int, L: int, flags: int = 0) -> int:
         n = ctypes.c_size_t()
-        _lib.check(self.lib.mi355x_sd_unet_plan(self.h, B, H, W, L, ctypes.byref(n)))
+        _lib.check(self.lib.mi355x_sd_unet_plan_ex(self.h, B, H, W, L, flags, ctypes.byref(n)))
         return n.value
+
+    def skip_shapes(self):
+        """[(C, H, W)] of every skip tensor in production order, then of the mid block's output (ControlNet residual shapes)"""
+        out = []
+        for i in range(self.lib.mi355x_sd_unet_num_skips(self.h) + 1):
+            c, h, w = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+            _lib.check(self.lib.mi355x_sd_unet_skip_shape(self.h, i, ctypes.byref(c), ctypes.byref(h), ctypes.byref(w)))
+            out.append((c.value, h.value, w.value))
+        return out
 
     def num_launches(self) -> int:
         return self.lib.mi355x_sd_unet_num_launches(self.h)
@@ -120,7 +129,9 @@ class CUNet2DConditionModel:
         self._geom = None
         self._workspace = None
 
-    def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None, return_dict: bool = True, in_scale=None):
+    def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None, return_dict: bool = True, in_scale=None,
+                attention_mask=None, encoder_attention_mask=None, down_block_additional_residuals=None,
+                mid_block_additional_residual=None):
         lib, h = self.hd.lib, self.hd.h
         cfgd = self.hd.config_dict
         if sample.dim() != 4 or sample.shape[1] != cfgd.get("in_channels", 4):
@@ -146,11 +157,30 @@ class CUNet2DConditionModel:
                                      f"the keyword argument `{key}` to be passed in `added_cond_kwargs`")
                 if tuple(added_cond_kwargs[key].shape) != (B, width):
                     raise ValueError(f"{key}: expected [{B}, {width}], got {tuple(added_cond_kwargs[key].shape)}")
-        if self._geom != (B, H, W, L):
-            nbytes = self.hd.plan(B, H, W, L)
+        controlnet = down_block_additional_residuals is not None
+        if controlnet != (mid_block_additional_residual is not None):
+            raise NotImplementedError("ControlNet residuals need both `down_block_additional_residuals` and "
+                                      "`mid_block_additional_residual` (the T2I-adapter form is not implemented)")
+        flags = ((_lib.UNET_ENC_MASK if encoder_attention_mask is not None else 0) | (_lib.UNET_SELF_MASK if attention_mask is not None else 0) |
+                 (_lib.UNET_CONTROLNET if controlnet else 0))
+        if encoder_attention_mask is not None and tuple(encoder_attention_mask.shape) != (B, L):
+            raise ValueError(f"encoder_attention_mask: expected [{B}, {L}], got {tuple(encoder_attention_mask.shape)}")
+        if attention_mask is not None and tuple(attention_mask.shape) != (B, H * W):
+            # (a mask over another number of key tokens cannot match the self-attention of the first level either)
+            raise ValueError(f"attention_mask: expected [{B}, {H * W}] (one entry per latent token), got {tuple(attention_mask.shape)}")
+        if self._geom != (B, H, W, L, flags):
+            nbytes = self.hd.plan(B, H, W, L, flags)
             self._workspace = torch.empty(nbytes, device=self.device, dtype=torch.uint8)
             _lib.check(lib.mi355x_sd_unet_bind_workspace(h, self._workspace.data_ptr(), nbytes))
-            self._geom = (B, H, W, L)
+            self._geom = (B, H, W, L, flags)
+        if controlnet:
+            shapes = self.hd.skip_shapes()
+            res = list(down_block_additional_residuals) + [mid_block_additional_residual]
+            if len(res) != len(shapes):
+                raise ValueError(f"expected {len(shapes) - 1} down_block_additional_residuals, got {len(res) - 1}")
+            for r, (c_, h_, w_) in zip(res, shapes):
+                if tuple(r.shape) != (B, c_, h_, w_):
+                    raise ValueError(f"ControlNet residual of shape {tuple(r.shape)}, expected {(B, c_, h_, w_)}")
         f32 = lambda t: t.to(device=self.device, dtype=torch.float32).contiguous()  # noqa: E731
         t = timestep if torch.is_tensor(timestep) else torch.tensor([float(timestep)])
         te = ti = None
@@ -165,10 +195,15 @@ class CUNet2DConditionModel:
             out = torch.empty((B, self.config.__dict__.get("out_channels", 4), H, W), device=self.device, dtype=torch.float32)
             _lib.check(lib.mi355x_sd_set_workspace(self._splitk.data_ptr(), self._splitk.numel()))
             p = lambda x: None if x is None else x.data_ptr()  # noqa: E731
-            _lib.check(lib.mi355x_sd_unet_forward(h, self._stream.cuda_stream, p(s), p(tt), p(e), p(te), p(ti), p(sc), p(out),
-                                                  1 if self.use_graph else 0))
+            em = None if encoder_attention_mask is None else f32(encoder_attention_mask)
+            sm = None if attention_mask is None else f32(attention_mask)
+            rs = [f32(r) for r in down_block_additional_residuals] if controlnet else []
+            rm = f32(mid_block_additional_residual) if controlnet else None
+            arr = (ctypes.c_void_p * max(1, len(rs)))(*[r.data_ptr() for r in rs]) if controlnet else None
+            _lib.check(lib.mi355x_sd_unet_forward_ex(h, self._stream.cuda_stream, p(s), p(tt), p(e), p(te), p(ti), p(sc), p(em), p(sm), arr,
+                                                     len(rs), p(rm), p(out), 1 if self.use_graph else 0))
         cur.wait_stream(self._stream)
-        for x in (s, tt, e, te, ti, sc):     # keep the staging tensors alive until the stream has consumed them
+        for x in [s, tt, e, te, ti, sc, em, sm, rm] + rs:     # keep the staging tensors alive until the stream has consumed them
             if x is not None:
                 x.record_stream(self._stream)
         if not return_dict:

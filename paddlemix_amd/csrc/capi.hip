@@ -502,6 +502,11 @@ int mi355x_sd_axpby(const float* x, const float* y, float* out, const float* coe
   return finish(launch_axpby(x, y, out, coef, (long)n, S(stream)), "mi355x_sd_axpby");
 }
 
+int mi355x_sd_mask_to_bias(const float* mask, float* bias, int64_t n, void* stream) {
+  if (!mask || !bias) return fail(SD_ERR_INVALID, "mi355x_sd_mask_to_bias: null pointer");
+  return finish(launch_mask_to_bias(mask, bias, (long)n, S(stream)), "mi355x_sd_mask_to_bias");
+}
+
 int mi355x_sd_cfg_axpby(const float* x, const float* eps_uncond, const float* eps_text, float* out, const float* coef,
                         float guidance_scale, int64_t n, void* stream) {
   if (!x || !eps_uncond || !eps_text || !out || !coef) return fail(SD_ERR_INVALID, "mi355x_sd_cfg_axpby: null pointer");

@@ -137,5 +137,6 @@ int launch_copy_rows(const bf16* x, int ldx, bf16* y, int ldy, long rows, int C,
 int launch_cfg_axpby(const float* x, const float* eu, const float* et, float* out, const float* coef, float gs, long n,
                      hipStream_t stream);
 int launch_axpby(const float* x, const float* y, float* out, const float* coef, long n, hipStream_t stream);
+int launch_mask_to_bias(const float* mask, float* bias, long n, hipStream_t stream);
 
 }  // namespace sd

@@ -600,6 +600,18 @@ int launch_cfg_axpby(const float* x, const float* eu, const float* et, float* ou
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
 
+// additive attention bias of a keep-mask: (1 - mask) * -10000 (unet_2d_condition.py:921-927, 1-D masks of 1 = attend, 0 = mask out)
+__global__ void mask_to_bias_kernel(const float* __restrict__ mask, float* __restrict__ bias, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) bias[i] = (1.0f - mask[i]) * -10000.0f;
+}
+int launch_mask_to_bias(const float* mask, float* bias, long n, hipStream_t stream) {
+  if (n <= 0) return SD_ERR_INVALID;
+  long nb = (n + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(mask_to_bias_kernel, dim3((unsigned)nb), dim3(256), 0, stream, mask, bias, n);
+  return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+}
+
 int launch_axpby(const float* x, const float* y, float* out, const float* coef, long n, hipStream_t stream) {
   if (n <= 0) return SD_ERR_INVALID;
   long nb = (n + 255) / 256;

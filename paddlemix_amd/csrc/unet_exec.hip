@@ -398,12 +398,27 @@ struct Exec {
   unsigned char* ws = nullptr;
   std::vector<std::function<int(void*)>> prog_sym;   // built at plan time, read `ws` at run time
   Ref in_sample, in_t, in_scale, in_enc, in_addin, in_tids, out;
+  // optional inputs chosen at plan time (mi355x_sd_unet_plan_ex flags)
+  int plan_flags = 0;
+  Ref enc_mask, enc_bias, self_mask, self_bias, ctrl_mid;
+  std::vector<Ref> ctrl_down;
+  struct SkipShape { int C, h, w; };
+  std::vector<SkipShape> skip_shapes;             // every skip tensor, then the mid block's output
   int text_dim = 0, n_ids = 0;
   bool planned = false, consts_set = false;
   hipGraphExec_t graph = nullptr;
   void* graph_stream = nullptr;
 
   void* at(const Ref& r) const { return r.buf < 0 ? const_cast<void*>(r.abs) : (void*)(ws + bufs[r.buf].off + r.off); }
+  void drop_plan() {
+    planned = false;
+    prog_sym.clear();
+    bufs.clear();
+    buf_index.clear();
+    skip_shapes.clear();
+    ctrl_down.clear();
+    ws = nullptr;
+  }
 };
 
 void expect(Exec& e, const std::string& name, std::vector<int64_t> shape) {
@@ -776,10 +791,24 @@ struct Planner {
     emit([=](void* st) { return mi355x_sd_cast_rows((const float*)ex->at(x.p), x.ld, ex->at(y.p), y.ld, x.rows, x.C, st); });
     return y;
   }
-  void attention(const View& q, const View& k, const View& v, const View& out, int heads, int sq, int skv, bool log2 = false) {
+  // bias: additive key mask [B, skv] (fp32), broadcast over heads and queries; has_bias selects the masked kernel
+  void attention(const View& q, const View& k, const View& v, const View& out, int heads, int sq, int skv, bool log2 = false,
+                 bool has_bias = false, Ref bias = Ref()) {
     const int d = q.C / heads;
     Exec* ex = &e;
     const int Bc = B;
+    if (has_bias) {
+      // (q may carry head_dim^-0.5 * log2(e) already -- folded into to_q at load: the masked kernel exponentiates
+      // exp2((q.k + bias / scale) * scale * log2(e)), so scale = ln 2 makes that exp2(q.k + bias * log2(e)), the same softmax;
+      // paddlemix_amd/unet.py attention())
+      const float scale = log2 ? (float)log(2.0) : (float)pow((double)d, -0.5);
+      emit([=](void* st) {
+        return mi355x_sd_sdpa(ex->at(q.p), ex->at(k.p), ex->at(v.p), (const float*)ex->at(bias), ex->at(out.p), Bc, heads, sq, skv, d,
+                              (int64_t)sq * q.ld, q.ld, (int64_t)skv * k.ld, k.ld, (int64_t)skv * v.ld, v.ld, (int64_t)sq * out.ld, out.ld,
+                              (int64_t)skv, 0, 0, scale, st);
+      });
+      return;
+    }
     if (log2) {
       emit([=](void* st) {
         return mi355x_sd_sdpa_ex(ex->at(q.p), ex->at(k.p), ex->at(v.p), nullptr, ex->at(out.p), Bc, heads, sq, skv, d, (int64_t)sq * q.ld, q.ld,
@@ -852,6 +881,24 @@ struct Planner {
     const View kv_all = view(persist((size_t)2 * B * L * e.kv_total), B * L, e.kv_total);
     linear(enc, "kv_all", kv_all, false);
 
+    // ---- optional inputs of this plan (mi355x_sd_unet_plan_ex) ----
+    const bool enc_masked = (e.plan_flags & MI355X_SD_UNET_ENC_MASK) != 0, self_masked = (e.plan_flags & MI355X_SD_UNET_SELF_MASK) != 0;
+    const bool controlnet = (e.plan_flags & MI355X_SD_UNET_CONTROLNET) != 0;
+    if (enc_masked) {
+      e.enc_mask = persist((size_t)4 * B * L);
+      e.enc_bias = persist((size_t)4 * B * L);
+      const Ref m = e.enc_mask, bz = e.enc_bias;
+      const int64_t n = (int64_t)B * L;
+      emit([=](void* st) { return mi355x_sd_mask_to_bias((const float*)ex->at(m), (float*)ex->at(bz), n, st); });
+    }
+    if (self_masked) {
+      e.self_mask = persist((size_t)4 * B * H * W);
+      e.self_bias = persist((size_t)4 * B * H * W);
+      const Ref m = e.self_mask, bz = e.self_bias;
+      const int64_t n = (int64_t)B * H * W;
+      emit([=](void* st) { return mi355x_sd_mask_to_bias((const float*)ex->at(m), (float*)ex->at(bz), n, st); });
+    }
+
     // ---- skip / concat buffers: pre-walk ----
     struct Sk { int C, h, w; };
     std::vector<Sk> skips;
@@ -917,12 +964,17 @@ struct Planner {
         View q2 = view(qkv.p, rows, ch);
         lnorm(hid, b + ".norm1", ln);
         linear(ln, b + ".attn1.qkv", qkv, false);
-        attention(qkv.cols(0, ch), qkv.cols(ch, ch), qkv.cols(2 * ch, ch), ao, d.heads, hw, hw, e.log2_blocks.count(b) != 0);
+        if (self_masked && hw != H * W)
+          // the reference pads a mask of the wrong length and then fails on the shapes of the add (attention_processor.py:616-622)
+          die(MI355X_SD_ERR_INVALID, "attention_mask has " + std::to_string(H * W) + " key tokens but " + b + ".attn1 attends over " +
+                                         std::to_string(hw) + " latent tokens (the mask must match the token count of every attention level)");
+        attention(qkv.cols(0, ch), qkv.cols(ch, ch), qkv.cols(2 * ch, ch), ao, d.heads, hw, hw, e.log2_blocks.count(b) != 0, self_masked,
+                  e.self_bias);
         linear(ao, b + ".attn1.out", hid, true, &hid);
         lnorm(hid, b + ".norm2", ln);
         linear(ln, b + ".attn2.q", q2, false);
         const int ko = e.kv_off[b];
-        attention(q2, kv_all.cols(ko, ch), kv_all.cols(ko + ch, ch), ao, d.heads, hw, L);
+        attention(q2, kv_all.cols(ko, ch), kv_all.cols(ko + ch, ch), ao, d.heads, hw, L, false, enc_masked, e.enc_bias);
         linear(ao, b + ".attn2.out", hid, true, &hid);
         lnorm(hid, b + ".norm3", ln);
         linear(ln, b + ".ff1", ff, true, nullptr, MI355X_SD_GEGLU);
@@ -975,6 +1027,31 @@ struct Planner {
         w_ = wo;
         cur = dst;
       } else if (d.kind == Layer::CAT) {
+        if (u == 0) {
+          // every skip tensor and the mid output are complete here: record their shapes (mi355x_sd_unet_skip_shape) and, with
+          // ControlNet residuals planned, add them in place (unet_2d_condition.py:1121-1132, 1151-1155) once the down path and the
+          // mid block have consumed the originals
+          e.skip_shapes.clear();
+          for (auto& sk : skips) e.skip_shapes.push_back({sk.C, sk.h, sk.w});
+          e.skip_shapes.push_back({cur.C, h, w_});
+          if (controlnet) {
+            const int f32 = RES == 4 ? 1 : 0, Bc = B;
+            e.ctrl_down.clear();
+            for (size_t kk = 0; kk < skips.size(); ++kk) {
+              const Ref rt = persist((size_t)4 * B * skips[kk].C * skips[kk].h * skips[kk].w);
+              e.ctrl_down.push_back(rt);
+              const View sl = skip_slot((int)kk);
+              const int cs = skips[kk].C;
+              const int64_t hw = (int64_t)skips[kk].h * skips[kk].w;
+              emit([=](void* st) { return mi355x_sd_add_nchw_ex(ex->at(sl.p), sl.ld, (const float*)ex->at(rt), Bc, cs, hw, f32, st); });
+            }
+            e.ctrl_mid = persist((size_t)4 * B * cur.C * h * w_);
+            const Ref rm = e.ctrl_mid;
+            const View cm = cur;
+            const int64_t hw = (int64_t)h * w_;
+            emit([=](void* st) { return mi355x_sd_add_nchw_ex(ex->at(cm.p), cm.ld, (const float*)ex->at(rm), Bc, cm.C, hw, f32, st); });
+          }
+        }
         cur = cats[u];
         ++u;
       } else if (d.kind == Layer::UP) {
@@ -1221,7 +1298,12 @@ int mi355x_sd_unet_finalize_weights(void* handle, void* device_buffer, size_t by
 }
 
 int mi355x_sd_unet_plan(void* handle, int B, int H, int W, int L, size_t* workspace_bytes) {
-  if (!handle || !workspace_bytes || B <= 0 || H <= 0 || W <= 0 || L <= 0) {
+  return mi355x_sd_unet_plan_ex(handle, B, H, W, L, 0, workspace_bytes);
+}
+
+int mi355x_sd_unet_plan_ex(void* handle, int B, int H, int W, int L, int flags, size_t* workspace_bytes) {
+  if (!handle || !workspace_bytes || B <= 0 || H <= 0 || W <= 0 || L <= 0 ||
+      (flags & ~(MI355X_SD_UNET_ENC_MASK | MI355X_SD_UNET_SELF_MASK | MI355X_SD_UNET_CONTROLNET))) {
     sd::set_last_error("mi355x_sd_unet_plan: bad argument");
     return MI355X_SD_ERR_INVALID;
   }
@@ -1233,6 +1315,9 @@ int mi355x_sd_unet_plan(void* handle, int B, int H, int W, int L, size_t* worksp
       e->graph = nullptr;
     }
     e->B = B; e->H = H; e->W = W; e->L = L;
+    e->plan_flags = flags;
+    e->planned = false;
+    e->ctrl_down.clear();
     e->bufs.clear();
     e->buf_index.clear();
     e->prog_sym.clear();
@@ -1243,8 +1328,10 @@ int mi355x_sd_unet_plan(void* handle, int B, int H, int W, int L, size_t* worksp
     *workspace_bytes = e->workspace_bytes;
     return MI355X_SD_OK;
   } catch (const ExecError& x) {
+    H_(handle)->drop_plan();   // a failed plan leaves no half-built program behind
     return report(x);
   } catch (const std::exception& x) {   // bad_alloc, a malformed number in the config ...: never across the C boundary
+    H_(handle)->drop_plan();
     sd::set_last_error((std::string("mi355x_sd_unet: ") + x.what()).c_str());
     return MI355X_SD_ERR_INVALID;
   }
@@ -1271,8 +1358,29 @@ int mi355x_sd_unet_num_launches(void* handle) { return handle ? (int)H_(handle)-
 // [B,6] fp32, out [B,Cout,H,W] fp32 -- all DEVICE pointers (the boundary never touches host memory per step); in_scale: optional
 // device scalar multiplied into the sample (the scheduler's scale_model_input), NULL = 1. use_graph != 0: the program is captured
 // into a hipGraph on first use with this stream and replayed afterwards.
+int mi355x_sd_unet_num_skips(void* handle) { return (handle && H_(handle)->planned) ? (int)H_(handle)->skip_shapes.size() - 1 : -1; }
+
+int mi355x_sd_unet_skip_shape(void* handle, int index, int* C, int* H, int* W) {
+  Exec* e = H_(handle);
+  if (!handle || !e->planned || !C || !H || !W || index < 0 || index >= (int)e->skip_shapes.size()) {
+    sd::set_last_error("mi355x_sd_unet_skip_shape: no plan, or index out of range");
+    return MI355X_SD_ERR_INVALID;
+  }
+  *C = e->skip_shapes[index].C; *H = e->skip_shapes[index].h; *W = e->skip_shapes[index].w;
+  return MI355X_SD_OK;
+}
+
 int mi355x_sd_unet_forward(void* handle, void* stream, const float* sample, const float* timestep, const float* encoder_hidden_states,
                            const float* text_embeds, const float* time_ids, const float* in_scale, float* out, int use_graph) {
+  return mi355x_sd_unet_forward_ex(handle, stream, sample, timestep, encoder_hidden_states, text_embeds, time_ids, in_scale, nullptr,
+                                   nullptr, nullptr, 0, nullptr, out, use_graph);
+}
+
+int mi355x_sd_unet_forward_ex(void* handle, void* stream, const float* sample, const float* timestep, const float* encoder_hidden_states,
+                              const float* text_embeds, const float* time_ids, const float* in_scale,
+                              const float* encoder_attention_mask, const float* attention_mask,
+                              const float* const* down_block_additional_residuals, int num_down_residuals,
+                              const float* mid_block_additional_residual, float* out, int use_graph) {
   Exec* e = H_(handle);
   if (!handle || !e->planned || !e->ws) {
     sd::set_last_error("mi355x_sd_unet_forward: plan and bind a workspace first");
@@ -1290,8 +1398,45 @@ int mi355x_sd_unet_forward(void* handle, void* stream, const float* sample, cons
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const Cfg& c = e->cfg;
   const int B = e->B, H = e->H, W = e->W, L = e->L;
+  // ---- the optional inputs must be exactly the ones the plan was built for ----
+  const bool want_enc = (e->plan_flags & MI355X_SD_UNET_ENC_MASK) != 0, want_self = (e->plan_flags & MI355X_SD_UNET_SELF_MASK) != 0;
+  const bool want_ctrl = (e->plan_flags & MI355X_SD_UNET_CONTROLNET) != 0;
+  const bool has_ctrl = down_block_additional_residuals != nullptr || mid_block_additional_residual != nullptr;
+  if (want_enc != (encoder_attention_mask != nullptr) || want_self != (attention_mask != nullptr) || want_ctrl != has_ctrl) {
+    sd::set_last_error("mi355x_sd_unet_forward_ex: optional inputs differ from the plan's flags (mi355x_sd_unet_plan_ex)");
+    return MI355X_SD_ERR_INVALID;
+  }
+  if (want_ctrl) {
+    if (!down_block_additional_residuals || !mid_block_additional_residual) {
+      // the reference's T2I-adapter form (down residuals only) is not built
+      sd::set_last_error("mi355x_sd_unet_forward_ex: ControlNet residuals need both down_block_additional_residuals and "
+                         "mid_block_additional_residual");
+      return MI355X_SD_ERR_INVALID;
+    }
+    if (num_down_residuals != (int)e->ctrl_down.size()) {
+      sd::set_last_error("mi355x_sd_unet_forward_ex: wrong number of down_block_additional_residuals (mi355x_sd_unet_num_skips)");
+      return MI355X_SD_ERR_INVALID;
+    }
+    for (int i = 0; i < num_down_residuals; ++i)
+      if (!down_block_additional_residuals[i]) {
+        sd::set_last_error("mi355x_sd_unet_forward_ex: null residual pointer");
+        return MI355X_SD_ERR_INVALID;
+      }
+  }
   // ---- stage inputs into the plan's static buffers (device-to-device, stream ordered) ----
   bool ok = hipMemcpyAsync(e->at(e->in_sample), sample, (size_t)4 * B * c.in_channels * H * W, hipMemcpyDeviceToDevice, st) == hipSuccess;
+  if (want_enc) ok = ok && hipMemcpyAsync(e->at(e->enc_mask), encoder_attention_mask, (size_t)4 * B * L, hipMemcpyDeviceToDevice, st) == hipSuccess;
+  if (want_self) ok = ok && hipMemcpyAsync(e->at(e->self_mask), attention_mask, (size_t)4 * B * H * W, hipMemcpyDeviceToDevice, st) == hipSuccess;
+  if (want_ctrl) {
+    for (size_t i = 0; i < e->ctrl_down.size(); ++i) {
+      const Exec::SkipShape& sk = e->skip_shapes[i];
+      ok = ok && hipMemcpyAsync(e->at(e->ctrl_down[i]), down_block_additional_residuals[i], (size_t)4 * B * sk.C * sk.h * sk.w,
+                                hipMemcpyDeviceToDevice, st) == hipSuccess;
+    }
+    const Exec::SkipShape& mk = e->skip_shapes.back();
+    ok = ok && hipMemcpyAsync(e->at(e->ctrl_mid), mid_block_additional_residual, (size_t)4 * B * mk.C * mk.h * mk.w, hipMemcpyDeviceToDevice,
+                              st) == hipSuccess;
+  }
   ok = ok && hipMemcpyAsync(e->at(e->in_t), timestep, 4, hipMemcpyDeviceToDevice, st) == hipSuccess;
   if (in_scale) {
     ok = ok && hipMemcpyAsync(e->at(e->in_scale), in_scale, 4, hipMemcpyDeviceToDevice, st) == hipSuccess;

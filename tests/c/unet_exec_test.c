@@ -2,7 +2,10 @@
  *
  *   gcc -std=c11 -O2 -I/opt/rocm/include -Iinclude tests/c/unet_exec_test.c -Lpaddlemix_amd -lmi355x_sd -L/opt/rocm/lib -lamdhip64 -lm \
  *       -Wl,-rpath,/opt/rocm/lib -o /tmp/unet_exec_test
- *   LD_LIBRARY_PATH=paddlemix_amd /tmp/unet_exec_test <config.json> <B> <H> <W> <L> <out.bin> [resid_f32]
+ *   LD_LIBRARY_PATH=paddlemix_amd /tmp/unet_exec_test <config.json> <B> <H> <W> <L> <out.bin> [resid_f32] [plan_ex flags]
+ *
+ * plan_ex flags (MI355X_SD_UNET_ENC_MASK = 1, _CONTROLNET = 4): the optional inputs of mi355x_sd_unet_forward_ex -- the encoder
+ * mask keeps the first 3/4 of the text tokens, the ControlNet residuals are LCG numbers (seed 20 + index) scaled by 0.3.
  *
  * Weights and inputs come from a 64-bit LCG so that tests/test_gpu_cexec.py can regenerate them and run the Python-planned model
  * on the same numbers: the two outputs must be bit-identical. Exit code 0 = ran; the comparison is the Python side's job. */
@@ -52,11 +55,12 @@ static uint64_t name_seed(const char* s) {
 
 int main(int argc, char** argv) {
   if (argc < 7) {
-    fprintf(stderr, "usage: %s config.json B H W L out.bin [resid_f32]\n", argv[0]);
+    fprintf(stderr, "usage: %s config.json B H W L out.bin [resid_f32] [plan_ex flags]\n", argv[0]);
     return 1;
   }
   const int B = atoi(argv[2]), H = atoi(argv[3]), W = atoi(argv[4]), L = atoi(argv[5]);
   const int resid_f32 = argc > 7 ? atoi(argv[7]) : 0;
+  const int flags = argc > 8 ? atoi(argv[8]) : 0;
   FILE* f = fopen(argv[1], "rb");
   if (!f) return 1;
   static char json[1 << 16];
@@ -98,7 +102,7 @@ int main(int argc, char** argv) {
   void *dw = NULL, *ws = NULL, *splitk = NULL;
   HK(hipMalloc(&dw, wbytes));
   CK(mi355x_sd_unet_finalize_weights(h, dw, wbytes, NULL));
-  CK(mi355x_sd_unet_plan(h, B, H, W, L, &sbytes));
+  CK(flags ? mi355x_sd_unet_plan_ex(h, B, H, W, L, flags, &sbytes) : mi355x_sd_unet_plan(h, B, H, W, L, &sbytes));
   HK(hipMalloc(&ws, sbytes));
   CK(mi355x_sd_unet_bind_workspace(h, ws, sbytes));
   HK(hipMalloc(&splitk, 32u << 20));
@@ -138,14 +142,48 @@ int main(int argc, char** argv) {
     HK(hipMemcpy(dte, hte, (size_t)B * td * 4, hipMemcpyHostToDevice));
     HK(hipMemcpy(dti, hti, (size_t)B * 6 * 4, hipMemcpyHostToDevice));
   }
+  /* ---- optional inputs (plan_ex flags) ---- */
+  float* dmask = NULL;
+  const float* dres[64];
+  const float* dmid = NULL;
+  int nres = 0;
+  if (flags & MI355X_SD_UNET_ENC_MASK) {
+    float* hm = (float*)malloc((size_t)B * L * 4);
+    for (int b = 0; b < B; ++b)
+      for (int l = 0; l < L; ++l) hm[b * L + l] = l < (3 * L) / 4 ? 1.0f : 0.0f;
+    HK(hipMalloc((void**)&dmask, (size_t)B * L * 4));
+    HK(hipMemcpy(dmask, hm, (size_t)B * L * 4, hipMemcpyHostToDevice));
+    free(hm);
+  }
+  if (flags & MI355X_SD_UNET_CONTROLNET) {
+    nres = mi355x_sd_unet_num_skips(h);
+    if (nres < 0 || nres >= 64) return 5;
+    for (int i = 0; i <= nres; ++i) {
+      int C_, H_, W_;
+      CK(mi355x_sd_unet_skip_shape(h, i, &C_, &H_, &W_));
+      const int64_t n = (int64_t)B * C_ * H_ * W_;
+      float* hr = (float*)malloc(n * 4);
+      fill(hr, n, 20 + (uint64_t)i, 0.3f, 0.0f);
+      float* dr;
+      HK(hipMalloc((void**)&dr, n * 4));
+      HK(hipMemcpy(dr, hr, n * 4, hipMemcpyHostToDevice));
+      free(hr);
+      if (i < nres) dres[i] = dr;
+      else dmid = dr;
+    }
+  }
   hipStream_t st;
   HK(hipStreamCreate(&st));
   /* eager, then graph capture + two replays: all must agree (checked by the Python side on the last result + a flag here) */
-  CK(mi355x_sd_unet_forward(h, st, ds, dt, de, dte, dti, NULL, dout, 0));
+  if (flags) CK(mi355x_sd_unet_forward_ex(h, st, ds, dt, de, dte, dti, NULL, dmask, NULL, nres ? dres : NULL, nres, dmid, dout, 0));
+  else CK(mi355x_sd_unet_forward(h, st, ds, dt, de, dte, dti, NULL, dout, 0));
   HK(hipStreamSynchronize(st));
   HK(hipMemcpy(ho, dout, no * 4, hipMemcpyDeviceToHost));
   float* ho2 = (float*)malloc(no * 4);
-  for (int rep = 0; rep < 3; ++rep) CK(mi355x_sd_unet_forward(h, st, ds, dt, de, dte, dti, NULL, dout, 1));
+  for (int rep = 0; rep < 3; ++rep) {
+    if (flags) CK(mi355x_sd_unet_forward_ex(h, st, ds, dt, de, dte, dti, NULL, dmask, NULL, nres ? dres : NULL, nres, dmid, dout, 1));
+    else CK(mi355x_sd_unet_forward(h, st, ds, dt, de, dte, dti, NULL, dout, 1));
+  }
   HK(hipStreamSynchronize(st));
   HK(hipMemcpy(ho2, dout, no * 4, hipMemcpyDeviceToHost));
   if (memcmp(ho, ho2, no * 4)) {

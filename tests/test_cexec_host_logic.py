@@ -119,3 +119,31 @@ def test_refusals_are_loud():
     assert lib.mi355x_sd_unet_load_weight(hd.h, b"no.such.weight", w.data_ptr(), shp, 2, 0) != 0
     n = ctypes.c_size_t()
     assert lib.mi355x_sd_unet_plan(hd.h, 1, 8, 8, 7, ctypes.byref(n)) != 0      # weights not finalized
+
+
+def test_plan_ex_flags_and_skip_shapes():
+    """mi355x_sd_unet_plan_ex on the host (planning touches no device memory): unknown flags are refused, the optional inputs add
+    their launches (mask -> bias; one in-place NCHW add per skip tensor + the mid output), the skip shapes are what the Python
+    planner hands ControlNet, and a self-attention mask is refused where the reference's shapes cannot take it."""
+    from paddlemix_amd.unet import synth_unet_params
+    lib = _lib.load()
+    hd = UNetHandle(TINY)
+    hd.load(synth_unet_params(TINY, seed=1))
+    image = hd.pack()
+    hd.attach(image)
+    n = ctypes.c_size_t()
+    assert lib.mi355x_sd_unet_plan_ex(hd.h, 2, 16, 16, 7, 8, ctypes.byref(n)) != 0        # unknown flag bit
+    base_ws = hd.plan(2, 16, 16, 7)
+    base = hd.num_launches()
+    shapes = hd.skip_shapes()
+    from tests.test_host_logic import _controlnet_residuals
+    down, mid = _controlnet_residuals(TINY, 2, 16, 16)
+    assert shapes == [tuple(d.shape[1:]) for d in down] + [tuple(mid.shape[1:])]
+    assert hd.plan(2, 16, 16, 7, _lib.UNET_ENC_MASK) > base_ws and hd.num_launches() == base + 1
+    assert hd.plan(2, 16, 16, 7, _lib.UNET_CONTROLNET) > base_ws and hd.num_launches() == base + len(shapes)
+    assert hd.plan(2, 16, 16, 7, _lib.UNET_ENC_MASK | _lib.UNET_CONTROLNET) > base_ws and hd.num_launches() == base + 1 + len(shapes)
+    # TINY attends at two resolutions: a mask over the H*W tokens of the first cannot fit the second (the reference fails on shapes)
+    with pytest.raises(_lib.MI355XError, match="key tokens"):
+        hd.plan(2, 16, 16, 7, _lib.UNET_SELF_MASK)
+    assert hd.num_launches() == 0 and lib.mi355x_sd_unet_num_skips(hd.h) == -1             # a failed plan leaves no plan behind
+    assert hd.plan(2, 16, 16, 7) == base_ws and hd.num_launches() == base

@@ -47,6 +47,82 @@ def test_handle_model_equals_python_planned_model(name, cfg, B, H, W, L, rd):
             m(_cuda(sample), 501, _cuda(enc))
 
 
+@pytest.mark.parametrize("rd", [None, "fp32"])
+def test_handle_optional_inputs_equal_python_planned_model(rd):
+    """mi355x_sd_unet_plan_ex / forward_ex: encoder_attention_mask, the self-attention attention_mask and the ControlNet residual
+    inputs of UNet2DConditionModel.forward (unet_2d_condition.py:916-927, 1121-1155) behind the C handle -- bit-identical to the
+    Python-planned model (same launches in the same order), eager and as a graph; inputs that differ from the plan are refused."""
+    from paddlemix_amd import _lib
+    from paddlemix_amd.cexec import CUNet2DConditionModel
+    from paddlemix_amd.unet import UNet2DConditionModel, synth_unet_params
+    from tests.test_host_logic import _controlnet_residuals
+    # -- encoder mask + ControlNet residuals on the SDXL-structured mini
+    cfg, B, H, W, L = MINI_XL, 2, 32, 32, 77
+    P = synth_unet_params(cfg, seed=1234)
+    sample, enc, added = _inputs(cfg, B, H, W, L)
+    down, mid = _controlnet_residuals(cfg, B, H, W)
+    em = torch.ones(B, L)
+    em[:, 60:] = 0
+    kw = dict(added_cond_kwargs=_cuda(added), encoder_attention_mask=em.cuda(), down_block_additional_residuals=[d.cuda() for d in down],
+              mid_block_additional_residual=mid.cuda())
+    want = UNet2DConditionModel(cfg, P, residual_dtype=rd, use_graph=False)(_cuda(sample), 501, _cuda(enc), **kw).sample
+    plain = UNet2DConditionModel(cfg, P, residual_dtype=rd, use_graph=False)(_cuda(sample), 501, _cuda(enc), added_cond_kwargs=_cuda(added)).sample
+    assert not torch.equal(want, plain)
+    for graph in (False, True):
+        m = CUNet2DConditionModel(cfg, P, use_graph=graph, residual_dtype=rd)
+        got = m(_cuda(sample), 501, _cuda(enc), **kw).sample
+        again = m(_cuda(sample), 501, _cuda(enc), **kw).sample
+        assert torch.equal(got, want) and torch.equal(again, want), (rd, graph, (got - want).abs().max())
+        assert m.hd.skip_shapes() == [tuple(d.shape[1:]) for d in down] + [tuple(mid.shape[1:])]
+        # the same handle re-plans when the optional inputs change
+        assert torch.equal(m(_cuda(sample), 501, _cuda(enc), added_cond_kwargs=_cuda(added)).sample, plain)
+    with pytest.raises(NotImplementedError, match="both"):
+        m(_cuda(sample), 501, _cuda(enc), added_cond_kwargs=_cuda(added), down_block_additional_residuals=[d.cuda() for d in down])
+    with pytest.raises(ValueError, match="residual"):
+        m(_cuda(sample), 501, _cuda(enc), added_cond_kwargs=_cuda(added), down_block_additional_residuals=[d.cuda() for d in down[:-1]],
+          mid_block_additional_residual=mid.cuda())
+    # the C entry point itself refuses inputs the plan was not built for
+    lib = _lib.load()
+    m(_cuda(sample), 501, _cuda(enc), added_cond_kwargs=_cuda(added))          # plan without optional inputs
+    z = torch.zeros(B, L, device="cuda")
+    o = torch.empty(B, 4, H, W, device="cuda")
+    s32, e32 = sample.cuda().float().contiguous(), enc.cuda().float().contiguous()
+    t32 = torch.tensor([501.0], device="cuda")
+    te, ti = added["text_embeds"].cuda().float().contiguous(), added["time_ids"].cuda().float().contiguous()
+    rc = lib.mi355x_sd_unet_forward_ex(m.hd.h, None, s32.data_ptr(), t32.data_ptr(), e32.data_ptr(), te.data_ptr(), ti.data_ptr(), None,
+                                       z.data_ptr(), None, None, 0, None, o.data_ptr(), 0)
+    assert rc != 0 and b"plan" in lib.mi355x_sd_last_error()
+    # -- self-attention mask on the geometry where the reference can take it (all attention at one resolution)
+    cfg, B, H, W, L = TINY, 2, 16, 16, 7
+    P = synth_unet_params(cfg, seed=1234)
+    sample, enc, _ = _inputs(cfg, B, H, W, L)
+    g = torch.Generator().manual_seed(3)
+    sm = (torch.rand(B, 64, generator=g) > 0.4).float()
+    sm[:, 0] = 1
+    ref = UNet2DConditionModel(cfg, P, residual_dtype=rd, use_graph=False)
+    plan_tokens = None
+    try:
+        want = ref(_cuda(sample), 10, _cuda(enc), attention_mask=sm.cuda()).sample
+        plan_tokens = 64
+    except ValueError:
+        pass
+    m = CUNet2DConditionModel(cfg, P, use_graph=False, residual_dtype=rd)
+    if plan_tokens is not None:   # (TINY attends at 8x8 = 64 latent tokens only when its first level has no attention)
+        with pytest.raises(ValueError, match="attention_mask"):
+            m(_cuda(sample), 10, _cuda(enc), attention_mask=sm.cuda())      # the handle takes a mask over H*W tokens only
+    full = torch.ones(B, H * W)
+    full[:, ::3] = 0
+    full[:, 0] = 1
+    try:
+        want = ref(_cuda(sample), 10, _cuda(enc), attention_mask=full.cuda()).sample
+    except ValueError as err:     # attention levels with other token counts: the C planner must refuse the same way
+        with pytest.raises(_lib.MI355XError, match="key tokens"):
+            m(_cuda(sample), 10, _cuda(enc), attention_mask=full.cuda())
+        assert "key tokens" in str(err)
+    else:
+        assert torch.equal(m(_cuda(sample), 10, _cuda(enc), attention_mask=full.cuda()).sample, want)
+
+
 def _lcg_uniform(n, seed):
     """the generator of tests/c/unet_exec_test.c, vectorised: s_i = a^i s_0 + c (1 + a + ... + a^(i-1)) mod 2^64"""
     a, c = np.uint64(6364136223846793005), np.uint64(1442695040888963407)
@@ -64,9 +140,11 @@ def _fnv(name):
     return h
 
 
-@pytest.mark.parametrize("name,cfg,B,H,W,L,rd", [("tiny", TINY, 2, 16, 16, 7, 0), ("mini-xl", MINI_XL, 1, 16, 16, 77, 0),
-                                                 ("mini-xl-f32resid", MINI_XL, 1, 16, 16, 77, 1)])
-def test_plain_c_client_matches_python_path(tmp_path, name, cfg, B, H, W, L, rd):
+@pytest.mark.parametrize("name,cfg,B,H,W,L,rd,flags", [("tiny", TINY, 2, 16, 16, 7, 0, 0), ("mini-xl", MINI_XL, 1, 16, 16, 77, 0, 0),
+                                                       ("mini-xl-f32resid", MINI_XL, 1, 16, 16, 77, 1, 0),
+                                                       ("mini-xl-mask-controlnet", MINI_XL, 1, 16, 16, 77, 0, 5),
+                                                       ("tiny-controlnet-f32resid", TINY, 2, 16, 16, 7, 1, 4)])
+def test_plain_c_client_matches_python_path(tmp_path, name, cfg, B, H, W, L, rd, flags):
     from paddlemix_amd.unet import UNet2DConditionModel, unet_param_shapes
     exe = str(tmp_path / "unet_exec_test")
     cc = ["gcc", "-std=c11", "-O2", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
@@ -77,7 +155,7 @@ def test_plain_c_client_matches_python_path(tmp_path, name, cfg, B, H, W, L, rd)
     cj.write_text(json.dumps({k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.items()}))
     out = tmp_path / "out.bin"
     env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "paddlemix_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
-    r = subprocess.run([exe, str(cj), str(B), str(H), str(W), str(L), str(out), str(rd)], env=env, capture_output=True, text=True)
+    r = subprocess.run([exe, str(cj), str(B), str(H), str(W), str(L), str(out), str(rd), str(flags)], env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr + r.stdout
     print(r.stdout.strip())
     got = torch.from_numpy(np.fromfile(out, dtype=np.float32).reshape(B, 4, H, W))
@@ -104,6 +182,17 @@ def test_plain_c_client_matches_python_path(tmp_path, name, cfg, B, H, W, L, rd)
         added = dict(text_embeds=torch.from_numpy((np.float32(1.7) * _lcg_uniform(B * td, 13)).reshape(B, td)),
                      time_ids=torch.tensor([[1024., 1024., 0., 0., 1024., 1024.]]).repeat(B, 1))
     model = UNet2DConditionModel(cfg, P, residual_dtype="fp32" if rd else None, use_graph=False)
-    want = model(_cuda(sample), 501, _cuda(enc), added_cond_kwargs=_cuda(added)).sample.cpu()
+    kw = {}
+    if flags & 1:    # MI355X_SD_UNET_ENC_MASK: the C client keeps the first 3/4 of the text tokens
+        em = torch.zeros(B, L)
+        em[:, :(3 * L) // 4] = 1
+        kw["encoder_attention_mask"] = em.cuda()
+    if flags & 4:    # MI355X_SD_UNET_CONTROLNET: LCG residuals, seed 20 + index, scale 0.3
+        from tests.test_host_logic import _controlnet_residuals
+        down, mid = _controlnet_residuals(cfg, B, H, W)
+        res = [torch.from_numpy((np.float32(0.3) * _lcg_uniform(t.numel(), 20 + i)).reshape(t.shape)) for i, t in enumerate(list(down) + [mid])]
+        kw["down_block_additional_residuals"] = [t.cuda() for t in res[:-1]]
+        kw["mid_block_additional_residual"] = res[-1].cuda()
+    want = model(_cuda(sample), 501, _cuda(enc), added_cond_kwargs=_cuda(added), **kw).sample.cpu()
     assert torch.isfinite(got).all() and got.abs().max() > 0
     assert torch.equal(got, want), (got - want).abs().max()
