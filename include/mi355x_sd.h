@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MI355X_SD_ABI_VERSION 9
+#define MI355X_SD_ABI_VERSION 10
 #define MI355X_SD_OK 0
 #define MI355X_SD_ERR_INVALID 1      /* bad argument (shape <= 0, null pointer ...)          */
 #define MI355X_SD_ERR_UNSUPPORTED 2  /* well-formed but outside the implemented configurations */

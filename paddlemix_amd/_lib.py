@@ -17,7 +17,7 @@ if ELEM_NAME not in _BUILDS:
     raise ValueError(f"MI355X_SD_DTYPE must be one of {sorted(_BUILDS)}, got {ELEM_NAME!r}")
 LIB_PATH = os.path.join(_HERE, _BUILDS[ELEM_NAME][0])
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 GEGLU, OUT_F32, SILU, GELU_TANH, PAD_BR, R_F32, CONV_KB64 = 1, 2, 4, 8, 16, 32, 64
 UNET_ENC_MASK, UNET_SELF_MASK, UNET_CONTROLNET = 1, 2, 4   # mi355x_sd_unet_plan_ex flags
 SDPA_LOG2 = 1
