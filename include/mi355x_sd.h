@@ -263,6 +263,14 @@ int mi355x_sd_groupnorm_workspace_floats(int B, int HW, int C);
 int mi355x_sd_groupnorm_stats(const void* x, int B, int HW, int C, int ldx, int groups, float eps,
                               const float* gamma, const float* beta, float* workspace, float* scale_shift,
                               void* stream);
+/* GroupNorm (+SiLU when silu != 0) of 16-bit rows in ONE launch: x, y [B][HW][ld >= C]. Only where a (batch, group) chunk fits a
+ * block's registers: HW * (C / groups) * 2 bytes <= 96 KiB and C / groups even (mi355x_sd_groupnorm_act_fits returns 1; else
+ * MI355X_SD_ERR_UNSUPPORTED -- use the stats + scale_shift_act pair). Same arithmetic as the pair (fp32 sums per thread, double
+ * mean / variance, y = x * (gamma * rstd) + (beta - mean * gamma * rstd)); the summation order differs, so results agree with the
+ * pair to fp32 rounding of the statistics, not bit for bit. */
+int mi355x_sd_groupnorm_act_fits(int HW, int C, int groups);
+int mi355x_sd_groupnorm_act(const void* x, int B, int HW, int C, int ldx, int groups, float eps, const float* gamma,
+                            const float* beta, int silu, void* y, int ldy, void* stream);
 /* y = act(x*scale[b][c] + shift[b][c]), act = SiLU when silu != 0 (the fused GN+SiLU of resnet.py:739-741). */
 int mi355x_sd_scale_shift_act(const void* x, int B, int HW, int C, int ldx, const float* scale_shift, int silu,
                               void* y, int ldy, void* stream);

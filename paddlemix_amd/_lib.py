@@ -70,6 +70,9 @@ SIGNATURES = {
     "mi355x_sd_layernorm": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int,
                                     c_void_p]),
     # fp32-residual-stream forms (x_f32 = 1: the input rows are fp32)
+    "mi355x_sd_groupnorm_act_fits": (c_int, [c_int, c_int, c_int]),
+    "mi355x_sd_groupnorm_act": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                                        c_void_p]),
     "mi355x_sd_groupnorm_stats_ex": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
                                              c_void_p, c_void_p, c_int, c_void_p]),
     "mi355x_sd_scale_shift_act_ex": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int,

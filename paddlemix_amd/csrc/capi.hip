@@ -337,6 +337,15 @@ int mi355x_sd_groupnorm_stats_ex(const void* x, int B, int HW, int C, int ldx, i
                 "mi355x_sd_groupnorm_stats_ex");
 }
 
+int mi355x_sd_groupnorm_act_fits(int HW, int C, int groups) { return groupnorm_act_fits(HW, C, groups); }
+
+int mi355x_sd_groupnorm_act(const void* x, int B, int HW, int C, int ldx, int groups, float eps, const float* gamma, const float* beta,
+                            int silu, void* y, int ldy, void* stream) {
+  if (!x || !gamma || !beta || !y) return fail(SD_ERR_INVALID, "mi355x_sd_groupnorm_act: null pointer");
+  return finish(launch_groupnorm_act((const bf16*)x, B, HW, C, ldx, groups, eps, gamma, beta, silu, (bf16*)y, ldy, S(stream)),
+                "mi355x_sd_groupnorm_act");
+}
+
 int mi355x_sd_scale_shift_act(const void* x, int B, int HW, int C, int ldx, const float* scale_shift, int silu, void* y,
                               int ldy, void* stream) {
   if (!x || !scale_shift || !y) return fail(SD_ERR_INVALID, "mi355x_sd_scale_shift_act: null pointer");

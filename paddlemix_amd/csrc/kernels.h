@@ -92,6 +92,10 @@ int launch_groupnorm_stats(const void* x, int x_f32, int B, int HW, int C, int l
 int groupnorm_partial_floats(int B, int HW, int C);
 int launch_scale_shift_act(const void* x, int x_f32, int B, int HW, int C, int ldx, const float* scale_shift, int silu, bf16* y,
                            int ldy, bf16* raw16, int ld_raw, hipStream_t stream);
+// GroupNorm (+SiLU) in one launch where a (batch, group) chunk fits a block's registers (norm.hip gn_fused_kernel); *_fits: 1 / 0
+int groupnorm_act_fits(int HW, int C, int groups);
+int launch_groupnorm_act(const bf16* x, int B, int HW, int C, int ldx, int groups, float eps, const float* gamma, const float* beta,
+                         int silu, bf16* y, int ldy, hipStream_t stream);
 // y = LN(x) * (1 + scale[b]) + shift[b]  (no affine; b = row / rows_per_batch): AdaLayerNormZero / Continuous
 // mod16 != 0: scale / shift (and gate / weight / bias below) are the build's 16-bit element type instead of fp32
 int launch_adaln(const bf16* x, int rows, int C, int ldx, const void* scale, const void* shift, int ld_mod, int mod16,

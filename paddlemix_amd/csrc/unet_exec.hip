@@ -765,6 +765,13 @@ struct Planner {
     const int Bc = B, groups = c.groups, f32 = x.es == 4;
     const bool has_raw = raw16 != nullptr;
     const View rv = raw16 ? *raw16 : View();
+    if (!f32 && !has_raw && mi355x_sd_groupnorm_act_fits(hw, x.C, groups)) {   // one launch for small (batch, group) chunks (unet.py gnorm)
+      emit([=](void* st) {
+        return mi355x_sd_groupnorm_act(ex->at(x.p), Bc, hw, x.C, x.ld, groups, eps, (const float*)ex->at(g), (const float*)ex->at(bt),
+                                       silu ? 1 : 0, ex->at(y.p), y.ld, st);
+      });
+      return y;
+    }
     emit([=](void* st) {
       return mi355x_sd_groupnorm_stats_ex(ex->at(x.p), Bc, hw, x.C, x.ld, groups, eps, (const float*)ex->at(g), (const float*)ex->at(bt),
                                           (float*)ex->at(ws), (float*)ex->at(ss), f32, st);

@@ -179,6 +179,23 @@ def sdpa(q: Tensor, k: Tensor, v: Tensor, bias: Optional[Tensor] = None, scale: 
     return out
 
 
+def groupnorm_act(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, silu: bool = False) -> Tensor:
+    """GroupNorm (+SiLU) of x [B,HW,C] in one launch (mi355x_sd_groupnorm_act); raises MI355XError where a (batch, group) chunk does
+    not fit a block's registers (`groupnorm_act_fits`): use groupnorm_scale_shift + scale_shift_act there."""
+    lib = _lib.load()
+    B, HW, C = x.shape
+    if x.dtype != _lib.elem_dtype() or x.stride(2) != 1 or x.stride(0) != HW * x.stride(1) or not x.is_cuda:
+        raise ValueError("x: expected bf16 cuda [B,HW,C] rows")
+    y = torch.empty((B, HW, C), device=x.device, dtype=_lib.elem_dtype())
+    check(lib.mi355x_sd_groupnorm_act(x.data_ptr(), B, HW, C, x.stride(1), groups, float(eps), _vec(gamma, C, "gamma").data_ptr(),
+                                      _vec(beta, C, "beta").data_ptr(), 1 if silu else 0, y.data_ptr(), C, _stream()))
+    return y
+
+
+def groupnorm_act_fits(HW: int, C: int, groups: int) -> bool:
+    return bool(_lib.load().mi355x_sd_groupnorm_act_fits(HW, C, groups))
+
+
 def groupnorm_scale_shift(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float) -> Tensor:
     """x [B,HW,C] (row stride >= C) -> scale_shift fp32 [B,2,C]."""
     lib = _lib.load()

@@ -542,6 +542,12 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
             ws = sc("gn_ws", 4 * nws)
             ss = sc("gn_ss", 4 * B * 2 * x.C)
             y = _V(sc("gn", 2 * x.rows * x.C), x.rows, x.C)
+            if x.es == 2 and lib.mi355x_sd_groupnorm_act_fits(hw, x.C, groups):
+                # small (batch, group) chunks: statistics + affine (+SiLU) in one launch (csrc/norm.hip gn_fused_kernel)
+                assert raw16 is None
+                emit(lib.mi355x_sd_groupnorm_act, (x.p, B, hw, x.C, x.ld, groups, eps_, wp(nkey + ".g"), wp(nkey + ".b"),
+                                                   1 if silu else 0, y.p, y.ld, stream), "gn_fused")
+                return y
             if x.es == 2:
                 assert raw16 is None
                 emit(lib.mi355x_sd_groupnorm_stats, (x.p, B, hw, x.C, x.ld, groups, eps_, wp(nkey + ".g"), wp(nkey + ".b"),

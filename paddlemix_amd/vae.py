@@ -358,6 +358,10 @@ class AutoencoderKL(DeviceProgram, PretrainedMixin):
             ws = sc("gn_ws", 4 * nws)
             ss = sc("gn_ss", 4 * B * 2 * x.C)
             y = _V(sc("gn", 2 * x.rows * x.C), x.rows, x.C)
+            if lib.mi355x_sd_groupnorm_act_fits(hw, x.C, groups):   # small (batch, group) chunks: one launch (csrc/norm.hip gn_fused_kernel)
+                emit(lib.mi355x_sd_groupnorm_act, (x.p, B, hw, x.C, x.ld, groups, 1e-6, wp(nkey + ".g"), wp(nkey + ".b"),
+                                                   1 if silu else 0, y.p, y.ld, stream), "gn_fused")
+                return y
             emit(lib.mi355x_sd_groupnorm_stats, (x.p, B, hw, x.C, x.ld, groups, 1e-6, wp(nkey + ".g"), wp(nkey + ".b"),
                                                  ws, ss, stream), "gn_stats")
             emit(lib.mi355x_sd_scale_shift_act, (x.p, B, hw, x.C, x.ld, ss, 1 if silu else 0, y.p, y.ld, stream),

@@ -13,6 +13,8 @@ from __future__ import annotations
 import ctypes
 import math
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -49,6 +51,18 @@ class Emulator:
 
     def mi355x_sd_groupnorm_workspace_floats(self, B, HW, C):
         return 64
+
+    def mi355x_sd_groupnorm_act_fits(self, HW, C, groups):
+        cpg = C // groups
+        return int(cpg % 2 == 0 and C % 8 == 0 and HW * (cpg // 2) <= 1024 * 24 and not os.environ.get("MI355X_SD_NO_GN_FUSED"))
+
+    def mi355x_sd_groupnorm_act(self, x, B, HW, C, ldx, groups, eps, gamma, beta, silu, y, ldy, stream):
+        ss = torch.empty(B * 2 * C, dtype=torch.float32)
+        self.mi355x_sd_groupnorm_stats(x, B, HW, C, ldx, groups, eps, gamma, beta, None, ss.data_ptr(), stream)
+        self.calls[-1] = "gn_fused"
+        rc = self.mi355x_sd_scale_shift_act(x, B, HW, C, ldx, ss.data_ptr(), silu, y, ldy, stream)
+        self.calls.pop()
+        return rc
 
     # ---- GEMM family ----
     def _epilogue(self, acc, N, bias, rowbias, rpb, ld_rb, R, ldr, out_scale, flags, C, ldc):

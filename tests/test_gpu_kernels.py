@@ -401,6 +401,35 @@ def test_groupnorm(ops, B, HW, C, groups, pad, silu, eps):
     check(out.permute(0, 2, 1).reshape(B, C, HW, 1), ref, what=f"groupnorm {B,HW,C}")
 
 
+@pytest.mark.parametrize("B,HW,C,groups,pad,silu,eps", [(1, 4096, 320, 32, 0, True, 1e-5), (2, 1024, 1280, 32, 64, True, 1e-5),
+                                                        (8, 1024, 1280, 32, 0, False, 1e-6), (1, 64, 1280, 32, 0, True, 1e-5),
+                                                        (2, 256, 1920, 32, 0, True, 1e-5), (3, 100, 64, 32, 8, True, 1e-5), (2, 256, 32, 8, 0, True, 1e-5),
+                                                        (1, 1024, 960, 32, 0, True, 1e-5)])
+def test_groupnorm_single_launch(ops, B, HW, C, groups, pad, silu, eps):
+    """mi355x_sd_groupnorm_act: GroupNorm (+SiLU) with the (batch, group) chunk held in registers, one launch. Against fp32
+    math, against the two-launch pair on the same input (statistics summed in another order: equal to the output's last bit or its
+    neighbour), and refused loudly where the chunk does not fit."""
+    g = torch.Generator().manual_seed(B * HW + C)
+    x = bfr(torch.randn(B, HW, C, generator=g) * 1.5 + 0.3)
+    gamma, beta = torch.randn(C, generator=g) * 0.2 + 1.0, torch.randn(C, generator=g) * 0.1
+    assert ops.groupnorm_act_fits(HW, C, groups)
+    xd = torch.zeros(B, HW, C + pad, device="cuda", dtype=torch.bfloat16)
+    xd[..., :C] = dev(x)
+    out = ops.groupnorm_act(xd[..., :C], dev(gamma, torch.float32), dev(beta, torch.float32), groups, eps, silu=silu)
+    ref = F.group_norm(x.permute(0, 2, 1).reshape(B, C, HW), groups, gamma, beta, eps).reshape(B, C, HW).permute(0, 2, 1)
+    if silu:
+        ref = F.silu(ref)
+    check(out, ref, what=f"groupnorm_act {B,HW,C}")
+    ss = ops.groupnorm_scale_shift(xd[..., :C], dev(gamma, torch.float32), dev(beta, torch.float32), groups, eps)
+    pair = ops.scale_shift_act(xd[..., :C], ss, silu)
+    d = (out.float() - pair.float()).abs()
+    assert (d <= 2 ** -7 * pair.float().abs() + 1e-3).all(), d.max()
+    assert not ops.groupnorm_act_fits(16384, 320, 32)
+    big = torch.zeros(1, 16384, 320, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(Exception):
+        ops.groupnorm_act(big, dev(torch.ones(320), torch.float32), dev(torch.zeros(320), torch.float32), 32, 1e-5)
+
+
 @pytest.mark.parametrize("rows,C", [(300, 64), (1000, 640), (77, 1280), (16, 2560)])
 def test_layernorm(ops, rows, C):
     g = torch.Generator().manual_seed(rows + C)

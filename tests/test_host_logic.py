@@ -67,7 +67,9 @@ def test_fp32_residual_stream_program(cfg, B, H, W, L):
     r16, r32 = _rel(o16, ref), _rel(o32, ref)
     assert r32 < 0.8 * r16 and r32 < 1e-2, (r16, r32)
     # same number of contractions; the extra launches are the operand casts in front of the down / upsampling convs
-    assert [c for c in e32.calls if c != "cast_rows"] == e16.calls and "cast_rows" in e32.calls
+    # (small GroupNorms of the 16-bit stream run as one launch; fp32 rows take the statistics + apply pair)
+    pair = [c2 for c in e16.calls for c2 in (("gn_stats", "scale_shift_act") if c == "gn_fused" else (c,))]
+    assert [c for c in e32.calls if c != "cast_rows"] == pair and "cast_rows" in e32.calls and "gn_fused" in e16.calls
     with pytest.raises(NotImplementedError):
         UNet2DConditionModel(cfg, P, residual_dtype="fp32", fold_layernorm=True, _test_backend=Emulator())
 
