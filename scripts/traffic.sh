@@ -1,12 +1,15 @@
 #!/bin/bash
 # HBM traffic of the dominant kernel class via rocprofv3 PMC, collected as MI355X_MICROARCH.md prescribes: FETCH_SIZE and
 # WRITE_SIZE in SEPARATE --pmc passes (TCC slots), no other tracing; FETCH_SIZE is doubled (gfx950 counts 128-B requests
-# as 64 B for wide coalesced reads), both are in KiB.  usage: traffic.sh <workload>
+# as 64 B for wide coalesced reads), both are in KiB.  usage: traffic.sh <workload> [seconds per pass]
+# Every pass runs under `timeout`: in round 3 one PMC pass of the whole bench did not come back within 20 minutes.
 cd /tmp && export TMPDIR=/tmp
 WL=${1:-sdxl-1024-bs8}
+LIM=${2:-240}
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/tr_$C
-  rocprofv3 --pmc $C --kernel-trace -d /tmp/tr_$C -o r -- python $GRAFT_REPO_ROOT/bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-graph > /tmp/tr_$C.log 2>&1
+  timeout $LIM rocprofv3 --pmc $C --kernel-trace -d /tmp/tr_$C -o r -- python $GRAFT_REPO_ROOT/bench.py --workload $WL --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-graph --no-parity-mode > /tmp/tr_$C.log 2>&1
+  echo "pass $C rc=$?" >&2
 done
 python - <<PY
 import sqlite3, glob, json
@@ -32,5 +35,5 @@ for k, d in res.items():
     d["hbm_read_GB_total"] = rd / 1e9
     d["hbm_write_GB_total"] = wr / 1e9
     d["hbm_bytes_per_launch"] = (rd + wr) / max(d["launches"], 1)
-print(json.dumps({"workload": "$WL", "steps_profiled": 3, "classes": res}, indent=1))
+print(json.dumps({"workload": "$WL", "forwards_profiled": "warm-up + 1 step (eager)", "classes": res}, indent=1))
 PY
