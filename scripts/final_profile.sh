@@ -18,5 +18,5 @@ rm -rf /tmp/pfin
 rocprofv3 --kernel-trace --stats -d /tmp/pfin -o r -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-roofline > /tmp/pfin.log 2>&1
 DB=$(find /tmp/pfin -name "*.db" | head -1)
 python $GRAFT_REPO_ROOT/scripts/rocprof_summary.py $DB $OUT/${TAG}_sdxl_bs8_kernel_stats.txt "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-roofline   ($(tail -1 /tmp/pfin.log | cut -c1-160))" > /dev/null
-bash $GRAFT_REPO_ROOT/scripts/traffic.sh sdxl-1024-bs8 > $OUT/${TAG}_traffic_sdxl-1024-bs8.json 2>/dev/null
+timeout 420 bash $GRAFT_REPO_ROOT/scripts/traffic.sh sdxl-1024-bs8 180 > $OUT/${TAG}_traffic_sdxl-1024-bs8.json 2>/dev/null
 tail -c 600 $OUT/${TAG}_bench.json; echo; head -12 $OUT/${TAG}_sdxl_bs8_kernel_stats.txt; head -c 400 $OUT/${TAG}_traffic_sdxl-1024-bs8.json
