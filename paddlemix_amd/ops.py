@@ -77,13 +77,14 @@ def linear(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, rowbias: Opti
     ldc = _rows(out, "out", torch.float32 if out_f32 else _lib.elem_dtype())
     if out.shape != (M, n_out):
         raise ValueError(f"out: expected {(M, n_out)}, got {tuple(out.shape)}")
-    ldr = _rows(residual, "residual") if residual is not None else 0
+    r_f32 = residual is not None and residual.dtype == torch.float32   # rows of the fp32 residual stream (MI355X_SD_R_F32)
+    ldr = _rows(residual, "residual", torch.float32 if r_f32 else None) if residual is not None else 0
     ld_rb = 0
     if rowbias is not None:
         if rowbias.dtype != torch.float32 or rowbias.dim() != 2 or rowbias.stride(1) != 1 or rowbias.shape[1] != N:
             raise ValueError("rowbias: expected fp32 [batches, N] rows")
         ld_rb = rowbias.stride(0)
-    flags = (GEGLU if geglu else 0) | (OUT_F32 if out_f32 else 0) | (SILU if silu else 0)
+    flags = (GEGLU if geglu else 0) | (OUT_F32 if out_f32 else 0) | (SILU if silu else 0) | (_lib.R_F32 if r_f32 else 0)
     check(lib.mi355x_sd_linear(a.data_ptr(), lda, w.data_ptr(), out.data_ptr(), ldc, M, N, K,
                                _p(_vec(bias, N, "bias")), _p(rowbias), rows_per_batch, ld_rb, _p(residual), ldr,
                                float(out_scale), flags, _stream()))

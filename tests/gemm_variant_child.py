@@ -50,6 +50,19 @@ for M, N, K, kind in ((8200, 1280, 1280, "wide"), (300, 1288, 640, "wide"), (820
         got = out[rows].float()
     res[f"gemm {M}x{N}x{K} {kind}"] = dict(sha=hashlib.sha256(out.cpu().view(torch.int16).numpy().tobytes()).hexdigest()[:16],
                                            rel=((got - ref).norm() / ref.norm()).item())
+# the fp32 residual stream (MI355X_SD_R_F32 | MI355X_SD_OUT_F32): fp32 residual rows in, fp32 sum out -- the early fetch holds two
+# row-tiles of them and requests the other two from the epilogue; ragged M, a launch too short for it (K = 128), an N it refuses
+for M, N, K in ((8192, 1280, 1280), (8200, 1280, 640), (32768, 640, 640), (1000, 1280, 128), (777, 1284, 1280)):
+    g = torch.Generator(device="cuda").manual_seed(M + N + K + 2)
+    a = torch.randn(M, K, device="cuda", generator=g).to(ed)
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(ed)
+    b = torch.randn(N, device="cuda", generator=g)
+    r = torch.randn(M, N, device="cuda", generator=g)
+    out = ops.linear(a, w, b, residual=r, out_f32=True)
+    rows = slice(M - 256, M)
+    ref = a[rows].float() @ w.float().t() + b + r[rows]
+    res[f"gemm {M}x{N}x{K} fp32 stream"] = dict(sha=hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest()[:16],
+                                                rel=((out[rows] - ref).norm() / ref.norm()).item())
 # resnet convs: time-embedding row bias (conv1) and shortcut residual (conv2), the operands the batched epilogue fetches per row-tile
 for B, H, W, Cin, Cout in ((2, 32, 32, 640, 640), (1, 30, 34, 320, 640)):
     g = torch.Generator(device="cuda").manual_seed(B + H + Cin + 7)
