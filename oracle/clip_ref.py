@@ -8,7 +8,9 @@ torch-CPU fp32 restatement of PPD/transformers/clip/modeling.py:
   last output), CLIPTextTransformer :726-843 (final_layer_norm, pooled = row of the EOS token: argmax(input_ids) when
   eos_token_id == 2, else first position equal to eos_token_id), CLIPTextModelWithProjection (text_projection, no bias).
 
-PARITY UNPINNED: the reference's CLIP tests need Paddle and real checkpoints; neither exists here.
+Pinned against the reference's own CLIPTextModelWithProjection / CLIPVisionModelWithProjection code (transformers/clip/modeling.py)
+executed over oracle/paddle_shim.py (tests/test_reference_modules.py, cases clip_text_*, clip_vision: bit-identical). The reference's
+CLIP tests need Paddle and real checkpoints; neither exists here.
 """
 from __future__ import annotations
 

@@ -10,7 +10,8 @@ branch -- the model ``DiTPipeline`` calls once per step (ppdiffusers/ppdiffusers
   * AdaLayerNormZero         ppdiffusers/ppdiffusers/models/normalization.py:50-86
   * CombinedTimestepLabelEmbeddings / LabelEmbedding / TimestepEmbedding   embeddings.py:549-565, 439-477, 250-295
   * FeedForward gelu-approximate   attention.py:600-677, activations.py:62-98
-Parity unpinned: the reference's DiT tests need Paddle RNG or hosted weights (tests/pipelines/dit/test_dit.py).
+Pinned against the reference's own Transformer2DModel code executed over oracle/paddle_shim.py (tests/test_reference_modules.py,
+case dit_mini: 2.6e-7 relative); the reference's DiT tests themselves need Paddle RNG or hosted weights (tests/pipelines/dit/test_dit.py).
 """
 from __future__ import annotations
 

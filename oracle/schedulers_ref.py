@@ -2,8 +2,9 @@
 
 Pinned against the reference's RNG-free full-loop known answers in tests/test_oracle_pins.py
 (DDIM: /root/reference/ppdiffusers/tests/schedulers/test_scheduler_ddim.py:68,121-190;
-Euler: test_scheduler_euler.py:84-163).  FlowMatchEuler has no test in the reference:
-parity unpinned for it (restated from scheduling_flow_match_euler_discrete.py:44-283).
+Euler: test_scheduler_euler.py:84-163), and -- all six, FlowMatchEuler (which has no test in the
+reference) included -- against the reference's own scheduler classes executed over
+oracle/paddle_shim.py in whole sampling loops (tests/test_reference_modules.py, cases sched_*).
 
 Paths relative to /root/reference/ppdiffusers/ppdiffusers/schedulers/.
 The reference keeps betas / alphas_cumprod / sigmas as float32 tensors; so do we
@@ -174,7 +175,8 @@ class EulerRef:
 
 
 class FlowMatchEulerRef:
-    """FlowMatchEulerDiscreteScheduler (scheduling_flow_match_euler_discrete.py:63-283). Parity unpinned."""
+    """FlowMatchEulerDiscreteScheduler (scheduling_flow_match_euler_discrete.py:63-283). Pinned by the live
+    reference run (case sched_flow_match_sd3, bit-identical)."""
 
     def __init__(self, num_train_timesteps=1000, shift=1.0):
         self.T, self.shift = num_train_timesteps, shift

@@ -1,9 +1,10 @@
 """torch-CPU restatement of ppdiffusers' SD3Transformer2DModel (MMDiT) forward (oracle; TEST INFRASTRUCTURE ONLY).
 
-PARITY UNPINNED: the reference holds no RNG-free known-answer vectors for this model (its test,
-ppdiffusers/tests/models/test_models_transformer_sd3.py:25-79, checks shapes only) and Paddle cannot run here, so this
-restatement is anchored on a line-by-line reading of the modules below and on the identities the reference itself
-relies on (fused op == unfused expression, paddlemix/triton_ops/triton_ops.py:790-808, 1031-1059).
+Pinned against the reference's own SD3Transformer2DModel code executed over oracle/paddle_shim.py (tests/test_reference_modules.py,
+cases sd3_mini / sd3_mini_trained_norm_bias: 2.6e-7 relative). That run also surfaced two state-dict entries of the reference this
+restatement had dropped -- the trainable LayerNorm biases of the two AdaLayerNormContinuous norms (normalization.py:182), zero at
+construction and absent from converted public checkpoints: optional parameters here (`_ln_bias`). The reference holds no RNG-free
+known-answer vectors for this model (its test, ppdiffusers/tests/models/test_models_transformer_sd3.py:25-79, checks shapes only).
 
 Follows (paths relative to /root/reference/ppdiffusers/ppdiffusers/models/):
   SD3Transformer2DModel.forward        transformer_sd3.py:279-365  (ctor :65-124)
@@ -81,6 +82,15 @@ def layer_norm_noaffine(x: Tensor, eps: float = 1e-6) -> Tensor:
     return F.layer_norm(x, (x.shape[-1],), None, None, eps)
 
 
+def _ln_bias(P: Params, bias_name: str, x: Tensor) -> Tensor:
+    """AdaLayerNormContinuous' inner norm (normalization.py:182: nn.LayerNorm(dim, eps, weight_attr=elementwise_affine=False,
+    bias_attr=bias=True)): no weight but a TRAINABLE bias, zero at construction and absent from the converted public
+    checkpoints -- optional here: a parameter set that carries it (a model fine-tuned with the reference) gets it added."""
+    y = layer_norm_noaffine(x)
+    b = P.get(bias_name)
+    return y if b is None else y + b
+
+
 def fake_quant_rows(t: Tensor) -> Tensor:
     """Per-token e4m3 fake quantisation (scale = absmax / 448 over the last dim): what the device's W8A8 mode feeds its
     fp8 GEMMs. The reference has no fp8 inference path; this only lets the checker see the same operands."""
@@ -106,7 +116,7 @@ def joint_block(P: Params, name: str, x: Tensor, c: Tensor, temb: Tensor, heads:
     nx = layer_norm_noaffine(x) * (1 + scale_msa[:, None]) + shift_msa[:, None]
     if context_pre_only:  # AdaLayerNormContinuous: scale first, then shift (normalization.py:192-193)
         c_scale, c_shift = linear(P, name + ".norm1_context.linear", st).chunk(2, dim=1)
-        nc = layer_norm_noaffine(c) * (1 + c_scale)[:, None, :] + c_shift[:, None, :]
+        nc = _ln_bias(P, name + ".norm1_context.norm.bias", c) * (1 + c_scale)[:, None, :] + c_shift[:, None, :]
     else:
         c_shift_msa, c_scale_msa, c_gate_msa, c_shift_mlp, c_scale_mlp, c_gate_mlp = \
             linear(P, name + ".norm1_context.linear", st).chunk(6, dim=1)
@@ -173,7 +183,7 @@ def sd3_forward(P: Params, config: dict, hidden_states: Tensor, encoder_hidden_s
                            act_quant=act_quant)
     # norm_out (AdaLayerNormContinuous, no affine, eps 1e-6) + proj_out + unpatchify (:341-356)
     scale, shift = linear(P, "norm_out.linear", F.silu(temb)).chunk(2, dim=1)
-    x = layer_norm_noaffine(x) * (1 + scale)[:, None, :] + shift[:, None, :]
+    x = _ln_bias(P, "norm_out.norm.bias", x) * (1 + scale)[:, None, :] + shift[:, None, :]
     x = linear(P, "proj_out", x)
     h, w = H // p, W // p
     oc = cfg["out_channels"]

@@ -8,7 +8,8 @@ torch-CPU fp32 restatement of PPD/transformers/t5/modeling.py for ``T5EncoderMod
 ``_relative_position_bucket`` :246-291 / ``compute_bias`` :293-306 computed in block 0 and shared by every block),
 T5LayerSelfAttention :426-453, T5LayerFF :187-203, T5Stack :922-1113 (final_layer_norm).
 
-PARITY UNPINNED: the reference's T5 tests need Paddle and real checkpoints; neither exists here.
+Pinned against the reference's own T5EncoderModel code (transformers/t5/modeling.py) executed over oracle/paddle_shim.py
+(tests/test_reference_modules.py, case t5_encoder: bit-identical). The reference's T5 tests need Paddle and real checkpoints.
 """
 from __future__ import annotations
 

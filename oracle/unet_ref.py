@@ -1,8 +1,10 @@
 """torch-CPU restatement of ppdiffusers' UNet2DConditionModel forward (oracle).
 
-TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py.  Parity unpinned at
-whole-UNet level (no Paddle, no real weights here); the sub-pieces with
-RNG-free known answers are pinned in tests/test_oracle_pins.py.
+TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py.  Pinned against the reference's own
+UNet2DConditionModel / ControlNetModel code executed over oracle/paddle_shim.py
+(tests/test_reference_modules.py: 23 UNet / ControlNet / IP-Adapter cases, bit-identical
+outputs); the sub-pieces with RNG-free known answers are pinned in tests/test_oracle_pins.py.
+Unpinned: Paddle's own kernels and real weights (neither exists here).
 
 All paths relative to /root/reference/ppdiffusers/ppdiffusers/ (``PPD/``).
 Parameters live in a flat dict keyed by the reference's parameter names

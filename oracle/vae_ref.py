@@ -19,10 +19,10 @@ and the pipelines' ``latents / vae.config.scaling_factor`` (pipeline_stable_diff
                                                  with padding=0 -> F.pad (0, 1, 0, 1) + unpadded stride-2 conv, resnet.py:277-279)
   * ``DiagonalGaussianDistribution``             PPD/models/vae.py:744-795
 
-PARITY UNPINNED: the reference's VAE tests (ppdiffusers/tests/models/test_models_vae.py) compare against slices produced
-with Paddle's RNG / real checkpoints, neither of which exists here; Paddle itself cannot be imported. The op-level
-building blocks (conv2d, group_norm, linear, sdpa_math) are the ones of oracle/unet_ref.py, which are pinned to the
-reference's RNG-free vectors where those exist.
+Pinned against the reference's own AutoencoderKL code (decode, encode mean / logvar) executed over oracle/paddle_shim.py
+(tests/test_reference_modules.py, case vae_mini: bit-identical). The reference's VAE tests
+(ppdiffusers/tests/models/test_models_vae.py) compare against slices produced with Paddle's RNG / real checkpoints, neither of
+which exists here.
 """
 from __future__ import annotations
 

@@ -94,13 +94,17 @@ def resolve_weight_files(model_dir: str):
     raise OSError(f"no weights found under {model_dir}: looked for {', '.join(_CANDIDATES)} (+ .index.json)")
 
 
-def to_paddle_layout(state: Mapping[str, Tensor], shapes: Mapping[str, tuple], data_format: str) -> Dict[str, Tensor]:
-    """Select the model's parameters and bring them to the reference's Paddle layouts (Linear: [in, out])."""
+def to_paddle_layout(state: Mapping[str, Tensor], shapes: Mapping[str, tuple], data_format: str,
+                     optional: Optional[Mapping[str, tuple]] = None) -> Dict[str, Tensor]:
+    """Select the model's parameters and bring them to the reference's Paddle layouts (Linear: [in, out]). `optional`: entries
+    of the reference's state dict that checkpoints may or may not carry (taken when present, never reported missing)."""
     out: Dict[str, Tensor] = {}
     missing, bad = [], []
-    for name, shape in shapes.items():
+    opt = dict(optional or {})
+    for name, shape in list(shapes.items()) + list(opt.items()):
         if name not in state:
-            missing.append(name)
+            if name not in opt:
+                missing.append(name)
             continue
         t = state[name]
         if data_format == "pt" and t.dim() == 2 and len(shape) == 2 and not isinstance(shape, Table):   # nn.Linear: torch keeps [out, in]
@@ -144,7 +148,8 @@ def save_pretrained(model_dir: str, config: Mapping, params: Mapping[str, Tensor
 
 
 def load_pretrained(model_dir: str, shapes_fn: Callable[[Mapping], Mapping[str, tuple]],
-                    subfolder: Optional[str] = None) -> Tuple[dict, Dict[str, Tensor]]:
+                    subfolder: Optional[str] = None, optional_fn: Optional[Callable[[Mapping], Mapping[str, tuple]]] = None
+                    ) -> Tuple[dict, Dict[str, Tensor]]:
     """-> (config dict, parameters in Paddle layouts) for a model directory (optionally ``subfolder`` of a pipeline)."""
     if subfolder:
         model_dir = os.path.join(model_dir, subfolder)
@@ -161,7 +166,7 @@ def load_pretrained(model_dir: str, shapes_fn: Callable[[Mapping], Mapping[str, 
             raise OSError("shards of one checkpoint disagree on the data format")
         fmt = f_fmt
         state.update(part)
-    return config, to_paddle_layout(state, shapes_fn(config), "pd" if fmt == "np" else fmt)
+    return config, to_paddle_layout(state, shapes_fn(config), "pd" if fmt == "np" else fmt, optional_fn(config) if optional_fn else None)
 
 
 def fuse_lora(params: Mapping[str, Tensor], lora: Mapping[str, Tensor], lora_scale: float = 1.0,
@@ -220,10 +225,11 @@ class PretrainedMixin:
     """``Model.from_pretrained(dir, subfolder=..., **ctor_kwargs)`` for the MI355X model classes; the class names its
     parameter table in ``_param_shapes``."""
     _param_shapes: Callable[[Mapping], Mapping[str, tuple]] = None
+    _optional_param_shapes: Optional[Callable[[Mapping], Mapping[str, tuple]]] = None   # taken from the checkpoint when present
 
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path: str, subfolder: Optional[str] = None, **kwargs):
         if not os.path.isdir(pretrained_model_name_or_path):
             raise OSError(f"{pretrained_model_name_or_path} is not a local directory (there is no hub access here)")
-        config, params = load_pretrained(pretrained_model_name_or_path, cls._param_shapes, subfolder)
+        config, params = load_pretrained(pretrained_model_name_or_path, cls._param_shapes, subfolder, cls._optional_param_shapes)
         return cls(config, params, **kwargs)

@@ -84,6 +84,15 @@ def sd3_param_shapes(config: Mapping) -> Dict[str, tuple]:
     return S
 
 
+def sd3_optional_param_shapes(config: Mapping) -> Dict[str, tuple]:
+    """State-dict entries of the reference model beyond the converted public checkpoints: the trainable biases of the two
+    AdaLayerNormContinuous norms (models/normalization.py:182; zero unless fine-tuned with the reference) -- honoured when a
+    checkpoint carries them (folded into the shift rows of the modulation GEMM at load)."""
+    cfg = normalize_config(config)
+    D, n = cfg["inner_dim"], cfg["num_layers"]
+    return {"norm_out.norm.bias": (D,), f"transformer_blocks.{n - 1}.norm1_context.norm.bias": (D,)}
+
+
 def synth_sd3_params(config: Mapping, seed: int = 1234, device="cpu", dtype=torch.float32) -> Dict[str, Tensor]:
     """Random-init parameters (same recipe as the oracle's synth_sd3_params)."""
     g = torch.Generator(device=device).manual_seed(seed)
@@ -135,6 +144,7 @@ class Transformer2DModelOutput(SimpleNamespace):
 
 class SD3Transformer2DModel(DeviceProgram, PretrainedMixin):
     _param_shapes = staticmethod(sd3_param_shapes)
+    _optional_param_shapes = staticmethod(sd3_optional_param_shapes)
 
     def __init__(self, config: Mapping, params: Mapping[str, Tensor], device="cuda", use_graph: bool = True,
                  profile: bool = False, weight_dtype: str = "bf16", act_dtype: str = "bf16", _test_backend=None):
@@ -201,11 +211,22 @@ class SD3Transformer2DModel(DeviceProgram, PretrainedMixin):
         self._mod_off: Dict[str, int] = {}
         off = 0
 
-        def add_mod(key, name):
+        def add_mod(key, name, norm_bias=None):
             nonlocal off
             wt = get(name + ".weight").t()
+            bias = get(name + ".bias")
+            nb = params.get(norm_bias) if norm_bias else None
+            if nb is not None and bool((nb != 0).any()):
+                # AdaLayerNormContinuous keeps a trainable LayerNorm bias (normalization.py:182; zero unless the model was
+                # fine-tuned with the reference): (LN(x) + nb) * (1 + scale) + shift == LN(x) * (1 + scale) + shift', with
+                # shift' = shift + nb + nb * scale -- linear in the conditioning, so it folds into the shift rows exactly
+                if tuple(nb.shape) != (D,):
+                    raise ValueError(f"{norm_bias}: shape {tuple(nb.shape)} != ({D},)")
+                nb = nb.to(device=dev, dtype=torch.float32)
+                wt = torch.cat([wt[:D], wt[D:] + nb[:, None] * wt[:D]], 0)
+                bias = torch.cat([bias[:D], bias[D:] + nb + nb * bias[:D]], 0)
             mod_w.append(bf(wt))
-            mod_b.append(get(name + ".bias"))
+            mod_b.append(bias)
             self._mod_off[key] = off
             off += wt.shape[0]
 
@@ -213,7 +234,7 @@ class SD3Transformer2DModel(DeviceProgram, PretrainedMixin):
             b = f"transformer_blocks.{i}"
             last = i == n - 1
             add_mod(b + ".norm1", b + ".norm1.linear")
-            add_mod(b + ".norm1_context", b + ".norm1_context.linear")
+            add_mod(b + ".norm1_context", b + ".norm1_context.linear", b + ".norm1_context.norm.bias" if last else None)
             cat = lambda names: torch.cat([get(b + ".attn." + x + ".weight").t() for x in names], 0)  # noqa: E731
             catb = lambda names: torch.cat([get(b + ".attn." + x + ".bias") for x in names], 0)  # noqa: E731
             put_q(b + ".qkv", cat(("to_q", "to_k", "to_v")), catb(("to_q", "to_k", "to_v")))
@@ -226,7 +247,7 @@ class SD3Transformer2DModel(DeviceProgram, PretrainedMixin):
                 pq(b + ".out_c", b + ".attn.to_add_out")
                 pq(b + ".ff1_c", b + ".ff_context.net.0.proj")
                 pq(b + ".ff2_c", b + ".ff_context.net.2")
-        add_mod("norm_out", "norm_out.linear")
+        add_mod("norm_out", "norm_out.linear", "norm_out.norm.bias")
         W["mod_all.w"] = torch.cat(mod_w, 0).contiguous()
         W["mod_all.b"] = torch.cat(mod_b, 0).contiguous()
         self._mod_total = off

@@ -1,0 +1,452 @@
+"""Cases that put the REFERENCE's own code beside the oracle.
+
+Each case builds seeded inputs and parameters, runs the oracle (oracle/*.py, the torch / numpy restatement every device parity
+test is checked against) and -- when asked to, which is only possible in the build container where /root/reference exists --
+runs the reference's unmodified module (ppdiffusers/ppdiffusers/models/*.py, schedulers/*.py) over oracle/paddle_shim.py via
+oracle/reference_runner.py. scripts/make_reference_golden.py stores the reference's outputs under
+tests/golden/reference_modules/; tests/test_reference_modules.py holds the oracle to them (everywhere) and to the live reference
+(here).
+
+    case(run_reference: bool) -> {"oracle": {name: tensor}, "reference": {name: tensor} | None}
+"""
+from __future__ import annotations
+
+import math
+import os
+
+import numpy as np
+import torch
+
+from tests import configs as C
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_modules")
+REL_TOL = 5e-5     # max |oracle - reference| / max |reference|: fp32 rounding of two evaluation orders, nothing structural
+
+
+def _rr():
+    from oracle import reference_runner
+    return reference_runner
+
+
+def _synth(shapes, seed):
+    g = torch.Generator().manual_seed(seed)
+    P = {}
+    for name, shape in shapes.items():
+        r = torch.randn(shape, generator=g)
+        if name.endswith(".bias"):
+            P[name] = 0.02 * r
+        elif len(shape) == 1:
+            P[name] = 1.0 + 0.05 * r
+        elif len(shape) == 2:
+            P[name] = r / shape[0] ** 0.5
+        else:
+            P[name] = r / math.sqrt(shape[1] * shape[2] * shape[3])
+    return P
+
+
+# ------------------------------------------------------------------------------------------------------------------ UNet
+def _unet_case(cfg, *, seed=1, masks=None, class_labels=None, controlnet_residuals=False, B=2, hw=16, L=7):
+    def run(ref):
+        from oracle import unet_ref as U
+        P = U.synth_unet_params(cfg, seed=seed)
+        g = torch.Generator().manual_seed(seed + 100)
+        x = torch.randn(B, cfg.get("in_channels", 4), hw, hw, generator=g)
+        cd = cfg["cross_attention_dim"]
+        cd = cd[0] if isinstance(cd, (tuple, list)) else cd
+        enc = torch.randn(B, L, cd, generator=g)
+        t = torch.tensor([10.0, 500.0])[:B]
+        kw = {}
+        if cfg.get("addition_embed_type") == "text_time":
+            td = cfg["projection_class_embeddings_input_dim"] - 6 * cfg["addition_time_embed_dim"]
+            kw["added_cond_kwargs"] = dict(text_embeds=torch.randn(B, td, generator=g),
+                                           time_ids=torch.tensor([[1024.0, 1024.0, 0.0, 0.0, 1024.0, 1024.0]]).repeat(B, 1))
+        if masks:
+            if masks.get("self_len"):
+                kw["attention_mask"] = (torch.rand(B, masks["self_len"], generator=g) > 0.2).float()
+            kw["encoder_attention_mask"] = (torch.rand(B, L, generator=g) > 0.3).float()
+        if class_labels is not None:
+            kw["class_labels"] = class_labels(g)
+        if controlnet_residuals:   # TINY at 16x16: the six skip tensors and the mid output
+            c0, c1 = cfg["block_out_channels"]
+            shapes = [(B, c0, hw, hw)] * 3 + [(B, c0, hw // 2, hw // 2)] + [(B, c1, hw // 2, hw // 2)] * 2
+            kw["down_block_additional_residuals"] = tuple(0.3 * torch.randn(s, generator=g) for s in shapes)
+            kw["mid_block_additional_residual"] = 0.3 * torch.randn(B, c1, hw // 2, hw // 2, generator=g)
+        with torch.no_grad():
+            out = {"oracle": {"sample": U.unet_forward(P, cfg, x, t, enc, **kw)}, "reference": None}
+            if ref:
+                rr = _rr()
+                net = rr.build_unet(cfg, P)
+                out["reference"] = {"sample": rr.from_shim(net(rr.to_shim(x), rr.to_shim(t), rr.to_shim(enc), **rr.to_shim(kw)).sample)}
+        return out
+    return run
+
+
+def _ip_adapter_case(ip_scale):
+    """IP-Adapter: ImageProjection + IPAdapterAttnProcessor on every cross-attention. The reference wires them in its checkpoint
+    loader (loaders/unet.py:754-828, file I/O, not loaded here): the case replays that wiring with the reference's own classes."""
+    def run(ref):
+        from oracle import unet_ref as U
+        cfg = dict(C.TINY, encoder_hid_dim_type="ip_image_proj", encoder_hid_dim=48)
+        P = U.synth_unet_params(cfg, seed=6)
+        g = torch.Generator().manual_seed(8)
+        x, enc = torch.randn(2, 4, 16, 16, generator=g), torch.randn(2, 7, 64, generator=g)
+        img, t = torch.randn(2, 48, generator=g), torch.tensor([10.0, 500.0])
+        with torch.no_grad():
+            out = {"oracle": {"sample": U.unet_forward(P, cfg, x, t, enc, added_cond_kwargs={"image_embeds": img}, ip_adapter_scale=ip_scale)},
+                   "reference": None}
+            if ref:
+                rr = _rr()
+                net = rr.ref_module("unet_2d_condition").UNet2DConditionModel(**C.TINY)
+                ap, emb = rr.ref_module("attention_processor"), rr.ref_module("embeddings")
+                procs = {}
+                for name in net.attn_processors.keys():                                   # loaders/unet.py:769-797
+                    if name.endswith("attn1.processor"):
+                        procs[name] = ap.AttnProcessor()
+                        continue
+                    boc = net.config.block_out_channels
+                    hidden = boc[-1] if name.startswith("mid_block") else (
+                        list(reversed(boc))[int(name[len("up_blocks.")])] if name.startswith("up_blocks") else boc[int(name[len("down_blocks.")])])
+                    procs[name] = ap.IPAdapterAttnProcessor(hidden_size=hidden, cross_attention_dim=net.config.cross_attention_dim, scale=1.0)
+                net.set_attn_processor(procs)                                             # :799
+                net.encoder_hid_proj = emb.ImageProjection(cross_attention_dim=64, image_embed_dim=48, num_image_text_embeds=4)   # :808-827
+                net.config["encoder_hid_dim_type"] = "ip_image_proj"                      # :828
+                for p in net.attn_processors.values():                                    # set_ip_adapter_scale (loaders/ip_adapter.py)
+                    if isinstance(p, ap.IPAdapterAttnProcessor):
+                        p.scale = ip_scale
+                net.eval()
+                rr.load_params(net, P)
+                out["reference"] = {"sample": rr.from_shim(net(rr.to_shim(x), rr.to_shim(t), rr.to_shim(enc),
+                                                                 added_cond_kwargs={"image_embeds": rr.to_shim(img)}).sample)}
+        return out
+    return run
+
+
+def _lora_case(ref):
+    """LoRA taken the way the reference takes it for inference -- merged into the weights (models/lora.py:312-344 conv, :404-425
+    linear). "oracle" here is the PRODUCT's host-side paddlemix_amd.checkpoint.fuse_lora (plain torch on CPU); the reference side
+    also runs the unfused forward (base layer + scale * LoRA branch, :364-398, :453-462), which the fused weights must reproduce."""
+    from paddlemix_amd.checkpoint import fuse_lora
+    g = torch.Generator().manual_seed(11)
+    rn = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
+    params = {"lin.weight": rn(16, 24) / 4, "lin.bias": 0.1 * rn(24), "conv.weight": rn(12, 8, 3, 3) / 8, "conv.bias": 0.1 * rn(12)}
+    lora = {"unet.lin.lora.down.weight": rn(16, 4) / 4, "unet.lin.lora.up.weight": rn(4, 24) / 2,
+            "unet.conv.lora.down.weight": rn(4, 8, 3, 3) / 8, "unet.conv.lora.up.weight": rn(12, 4, 1, 1) / 2}
+    alphas, scale = {"lin": 2.0}, 0.7
+    x, img = rn(3, 16), rn(2, 8, 6, 6)
+    fused = fuse_lora(params, lora, lora_scale=scale, network_alphas=alphas)
+    F = torch.nn.functional
+    out = {"oracle": {"lin.weight": fused["lin.weight"], "conv.weight": fused["conv.weight"],
+                      "lin(x)": x @ fused["lin.weight"] + fused["lin.bias"],
+                      "conv(x)": F.conv2d(img, fused["conv.weight"], fused["conv.bias"], padding=1)}, "reference": None}
+    if ref:
+        rr = _rr()
+        m = rr.ref_module("lora")
+        lin = m.LoRACompatibleLinear(16, 24)
+        lin.set_lora_layer(m.LoRALinearLayer(16, 24, rank=4, network_alpha=alphas["lin"]))
+        rr.load_params(lin, {"weight": params["lin.weight"], "bias": params["lin.bias"],
+                             "lora_layer.down.weight": lora["unet.lin.lora.down.weight"], "lora_layer.up.weight": lora["unet.lin.lora.up.weight"]})
+        conv = m.LoRACompatibleConv(8, 12, 3, padding=1)
+        conv.set_lora_layer(m.LoRAConv2dLayer(8, 12, rank=4, kernel_size=3, padding=1))
+        rr.load_params(conv, {"weight": params["conv.weight"], "bias": params["conv.bias"],
+                              "lora_layer.down.weight": lora["unet.conv.lora.down.weight"], "lora_layer.up.weight": lora["unet.conv.lora.up.weight"]})
+        unfused = {"lin(x)": rr.from_shim(lin(rr.to_shim(x), scale)), "conv(x)": rr.from_shim(conv(rr.to_shim(img), scale))}
+        lin._fuse_lora(scale)
+        conv._fuse_lora(scale)
+        out["reference"] = {"lin.weight": rr.from_shim(lin.weight), "conv.weight": rr.from_shim(conv.weight), **unfused}
+        assert torch.allclose(rr.from_shim(lin(rr.to_shim(x))), unfused["lin(x)"], atol=1e-5)     # the reference's own identity
+    return out
+
+
+def _controlnet_case(order, guess):
+    def run(ref):
+        from oracle import unet_ref as U
+        cfg = dict(C.TINY, controlnet_conditioning_channel_order=order)
+        P = _synth(U.controlnet_param_shapes(cfg), 3)
+        g = torch.Generator().manual_seed(0)
+        x, enc = torch.randn(1, 4, 8, 8, generator=g), torch.randn(1, 7, 64, generator=g)
+        cond, t = torch.randn(1, 3, 64, 64, generator=g), torch.tensor([20.0])
+        with torch.no_grad():
+            downs, mid = U.controlnet_forward(P, cfg, x, t, enc, cond, 0.7, guess)
+            out = {"oracle": {**{f"down{i}": d for i, d in enumerate(downs)}, "mid": mid}, "reference": None}
+            if ref:
+                rr = _rr()
+                kw = {k: v for k, v in cfg.items() if k not in ("up_block_types", "sample_size")}
+                net = rr.ref_module("controlnet").ControlNetModel(**kw)
+                net.eval()
+                rr.load_params(net, P)
+                rd, rm = net(rr.to_shim(x), rr.to_shim(t), rr.to_shim(enc), rr.to_shim(cond), conditioning_scale=0.7,
+                             guess_mode=guess, return_dict=False)
+                assert len(rd) == len(downs)
+                out["reference"] = {**{f"down{i}": rr.from_shim(d) for i, d in enumerate(rd)}, "mid": rr.from_shim(rm)}
+        return out
+    return run
+
+
+# ------------------------------------------------------------------------------------------------------------------ DiT / SD3 / VAE
+def _dit_case(ref):
+    from oracle import dit_ref as D
+    cfg = C.MINI_DIT
+    P = D.synth_dit_params(cfg, seed=2)
+    g = torch.Generator().manual_seed(0)
+    x, t, y = torch.randn(2, 4, 16, 16, generator=g), torch.tensor([3, 900]), torch.tensor([1, 7])
+    with torch.no_grad():
+        out = {"oracle": {"sample": D.dit_forward(P, cfg, x, t, y)}, "reference": None}
+        if ref:
+            rr = _rr()
+            full = D.normalize_config(cfg)
+            full.pop("inner_dim")
+            net = rr.ref_module("transformer_2d").Transformer2DModel(**full)
+            net.eval()
+            rr.load_params(net, P)
+            out["reference"] = {"sample": rr.from_shim(net(rr.to_shim(x), timestep=rr.to_shim(t), class_labels=rr.to_shim(y)).sample)}
+    return out
+
+
+SD3_COMPUTED = ("pos_embed.pos_embed",)                                      # persistable buffer derived from the config
+SD3_OPTIONAL = ("norm_out.norm.bias", "norm1_context.norm.bias")             # trainable, zero at construction (normalization.py:182)
+
+
+def _sd3_case(trained_norm_bias):
+    def run(ref):
+        from oracle import sd3_ref as S
+        cfg = C.MINI_SD3
+        P = S.synth_sd3_params(cfg, seed=3)
+        g = torch.Generator().manual_seed(0)
+        if trained_norm_bias:
+            n, D = cfg["num_layers"], cfg["num_attention_heads"] * cfg["attention_head_dim"]
+            P["norm_out.norm.bias"] = 0.5 * torch.randn(D, generator=g)
+            P[f"transformer_blocks.{n - 1}.norm1_context.norm.bias"] = 0.5 * torch.randn(D, generator=g)
+        x, enc = torch.randn(2, 4, 16, 16, generator=g), torch.randn(2, 9, 64, generator=g)
+        pooled, t = torch.randn(2, 64, generator=g), torch.tensor([3.0, 900.0])
+        with torch.no_grad():
+            out = {"oracle": {"sample": S.sd3_forward(P, cfg, x, enc, pooled, t)}, "reference": None}
+            if ref:
+                rr = _rr()
+                net = rr.ref_module("transformer_sd3").SD3Transformer2DModel(**cfg)
+                net.eval()
+                rr.load_params(net, P, computed=SD3_COMPUTED + (() if trained_norm_bias else SD3_OPTIONAL))
+                # the buffer the reference derives is the table the oracle crops from
+                full = S.normalize_config(cfg)
+                table = rr.from_shim(net.pos_embed.pos_embed)
+                mx = cfg["pos_embed_max_size"]
+                own = S.cropped_pos_embed(dict(full, sample_size=cfg["sample_size"]), mx * cfg["patch_size"], mx * cfg["patch_size"])
+                assert torch.allclose(table.reshape(own.shape), own.float(), atol=1e-6)
+                out["reference"] = {"sample": rr.from_shim(net(rr.to_shim(x), encoder_hidden_states=rr.to_shim(enc),
+                                                                 pooled_projections=rr.to_shim(pooled), timestep=rr.to_shim(t)).sample)}
+        return out
+    return run
+
+
+def _vae_case(ref):
+    from oracle import vae_ref as V
+    cfg = C.MINI_VAE
+    P = V.synth_decoder_params(cfg, seed=2)
+    P.update(_synth(V.encoder_param_shapes(cfg), 7))
+    g = torch.Generator().manual_seed(0)
+    z, img = torch.randn(2, 4, 8, 8, generator=g), torch.randn(2, 3, 32, 32, generator=g)
+    with torch.no_grad():
+        mean, logvar, _ = V.encode(P, cfg, img)
+        out = {"oracle": {"decode": V.decode(P, cfg, z), "encode_mean": mean, "encode_logvar": logvar}, "reference": None}
+        if ref:
+            rr = _rr()
+            full = V.normalize_config(cfg)
+            n = len(full["block_out_channels"])
+            full.update(down_block_types=("DownEncoderBlock2D",) * n, up_block_types=("UpDecoderBlock2D",) * n)
+            full.pop("use_post_quant_conv", None)
+            full.pop("use_quant_conv", None)
+            net = rr.ref_module("autoencoder_kl").AutoencoderKL(**full)
+            net.eval()
+            rr.load_params(net, P)
+            post = net.encode(rr.to_shim(img)).latent_dist
+            out["reference"] = {"decode": rr.from_shim(net.decode(rr.to_shim(z)).sample), "encode_mean": rr.from_shim(post.mean),
+                                "encode_logvar": rr.from_shim(post.logvar)}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------ text / image encoders
+def _transformers_module(rr, name):
+    import importlib
+    rr.install()
+    return importlib.import_module("ppdiffusers.transformers." + name)
+
+
+def _clip_text_case(act):
+    def run(ref):
+        from oracle import clip_ref as K
+        cfg = dict(C.MINI_CLIP, with_projection=True, hidden_act=act)
+        P = K.synth_clip_params(cfg, seed=2)
+        g = torch.Generator().manual_seed(0)
+        ids = torch.randint(3, 1000, (2, 77), generator=g)
+        ids[0, 20], ids[0, 21:], ids[1, 76] = 2, 0, 2         # EOS (the largest id) mid-sequence + padding, and at the end
+        with torch.no_grad():
+            o = K.clip_text_forward(P, cfg, ids)
+            out = {"oracle": {"last_hidden_state": o["last_hidden_state"], "text_embeds": o["text_embeds"],
+                              "penultimate": o["hidden_states"][-2]}, "reference": None}
+            if ref:
+                rr = _rr()
+                conf = _transformers_module(rr, "clip.configuration").CLIPTextConfig(**{k: v for k, v in cfg.items() if k != "with_projection"})
+                net = _transformers_module(rr, "clip.modeling").CLIPTextModelWithProjection(conf)
+                net.eval()
+                rr.load_params(net, P)
+                r = net(rr.to_shim(ids), output_hidden_states=True)
+                out["reference"] = {"last_hidden_state": rr.from_shim(r.last_hidden_state), "text_embeds": rr.from_shim(r.text_embeds),
+                                    "penultimate": rr.from_shim(r.hidden_states[-2])}
+        return out
+    return run
+
+
+def _clip_vision_case(ref):
+    from oracle import clip_ref as K
+    cfg = C.MINI_CLIP_VISION
+    g = torch.Generator().manual_seed(5)
+    P = {}
+    for k, shp in K.clip_vision_param_shapes(cfg).items():
+        r = torch.randn(shp, generator=g)
+        if k.endswith(".bias"):
+            P[k] = 0.02 * r
+        elif "embedding" in k and len(shp) <= 2:
+            P[k] = 0.5 * r
+        elif len(shp) == 1:
+            P[k] = 1.0 + 0.02 * r
+        else:
+            P[k] = r / math.sqrt(shp[0] if len(shp) == 2 else shp[1] * shp[2] * shp[3])
+    px = torch.randn(2, 3, 56, 56, generator=g)
+    with torch.no_grad():
+        o = K.clip_vision_forward(P, cfg, px)
+        out = {"oracle": {"image_embeds": o["image_embeds"], "penultimate": o["hidden_states"][-2]}, "reference": None}
+        if ref:
+            rr = _rr()
+            conf = _transformers_module(rr, "clip.configuration").CLIPVisionConfig(**cfg)
+            net = _transformers_module(rr, "clip.modeling").CLIPVisionModelWithProjection(conf)
+            net.eval()
+            rr.load_params(net, P)
+            r = net(rr.to_shim(px), output_hidden_states=True)
+            out["reference"] = {"image_embeds": rr.from_shim(r.image_embeds), "penultimate": rr.from_shim(r.hidden_states[-2])}
+    return out
+
+
+def _t5_case(ref):
+    from oracle import t5_ref as T
+    cfg = C.MINI_T5
+    P = T.synth_t5_params(cfg, seed=6)
+    ids = torch.randint(0, 500, (2, 33), generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        out = {"oracle": {"last_hidden_state": T.t5_encoder_forward(P, cfg, ids)}, "reference": None}
+        if ref:
+            rr = _rr()
+            conf = _transformers_module(rr, "t5.configuration").T5Config(**T.normalize_config(cfg))
+            net = _transformers_module(rr, "t5.modeling").T5EncoderModel(conf)
+            net.eval()
+            rr.load_params(net, P)          # `encoder.embed_tokens.weight` is `shared.weight` (tied): one entry, like Paddle's state dict
+            out["reference"] = {"last_hidden_state": rr.from_shim(net(rr.to_shim(ids))[0])}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------ schedulers
+_SD = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear")
+
+
+def _scheduler_case(module, cls, oracle_cls, kw, steps, scale=True, noisy=False):
+    """full sampling loop around a deterministic stand-in for the model; the final latents and the timestep table are compared"""
+    def run(ref):
+        from oracle import schedulers_ref as S
+        g = torch.Generator().manual_seed(0)
+        x0, pat = torch.randn(1, 4, 8, 8, generator=g), torch.randn(1, 4, 8, 8, generator=g)
+        draws = [torch.randn(1, 4, 8, 8, generator=g) for _ in range(steps)]
+
+        def model(x, t):
+            return 0.3 * x * math.cos(0.01 * float(t)) + 0.1 * pat
+
+        sch = getattr(S, oracle_cls)(**kw)
+        sch.set_timesteps(steps)
+        x = (x0 * float(getattr(sch, "init_noise_sigma", 1.0))).numpy()
+        for i, t in enumerate(sch.timesteps):
+            xin = sch.scale_model_input(x, t) if scale else x
+            eps = model(torch.from_numpy(np.asarray(xin, dtype=np.float32)), t).numpy()
+            if noisy:
+                x = sch.step(eps, t, x, noise=None if i == steps - 1 else draws[i].numpy())[0]
+            else:
+                x = sch.step(eps, t, x)
+        out = {"oracle": {"latents": torch.from_numpy(np.asarray(x, dtype=np.float32)),
+                          "timesteps": torch.from_numpy(np.asarray(sch.timesteps, dtype=np.float32))}, "reference": None}
+        if ref:
+            rr = _rr()
+            rs = getattr(rr.ref_module(module, "schedulers"), cls)(**kw)
+            rs.set_timesteps(steps)
+            ins = getattr(rs, "init_noise_sigma", 1.0)
+            xr = rr.to_shim(x0 * float(ins if isinstance(ins, (int, float)) else rr.from_shim(ins)))
+            for i, t in enumerate(rs.timesteps):
+                xin = rs.scale_model_input(xr, t) if scale else xr
+                eps = rr.to_shim(model(rr.from_shim(xin), rr.from_shim(t)))
+                if noisy:
+                    xr = rs.step(eps, t, xr, generator=lambda shape, i=i: draws[i], return_dict=False)[0]
+                else:
+                    xr = rs.step(eps, t, xr, return_dict=False)[0]
+            out["reference"] = {"latents": rr.from_shim(xr).float(),
+                                "timesteps": torch.tensor([float(rr.from_shim(t)) for t in rs.timesteps])}
+        return out
+    return run
+
+
+def _labels(kind):
+    return {
+        "index": lambda g: torch.tensor([3, 8]),
+        "time": lambda g: torch.tensor([3.0, 8.0]),
+        "vec256": lambda g: torch.randn(2, 256, generator=g),
+        "vec24": lambda g: torch.randn(2, 24, generator=g),
+    }[kind]
+
+
+CASES = {
+    # UNet2DConditionModel.forward (models/unet_2d_condition.py) on the tiny / SDXL-shaped configs and every configuration variant
+    "unet_tiny": _unet_case(C.TINY),
+    "unet_mini_xl": _unet_case(C.MINI_XL),
+    **{"unet_" + k.replace("-", "_"): _unet_case(v) for k, v in C.UNET_VARIANTS.items()},
+    "unet_tiny_masks": _unet_case(C.TINY, masks=dict(self_len=64)),
+    "unet_mini_xl_encoder_mask": _unet_case(C.MINI_XL, masks=dict()),
+    "unet_class_embeds": _unet_case(dict(C.TINY, num_class_embeds=10), seed=4, class_labels=_labels("index")),
+    "unet_class_timestep": _unet_case(dict(C.TINY, class_embed_type="timestep"), seed=4, class_labels=_labels("time")),
+    "unet_class_identity": _unet_case(dict(C.TINY, class_embed_type="identity"), seed=4, class_labels=_labels("vec256")),
+    "unet_class_projection": _unet_case(dict(C.TINY, class_embed_type="projection", projection_class_embeddings_input_dim=24), seed=4,
+                                        class_labels=_labels("vec24")),
+    "unet_class_simple_projection": _unet_case(dict(C.TINY, class_embed_type="simple_projection", projection_class_embeddings_input_dim=24),
+                                               seed=4, class_labels=_labels("vec24")),
+    "unet_class_concat": _unet_case(dict(C.TINY, class_embed_type="projection", projection_class_embeddings_input_dim=24,
+                                         class_embeddings_concat=True), seed=4, class_labels=_labels("vec24")),
+    "unet_controlnet_residuals": _unet_case(C.TINY, seed=4, controlnet_residuals=True),
+    "unet_ip_adapter": _ip_adapter_case(1.0),
+    "unet_ip_adapter_scale_0p6": _ip_adapter_case(0.6),
+    "lora_fuse": _lora_case,
+    # ControlNetModel.forward (models/controlnet.py)
+    "controlnet_rgb": _controlnet_case("rgb", False),
+    "controlnet_bgr_guess_mode": _controlnet_case("bgr", True),
+    # Transformer2DModel.forward, DiT branch (models/transformer_2d.py); SD3Transformer2DModel.forward (models/transformer_sd3.py)
+    "dit_mini": _dit_case,
+    "sd3_mini": _sd3_case(False),
+    "sd3_mini_trained_norm_bias": _sd3_case(True),
+    # AutoencoderKL.decode / encode (models/autoencoder_kl.py, models/vae.py)
+    "vae_mini": _vae_case,
+    # transformers/clip/modeling.py (text towers of SD / SDXL, the IP-Adapter image tower), transformers/t5/modeling.py (SD3's T5 encoder)
+    "clip_text_quick_gelu": _clip_text_case("quick_gelu"),
+    "clip_text_gelu": _clip_text_case("gelu"),
+    "clip_vision": _clip_vision_case,
+    "t5_encoder": _t5_case,
+    # schedulers/*.py: whole sampling loops
+    "sched_ddim_sd15": _scheduler_case("scheduling_ddim", "DDIMScheduler", "DDIMRef", dict(_SD, clip_sample=False, set_alpha_to_one=False, steps_offset=1), 20),
+    "sched_ddim_trailing_clip": _scheduler_case("scheduling_ddim", "DDIMScheduler", "DDIMRef", dict(_SD, clip_sample=True, timestep_spacing="trailing"), 10),
+    "sched_euler_sdxl": _scheduler_case("scheduling_euler_discrete", "EulerDiscreteScheduler", "EulerRef", dict(_SD, timestep_spacing="leading", steps_offset=1), 30),
+    "sched_euler_karras": _scheduler_case("scheduling_euler_discrete", "EulerDiscreteScheduler", "EulerRef", dict(_SD, use_karras_sigmas=True), 12),
+    "sched_flow_match_sd3": _scheduler_case("scheduling_flow_match_euler_discrete", "FlowMatchEulerDiscreteScheduler", "FlowMatchEulerRef", dict(shift=3.0), 28, scale=False),
+    "sched_pndm_sd15": _scheduler_case("scheduling_pndm", "PNDMScheduler", "PNDMRef", dict(_SD, skip_prk_steps=True, steps_offset=1), 20),
+    "sched_pndm_prk": _scheduler_case("scheduling_pndm", "PNDMScheduler", "PNDMRef", dict(_SD), 10),
+    "sched_dpmpp_2m": _scheduler_case("scheduling_dpmsolver_multistep", "DPMSolverMultistepScheduler", "DPMSolverMultistepRef", dict(_SD), 20),
+    "sched_dpmpp_2m_karras_heun": _scheduler_case("scheduling_dpmsolver_multistep", "DPMSolverMultistepScheduler", "DPMSolverMultistepRef",
+                                                  dict(_SD, use_karras_sigmas=True, solver_type="heun"), 12),
+    "sched_dpm_order1_leading": _scheduler_case("scheduling_dpmsolver_multistep", "DPMSolverMultistepScheduler", "DPMSolverMultistepRef",
+                                                dict(_SD, algorithm_type="dpmsolver", solver_order=1, timestep_spacing="leading", steps_offset=1), 10),
+    "sched_lcm": _scheduler_case("scheduling_lcm", "LCMScheduler", "LCMRef", dict(_SD), 4, scale=False, noisy=True),
+}
+
+
+def golden_path(name):
+    return os.path.join(GOLDEN_DIR, name + ".npz")

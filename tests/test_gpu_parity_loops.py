@@ -1,7 +1,7 @@
 """-m gpu: north_star's parity bar on the real depth. "Latents within 1e-3 rel-err of the CPU reference": the full SDXL parameter
 set (2.6 B parameters), 30 Euler steps, free-running device loop against the committed oracle trajectory
 (tests/golden/parity/sdxl_1x4x32x32_euler30.npz, made by scripts/make_parity_golden.py; oracle = torch-CPU restatement of
-ppdiffusers, unpinned against Paddle itself), in the four device modes {bf16, fp16 elements} x {16-bit, fp32 residual stream}.
+ppdiffusers, pinned to the reference's own module code by tests/test_reference_modules.py), in the four device modes {bf16, fp16 elements} x {16-bit, fp32 residual stream}.
 
 The ABSOLUTE target is asserted where it is met (fp16 elements; must pass) and recorded as a strict xfail where it is not (the bf16
 headline: the 2^-9 operand rounding of ~230 sequential contractions) -- so the suite states the gap instead of

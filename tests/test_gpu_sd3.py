@@ -1,5 +1,5 @@
 """-m gpu parity of the SD3 MMDiT path: new kernels (adaLN, gated / remapped GEMM epilogues, GELU-tanh, patchify) and the
-whole SD3Transformer2DModel against the torch-CPU oracle (oracle/sd3_ref.py; parity unpinned at model level)."""
+whole SD3Transformer2DModel against the torch-CPU oracle (oracle/sd3_ref.py; pinned to the reference's module code by tests/test_reference_modules.py)."""
 import math
 
 import pytest

@@ -1,8 +1,8 @@
 """-m gpu whole-model parity: the HIP UNet2DConditionModel against the torch-CPU oracle on identical synthetic
 weights (bf16-representable) and inputs.  Stated tolerance for bf16 activations / fp32 accumulation: rel-L2 of the
 noise prediction <= 2e-2 per forward (the host-memory emulator, which has the same rounding points but fp32 math,
-sits at ~1e-2 against the same oracle; see DESIGN.md "Numerics").  Whole-UNet parity against real checkpoints is
-unpinned in this environment (no Paddle, no weights) -- see oracle/__init__.py."""
+sits at ~1e-2 against the same oracle; see DESIGN.md "Numerics").  The oracle itself is held to the reference's own
+UNet2DConditionModel code by tests/test_reference_modules.py; real checkpoints do not exist in this environment (oracle/__init__.py)."""
 import pytest
 import torch
 

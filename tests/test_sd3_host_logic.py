@@ -32,6 +32,27 @@ def test_sd3_program_matches_oracle(B, H, W, L):
     assert torch.equal(out, model(x, enc, pooled, 501.0).sample)
 
 
+def test_sd3_trained_adaln_continuous_bias_folds_into_the_modulation_rows():
+    """the reference's AdaLayerNormContinuous norms own a trainable bias (normalization.py:182; found by running the reference's
+    module over oracle/paddle_shim.py): a checkpoint that carries non-zero ones gets them, folded into the shift rows"""
+    from paddlemix_amd.sd3 import sd3_optional_param_shapes
+    cfg = MINI_SD3
+    P = synth_sd3_params(cfg, seed=1234)
+    g = torch.Generator().manual_seed(5)
+    opt = sd3_optional_param_shapes(cfg)
+    assert sorted(opt) == ["norm_out.norm.bias", "transformer_blocks.2.norm1_context.norm.bias"]
+    extra = {k: 0.5 * torch.randn(s, generator=g) for k, s in opt.items()}
+    x, enc, pooled = _inputs(cfg, 2, 16, 16, 10)
+    Pb = {k: v.to(torch.bfloat16).float() if v.dim() > 1 else v for k, v in P.items()}
+    plain = R.sd3_forward(Pb, cfg, x, enc, pooled, 501.0)
+    ref = R.sd3_forward({**Pb, **extra}, cfg, x, enc, pooled, 501.0)
+    assert _rel(plain, ref) > 0.1                        # the biases matter
+    out = SD3Transformer2DModel(cfg, {**P, **extra}, _test_backend=Emulator())(x, enc, pooled, 501.0).sample
+    assert _rel(out, ref) < 2e-2, _rel(out, ref)
+    zero = SD3Transformer2DModel(cfg, {**P, **{k: torch.zeros_like(v) for k, v in extra.items()}}, _test_backend=Emulator())(x, enc, pooled, 501.0).sample
+    assert torch.equal(zero, SD3Transformer2DModel(cfg, P, _test_backend=Emulator())(x, enc, pooled, 501.0).sample)
+
+
 def test_sd3_inventory_and_synth_match_oracle():
     for cfg in (MINI_SD3, SD3_MEDIUM):
         assert list(sd3_param_shapes(cfg).items()) == list(R.sd3_param_shapes(cfg).items())
