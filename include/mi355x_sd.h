@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MI355X_SD_ABI_VERSION 10
+#define MI355X_SD_ABI_VERSION 11
 #define MI355X_SD_OK 0
 #define MI355X_SD_ERR_INVALID 1      /* bad argument (shape <= 0, null pointer ...)          */
 #define MI355X_SD_ERR_UNSUPPORTED 2  /* well-formed but outside the implemented configurations */
@@ -119,6 +119,35 @@ int mi355x_sd_unet_forward_ex(void* handle, void* stream, const float* sample, c
                               const float* in_scale, const float* encoder_attention_mask, const float* attention_mask,
                               const float* const* down_block_additional_residuals, int num_down_residuals,
                               const float* mid_block_additional_residual, float* out, int use_graph);
+/* ---- seam B2: any exported step program behind one handle (paddlemix_amd/csrc/program_exec.hip) --------------------------------
+ * Every model of the path (UNet2DConditionModel, ControlNetModel, SD3Transformer2DModel, the DiT Transformer2DModel, AutoencoderKL
+ * decode / encode, the CLIP and T5 text encoders) runs as a static list of the per-op launches below over weights + scratch. The
+ * Python planners build that list; `paddlemix_amd.export.export_program(model, plan, path)` writes it to a file (entry-point
+ * names, arguments with every device pointer as (region, offset), packed weights, plan-time constants, the named input / output
+ * regions), and a host without Python replays it -- the shape of the reference's own deployment path: export offline
+ * (PPD/../deploy/sd15/export_model.py:78-90), then run behind a predictor with named inputs
+ * (PaddleInferRuntimeModel.__call__, PPD/models/paddleinfer_runtime.py:47-126: get_input_handle / copy_from_cpu / run / copy_to_cpu):
+ *   load(path)  host only: parses and type-checks every launch against this library's entry points (refuses another ABI version
+ *               or the other 16-bit element build) -> device_bytes -> bind(caller's device buffer, 256-byte aligned: uploads
+ *               weights and constants, resolves the pointers) -> io_info(i): name, direction, dtype, shape and DEVICE ADDRESS of
+ *               each input / output region (copy inputs there, in the dtype it names) -> run(stream) per call -> destroy.
+ * The library allocates no device memory; run() binds the split-K workspace the program was planned with (inside the same
+ * buffer), so it reproduces the exporting process bit for bit. Option "use_graph" = 1: the replay becomes one hipGraph. */
+#define MI355X_SD_IO_F32 0
+#define MI355X_SD_IO_ELEM16 1   /* the build's 16-bit element type (mi355x_sd_elem_dtype) */
+#define MI355X_SD_IO_I32 2
+#define MI355X_SD_IO_U8 3
+int mi355x_sd_program_load(const char* path, void** handle);
+int mi355x_sd_program_destroy(void* handle);
+int mi355x_sd_program_set_option(void* handle, const char* key, int value);
+int mi355x_sd_program_num_launches(void* handle);
+int mi355x_sd_program_device_bytes(void* handle, size_t* bytes);
+int mi355x_sd_program_bind(void* handle, void* device_buffer, size_t bytes, void* stream);
+int mi355x_sd_program_num_io(void* handle);
+int mi355x_sd_program_io_info(void* handle, int index, const char** name, int* is_output, int* dtype, int64_t* shape4, int* ndim,
+                              size_t* bytes, void** device_ptr);
+int mi355x_sd_program_run(void* handle, void* stream);
+
 /* bias[i] = (1 - mask[i]) * -10000: the additive form of a keep-mask (unet_2d_condition.py:921-927) */
 int mi355x_sd_mask_to_bias(const float* mask, float* bias, int64_t n, void* stream);
 

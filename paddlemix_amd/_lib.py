@@ -17,7 +17,7 @@ if ELEM_NAME not in _BUILDS:
     raise ValueError(f"MI355X_SD_DTYPE must be one of {sorted(_BUILDS)}, got {ELEM_NAME!r}")
 LIB_PATH = os.path.join(_HERE, _BUILDS[ELEM_NAME][0])
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 GEGLU, OUT_F32, SILU, GELU_TANH, PAD_BR, R_F32, CONV_KB64 = 1, 2, 4, 8, 16, 32, 64
 UNET_ENC_MASK, UNET_SELF_MASK, UNET_CONTROLNET = 1, 2, 4   # mi355x_sd_unet_plan_ex flags
 SDPA_LOG2 = 1
@@ -30,6 +30,16 @@ SIGNATURES = {
     "mi355x_sd_last_error": (c_char_p, []),
     "mi355x_sd_set_workspace": (c_int, [c_void_p, ctypes.c_size_t]),
     "mi355x_sd_init": (c_int, [c_int]),
+    "mi355x_sd_program_load": (c_int, [c_char_p, POINTER(c_void_p)]),
+    "mi355x_sd_program_destroy": (c_int, [c_void_p]),
+    "mi355x_sd_program_set_option": (c_int, [c_void_p, c_char_p, c_int]),
+    "mi355x_sd_program_num_launches": (c_int, [c_void_p]),
+    "mi355x_sd_program_device_bytes": (c_int, [c_void_p, POINTER(ctypes.c_size_t)]),
+    "mi355x_sd_program_bind": (c_int, [c_void_p, c_void_p, ctypes.c_size_t, c_void_p]),
+    "mi355x_sd_program_num_io": (c_int, [c_void_p]),
+    "mi355x_sd_program_io_info": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(c_int), POINTER(c_int), POINTER(c_int64),
+                                          POINTER(c_int), POINTER(ctypes.c_size_t), POINTER(c_void_p)]),
+    "mi355x_sd_program_run": (c_int, [c_void_p, c_void_p]),
     "mi355x_sd_linear": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                  c_int, c_int, c_void_p, c_int, c_float, c_int, c_void_p]),
     "mi355x_sd_linear_ex": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int,

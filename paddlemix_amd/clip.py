@@ -210,6 +210,7 @@ class CLIPTextModel(DeviceProgram, PretrainedMixin):
         # causal mask as the attention kernel's additive bias: [S, S] shared by every batch item and head
         mask = persist((S, S), torch.float32)
         mask.copy_(torch.triu(torch.full((S, S), -1e30), diagonal=1))
+        plan.consts = [mask]       # filled here, read by every run (paddlemix_amd/export.py ships its contents)
         plan.hidden = [persist((rows, D), _lib.elem_dtype()) for _ in range(n + 1)]   # encoder hidden_states tuple
         plan.last = persist((rows, D), _lib.elem_dtype())
         emit(lib.mi355x_sd_embed_tokens, (plan.ids.data_ptr(), rows, S, W["tok"].data_ptr(), W["pos"].data_ptr(), D,
@@ -404,6 +405,7 @@ class CLIPVisionModelWithProjection(DeviceProgram, PretrainedMixin):
         emb.reshape(B, S, D)[:, 0].copy_(W["cls_row"])      # class token + position 0: never overwritten
         pos_t = persist((B * N, D), _lib.elem_dtype())
         pos_t.reshape(B, N, D).copy_(W["pos_patches"])
+        plan.consts = [cols, emb, pos_t]   # initialised here (paddlemix_amd/export.py ships their contents)
         emit(lib.mi355x_sd_patchify, (plan.pixels.data_ptr(), B, C, side, side, p, cols.data_ptr(), Kp, stream), "misc")
         # patch rows of image b land at token rows b * S + 1 ..: C row remap (rows_per_batch N, batch stride S * D)
         emit(lib.mi355x_sd_linear_ex, (cols.data_ptr(), Kp, 0, 0, W["patch.w"].data_ptr(), None, emb.data_ptr() + 2 * D, D, N,

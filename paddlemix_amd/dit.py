@@ -220,6 +220,7 @@ class DiTTransformer2DModel(DeviceProgram, PretrainedMixin):
         pos = torch.from_numpy(sincos_pos_embed(D, hp, base, max(cfg["sample_size"] // 64, 1))).float()
         pos_t = persist((B * S, D), ET)
         pos_t.copy_(pos.reshape(1, S, D).expand(B, S, D).reshape(B * S, D))
+        plan.consts = [pos_t]      # filled here, read by every run (paddlemix_amd/export.py ships its contents)
         kp = cfg["in_channels"] * p * p
         patches = persist((B * S, kp), ET)
         emit(lib.mi355x_sd_patchify, (plan.sample.data_ptr(), B, cfg["in_channels"], H, Wd, p, patches.data_ptr(), kp, stream),

@@ -344,6 +344,7 @@ class SD3Transformer2DModel(DeviceProgram, PretrainedMixin):
         pos = self._pos_table[top:top + hp, left:left + wp].reshape(1, S1, D).expand(B, S1, D).reshape(B * S1, D)
         pos_t = persist((B * S1, D), _lib.elem_dtype())
         pos_t.copy_(pos)
+        plan.consts = [pos_t]      # filled here, read by every run (paddlemix_amd/export.py ships its contents)
 
         # ---- patch embedding + cropped sincos pos-emb (embeddings.py:209-247) ----
         kp = cfg["in_channels"] * p * p

@@ -173,6 +173,7 @@ class T5EncoderModel(DeviceProgram, PretrainedMixin):
         plan.ids = persist((rows,), torch.int32)
         bias = persist((H, S, S), torch.float32)
         bias.copy_(self._position_bias(S))
+        plan.consts = [bias]       # filled here, read by every run (paddlemix_amd/export.py ships its contents)
         xa, xb = persist((rows, D), _lib.elem_dtype()), persist((rows, D), _lib.elem_dtype())
         h = persist((rows, D), _lib.elem_dtype())
         qkv = persist((rows, 3 * inner), _lib.elem_dtype())

@@ -453,6 +453,7 @@ class AutoencoderKL(DeviceProgram, PretrainedMixin):
             else:
                 scale_t = persist((1,), torch.float32)
                 scale_t.fill_(float(in_scale))
+                plan.consts = [scale_t]   # filled here (paddlemix_amd/export.py ships its contents)
                 emit(lib.mi355x_sd_conv_in3x3, (plan.z.data_ptr(), scale_t.data_ptr(), wp("decoder.conv_in.w"),
                                                 wp("decoder.conv_in.b"), x.p, B, lc, h, w_, top, x.ld, stream), "misc")
             x = mid_block(x, "decoder", h, w_)

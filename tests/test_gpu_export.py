@@ -1,0 +1,79 @@
+"""-m gpu: an exported step replayed by the C runtime (mi355x_sd_program_*) produces the bits of the Python-planned model that
+exported it -- for every model family through the ctypes wrapper, and for three of them through a plain-C client
+(tests/c/program_test.c: gcc, hipMalloc, no torch, no Python), eager and as one hipGraph."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from paddlemix_amd.export import ExportedProgram, _named_tensors, export_program
+from tests import export_cases as EC
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _step(name, tmp_path, **kw):
+    model, run, outputs = EC.build(name, False, **kw)
+    run()
+    torch.cuda.synchronize()
+    plan = EC.last_plan(model)
+    named = dict(_named_tensors(plan))
+    is_out = lambda n: any(n == o or n.startswith(o + ".") for o in outputs)  # noqa: E731
+    want = {n: t.clone() for n, t in named.items() if is_out(n)}
+    inputs = {n: t.clone() for n, t in named.items() if not is_out(n)}
+    path = str(tmp_path / (name + ".mi3prg"))
+    summary = export_program(model, plan, path, outputs)
+    return model, run, path, summary, inputs, want
+
+
+@pytest.mark.parametrize("name", EC.NAMES)
+def test_exported_program_reproduces_the_planned_model(name, tmp_path):
+    model, run, path, summary, inputs, want = _step(name, tmp_path, use_graph=False)
+    assert want and all(torch.isfinite(t.float()).all() for t in want.values())
+    prog = ExportedProgram(path).bind()
+    got = prog.run(**inputs)
+    assert sorted(got) == sorted(want)
+    for k in want:
+        assert torch.equal(got[k], want[k]), (k, (got[k].float() - want[k].float()).abs().max().item())
+    # a second call on new inputs follows the model too (nothing of the first call is baked in)
+    first = next(k for k, v in inputs.items() if v.dtype.is_floating_point and v.numel() > 16)
+    inputs[first] = inputs[first] * 0.5
+    again = prog.run(**inputs)
+    assert any(not torch.equal(again[k], want[k]) for k in want)
+    assert all(torch.equal(again[k], prog.run(**inputs)[k]) for k in want)
+    print(f"{name}: {summary['launches']} launches, device bytes {summary['device_bytes']}, file {summary['file_bytes']} bytes")
+    prog.close()
+
+
+@pytest.mark.parametrize("name,use_graph", [("sd3_mini", 0), ("sd3_mini", 1), ("vae_decode", 1), ("unet_mini_xl", 1), ("t5_encoder", 0)])
+def test_plain_c_client_replays_the_exported_program(name, use_graph, tmp_path):
+    exe = str(tmp_path / "program_test")
+    subprocess.run(["gcc", "-std=c11", "-O2", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c", "program_test.c"), "-L" + os.path.join(ROOT, "paddlemix_amd"), "-lmi355x_sd",
+                    "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
+    model, run, path, summary, inputs, want = _step(name, tmp_path)
+    prog = ExportedProgram(path)
+    order = prog.info()
+    prog.close()
+    with open(tmp_path / "inputs.bin", "wb") as fh:
+        for io in order:
+            if not io["is_output"]:
+                fh.write(inputs[io["name"]].contiguous().view(torch.uint8).cpu().numpy().tobytes())
+    lib = "libmi355x_sd_f16.so" if os.environ.get("MI355X_SD_DTYPE") == "fp16" else "libmi355x_sd.so"
+    assert lib == "libmi355x_sd.so", "the C client links the bf16 build"
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "paddlemix_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([exe, path, str(tmp_path / "inputs.bin"), str(tmp_path / "outputs.bin"), str(use_graph), "2"], env=env,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    print(r.stdout.strip().splitlines()[-1])
+    raw = np.fromfile(tmp_path / "outputs.bin", dtype=np.uint8)
+    pos = 0
+    for io in order:
+        if io["is_output"]:
+            w = want[io["name"]].contiguous().view(torch.uint8).cpu().numpy().reshape(-1)
+            assert np.array_equal(raw[pos: pos + w.size], w), io["name"]
+            pos += w.size
+    assert pos == raw.size
