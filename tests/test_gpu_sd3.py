@@ -189,6 +189,22 @@ def _run(cfg, B, H, W, L, P, use_graph=True, **kw):
     return out, (x, enc, pooled)
 
 
+def test_mini_sd3_trained_adaln_continuous_bias_vs_oracle():
+    """the reference's AdaLayerNormContinuous norms own a trainable bias (normalization.py:182): folded into the modulation GEMM"""
+    from paddlemix_amd.sd3 import sd3_optional_param_shapes, synth_sd3_params
+    cfg = MINI_SD3
+    P = {k: (bfr(v) if v.dim() > 1 else v) for k, v in synth_sd3_params(cfg, 1234).items()}
+    g = torch.Generator().manual_seed(5)
+    P.update({k: 0.5 * torch.randn(s, generator=g) for k, s in sd3_optional_param_shapes(cfg).items()})
+    out, (x, enc, pooled) = _run(cfg, 2, 16, 16, 10, P)
+    ref = R.sd3_forward(P, cfg, x, enc, pooled, 501.0)
+    plain = R.sd3_forward({k: v for k, v in P.items() if not k.endswith("norm.bias")}, cfg, x, enc, pooled, 501.0)
+    assert _rel(plain, ref) > 0.1
+    r = _rel(out.cpu(), ref)
+    print(f"mini-sd3 with trained norm biases: rel-L2 vs oracle {r:.3e}")
+    assert r < 2e-2, r
+
+
 def test_mini_sd3_vs_oracle():
     from paddlemix_amd.sd3 import synth_sd3_params
     cfg = MINI_SD3
