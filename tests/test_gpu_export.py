@@ -39,8 +39,12 @@ def test_exported_program_reproduces_the_planned_model(name, tmp_path):
     for k in want:
         assert torch.equal(got[k], want[k]), (k, (got[k].float() - want[k].float()).abs().max().item())
     # a second call on new inputs follows the model too (nothing of the first call is baked in)
-    first = next(k for k, v in inputs.items() if v.dtype.is_floating_point and v.numel() > 16)
-    inputs[first] = inputs[first] * 0.5
+    first = next((k for k, v in inputs.items() if v.dtype.is_floating_point and v.numel() > 16), None)
+    if first is not None:
+        inputs[first] = inputs[first] * 0.5
+    else:                                       # token ids only: another prompt
+        first = next(k for k, v in inputs.items() if v.numel() > 16)
+        inputs[first] = torch.roll(inputs[first], 3)
     again = prog.run(**inputs)
     assert any(not torch.equal(again[k], want[k]) for k in want)
     assert all(torch.equal(again[k], prog.run(**inputs)[k]) for k in want)
