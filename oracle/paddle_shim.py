@@ -255,6 +255,12 @@ class Tensor:
     def mean(self, axis=None, keepdim=False):
         return mean(self, axis, keepdim)
 
+    def std(self, axis=None, unbiased=True, keepdim=False):
+        return Tensor(self.t.std(unbiased=unbiased) if axis is None else self.t.std(dim=axis, unbiased=unbiased, keepdim=keepdim))
+
+    def var(self, axis=None, unbiased=True, keepdim=False):
+        return Tensor(self.t.var(unbiased=unbiased) if axis is None else self.t.var(dim=axis, unbiased=unbiased, keepdim=keepdim))
+
     def max(self, axis=None, keepdim=False):
         return Tensor(self.t.max()) if axis is None else Tensor(self.t.amax(dim=axis, keepdim=keepdim))
 
@@ -871,6 +877,10 @@ class Linear(Layer):
 
     def forward(self, x):
         return F_linear(x, self.weight, self.bias)
+
+    # ppdiffusers/patches/paddle_patch.py:218-228 adds these two properties to paddle.nn.Linear
+    in_features = property(lambda self: self.weight.shape[0])
+    out_features = property(lambda self: self.weight.shape[1])
 
 
 def _pair(v):

@@ -97,7 +97,8 @@ def _stub_modules(shim):
                  scale_lora_layers=lambda *a, **k: None, unscale_lora_layers=lambda *a, **k: None,
                  is_ppxformers_available=lambda: False, recompute_use_reentrant=lambda: False, use_old_recompute=lambda: False,
                  is_paddle_available=lambda: True, is_torch_available=lambda: False, NEG_INF=-1e4,
-                 apply_forward_hook=lambda fn: fn)
+                 apply_forward_hook=lambda fn: fn, replace_example_docstring=lambda doc: (lambda fn: fn),
+                 is_pp_invisible_watermark_available=lambda: False)
     utils = mod(f"{PKG}.utils", **flags)
     utils.__path__ = []
     mod(f"{PKG}.utils.import_utils", is_ppxformers_available=lambda: False)
@@ -123,17 +124,22 @@ def _stub_modules(shim):
             object.__setattr__(self, "_internal_dict", d)
 
     mod(f"{PKG}.configuration_utils", ConfigMixin=ConfigMixin, register_to_config=_register_to_config, FrozenDict=FrozenConfig)
-    mod(f"{PKG}.loaders", UNet2DConditionLoadersMixin=_NoLoaders, FromOriginalVAEMixin=_NoLoaders, FromOriginalControlnetMixin=_NoLoaders,
-        PeftAdapterMixin=_NoLoaders, FromOriginalModelMixin=_NoLoaders)
+    mod(f"{PKG}.loaders", **{n: type(n, (_NoLoaders,), {}) for n in (
+        "UNet2DConditionLoadersMixin", "FromOriginalVAEMixin", "FromOriginalControlnetMixin", "PeftAdapterMixin", "FromOriginalModelMixin",
+        "FromSingleFileMixin", "IPAdapterMixin", "LoraLoaderMixin", "TextualInversionLoaderMixin", "StableDiffusionXLLoraLoaderMixin",
+        "SD3LoraLoaderMixin")})
     mod(f"{PKG}.loaders.single_file_model", FromOriginalModelMixin=_NoLoaders)
     # ppdiffusers.transformers: a bare package over the reference's directory (clip/modeling.py and t5/modeling.py load for real,
     # see _stub_text_encoders); lora.py only wants two class objects for isinstance checks
-    tr = mod(f"{PKG}.transformers", CLIPTextModel=type("CLIPTextModel", (), {}), CLIPTextModelWithProjection=type("CLIPTextModelWithProjection", (), {}))
+    tr = mod(f"{PKG}.transformers", **{n: type(n, (), {}) for n in (
+        "CLIPTextModel", "CLIPTextModelWithProjection", "CLIPImageProcessor", "CLIPTokenizer", "CLIPVisionModelWithProjection",
+        "T5EncoderModel", "T5Tokenizer")})
     tr.__path__ = [os.path.join(REF_ROOT, PKG, "transformers")]
     for sub in ("clip", "t5"):
         m = mod(f"{PKG}.transformers.{sub}")
         m.__path__ = [os.path.join(REF_ROOT, PKG, "transformers", sub)]
     _stub_text_encoders(P, mod)
+    _stub_pipelines(P, mod, ConfigMixin)
 
     class ModelMixin(P.nn.Layer):
         _supports_gradient_checkpointing = False
@@ -147,6 +153,65 @@ def _stub_modules(shim):
     mod(f"{PKG}.models.simplified_facebook_dit", SimplifiedFacebookDIT=type("SimplifiedFacebookDIT", (), {}))
     mod(f"{PKG}.models.simplified_sd3", SimplifiedSD3=type("SimplifiedSD3", (), {}))
     return mods
+
+
+def _stub_pipelines(P, mod, ConfigMixin):
+    """what pipelines/stable_diffusion*/pipeline_*.py import besides models and schedulers: the DiffusionPipeline base class (hub /
+    device placement / progress bar: dropped to attribute registration), the image post-processor (identity: the cases ask for
+    output_type="latent"), the safety checker (absent)."""
+    import contextlib
+
+    for sub in ("pipelines", "pipelines.stable_diffusion", "pipelines.stable_diffusion_xl", "pipelines.stable_diffusion_3"):
+        m = mod(f"{PKG}.{sub}")
+        m.__path__ = [os.path.join(REF_ROOT, PKG, *sub.split("."))]
+
+    class _Bar:
+        def update(self, *a, **k):
+            pass
+
+    class DiffusionPipeline(ConfigMixin):
+        def register_modules(self, **kw):
+            for k, v in kw.items():
+                setattr(self, k, v)
+
+        @contextlib.contextmanager
+        def progress_bar(self, iterable=None, total=None):
+            yield _Bar()
+
+        def maybe_free_model_hooks(self):
+            pass
+
+        def set_progress_bar_config(self, **kw):
+            pass
+
+        @property
+        def _execution_device(self):
+            return None
+
+    mod(f"{PKG}.pipelines.pipeline_utils", DiffusionPipeline=DiffusionPipeline)
+
+    class VaeImageProcessor:
+        def __init__(self, *a, **k):
+            pass
+
+        def postprocess(self, image, output_type="pil", do_denormalize=None):
+            assert output_type in ("latent", "pd"), "paddle_shim cases keep tensors"
+            return image
+
+    mod(f"{PKG}.image_processor", VaeImageProcessor=VaeImageProcessor, PipelineImageInput=object)
+    mod(f"{PKG}.pipelines.stable_diffusion.safety_checker", StableDiffusionSafetyChecker=type("StableDiffusionSafetyChecker", (), {}))
+
+
+def ref_pipeline(module: str, package: str = "pipelines.stable_diffusion"):
+    """import ppdiffusers.pipelines.<...>.<module> from the reference tree; `from ...models import UNet2DConditionModel` and
+    `from ...schedulers import KarrasDiffusionSchedulers` inside it resolve to the real classes"""
+    install()
+    models, scheds = sys.modules[f"{PKG}.models"], sys.modules[f"{PKG}.schedulers"]
+    models.UNet2DConditionModel = ref_module("unet_2d_condition").UNet2DConditionModel
+    models.AutoencoderKL = ref_module("autoencoder_kl").AutoencoderKL
+    scheds.KarrasDiffusionSchedulers = ref_module("scheduling_utils", "schedulers").KarrasDiffusionSchedulers
+    scheds.FlowMatchEulerDiscreteScheduler = ref_module("scheduling_flow_match_euler_discrete", "schedulers").FlowMatchEulerDiscreteScheduler
+    return importlib.import_module(f"{PKG}.{package}.{module}")
 
 
 def _stub_text_encoders(P, mod):

@@ -388,6 +388,120 @@ def _scheduler_case(module, cls, oracle_cls, kw, steps, scale=True, noisy=False)
     return run
 
 
+# ------------------------------------------------------------------------------------------------------------------ pipelines (the caller)
+class _FakeVAE:     # with output_type="latent" the pipelines read only these two config entries
+    def __init__(self, rr, **extra):
+        self.config = rr.FrozenConfig(block_out_channels=(1, 1, 1, 1), **extra)
+
+
+def _pipe_sd_case(ref):
+    """StableDiffusionPipeline.__call__ (pipelines/stable_diffusion/pipeline_stable_diffusion.py:647-932) given prompt embeddings and
+    start latents: CFG with [negative, positive] batching, guidance_rescale, DDIM. The oracle side is the loop of tests/test_pipeline.py."""
+    from oracle import schedulers_ref as S, unet_ref as U
+    cfg = C.TINY
+    P = U.synth_unet_params(cfg, seed=1)
+    g = torch.Generator().manual_seed(0)
+    pe, ne, lat0 = torch.randn(1, 7, 64, generator=g), torch.randn(1, 7, 64, generator=g), torch.randn(1, 4, 8, 8, generator=g)
+    steps, gs, gr = 6, 7.5, 0.7
+    kw = dict(_SD, clip_sample=False, set_alpha_to_one=False, steps_offset=1)
+    sch = S.DDIMRef(**kw)
+    sch.set_timesteps(steps)
+    x = lat0.numpy() * sch.init_noise_sigma
+    with torch.no_grad():
+        for t in sch.timesteps:
+            eps = U.unet_forward(P, cfg, torch.from_numpy(np.concatenate([x, x])), int(t), torch.cat([ne, pe]))
+            eu, et = eps[:1], eps[1:]
+            e = eu + gs * (et - eu)
+            e = gr * (e * (et.std(dim=(1, 2, 3), keepdim=True) / e.std(dim=(1, 2, 3), keepdim=True))) + (1 - gr) * e   # rescale_noise_cfg (:69-80)
+            x = sch.step(e.numpy(), t, x)
+    out = {"oracle": {"latents": torch.from_numpy(x)}, "reference": None}
+    if ref:
+        rr = _rr()
+        pm = rr.ref_pipeline("pipeline_stable_diffusion")
+        pipe = pm.StableDiffusionPipeline(vae=_FakeVAE(rr, scaling_factor=0.18215), text_encoder=None, tokenizer=None, unet=rr.build_unet(cfg, P),
+                                          scheduler=rr.ref_module("scheduling_ddim", "schedulers").DDIMScheduler(**kw), safety_checker=None,
+                                          feature_extractor=None, requires_safety_checker=False)
+        with torch.no_grad():
+            r = pipe(prompt_embeds=rr.to_shim(pe), negative_prompt_embeds=rr.to_shim(ne), latents=rr.to_shim(lat0.clone()), num_inference_steps=steps,
+                     guidance_scale=gs, guidance_rescale=gr, output_type="latent", height=64, width=64, return_dict=False)[0]
+        out["reference"] = {"latents": rr.from_shim(r)}
+    return out
+
+
+def _pipe_sdxl_case(ref):
+    """StableDiffusionXLPipeline.__call__ (pipelines/stable_diffusion_xl/pipeline_stable_diffusion_xl.py): pooled embeddings +
+    micro-conditioning (_get_add_time_ids: original size, crop, target size), CFG, Euler with `leading` spacing."""
+    from oracle import schedulers_ref as S, unet_ref as U
+    cfg = C.MINI_XL
+    P = U.synth_unet_params(cfg, seed=1)
+    g = torch.Generator().manual_seed(0)
+    cd = cfg["cross_attention_dim"]
+    pe, ne = torch.randn(1, 9, cd, generator=g), torch.randn(1, 9, cd, generator=g)
+    pp, npp, lat0 = torch.randn(1, 64, generator=g), torch.randn(1, 64, generator=g), torch.randn(1, 4, 8, 8, generator=g)
+    steps, gs = 5, 5.0
+    kw = dict(_SD, steps_offset=1, timestep_spacing="leading")
+    sch = S.EulerRef(**kw)
+    sch.set_timesteps(steps)
+    x = lat0.numpy() * sch.init_noise_sigma
+    added = dict(text_embeds=torch.cat([npp, pp]), time_ids=torch.tensor([[96.0, 80.0, 3.0, 5.0, 64.0, 64.0]]).repeat(2, 1))
+    with torch.no_grad():
+        for t in sch.timesteps:
+            xin = sch.scale_model_input(np.concatenate([x, x]), t)
+            eps = U.unet_forward(P, cfg, torch.from_numpy(np.asarray(xin, dtype=np.float32)), float(t), torch.cat([ne, pe]), added_cond_kwargs=added).numpy()
+            x = sch.step(eps[:1] + gs * (eps[1:] - eps[:1]), t, x)
+    out = {"oracle": {"latents": torch.from_numpy(np.asarray(x, dtype=np.float32))}, "reference": None}
+    if ref:
+        rr = _rr()
+        pm = rr.ref_pipeline("pipeline_stable_diffusion_xl", "pipelines.stable_diffusion_xl")
+        te2 = type("TextEncoder2", (), {"config": rr.FrozenConfig(projection_dim=64), "dtype": torch.float32})()
+        pipe = pm.StableDiffusionXLPipeline(vae=_FakeVAE(rr, scaling_factor=0.13025, force_upcast=False), text_encoder=None, text_encoder_2=te2,
+                                            tokenizer=None, tokenizer_2=None, unet=rr.build_unet(cfg, P),
+                                            scheduler=rr.ref_module("scheduling_euler_discrete", "schedulers").EulerDiscreteScheduler(**kw))
+        with torch.no_grad():
+            r = pipe(prompt_embeds=rr.to_shim(pe), negative_prompt_embeds=rr.to_shim(ne), pooled_prompt_embeds=rr.to_shim(pp),
+                     negative_pooled_prompt_embeds=rr.to_shim(npp), latents=rr.to_shim(lat0.clone()), num_inference_steps=steps, guidance_scale=gs,
+                     output_type="latent", height=64, width=64, original_size=(96, 80), crops_coords_top_left=(3, 5), target_size=(64, 64),
+                     return_dict=False)[0]
+        out["reference"] = {"latents": rr.from_shim(r)}
+    return out
+
+
+def _pipe_sd3_case(ref):
+    """StableDiffusion3Pipeline.__call__ (pipelines/stable_diffusion_3/pipeline_stable_diffusion_3.py:795-860): CFG on the MMDiT's
+    velocity, per-sample timestep vector, flow-matching Euler (shift 3)."""
+    from oracle import schedulers_ref as S, sd3_ref as R3
+    cfg = C.MINI_SD3
+    P = R3.synth_sd3_params(cfg, seed=3)
+    g = torch.Generator().manual_seed(0)
+    pe, ne = torch.randn(1, 9, 64, generator=g), torch.randn(1, 9, 64, generator=g)
+    pp, npp, lat0 = torch.randn(1, 64, generator=g), torch.randn(1, 64, generator=g), torch.randn(1, 4, 16, 16, generator=g)
+    steps, gs = 6, 7.0
+    sch = S.FlowMatchEulerRef(shift=3.0)
+    sch.set_timesteps(steps)
+    x = lat0.numpy()
+    with torch.no_grad():
+        for t in sch.timesteps:
+            v = R3.sd3_forward(P, cfg, torch.from_numpy(np.concatenate([x, x])), torch.cat([ne, pe]), torch.cat([npp, pp]),
+                               torch.tensor([float(t)] * 2)).numpy()
+            x = sch.step(v[:1] + gs * (v[1:] - v[:1]), t, x)
+    out = {"oracle": {"latents": torch.from_numpy(x)}, "reference": None}
+    if ref:
+        rr = _rr()
+        pm = rr.ref_pipeline("pipeline_stable_diffusion_3", "pipelines.stable_diffusion_3")
+        net = rr.ref_module("transformer_sd3").SD3Transformer2DModel(**cfg)
+        net.eval()
+        rr.load_params(net, P, computed=SD3_COMPUTED + SD3_OPTIONAL)
+        sched = rr.ref_module("scheduling_flow_match_euler_discrete", "schedulers").FlowMatchEulerDiscreteScheduler(shift=3.0)
+        pipe = pm.StableDiffusion3Pipeline(transformer=net, scheduler=sched, vae=_FakeVAE(rr, scaling_factor=1.5305, shift_factor=0.0609), text_encoder=None,
+                                           tokenizer=None, text_encoder_2=None, tokenizer_2=None, text_encoder_3=None, tokenizer_3=None)
+        with torch.no_grad():
+            r = pipe(prompt_embeds=rr.to_shim(pe), negative_prompt_embeds=rr.to_shim(ne), pooled_prompt_embeds=rr.to_shim(pp),
+                     negative_pooled_prompt_embeds=rr.to_shim(npp), latents=rr.to_shim(lat0.clone()), num_inference_steps=steps, guidance_scale=gs,
+                     output_type="latent", height=128, width=128, return_dict=False)[0]
+        out["reference"] = {"latents": rr.from_shim(r)}
+    return out
+
+
 def _labels(kind):
     return {
         "index": lambda g: torch.tensor([3, 8]),
@@ -431,6 +545,10 @@ CASES = {
     "clip_text_gelu": _clip_text_case("gelu"),
     "clip_vision": _clip_vision_case,
     "t5_encoder": _t5_case,
+    # the callers: pipelines/*/pipeline_*.py __call__ from prompt embeddings + start latents to final latents
+    "pipe_sd_ddim_cfg_rescale": _pipe_sd_case,
+    "pipe_sdxl_euler_cfg_microcond": _pipe_sdxl_case,
+    "pipe_sd3_flow_match_cfg": _pipe_sd3_case,
     # schedulers/*.py: whole sampling loops
     "sched_ddim_sd15": _scheduler_case("scheduling_ddim", "DDIMScheduler", "DDIMRef", dict(_SD, clip_sample=False, set_alpha_to_one=False, steps_offset=1), 20),
     "sched_ddim_trailing_clip": _scheduler_case("scheduling_ddim", "DDIMScheduler", "DDIMRef", dict(_SD, clip_sample=True, timestep_spacing="trailing"), 10),

@@ -38,13 +38,58 @@ def test_oracle_reproduces_the_committed_reference_outputs(name):
 
 @pytest.mark.skipif(not reference_runner.available(), reason="/root/reference exists only in the build container")
 @pytest.mark.parametrize("name", ["unet_tiny", "unet_mini_xl", "unet_tiny_masks", "controlnet_bgr_guess_mode", "dit_mini", "sd3_mini_trained_norm_bias",
-                                  "vae_mini", "sched_euler_sdxl", "sched_dpmpp_2m_karras_heun", "sched_lcm"])
+                                  "vae_mini", "sched_euler_sdxl", "sched_dpmpp_2m_karras_heun", "sched_lcm", "clip_text_gelu", "t5_encoder",
+                                  "unet_ip_adapter_scale_0p6", "lora_fuse", "pipe_sdxl_euler_cfg_microcond", "pipe_sd3_flow_match_cfg"])
 def test_live_reference_run_agrees(name):
     out = RC.CASES[name](True)
     gold = np.load(RC.golden_path(name))
     for k, r in out["reference"].items():
         assert _rel(out["oracle"][k], r) < RC.REL_TOL, (k, _rel(out["oracle"][k], r))
         assert _rel(torch.from_numpy(gold[k]), r) < 1e-6, k       # the committed vectors are this very computation
+
+
+def test_product_pipelines_follow_the_reference_pipelines():
+    """the PRODUCT's host-side denoising loops (paddlemix_amd/pipeline.py + schedulers.py; the UNet / MMDiT program interpreted on host
+    memory with the device's rounding points) against the committed outputs of the reference's own pipeline __call__: same prompt
+    embeddings, start latents, steps, guidance. Tolerance = 16-bit rounding of the chained model evaluations under guidance."""
+    from paddlemix_amd.pipeline import StableDiffusion3Denoiser, StableDiffusionDenoiser
+    from paddlemix_amd.schedulers import DDIMScheduler, EulerDiscreteScheduler, FlowMatchEulerDiscreteScheduler
+    from paddlemix_amd.sd3 import SD3Transformer2DModel, synth_sd3_params
+    from paddlemix_amd.unet import UNet2DConditionModel, synth_unet_params
+    from tests.abi_emulator import Emulator
+    from tests.configs import MINI_SD3, MINI_XL, TINY
+
+    def rel(a, name):
+        g = torch.from_numpy(np.load(RC.golden_path(name))["latents"])
+        return float((a - g).norm() / g.norm())
+
+    SD = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", steps_offset=1)
+    g = torch.Generator().manual_seed(0)
+    pe, ne, lat0 = torch.randn(1, 7, 64, generator=g), torch.randn(1, 7, 64, generator=g), torch.randn(1, 4, 8, 8, generator=g)
+    pipe = StableDiffusionDenoiser(UNet2DConditionModel(TINY, synth_unet_params(TINY, seed=1), _test_backend=Emulator()),
+                                   DDIMScheduler(clip_sample=False, set_alpha_to_one=False, **SD))
+    out = pipe(pe, ne, num_inference_steps=6, guidance_scale=7.5, guidance_rescale=0.7, latents=lat0.clone())
+    assert rel(out, "pipe_sd_ddim_cfg_rescale") < 3e-2, rel(out, "pipe_sd_ddim_cfg_rescale")
+
+    g = torch.Generator().manual_seed(0)
+    cd = MINI_XL["cross_attention_dim"]
+    pe, ne = torch.randn(1, 9, cd, generator=g), torch.randn(1, 9, cd, generator=g)
+    pp, npp, lat0 = torch.randn(1, 64, generator=g), torch.randn(1, 64, generator=g), torch.randn(1, 4, 8, 8, generator=g)
+    pipe = StableDiffusionDenoiser(UNet2DConditionModel(MINI_XL, synth_unet_params(MINI_XL, seed=1), _test_backend=Emulator()),
+                                   EulerDiscreteScheduler(timestep_spacing="leading", **SD))
+    tids = pipe.get_add_time_ids((96, 80), (3, 5), (64, 64), 64, "cpu")          # the reference's _get_add_time_ids
+    assert tids.tolist() == [[96.0, 80.0, 3.0, 5.0, 64.0, 64.0]]
+    out = pipe(pe, ne, num_inference_steps=5, guidance_scale=5.0, latents=lat0.clone(), added_cond_kwargs=dict(text_embeds=pp, time_ids=tids),
+               negative_added_cond_kwargs=dict(text_embeds=npp, time_ids=tids))
+    assert rel(out, "pipe_sdxl_euler_cfg_microcond") < 3e-2, rel(out, "pipe_sdxl_euler_cfg_microcond")
+
+    g = torch.Generator().manual_seed(0)
+    pe, ne = torch.randn(1, 9, 64, generator=g), torch.randn(1, 9, 64, generator=g)
+    pp, npp, lat0 = torch.randn(1, 64, generator=g), torch.randn(1, 64, generator=g), torch.randn(1, 4, 16, 16, generator=g)
+    pipe3 = StableDiffusion3Denoiser(SD3Transformer2DModel(MINI_SD3, synth_sd3_params(MINI_SD3, seed=3), _test_backend=Emulator()),
+                                     FlowMatchEulerDiscreteScheduler(shift=3.0))
+    out = pipe3(pe, pp, ne, npp, num_inference_steps=6, guidance_scale=7.0, latents=lat0.clone())
+    assert rel(out, "pipe_sd3_flow_match_cfg") < 3e-2, rel(out, "pipe_sd3_flow_match_cfg")
 
 
 def test_the_shim_is_test_infrastructure_only():
