@@ -98,7 +98,7 @@ def _stub_modules(shim):
                  is_ppxformers_available=lambda: False, recompute_use_reentrant=lambda: False, use_old_recompute=lambda: False,
                  is_paddle_available=lambda: True, is_torch_available=lambda: False, NEG_INF=-1e4,
                  apply_forward_hook=lambda fn: fn, replace_example_docstring=lambda doc: (lambda fn: fn),
-                 is_pp_invisible_watermark_available=lambda: False)
+                 is_pp_invisible_watermark_available=lambda: False, PIL_INTERPOLATION={}, CONFIG_NAME="config.json")
     utils = mod(f"{PKG}.utils", **flags)
     utils.__path__ = []
     mod(f"{PKG}.utils.import_utils", is_ppxformers_available=lambda: False)
@@ -157,11 +157,11 @@ def _stub_modules(shim):
 
 def _stub_pipelines(P, mod, ConfigMixin):
     """what pipelines/stable_diffusion*/pipeline_*.py import besides models and schedulers: the DiffusionPipeline base class (hub /
-    device placement / progress bar: dropped to attribute registration), the image post-processor (identity: the cases ask for
-    output_type="latent"), the safety checker (absent)."""
+    device placement / progress bar: dropped to attribute registration), the safety checker (absent). image_processor.py
+    (VaeImageProcessor: tensor pre-processing, mask binarisation, resize) is the reference's real file."""
     import contextlib
 
-    for sub in ("pipelines", "pipelines.stable_diffusion", "pipelines.stable_diffusion_xl", "pipelines.stable_diffusion_3"):
+    for sub in ("pipelines", "pipelines.stable_diffusion", "pipelines.stable_diffusion_xl", "pipelines.stable_diffusion_3", "pipelines.controlnet"):
         m = mod(f"{PKG}.{sub}")
         m.__path__ = [os.path.join(REF_ROOT, PKG, *sub.split("."))]
 
@@ -190,15 +190,6 @@ def _stub_pipelines(P, mod, ConfigMixin):
 
     mod(f"{PKG}.pipelines.pipeline_utils", DiffusionPipeline=DiffusionPipeline)
 
-    class VaeImageProcessor:
-        def __init__(self, *a, **k):
-            pass
-
-        def postprocess(self, image, output_type="pil", do_denormalize=None):
-            assert output_type in ("latent", "pd"), "paddle_shim cases keep tensors"
-            return image
-
-    mod(f"{PKG}.image_processor", VaeImageProcessor=VaeImageProcessor, PipelineImageInput=object)
     mod(f"{PKG}.pipelines.stable_diffusion.safety_checker", StableDiffusionSafetyChecker=type("StableDiffusionSafetyChecker", (), {}))
 
 
@@ -211,6 +202,12 @@ def ref_pipeline(module: str, package: str = "pipelines.stable_diffusion"):
     models.AutoencoderKL = ref_module("autoencoder_kl").AutoencoderKL
     scheds.KarrasDiffusionSchedulers = ref_module("scheduling_utils", "schedulers").KarrasDiffusionSchedulers
     scheds.FlowMatchEulerDiscreteScheduler = ref_module("scheduling_flow_match_euler_discrete", "schedulers").FlowMatchEulerDiscreteScheduler
+    models.ControlNetModel = ref_module("controlnet").ControlNetModel
+    models.AsymmetricAutoencoderKL = type("AsymmetricAutoencoderKL", (), {})      # isinstance checks of the inpaint pipeline only
+    scheds.LCMScheduler = ref_module("scheduling_lcm", "schedulers").LCMScheduler
+    sdpkg = sys.modules[f"{PKG}.pipelines.stable_diffusion"]
+    sdpkg.StableDiffusionSafetyChecker = sys.modules[f"{PKG}.pipelines.stable_diffusion.safety_checker"].StableDiffusionSafetyChecker
+    sdpkg.StableDiffusionPipelineOutput = importlib.import_module(f"{PKG}.pipelines.stable_diffusion.pipeline_output").StableDiffusionPipelineOutput
     return importlib.import_module(f"{PKG}.{package}.{module}")
 
 

@@ -502,6 +502,210 @@ def _pipe_sd3_case(ref):
     return out
 
 
+def _ref_vae(rr, Pv):
+    from oracle import vae_ref as V
+    full = V.normalize_config(C.MINI_VAE)
+    n = len(full["block_out_channels"])
+    full.update(down_block_types=("DownEncoderBlock2D",) * n, up_block_types=("UpDecoderBlock2D",) * n)
+    full.pop("use_post_quant_conv", None)
+    full.pop("use_quant_conv", None)
+    vae = rr.ref_module("autoencoder_kl").AutoencoderKL(**full)
+    vae.eval()
+    return rr.load_params(vae, Pv)
+
+
+def _sd_parts(rr, pipeline_module, cls, cfg, P, sched_module, sched_cls, sched_kw, vae=None, **extra):
+    pm = rr.ref_pipeline(pipeline_module, extra.pop("package", "pipelines.stable_diffusion"))
+    sched = getattr(rr.ref_module(sched_module, "schedulers"), sched_cls)(**sched_kw)
+    return getattr(pm, cls)(vae=vae or _FakeVAE(rr, scaling_factor=0.18215), text_encoder=None, tokenizer=None, unet=rr.build_unet(cfg, P),
+                            scheduler=sched, safety_checker=None, feature_extractor=None, requires_safety_checker=False, **extra)
+
+
+def _vae_params(seed):
+    from oracle import vae_ref as V
+    P = V.synth_decoder_params(C.MINI_VAE, seed=seed)
+    P.update(_synth(V.encoder_param_shapes(C.MINI_VAE), seed + 1))
+    return P
+
+
+def _pipe_img2img_case(kind):
+    """StableDiffusionImg2ImgPipeline.__call__ (pipeline_stable_diffusion_img2img.py): encode -> posterior sample * scaling_factor
+    -> add_noise at the first kept timestep -> the last int(steps * strength) steps. Also fixes the ORDER of the random draws
+    (posterior noise [1,4,h,w], then forward-process noise [B,4,h,w]) that paddlemix_amd/pipeline.py assumes."""
+    def run(ref):
+        from oracle import schedulers_ref as S, unet_ref as U, vae_ref as V
+        cfg = C.TINY
+        P, Pv = U.synth_unet_params(cfg, seed=1), _vae_params(6)
+        if kind == "ddim":
+            kw, ocls, smod, scls = dict(_SD, clip_sample=False, set_alpha_to_one=False, steps_offset=1), S.DDIMRef, "scheduling_ddim", "DDIMScheduler"
+        else:
+            kw, ocls, smod, scls = dict(_SD, steps_offset=1, timestep_spacing="leading"), S.EulerRef, "scheduling_euler_discrete", "EulerDiscreteScheduler"
+        g = torch.Generator().manual_seed(3)
+        pe, ne = torch.randn(2, 7, 64, generator=g), torch.randn(2, 7, 64, generator=g)
+        image = torch.rand(1, 3, 32, 32, generator=g) * 2 - 1
+        steps, strength, gs, sf = 10, 0.6, 5.0, C.MINI_VAE["scaling_factor"]
+        gg = torch.Generator().manual_seed(11)
+        n1, n2 = torch.randn(1, 4, 8, 8, generator=gg), torch.randn(2, 4, 8, 8, generator=gg)
+        with torch.no_grad():
+            z = V.encode(Pv, C.MINI_VAE, image, n1)[2]
+            sch = ocls(**kw)
+            sch.set_timesteps(steps)
+            kept = sch.timesteps[steps - int(steps * strength):]
+            x = sch.add_noise(torch.cat([z * sf] * 2).numpy(), n2.numpy(), kept[0] if ocls is S.DDIMRef else np.repeat(kept[:1], 2))
+            for t in kept:
+                xin = sch.scale_model_input(np.concatenate([x, x]), t)
+                eps = U.unet_forward(P, cfg, torch.from_numpy(np.asarray(xin, dtype=np.float32)), float(t), torch.cat([ne, pe])).numpy()
+                x = sch.step(eps[:2] + gs * (eps[2:] - eps[:2]), t, x)
+        out = {"oracle": {"latents": torch.from_numpy(np.asarray(x, dtype=np.float32))}, "reference": None}
+        if ref:
+            rr = _rr()
+            pipe = _sd_parts(rr, "pipeline_stable_diffusion_img2img", "StableDiffusionImg2ImgPipeline", cfg, P, smod, scls, kw, vae=_ref_vae(rr, Pv))
+            gg = torch.Generator().manual_seed(11)
+            shapes = []
+            with torch.no_grad():
+                r = pipe(prompt_embeds=rr.to_shim(pe), negative_prompt_embeds=rr.to_shim(ne), image=rr.to_shim(image), strength=strength,
+                         num_inference_steps=steps, guidance_scale=gs, output_type="latent", return_dict=False,
+                         generator=lambda shape: (shapes.append(list(shape)), torch.randn(shape, generator=gg))[1])[0]
+            assert shapes[:2] == [[1, 4, 8, 8], [2, 4, 8, 8]], shapes
+            out["reference"] = {"latents": rr.from_shim(r)}
+        return out
+    return run
+
+
+def _pipe_inpaint_case(nine):
+    """StableDiffusionInpaintPipeline.__call__ (pipeline_stable_diffusion_inpaint.py): a 4-channel UNet has the kept region re-imposed
+    after every step from the re-noised image latents; a 9-channel UNet is fed [latents | mask | masked-image latents]. Mask
+    binarisation / resize by the reference's real VaeImageProcessor; draw order image posterior, noise, masked-image posterior."""
+    def run(ref):
+        import torch.nn.functional as F
+        from oracle import schedulers_ref as S, unet_ref as U, vae_ref as V
+        Pv, sf = _vae_params(6), C.MINI_VAE["scaling_factor"]
+        g = torch.Generator().manual_seed(8)
+        pe, ne = torch.randn(1, 7, 64, generator=g), torch.randn(1, 7, 64, generator=g)
+        image = torch.rand(1, 3, 32, 32, generator=g) * 2 - 1
+        mask_px = torch.zeros(1, 1, 32, 32)
+        mask_px[:, :, 8:24, 12:32] = 0.9
+        mk = F.interpolate((mask_px >= 0.5).float(), size=(8, 8)).numpy()
+        enc = lambda img, n: V.encode(Pv, C.MINI_VAE, img, n)[2] * sf  # noqa: E731
+        if not nine:
+            cfg, seed, steps, gs, strength = C.TINY, 31, 5, 4.0, 1.0
+            P = U.synth_unet_params(cfg, seed=1)
+            kw, smod, scls = dict(_SD, clip_sample=False, set_alpha_to_one=False, steps_offset=1), "scheduling_ddim", "DDIMScheduler"
+        else:
+            cfg, seed, steps, gs, strength = dict(C.TINY, in_channels=9), 32, 10, 1.0, 0.6
+            P = U.synth_unet_params(cfg, seed=77)
+            kw, smod, scls = dict(_SD, steps_offset=1, timestep_spacing="leading"), "scheduling_euler_discrete", "EulerDiscreteScheduler"
+        gg = torch.Generator().manual_seed(seed)
+        n_img, noise, n_msk = (torch.randn(1, 4, 8, 8, generator=gg) for _ in range(3))
+        with torch.no_grad():
+            img_lat = enc(image, n_img).numpy()
+            if not nine:
+                sch = S.DDIMRef(**kw)
+                sch.set_timesteps(steps)
+                x = noise.numpy() * sch.init_noise_sigma
+                for i, t in enumerate(sch.timesteps):
+                    eps = U.unet_forward(P, cfg, torch.from_numpy(np.concatenate([x, x]).astype(np.float32)), int(t), torch.cat([ne, pe])).numpy()
+                    x = sch.step(eps[:1] + gs * (eps[1:] - eps[:1]), t, x)
+                    proper = img_lat if i == steps - 1 else sch.add_noise(img_lat, noise.numpy(), int(sch.timesteps[i + 1]))
+                    x = (1 - mk) * proper + mk * x
+            else:
+                mil = enc(image * (mask_px < 0.5).float(), n_msk).numpy()
+                sch = S.EulerRef(**kw)
+                sch.set_timesteps(steps)
+                kept = sch.timesteps[steps - int(steps * strength):]
+                x = sch.add_noise(img_lat, noise.numpy(), kept[:1])
+                for t in kept:
+                    xin = np.concatenate([sch.scale_model_input(x, t), mk, mil], axis=1).astype(np.float32)
+                    x = sch.step(U.unet_forward(P, cfg, torch.from_numpy(xin), float(t), pe).numpy(), t, x)
+        out = {"oracle": {"latents": torch.from_numpy(np.asarray(x, dtype=np.float32))}, "reference": None}
+        if ref:
+            rr = _rr()
+            pipe = _sd_parts(rr, "pipeline_stable_diffusion_inpaint", "StableDiffusionInpaintPipeline", cfg, P, smod, scls, kw, vae=_ref_vae(rr, Pv))
+            gg = torch.Generator().manual_seed(seed)
+            with torch.no_grad():
+                r = pipe(prompt_embeds=rr.to_shim(pe), negative_prompt_embeds=rr.to_shim(ne) if gs > 1 else None, image=rr.to_shim(image),
+                         mask_image=rr.to_shim(mask_px), strength=strength, num_inference_steps=steps, guidance_scale=gs, output_type="latent",
+                         height=32, width=32, return_dict=False, generator=lambda shape: torch.randn(shape, generator=gg))[0]
+            out["reference"] = {"latents": rr.from_shim(r)}
+        return out
+    return run
+
+
+def _pipe_controlnet_case(guess, scale):
+    """StableDiffusionControlNetPipeline.__call__ (pipelines/controlnet/pipeline_controlnet.py): every step the ControlNet sees the
+    UNet's scaled input batch; guess mode under CFG runs it on the conditional half only, zeros for the unconditional half."""
+    def run(ref):
+        from oracle import schedulers_ref as S, unet_ref as U
+        cfg = C.TINY
+        P, Pc = U.synth_unet_params(cfg, seed=1), _synth(U.controlnet_param_shapes(cfg), 8)
+        g = torch.Generator().manual_seed(0)
+        pe, ne = torch.randn(1, 7, 64, generator=g), torch.randn(1, 7, 64, generator=g)
+        lat0, hint = torch.randn(1, 4, 8, 8, generator=g), torch.rand(1, 3, 64, 64, generator=g)
+        kw = dict(_SD, clip_sample=False, set_alpha_to_one=False, steps_offset=1)
+        steps, gs = 3, 5.0
+        sch = S.DDIMRef(**kw)
+        sch.set_timesteps(steps)
+        x, emb = lat0.numpy() * sch.init_noise_sigma, torch.cat([ne, pe])
+        with torch.no_grad():
+            for t in sch.timesteps:
+                xin = torch.from_numpy(np.concatenate([x, x]).astype(np.float32))
+                if guess:
+                    d, m = U.controlnet_forward(Pc, cfg, xin[1:], int(t), pe, hint, scale, True)
+                    d, m = tuple(torch.cat([torch.zeros_like(v), v]) for v in d), torch.cat([torch.zeros_like(m), m])
+                else:
+                    d, m = U.controlnet_forward(Pc, cfg, xin, int(t), emb, torch.cat([hint, hint]), scale, False)
+                eps = U.unet_forward(P, cfg, xin, int(t), emb, down_block_additional_residuals=d, mid_block_additional_residual=m).numpy()
+                x = sch.step(eps[:1] + gs * (eps[1:] - eps[:1]), t, x)
+        out = {"oracle": {"latents": torch.from_numpy(np.asarray(x, dtype=np.float32))}, "reference": None}
+        if ref:
+            rr = _rr()
+            rr.ref_pipeline("pipeline_stable_diffusion")
+            cn = rr.ref_module("controlnet").ControlNetModel(**{k: v for k, v in cfg.items() if k not in ("up_block_types", "sample_size")})
+            cn.eval()
+            rr.load_params(cn, Pc)
+            pipe = _sd_parts(rr, "pipeline_controlnet", "StableDiffusionControlNetPipeline", cfg, P, "scheduling_ddim", "DDIMScheduler", kw,
+                             package="pipelines.controlnet", controlnet=cn)
+            with torch.no_grad():
+                r = pipe(prompt_embeds=rr.to_shim(pe), negative_prompt_embeds=rr.to_shim(ne), image=rr.to_shim(hint), latents=rr.to_shim(lat0.clone()),
+                         num_inference_steps=steps, guidance_scale=gs, controlnet_conditioning_scale=scale, guess_mode=guess, output_type="latent",
+                         height=64, width=64, return_dict=False)[0]
+            out["reference"] = {"latents": rr.from_shim(r)}
+        return out
+    return run
+
+
+def _pipe_lcm_case(ref):
+    """Latent-consistency sampling through StableDiffusionPipeline.__call__: a guidance-distilled UNet (time_cond_proj_dim) takes
+    get_guidance_scale_embedding(guidance_scale - 1) as timestep_cond instead of a doubled batch (pipeline_stable_diffusion.py:
+    588-616, 846-852); LCMScheduler re-noises between its steps with the pipeline's generator."""
+    from oracle import schedulers_ref as S, unet_ref as U
+    cfg = dict(C.TINY, time_cond_proj_dim=32)
+    P = U.synth_unet_params(cfg, seed=1)
+    g = torch.Generator().manual_seed(0)
+    pe, lat0 = torch.randn(2, 7, 64, generator=g), torch.randn(2, 4, 8, 8, generator=g)
+    steps, gs = 4, 8.0
+    f = np.exp(-np.log(10000.0) * np.arange(16) / 15)
+    tc = torch.from_numpy(np.tile(np.concatenate([np.sin(7000.0 * f), np.cos(7000.0 * f)]), (2, 1)).astype(np.float32))
+    sch = S.LCMRef(**_SD)
+    sch.set_timesteps(steps)
+    gg = torch.Generator().manual_seed(21)
+    x = lat0.numpy().astype(np.float64)
+    with torch.no_grad():
+        for i, t in enumerate(sch.timesteps):
+            eps = U.unet_forward(P, cfg, torch.from_numpy(x.astype(np.float32)), int(t), pe, timestep_cond=tc).numpy()
+            x, _ = sch.step(eps, t, x, None if i == steps - 1 else torch.randn(lat0.shape, generator=gg).numpy())
+    out = {"oracle": {"latents": torch.from_numpy(x.astype(np.float32))}, "reference": None}
+    if ref:
+        rr = _rr()
+        pipe = _sd_parts(rr, "pipeline_stable_diffusion", "StableDiffusionPipeline", cfg, P, "scheduling_lcm", "LCMScheduler", dict(_SD))
+        gg = torch.Generator().manual_seed(21)
+        with torch.no_grad():
+            r = pipe(prompt_embeds=rr.to_shim(pe), latents=rr.to_shim(lat0.clone()), num_inference_steps=steps, guidance_scale=gs, output_type="latent",
+                     height=64, width=64, return_dict=False, generator=lambda shape: torch.randn(shape, generator=gg))[0]
+        out["reference"] = {"latents": rr.from_shim(r)}
+    return out
+
+
 def _labels(kind):
     return {
         "index": lambda g: torch.tensor([3, 8]),
@@ -549,6 +753,13 @@ CASES = {
     "pipe_sd_ddim_cfg_rescale": _pipe_sd_case,
     "pipe_sdxl_euler_cfg_microcond": _pipe_sdxl_case,
     "pipe_sd3_flow_match_cfg": _pipe_sd3_case,
+    "pipe_img2img_ddim": _pipe_img2img_case("ddim"),
+    "pipe_img2img_euler": _pipe_img2img_case("euler"),
+    "pipe_inpaint_4ch_ddim_cfg": _pipe_inpaint_case(False),
+    "pipe_inpaint_9ch_euler": _pipe_inpaint_case(True),
+    "pipe_controlnet": _pipe_controlnet_case(False, 0.8),
+    "pipe_controlnet_guess_mode": _pipe_controlnet_case(True, 1.0),
+    "pipe_lcm_timestep_cond": _pipe_lcm_case,
     # schedulers/*.py: whole sampling loops
     "sched_ddim_sd15": _scheduler_case("scheduling_ddim", "DDIMScheduler", "DDIMRef", dict(_SD, clip_sample=False, set_alpha_to_one=False, steps_offset=1), 20),
     "sched_ddim_trailing_clip": _scheduler_case("scheduling_ddim", "DDIMScheduler", "DDIMRef", dict(_SD, clip_sample=True, timestep_spacing="trailing"), 10),

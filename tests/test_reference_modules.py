@@ -39,7 +39,8 @@ def test_oracle_reproduces_the_committed_reference_outputs(name):
 @pytest.mark.skipif(not reference_runner.available(), reason="/root/reference exists only in the build container")
 @pytest.mark.parametrize("name", ["unet_tiny", "unet_mini_xl", "unet_tiny_masks", "controlnet_bgr_guess_mode", "dit_mini", "sd3_mini_trained_norm_bias",
                                   "vae_mini", "sched_euler_sdxl", "sched_dpmpp_2m_karras_heun", "sched_lcm", "clip_text_gelu", "t5_encoder",
-                                  "unet_ip_adapter_scale_0p6", "lora_fuse", "pipe_sdxl_euler_cfg_microcond", "pipe_sd3_flow_match_cfg"])
+                                  "unet_ip_adapter_scale_0p6", "lora_fuse", "pipe_sdxl_euler_cfg_microcond", "pipe_sd3_flow_match_cfg",
+                                  "pipe_inpaint_9ch_euler", "pipe_controlnet_guess_mode", "pipe_lcm_timestep_cond"])
 def test_live_reference_run_agrees(name):
     out = RC.CASES[name](True)
     gold = np.load(RC.golden_path(name))
@@ -90,6 +91,67 @@ def test_product_pipelines_follow_the_reference_pipelines():
                                      FlowMatchEulerDiscreteScheduler(shift=3.0))
     out = pipe3(pe, pp, ne, npp, num_inference_steps=6, guidance_scale=7.0, latents=lat0.clone())
     assert rel(out, "pipe_sd3_flow_match_cfg") < 3e-2, rel(out, "pipe_sd3_flow_match_cfg")
+
+
+def test_product_image_pipelines_follow_the_reference_pipelines():
+    """img2img, both inpainting forms, ControlNet (plain and guess mode) and latent-consistency sampling of
+    paddlemix_amd/pipeline.py (emulated device) against the committed final latents of the reference's own
+    StableDiffusionImg2ImgPipeline / StableDiffusionInpaintPipeline / StableDiffusionControlNetPipeline / StableDiffusionPipeline
+    __call__ -- same weights, embeddings, images, masks, seeds: the random draws must come in the reference's order."""
+    from oracle import unet_ref as U
+    from paddlemix_amd.pipeline import StableDiffusionDenoiser
+    from paddlemix_amd.schedulers import DDIMScheduler, EulerDiscreteScheduler, LCMScheduler
+    from paddlemix_amd.unet import ControlNetModel, UNet2DConditionModel
+    from paddlemix_amd.vae import AutoencoderKL
+    from tests.abi_emulator import Emulator
+    from tests.configs import MINI_VAE, TINY
+
+    def rel(a, name):
+        g = torch.from_numpy(np.load(RC.golden_path(name))["latents"])
+        return float((a - g).norm() / g.norm())
+
+    SD = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear")
+    ddim = lambda: DDIMScheduler(clip_sample=False, set_alpha_to_one=False, steps_offset=1, **SD)  # noqa: E731
+    euler = lambda: EulerDiscreteScheduler(timestep_spacing="leading", steps_offset=1, **SD)  # noqa: E731
+    unet = lambda cfg, seed: UNet2DConditionModel(cfg, U.synth_unet_params(cfg, seed=seed), _test_backend=Emulator())  # noqa: E731
+    vae = AutoencoderKL(MINI_VAE, RC._vae_params(6), _test_backend=Emulator())
+    # img2img
+    g = torch.Generator().manual_seed(3)
+    pe, ne = torch.randn(2, 7, 64, generator=g), torch.randn(2, 7, 64, generator=g)
+    image = torch.rand(1, 3, 32, 32, generator=g) * 2 - 1
+    for name, sch in (("pipe_img2img_ddim", ddim()), ("pipe_img2img_euler", euler())):
+        out = StableDiffusionDenoiser(unet(TINY, 1), sch, vae=vae)(pe, ne, num_inference_steps=10, guidance_scale=5.0, image=image, strength=0.6,
+                                                                  generator=torch.Generator().manual_seed(11))
+        assert rel(out, name) < 5e-2, (name, rel(out, name))
+    # inpaint
+    g = torch.Generator().manual_seed(8)
+    pe, ne = torch.randn(1, 7, 64, generator=g), torch.randn(1, 7, 64, generator=g)
+    image = torch.rand(1, 3, 32, 32, generator=g) * 2 - 1
+    mask_px = torch.zeros(1, 1, 32, 32)
+    mask_px[:, :, 8:24, 12:32] = 0.9
+    out = StableDiffusionDenoiser(unet(TINY, 1), ddim(), vae=vae)(pe, ne, num_inference_steps=5, guidance_scale=4.0, image=image, mask_image=mask_px,
+                                                                   generator=torch.Generator().manual_seed(31))
+    assert rel(out, "pipe_inpaint_4ch_ddim_cfg") < 5e-2, rel(out, "pipe_inpaint_4ch_ddim_cfg")
+    cfg9 = dict(TINY, in_channels=9)
+    out = StableDiffusionDenoiser(unet(cfg9, 77), euler(), vae=vae)(pe, num_inference_steps=10, guidance_scale=1.0, image=image, mask_image=mask_px,
+                                                                     strength=0.6, generator=torch.Generator().manual_seed(32))
+    assert rel(out, "pipe_inpaint_9ch_euler") < 5e-2, rel(out, "pipe_inpaint_9ch_euler")
+    # ControlNet
+    g = torch.Generator().manual_seed(0)
+    pe, ne = torch.randn(1, 7, 64, generator=g), torch.randn(1, 7, 64, generator=g)
+    lat0, hint = torch.randn(1, 4, 8, 8, generator=g), torch.rand(1, 3, 64, 64, generator=g)
+    cn = ControlNetModel(TINY, RC._synth(U.controlnet_param_shapes(TINY), 8), _test_backend=Emulator())
+    pipe = StableDiffusionDenoiser(unet(TINY, 1), ddim(), controlnet=cn)
+    for name, guess, sc in (("pipe_controlnet", False, 0.8), ("pipe_controlnet_guess_mode", True, 1.0)):
+        out = pipe(pe, ne, num_inference_steps=3, guidance_scale=5.0, latents=lat0.clone(), control_image=hint, controlnet_conditioning_scale=sc,
+                   guess_mode=guess)
+        assert rel(out, name) < 5e-2, (name, rel(out, name))
+    # latent-consistency sampling
+    g = torch.Generator().manual_seed(0)
+    pe, lat0 = torch.randn(2, 7, 64, generator=g), torch.randn(2, 4, 8, 8, generator=g)
+    out = StableDiffusionDenoiser(unet(dict(TINY, time_cond_proj_dim=32), 1), LCMScheduler(**SD))(
+        pe, num_inference_steps=4, guidance_scale=8.0, latents=lat0.clone(), generator=torch.Generator().manual_seed(21))
+    assert rel(out, "pipe_lcm_timestep_cond") < 5e-2, rel(out, "pipe_lcm_timestep_cond")
 
 
 def test_the_shim_is_test_infrastructure_only():
