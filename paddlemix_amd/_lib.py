@@ -184,6 +184,10 @@ def load() -> ctypes.CDLL:
         raise MI355XError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C paddlemix_amd/csrc`). paddlemix_amd has no CPU / PyTorch fallback.")
+    # torch ships its own copy of the HIP runtime (torch/lib/libamdhip64.so); the library links /opt/rocm's. Whichever is loaded
+    # first becomes the process's runtime -- and if it is /opt/rocm's, torch's copy then finds no device ("no HIP device
+    # visible" from mi355x_sd_init). The Python host shares device memory and streams with torch, so torch's goes first.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
