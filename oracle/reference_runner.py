@@ -91,7 +91,8 @@ def _stub_modules(shim):
         return None
 
     class _NoLoaders:
-        pass
+        def maybe_convert_prompt(self, prompt, tokenizer):   # TextualInversionLoaderMixin: no learned tokens loaded
+            return prompt
 
     flags = dict(USE_PEFT_BACKEND=False, BaseOutput=BaseOutput, deprecate=deprecate, logging=_Logging,
                  scale_lora_layers=lambda *a, **k: None, unscale_lora_layers=lambda *a, **k: None,
@@ -159,9 +160,8 @@ def _stub_pipelines(P, mod, ConfigMixin):
     """what pipelines/stable_diffusion*/pipeline_*.py import besides models and schedulers: the DiffusionPipeline base class (hub /
     device placement / progress bar: dropped to attribute registration), the safety checker (absent). image_processor.py
     (VaeImageProcessor: tensor pre-processing, mask binarisation, resize) is the reference's real file."""
-    import contextlib
-
-    for sub in ("pipelines", "pipelines.stable_diffusion", "pipelines.stable_diffusion_xl", "pipelines.stable_diffusion_3", "pipelines.controlnet"):
+    for sub in ("pipelines", "pipelines.stable_diffusion", "pipelines.stable_diffusion_xl", "pipelines.stable_diffusion_3", "pipelines.controlnet",
+                "pipelines.dit"):
         m = mod(f"{PKG}.{sub}")
         m.__path__ = [os.path.join(REF_ROOT, PKG, *sub.split("."))]
 
@@ -169,14 +169,19 @@ def _stub_pipelines(P, mod, ConfigMixin):
         def update(self, *a, **k):
             pass
 
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
     class DiffusionPipeline(ConfigMixin):
         def register_modules(self, **kw):
             for k, v in kw.items():
                 setattr(self, k, v)
 
-        @contextlib.contextmanager
         def progress_bar(self, iterable=None, total=None):
-            yield _Bar()
+            return iterable if iterable is not None else _Bar()     # `for t in self.progress_bar(ts)` | `with self.progress_bar(total=n)`
 
         def maybe_free_model_hooks(self):
             pass
@@ -188,7 +193,11 @@ def _stub_pipelines(P, mod, ConfigMixin):
         def _execution_device(self):
             return None
 
-    mod(f"{PKG}.pipelines.pipeline_utils", DiffusionPipeline=DiffusionPipeline)
+    class ImagePipelineOutput:
+        def __init__(self, images):
+            self.images = images
+
+    mod(f"{PKG}.pipelines.pipeline_utils", DiffusionPipeline=DiffusionPipeline, ImagePipelineOutput=ImagePipelineOutput)
 
     mod(f"{PKG}.pipelines.stable_diffusion.safety_checker", StableDiffusionSafetyChecker=type("StableDiffusionSafetyChecker", (), {}))
 
@@ -203,6 +212,7 @@ def ref_pipeline(module: str, package: str = "pipelines.stable_diffusion"):
     scheds.KarrasDiffusionSchedulers = ref_module("scheduling_utils", "schedulers").KarrasDiffusionSchedulers
     scheds.FlowMatchEulerDiscreteScheduler = ref_module("scheduling_flow_match_euler_discrete", "schedulers").FlowMatchEulerDiscreteScheduler
     models.ControlNetModel = ref_module("controlnet").ControlNetModel
+    models.Transformer2DModel = ref_module("transformer_2d").Transformer2DModel
     models.AsymmetricAutoencoderKL = type("AsymmetricAutoencoderKL", (), {})      # isinstance checks of the inpaint pipeline only
     scheds.LCMScheduler = ref_module("scheduling_lcm", "schedulers").LCMScheduler
     sdpkg = sys.modules[f"{PKG}.pipelines.stable_diffusion"]

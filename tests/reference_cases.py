@@ -706,6 +706,149 @@ def _pipe_lcm_case(ref):
     return out
 
 
+class _FakeTokenizer:
+    """the tokenizers' vocabulary files are not part of the path: a table prompt -> ids stands in (padding="longest" answers a
+    shorter row, like a real tokenizer on a short prompt, so the pipelines' truncation warning stays silent)"""
+    model_max_length = 77
+
+    def __init__(self, rr, table):
+        self.rr, self.table = rr, table
+
+    def __call__(self, prompt, padding=None, max_length=None, truncation=None, return_tensors=None, add_special_tokens=True):
+        prompt = [prompt] if isinstance(prompt, str) else prompt
+        ids = torch.stack([self.table[p] for p in prompt])
+        if padding == "longest":
+            ids = ids[:, :20]
+        return type("Encoding", (), {"input_ids": self.rr.to_shim(ids)})()
+
+
+def _text_encoders(rr, specs):
+    """specs: (kind, config, params) -> the reference's CLIPTextModel / CLIPTextModelWithProjection / T5EncoderModel"""
+    out = []
+    for kind, cfg, P in specs:
+        if kind == "t5":
+            from oracle import t5_ref as T
+            net = _transformers_module(rr, "t5.modeling").T5EncoderModel(_transformers_module(rr, "t5.configuration").T5Config(**T.normalize_config(cfg)))
+        else:
+            conf = _transformers_module(rr, "clip.configuration").CLIPTextConfig(**{k: v for k, v in cfg.items() if k != "with_projection"})
+            net = getattr(_transformers_module(rr, "clip.modeling"), "CLIPTextModelWithProjection" if kind == "clip_proj" else "CLIPTextModel")(conf)
+        net.eval()
+        out.append(rr.load_params(net, P))
+    return out
+
+
+def encode_prompt_inputs():
+    """token ids and encoder parameters shared by the encode_prompt cases and the product test that replays them"""
+    from oracle import clip_ref as K, t5_ref as T
+    g = torch.Generator().manual_seed(4)
+    ids = {}
+    for name in ("a", "b", "c"):
+        t = torch.randint(3, 1000, (77,), generator=g)
+        t[30], t[31:] = 2, 0
+        ids[name] = t
+    t5_ids = torch.randint(1, 500, (77,), generator=g)
+    c1 = dict(C.MINI_CLIP, with_projection=False)
+    c1p = dict(C.MINI_CLIP, with_projection=True)
+    c2 = dict(C.MINI_CLIP, with_projection=True, hidden_act="gelu")
+    t5 = dict(C.MINI_T5, d_model=160)
+    return dict(ids=ids, t5_ids=t5_ids, c1=c1, c1p=c1p, c2=c2, t5=t5, P1=K.synth_clip_params(c1, seed=2), P1p=K.synth_clip_params(c1p, seed=2),
+                P2=K.synth_clip_params(c2, seed=3), P3=T.synth_t5_params(t5, seed=6))
+
+
+def _encode_prompt_sdxl_case(ref):
+    """StableDiffusionXLPipeline.encode_prompt (pipeline_stable_diffusion_xl.py:262-460): hidden_states[-2] of both encoders side by
+    side, pooled = the second encoder's projected EOS row, zeros for the empty negative prompt (force_zeros_for_empty_prompt)."""
+    from oracle import clip_ref as K
+    E = encode_prompt_inputs()
+    a, b = E["ids"]["a"][None], E["ids"]["b"][None]
+    with torch.no_grad():
+        o1, o2 = K.clip_text_forward(E["P1"], E["c1"], a), K.clip_text_forward(E["P2"], E["c2"], b)
+        out = {"oracle": {"prompt_embeds": torch.cat([o1["hidden_states"][-2], o2["hidden_states"][-2]], -1), "pooled": o2["text_embeds"]}, "reference": None}
+        if ref:
+            rr = _rr()
+            pm = rr.ref_pipeline("pipeline_stable_diffusion_xl", "pipelines.stable_diffusion_xl")
+            te1, te2 = _text_encoders(rr, [("clip", E["c1"], E["P1"]), ("clip_proj", E["c2"], E["P2"])])
+            unet_stub = type("U", (), {"config": rr.FrozenConfig(sample_size=8), "dtype": torch.float32})()
+            pipe = pm.StableDiffusionXLPipeline(vae=_FakeVAE(rr), text_encoder=te1, text_encoder_2=te2, tokenizer=_FakeTokenizer(rr, E["ids"]),
+                                                tokenizer_2=_FakeTokenizer(rr, E["ids"]), unet=unet_stub, scheduler=None)
+            pe, ne, pp, npp = pipe.encode_prompt(prompt="a", prompt_2="b", do_classifier_free_guidance=True)
+            assert float(rr.from_shim(ne).abs().max()) == 0 and float(rr.from_shim(npp).abs().max()) == 0 and ne.shape == pe.shape
+            out["reference"] = {"prompt_embeds": rr.from_shim(pe), "pooled": rr.from_shim(pp)}
+    return out
+
+
+def _encode_prompt_sd3_case(ref):
+    """StableDiffusion3Pipeline.encode_prompt (pipeline_stable_diffusion_3.py:201-420): two projected CLIP encoders (hidden_states[-2]
+    side by side, zero-padded to the T5 width) followed on the token axis by the T5 sequence; pooled = both projected EOS rows."""
+    from oracle import clip_ref as K, t5_ref as T
+    E = encode_prompt_inputs()
+    a, b, c = E["ids"]["a"][None], E["ids"]["b"][None], E["t5_ids"][None]
+    with torch.no_grad():
+        o1, o2 = K.clip_text_forward(E["P1p"], E["c1p"], a), K.clip_text_forward(E["P2"], E["c2"], b)
+        t5 = T.t5_encoder_forward(E["P3"], E["t5"], c)
+        clip = torch.cat([o1["hidden_states"][-2], o2["hidden_states"][-2]], -1)
+        clip = torch.nn.functional.pad(clip, (0, t5.shape[-1] - clip.shape[-1]))
+        out = {"oracle": {"prompt_embeds": torch.cat([clip, t5], -2), "pooled": torch.cat([o1["text_embeds"], o2["text_embeds"]], -1)}, "reference": None}
+        if ref:
+            rr = _rr()
+            pm = rr.ref_pipeline("pipeline_stable_diffusion_3", "pipelines.stable_diffusion_3")
+            te1, te2, te3 = _text_encoders(rr, [("clip_proj", E["c1p"], E["P1p"]), ("clip_proj", E["c2"], E["P2"]), ("t5", E["t5"], E["P3"])])
+            tr = type("T", (), {"config": rr.FrozenConfig(sample_size=8, joint_attention_dim=160)})()
+            tok3 = _FakeTokenizer(rr, {"c": E["t5_ids"]})
+            pipe = pm.StableDiffusion3Pipeline(transformer=tr, scheduler=None, vae=_FakeVAE(rr), text_encoder=te1, tokenizer=_FakeTokenizer(rr, E["ids"]),
+                                               text_encoder_2=te2, tokenizer_2=_FakeTokenizer(rr, E["ids"]), text_encoder_3=te3, tokenizer_3=tok3)
+            pe, _, pp, _ = pipe.encode_prompt(prompt="a", prompt_2="b", prompt_3="c", do_classifier_free_guidance=False)
+            out["reference"] = {"prompt_embeds": rr.from_shim(pe), "pooled": rr.from_shim(pp)}
+    return out
+
+
+DIT_PIPE_CFG = dict(C.MINI_DIT, num_embeds_ada_norm=1000)     # the reference pipeline hard-codes the null class 1000 (pipeline_dit.py:184)
+
+
+def _pipe_dit_case(ref):
+    """DiTPipeline.__call__ (pipelines/dit/pipeline_dit.py:158-246): class-conditional CFG with the null class on the duplicated latent
+    half, guidance on the epsilon channels only, learned-sigma channels dropped before scheduler.step. The reference returns decoded
+    images only, so its vae slot holds a linear stand-in (decode(x) = 0.01 x, scaling_factor 1) that is inverted afterwards."""
+    from oracle import dit_ref as D, schedulers_ref as S
+    cfg = DIT_PIPE_CFG
+    P = D.synth_dit_params(cfg, seed=2)
+    labels, gs, steps = [3, 8], 4.0, 5
+    lat0 = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(5))
+    kw = dict(_SD, clip_sample=False, set_alpha_to_one=False, steps_offset=1)
+    sch = S.DDIMRef(**kw)
+    sch.set_timesteps(steps)
+    x = torch.cat([lat0, lat0]).numpy()
+    lab = torch.tensor(labels + [1000, 1000])
+    with torch.no_grad():
+        for t in sch.timesteps:
+            x[2:] = x[:2]
+            n = D.dit_forward(P, cfg, torch.from_numpy(x), torch.full((4,), int(t)), lab).numpy()
+            eps = n[:, :4]
+            half = eps[2:] + gs * (eps[:2] - eps[2:])
+            x = sch.step(np.concatenate([half, half]), t, x)
+    out = {"oracle": {"latents": torch.from_numpy(np.asarray(x[:2], dtype=np.float32))}, "reference": None}
+    if ref:
+        rr = _rr()
+        pm = rr.ref_pipeline("pipeline_dit", "pipelines.dit")
+        full = D.normalize_config(cfg)
+        full.pop("inner_dim")
+        net = rr.ref_module("transformer_2d").Transformer2DModel(**full)
+        net.eval()
+        rr.load_params(net, P)
+
+        class LinearVAE:
+            config = rr.FrozenConfig(scaling_factor=1.0)
+
+            def decode(self, z):
+                return type("O", (), {"sample": z * 0.01})()
+
+        pipe = pm.DiTPipeline(transformer=net, vae=LinearVAE(), scheduler=rr.ref_module("scheduling_ddim", "schedulers").DDIMScheduler(**kw))
+        img = pipe(class_labels=labels, guidance_scale=gs, num_inference_steps=steps, output_type="np", return_dict=False,
+                   generator=lambda shape: lat0.clone())[0]
+        out["reference"] = {"latents": torch.from_numpy(((np.asarray(img, dtype=np.float64) - 0.5) * 200.0).astype(np.float32)).permute(0, 3, 1, 2).contiguous()}
+    return out
+
+
 def _labels(kind):
     return {
         "index": lambda g: torch.tensor([3, 8]),
@@ -753,6 +896,9 @@ CASES = {
     "pipe_sd_ddim_cfg_rescale": _pipe_sd_case,
     "pipe_sdxl_euler_cfg_microcond": _pipe_sdxl_case,
     "pipe_sd3_flow_match_cfg": _pipe_sd3_case,
+    "encode_prompt_sdxl": _encode_prompt_sdxl_case,
+    "encode_prompt_sd3": _encode_prompt_sd3_case,
+    "pipe_dit_class_cfg": _pipe_dit_case,
     "pipe_img2img_ddim": _pipe_img2img_case("ddim"),
     "pipe_img2img_euler": _pipe_img2img_case("euler"),
     "pipe_inpaint_4ch_ddim_cfg": _pipe_inpaint_case(False),

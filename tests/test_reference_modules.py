@@ -40,7 +40,7 @@ def test_oracle_reproduces_the_committed_reference_outputs(name):
 @pytest.mark.parametrize("name", ["unet_tiny", "unet_mini_xl", "unet_tiny_masks", "controlnet_bgr_guess_mode", "dit_mini", "sd3_mini_trained_norm_bias",
                                   "vae_mini", "sched_euler_sdxl", "sched_dpmpp_2m_karras_heun", "sched_lcm", "clip_text_gelu", "t5_encoder",
                                   "unet_ip_adapter_scale_0p6", "lora_fuse", "pipe_sdxl_euler_cfg_microcond", "pipe_sd3_flow_match_cfg",
-                                  "pipe_inpaint_9ch_euler", "pipe_controlnet_guess_mode", "pipe_lcm_timestep_cond"])
+                                  "pipe_inpaint_9ch_euler", "pipe_controlnet_guess_mode", "pipe_lcm_timestep_cond", "encode_prompt_sdxl", "encode_prompt_sd3", "pipe_dit_class_cfg"])
 def test_live_reference_run_agrees(name):
     out = RC.CASES[name](True)
     gold = np.load(RC.golden_path(name))
@@ -146,12 +146,46 @@ def test_product_image_pipelines_follow_the_reference_pipelines():
         out = pipe(pe, ne, num_inference_steps=3, guidance_scale=5.0, latents=lat0.clone(), control_image=hint, controlnet_conditioning_scale=sc,
                    guess_mode=guess)
         assert rel(out, name) < 5e-2, (name, rel(out, name))
+    # class-conditional DiT (DiTPipeline.__call__)
+    from oracle import dit_ref as D
+    from paddlemix_amd.dit import DiTTransformer2DModel
+    from paddlemix_amd.pipeline import DiTDenoiser
+    lat0 = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(5))
+    dit = DiTDenoiser(DiTTransformer2DModel(RC.DIT_PIPE_CFG, D.synth_dit_params(RC.DIT_PIPE_CFG, seed=2), _test_backend=Emulator()), ddim())
+    out = dit([3, 8], guidance_scale=4.0, num_inference_steps=5, latents=lat0.clone())
+    assert rel(out, "pipe_dit_class_cfg") < 5e-2, rel(out, "pipe_dit_class_cfg")
     # latent-consistency sampling
     g = torch.Generator().manual_seed(0)
     pe, lat0 = torch.randn(2, 7, 64, generator=g), torch.randn(2, 4, 8, 8, generator=g)
     out = StableDiffusionDenoiser(unet(dict(TINY, time_cond_proj_dim=32), 1), LCMScheduler(**SD))(
         pe, num_inference_steps=4, guidance_scale=8.0, latents=lat0.clone(), generator=torch.Generator().manual_seed(21))
     assert rel(out, "pipe_lcm_timestep_cond") < 5e-2, rel(out, "pipe_lcm_timestep_cond")
+
+
+def test_product_encode_prompt_follows_the_reference_pipelines():
+    """paddlemix_amd/pipeline.py encode_prompt (emulated device: CLIP / T5 programs on host memory) against the committed outputs of
+    StableDiffusionXLPipeline.encode_prompt and StableDiffusion3Pipeline.encode_prompt run with the same token ids and weights"""
+    from paddlemix_amd.clip import CLIPTextModel, CLIPTextModelWithProjection
+    from paddlemix_amd.pipeline import StableDiffusion3Denoiser, StableDiffusionDenoiser
+    from paddlemix_amd.t5 import T5EncoderModel
+    from tests.abi_emulator import Emulator
+    E = RC.encode_prompt_inputs()
+    a, b, c = E["ids"]["a"][None], E["ids"]["b"][None], E["t5_ids"][None]
+
+    def rel(x, name, key):
+        g = torch.from_numpy(np.load(RC.golden_path(name))[key])
+        assert x.shape == g.shape, (x.shape, g.shape)
+        return float((x.float() - g).norm() / g.norm())
+
+    xl = StableDiffusionDenoiser(None, None, text_encoder=CLIPTextModel(E["c1"], E["P1"], _test_backend=Emulator()),
+                                 text_encoder_2=CLIPTextModelWithProjection(E["c2"], E["P2"], _test_backend=Emulator()))
+    pe, pooled = xl.encode_prompt(a, b)
+    assert rel(pe, "encode_prompt_sdxl", "prompt_embeds") < 1.5e-2 and rel(pooled, "encode_prompt_sdxl", "pooled") < 2e-2
+    s3 = StableDiffusion3Denoiser(None, None, text_encoder=CLIPTextModelWithProjection(E["c1p"], E["P1p"], _test_backend=Emulator()),
+                                  text_encoder_2=CLIPTextModelWithProjection(E["c2"], E["P2"], _test_backend=Emulator()),
+                                  text_encoder_3=T5EncoderModel(E["t5"], E["P3"], _test_backend=Emulator()))
+    pe, pooled = s3.encode_prompt(a, b, c)
+    assert rel(pe, "encode_prompt_sd3", "prompt_embeds") < 1.5e-2 and rel(pooled, "encode_prompt_sd3", "pooled") < 2e-2
 
 
 def test_the_shim_is_test_infrastructure_only():
