@@ -188,6 +188,50 @@ def test_product_encode_prompt_follows_the_reference_pipelines():
     assert rel(pe, "encode_prompt_sd3", "prompt_embeds") < 1.5e-2 and rel(pooled, "encode_prompt_sd3", "pooled") < 2e-2
 
 
+_PRODUCT_SCHEDULERS = {
+    "sched_ddim_sd15": ("DDIMScheduler", dict(clip_sample=False, set_alpha_to_one=False, steps_offset=1), 20),
+    "sched_ddim_trailing_clip": ("DDIMScheduler", dict(clip_sample=True, timestep_spacing="trailing"), 10),
+    "sched_euler_sdxl": ("EulerDiscreteScheduler", dict(timestep_spacing="leading", steps_offset=1), 30),
+    "sched_euler_karras": ("EulerDiscreteScheduler", dict(use_karras_sigmas=True), 12),
+    "sched_flow_match_sd3": ("FlowMatchEulerDiscreteScheduler", dict(shift=3.0), 28),
+    "sched_pndm_sd15": ("PNDMScheduler", dict(skip_prk_steps=True, steps_offset=1), 20),
+    "sched_pndm_prk": ("PNDMScheduler", dict(), 10),
+    "sched_dpmpp_2m": ("DPMSolverMultistepScheduler", dict(), 20),
+    "sched_dpmpp_2m_karras_heun": ("DPMSolverMultistepScheduler", dict(use_karras_sigmas=True, solver_type="heun"), 12),
+    "sched_dpm_order1_leading": ("DPMSolverMultistepScheduler", dict(algorithm_type="dpmsolver", solver_order=1, timestep_spacing="leading", steps_offset=1), 10),
+    "sched_lcm": ("LCMScheduler", dict(), 4),
+}
+
+
+@pytest.mark.parametrize("name", list(_PRODUCT_SCHEDULERS))
+def test_product_schedulers_reproduce_the_reference_sampling_loops(name):
+    """paddlemix_amd/schedulers.py (the classes the pipelines and bench.py use) through the same sampling loop as the reference's own
+    scheduler class (tests/reference_cases.py _scheduler_case), against the committed reference latents and timestep tables"""
+    import math
+
+    import paddlemix_amd.schedulers as PS
+    cls, kw, steps = _PRODUCT_SCHEDULERS[name]
+    if cls != "FlowMatchEulerDiscreteScheduler":
+        kw = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", **kw)
+    gold = np.load(RC.golden_path(name))
+    g = torch.Generator().manual_seed(0)
+    x0, pat = torch.randn(1, 4, 8, 8, generator=g), torch.randn(1, 4, 8, 8, generator=g)
+    draws = [torch.randn(1, 4, 8, 8, generator=g) for _ in range(steps)]
+    sch = getattr(PS, cls)(**kw)
+    sch.set_timesteps(steps)
+    x = x0 * float(getattr(sch, "init_noise_sigma", 1.0))
+    for i, t in enumerate(sch.timesteps):
+        xin = sch.scale_model_input(x, t)
+        eps = 0.3 * xin * math.cos(0.01 * float(t)) + 0.1 * pat
+        if cls == "LCMScheduler":
+            x = sch.step(eps, t, x, noise=None if i == steps - 1 else draws[i], return_dict=False)[0]
+        else:
+            x = sch.step(eps, t, x, return_dict=False)[0]
+    ts = torch.tensor([float(t) for t in sch.timesteps])
+    assert _rel(ts, torch.from_numpy(gold["timesteps"])) < 1e-6
+    assert _rel(x, torch.from_numpy(gold["latents"])) < 2e-5, _rel(x, torch.from_numpy(gold["latents"]))
+
+
 def test_the_shim_is_test_infrastructure_only():
     """nothing under paddlemix_amd/ (the product), bench.py's timed path or __graft_entry__ may touch the shim or the runner"""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
