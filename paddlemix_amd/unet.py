@@ -312,6 +312,11 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
         pub = dict(UNET_DEFAULTS)
         pub.update({k: v for k, v in config.items() if not k.startswith("_")})
         self.config = SimpleNamespace(**pub)
+        if self.cfg["addition_embed_type"] == "text_time":
+            # StableDiffusionXLPipeline._get_add_time_ids (pipeline_stable_diffusion_xl.py:603-619) sizes its check from
+            # `unet.add_embedding.linear_1.in_features`: the one sub-layer attribute a pipeline reads off the UNet
+            pdim = self.cfg["projection_class_embeddings_input_dim"]
+            self.add_embedding = SimpleNamespace(linear_1=SimpleNamespace(in_features=pdim, out_features=self.cfg["block_out_channels"][0] * 4))
         self._load_weights(params)
 
     _encoder_only = False   # ControlNetModel: stop after the mid block

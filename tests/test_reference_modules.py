@@ -188,6 +188,114 @@ def test_product_encode_prompt_follows_the_reference_pipelines():
     assert rel(pe, "encode_prompt_sd3", "prompt_embeds") < 1.5e-2 and rel(pooled, "encode_prompt_sd3", "pooled") < 2e-2
 
 
+class _Bridge:
+    """The reference pipeline hands `paddle` tensors (here: shim tensors) to whatever sits in its unet / transformer slot; the MI355X
+    models take device tensors. This is the glue INTEGRATION.md section 4b describes (tensor -> pointer and back), nothing else:
+    attribute access (`.config`, `.dtype`) and the call signature are the product model's own."""
+
+    def __init__(self, model):
+        self._m = model
+
+    def __getattr__(self, k):
+        return getattr(self._m, k)
+
+    def __call__(self, *a, **k):
+        out = self._m(*reference_runner.from_shim(a), **{n: reference_runner.from_shim(v) if not isinstance(v, dict) else
+                                                         {kk: reference_runner.from_shim(vv) for kk, vv in v.items()} for n, v in k.items()})
+        return reference_runner.to_shim(tuple(out) if isinstance(out, (tuple, list)) else out)
+
+
+@pytest.mark.skipif(not reference_runner.available(), reason="/root/reference exists only in the build container")
+def test_product_models_drop_into_the_reference_pipelines_call():
+    """north_star: "keeping the ppdiffusers DiffusionPipeline / scheduler API surface so it drops in for
+    StableDiffusionPipeline.__call__". The reference's OWN pipeline objects (unmodified pipeline_stable_diffusion.py,
+    pipeline_stable_diffusion_xl.py, pipeline_stable_diffusion_3.py and scheduler classes, executed over the shim) run their __call__
+    with the MI355X UNet2DConditionModel / SD3Transformer2DModel (emulated device) in the unet / transformer slot, called exactly the
+    way the pipeline calls its own model -- and land on the latents the reference model gives (16-bit tolerance)."""
+    from oracle import sd3_ref as R3
+    from oracle import unet_ref as U
+    from paddlemix_amd.sd3 import SD3Transformer2DModel
+    from paddlemix_amd.unet import UNet2DConditionModel
+    from tests.abi_emulator import Emulator
+    from tests.configs import MINI_SD3, MINI_XL, TINY
+    rr = reference_runner
+    SD = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", steps_offset=1)
+
+    def rel(a, name):
+        g = torch.from_numpy(np.load(RC.golden_path(name))["latents"])
+        return float((a - g).norm() / g.norm())
+
+    # StableDiffusionPipeline: CFG + guidance_rescale + DDIM
+    g = torch.Generator().manual_seed(0)
+    pe, ne, lat0 = torch.randn(1, 7, 64, generator=g), torch.randn(1, 7, 64, generator=g), torch.randn(1, 4, 8, 8, generator=g)
+    pm = rr.ref_pipeline("pipeline_stable_diffusion")
+    unet = _Bridge(UNet2DConditionModel(TINY, U.synth_unet_params(TINY, seed=1), _test_backend=Emulator()))
+    sched = rr.ref_module("scheduling_ddim", "schedulers").DDIMScheduler(clip_sample=False, set_alpha_to_one=False, **SD)
+    pipe = pm.StableDiffusionPipeline(vae=RC._FakeVAE(rr, scaling_factor=0.18215), text_encoder=None, tokenizer=None, unet=unet, scheduler=sched,
+                                      safety_checker=None, feature_extractor=None, requires_safety_checker=False)
+    out = pipe(prompt_embeds=rr.to_shim(pe), negative_prompt_embeds=rr.to_shim(ne), latents=rr.to_shim(lat0.clone()), num_inference_steps=6,
+               guidance_scale=7.5, guidance_rescale=0.7, output_type="latent", height=64, width=64, return_dict=False)[0]
+    assert rel(rr.from_shim(out), "pipe_sd_ddim_cfg_rescale") < 3e-2
+    # StableDiffusionXLPipeline: pooled embeddings + micro-conditioning through added_cond_kwargs, Euler
+    g = torch.Generator().manual_seed(0)
+    cd = MINI_XL["cross_attention_dim"]
+    pe, ne = torch.randn(1, 9, cd, generator=g), torch.randn(1, 9, cd, generator=g)
+    pp, npp, lat0 = torch.randn(1, 64, generator=g), torch.randn(1, 64, generator=g), torch.randn(1, 4, 8, 8, generator=g)
+    pmx = rr.ref_pipeline("pipeline_stable_diffusion_xl", "pipelines.stable_diffusion_xl")
+    unet = _Bridge(UNet2DConditionModel(MINI_XL, U.synth_unet_params(MINI_XL, seed=1), _test_backend=Emulator()))
+    te2 = type("TextEncoder2", (), {"config": rr.FrozenConfig(projection_dim=64), "dtype": torch.float32})()
+    pipe = pmx.StableDiffusionXLPipeline(vae=RC._FakeVAE(rr, scaling_factor=0.13025, force_upcast=False), text_encoder=None, text_encoder_2=te2,
+                                         tokenizer=None, tokenizer_2=None, unet=unet,
+                                         scheduler=rr.ref_module("scheduling_euler_discrete", "schedulers").EulerDiscreteScheduler(timestep_spacing="leading", **SD))
+    out = pipe(prompt_embeds=rr.to_shim(pe), negative_prompt_embeds=rr.to_shim(ne), pooled_prompt_embeds=rr.to_shim(pp),
+               negative_pooled_prompt_embeds=rr.to_shim(npp), latents=rr.to_shim(lat0.clone()), num_inference_steps=5, guidance_scale=5.0,
+               output_type="latent", height=64, width=64, original_size=(96, 80), crops_coords_top_left=(3, 5), target_size=(64, 64), return_dict=False)[0]
+    assert rel(rr.from_shim(out), "pipe_sdxl_euler_cfg_microcond") < 3e-2
+    # StableDiffusion3Pipeline: the MMDiT in the transformer slot
+    g = torch.Generator().manual_seed(0)
+    pe, ne = torch.randn(1, 9, 64, generator=g), torch.randn(1, 9, 64, generator=g)
+    pp, npp, lat0 = torch.randn(1, 64, generator=g), torch.randn(1, 64, generator=g), torch.randn(1, 4, 16, 16, generator=g)
+    pm3 = rr.ref_pipeline("pipeline_stable_diffusion_3", "pipelines.stable_diffusion_3")
+    tr = _Bridge(SD3Transformer2DModel(MINI_SD3, R3.synth_sd3_params(MINI_SD3, seed=3), _test_backend=Emulator()))
+    sched = rr.ref_module("scheduling_flow_match_euler_discrete", "schedulers").FlowMatchEulerDiscreteScheduler(shift=3.0)
+    pipe = pm3.StableDiffusion3Pipeline(transformer=tr, scheduler=sched, vae=RC._FakeVAE(rr, scaling_factor=1.5305, shift_factor=0.0609), text_encoder=None,
+                                        tokenizer=None, text_encoder_2=None, tokenizer_2=None, text_encoder_3=None, tokenizer_3=None)
+    out = pipe(prompt_embeds=rr.to_shim(pe), negative_prompt_embeds=rr.to_shim(ne), pooled_prompt_embeds=rr.to_shim(pp),
+               negative_pooled_prompt_embeds=rr.to_shim(npp), latents=rr.to_shim(lat0.clone()), num_inference_steps=6, guidance_scale=7.0,
+               output_type="latent", height=128, width=128, return_dict=False)[0]
+    assert rel(rr.from_shim(out), "pipe_sd3_flow_match_cfg") < 3e-2
+    # StableDiffusionImg2ImgPipeline / StableDiffusionInpaintPipeline (9-channel UNet): the reference's VAE, image processor and
+    # schedulers around the MI355X UNet
+    Pv = RC._vae_params(6)
+    g = torch.Generator().manual_seed(3)
+    pe, ne = torch.randn(2, 7, 64, generator=g), torch.randn(2, 7, 64, generator=g)
+    image = torch.rand(1, 3, 32, 32, generator=g) * 2 - 1
+    pmi = rr.ref_pipeline("pipeline_stable_diffusion_img2img")
+    unet = _Bridge(UNet2DConditionModel(TINY, U.synth_unet_params(TINY, seed=1), _test_backend=Emulator()))
+    pipe = pmi.StableDiffusionImg2ImgPipeline(vae=RC._ref_vae(rr, Pv), text_encoder=None, tokenizer=None, unet=unet,
+                                              scheduler=rr.ref_module("scheduling_ddim", "schedulers").DDIMScheduler(clip_sample=False, set_alpha_to_one=False, **SD),
+                                              safety_checker=None, feature_extractor=None, requires_safety_checker=False)
+    gg = torch.Generator().manual_seed(11)
+    out = pipe(prompt_embeds=rr.to_shim(pe), negative_prompt_embeds=rr.to_shim(ne), image=rr.to_shim(image), strength=0.6, num_inference_steps=10,
+               guidance_scale=5.0, output_type="latent", return_dict=False, generator=lambda shape: torch.randn(shape, generator=gg))[0]
+    assert rel(rr.from_shim(out), "pipe_img2img_ddim") < 5e-2
+    g = torch.Generator().manual_seed(8)
+    pe, ne = torch.randn(1, 7, 64, generator=g), torch.randn(1, 7, 64, generator=g)
+    image = torch.rand(1, 3, 32, 32, generator=g) * 2 - 1
+    mask_px = torch.zeros(1, 1, 32, 32)
+    mask_px[:, :, 8:24, 12:32] = 0.9
+    cfg9 = dict(TINY, in_channels=9)
+    pmp = rr.ref_pipeline("pipeline_stable_diffusion_inpaint")
+    unet = _Bridge(UNet2DConditionModel(cfg9, U.synth_unet_params(cfg9, seed=77), _test_backend=Emulator()))
+    pipe = pmp.StableDiffusionInpaintPipeline(vae=RC._ref_vae(rr, Pv), text_encoder=None, tokenizer=None, unet=unet,
+                                              scheduler=rr.ref_module("scheduling_euler_discrete", "schedulers").EulerDiscreteScheduler(timestep_spacing="leading", **SD),
+                                              safety_checker=None, feature_extractor=None, requires_safety_checker=False)
+    gg = torch.Generator().manual_seed(32)
+    out = pipe(prompt_embeds=rr.to_shim(pe), image=rr.to_shim(image), mask_image=rr.to_shim(mask_px), strength=0.6, num_inference_steps=10,
+               guidance_scale=1.0, output_type="latent", height=32, width=32, return_dict=False, generator=lambda shape: torch.randn(shape, generator=gg))[0]
+    assert rel(rr.from_shim(out), "pipe_inpaint_9ch_euler") < 5e-2
+
+
 _PRODUCT_SCHEDULERS = {
     "sched_ddim_sd15": ("DDIMScheduler", dict(clip_sample=False, set_alpha_to_one=False, steps_offset=1), 20),
     "sched_ddim_trailing_clip": ("DDIMScheduler", dict(clip_sample=True, timestep_spacing="trailing"), 10),
