@@ -118,6 +118,8 @@ class CUNet2DConditionModel:
         self.hd = UNetHandle(config, residual_dtype, fold_softmax_scale)
         _lib.check(self.hd.lib.mi355x_sd_init(self.device.index))
         self.config = SimpleNamespace(**self.hd.config_dict)
+        if self.hd.config_dict.get("addition_embed_type") == "text_time":   # read by StableDiffusionXLPipeline._get_add_time_ids (:611)
+            self.add_embedding = SimpleNamespace(linear_1=SimpleNamespace(in_features=self.hd.config_dict["projection_class_embeddings_input_dim"]))
         self.dtype = _lib.elem_dtype()
         self.use_graph = use_graph
         self._stream = torch.cuda.Stream(device=self.device)
