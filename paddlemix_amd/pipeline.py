@@ -93,7 +93,17 @@ class StableDiffusionDenoiser:
             raise ValueError("output_type != 'latent' needs a `vae`")
         if output_type not in ("pt", "np"):
             raise ValueError(f"output_type must be 'latent', 'pt' or 'np', got {output_type!r}")
-        image = self.vae.decode(latents, return_dict=False, in_scale=1.0 / self.vae.config.scaling_factor)[0]
+        vc = self.vae.config
+        mean, std = getattr(vc, "latents_mean", None), getattr(vc, "latents_std", None)
+        if mean is not None and std is not None:
+            # StableDiffusionXLPipeline (pipeline_stable_diffusion_xl.py:1105-1110): VAEs that publish per-channel latent statistics
+            # are denormalised with them instead of the plain 1 / scaling_factor
+            shape = (1, -1, 1, 1)
+            latents = latents * torch.as_tensor(std, dtype=latents.dtype, device=latents.device).reshape(shape) / vc.scaling_factor \
+                + torch.as_tensor(mean, dtype=latents.dtype, device=latents.device).reshape(shape)
+            image = self.vae.decode(latents, return_dict=False)[0]
+        else:
+            image = self.vae.decode(latents, return_dict=False, in_scale=1.0 / vc.scaling_factor)[0]
         image = (image / 2 + 0.5).clamp(0, 1)
         return image if output_type == "pt" else image.cpu().permute(0, 2, 3, 1).float().numpy()
 
@@ -448,7 +458,7 @@ class StableDiffusion3Denoiser:
         if output_type not in ("pt", "np"):
             raise ValueError(f"output_type must be 'latent', 'pt' or 'np', got {output_type!r}")
         vc = self.vae.config
-        z = latents / vc.scaling_factor + getattr(vc, "shift_factor", 0.0)
+        z = latents / vc.scaling_factor + (getattr(vc, "shift_factor", None) or 0.0)
         image = (self.vae.decode(z, return_dict=False)[0] / 2 + 0.5).clamp(0, 1)
         return image if output_type == "pt" else image.cpu().permute(0, 2, 3, 1).float().numpy()
 

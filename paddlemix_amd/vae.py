@@ -39,7 +39,9 @@ Tensor = torch.Tensor
 
 VAE_DEFAULTS = dict(in_channels=3, out_channels=3, latent_channels=4, block_out_channels=(128, 256, 512, 512),
                     layers_per_block=2, norm_num_groups=32, act_fn="silu", scaling_factor=0.18215,
-                    use_post_quant_conv=True, use_quant_conv=True, sample_size=512, force_upcast=True)
+                    use_post_quant_conv=True, use_quant_conv=True, sample_size=512, force_upcast=True,
+                    # read by the pipelines off `vae.config` (autoencoder_kl.py:83-86 defaults): SD3's latent shift, SDXL's per-channel statistics
+                    shift_factor=None, latents_mean=None, latents_std=None)
 _MAX_ELEMS = 1 << 30   # largest activation (elements) one launch may address; bigger batches are decoded in slices
 
 

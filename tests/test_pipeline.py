@@ -90,6 +90,13 @@ def test_pipeline_with_vae_decode_outputs_images():
     assert (img - ref).abs().max() < 2e-2
     arr = pipe(pe, num_inference_steps=2, guidance_scale=1.0, latents=lat0.clone(), output_type="np")
     assert arr.shape == (1, 32, 32, 3) and arr.dtype == np.float32
+    # a VAE that publishes per-channel latent statistics (pipeline_stable_diffusion_xl.py:1105-1110): latents * std / sf + mean
+    stats = dict(MINI_VAE, latents_mean=[0.1, -0.2, 0.3, 0.0], latents_std=[1.5, 0.5, 1.0, 2.0])
+    pipe_s = StableDiffusionDenoiser(pipe.unet, pipe.scheduler, vae=AutoencoderKL(stats, Pv, _test_backend=Emulator()))
+    img_s = pipe_s.decode_latents(lat, "pt")
+    z = lat * torch.tensor(stats["latents_std"]).reshape(1, 4, 1, 1) / MINI_VAE["scaling_factor"] + torch.tensor(stats["latents_mean"]).reshape(1, 4, 1, 1)
+    ref_s = (V.decode(Pr, MINI_VAE, z) / 2 + 0.5).clamp(0, 1)
+    assert (img_s - ref_s).abs().max() < 2e-2 and (img_s - img).abs().max() > 5e-2
     import pytest
     with pytest.raises(ValueError):
         StableDiffusionDenoiser(pipe.unet, pipe.scheduler)(pe, num_inference_steps=1, guidance_scale=1.0,
