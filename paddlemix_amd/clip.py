@@ -268,6 +268,21 @@ class CLIPTextModel(DeviceProgram, PretrainedMixin):
 
     __call__ = forward
 
+    def final_layer_norm(self, hidden: Tensor) -> Tensor:
+        """``text_model.final_layer_norm`` on arbitrary hidden states [B, S, D] -- what the single-encoder pipelines apply to the
+        clip_skip layer (pipeline_stable_diffusion.py:378-391); also reachable as ``model.text_model.final_layer_norm``."""
+        D = self.cfg["hidden_size"]
+        x = hidden.reshape(-1, D).to(_lib.elem_dtype()).contiguous()
+        out = torch.empty_like(x)
+        s = 0 if self._emulated else torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._lib.mi355x_sd_layernorm(x.data_ptr(), x.shape[0], D, D, self.w["lnf.g"].data_ptr(), self.w["lnf.b"].data_ptr(),
+                                                 float(self.cfg["layer_norm_eps"]), out.data_ptr(), D, s))
+        return out.reshape(hidden.shape).float()
+
+    @property
+    def text_model(self):
+        return SimpleNamespace(final_layer_norm=self.final_layer_norm)
+
     def _project(self, pooled: Tensor) -> Tensor:
         """text_projection (bias-free Linear) of the pooled rows through the C ABI."""
         w = self.w["proj.w"]

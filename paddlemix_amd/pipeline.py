@@ -45,7 +45,9 @@ class StableDiffusionDenoiser:
         if self.text_encoder_2 is None:
             if clip_skip is None:
                 return self.text_encoder(input_ids)[0], None
-            raise NotImplementedError("clip_skip for the single-encoder pipeline")
+            # :378-391: the hidden state clip_skip layers before the last, then the encoder's final LayerNorm
+            hidden = self.text_encoder(input_ids, output_hidden_states=True).hidden_states[-(clip_skip + 1)]
+            return self.text_encoder.text_model.final_layer_norm(hidden), None
         embeds, pooled = [], None
         for enc, ids in ((self.text_encoder, input_ids), (self.text_encoder_2, input_ids if input_ids_2 is None else input_ids_2)):
             out = enc(ids, output_hidden_states=True)

@@ -755,6 +755,31 @@ def encode_prompt_inputs():
                 P2=K.synth_clip_params(c2, seed=3), P3=T.synth_t5_params(t5, seed=6))
 
 
+def _encode_prompt_sd_clip_skip_case(ref):
+    """StableDiffusionPipeline.encode_prompt with clip_skip (pipeline_stable_diffusion.py:378-391): the hidden state clip_skip layers
+    before the last one, passed through the text encoder's final LayerNorm."""
+    import torch.nn.functional as F
+    from oracle import clip_ref as K
+    E = encode_prompt_inputs()
+    a = E["ids"]["a"][None]
+    with torch.no_grad():
+        o = K.clip_text_forward(E["P1"], E["c1"], a)
+        D = E["c1"]["hidden_size"]
+        skip1 = F.layer_norm(o["hidden_states"][-2], (D,), E["P1"]["text_model.final_layer_norm.weight"], E["P1"]["text_model.final_layer_norm.bias"], 1e-5)
+        out = {"oracle": {"prompt_embeds": o["last_hidden_state"], "prompt_embeds_clip_skip_1": skip1}, "reference": None}
+        if ref:
+            rr = _rr()
+            pm = rr.ref_pipeline("pipeline_stable_diffusion")
+            (te,) = _text_encoders(rr, [("clip", E["c1"], E["P1"])])
+            unet_stub = type("U", (), {"config": rr.FrozenConfig(sample_size=8), "dtype": torch.float32})()
+            pipe = pm.StableDiffusionPipeline(vae=_FakeVAE(rr), text_encoder=te, tokenizer=_FakeTokenizer(rr, E["ids"]), unet=unet_stub, scheduler=type("S", (), {"config": rr.FrozenConfig()})(),
+                                              safety_checker=None, feature_extractor=None, requires_safety_checker=False)
+            pe, _ = pipe.encode_prompt("a", 1, False)
+            ps, _ = pipe.encode_prompt("a", 1, False, clip_skip=1)
+            out["reference"] = {"prompt_embeds": rr.from_shim(pe), "prompt_embeds_clip_skip_1": rr.from_shim(ps)}
+    return out
+
+
 def _encode_prompt_sdxl_case(ref):
     """StableDiffusionXLPipeline.encode_prompt (pipeline_stable_diffusion_xl.py:262-460): hidden_states[-2] of both encoders side by
     side, pooled = the second encoder's projected EOS row, zeros for the empty negative prompt (force_zeros_for_empty_prompt)."""
@@ -896,6 +921,7 @@ CASES = {
     "pipe_sd_ddim_cfg_rescale": _pipe_sd_case,
     "pipe_sdxl_euler_cfg_microcond": _pipe_sdxl_case,
     "pipe_sd3_flow_match_cfg": _pipe_sd3_case,
+    "encode_prompt_sd_clip_skip": _encode_prompt_sd_clip_skip_case,
     "encode_prompt_sdxl": _encode_prompt_sdxl_case,
     "encode_prompt_sd3": _encode_prompt_sd3_case,
     "pipe_dit_class_cfg": _pipe_dit_case,

@@ -54,6 +54,14 @@ def test_mini_clip_vs_oracle():
     assert torch.equal(out2.last_hidden_state, out.last_hidden_state)
     eager = CLIPTextModelWithProjection(cfg, P, use_graph=False)(ids.cuda())
     assert torch.equal(eager.last_hidden_state, out.last_hidden_state)
+    # clip_skip of the single-encoder pipelines (pipeline_stable_diffusion.py:378-391): final LayerNorm of an earlier hidden state
+    import torch.nn.functional as F
+    from paddlemix_amd.pipeline import StableDiffusionDenoiser
+    skip = StableDiffusionDenoiser(None, None, text_encoder=model).encode_prompt(ids.cuda(), clip_skip=1)[0]
+    want = F.layer_norm(ref["hidden_states"][-2], (cfg["hidden_size"],), P["text_model.final_layer_norm.weight"], P["text_model.final_layer_norm.bias"], 1e-5)
+    assert _rel(skip, want) < 1.5e-2, _rel(skip, want)
+    # the last hidden state through the same method is the model's own output
+    assert _rel(model.text_model.final_layer_norm(out.hidden_states[-1]), ref["last_hidden_state"]) < 1.5e-2
 
 
 def test_clip_l_architecture():

@@ -177,6 +177,9 @@ def test_product_encode_prompt_follows_the_reference_pipelines():
         assert x.shape == g.shape, (x.shape, g.shape)
         return float((x.float() - g).norm() / g.norm())
 
+    sd = StableDiffusionDenoiser(None, None, text_encoder=CLIPTextModel(E["c1"], E["P1"], _test_backend=Emulator()))
+    assert rel(sd.encode_prompt(a)[0], "encode_prompt_sd_clip_skip", "prompt_embeds") < 1.5e-2
+    assert rel(sd.encode_prompt(a, clip_skip=1)[0], "encode_prompt_sd_clip_skip", "prompt_embeds_clip_skip_1") < 1.5e-2
     xl = StableDiffusionDenoiser(None, None, text_encoder=CLIPTextModel(E["c1"], E["P1"], _test_backend=Emulator()),
                                  text_encoder_2=CLIPTextModelWithProjection(E["c2"], E["P2"], _test_backend=Emulator()))
     pe, pooled = xl.encode_prompt(a, b)
