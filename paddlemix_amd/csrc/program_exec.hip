@@ -165,10 +165,12 @@ int mi355x_sd_program_load(const char* path, void** handle) {
     g.data_off = r.get<uint64_t>();
     g.name = r.str();
     if (g.kind > R_IO) return bail(MI355X_SD_ERR_INVALID, "bad region kind");
+    if (g.bytes > (1ull << 40)) return bail(MI355X_SD_ERR_INVALID, "implausible region size");
     g.dev_off = off;
     off += round_up(g.bytes);
     p->regions.push_back(std::move(g));
   }
+  if (!r.ok || p->regions.size() != n_regions) return bail(MI355X_SD_ERR_INVALID, "truncated file (region table)");
   p->workspace_off = off;
   p->device_bytes = off + round_up(p->workspace_bytes);
   for (uint32_t k = 0; k < n_io && r.ok; ++k) {
@@ -182,6 +184,7 @@ int mi355x_sd_program_load(const char* path, void** handle) {
     if (io.region >= n_regions || io.ndim > 4) return bail(MI355X_SD_ERR_INVALID, "bad I/O entry");
     p->ios.push_back(std::move(io));
   }
+  if (!r.ok || p->ios.size() != n_io) return bail(MI355X_SD_ERR_INVALID, "truncated file (I/O table)");
   const auto& table = op_table();
   for (uint32_t k = 0; k < n_ops && r.ok; ++k) {
     const std::string name = r.str();
