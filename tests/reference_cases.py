@@ -72,7 +72,8 @@ def _unet_case(cfg, *, seed=1, masks=None, class_labels=None, controlnet_residua
             kw["down_block_additional_residuals"] = tuple(0.3 * torch.randn(s, generator=g) for s in shapes)
             kw["mid_block_additional_residual"] = 0.3 * torch.randn(B, c1, hw // 2, hw // 2, generator=g)
         with torch.no_grad():
-            out = {"oracle": {"sample": U.unet_forward(P, cfg, x, t, enc, **kw)}, "reference": None}
+            out = {"oracle": {"sample": U.unet_forward(P, cfg, x, t, enc, **kw)}, "reference": None,
+                   "inputs": dict(cfg=cfg, P=P, x=x, t=t, enc=enc, kw=kw)}
             if ref:
                 rr = _rr()
                 net = rr.build_unet(cfg, P)
@@ -167,7 +168,8 @@ def _controlnet_case(order, guess):
         cond, t = torch.randn(1, 3, 64, 64, generator=g), torch.tensor([20.0])
         with torch.no_grad():
             downs, mid = U.controlnet_forward(P, cfg, x, t, enc, cond, 0.7, guess)
-            out = {"oracle": {**{f"down{i}": d for i, d in enumerate(downs)}, "mid": mid}, "reference": None}
+            out = {"oracle": {**{f"down{i}": d for i, d in enumerate(downs)}, "mid": mid}, "reference": None,
+                   "inputs": dict(cfg=cfg, P=P, x=x, t=t, enc=enc, cond=cond, scale=0.7, guess=guess)}
             if ref:
                 rr = _rr()
                 kw = {k: v for k, v in cfg.items() if k not in ("up_block_types", "sample_size")}
@@ -190,7 +192,7 @@ def _dit_case(ref):
     g = torch.Generator().manual_seed(0)
     x, t, y = torch.randn(2, 4, 16, 16, generator=g), torch.tensor([3, 900]), torch.tensor([1, 7])
     with torch.no_grad():
-        out = {"oracle": {"sample": D.dit_forward(P, cfg, x, t, y)}, "reference": None}
+        out = {"oracle": {"sample": D.dit_forward(P, cfg, x, t, y)}, "reference": None, "inputs": dict(cfg=cfg, P=P, x=x, t=t, y=y)}
         if ref:
             rr = _rr()
             full = D.normalize_config(cfg)
@@ -219,7 +221,8 @@ def _sd3_case(trained_norm_bias):
         x, enc = torch.randn(2, 4, 16, 16, generator=g), torch.randn(2, 9, 64, generator=g)
         pooled, t = torch.randn(2, 64, generator=g), torch.tensor([3.0, 900.0])
         with torch.no_grad():
-            out = {"oracle": {"sample": S.sd3_forward(P, cfg, x, enc, pooled, t)}, "reference": None}
+            out = {"oracle": {"sample": S.sd3_forward(P, cfg, x, enc, pooled, t)}, "reference": None,
+                   "inputs": dict(cfg=cfg, P=P, x=x, enc=enc, pooled=pooled, t=t)}
             if ref:
                 rr = _rr()
                 net = rr.ref_module("transformer_sd3").SD3Transformer2DModel(**cfg)
@@ -246,7 +249,8 @@ def _vae_case(ref):
     z, img = torch.randn(2, 4, 8, 8, generator=g), torch.randn(2, 3, 32, 32, generator=g)
     with torch.no_grad():
         mean, logvar, _ = V.encode(P, cfg, img)
-        out = {"oracle": {"decode": V.decode(P, cfg, z), "encode_mean": mean, "encode_logvar": logvar}, "reference": None}
+        out = {"oracle": {"decode": V.decode(P, cfg, z), "encode_mean": mean, "encode_logvar": logvar}, "reference": None,
+               "inputs": dict(cfg=cfg, P=P, z=z, img=img)}
         if ref:
             rr = _rr()
             full = V.normalize_config(cfg)
@@ -281,7 +285,7 @@ def _clip_text_case(act):
         with torch.no_grad():
             o = K.clip_text_forward(P, cfg, ids)
             out = {"oracle": {"last_hidden_state": o["last_hidden_state"], "text_embeds": o["text_embeds"],
-                              "penultimate": o["hidden_states"][-2]}, "reference": None}
+                              "penultimate": o["hidden_states"][-2]}, "reference": None, "inputs": dict(cfg=cfg, P=P, ids=ids)}
             if ref:
                 rr = _rr()
                 conf = _transformers_module(rr, "clip.configuration").CLIPTextConfig(**{k: v for k, v in cfg.items() if k != "with_projection"})
@@ -313,7 +317,8 @@ def _clip_vision_case(ref):
     px = torch.randn(2, 3, 56, 56, generator=g)
     with torch.no_grad():
         o = K.clip_vision_forward(P, cfg, px)
-        out = {"oracle": {"image_embeds": o["image_embeds"], "penultimate": o["hidden_states"][-2]}, "reference": None}
+        out = {"oracle": {"image_embeds": o["image_embeds"], "penultimate": o["hidden_states"][-2]}, "reference": None,
+               "inputs": dict(cfg=cfg, P=P, px=px)}
         if ref:
             rr = _rr()
             conf = _transformers_module(rr, "clip.configuration").CLIPVisionConfig(**cfg)
@@ -331,7 +336,7 @@ def _t5_case(ref):
     P = T.synth_t5_params(cfg, seed=6)
     ids = torch.randint(0, 500, (2, 33), generator=torch.Generator().manual_seed(0))
     with torch.no_grad():
-        out = {"oracle": {"last_hidden_state": T.t5_encoder_forward(P, cfg, ids)}, "reference": None}
+        out = {"oracle": {"last_hidden_state": T.t5_encoder_forward(P, cfg, ids)}, "reference": None, "inputs": dict(cfg=cfg, P=P, ids=ids)}
         if ref:
             rr = _rr()
             conf = _transformers_module(rr, "t5.configuration").T5Config(**T.normalize_config(cfg))
