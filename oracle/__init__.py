@@ -33,6 +33,9 @@ Parity pin status:
     tests/test_reference_modules.py holds the oracle to them everywhere and to a live run
     where /root/reference exists.  This pins the restatement's STRUCTURE -- parameter names
     and shapes, wiring, axes, scales, epsilons, the order of scheduler updates;
+    At the real architectures (SD-1.5, SDXL, SD3-medium parameter sets) the stored per-step
+    predictions of tests/golden/parity/*.npz are reproduced bit for bit by the reference's
+    model classes (scripts/check_parity_fixtures_against_reference.py);
   * what remains unpinned: Paddle's own kernels (the array library under the reference's
     code is torch's here) and real checkpoints (none exist in this environment).
 """

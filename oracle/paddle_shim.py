@@ -1,18 +1,20 @@
 """TEST INFRASTRUCTURE (oracle/): a torch-CPU stand-in for the `paddle` package, just large enough to EXECUTE THE REFERENCE'S OWN
-MODEL CODE for the hot path -- ppdiffusers/ppdiffusers/models/{unet_2d_condition, unet_2d_blocks, resnet, transformer_2d, attention,
-attention_processor, embeddings, activations, normalization, lora}.py, loaded unmodified from /root/reference by
-oracle/reference_runner.py -- in this container, where PaddlePaddle itself cannot be installed.
+PYTHON for the hot path and its callers -- ppdiffusers/ppdiffusers/models/*.py (UNet, ControlNet, DiT, SD3 MMDiT, AutoencoderKL and
+their blocks, attention processors, embeddings, LoRA layers), schedulers/scheduling_*.py, transformers/{clip,t5}/modeling.py,
+image_processor.py and pipelines/*/pipeline_*.py -- loaded unmodified from /root/reference by oracle/reference_runner.py, in this
+container, where PaddlePaddle itself cannot be installed.
 
 Why: the oracle (oracle/unet_ref.py ...) is a restatement of that code; until round 3 its whole-model numerics were "unpinned"
 (only the RNG-free scheduler / embedding vectors of the reference's tests pinned it). Running the reference's module graph --
-its constructors, its forward methods, its attention processors, its reshapes / transposes / concatenations, verbatim -- on
-the oracle's parameters and inputs and comparing the outputs pins the STRUCTURE of the restatement (what is wired to what, which
-axis, which scale, which epsilon) to the reference itself. What it does not pin is Paddle's own kernels: every array operation
-below is torch's fp32 CPU implementation of the documented Paddle semantics (paddle.nn.Linear keeps weight [in, out];
-Tensor.transpose takes a permutation; chunk / split / concat take `axis`; GroupNorm / LayerNorm epsilon arguments are `epsilon`).
+its constructors, its forward methods, its attention processors, its reshapes / transposes / concatenations, its sampling and
+pipeline loops, verbatim -- on the oracle's parameters and inputs and comparing the outputs pins the STRUCTURE of the restatement
+(what is wired to what, which axis, which scale, which epsilon, which order of random draws) to the reference itself. What it does
+not pin is Paddle's own kernels: every array operation below is torch's fp32 CPU implementation of the documented Paddle
+semantics (paddle.nn.Linear keeps weight [in, out]; Tensor.transpose takes a permutation; reshape's 0 copies a dimension; chunk /
+split / concat take `axis`; a tied parameter is listed once in a state dict; GroupNorm / LayerNorm take `epsilon`).
 
 Only what those files use is implemented; anything else raises AttributeError / NotImplementedError loudly. Nothing outside
-tests/ and scripts/make_reference_golden.py imports this module.
+tests/, scripts/make_reference_golden.py and scripts/check_parity_fixtures_against_reference.py imports this module.
 """
 from __future__ import annotations
 

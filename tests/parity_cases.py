@@ -7,7 +7,9 @@ then magnitudes below fp16's smallest normal 2^-14 set to zero): the bf16 build,
 by identical numbers, so one oracle trajectory serves every device mode.  Latent state and scheduler arithmetic: float64 on
 the host for oracle and device alike, so what is compared is the accumulated error of the noise predictions only.
 
-The oracle is the torch-CPU restatement of ppdiffusers, held to the reference's own module code by tests/test_reference_modules.py
+The oracle is the torch-CPU restatement of ppdiffusers, held to the reference's own module code by tests/test_reference_modules.py;
+the stored per-step predictions of these fixtures are reproduced bit for bit by the reference's own model classes at these real
+architectures (scripts/check_parity_fixtures_against_reference.py, profiles/r03_parity_fixtures_vs_reference.txt)
 (Paddle itself cannot be installed here: see oracle/__init__.py for what that leaves unpinned).
 """
 from __future__ import annotations

@@ -191,6 +191,31 @@ def test_product_encode_prompt_follows_the_reference_pipelines():
     assert rel(pe, "encode_prompt_sd3", "prompt_embeds") < 1.5e-2 and rel(pooled, "encode_prompt_sd3", "pooled") < 2e-2
 
 
+@pytest.mark.skipif(not reference_runner.available(), reason="/root/reference exists only in the build container")
+def test_full_size_parity_fixture_is_the_references_prediction():
+    """tests/golden/parity/sd15_1x4x64x64_ddim50.npz (what tests/test_gpu_parity_loops.py replays on the device) against the reference's
+    own UNet2DConditionModel at the real SD-1.5 architecture (859.5 M parameters): the stored first-step prediction is reproduced.
+    scripts/check_parity_fixtures_against_reference.py does this for every stored step of every fixture, SDXL and SD3-medium included
+    (profiles/r03_parity_fixtures_vs_reference.txt)."""
+    import os as _os
+
+    from tests import parity_cases as PC
+    name = "sd15_1x4x64x64_ddim50"
+    case = PC.CASES[name]
+    fx = np.load(_os.path.join(PC.GOLDEN_DIR, name + ".npz"))
+    P = PC.case_params(case)
+    assert sum(v.numel() for v in P.values()) == 859_520_964
+    _, enc, extra = PC.case_inputs(case)
+    net = reference_runner.build_unet(case["cfg"], P)
+    step = int(fx["kept"][0])
+    with torch.no_grad():
+        ref = reference_runner.from_shim(net(reference_runner.to_shim(torch.from_numpy(fx["x_in"][0])),
+                                             reference_runner.to_shim(torch.tensor([float(int(fx["sched"][step][0]))])),
+                                             reference_runner.to_shim(enc)).sample)
+    want = torch.from_numpy(fx["pred"][0])
+    assert _rel(ref, want) < 5e-6, _rel(ref, want)
+
+
 class _Bridge:
     """The reference pipeline hands `paddle` tensors (here: shim tensors) to whatever sits in its unet / transformer slot; the MI355X
     models take device tensors. This is the glue INTEGRATION.md section 4b describes (tensor -> pointer and back), nothing else:
