@@ -5,7 +5,6 @@ oracle/paddle_shim.py in the build container, scripts/make_reference_golden.py).
 and inputs (tests/reference_cases.py regenerates them from their seeds; only the oracle side of a case runs, to rebuild the inputs)
 and are compared with those committed reference outputs directly. Stated tolerance: rel-L2 <= 2e-2 for 16-bit weights and
 activations with fp32 accumulation (the weights are rounded to the element type on load; the reference ran them in fp32)."""
-import os
 
 import numpy as np
 import pytest
