@@ -1136,5 +1136,3 @@ def build_modules():
             "paddle.distributed.fleet": fleet, "paddle.distributed.fleet.utils": futils, "paddle.incubate": incubate,
             "paddle.framework": paddle.framework, "paddle.device": paddle.device}
 
-
-_ = math  # (kept for interactive use)
