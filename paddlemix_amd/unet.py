@@ -95,6 +95,18 @@ def normalize_config(config: Mapping) -> dict:
         raise ValueError(f"`class_embed_type`: '{ct}' requires `projection_class_embeddings_input_dim` be set")
     if cfg["class_embeddings_concat"] and cfg["addition_embed_type"] is not None:
         raise NotImplementedError("class_embeddings_concat together with addition_embed_type")
+    # "Check inputs" of the reference's constructor (unet_2d_condition.py:247-281; same messages, same order)
+    dbt, ubt = cfg["down_block_types"], cfg["up_block_types"]
+    if len(dbt) != len(ubt):
+        raise ValueError(f"Must provide the same number of `down_block_types` as `up_block_types`. `down_block_types`: {dbt}. "
+                         f"`up_block_types`: {ubt}.")
+    for key, shown, seq in (("block_out_channels", "block_out_channels", (list, tuple)), ("only_cross_attention", "only_cross_attention", (list, tuple)),
+                            ("attention_head_dim", "num_attention_heads", (list, tuple)),   # num_attention_heads = attention_head_dim (:245)
+                            ("attention_head_dim", "attention_head_dim", (list, tuple)), ("cross_attention_dim", "cross_attention_dim", (list,)),
+                            ("layers_per_block", "layers_per_block", (list, tuple))):
+        v = cfg[key]
+        if isinstance(v, seq) and len(v) != len(dbt):
+            raise ValueError(f"Must provide the same number of `{shown}` as `down_block_types`. `{shown}`: {v}. `down_block_types`: {dbt}.")
     n = len(cfg["down_block_types"])
     tup = lambda x: tuple(x) if isinstance(x, (list, tuple)) else (x,) * n  # noqa: E731
     cfg["block_out_channels"] = tuple(cfg["block_out_channels"])

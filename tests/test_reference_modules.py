@@ -216,6 +216,42 @@ def test_full_size_parity_fixture_is_the_references_prediction():
     assert _rel(ref, want) < 5e-6, _rel(ref, want)
 
 
+@pytest.mark.skipif(not reference_runner.available(), reason="/root/reference exists only in the build container")
+def test_error_behaviour_is_the_references():
+    """same conditions, same exception type, same text (the class path in the text aside): constructor input checks
+    (unet_2d_condition.py:247-281) and the forward's missing-conditioning errors (:959, :991-1002)"""
+    from oracle import unet_ref as U
+    from paddlemix_amd.unet import UNet2DConditionModel
+    from tests.abi_emulator import Emulator
+    from tests.configs import MINI_XL, TINY
+    rm = reference_runner.ref_module("unet_2d_condition")
+
+    def message(fn):
+        try:
+            fn()
+        except Exception as e:   # noqa: BLE001
+            return type(e).__name__, str(e).replace("ppdiffusers.models.unet_2d_condition", "X").replace("paddlemix_amd.unet", "X")
+        return None
+
+    for bad in (dict(TINY, up_block_types=("UpBlock2D",)), dict(TINY, block_out_channels=(64, 128, 256)), dict(TINY, attention_head_dim=(8,)),
+                dict(TINY, layers_per_block=(1,)), dict(TINY, only_cross_attention=(True,)), dict(TINY, cross_attention_dim=[64]),
+                dict(TINY, encoder_hid_dim_type="ip_image_proj")):
+        want = message(lambda: rm.UNet2DConditionModel(**bad))
+        got = message(lambda: UNet2DConditionModel(bad, {}, _test_backend=Emulator()))
+        assert want is not None and got == want, (bad, want, got)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 4, 16, 16, generator=g)
+    for cfg, kw in ((MINI_XL, dict(added_cond_kwargs={})), (MINI_XL, dict(added_cond_kwargs={"text_embeds": torch.zeros(1, 64)})),
+                    (dict(TINY, num_class_embeds=10), {})):
+        P = U.synth_unet_params(cfg, seed=1)
+        enc = torch.randn(1, 7, cfg["cross_attention_dim"], generator=g)
+        ref, prod = reference_runner.build_unet(cfg, P), UNet2DConditionModel(cfg, P, _test_backend=Emulator())
+        sh = reference_runner.to_shim
+        want = message(lambda: ref(sh(x), sh(torch.tensor([10.0])), sh(enc), **sh(kw)))
+        got = message(lambda: prod(x, 10.0, enc, **kw))
+        assert want is not None and want[0] == "ValueError" and got == want, (want, got)
+
+
 class _Bridge:
     """The reference pipeline hands `paddle` tensors (here: shim tensors) to whatever sits in its unet / transformer slot; the MI355X
     models take device tensors. This is the glue INTEGRATION.md section 4b describes (tensor -> pointer and back), nothing else:
