@@ -363,9 +363,12 @@ def downsample(P: Params, name: str, x: Tensor, padding: int = 1) -> Tensor:
     return conv2d(P, name + ".conv", x, stride=2, padding=padding)
 
 
-def upsample(P: Params, name: str, x: Tensor) -> Tensor:
-    """Upsample2D.forward: nearest x2 then conv3x3 (resnet.py:169-218)."""
-    x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+def upsample(P: Params, name: str, x: Tensor, output_size=None) -> Tensor:
+    """Upsample2D.forward: nearest x2 -- or to `output_size` when the UNet forwards the skip's size -- then conv3x3 (resnet.py:169-218)."""
+    if output_size is None:
+        x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+    else:
+        x = F.interpolate(x, size=tuple(int(s) for s in output_size), mode="nearest")
     return conv2d(P, name + ".conv", x)
 
 
@@ -494,6 +497,7 @@ def unet_forward(P: Params, config: dict, sample: Tensor, timestep, encoder_hidd
         return downs, conv2d(P, "controlnet_mid_block", x, padding=0)
 
     # up (:1158-1191)
+    forward_upsample_size = any(int(s) % (2 ** (n_blocks - 1)) != 0 for s in sample.shape[-2:])
     rev_heads = tuple(reversed(cfg["num_attention_heads"]))
     rev_layers = tuple(reversed(cfg["layers_per_block"]))
     rev_tlayers = tuple(reversed(cfg["transformer_layers_per_block"]))
@@ -509,7 +513,8 @@ def unet_forward(P: Params, config: dict, sample: Tensor, timestep, encoder_hidd
             elif btype != "UpBlock2D":
                 raise NotImplementedError(btype)
         if i != n_blocks - 1:
-            x = upsample(P, f"up_blocks.{i}.upsamplers.0", x)
+            # latents that are not multiples of 2^(number of upsamplers) (:900-906, :1165-1169): the next skip's size is forced
+            x = upsample(P, f"up_blocks.{i}.upsamplers.0", x, skips[-1].shape[2:] if forward_upsample_size else None)
         if taps is not None:
             taps[f"up_{i}"] = x
 

@@ -1317,6 +1317,12 @@ int mi355x_sd_unet_plan_ex(void* handle, int B, int H, int W, int L, int flags, 
   try {
     Exec* e = H_(handle);
     if (!e->dev_w) die(MI355X_SD_ERR_INVALID, "mi355x_sd_unet_plan: call mi355x_sd_unet_finalize_weights first");
+    {   // the reference forwards the skips' sizes to its upsamplers for other sizes (unet_2d_condition.py:900-906); the conv gather folds an exact x2
+      const int up_factor = 1 << (int)(e->cfg.boc.size() - 1);
+      if (H % up_factor || W % up_factor)
+        die(MI355X_SD_ERR_UNSUPPORTED, "mi355x_sd_unet_plan: latent height and width must be multiples of " + std::to_string(up_factor) +
+                                           " (the forward_upsample_size path is not implemented)");
+    }
     if (e->graph) {
       (void)hipGraphExecDestroy(e->graph);
       e->graph = nullptr;

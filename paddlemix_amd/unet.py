@@ -505,6 +505,12 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
         boc = cfg["block_out_channels"]
         groups, eps = cfg["norm_num_groups"], float(cfg["norm_eps"])
         ted = boc[0] * 4
+        up_factor = 2 ** (len(boc) - 1)
+        if not self._encoder_only and (H % up_factor or Wd % up_factor):
+            # the reference then forwards each skip's size to its upsamplers (`forward_upsample_size`, unet_2d_condition.py:900-906,
+            # :1165-1169; Upsample2D interpolates to that size instead of x2); the conv gather here folds an exact x2 only
+            raise NotImplementedError(f"UNet2DConditionModel(mi355x): latent height and width must be multiples of {up_factor} "
+                                      f"(got {H} x {Wd}); the forward_upsample_size path is not implemented")
         plan = _Plan()
         prog: List[tuple] = []     # (cfunc, args(list with _Ref placeholders), kind, flops)
         scratch: Dict[str, int] = {}

@@ -893,6 +893,7 @@ CASES = {
     "unet_tiny": _unet_case(C.TINY),
     "unet_mini_xl": _unet_case(C.MINI_XL),
     **{"unet_" + k.replace("-", "_"): _unet_case(v) for k, v in C.UNET_VARIANTS.items()},
+    "unet_mini_xl_odd_size": _unet_case(C.MINI_XL, hw=18),          # 18 % 4 != 0: forward_upsample_size (unet_2d_condition.py:900-906)
     "unet_tiny_masks": _unet_case(C.TINY, masks=dict(self_len=64)),
     "unet_mini_xl_encoder_mask": _unet_case(C.MINI_XL, masks=dict()),
     "unet_class_embeds": _unet_case(dict(C.TINY, num_class_embeds=10), seed=4, class_labels=_labels("index")),

@@ -381,3 +381,23 @@ def test_semantics_changing_config_keys_are_refused(key, val):
     with pytest.raises(NotImplementedError, match=key):
         unet_param_shapes(dict(TINY, **{key: val}))
     unet_param_shapes(dict(TINY, attention_type="default", conv_in_kernel=3, dropout=0.0))   # defaults spelled out are fine
+
+
+def test_latent_sizes_the_upsamplers_cannot_double_are_refused():
+    """the reference forwards each skip's size to its upsamplers when the latent size is not a multiple of 2^(levels - 1)
+    (forward_upsample_size, unet_2d_condition.py:900-906; pinned in the oracle by the reference case unet_mini_xl_odd_size); the
+    device program folds an exact x2 into its conv gather and refuses such sizes loudly. The ControlNet (no upsamplers) takes them."""
+    import pytest
+    from paddlemix_amd.unet import ControlNetModel, UNet2DConditionModel, synth_controlnet_params, synth_unet_params
+    m = UNet2DConditionModel(MINI_XL, synth_unet_params(MINI_XL, seed=1), _test_backend=Emulator())
+    g = torch.Generator().manual_seed(0)
+    td = MINI_XL["projection_class_embeddings_input_dim"] - 6 * MINI_XL["addition_time_embed_dim"]
+    added = dict(text_embeds=torch.randn(1, td, generator=g), time_ids=torch.tensor([[1024., 1024., 0., 0., 1024., 1024.]]))
+    with pytest.raises(NotImplementedError, match="multiples of 4"):
+        m(torch.randn(1, 4, 18, 18, generator=g), 10.0, torch.randn(1, 7, 128, generator=g), added_cond_kwargs=added)
+    assert m(torch.randn(1, 4, 20, 12, generator=g), 10.0, torch.randn(1, 7, 128, generator=g), added_cond_kwargs=added).sample.shape == (1, 4, 20, 12)
+    cn = ControlNetModel(TINY, synth_controlnet_params(TINY, seed=3), _test_backend=Emulator())
+    d, mid = cn(torch.randn(1, 4, 15, 15, generator=g), 10.0, torch.randn(1, 7, 64, generator=g), torch.randn(1, 3, 120, 120, generator=g), return_dict=False)
+    ref_d, ref_mid = U.controlnet_forward({k: (v.to(torch.bfloat16).float() if v.dim() > 1 else v) for k, v in synth_controlnet_params(TINY, seed=3).items()}, TINY,
+                                          torch.randn(1, 4, 15, 15, generator=torch.Generator().manual_seed(99)), 10, torch.randn(1, 7, 64), torch.randn(1, 3, 120, 120))
+    assert tuple(mid.shape) == tuple(ref_mid.shape) == (1, 128, 8, 8) and [tuple(t.shape) for t in d] == [tuple(t.shape) for t in ref_d]
