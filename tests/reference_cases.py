@@ -879,6 +879,41 @@ def _pipe_dit_case(ref):
     return out
 
 
+def _scheduler_ddim_eta_case(ref):
+    """DDIM with eta > 0 (scheduling_ddim.py:350-475): the stochastic term std_dev_t * variance_noise on top of the deterministic
+    update, use_clipped_model_output, clip_sample; the noise is injected (variance_noise) so both sides see the same draws."""
+    from oracle import schedulers_ref as S
+    kw, steps, eta = dict(_SD, clip_sample=True, clip_sample_range=2.0, set_alpha_to_one=False, steps_offset=1), 10, 0.6
+    g = torch.Generator().manual_seed(0)
+    x0, pat = torch.randn(1, 4, 8, 8, generator=g), torch.randn(1, 4, 8, 8, generator=g)
+    draws = [torch.randn(1, 4, 8, 8, generator=g) for _ in range(steps)]
+    model = lambda x, t: 0.3 * x * math.cos(0.01 * float(t)) + 0.1 * pat  # noqa: E731
+    sch = S.DDIMRef(**kw)
+    sch.set_timesteps(steps)
+    x = x0.numpy().copy()
+    for i, t in enumerate(sch.timesteps):
+        eps = model(torch.from_numpy(x), t).numpy()
+        t_i = int(t)
+        prev_t = t_i - sch.T // steps
+        a_t = sch.alphas_cumprod[t_i]
+        a_prev = sch.alphas_cumprod[prev_t] if prev_t >= 0 else sch.final_alpha_cumprod
+        x_0 = np.clip((x - (1 - a_t) ** 0.5 * eps) / a_t ** 0.5, -2.0, 2.0)
+        std = eta * sch._get_variance(t_i, prev_t) ** 0.5
+        eps_c = (x - a_t ** 0.5 * x_0) / (1 - a_t) ** 0.5                      # use_clipped_model_output: epsilon re-derived from the clipped x0
+        x = (a_prev ** 0.5 * x_0 + (1 - a_prev - std ** 2) ** 0.5 * eps_c + std * draws[i].numpy()).astype(np.float32)
+    out = {"oracle": {"latents": torch.from_numpy(x)}, "reference": None}
+    if ref:
+        rr = _rr()
+        rs = rr.ref_module("scheduling_ddim", "schedulers").DDIMScheduler(**kw)
+        rs.set_timesteps(steps)
+        xr = rr.to_shim(x0.clone())
+        for i, t in enumerate(rs.timesteps):
+            eps = rr.to_shim(model(rr.from_shim(xr), rr.from_shim(t)))
+            xr = rs.step(eps, t, xr, eta=eta, use_clipped_model_output=True, variance_noise=rr.to_shim(draws[i]), return_dict=False)[0]
+        out["reference"] = {"latents": rr.from_shim(xr).float()}
+    return out
+
+
 def _labels(kind):
     return {
         "index": lambda g: torch.tensor([3, 8]),
@@ -952,6 +987,18 @@ CASES = {
     "sched_dpm_order1_leading": _scheduler_case("scheduling_dpmsolver_multistep", "DPMSolverMultistepScheduler", "DPMSolverMultistepRef",
                                                 dict(_SD, algorithm_type="dpmsolver", solver_order=1, timestep_spacing="leading", steps_offset=1), 10),
     "sched_lcm": _scheduler_case("scheduling_lcm", "LCMScheduler", "LCMRef", dict(_SD), 4, scale=False, noisy=True),
+    "sched_ddim_eta_clipped": _scheduler_ddim_eta_case,
+    # the other prediction types (SD-2.x checkpoints are v-prediction) and spacings
+    "sched_ddim_v_prediction": _scheduler_case("scheduling_ddim", "DDIMScheduler", "DDIMRef", dict(_SD, clip_sample=False, set_alpha_to_one=False, steps_offset=1,
+                                                                                                  prediction_type="v_prediction"), 12),
+    "sched_ddim_sample_prediction": _scheduler_case("scheduling_ddim", "DDIMScheduler", "DDIMRef", dict(_SD, clip_sample=False, prediction_type="sample"), 8),
+    "sched_euler_v_prediction_trailing": _scheduler_case("scheduling_euler_discrete", "EulerDiscreteScheduler", "EulerRef",
+                                                         dict(_SD, prediction_type="v_prediction", timestep_spacing="trailing"), 10),
+    "sched_pndm_v_prediction": _scheduler_case("scheduling_pndm", "PNDMScheduler", "PNDMRef", dict(_SD, skip_prk_steps=True, steps_offset=1, prediction_type="v_prediction"), 12),
+    "sched_dpmpp_v_prediction": _scheduler_case("scheduling_dpmsolver_multistep", "DPMSolverMultistepScheduler", "DPMSolverMultistepRef",
+                                                dict(_SD, prediction_type="v_prediction"), 12),
+    "sched_dpmpp_sample_prediction_euler_final": _scheduler_case("scheduling_dpmsolver_multistep", "DPMSolverMultistepScheduler", "DPMSolverMultistepRef",
+                                                                 dict(_SD, prediction_type="sample", euler_at_final=True, timestep_spacing="trailing"), 16),
 }
 
 
