@@ -102,7 +102,7 @@ def _stub_modules(shim):
                  is_pp_invisible_watermark_available=lambda: False, PIL_INTERPOLATION={}, CONFIG_NAME="config.json")
     utils = mod(f"{PKG}.utils", **flags)
     utils.__path__ = []
-    mod(f"{PKG}.utils.import_utils", is_ppxformers_available=lambda: False)
+    mod(f"{PKG}.utils.import_utils", is_ppxformers_available=lambda: False, is_torch_available=lambda: False)
     def randn_tensor(shape, generator=None, dtype=None, **_):
         """utils/paddle_utils.py randn_tensor: here the caller owns the draws -- `generator` is a callable shape -> torch tensor
         (the schedulers' deterministic paths draw and then multiply by zero: without one they get zeros)"""

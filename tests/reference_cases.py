@@ -914,6 +914,39 @@ def _scheduler_ddim_eta_case(ref):
     return out
 
 
+def _checkpoint_layout_case(ref):
+    """torch-layout checkpoint -> Paddle layouts: the reference's convert_pytorch_state_dict_to_paddle (models/
+    modeling_pytorch_paddle_utils.py:27-63: every nn.Linear weight transposed, embedding tables and conv kernels not) against the
+    PRODUCT's paddlemix_amd.checkpoint.to_paddle_layout on a UNet that has all three kinds (linear projections, a class-embedding
+    table, convs). "oracle" here is the product's host code; what is compared is a per-parameter digest of the converted tensors."""
+    from oracle import unet_ref as U
+    from paddlemix_amd.checkpoint import to_paddle_layout
+    from paddlemix_amd.unet import unet_param_shapes
+    cfg = dict(C.TINY, use_linear_projection=True, num_class_embeds=10)
+    P = U.synth_unet_params(cfg, seed=5)
+    shapes = unet_param_shapes(cfg)
+    # a torch-layout checkpoint of this model: what torch.nn.Linear stores is [out, in]
+    is_table = lambda k: k == "class_embedding.weight"  # noqa: E731
+    pt = {k: (v.t().contiguous() if v.dim() == 2 and not is_table(k) else v.clone()) for k, v in P.items()}
+
+    def digest(d):
+        keys = sorted(d)
+        return torch.tensor([float((torch.as_tensor(np.asarray(d[k])).double().flatten() * (torch.arange(1, torch.as_tensor(np.asarray(d[k])).numel() + 1) % 97).double()).sum())
+                             for k in keys], dtype=torch.float64)
+
+    ours = to_paddle_layout(pt, shapes, "pt")
+    assert all(torch.equal(ours[k], P[k]) for k in P)                      # and the round trip is exact
+    out = {"oracle": {"digest": digest(ours).float()}, "reference": None}
+    if ref:
+        rr = _rr()
+        net = rr.ref_module("unet_2d_condition").UNet2DConditionModel(**cfg)
+        conv = rr.ref_module("modeling_pytorch_paddle_utils").convert_pytorch_state_dict_to_paddle
+        theirs = conv(net, {k: v.numpy().copy() for k, v in pt.items()})
+        assert sorted(theirs) == sorted(P) and all(tuple(theirs[k].shape) == tuple(P[k].shape) for k in P)
+        out["reference"] = {"digest": digest(theirs).float()}
+    return out
+
+
 def _labels(kind):
     return {
         "index": lambda g: torch.tensor([3, 8]),
@@ -944,6 +977,7 @@ CASES = {
     "unet_ip_adapter": _ip_adapter_case(1.0),
     "unet_ip_adapter_scale_0p6": _ip_adapter_case(0.6),
     "lora_fuse": _lora_case,
+    "checkpoint_layout_pt_to_paddle": _checkpoint_layout_case,
     # ControlNetModel.forward (models/controlnet.py)
     "controlnet_rgb": _controlnet_case("rgb", False),
     "controlnet_bgr_guess_mode": _controlnet_case("bgr", True),
