@@ -505,12 +505,6 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
         boc = cfg["block_out_channels"]
         groups, eps = cfg["norm_num_groups"], float(cfg["norm_eps"])
         ted = boc[0] * 4
-        up_factor = 2 ** (len(boc) - 1)
-        if not self._encoder_only and (H % up_factor or Wd % up_factor):
-            # the reference then forwards each skip's size to its upsamplers (`forward_upsample_size`, unet_2d_condition.py:900-906,
-            # :1165-1169; Upsample2D interpolates to that size instead of x2); the conv gather here folds an exact x2 only
-            raise NotImplementedError(f"UNet2DConditionModel(mi355x): latent height and width must be multiples of {up_factor} "
-                                      f"(got {H} x {Wd}); the forward_upsample_size path is not implemented")
         plan = _Plan()
         prog: List[tuple] = []     # (cfunc, args(list with _Ref placeholders), kind, flops)
         scratch: Dict[str, int] = {}
@@ -766,12 +760,14 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
                      for cs, hs, ws_ in skips] if self._encoder_only else None   # no up path to host them
         cats: List[_V] = []
         cat_xc: List[int] = []
+        cat_hw: List[Tuple[int, int]] = []
         for u, d in enumerate(ups):  # up resnet u consumes skip n-1-u
             cs, hs, ws_ = skips[len(skips) - 1 - u]
             cx = d[2] - cs
             t = persist((B * hs * ws_, cx + cs), res_dt)
             cats.append(_V(t.data_ptr(), B * hs * ws_, cx + cs, es=RES))
             cat_xc.append(cx)
+            cat_hw.append((hs, ws_))
 
         def skip_slot(k: int) -> _V:  # where skip k is produced
             if own_skips is not None:
@@ -921,8 +917,31 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
                 u += 1
             elif d[0] == "up":
                 dst = x_slot(u)
-                conv3(cast16(cur, "xc16"), h, w_, d[1], dst, up=1)
-                h, w_ = 2 * h, 2 * w_
+                ht, wt = cat_hw[u]                 # the size of the skip the next resnet concatenates with
+                src = cast16(cur, "xc16")
+                if (ht, wt) == (2 * h, 2 * w_):
+                    conv3(src, h, w_, d[1], dst, up=1)     # nearest x2 folded into the conv's gather
+                else:
+                    # `forward_upsample_size` (unet_2d_condition.py:900-906, :1165-1169; Upsample2D interpolates to the skip's size):
+                    # latents that are not multiples of 2^(levels - 1) leave a skip of odd size 2h - 1, and nearest interpolation
+                    # from h to 2h - 1 reads source row y >> 1 like the x2 form, cropped. The crop moves the zero padding of the
+                    # conv, so the upsampled tensor is materialised here (strided row copies: one per source row and parity --
+                    # many small launches, on this rare path only) and a plain 3x3 conv follows.
+                    assert ht in (2 * h - 1, 2 * h) and wt in (2 * w_ - 1, 2 * w_), (h, w_, ht, wt)
+                    C_ = src.C
+                    upb = _V(sc("upx", 2 * B * ht * wt * C_), B * ht * wt, C_)
+                    for b in range(B):
+                        for i_ in range(h):
+                            for dy in (0, 1):
+                                y = 2 * i_ + dy
+                                if y >= ht:
+                                    continue
+                                for dx in (0, 1):
+                                    n = (wt - dx + 1) // 2
+                                    emit(lib.mi355x_sd_copy_rows, (src.p + 2 * ((b * h + i_) * w_) * src.ld, src.ld,
+                                                                    upb.p + 2 * ((b * ht + y) * wt + dx) * C_, 2 * C_, n, C_, stream), "misc")
+                    conv3(upb, ht, wt, d[1], dst)
+                h, w_ = ht, wt
                 cur = dst
             i += 1
         assert k == len(skips) and u == len(ups) and ((h, w_) == (H, Wd) or self._encoder_only)

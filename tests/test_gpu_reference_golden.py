@@ -33,7 +33,7 @@ def _c(x):
 
 
 UNET_CASES = ["unet_tiny", "unet_mini_xl", "unet_sd2_layout", "unet_tiny_masks", "unet_mini_xl_encoder_mask", "unet_class_embeds",
-              "unet_class_projection", "unet_controlnet_residuals"]
+              "unet_class_projection", "unet_controlnet_residuals", "unet_mini_xl_odd_size"]
 
 
 def _row(v, b):
