@@ -5,11 +5,13 @@ package: only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
 leg of ``bench.py`` use it, and only as the checker / reported CPU baseline.
 
 What it is: a torch-CPU fp32 (optionally fp64) restatement of the reference's
-UNet2DConditionModel / SD3 MMDiT forward and of the three schedulers on the
-path.  PaddlePaddle is not installable in this environment (``import paddle``
-fails, no network; pinned upstream: paddlepaddle-gpu==3.0.0b1,
-/root/reference/build_paddle_env.sh:28-42), so the reference itself cannot be
-executed; every function cites the reference file:line it follows.
+UNet2DConditionModel / ControlNet / DiT / SD3 MMDiT / AutoencoderKL / CLIP / T5
+forwards and of the six schedulers on the path; every function cites the
+reference file:line it follows.  PaddlePaddle is not installable in this
+environment (``import paddle`` fails, no network; pinned upstream:
+paddlepaddle-gpu==3.0.0b1, /root/reference/build_paddle_env.sh:28-42), so the
+reference cannot run on Paddle here -- its Python runs over
+``oracle/paddle_shim.py`` instead (next paragraph).
 
 Parity pin status:
   * pinned by the reference's own RNG-free known-answer tests:
