@@ -57,9 +57,10 @@ def _unet_case(cfg, *, seed=1, masks=None, class_labels=None, controlnet_residua
         t = torch.tensor([10.0, 500.0])[:B]
         kw = {}
         if cfg.get("addition_embed_type") == "text_time":
-            td = cfg["projection_class_embeddings_input_dim"] - 6 * cfg["addition_time_embed_dim"]
+            n_ids = cfg.get("_n_time_ids", 6)      # 6: SDXL base (sizes, crop, target); 5: the refiner (sizes, crop, aesthetic score)
+            td = cfg["projection_class_embeddings_input_dim"] - n_ids * cfg["addition_time_embed_dim"]
             kw["added_cond_kwargs"] = dict(text_embeds=torch.randn(B, td, generator=g),
-                                           time_ids=torch.tensor([[1024.0, 1024.0, 0.0, 0.0, 1024.0, 1024.0]]).repeat(B, 1))
+                                           time_ids=torch.tensor([[1024.0, 1024.0, 0.0, 0.0, 1024.0, 1024.0][:n_ids - 1] + [6.0 if n_ids == 5 else 1024.0]]).repeat(B, 1))
         if masks:
             if masks.get("self_len"):
                 kw["attention_mask"] = (torch.rand(B, masks["self_len"], generator=g) > 0.2).float()
@@ -961,6 +962,7 @@ CASES = {
     "unet_tiny": _unet_case(C.TINY),
     "unet_mini_xl": _unet_case(C.MINI_XL),
     **{"unet_" + k.replace("-", "_"): _unet_case(v) for k, v in C.UNET_VARIANTS.items()},
+    "unet_mini_xl_refiner_5_time_ids": _unet_case(dict(C.MINI_XL, projection_class_embeddings_input_dim=32 * 5 + 64, _n_time_ids=5)),
     "unet_mini_xl_odd_size": _unet_case(C.MINI_XL, hw=18),          # 18 % 4 != 0: forward_upsample_size (unet_2d_condition.py:900-906)
     "unet_tiny_masks": _unet_case(C.TINY, masks=dict(self_len=64)),
     "unet_mini_xl_encoder_mask": _unet_case(C.MINI_XL, masks=dict()),
