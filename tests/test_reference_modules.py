@@ -257,6 +257,8 @@ class _Bridge:
     models take device tensors. This is the glue INTEGRATION.md section 4b describes (tensor -> pointer and back), nothing else:
     attribute access (`.config`, `.dtype`) and the call signature are the product model's own."""
 
+    dtype = torch.float32     # what the pipeline casts its embeddings to before the call; the bridge hands the model fp32 tensors
+
     def __init__(self, model):
         self._m = model
 
@@ -358,6 +360,24 @@ def test_product_models_drop_into_the_reference_pipelines_call():
     out = pipe(prompt_embeds=rr.to_shim(pe), image=rr.to_shim(image), mask_image=rr.to_shim(mask_px), strength=0.6, num_inference_steps=10,
                guidance_scale=1.0, output_type="latent", height=32, width=32, return_dict=False, generator=lambda shape: torch.randn(shape, generator=gg))[0]
     assert rel(rr.from_shim(out), "pipe_inpaint_9ch_euler") < 5e-2
+    # StableDiffusionControlNetPipeline: the reference's ControlNetModel feeds its residuals to the MI355X UNet the way the pipeline
+    # passes them (down_block_additional_residuals list + mid_block_additional_residual), plain and in guess mode
+    g = torch.Generator().manual_seed(0)
+    pe, ne = torch.randn(1, 7, 64, generator=g), torch.randn(1, 7, 64, generator=g)
+    lat0, hint = torch.randn(1, 4, 8, 8, generator=g), torch.rand(1, 3, 64, 64, generator=g)
+    pmc = rr.ref_pipeline("pipeline_controlnet", "pipelines.controlnet")
+    cn = rr.ref_module("controlnet").ControlNetModel(**{k: v for k, v in TINY.items() if k not in ("up_block_types", "sample_size")})
+    cn.eval()
+    rr.load_params(cn, RC._synth(U.controlnet_param_shapes(TINY), 8))
+    unet = _Bridge(UNet2DConditionModel(TINY, U.synth_unet_params(TINY, seed=1), _test_backend=Emulator()))
+    pipe = pmc.StableDiffusionControlNetPipeline(vae=RC._FakeVAE(rr, scaling_factor=0.18215), text_encoder=None, tokenizer=None, unet=unet, controlnet=cn,
+                                                 scheduler=rr.ref_module("scheduling_ddim", "schedulers").DDIMScheduler(clip_sample=False, set_alpha_to_one=False, **SD),
+                                                 safety_checker=None, feature_extractor=None, requires_safety_checker=False)
+    for name, guess, sc in (("pipe_controlnet", False, 0.8), ("pipe_controlnet_guess_mode", True, 1.0)):
+        out = pipe(prompt_embeds=rr.to_shim(pe), negative_prompt_embeds=rr.to_shim(ne), image=rr.to_shim(hint), latents=rr.to_shim(lat0.clone()),
+                   num_inference_steps=3, guidance_scale=5.0, controlnet_conditioning_scale=sc, guess_mode=guess, output_type="latent", height=64, width=64,
+                   return_dict=False)[0]
+        assert rel(rr.from_shim(out), name) < 5e-2, (name, rel(rr.from_shim(out), name))
 
 
 _PRODUCT_SCHEDULERS = {
