@@ -95,3 +95,82 @@ def test_export_refuses_a_plan_that_is_not_complete(tmp_path):
     plan = m._get_plan(1, 16, 16, 7)          # text_time widths are only known at the first forward
     with pytest.raises(ValueError, match="run the model once"):
         export_program(m, plan, str(tmp_path / "x.mi3prg"))
+
+
+def _replay_on_host(path, inputs):
+    """interpret a program FILE on host memory: regions become byte buffers (weights / constants from the file), every launch goes to
+    the emulator's function of the same name with its pointers resolved -- nothing of the exporting model is used"""
+    import numpy as np
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"MI3SDPRG"
+    _, _, _, n_regions, n_ops, n_io, _ = struct.unpack_from("<IIIIIIQ", raw, 8)
+    pos = 8 + struct.calcsize("<IIIIIIQ")
+    regions = []
+    for _ in range(n_regions):
+        kind, nbytes, off = struct.unpack_from("<IQQ", raw, pos)
+        pos += 20
+        (n,) = struct.unpack_from("<I", raw, pos)
+        pos += 4 + n
+        buf = np.zeros(max(nbytes, 1) + 64, dtype=np.uint8)
+        if off:
+            buf[:nbytes] = np.frombuffer(raw, dtype=np.uint8, count=nbytes, offset=off)
+        regions.append(buf)
+    ios = []
+    for _ in range(n_io):
+        region, is_out, dtype, ndim, *shape = struct.unpack_from("<IIII4q", raw, pos)
+        pos += struct.calcsize("<IIII4q")
+        (n,) = struct.unpack_from("<I", raw, pos)
+        name = raw[pos + 4: pos + 4 + n].decode()
+        pos += 4 + n
+        ios.append((name, region, is_out, dtype, shape[:ndim]))
+    tdt = {0: torch.float32, 1: _lib.elem_dtype(), 2: torch.int32, 3: torch.uint8}
+
+    def view(region, dtype, shape):
+        n = 1
+        for s_ in shape:
+            n *= s_
+        t = torch.from_numpy(regions[region])[: n * torch.empty(0, dtype=tdt[dtype]).element_size()].view(tdt[dtype])
+        return t.reshape(shape)
+
+    for name, region, is_out, dtype, shape in ios:
+        if not is_out and name in inputs:
+            view(region, dtype, shape).copy_(inputs[name].reshape(shape))
+    emu = Emulator()
+    for _ in range(n_ops):
+        (n,) = struct.unpack_from("<I", raw, pos)
+        sym = raw[pos + 4: pos + 4 + n].decode()
+        pos += 4 + n
+        (nargs,) = struct.unpack_from("<I", raw, pos)
+        pos += 4
+        args = []
+        for _ in range(nargs):
+            tag, u, v = struct.unpack_from("<IQQ", raw, pos)
+            pos += 20
+            if tag == 0:
+                args.append(u - (1 << 64) if u >= (1 << 63) else u)
+            elif tag == 1:
+                args.append(struct.unpack("<d", struct.pack("<Q", u))[0])
+            elif tag == 2:
+                args.append(regions[u].ctypes.data + v)
+            elif tag == 3:
+                args.append(None)
+            else:
+                args.append(0)
+        rc = getattr(emu, sym)(*args)
+        assert not rc, (sym, rc)
+    return {name: view(region, dtype, shape).clone() for name, region, is_out, dtype, shape in ios if is_out}
+
+
+@pytest.mark.parametrize("name", ["unet_mini_xl", "unet_tiny_masked_controlnet", "unet_ip_adapter", "sd3_mini", "vae_encode", "clip_vision", "t5_encoder"])
+def test_program_file_is_self_contained(name, tmp_path):
+    from paddlemix_amd.export import _named_tensors
+    model, plan, outputs, path, _ = _export(name, tmp_path)
+    named = dict(_named_tensors(plan))
+    is_out = lambda n: any(n == o or n.startswith(o + ".") for o in outputs)  # noqa: E731
+    want = {n: t.clone() for n, t in named.items() if is_out(n)}
+    inputs = {n: t.clone() for n, t in named.items() if not is_out(n)}
+    del model, plan
+    got = _replay_on_host(path, inputs)
+    assert sorted(got) == sorted(want)
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
