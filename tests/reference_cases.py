@@ -209,7 +209,7 @@ SD3_COMPUTED = ("pos_embed.pos_embed",)                                      # p
 SD3_OPTIONAL = ("norm_out.norm.bias", "norm1_context.norm.bias")             # trainable, zero at construction (normalization.py:182)
 
 
-def _sd3_case(trained_norm_bias):
+def _sd3_case(trained_norm_bias, hw=(16, 16)):
     def run(ref):
         from oracle import sd3_ref as S
         cfg = C.MINI_SD3
@@ -219,7 +219,7 @@ def _sd3_case(trained_norm_bias):
             n, D = cfg["num_layers"], cfg["num_attention_heads"] * cfg["attention_head_dim"]
             P["norm_out.norm.bias"] = 0.5 * torch.randn(D, generator=g)
             P[f"transformer_blocks.{n - 1}.norm1_context.norm.bias"] = 0.5 * torch.randn(D, generator=g)
-        x, enc = torch.randn(2, 4, 16, 16, generator=g), torch.randn(2, 9, 64, generator=g)
+        x, enc = torch.randn(2, 4, *hw, generator=g), torch.randn(2, 9, 64, generator=g)
         pooled, t = torch.randn(2, 64, generator=g), torch.tensor([3.0, 900.0])
         with torch.no_grad():
             out = {"oracle": {"sample": S.sd3_forward(P, cfg, x, enc, pooled, t)}, "reference": None,
@@ -987,6 +987,7 @@ CASES = {
     "dit_mini": _dit_case,
     "sd3_mini": _sd3_case(False),
     "sd3_mini_trained_norm_bias": _sd3_case(True),
+    "sd3_mini_nonsquare_8x24": _sd3_case(False, hw=(8, 24)),          # the centre crop of the position table: height / width order
     # AutoencoderKL.decode / encode (models/autoencoder_kl.py, models/vae.py)
     "vae_mini": _vae_case,
     # transformers/clip/modeling.py (text towers of SD / SDXL, the IP-Adapter image tower), transformers/t5/modeling.py (SD3's T5 encoder)

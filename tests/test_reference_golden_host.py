@@ -32,7 +32,7 @@ def test_controlnet_dit_sd3():
     m = DiTTransformer2DModel(i["cfg"], i["P"], **E)
     rows = [m(i["x"][b:b + 1], timestep=i["t"][b:b + 1], class_labels=i["y"][b:b + 1]).sample for b in range(2)]
     assert _rel(torch.cat(rows), _gold("dit_mini")["sample"]) < 2e-2
-    for name in ("sd3_mini", "sd3_mini_trained_norm_bias"):
+    for name in ("sd3_mini", "sd3_mini_trained_norm_bias", "sd3_mini_nonsquare_8x24"):
         i = RC.CASES[name](False)["inputs"]
         m = SD3Transformer2DModel(i["cfg"], i["P"], **E)
         rows = [m(i["x"][b:b + 1], i["enc"][b:b + 1], i["pooled"][b:b + 1], float(i["t"][b])).sample for b in range(2)]
