@@ -186,12 +186,12 @@ def _controlnet_case(order, guess):
 
 
 # ------------------------------------------------------------------------------------------------------------------ DiT / SD3 / VAE
-def _dit_case(ref):
+def _dit_case(ref, side=16):
     from oracle import dit_ref as D
     cfg = C.MINI_DIT
     P = D.synth_dit_params(cfg, seed=2)
     g = torch.Generator().manual_seed(0)
-    x, t, y = torch.randn(2, 4, 16, 16, generator=g), torch.tensor([3, 900]), torch.tensor([1, 7])
+    x, t, y = torch.randn(2, 4, side, side, generator=g), torch.tensor([3, 900]), torch.tensor([1, 7])
     with torch.no_grad():
         out = {"oracle": {"sample": D.dit_forward(P, cfg, x, t, y)}, "reference": None, "inputs": dict(cfg=cfg, P=P, x=x, t=t, y=y)}
         if ref:
@@ -985,6 +985,7 @@ CASES = {
     "controlnet_bgr_guess_mode": _controlnet_case("bgr", True),
     # Transformer2DModel.forward, DiT branch (models/transformer_2d.py); SD3Transformer2DModel.forward (models/transformer_sd3.py)
     "dit_mini": _dit_case,
+    "dit_mini_other_resolution": lambda ref: _dit_case(ref, side=24),     # latents larger than sample_size: the position table is rebuilt for the grid
     "sd3_mini": _sd3_case(False),
     "sd3_mini_trained_norm_bias": _sd3_case(True),
     "sd3_mini_nonsquare_8x24": _sd3_case(False, hw=(8, 24)),          # the centre crop of the position table: height / width order

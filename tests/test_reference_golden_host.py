@@ -28,10 +28,11 @@ def test_controlnet_dit_sd3():
     downs, mid = ControlNetModel(i["cfg"], i["P"], **E)(i["x"], float(i["t"][0]), i["enc"], i["cond"], conditioning_scale=i["scale"],
                                                         guess_mode=i["guess"], return_dict=False)
     assert all(_rel(d, gold[f"down{k}"]) < 2e-2 for k, d in enumerate(downs)) and _rel(mid, gold["mid"]) < 2e-2
-    i = RC.CASES["dit_mini"](False)["inputs"]
-    m = DiTTransformer2DModel(i["cfg"], i["P"], **E)
-    rows = [m(i["x"][b:b + 1], timestep=i["t"][b:b + 1], class_labels=i["y"][b:b + 1]).sample for b in range(2)]
-    assert _rel(torch.cat(rows), _gold("dit_mini")["sample"]) < 2e-2
+    for name in ("dit_mini", "dit_mini_other_resolution"):
+        i = RC.CASES[name](False)["inputs"]
+        m = DiTTransformer2DModel(i["cfg"], i["P"], **E)
+        rows = [m(i["x"][b:b + 1], timestep=i["t"][b:b + 1], class_labels=i["y"][b:b + 1]).sample for b in range(2)]
+        assert _rel(torch.cat(rows), _gold(name)["sample"]) < 2e-2, name
     for name in ("sd3_mini", "sd3_mini_trained_norm_bias", "sd3_mini_nonsquare_8x24"):
         i = RC.CASES[name](False)["inputs"]
         m = SD3Transformer2DModel(i["cfg"], i["P"], **E)
