@@ -241,13 +241,13 @@ def _sd3_case(trained_norm_bias, hw=(16, 16)):
     return run
 
 
-def _vae_case(ref):
+def _vae_case(ref, zhw=(8, 8), ihw=(32, 32)):
     from oracle import vae_ref as V
     cfg = C.MINI_VAE
     P = V.synth_decoder_params(cfg, seed=2)
     P.update(_synth(V.encoder_param_shapes(cfg), 7))
     g = torch.Generator().manual_seed(0)
-    z, img = torch.randn(2, 4, 8, 8, generator=g), torch.randn(2, 3, 32, 32, generator=g)
+    z, img = torch.randn(2, 4, *zhw, generator=g), torch.randn(2, 3, *ihw, generator=g)
     with torch.no_grad():
         mean, logvar, _ = V.encode(P, cfg, img)
         out = {"oracle": {"decode": V.decode(P, cfg, z), "encode_mean": mean, "encode_logvar": logvar}, "reference": None,
@@ -991,6 +991,7 @@ CASES = {
     "sd3_mini_nonsquare_8x24": _sd3_case(False, hw=(8, 24)),          # the centre crop of the position table: height / width order
     # AutoencoderKL.decode / encode (models/autoencoder_kl.py, models/vae.py)
     "vae_mini": _vae_case,
+    "vae_mini_ragged": lambda ref: _vae_case(ref, zhw=(7, 8), ihw=(30, 32)),      # odd sizes through the bottom / right padded stride-2 convs
     # transformers/clip/modeling.py (text towers of SD / SDXL, the IP-Adapter image tower), transformers/t5/modeling.py (SD3's T5 encoder)
     "clip_text_quick_gelu": _clip_text_case("quick_gelu"),
     "clip_text_gelu": _clip_text_case("gelu"),
