@@ -275,14 +275,17 @@ def _transformers_module(rr, name):
     return importlib.import_module("ppdiffusers.transformers." + name)
 
 
-def _clip_text_case(act):
+def _clip_text_case(act, eos=2):
     def run(ref):
         from oracle import clip_ref as K
-        cfg = dict(C.MINI_CLIP, with_projection=True, hidden_act=act)
+        cfg = dict(C.MINI_CLIP, with_projection=True, hidden_act=act, eos_token_id=eos)
         P = K.synth_clip_params(cfg, seed=2)
         g = torch.Generator().manual_seed(0)
         ids = torch.randint(3, 1000, (2, 77), generator=g)
         ids[0, 20], ids[0, 21:], ids[1, 76] = 2, 0, 2         # EOS (the largest id) mid-sequence + padding, and at the end
+        if eos != 2:      # configs after the eos fix: pooled = FIRST position holding eos_token_id, not the arg-max id (modeling.py:808-822)
+            ids[ids == eos] = eos + 1
+            ids[0, 15], ids[0, 30], ids[1, 40] = eos, eos, eos
         with torch.no_grad():
             o = K.clip_text_forward(P, cfg, ids)
             out = {"oracle": {"last_hidden_state": o["last_hidden_state"], "text_embeds": o["text_embeds"],
@@ -995,6 +998,7 @@ CASES = {
     # transformers/clip/modeling.py (text towers of SD / SDXL, the IP-Adapter image tower), transformers/t5/modeling.py (SD3's T5 encoder)
     "clip_text_quick_gelu": _clip_text_case("quick_gelu"),
     "clip_text_gelu": _clip_text_case("gelu"),
+    "clip_text_eos_by_id": _clip_text_case("quick_gelu", eos=7),
     "clip_vision": _clip_vision_case,
     "t5_encoder": _t5_case,
     # the callers: pipelines/*/pipeline_*.py __call__ from prompt embeddings + start latents to final latents

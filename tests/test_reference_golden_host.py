@@ -55,7 +55,7 @@ def test_vae_and_text_encoders():
     assert _rel(vae.decode(i["z"]).sample, gold["decode"]) < 2e-2
     with pytest.raises(ValueError, match="multiples of 4"):
         vae.encode(i["img"])
-    for name in ("clip_text_quick_gelu", "clip_text_gelu"):
+    for name in ("clip_text_quick_gelu", "clip_text_gelu", "clip_text_eos_by_id"):
         i, gold = RC.CASES[name](False)["inputs"], _gold(name)
         out = CLIPTextModelWithProjection(i["cfg"], i["P"], **E)(i["ids"], output_hidden_states=True)
         assert _rel(out.last_hidden_state, gold["last_hidden_state"]) < 1.5e-2 and _rel(out.text_embeds, gold["text_embeds"]) < 2e-2
