@@ -161,7 +161,7 @@ def _stub_pipelines(P, mod, ConfigMixin):
     device placement / progress bar: dropped to attribute registration), the safety checker (absent). image_processor.py
     (VaeImageProcessor: tensor pre-processing, mask binarisation, resize) is the reference's real file."""
     for sub in ("pipelines", "pipelines.stable_diffusion", "pipelines.stable_diffusion_xl", "pipelines.stable_diffusion_3", "pipelines.controlnet",
-                "pipelines.dit"):
+                "pipelines.dit", "pipelines.latent_consistency_models"):
         m = mod(f"{PKG}.{sub}")
         m.__path__ = [os.path.join(REF_ROOT, PKG, *sub.split("."))]
 

@@ -951,6 +951,47 @@ def _checkpoint_layout_case(ref):
     return out
 
 
+def _pipe_lcm_img2img_case(ref):
+    """LatentConsistencyModelImg2ImgPipeline.__call__ (pipelines/latent_consistency_models/pipeline_latent_consistency_img2img.py):
+    `strength` goes INTO LCMScheduler.set_timesteps (the distillation schedule is shortened and ALL num_inference_steps of it run --
+    not the SD img2img rule), the start latents are the image latents re-noised at the first timestep."""
+    from oracle import schedulers_ref as S, unet_ref as U
+    cfg = dict(C.TINY, time_cond_proj_dim=32)
+    P = U.synth_unet_params(cfg, seed=1)
+    g = torch.Generator().manual_seed(0)
+    pe, img_lat = torch.randn(1, 7, 64, generator=g), torch.randn(1, 4, 8, 8, generator=g)
+    steps, gs, strength = 4, 8.0, 0.5
+    f = np.exp(-np.log(10000.0) * np.arange(16) / 15)
+    tc = torch.from_numpy(np.concatenate([np.sin(7000.0 * f), np.cos(7000.0 * f)])[None].astype(np.float32))
+    sch = S.LCMRef(**_SD)
+    sch.set_timesteps(steps, strength=strength)
+    assert list(sch.timesteps) == [499, 379, 259, 139]
+    gg = torch.Generator().manual_seed(3)
+    n0 = torch.randn(img_lat.shape, generator=gg).numpy()
+    a0 = float(sch.alphas_cumprod[int(sch.timesteps[0])])
+    x = (a0 ** 0.5 * img_lat.numpy() + (1 - a0) ** 0.5 * n0).astype(np.float64)
+    with torch.no_grad():
+        for i, t in enumerate(sch.timesteps):
+            eps = U.unet_forward(P, cfg, torch.from_numpy(x.astype(np.float32)), int(t), pe, timestep_cond=tc).numpy()
+            x, _ = sch.step(eps, t, x, None if i == steps - 1 else torch.randn(img_lat.shape, generator=gg).numpy())
+    out = {"oracle": {"latents": torch.from_numpy(x.astype(np.float32))}, "reference": None}
+    if ref:
+        rr = _rr()
+        rr.ref_pipeline("pipeline_stable_diffusion")
+        import importlib
+        pm = importlib.import_module("ppdiffusers.pipelines.latent_consistency_models.pipeline_latent_consistency_img2img")
+        sched = rr.ref_module("scheduling_lcm", "schedulers").LCMScheduler(**_SD)
+        pipe = pm.LatentConsistencyModelImg2ImgPipeline(vae=_FakeVAE(rr, scaling_factor=0.18215), text_encoder=None, tokenizer=None, unet=rr.build_unet(cfg, P),
+                                                        scheduler=sched, safety_checker=None, feature_extractor=None, requires_safety_checker=False)
+        gg = torch.Generator().manual_seed(3)
+        with torch.no_grad():
+            r = pipe(prompt_embeds=rr.to_shim(pe), image=rr.to_shim(img_lat), num_inference_steps=steps, strength=strength, guidance_scale=gs,
+                     output_type="latent", return_dict=False, generator=lambda shape: torch.randn(shape, generator=gg))[0]
+        assert [int(rr.from_shim(t)) for t in sched.timesteps] == [499, 379, 259, 139]
+        out["reference"] = {"latents": rr.from_shim(r)}
+    return out
+
+
 def _labels(kind):
     return {
         "index": lambda g: torch.tensor([3, 8]),
@@ -1016,6 +1057,7 @@ CASES = {
     "pipe_controlnet": _pipe_controlnet_case(False, 0.8),
     "pipe_controlnet_guess_mode": _pipe_controlnet_case(True, 1.0),
     "pipe_lcm_timestep_cond": _pipe_lcm_case,
+    "pipe_lcm_img2img_strength": _pipe_lcm_img2img_case,
     # schedulers/*.py: whole sampling loops
     "sched_ddim_sd15": _scheduler_case("scheduling_ddim", "DDIMScheduler", "DDIMRef", dict(_SD, clip_sample=False, set_alpha_to_one=False, steps_offset=1), 20),
     "sched_ddim_trailing_clip": _scheduler_case("scheduling_ddim", "DDIMScheduler", "DDIMRef", dict(_SD, clip_sample=True, timestep_spacing="trailing"), 10),

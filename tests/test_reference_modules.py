@@ -160,6 +160,12 @@ def test_product_image_pipelines_follow_the_reference_pipelines():
     out = StableDiffusionDenoiser(unet(dict(TINY, time_cond_proj_dim=32), 1), LCMScheduler(**SD))(
         pe, num_inference_steps=4, guidance_scale=8.0, latents=lat0.clone(), generator=torch.Generator().manual_seed(21))
     assert rel(out, "pipe_lcm_timestep_cond") < 5e-2, rel(out, "pipe_lcm_timestep_cond")
+    # ... and its img2img form (LatentConsistencyModelImg2ImgPipeline): strength shortens the distillation schedule, all steps run
+    g = torch.Generator().manual_seed(0)
+    pe, img_lat = torch.randn(1, 7, 64, generator=g), torch.randn(1, 4, 8, 8, generator=g)
+    out = StableDiffusionDenoiser(unet(dict(TINY, time_cond_proj_dim=32), 1), LCMScheduler(**SD))(
+        pe, num_inference_steps=4, guidance_scale=8.0, image=img_lat, strength=0.5, generator=torch.Generator().manual_seed(3))
+    assert rel(out, "pipe_lcm_img2img_strength") < 5e-2, rel(out, "pipe_lcm_img2img_strength")
 
 
 def test_product_encode_prompt_follows_the_reference_pipelines():
