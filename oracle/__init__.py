@@ -26,7 +26,7 @@ Parity pin status:
     transformers/{clip, t5}/modeling.py -- are loaded unmodified from /root/reference and
     executed on CPU over ``oracle/paddle_shim.py`` (a torch-fp32 stand-in for the ``paddle``
     package) by ``oracle/reference_runner.py``, on this oracle's parameters and inputs.
-    Every restated forward agrees with the reference's to fp32 rounding (72 cases, worst
+    Every restated forward agrees with the reference's to fp32 rounding (73 cases, worst
     relative difference 4.7e-6 -- a 5-step SDXL pipeline loop; 1.3e-6 for single forwards --
     most bit-identical), eleven pipeline __call__ loops and the SDXL / SD3 encode_prompt (pipelines/stable_diffusion*/pipeline_*.py,
     pipelines/controlnet/pipeline_controlnet.py: text2img, img2img, inpaint, ControlNet, LCM)

@@ -992,6 +992,39 @@ def _pipe_lcm_img2img_case(ref):
     return out
 
 
+def _pipe_sd_from_prompts_case(ref):
+    """StableDiffusionPipeline.__call__ from prompt STRINGS (table tokenizer): encode_prompt of the prompt and of the negative prompt
+    through the real CLIP text tower, [negative, positive] batching, CFG, DDIM. The cross-attention width of the UNet is the text
+    tower's hidden size."""
+    from oracle import clip_ref as K, schedulers_ref as S, unet_ref as U
+    E = encode_prompt_inputs()
+    cfg = C.TINY                                   # cross_attention_dim 64 = MINI_CLIP hidden size
+    P = U.synth_unet_params(cfg, seed=1)
+    lat0 = torch.randn(1, 4, 8, 8, generator=torch.Generator().manual_seed(9))
+    steps, gs = 4, 6.0
+    kw = dict(_SD, clip_sample=False, set_alpha_to_one=False, steps_offset=1)
+    with torch.no_grad():
+        pe = K.clip_text_forward(E["P1"], E["c1"], E["ids"]["a"][None])["last_hidden_state"]
+        ne = K.clip_text_forward(E["P1"], E["c1"], E["ids"]["b"][None])["last_hidden_state"]
+        sch = S.DDIMRef(**kw)
+        sch.set_timesteps(steps)
+        x = lat0.numpy() * sch.init_noise_sigma
+        for t in sch.timesteps:
+            eps = U.unet_forward(P, cfg, torch.from_numpy(np.concatenate([x, x])), int(t), torch.cat([ne, pe])).numpy()
+            x = sch.step(eps[:1] + gs * (eps[1:] - eps[:1]), t, x)
+    out = {"oracle": {"latents": torch.from_numpy(x)}, "reference": None}
+    if ref:
+        rr = _rr()
+        (te,) = _text_encoders(rr, [("clip", E["c1"], E["P1"])])
+        pipe = _sd_parts(rr, "pipeline_stable_diffusion", "StableDiffusionPipeline", cfg, P, "scheduling_ddim", "DDIMScheduler", kw)
+        pipe.text_encoder, pipe.tokenizer = te, _FakeTokenizer(rr, E["ids"])
+        with torch.no_grad():
+            r = pipe(prompt="a", negative_prompt="b", latents=rr.to_shim(lat0.clone()), num_inference_steps=steps, guidance_scale=gs,
+                     output_type="latent", height=64, width=64, return_dict=False)[0]
+        out["reference"] = {"latents": rr.from_shim(r)}
+    return out
+
+
 def _labels(kind):
     return {
         "index": lambda g: torch.tensor([3, 8]),
@@ -1044,6 +1077,7 @@ CASES = {
     "t5_encoder": _t5_case,
     # the callers: pipelines/*/pipeline_*.py __call__ from prompt embeddings + start latents to final latents
     "pipe_sd_ddim_cfg_rescale": _pipe_sd_case,
+    "pipe_sd_from_prompt_strings": _pipe_sd_from_prompts_case,
     "pipe_sdxl_euler_cfg_microcond": _pipe_sdxl_case,
     "pipe_sd3_flow_match_cfg": _pipe_sd3_case,
     "encode_prompt_sd_clip_skip": _encode_prompt_sd_clip_skip_case,

@@ -188,6 +188,18 @@ def test_product_encode_prompt_follows_the_reference_pipelines():
     assert rel(sd.encode_prompt(a, clip_skip=1)[0], "encode_prompt_sd_clip_skip", "prompt_embeds_clip_skip_1") < 1.5e-2
     xl = StableDiffusionDenoiser(None, None, text_encoder=CLIPTextModel(E["c1"], E["P1"], _test_backend=Emulator()),
                                  text_encoder_2=CLIPTextModelWithProjection(E["c2"], E["P2"], _test_backend=Emulator()))
+    # the whole single-encoder call from token ids (StableDiffusionPipeline.__call__ from prompt strings on the reference side)
+    from oracle import unet_ref as U
+    from paddlemix_amd.schedulers import DDIMScheduler
+    from paddlemix_amd.unet import UNet2DConditionModel
+    from tests.configs import TINY
+    pipe = StableDiffusionDenoiser(UNet2DConditionModel(TINY, U.synth_unet_params(TINY, seed=1), _test_backend=Emulator()),
+                                   DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
+                                                 set_alpha_to_one=False, steps_offset=1),
+                                   text_encoder=CLIPTextModel(E["c1"], E["P1"], _test_backend=Emulator()))
+    lat0 = torch.randn(1, 4, 8, 8, generator=torch.Generator().manual_seed(9))
+    out = pipe(prompt_ids=a, negative_prompt_ids=b, latents=lat0.clone(), num_inference_steps=4, guidance_scale=6.0)
+    assert rel(out, "pipe_sd_from_prompt_strings", "latents") < 5e-2
     pe, pooled = xl.encode_prompt(a, b)
     assert rel(pe, "encode_prompt_sdxl", "prompt_embeds") < 1.5e-2 and rel(pooled, "encode_prompt_sdxl", "pooled") < 2e-2
     s3 = StableDiffusion3Denoiser(None, None, text_encoder=CLIPTextModelWithProjection(E["c1p"], E["P1p"], _test_backend=Emulator()),
