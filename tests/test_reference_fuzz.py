@@ -59,6 +59,73 @@ def test_random_unet_configurations(seed):
         assert d_ref < 5e-5 and d_dev < 2.5e-2, (cfg, extra, hw, d_ref, d_dev)
 
 
+_REF_SCHED = {"DDIMScheduler": "scheduling_ddim", "EulerDiscreteScheduler": "scheduling_euler_discrete", "PNDMScheduler": "scheduling_pndm",
+              "DPMSolverMultistepScheduler": "scheduling_dpmsolver_multistep"}
+
+
+def one_scheduler_trial(trial: int, rng: random.Random):
+    """-> (description, outcome of the reference class, outcome of paddlemix_amd.schedulers' class); an outcome is ("ok", latents,
+    timesteps) | ("nan",) | ("raises", type name, message)"""
+    import math
+
+    import paddlemix_amd.schedulers as PS
+    cls = rng.choice(list(_REF_SCHED))
+    kw = dict(beta_start=0.00085, beta_end=0.012, beta_schedule=rng.choice(["linear", "scaled_linear"]),
+              prediction_type=rng.choice(["epsilon", "v_prediction"]), timestep_spacing=rng.choice(["leading", "trailing", "linspace"]),
+              steps_offset=rng.choice([0, 1]))
+    if cls == "DDIMScheduler":
+        kw.update(clip_sample=rng.choice([True, False]), set_alpha_to_one=rng.choice([True, False]))
+    elif cls == "EulerDiscreteScheduler":
+        kw.update(use_karras_sigmas=rng.choice([True, False]))
+    elif cls == "PNDMScheduler":
+        kw.update(skip_prk_steps=rng.choice([True, False]), set_alpha_to_one=rng.choice([True, False]))
+    else:
+        kw.update(solver_order=rng.choice([1, 2]), algorithm_type=rng.choice(["dpmsolver++", "dpmsolver"]), solver_type=rng.choice(["midpoint", "heun"]),
+                  use_karras_sigmas=rng.choice([True, False]), euler_at_final=rng.choice([True, False]), lower_order_final=rng.choice([True, False]))
+    steps = rng.choice([3, 5, 8, 12, 14, 20])
+    g = torch.Generator().manual_seed(trial)
+    x0, pat = torch.randn(1, 4, 8, 8, generator=g), torch.randn(1, 4, 8, 8, generator=g)
+    model = lambda x, t: 0.3 * x * math.cos(0.01 * float(t)) + 0.1 * pat  # noqa: E731
+
+    def loop(sch, wrap, unwrap):
+        try:
+            sch.set_timesteps(steps)
+            ins = getattr(sch, "init_noise_sigma", 1.0)
+            x = wrap(x0 * float(ins if isinstance(ins, (int, float)) else unwrap(ins)))
+            for t in sch.timesteps:
+                x = sch.step(wrap(model(unwrap(sch.scale_model_input(x, t)), unwrap(t))), t, x, return_dict=False)[0]
+            x = unwrap(x).float()
+            return ("nan",) if torch.isnan(x).any() else ("ok", x, [float(unwrap(t)) for t in sch.timesteps])
+        except Exception as e:   # noqa: BLE001
+            return ("raises", type(e).__name__, str(e)[:60])
+
+    ref = loop(getattr(rr.ref_module(_REF_SCHED[cls], "schedulers"), cls)(**kw), rr.to_shim, rr.from_shim)
+    prod = loop(getattr(PS, cls)(**kw), lambda v: v, lambda v: v)
+    return f"{cls}({kw}) x {steps}", ref, prod
+
+
+@pytest.mark.skipif(not rr.available(), reason="/root/reference exists only in the build container")
+def test_random_scheduler_configurations():
+    """40 random (class, beta schedule, prediction type, spacing, offsets, solver options, step count) combinations: the product's
+    scheduler follows the reference's class to 5e-5 -- and fails the way the reference fails where the reference fails (NaN from
+    DPM-Solver's h = inf second-order final step; the 3-step PRK schedule of PNDM that cannot be built)"""
+    import warnings
+    rng = random.Random(0)
+    kinds = set()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for trial in range(40):
+            what, ref, prod = one_scheduler_trial(trial, rng)
+            assert ref[0] == prod[0], (what, ref[:3], prod[:3])
+            kinds.add(ref[0])
+            if ref[0] == "raises":
+                assert ref[1:] == prod[1:], (what, ref, prod)
+            elif ref[0] == "ok":
+                assert len(ref[2]) == len(prod[2]) and max(abs(a - b) for a, b in zip(ref[2], prod[2])) < 1e-3, what
+                assert float((prod[1] - ref[1]).abs().max() / ref[1].abs().max()) < 5e-5, what
+    assert "ok" in kinds
+
+
 if __name__ == "__main__":
     rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
     for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
