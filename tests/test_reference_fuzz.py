@@ -126,6 +126,63 @@ def test_random_scheduler_configurations():
     assert "ok" in kinds
 
 
+@pytest.mark.skipif(not rr.available(), reason="/root/reference exists only in the build container")
+def test_random_pipeline_calls():
+    """8 random text-to-image calls -- SD or SDXL (micro-conditioning), DDIM / Euler (Karras) / PNDM / DPM-Solver, leading / trailing
+    spacing, 2-5 steps, guidance 1 / 3 / 7.5, guidance_rescale 0 / 0.6, batch 1 / 2: paddlemix_amd.pipeline.StableDiffusionDenoiser with
+    the product's scheduler and the UNet on the emulated device against the reference's own pipeline __call__ with the reference's
+    model and scheduler. Tolerance: chained 16-bit model evaluations under guidance."""
+    import warnings
+
+    import paddlemix_amd.schedulers as PS
+    from paddlemix_amd.pipeline import StableDiffusionDenoiser
+    from paddlemix_amd.unet import UNet2DConditionModel
+    from tests import configs as C
+    from tests import reference_cases as RC
+    from tests.abi_emulator import Emulator
+    rng = random.Random(0)
+    warnings.simplefilter("ignore")
+    for trial in range(8):
+        xl = rng.choice([False, True])
+        cfg = C.MINI_XL if xl else C.TINY
+        cls = rng.choice(list(_REF_SCHED))
+        kw = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", steps_offset=1, timestep_spacing=rng.choice(["leading", "trailing"]))
+        if cls == "DDIMScheduler":
+            kw.update(clip_sample=False, set_alpha_to_one=False)
+        elif cls == "PNDMScheduler":
+            kw.update(skip_prk_steps=True)
+        elif cls == "EulerDiscreteScheduler":
+            kw.update(use_karras_sigmas=rng.choice([True, False]))
+        steps, gs, gr, B = rng.choice([2, 3, 5]), rng.choice([1.0, 3.0, 7.5]), rng.choice([0.0, 0.6]), rng.choice([1, 2])
+        g = torch.Generator().manual_seed(trial)
+        cd = cfg["cross_attention_dim"]
+        pe, ne, lat0 = torch.randn(B, 7, cd, generator=g), torch.randn(B, 7, cd, generator=g), torch.randn(B, 4, 8, 8, generator=g)
+        P = U.synth_unet_params(cfg, seed=trial)
+        sh = rr.to_shim
+        common = dict(latents=sh(lat0.clone()), num_inference_steps=steps, guidance_scale=gs, guidance_rescale=gr, output_type="latent", height=64, width=64,
+                      return_dict=False)
+        akw = {}
+        with torch.no_grad():
+            if xl:
+                pp, npp = torch.randn(B, 64, generator=g), torch.randn(B, 64, generator=g)
+                pm = rr.ref_pipeline("pipeline_stable_diffusion_xl", "pipelines.stable_diffusion_xl")
+                te2 = type("TextEncoder2", (), {"config": rr.FrozenConfig(projection_dim=64), "dtype": torch.float32})()
+                sched = getattr(rr.ref_module(_REF_SCHED[cls], "schedulers"), cls)(**kw)
+                pipe = pm.StableDiffusionXLPipeline(vae=RC._FakeVAE(rr, scaling_factor=0.13025, force_upcast=False), text_encoder=None, text_encoder_2=te2,
+                                                    tokenizer=None, tokenizer_2=None, unet=rr.build_unet(cfg, P), scheduler=sched)
+                ref = pipe(prompt_embeds=sh(pe), negative_prompt_embeds=sh(ne), pooled_prompt_embeds=sh(pp), negative_pooled_prompt_embeds=sh(npp), **common)[0]
+                tids = torch.tensor([[64.0, 64.0, 0.0, 0.0, 64.0, 64.0]]).repeat(B, 1)
+                akw = dict(added_cond_kwargs=dict(text_embeds=pp, time_ids=tids), negative_added_cond_kwargs=dict(text_embeds=npp, time_ids=tids))
+            else:
+                pipe = RC._sd_parts(rr, "pipeline_stable_diffusion", "StableDiffusionPipeline", cfg, P, _REF_SCHED[cls], cls, kw)
+                ref = pipe(prompt_embeds=sh(pe), negative_prompt_embeds=sh(ne), **common)[0]
+        ref = rr.from_shim(ref)
+        out = StableDiffusionDenoiser(UNet2DConditionModel(cfg, P, _test_backend=Emulator()), getattr(PS, cls)(**kw))(
+            pe, ne, num_inference_steps=steps, guidance_scale=gs, guidance_rescale=gr, latents=lat0.clone(), **akw)
+        d = float((out - ref).norm() / ref.norm())
+        assert d < 5e-2, (trial, xl, cls, kw, steps, gs, gr, B, d)
+
+
 if __name__ == "__main__":
     rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
     for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
