@@ -30,7 +30,8 @@ PKG = "ppdiffusers"
 
 
 def available() -> bool:
-    return os.path.isdir(os.path.join(REF_ROOT, PKG, "models"))
+    """False on machines without the reference checkout (ORACLE_NO_REFERENCE=1 simulates one: the committed vectors must suffice)"""
+    return not os.environ.get("ORACLE_NO_REFERENCE") and os.path.isdir(os.path.join(REF_ROOT, PKG, "models"))
 
 
 class FrozenConfig(dict):
