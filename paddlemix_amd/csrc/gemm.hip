@@ -336,7 +336,11 @@ static int pick_tile_model(const GemmArgs& a) {
     // 32768 x 1536 x 1536 + R 175.0 vs 199.3) although the bytes-per-CU model below ranks the larger tiles first: its rounds are
     // exact multiples of the chip there, its residual arrives early (gemm_pipe_pre_kernel), and with 20-24 K-tiles per output
     // tile the per-tile fixed costs weigh as much as the loop. Long K keeps the model's choice (FF2 at K = 5120 / 6144, every conv).
-    if (c.id == 160 && !a.conv && !a.geglu && a.K <= 1536 && !a.wscale && !a.rowstat && !a.a_rpb && !a.c_rpb) cost *= 0.6;   // (measured forms only)
+    static const double p160 = [] {   // MI355X_SD_GEMM_P160: the short-K weight of the 256x160 tile (A/B measurements inside the step)
+      const char* e = getenv("MI355X_SD_GEMM_P160");
+      return e ? atof(e) : 0.6;
+    }();
+    if (c.id == 160 && !a.conv && !a.geglu && a.K <= 1536 && !a.wscale && !a.rowstat && !a.a_rpb && !a.c_rpb) cost *= p160;   // (measured forms only)
     static const double p257 = [] {   // MI355X_SD_GEMM_P257: re-weights the phased 256x256 kernel (A/B measurements)
       const char* e = getenv("MI355X_SD_GEMM_P257");
       return e ? atof(e) : 1.0;

@@ -18,6 +18,8 @@
 // wave has retired its reads of tile t (lgkmcnt(0) before the barrier; the k-step-0 reads of t+1 are issued after it).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "gemm_cfg.h"
 #include "gemm_epilogue.h"
@@ -35,6 +37,20 @@ constexpr int GEMM_LOADERS_DEFAULT = -1;
     __builtin_amdgcn_s_barrier();         \
     __builtin_amdgcn_sched_barrier(0);    \
   } while (0)
+
+// compile-time loop: f(std::integral_constant<int, I>{}) for I = B .. E-1 (every index a constant expression: register arrays stay
+// in registers, and `if constexpr` inside f places an instruction at exactly one step of an unrolled schedule)
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+template <int V>
+using ic_t = std::integral_constant<int, V>;
+// step (of NSTEP) at which the i-th of np LDS-DMA pieces of a half-iteration is issued: spread, none at step 0
+constexpr int il_piece_step(int i, int np, int nstep) { return 1 + (i * (nstep - 1)) / np; }
 
 // 16-byte-per-lane LDS-DMA from a buffer resource. A plain (non-template) function on purpose: called with
 // type-dependent arguments straight from the kernel template, the builtin makes the host pass of hipcc drop the kernel's
@@ -67,9 +83,12 @@ __device__ __forceinline__ void sgb_reads_under_mfmas() {
 // PRE: the epilogue's residual / bias operands are fetched during the last K iterations (gemm_epilogue.h EpiPre). Its own
 // instantiation, not a run-time branch: two alternative consumers of the accumulators make the register allocator split their
 // live ranges and spill inside the K loop (header of gemm_epilogue.h).
-template <bool CONV, class CFG, bool LN, int LW, int SG, bool PRE>
+// IL (round 4): the INTERLEAVED K loop -- every LDS-DMA piece and every fragment read sits between two small MFMA groups instead of
+// in a burst at the top of the iteration; see the IL sections below. LW == 0 only.
+template <bool CONV, class CFG, bool LN, int LW, int SG, bool PRE, int IL = 0>
 __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& p) {
   static_assert(!PRE || (LW == 0 && !LN && (CFG::TM + CFG::TN) <= 10), "early epilogue operands: register-pipelined tiles without loader waves");
+  static_assert(!IL || LW == 0, "the interleaved loop has no loader waves");
   constexpr int BM = CFG::BM, BN = CFG::BN, TM = CFG::TM, TN = CFG::TN, ST = CFG::STAGES, NW = CFG::NW;
   constexpr int PW = LW ? LW : NW;                       // waves that own LDS-DMA pieces
   constexpr int AP = (CFG::A_TOTAL + PW - 1) / PW, WP = (CFG::W_TOTAL + PW - 1) / PW;
@@ -194,6 +213,47 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& p) {
     else wait_vmcnt_imm<(PMAX > 2 ? PMAX - 2 : 0)>();
   };
 
+  // ---- piece-level issue (IL loops): A piece i / W piece i of this wave; kA / kW = K offset of the A / W tile being staged ----
+  [[maybe_unused]] int kA = t0 * BK, kW = t0 * BK;
+  [[maybe_unused]] auto issue_a = [&](auto ic, const int stage) {
+    constexpr int i = decltype(ic)::value;
+    if ((i + 1) * PW <= CFG::A_TOTAL || pw + i * PW < CFG::A_TOTAL) {   // (only a ragged last piece is a run-time question)
+      unsigned char* a = As + stage * STAGE_A + (pw + i * PW) * 1024;
+      if (CONV) {
+        const int ky = gtap / 3, kx = gtap - ky * 3;
+        const int Hin = p.Hs << p.up, Win = p.Ws << p.up;
+        const int iy = oy[i] * p.stride + ky - p.pad;
+        const int ix = ox[i] * p.stride + kx - p.pad;
+        const bool ok = a_ok[i] && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
+        const unsigned off = a_off[i] + (unsigned)(((iy >> p.up) * p.Ws + (ix >> p.up)) * p.lda + gcch) * 2u;
+        dma(a_rsrc, a, ok ? off : OOB, 0);
+      } else {
+        dma(a_rsrc, a, a_off[i], kA * 2);
+      }
+    }
+  };
+  [[maybe_unused]] auto next_a = [&]() {
+    kA += BK;
+    if (CONV) conv_k_next(p.kb64, p.Cin, gtap, gcch);
+  };
+  [[maybe_unused]] auto issue_w = [&](auto ic, const int stage) {
+    constexpr int i = decltype(ic)::value;
+    if ((i + 1) * PW <= CFG::W_TOTAL || pw + i * PW < CFG::W_TOTAL) dma(w_rsrc, Ws + stage * STAGE_W + (pw + i * PW) * 1024, w_off[i], kW * 2);
+  };
+  [[maybe_unused]] auto next_w = [&]() { kW += BK; };
+  int mine_a = 0;   // this wave's A pieces per K-tile (mine - mine_a = its W pieces)
+#pragma unroll
+  for (int i = 0; i < AP; ++i) mine_a += (pw + i * PW < CFG::A_TOTAL) ? 1 : 0;
+  // s_waitcnt vmcnt(BASE [+ the pieces of one tile]). Where the pieces do not divide evenly over the waves (256 x 160: 20 W pieces on
+  // 8 waves) the count is the SMALLER one for every wave: exact for the waves that own fewer pieces; the others also wait for
+  // the oldest piece of the newer tile, issued most of an iteration earlier -- cheaper than the branch per K-tile that picks the
+  // immediate by wave (s_waitcnt takes no register operand).
+  [[maybe_unused]] auto wait_newer = [&](auto basec, auto newerc) {
+    constexpr int BASE = decltype(basec)::value;
+    constexpr int PMIN = CFG::A_TOTAL / PW + CFG::W_TOTAL / PW;
+    wait_vmcnt_imm<BASE + (decltype(newerc)::value ? PMIN : 0)>();
+  };
+
   constexpr bool STREAM = (TM + TN) > 10;   // two full fragment sets would not fit next to the accumulators
   if (LW > 0 && loader) {
     // ---- loader waves: the K loop's DMA side, barrier for barrier what the compute waves below execute ----
@@ -286,7 +346,121 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& p) {
   const int a_row = (wm * (TM * 16) + frow) * 128, w_row = (wn * (TN * 16) + frow) * 128;
   const int c0 = ((0 * 4 + fkc) ^ rsw) << 4, c1 = ((1 * 4 + fkc) ^ rsw) << 4;
 
-  if constexpr (!STREAM) {
+  if constexpr (IL && !STREAM) {
+  // ---- interleaved loop, register-pipelined tiles (round 4) ----
+  // The loop above issues a K-tile's 6-7 LDS-DMA pieces as one burst and its 9 fragment reads as two bursts; both waves of a SIMD do
+  // so at the same moment (one barrier per K-tile keeps them in step), and an LDS-DMA piece costs an in-order wave 60-180 cycles of
+  // issue (MI355X_MICROARCH.md constants) in which it feeds the matrix pipe nothing: in-loop 0.47-0.55 of the MFMA rate on the
+  // 256x160 tile (scripts/gemm_timeline.py, 1.15 us per K-tile for 0.53 us of MFMA work). Here a half-iteration is NSTEP steps of
+  //     [one ds_read_b128 of the OTHER fragment set] [at most one LDS-DMA piece] [G MFMAs]
+  // fenced with sched_barrier(0) so that this is the emitted order: the non-MFMA issue slots sit in the shadow of MFMAs of the same
+  // wave or of its SIMD partner, and the two waves of a SIMD drift apart by themselves instead of colliding on the VMEM port.
+  // The DMA work of a tile is split over TWO half-iterations: the W pieces of tile t+AHEAD go out in half 0 of iteration t, the A
+  // pieces of tile t+1+AHEAD in half 1 of iteration t -- into the stage of tile t itself, which the mid barrier of iteration t has
+  // just proven fully read (every wave retires its reads of tile t, lgkmcnt(0), before that barrier; half 1 multiplies fragments
+  // that are in registers already). RAW as before: a wave waits for its own pieces of tile t+1 (counted vmcnt: the A and W pieces
+  // of tile t+2 -- and the early residual loads of iterations t-1 and t -- may stay in flight) before the mid barrier of
+  // iteration t; every read of tile t+1 comes after that barrier.
+  // The last iterations are UNROLLED (template R = tiles after this one): what is issued and the wait counts are compile-time
+  // facts there, and the main loop has neither the "is there a next tile" conditionals nor the run-time vmcnt switch
+  // (wait_vmcnt_dyn: ~40 of the 155 scalar instructions per K-tile of the round-3 PRE loop).
+  constexpr int AHEAD = ST - 1, NM = TM * TN, NR = TM + TN, G = 2, NSTEP = (NM + G - 1) / G;
+  static_assert(NR <= NSTEP && AP < NSTEP && WP < NSTEP, "one read and at most one DMA piece per step");
+  constexpr int LPR = EpiPre<(PRE ? TM : 1), (PRE ? TN : 1)>::LOADS_PER_ROW;
+  constexpr int NTAIL = (PRE && TM > AHEAD ? TM : AHEAD) + 1;
+  bf16x8 fa[2][TM], fw[2][TN];
+  // read k of a fragment set, in the order the MFMAs consume them: w0, a0 .. a(TM-1), w1 .. w(TN-1)
+  auto read_one = [&](auto setc, auto kc, const int stage) {
+    constexpr int set = decltype(setc)::value, k = decltype(kc)::value;
+    if constexpr (k == 0 || k > TM) {
+      constexpr int i = k == 0 ? 0 : k - TM;
+      fw[set][i] = *reinterpret_cast<const bf16x8*>(Ws + stage * STAGE_W + w_row + (set ? c1 : c0) + i * 16 * 128);
+    } else {
+      fa[set][k - 1] = *reinterpret_cast<const bf16x8*>(As + stage * STAGE_A + a_row + (set ? c1 : c0) + (k - 1) * 16 * 128);
+    }
+  };
+  // one half-iteration. SET: the fragment set the MFMAs consume (the reads fill the other one from rstage); DK: 0 no DMA, 1 this
+  // wave's W pieces, 2 its A pieces (-> dstage); PR: residual row-tile requested at the last step (-1: none)
+  auto half = [&](auto setc, auto rdc, auto dkc, auto prc, const int rstage, const int dstage) {
+    constexpr int SET = decltype(setc)::value, RD = decltype(rdc)::value, DK = decltype(dkc)::value, PR = decltype(prc)::value;
+    static_for<0, NSTEP>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      if constexpr (RD && k < NR) read_one(ic_t<SET ^ 1>{}, kc, rstage);
+      if constexpr (DK == 1) static_for<0, WP>([&](auto ic) {
+        if constexpr (il_piece_step(decltype(ic)::value, WP, NSTEP) == k) issue_w(ic, dstage);
+      });
+      if constexpr (DK == 2) static_for<0, AP>([&](auto ic) {
+        if constexpr (il_piece_step(decltype(ic)::value, AP, NSTEP) == k) issue_a(ic, dstage);
+      });
+      if constexpr (PRE && PR >= 0 && k == NSTEP - 1) epi_prefetch_row<(PR >= 0 ? PR : 0), TM, TN>(p, r_srd, m_pre, n_pre, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<0, G>([&](auto gc) {
+        constexpr int q = k * G + decltype(gc)::value;
+        if constexpr (q < NM) acc[q / TM][q % TM] = mfma_16x16x32(fw[SET][q / TM], fa[SET][q % TM], acc[q / TM][q % TM]);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+  // iteration of tile t in `stage`; R = tiles after it when that is a compile-time fact (tail), -1: at least NTAIL. Returns the
+  // stage of tile t+1.
+  int stage = 0, s1 = 1, sw = ST - 1;   // stages of tiles t, t+1, t+AHEAD (rotated by iter)
+  auto iter = [&](auto rc) {
+    constexpr int R = decltype(rc)::value;
+    constexpr bool has1 = R != 0, hasW = R < 0 || R >= AHEAD, hasA = R < 0 || R >= AHEAD + 1;
+    constexpr int PR = (PRE && R >= 1 && R <= TM) ? TM - R : -1;
+    half(ic_t<0>{}, ic_t<1>{}, ic_t<(hasW ? 1 : 0)>{}, ic_t<PR>{}, stage, sw);
+    if constexpr (hasW) next_w();
+    __builtin_amdgcn_s_waitcnt(0xC07F);          // every read of tile t retired
+    if constexpr (has1) {
+      // tile t+1 must have landed; issued after it: (three stages) the residual loads of iteration t-1, the A and W pieces of tile
+      // t+2, this iteration's residual loads; (two stages) only this iteration's residual loads
+      constexpr int rcur = PR >= 0 ? LPR : 0, rprev = (PRE && R >= 0 && R + 1 <= TM) ? LPR : 0;
+      wait_newer(ic_t<(AHEAD == 2 ? rprev + rcur : rcur)>{}, ic_t<(AHEAD == 2 && (R < 0 || R >= 2) ? 1 : 0)>{});
+      SD_PIPE_BARRIER();                         // publishes tile t+1; every wave is done reading tile t
+    }
+    half(ic_t<1>{}, ic_t<(has1 ? 1 : 0)>{}, ic_t<(hasA ? 2 : 0)>{}, ic_t<-1>{}, s1, stage);
+    if constexpr (hasA) next_a();
+    const int s0 = stage;
+    stage = s1;
+    if constexpr (ST == 3) {
+      s1 = sw;
+      sw = s0;
+    } else {
+      s1 = sw = s0;
+    }
+  };
+
+  const int nt = t1 - t0;
+  // prologue: tile t0 (and t0+1 with three stages), then what "half 1 of iteration t0-1" would have issued: the A pieces of t0+AHEAD
+  static_for<0, AP>([&](auto ic) { issue_a(ic, 0); });
+  static_for<0, WP>([&](auto ic) { issue_w(ic, 0); });
+  next_a();
+  next_w();
+  int newer = 0;
+  if (AHEAD == 2 && nt > 1) {
+    static_for<0, AP>([&](auto ic) { issue_a(ic, 1); });
+    static_for<0, WP>([&](auto ic) { issue_w(ic, 1); });
+    next_a();
+    next_w();
+    newer = mine;
+  }
+  if (nt > AHEAD) {
+    static_for<0, AP>([&](auto ic) { issue_a(ic, AHEAD); });
+    next_a();
+    newer += mine_a;
+  }
+  wait_vmcnt_dyn(newer);
+  SD_PIPE_BARRIER();
+  stamp(1);
+  init_acc();
+  static_for<0, NR>([&](auto kc) { read_one(ic_t<0>{}, kc, 0); });
+  int nrem = nt;
+  for (; nrem > NTAIL; --nrem) iter(ic_t<-1>{});
+  static_for<0, NTAIL>([&](auto jc) {
+    constexpr int R = NTAIL - 1 - decltype(jc)::value;
+    if (PRE || nrem > R) iter(ic_t<R>{});   // (PRE launches have at least TM + 2 > NTAIL - 1 K-tiles: launch_pipe)
+  });
+  } else if constexpr (!STREAM) {
   // ---- fragments: two register sets (k-step 0 / 1 of a K-tile) ----
   bf16x8 fa[2][TM], fw[2][TN];
   auto read_frag = [&](const int set, const int stage) {
@@ -386,6 +560,87 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& p) {
     mma(1);
     stage = s1;
   }
+  } else if constexpr (IL) {
+  // ---- interleaved streaming loop (round 4): the streaming variant below with the LDS-DMA pieces of a tile issued ONE PER STEP ----
+  // instead of as a burst of 8-9 at the top of the iteration. Two LDS stages: the stage of tile t is free once every wave has
+  // passed the roll-over barrier of iteration t (step STEPS - Q), so the first Q pieces of tile t+2 go out in the Q steps after
+  // that barrier and its remaining pieces in the first steps of iteration t+1; the roll-over of iteration t+1 waits for all of
+  // them (vmcnt(0): nothing newer is in flight), at least STEPS - Q - (pieces - Q) steps (> 700 cycles) after the last one was
+  // issued. W pieces first: a conv's gather state advances once per tile, with the A pieces, which then all sit in one iteration.
+  static_assert(ST == 2, "streaming loop is written for two LDS stages");
+  constexpr bool HOLD_A = TM <= TN;
+  constexpr int HN = HOLD_A ? TM : TN, SN = HOLD_A ? TN : TM, Q = 3, QN = Q + 1, STEPS = 2 * SN, NP = AP + WP;
+  static_assert(WP >= Q && NP - Q <= STEPS - Q - 4, "piece schedule of the interleaved streaming loop");
+  const int h_row = HOLD_A ? a_row : w_row, s_row = HOLD_A ? w_row : a_row;
+  bf16x8 hold[2][HN], qf[QN];
+  auto read_hold = [&](auto setc, const int stage) {
+    constexpr int set = decltype(setc)::value;
+    const unsigned char* b = (HOLD_A ? As + stage * STAGE_A : Ws + stage * STAGE_W) + h_row + (set ? c1 : c0);
+    static_for<0, HN>([&](auto ic) { hold[set][decltype(ic)::value] = *reinterpret_cast<const bf16x8*>(b + decltype(ic)::value * 16 * 128); });
+  };
+  auto read_stream = [&](auto slotc, const int stage, auto jc) {   // fragment of step j (0 .. STEPS-1) of the tile in `stage`
+    constexpr int j = decltype(jc)::value, ks = j / SN, sidx = j % SN;
+    const unsigned char* b = (HOLD_A ? Ws + stage * STAGE_W : As + stage * STAGE_A) + s_row + (ks ? c1 : c0);
+    qf[decltype(slotc)::value] = *reinterpret_cast<const bf16x8*>(b + sidx * 16 * 128);
+  };
+  auto issue_piece = [&](auto ic, const int stage) {   // W pieces 0 .. WP-1, then A pieces
+    constexpr int i = decltype(ic)::value;
+    if constexpr (i < WP) {
+      issue_w(ic, stage);
+      if constexpr (i == WP - 1) next_w();
+    } else {
+      issue_a(ic_t<i - WP>{}, stage);
+      if constexpr (i == NP - 1) next_a();
+    }
+  };
+  // (two copies of the body: every iteration but the last, and the last; whether tile t+2 exists is a run-time flag there -- three
+  // uniform branches per K-tile; a third copy made the register allocator shuffle the accumulators between the copies)
+  auto iter = [&](auto rc, const int cur, const bool more2) {
+    constexpr bool more = decltype(rc)::value != 0;
+    const int nxt = cur ^ 1;
+    static_for<0, STEPS>([&](auto jc) {
+      constexpr int j = decltype(jc)::value, ks = j / SN, sidx = j % SN;
+      // (the k-step-1 held set is read two steps before its first use, not at step 0: its registers are free while the pieces
+      // of the first steps -- a conv's gather arithmetic -- are issued; at step 0 the same code spilled 110 registers)
+      if constexpr (j == SN - 2) read_hold(ic_t<1>{}, cur);
+      if constexpr (j == STEPS - Q && more) {
+        wait_vmcnt_imm<0>();                      // own pieces of tile t+1 (the last one issued STEPS - NP steps ago)
+        __builtin_amdgcn_s_waitcnt(0xC07F);       // every read of tile t retired
+        SD_PIPE_BARRIER();
+        read_hold(ic_t<0>{}, nxt);
+      }
+      constexpr int jr = j + Q;
+      if constexpr (jr < STEPS) read_stream(ic_t<jr % QN>{}, cur, ic_t<jr>{});
+      else if constexpr (more) read_stream(ic_t<jr % QN>{}, nxt, ic_t<jr - STEPS>{});
+      if constexpr (more && j < NP - Q) issue_piece(ic_t<Q + j>{}, nxt);
+      if constexpr (more && j >= STEPS - Q) {
+        if (more2) issue_piece(ic_t<j - (STEPS - Q)>{}, cur);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // keep the read Q steps ahead of its use (the scheduler would sink it)
+      static_for<0, HN>([&](auto hc) {
+        constexpr int h = decltype(hc)::value;
+        if constexpr (HOLD_A) acc[sidx][h] = mfma_16x16x32(qf[j % QN], hold[ks][h], acc[sidx][h]);
+        else acc[h][sidx] = mfma_16x16x32(hold[ks][h], qf[j % QN], acc[h][sidx]);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  const int nt = t1 - t0;
+  static_for<0, NP>([&](auto ic) { issue_piece(ic, 0); });
+  wait_vmcnt_imm<0>();
+  SD_PIPE_BARRIER();
+  if (nt > 1) static_for<0, Q>([&](auto ic) { issue_piece(ic, 1); });
+  stamp(1);
+  init_acc();
+  read_hold(ic_t<0>{}, 0);
+  static_for<0, Q>([&](auto jc) { read_stream(ic_t<decltype(jc)::value % QN>{}, 0, jc); });
+  int cur = 0, nrem = nt;
+  for (; nrem > 1; --nrem) {
+    iter(ic_t<1>{}, cur, nrem > 2);
+    cur ^= 1;
+  }
+  iter(ic_t<0>{}, cur, false);
   } else {
   // ---- streaming variant (256x320 tiles: 160 accumulator registers) ----
   // The smaller operand of a k-step is HELD (two sets, k-step 0 / 1), the larger one STREAMS through a (Q+1)-slot
@@ -491,15 +746,15 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& p) {
   }   // tiles of this block
 }
 
-template <bool CONV, class CFG, bool LN, int LW = 0, int SG = 0>
+template <bool CONV, class CFG, bool LN, int LW = 0, int SG = 0, int IL = 0>
 __global__ __launch_bounds__(CFG::THREADS + LW * 64, (LW ? 3 : CFG::MIN_WAVES)) void gemm_pipe_kernel(const GemmArgs p) {
-  gemm_pipe_body<CONV, CFG, LN, LW, SG, false>(p);
+  gemm_pipe_body<CONV, CFG, LN, LW, SG, false, IL>(p);
 }
 // the early-residual form: the compiler allocates v0 .. v215 only, v216 .. v255 are the landing zone of the asm loads
 // (gemm_epilogue.h EpiPre; the attribute takes no template-dependent argument, hence the second entry point)
-template <bool CONV, class CFG>
+template <bool CONV, class CFG, int IL = 0>
 __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES) __attribute__((amdgpu_num_vgpr(216))) void gemm_pipe_pre_kernel(const GemmArgs p) {
-  gemm_pipe_body<CONV, CFG, false, 0, 0, true>(p);
+  gemm_pipe_body<CONV, CFG, false, 0, 0, true, IL>(p);
 }
 
 // Grid of a launch: one block per tile, capped at what the chip holds at once (persistent blocks, see the kernel) when there are
@@ -558,6 +813,44 @@ static bool pre_applies(const GemmArgs& a) {
   }
 }
 
+// interleaved K loop (template IL): MI355X_SD_GEMM_IL=0 selects the round-3 burst loop (A/B switch; same results bit for bit)
+static int gemm_il() {
+  static const int v = [] {
+    const char* e = getenv("MI355X_SD_GEMM_IL");
+    return e ? atoi(e) : 1;
+  }();
+  return v;
+}
+
+template <bool CONV, class CFG, bool LN, int IL>
+static int launch_pipe_il(const GemmArgs& a, hipStream_t stream) {
+  const int ntm = (a.M + CFG::BM - 1) / CFG::BM, ntn = (a.N + CFG::BN - 1) / CFG::BN;
+  const int ny = a.splitk > 1 ? a.splitk : 1;
+  if constexpr (!CONV && !LN && (CFG::TM + CFG::TN) <= 10 && CFG::TM <= 4) {
+    // residual launches (to_out, proj_out, FF2): the residual is fetched during the last TM + 1 K iterations. bf16 residual rows
+    // addressed with 32-bit offsets, N % 8 == 0 (a 16-byte pair load never straddles the row's end), bias in the accumulators, no
+    // GEGLU / gate / fp8 scale / split-K (those epilogues live elsewhere); not the implicit-GEMM convs (their gather state leaves no
+    // room for the 40 landing registers)
+    if (pre_applies<CONV, CFG, LN>(a)) {
+      static const bool pre_ok = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_pre_kernel<CONV, CFG, IL>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES) == hipSuccess;
+      }();
+      if (!pre_ok) return SD_ERR_HIP;
+      hipLaunchKernelGGL((gemm_pipe_pre_kernel<CONV, CFG, IL>), dim3(pipe_grid_x<CFG, 0>(ntm * ntn, ny), ny), dim3(CFG::THREADS), CFG::LDS_BYTES, stream, a);
+      return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+    }
+  }
+  static const bool attr_ok = [] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<CONV, CFG, LN, 0, 0, IL>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES) == hipSuccess;
+  }();
+  if (!attr_ok) return SD_ERR_HIP;
+  hipLaunchKernelGGL((gemm_pipe_kernel<CONV, CFG, LN, 0, 0, IL>), dim3(pipe_grid_x<CFG, 0>(ntm * ntn, ny), ny), dim3(CFG::THREADS), CFG::LDS_BYTES, stream, a);
+  if (a.splitk > 1) launch_splitk_reduce(a, stream);
+  return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+}
+
 template <bool CONV, class CFG, bool LN>
 static int launch_pipe(const GemmArgs& a, hipStream_t stream) {
   // only the 256x160 three-stage tile leaves room for 12 waves per CU (166 VGPRs <= the 168 of three waves per SIMD); the larger
@@ -569,31 +862,7 @@ static int launch_pipe(const GemmArgs& a, hipStream_t stream) {
     if (gemm_loaders() == 5 || (gemm_loaders() == -1 && a.K >= 4096 && a.splitk <= 1 && !pre_applies<CONV, CFG, LN>(a)))
       return launch_pipe_lw<CONV, CFG, LN, 4, 1>(a, stream);   // + interleaved fragment reads
   }
-  const int ntm = (a.M + CFG::BM - 1) / CFG::BM, ntn = (a.N + CFG::BN - 1) / CFG::BN;
-  const int ny = a.splitk > 1 ? a.splitk : 1;
-  if constexpr (!CONV && !LN && (CFG::TM + CFG::TN) <= 10 && CFG::TM <= 4) {
-    // residual launches (to_out, proj_out, FF2): the residual is fetched during the last TM + 1 K iterations. bf16 residual rows
-    // addressed with 32-bit offsets, N % 8 == 0 (a 16-byte pair load never straddles the row's end), bias in the accumulators, no
-    // GEGLU / gate / fp8 scale / split-K (those epilogues live elsewhere); not the implicit-GEMM convs (their gather state leaves no
-    // room for the 40 landing registers)
-    if (pre_applies<CONV, CFG, LN>(a)) {
-      static const bool pre_ok = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_pre_kernel<CONV, CFG>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES) == hipSuccess;
-      }();
-      if (!pre_ok) return SD_ERR_HIP;
-      hipLaunchKernelGGL((gemm_pipe_pre_kernel<CONV, CFG>), dim3(pipe_grid_x<CFG, 0>(ntm * ntn, ny), ny), dim3(CFG::THREADS), CFG::LDS_BYTES, stream, a);
-      return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
-    }
-  }
-  static const bool attr_ok = [] {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<CONV, CFG, LN>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES) == hipSuccess;
-  }();
-  if (!attr_ok) return SD_ERR_HIP;
-  hipLaunchKernelGGL((gemm_pipe_kernel<CONV, CFG, LN>), dim3(pipe_grid_x<CFG, 0>(ntm * ntn, ny), ny), dim3(CFG::THREADS), CFG::LDS_BYTES, stream, a);
-  if (a.splitk > 1) launch_splitk_reduce(a, stream);
-  return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+  return gemm_il() ? launch_pipe_il<CONV, CFG, LN, 1>(a, stream) : launch_pipe_il<CONV, CFG, LN, 0>(a, stream);
 }
 
 // tile: 128 | 160 (pick_tile ids). Returns SD_ERR_UNSUPPORTED when the fast path does not apply (caller falls back).

@@ -77,6 +77,20 @@ for B, H, W, Cin, Cout in ((2, 32, 32, 640, 640), (1, 30, 34, 320, 640)):
     res[f"conv {B}x{H}x{W}x{Cin}->{Cout} +temb+R"] = dict(
         sha=hashlib.sha256(out.cpu().view(torch.int16).numpy().tobytes()).hexdigest()[:16],
         rel=((out[:H * W].float() - ref).norm() / ref.norm()).item())
+# launches of 1, 2, 3 and 5 K-tiles (the interleaved loop's unrolled tail alone; too short for the early residual fetch) and one
+# small-M launch that takes split-K slices (uneven last slice)
+for M, N, K, resid in ((300, 1280, 64, True), (4100, 2560, 128, False), (300, 640, 192, True), (8192, 1280, 320, True),
+                       (256, 1280, 5184, False), (96, 640, 2240, True)):
+    g = torch.Generator(device="cuda").manual_seed(M + N + K + 3)
+    a = torch.randn(M, K, device="cuda", generator=g).to(ed)
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(ed)
+    b = torch.randn(N, device="cuda", generator=g)
+    r = torch.randn(M, N, device="cuda", generator=g).to(ed) if resid else None
+    out = ops.linear(a, w, b, residual=r)
+    ref = a.float() @ w.float().t() + b + (r.float() if resid else 0)
+    res[f"gemm {M}x{N}x{K}{'+R' if resid else ''} short"] = dict(
+        sha=hashlib.sha256(out.cpu().view(torch.int16).numpy().tobytes()).hexdigest()[:16],
+        rel=((out.float() - ref).norm() / ref.norm()).item())
 for B, H, W, Cin, Cout in ((8, 32, 32, 1280, 1280), (2, 30, 34, 640, 1280)):      # 11520- / 5760-deep implicit-GEMM convs
     g = torch.Generator(device="cuda").manual_seed(B + H + Cin)
     x = torch.randn(B, H, W, Cin, device="cuda", generator=g).to(ed)

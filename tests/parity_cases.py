@@ -30,6 +30,9 @@ CASES = {
     "sdxl_1x4x32x32_euler30": dict(kind="unet", cfg=SDXL, B=1, C=4, H=32, W=32, L=77, sched="euler", steps=30, keep="all"),
     # one prompt of the headline geometry, 10 Euler steps
     "sdxl_1x4x128x128_euler10": dict(kind="unet", cfg=SDXL, B=1, C=4, H=128, W=128, L=77, sched="euler", steps=10, keep=[0, 9]),
+    # the same prompt over the metric's whole 30-step Euler schedule (round 4: north_star's tolerance is stated on the end latents
+    # of the headline geometry; 16 minutes of CPU for the oracle loop)
+    "sdxl_1x4x128x128_euler30": dict(kind="unet", cfg=SDXL, B=1, C=4, H=128, W=128, L=77, sched="euler", steps=30, keep=[0, 15, 29]),
     # BASELINE config 2: SD-1.5, 50 DDIM steps
     "sd15_1x4x64x64_ddim50": dict(kind="unet", cfg=SD15, B=1, C=4, H=64, W=64, L=77, sched="ddim", steps=50, keep=[0, 25, 49]),
     # BASELINE config 5: SD3-medium MMDiT, 28 flow-matching Euler steps (512^2 image = 64x64 latents: the CPU oracle at 128x128

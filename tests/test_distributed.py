@@ -86,10 +86,17 @@ def test_bench_gpus_n_starts_its_own_ranks():
         if p.returncode == 0 or "address already in use" not in p.stderr.lower():
             break
     assert p.returncode == 0, p.stderr[-2000:]
-    # (the gloo transport of the CPU stand-in announces its connections on stdout; RCCL does not)
-    lines = [ln for ln in p.stdout.splitlines() if ln.strip() and "[Gloo]" not in ln and "peer ranks" not in ln]
+    # the gloo transport of the CPU stand-in announces its connections on stdout (RCCL does not) and two ranks interleave those
+    # banners, fragments included: the JSON line is the one that parses, and there is exactly one
+    lines = []
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{"):
+            try:
+                lines.append(json.loads(ln))
+            except ValueError:
+                pass
     assert len(lines) == 1, p.stdout
-    r = json.loads(lines[0])
+    r = lines[0]
     assert r["n_gpus"] == 2 and r["steps"] == 2 and r["warmup"] == 1 and r["scaling"] == "weak" and "selftest" in r
     assert len(r["per_rank_ms_per_step"]) == 2 and r["gathered_latents"] == [4, 4, 8, 8]
     assert r["config"]["global_batch"] == 2 * r["config"]["batch_per_gpu"]

@@ -73,3 +73,19 @@ def test_four_wave_tiles(tile_map):
         # order: equal within the tolerance only.)
         if "257" not in tile_map:
             assert got[k]["sha"] == base[k]["sha"], (tile_map, k, got[k], base[k])
+
+
+@pytest.mark.parametrize("tile_env", [{}, {"MI355X_SD_GEMM_TILE": "320"}, {"MI355X_SD_GEMM_TILE": "128"}, {"MI355X_SD_GEMM_TILE": "129"},
+                                      {"MI355X_SD_GEMM_TILE": "160"}, {"MI355X_SD_GEMM_TILE": "257", "MI355X_SD_PIPE256": "1"}],
+                         ids=["picker", "256x320", "128x128", "128x160", "256x160", "256x256-pipelined"])
+def test_interleaved_k_loop_is_bit_identical_to_the_burst_loop(tile_env):
+    """Round 4: the interleaved K loop (csrc/gemm_pipe.hip, template IL: one LDS-DMA piece / one fragment read between small MFMA
+    groups, the A and W pieces of a tile issued in different half-iterations, unrolled tail, static vmcnt) against the round-3 loop
+    (MI355X_SD_GEMM_IL=0) on every tile family: WHEN operands are staged changes, the accumulation order does not -- same bits.
+    Covers the register-pipelined and the streaming form, two and three LDS stages, the early-residual kernels, GEGLU, ragged M / N,
+    launches of 1 .. 3 K-tiles (the unrolled tail alone) and the implicit-GEMM convs."""
+    old = _run(dict(tile_env, MI355X_SD_GEMM_IL="0", MI355X_SD_GEMM_LOADERS="0"))
+    new = _run(dict(tile_env, MI355X_SD_GEMM_IL="1", MI355X_SD_GEMM_LOADERS="0"))
+    for k, v in new.items():
+        assert v["rel"] < 4e-3, (tile_env, k, v)
+        assert v["sha"] == old[k]["sha"], (tile_env, k, v, old[k])
