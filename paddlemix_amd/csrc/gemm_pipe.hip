@@ -241,9 +241,6 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& p) {
     if ((i + 1) * PW <= CFG::W_TOTAL || pw + i * PW < CFG::W_TOTAL) dma(w_rsrc, Ws + stage * STAGE_W + (pw + i * PW) * 1024, w_off[i], kW * 2);
   };
   [[maybe_unused]] auto next_w = [&]() { kW += BK; };
-  int mine_a = 0;   // this wave's A pieces per K-tile (mine - mine_a = its W pieces)
-#pragma unroll
-  for (int i = 0; i < AP; ++i) mine_a += (pw + i * PW < CFG::A_TOTAL) ? 1 : 0;
   // s_waitcnt vmcnt(BASE [+ the pieces of one tile]). Where the pieces do not divide evenly over the waves (256 x 160: 20 W pieces on
   // 8 waves) the count is the SMALLER one for every wave: exact for the waves that own fewer pieces; the others also wait for
   // the oldest piece of the newer tile, issued most of an iteration earlier -- cheaper than the branch per K-tile that picks the
@@ -380,19 +377,34 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& p) {
     }
   };
   // one half-iteration. SET: the fragment set the MFMAs consume (the reads fill the other one from rstage); DK: 0 no DMA, 1 this
-  // wave's W pieces, 2 its A pieces (-> dstage); PR: residual row-tile requested at the last step (-1: none)
-  auto half = [&](auto setc, auto rdc, auto dkc, auto prc, const int rstage, const int dstage) {
+  // wave's W pieces, 2 its A pieces (-> dstage), +2: only if dma_on (run-time, wave-uniform); PR: residual row-tile requested at
+  // the last step (-1: none, -2: row pr_rt, run-time)
+  auto half = [&](auto setc, auto rdc, auto dkc, auto prc, const int rstage, const int dstage, const bool dma_on, const int pr_rt) {
     constexpr int SET = decltype(setc)::value, RD = decltype(rdc)::value, DK = decltype(dkc)::value, PR = decltype(prc)::value;
     static_for<0, NSTEP>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
       if constexpr (RD && k < NR) read_one(ic_t<SET ^ 1>{}, kc, rstage);
-      if constexpr (DK == 1) static_for<0, WP>([&](auto ic) {
-        if constexpr (il_piece_step(decltype(ic)::value, WP, NSTEP) == k) issue_w(ic, dstage);
+      if constexpr (DK == 1 || DK == 3) static_for<0, WP>([&](auto ic) {
+        if constexpr (il_piece_step(decltype(ic)::value, WP, NSTEP) == k) {
+          if (DK == 1 || dma_on) issue_w(ic, dstage);
+        }
       });
-      if constexpr (DK == 2) static_for<0, AP>([&](auto ic) {
-        if constexpr (il_piece_step(decltype(ic)::value, AP, NSTEP) == k) issue_a(ic, dstage);
+      if constexpr (DK == 2 || DK == 4) static_for<0, AP>([&](auto ic) {
+        if constexpr (il_piece_step(decltype(ic)::value, AP, NSTEP) == k) {
+          if (DK == 2 || dma_on) issue_a(ic, dstage);
+        }
       });
-      if constexpr (PRE && PR >= 0 && k == NSTEP - 1) epi_prefetch_row<(PR >= 0 ? PR : 0), TM, TN>(p, r_srd, m_pre, n_pre, lane);
+      if constexpr (PRE && k == NSTEP - 1) {
+        if constexpr (PR >= 0) {
+          epi_prefetch_row<(PR >= 0 ? PR : 0), TM, TN>(p, r_srd, m_pre, n_pre, lane);
+        } else if constexpr (PR == -2) {
+          static_assert(!PRE || TM <= 4, "four row-tiles enumerated");
+          if (pr_rt == 0) epi_prefetch_row<0, TM, TN>(p, r_srd, m_pre, n_pre, lane);
+          if constexpr (TM > 1) if (pr_rt == 1) epi_prefetch_row<(TM > 1 ? 1 : 0), TM, TN>(p, r_srd, m_pre, n_pre, lane);
+          if constexpr (TM > 2) if (pr_rt == 2) epi_prefetch_row<(TM > 2 ? 2 : 0), TM, TN>(p, r_srd, m_pre, n_pre, lane);
+          if constexpr (TM > 3) if (pr_rt == 3) epi_prefetch_row<(TM > 3 ? 3 : 0), TM, TN>(p, r_srd, m_pre, n_pre, lane);
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
       static_for<0, G>([&](auto gc) {
         constexpr int q = k * G + decltype(gc)::value;
@@ -401,25 +413,8 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& p) {
       __builtin_amdgcn_sched_barrier(0);
     });
   };
-  // iteration of tile t in `stage`; R = tiles after it when that is a compile-time fact (tail), -1: at least NTAIL. Returns the
-  // stage of tile t+1.
-  int stage = 0, s1 = 1, sw = ST - 1;   // stages of tiles t, t+1, t+AHEAD (rotated by iter)
-  auto iter = [&](auto rc) {
-    constexpr int R = decltype(rc)::value;
-    constexpr bool has1 = R != 0, hasW = R < 0 || R >= AHEAD, hasA = R < 0 || R >= AHEAD + 1;
-    constexpr int PR = (PRE && R >= 1 && R <= TM) ? TM - R : -1;
-    half(ic_t<0>{}, ic_t<1>{}, ic_t<(hasW ? 1 : 0)>{}, ic_t<PR>{}, stage, sw);
-    if constexpr (hasW) next_w();
-    __builtin_amdgcn_s_waitcnt(0xC07F);          // every read of tile t retired
-    if constexpr (has1) {
-      // tile t+1 must have landed; issued after it: (three stages) the residual loads of iteration t-1, the A and W pieces of tile
-      // t+2, this iteration's residual loads; (two stages) only this iteration's residual loads
-      constexpr int rcur = PR >= 0 ? LPR : 0, rprev = (PRE && R >= 0 && R + 1 <= TM) ? LPR : 0;
-      wait_newer(ic_t<(AHEAD == 2 ? rprev + rcur : rcur)>{}, ic_t<(AHEAD == 2 && (R < 0 || R >= 2) ? 1 : 0)>{});
-      SD_PIPE_BARRIER();                         // publishes tile t+1; every wave is done reading tile t
-    }
-    half(ic_t<1>{}, ic_t<(has1 ? 1 : 0)>{}, ic_t<(hasA ? 2 : 0)>{}, ic_t<-1>{}, s1, stage);
-    if constexpr (hasA) next_a();
+  int stage = 0, s1 = 1, sw = ST - 1;   // stages of tiles t, t+1, t+AHEAD (rotated after every iteration)
+  auto rotate = [&]() {
     const int s0 = stage;
     stage = s1;
     if constexpr (ST == 3) {
@@ -429,6 +424,47 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& p) {
       s1 = sw = s0;
     }
   };
+  // iteration of tile t; R = tiles after it when that is a compile-time fact (unrolled tail), -1: at least NTAIL
+  auto iter = [&](auto rc) {
+    constexpr int R = decltype(rc)::value;
+    constexpr bool has1 = R != 0, hasW = R < 0 || R >= AHEAD, hasA = R < 0 || R >= AHEAD + 1;
+    constexpr int PR = (PRE && R >= 1 && R <= TM) ? TM - R : -1;
+    half(ic_t<0>{}, ic_t<1>{}, ic_t<(hasW ? 1 : 0)>{}, ic_t<PR>{}, stage, sw, true, 0);
+    if constexpr (hasW) next_w();
+    __builtin_amdgcn_s_waitcnt(0xC07F);          // every read of tile t retired
+    if constexpr (has1) {
+      // tile t+1 must have landed; issued after it: (three stages) the residual loads of iteration t-1, the A and W pieces of tile
+      // t+2, this iteration's residual loads; (two stages) only this iteration's residual loads
+      constexpr int rcur = PR >= 0 ? LPR : 0, rprev = (PRE && R >= 0 && R + 1 <= TM) ? LPR : 0;
+      wait_newer(ic_t<(AHEAD == 2 ? rprev + rcur : rcur)>{}, ic_t<(AHEAD == 2 && (R < 0 || R >= 2) ? 1 : 0)>{});
+      SD_PIPE_BARRIER();                         // publishes tile t+1; every wave is done reading tile t
+    }
+    half(ic_t<1>{}, ic_t<(has1 ? 1 : 0)>{}, ic_t<(hasA ? 2 : 0)>{}, ic_t<-1>{}, s1, stage, true, 0);
+    if constexpr (hasA) next_a();
+    rotate();
+  };
+  // the same with R = TM .. 1 at run time: the early-residual kernels walk their last iterations in a LOOP. Unrolled, the register
+  // allocator renames accumulators between the copies (out-of-place MFMA destinations) and took registers above v215 -- the
+  // landing zone of the residual rows, which amdgpu_num_vgpr(216) budgets but does not reserve: the rows were overwritten (NaN on
+  // the first hardware run; scripts/check_landing_zone.py now checks every build). In a loop the accumulators are loop-carried
+  // and stay where they are. Cost: three small wave-uniform selections per K-tile in these TM iterations only.
+  [[maybe_unused]] auto iter_rt = [&](const int R) {
+    const bool hasW = R >= AHEAD, hasA = R >= AHEAD + 1;
+    half(ic_t<0>{}, ic_t<1>{}, ic_t<3>{}, ic_t<-2>{}, stage, sw, hasW, TM - R);
+    if (hasW) next_w();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    if constexpr (AHEAD == 2) {   // (the counts of iter<R> above)
+      if (R == TM) wait_newer(ic_t<LPR>{}, ic_t<1>{});
+      else if (R >= 2) wait_newer(ic_t<2 * LPR>{}, ic_t<1>{});
+      else wait_newer(ic_t<2 * LPR>{}, ic_t<0>{});
+    } else {
+      wait_newer(ic_t<LPR>{}, ic_t<0>{});
+    }
+    SD_PIPE_BARRIER();
+    half(ic_t<1>{}, ic_t<1>{}, ic_t<4>{}, ic_t<-1>{}, s1, stage, hasA, 0);
+    if (hasA) next_a();
+    rotate();
+  };
 
   const int nt = t1 - t0;
   // prologue: tile t0 (and t0+1 with three stages), then what "half 1 of iteration t0-1" would have issued: the A pieces of t0+AHEAD
@@ -436,30 +472,38 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& p) {
   static_for<0, WP>([&](auto ic) { issue_w(ic, 0); });
   next_a();
   next_w();
-  int newer = 0;
+  constexpr int PA = CFG::A_TOTAL / PW, PT = CFG::A_TOTAL / PW + CFG::W_TOTAL / PW;   // pieces every wave owns (wait_newer)
   if (AHEAD == 2 && nt > 1) {
     static_for<0, AP>([&](auto ic) { issue_a(ic, 1); });
     static_for<0, WP>([&](auto ic) { issue_w(ic, 1); });
     next_a();
     next_w();
-    newer = mine;
   }
   if (nt > AHEAD) {
     static_for<0, AP>([&](auto ic) { issue_a(ic, AHEAD); });
     next_a();
-    newer += mine_a;
   }
-  wait_vmcnt_dyn(newer);
+  // tile t0 landed; what was issued after it may stay in flight
+  if (nt > AHEAD) wait_vmcnt_imm<(AHEAD == 2 ? PT + PA : PA)>();
+  else if (AHEAD == 2 && nt > 1) wait_vmcnt_imm<PT>();
+  else wait_vmcnt_imm<0>();
   SD_PIPE_BARRIER();
   stamp(1);
   init_acc();
   static_for<0, NR>([&](auto kc) { read_one(ic_t<0>{}, kc, 0); });
   int nrem = nt;
   for (; nrem > NTAIL; --nrem) iter(ic_t<-1>{});
-  static_for<0, NTAIL>([&](auto jc) {
-    constexpr int R = NTAIL - 1 - decltype(jc)::value;
-    if (PRE || nrem > R) iter(ic_t<R>{});   // (PRE launches have at least TM + 2 > NTAIL - 1 K-tiles: launch_pipe)
-  });
+  if constexpr (PRE) {   // (these launches have at least TM + 2 > NTAIL K-tiles: launch_pipe)
+    static_assert(!PRE || (TM >= AHEAD && NTAIL == TM + 1), "tail of the early-residual kernels");
+#pragma nounroll
+    for (int R = TM; R >= 1; --R) iter_rt(R);
+    iter(ic_t<0>{});
+  } else {
+    static_for<0, NTAIL>([&](auto jc) {
+      constexpr int R = NTAIL - 1 - decltype(jc)::value;
+      if (nrem > R) iter(ic_t<R>{});
+    });
+  }
   } else if constexpr (!STREAM) {
   // ---- fragments: two register sets (k-step 0 / 1 of a K-tile) ----
   bf16x8 fa[2][TM], fw[2][TN];
@@ -593,17 +637,17 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& p) {
       if constexpr (i == NP - 1) next_a();
     }
   };
-  // (two copies of the body: every iteration but the last, and the last; whether tile t+2 exists is a run-time flag there -- three
-  // uniform branches per K-tile; a third copy made the register allocator shuffle the accumulators between the copies)
-  auto iter = [&](auto rc, const int cur, const bool more2) {
-    constexpr bool more = decltype(rc)::value != 0;
+  // ONE copy of the body; "is there a tile t+1 / t+2" are run-time flags (a dozen never-taken wave-uniform branches per K-tile).
+  // Separate copies for the last iterations (as the register-pipelined loop has them) made the register allocator rename the
+  // 160 accumulators between the copies: 110 spilled registers in the conv instantiation, 27-70 in the others.
+  auto iter = [&](auto rc, const int cur, const bool more2, const bool more) {
     const int nxt = cur ^ 1;
     static_for<0, STEPS>([&](auto jc) {
       constexpr int j = decltype(jc)::value, ks = j / SN, sidx = j % SN;
       // (the k-step-1 held set is read two steps before its first use, not at step 0: its registers are free while the pieces
       // of the first steps -- a conv's gather arithmetic -- are issued; at step 0 the same code spilled 110 registers)
       if constexpr (j == SN - 2) read_hold(ic_t<1>{}, cur);
-      if constexpr (j == STEPS - Q && more) {
+      if (j == STEPS - Q && more) {
         wait_vmcnt_imm<0>();                      // own pieces of tile t+1 (the last one issued STEPS - NP steps ago)
         __builtin_amdgcn_s_waitcnt(0xC07F);       // every read of tile t retired
         SD_PIPE_BARRIER();
@@ -611,10 +655,10 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& p) {
       }
       constexpr int jr = j + Q;
       if constexpr (jr < STEPS) read_stream(ic_t<jr % QN>{}, cur, ic_t<jr>{});
-      else if constexpr (more) read_stream(ic_t<jr % QN>{}, nxt, ic_t<jr - STEPS>{});
-      if constexpr (more && j < NP - Q) issue_piece(ic_t<Q + j>{}, nxt);
-      if constexpr (more && j >= STEPS - Q) {
-        if (more2) issue_piece(ic_t<j - (STEPS - Q)>{}, cur);
+      else if (more) read_stream(ic_t<jr % QN>{}, nxt, ic_t<(jr >= STEPS ? jr - STEPS : 0)>{});
+      if constexpr (j < NP - Q) { if (more) issue_piece(ic_t<(j < NP - Q ? Q + j : 0)>{}, nxt); }
+      if constexpr (j >= STEPS - Q) {
+        if (more2) issue_piece(ic_t<(j >= STEPS - Q ? j - (STEPS - Q) : 0)>{}, cur);
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the read Q steps ahead of its use (the scheduler would sink it)
       static_for<0, HN>([&](auto hc) {
@@ -636,11 +680,10 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& p) {
   read_hold(ic_t<0>{}, 0);
   static_for<0, Q>([&](auto jc) { read_stream(ic_t<decltype(jc)::value % QN>{}, 0, jc); });
   int cur = 0, nrem = nt;
-  for (; nrem > 1; --nrem) {
-    iter(ic_t<1>{}, cur, nrem > 2);
+  for (; nrem > 0; --nrem) {
+    iter(ic_t<1>{}, cur, nrem > 2, nrem > 1);
     cur ^= 1;
   }
-  iter(ic_t<0>{}, cur, false);
   } else {
   // ---- streaming variant (256x320 tiles: 160 accumulator registers) ----
   // The smaller operand of a k-step is HELD (two sets, k-step 0 / 1), the larger one STREAMS through a (Q+1)-slot

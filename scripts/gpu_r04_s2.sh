@@ -4,7 +4,7 @@
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $O
 cd $GRAFT_REPO_ROOT
-T=r04_s1
+T=r04_s2
 ( timeout 900 python -m pytest tests/test_gpu_gemm_variants.py -m gpu -q -x -k "interleaved" 2>&1 | tail -15 ) > $O/${T}_tests.txt
 cat $O/${T}_tests.txt
 : > $O/${T}_variants.txt

@@ -38,7 +38,29 @@ CASES = {
     # BASELINE config 5: SD3-medium MMDiT, 28 flow-matching Euler steps (512^2 image = 64x64 latents: the CPU oracle at 128x128
     # needs ~1.5 min per step here)
     "sd3_1x16x64x64_flow28": dict(kind="sd3", cfg=SD3_MEDIUM, B=1, C=16, H=64, W=64, L=154, sched="flow", steps=28, keep=[0, 14, 27]),
+    # the same loop as the fp8 modes see it (round 4): the oracle multiplies by the SAME quantised operands -- block matrices through
+    # the e4m3 + per-channel-scale round trip (fp8w), plus per-token e4m3 activations into the block GEMMs (w8a8,
+    # oracle/sd3_ref.py act_quant) -- so that what is compared is the kernels' arithmetic, not the quantisation the mode chose
+    "sd3_1x16x64x64_flow28_fp8w": dict(kind="sd3", cfg=SD3_MEDIUM, B=1, C=16, H=64, W=64, L=154, sched="flow", steps=28, keep=[0, 14, 27],
+                                       quant="fp8w"),
+    "sd3_1x16x64x64_flow28_w8a8": dict(kind="sd3", cfg=SD3_MEDIUM, B=1, C=16, H=64, W=64, L=154, sched="flow", steps=28, keep=[0, 14, 27],
+                                       quant="w8a8"),
 }
+
+
+def fp8_roundtrip(P):
+    """block matrices -> e4m3 with one fp32 scale per output channel (absmax / 448) and back: the numbers a weight_dtype="fp8" model
+    multiplies by (paddlemix_amd/sd3.py quantize_fp8_rows is the device-side definition; restated here for the checker)"""
+    out = {}
+    for k, v in P.items():
+        if k.startswith("transformer_blocks.") and k.endswith(".weight") and ".norm1" not in k:
+            w = v.t().contiguous()                                    # [N, K]
+            scale = w.abs().amax(dim=1).clamp_min(1e-12) / 448.0
+            q = (w / scale[:, None]).to(torch.float8_e4m3fn).to(torch.float32)
+            out[k] = (q * scale[:, None]).t().contiguous()
+        else:
+            out[k] = v
+    return out
 
 
 def dual16(P):
@@ -138,7 +160,10 @@ def run_loop(case, predict, x_init, on_step=None, sched=None):
 def oracle_predictor(case, P, enc, extra):
     if case["kind"] == "sd3":
         from oracle.sd3_ref import sd3_forward
-        return lambda x_in, t, i: sd3_forward(P, case["cfg"], x_in, enc, extra, float(t))
+        if case.get("quant"):
+            P = fp8_roundtrip(P)
+        aq = case.get("quant") == "w8a8"
+        return lambda x_in, t, i: sd3_forward(P, case["cfg"], x_in, enc, extra, float(t), act_quant=aq)
     from oracle.unet_ref import unet_forward
     return lambda x_in, t, i: unet_forward(P, case["cfg"], x_in, int(t), enc, added_cond_kwargs=extra)
 

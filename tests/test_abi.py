@@ -48,3 +48,16 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
                 assert not re.search(r"^\s*(from|import)\s+tests\b", txt, flags=re.M), f
+
+
+def test_early_residual_kernels_keep_their_landing_registers():
+    """csrc/gemm_pipe.hip gemm_pipe_pre_kernel: the residual rows land in v216 .. v255 through hand-written loads; nothing the
+    compiler generated may name those registers (amdgpu_num_vgpr(216) is a budget, not a reservation -- round 4 hit exactly
+    that). Disassembles both built libraries; no GPU needed."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_landing_zone.py")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "6 early-residual kernels, 0 compiler-generated uses" in p.stdout, p.stdout

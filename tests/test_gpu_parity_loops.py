@@ -1,13 +1,17 @@
-"""-m gpu: north_star's parity bar on the real depth. "Latents within 1e-3 rel-err of the CPU reference": the full SDXL parameter
-set (2.6 B parameters), 30 Euler steps, free-running device loop against the committed oracle trajectory
-(tests/golden/parity/sdxl_1x4x32x32_euler30.npz, made by scripts/make_parity_golden.py; oracle = torch-CPU restatement of
-ppdiffusers, pinned to the reference's own module code by tests/test_reference_modules.py), in the four device modes {bf16, fp16 elements} x {16-bit, fp32 residual stream}.
+"""-m gpu: north_star's parity bar on the real depth, every full-depth fixture of tests/golden/parity in the suite (round 4).
+"Latents within 1e-3 rel-err of the CPU reference": free-running device loops against the committed oracle trajectories
+(scripts/make_parity_golden.py; oracle = torch-CPU restatement of ppdiffusers, its stored predictions reproduced bit for bit by the
+reference's own model code over the paddle shim, profiles/r03_parity_fixtures_vs_reference.txt):
 
-The ABSOLUTE target is asserted where it is met (fp16 elements; must pass) and recorded as a strict xfail where it is not (the bf16
-headline: the 2^-9 operand rounding of ~230 sequential contractions) -- so the suite states the gap instead of
-hiding it behind "1.5 x whatever was measured". All four numbers, the other geometries (128x128 latents, SD-1.5 / 50 DDIM steps,
-SD3 / 28 flow-matching steps with 16-bit and fp8 weights) and the per-step prediction errors are in profiles/r03_parity.json
-(scripts/parity_loops.py)."""
+  * full SDXL (2.6 B parameters): 30 Euler steps at 1x4x32x32; 10 AND 30 Euler steps at 1x4x128x128 (one prompt of the headline
+    geometry over the metric's whole schedule);
+  * full SD-1.5, 50 DDIM steps at 1x4x64x64 (BASELINE config 2); SD3-medium, 28 flow-matching steps at 1x16x64x64 (config 5);
+  * the SD3 loop in the fp8 modes against oracle trajectories computed on the SAME quantised operands (weight-only e4m3; W8A8).
+
+The ABSOLUTE target is asserted where it is met -- fp16 elements, with the 16-bit residual stream of the headline as well as with
+the fp32 stream: must pass -- and recorded as a strict xfail with the measured number where it is not (bf16 elements: the 2^-9
+operand rounding of ~230 sequential contractions), so the suite states the gap instead of hiding it behind
+"1.5 x whatever was measured". Measured values: profiles/r04_parity.json (scripts/parity_loops.py, the same children)."""
 import json
 import os
 import subprocess
@@ -17,53 +21,84 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CASE = "sdxl_1x4x32x32_euler30"
 TARGET = 1e-3
+SDXL_CASES = ("sdxl_1x4x32x32_euler30", "sdxl_1x4x128x128_euler10", "sdxl_1x4x128x128_euler30")
+OTHER_CASES = ("sd15_1x4x64x64_ddim50", "sd3_1x16x64x64_flow28")
+FP8_CASES = ("sd3_1x16x64x64_flow28_fp8w", "sd3_1x16x64x64_flow28_w8a8")
+ALL = SDXL_CASES + OTHER_CASES + FP8_CASES
 
 
 @pytest.fixture(scope="module")
 def loops(tmp_path_factory):
-    """one child process per library build (one element type per process); the seeded weights are drawn once and shared"""
+    """one child process per library build (one element type per process); the seeded weights of a model family are drawn once and
+    shared between the children through a file"""
     cache = str(tmp_path_factory.mktemp("parity_params"))
     out = {}
     for elem in ("bf16", "fp16"):
         env = dict(os.environ, MI355X_SD_DTYPE=elem)
         env.pop("MI355X_SD_RESID", None)
-        p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "parity_loops.py"), "--child", elem, "--cases", CASE,
-                            "--cache-dir", cache], env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "parity_loops.py"), "--child", elem, "--cases", ",".join(ALL),
+                            "--cache-dir", cache], env=env, cwd=ROOT, capture_output=True, text=True, timeout=3000)
         assert p.returncode == 0, p.stderr[-3000:]
         line = [ln for ln in p.stdout.splitlines() if ln.startswith("PARITY_JSON ")][-1]
-        out[elem] = json.loads(line[len("PARITY_JSON "):])[CASE]
-    print("full SDXL, 30 Euler steps, rel-L2 vs the oracle trajectory:", json.dumps(out))
+        out[elem] = json.loads(line[len("PARITY_JSON "):])
+    print("full-depth loops, rel-L2 of the end latents vs the oracle trajectories:",
+          json.dumps({e: {c: {m: round(r["end_latents_rel"], 6) for m, r in v.items()} for c, v in d.items()} for e, d in out.items()}))
     return out
 
 
-def test_fp16_fp32_stream_meets_the_latents_target(loops):
-    r = loops["fp16"]["resid_fp32"]
-    assert r["end_latents_rel"] < TARGET, r            # the configuration bench.py reports as "parity_mode"
-    assert r["pred_rel_teacher_forced_max"] < 2.5e-3, r
+@pytest.mark.parametrize("case", SDXL_CASES + OTHER_CASES)
+def test_fp16_meets_the_latents_target(loops, case):
+    """fp16 elements: both residual-stream types (UNets) / 16-bit weights (SD3) -- the mode bench.py reports as "parity_mode" is
+    fp16 + the 16-bit stream, i.e. the headline kernels on the other element type"""
+    for mode, r in loops["fp16"][case].items():
+        assert r["end_latents_rel"] < TARGET, (case, mode, r)
+        assert r["pred_rel_teacher_forced_max"] < 4e-3, (case, mode, r)
 
 
-def test_fp16_16bit_stream_meets_the_latents_target(loops):
-    r = loops["fp16"]["resid_16"]
-    assert r["end_latents_rel"] < TARGET, r
-    assert r["pred_rel_teacher_forced_max"] < 4e-3, r
+# bf16 elements, measured on the MI355X in round 3 (profiles/r03_parity.json): end latents, 16-bit / fp32 residual stream
+BF16_R03 = {"sdxl_1x4x32x32_euler30": (2.37e-3, 1.58e-3), "sdxl_1x4x128x128_euler10": (3.47e-3, 2.19e-3),
+            "sdxl_1x4x128x128_euler30": (None, None), "sd15_1x4x64x64_ddim50": (1.42e-3, 9.3e-4), "sd3_1x16x64x64_flow28": (2.26e-3, None)}
 
 
-@pytest.mark.xfail(strict=True, reason="bf16 elements miss north_star's 1e-3 on the end latents: 2.6e-3 (16-bit stream) measured on "
-                                       "the full SDXL depth in round 2, profiles/r02_parity.json -- operand rounding 2^-9 x ~230 "
-                                       "sequential contractions; the fp16 build meets it")
-def test_bf16_16bit_stream_latents_target(loops):
-    assert loops["bf16"]["resid_16"]["end_latents_rel"] < TARGET
+@pytest.mark.parametrize("case", SDXL_CASES + OTHER_CASES)
+@pytest.mark.xfail(strict=True, reason="bf16 elements with the 16-bit stream miss north_star's 1e-3 on the end latents at every full-depth "
+                                       "geometry (1.4e-3 .. 3.5e-3, profiles/r03_parity.json / r04_parity.json): operand rounding 2^-9 x "
+                                       "~230 sequential contractions; the fp16 build meets it")
+def test_bf16_16bit_stream_latents_target(loops, case):
+    mode = "w16" if case.startswith("sd3") else "resid_16"
+    assert loops["bf16"][case][mode]["end_latents_rel"] < TARGET
 
 
-@pytest.mark.xfail(strict=True, reason="bf16 elements + fp32 residual stream: 1.6e-3 on the end latents (round 2), still above 1e-3")
-def test_bf16_fp32_stream_latents_target(loops):
-    assert loops["bf16"]["resid_fp32"]["end_latents_rel"] < TARGET
+@pytest.mark.parametrize("case", SDXL_CASES)
+@pytest.mark.xfail(strict=True, reason="bf16 elements + fp32 residual stream on the SDXL depth: 1.6e-3 .. 2.2e-3 on the end latents")
+def test_bf16_fp32_stream_latents_target_sdxl(loops, case):
+    assert loops["bf16"][case]["resid_fp32"]["end_latents_rel"] < TARGET
+
+
+def test_bf16_fp32_stream_meets_the_target_on_sd15(loops):
+    """the one bf16 configuration that does meet the bar: SD-1.5 (half the depth of SDXL), fp32 residual stream (9.3e-4 in round 3)"""
+    assert loops["bf16"]["sd15_1x4x64x64_ddim50"]["resid_fp32"]["end_latents_rel"] < TARGET
 
 
 def test_bf16_regression_bars(loops):
-    """what the bf16 headline DOES hold (regression guards at 1.5 x the measured values of profiles/r02_parity.json)"""
-    assert loops["bf16"]["resid_16"]["end_latents_rel"] < 1.5 * 2.6e-3 and loops["bf16"]["resid_fp32"]["end_latents_rel"] < 1.5 * 1.63e-3
-    assert loops["bf16"]["resid_16"]["pred_rel_teacher_forced_max"] < 1.5 * 1.6e-2
-    assert loops["bf16"]["resid_fp32"]["end_latents_rel"] < loops["bf16"]["resid_16"]["end_latents_rel"]
+    """what the bf16 headline DOES hold (regression guards at 1.5 x the values measured in round 3)"""
+    for case, (r16, r32) in BF16_R03.items():
+        got = loops["bf16"][case]
+        m16 = got.get("resid_16") or got["w16"]
+        assert m16["end_latents_rel"] < 1.5 * (r16 or 3.5e-3), (case, m16)
+        assert m16["pred_rel_teacher_forced_max"] < 1.5 * 1.63e-2, (case, m16)
+        if "resid_fp32" in got:
+            assert got["resid_fp32"]["end_latents_rel"] < min(1.5 * (r32 or 2.2e-3), m16["end_latents_rel"]), (case, got)
+
+
+@pytest.mark.parametrize("case", FP8_CASES)
+def test_fp8_modes_vs_the_oracle_on_the_same_quantised_operands(loops, case):
+    """BASELINE config 5: the fp8 modes against an oracle that multiplies by the same e4m3 operands. What remains is what the bf16
+    path has on this loop (16-bit activations between the GEMMs; 2.3e-3 in round 3) -- against the unquantised oracle the same
+    device loops sit at 1e-2, which is the quantisation the mode chose, not kernel error. Bars: 1.5 x the bf16-weights loop's value
+    for weight-only fp8; W8A8 quantises activations at 3 mantissa bits, where a rounding tie decided differently by the device
+    (bf16 producer) and the fp32 oracle moves a whole e4m3 step: 3 x."""
+    (mode, r), = loops["bf16"][case].items()
+    bar = 1.5 * 2.26e-3 if mode == "fp8w" else 3 * 2.26e-3
+    assert r["end_latents_rel"] < bar, (case, r)
