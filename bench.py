@@ -80,6 +80,9 @@ def parse():
     # the one-JSON-line contract on CPU ranks (gloo) with the C-ABI interpreter of tests/abi_emulator.py standing in for the
     # library on the tiny test UNet. The line it prints says "selftest": it is never a measurement.
     ap.add_argument("--selftest-cpu", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the multi-rank code path (RCCL process group, weight broadcast, text encoders from broadcast weights, "
+                         "barriers, final all-gather) even with one rank: the N > 1 path on the one GPU a box has")
     # the child process of the parity legs (one element type per process; --dtype / --residual say which): the seeded weights of
     # tests/parity_cases.py, a timed loop at the headline geometry, then the full-depth replays against the committed oracle
     # trajectories (the checker: tests/ + tests/golden/, never part of a timed region)
@@ -132,9 +135,13 @@ def main():
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    multi = world > 1 or args.force_dist     # the multi-rank code path (collectives included)
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "RANK" not in os.environ:         # --force-dist outside a launcher: a one-rank group of its own
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
         if cpu:
             dist.init_process_group("gloo")
         else:
@@ -162,7 +169,7 @@ def main():
     # ---- weights: rank 0 draws them, everyone else receives them over RCCL, as the 16-bit matrices the kernels consume ----
     from paddlemix_amd.dist import empty_wire_params, gather_latents, wire_params
     ed = _lib.elem_dtype()
-    with_te = (args.text_encoders or world > 1) and not is_sd3 and args.workload.startswith("sdxl")
+    with_te = (args.text_encoders or multi) and not is_sd3 and args.workload.startswith("sdxl")
     te_cfgs = {}
     if with_te:
         from paddlemix_amd.clip import CLIPTextModel, CLIPTextModelWithProjection, clip_param_shapes, synth_clip_params
@@ -179,7 +186,7 @@ def main():
         P = empty_wire_params(unet_param_shapes(cfg), ed, dev)
         PT = {k: empty_wire_params(clip_param_shapes(c), ed, dev) for k, (c, _) in te_cfgs.items()}
     bcast_s = bcast_bytes = None
-    if world > 1:
+    if multi:
         dev_sync()
         dist.barrier()
         t0 = time.time()
@@ -195,7 +202,7 @@ def main():
         from tests.abi_emulator import Emulator   # test plumbing only (see --selftest-cpu above)
         kw["_test_backend"] = Emulator()
     model = UNet2DConditionModel(cfg, P, device=dev, use_graph=not args.no_graph, **kw)
-    P_cpu_needed = rank == 0 and world == 1 and not args.no_cpu_baseline and not is_sd3
+    P_cpu_needed = rank == 0 and not multi and not args.no_cpu_baseline and not is_sd3
     if not P_cpu_needed:
         del P
     if not cpu:
@@ -305,7 +312,7 @@ def main():
         if not torch.isfinite(allz).all():
             raise SystemExit("non-finite latents on some rank")
         if cpu and rank == 0:   # self-test: the ranks drew different prompts (per-rank seed) and the gather is rank-major
-            assert torch.equal(allz[:B], latents) and not torch.allclose(allz[:B], allz[B:2 * B])
+            assert torch.equal(allz[:B], latents) and (world == 1 or not torch.allclose(allz[:B], allz[B:2 * B]))
 
     res = {
         "metric": {"sdxl-1024-bs8": "UNet denoising steps/sec (SD-XL 1024^2, bs=8)",
@@ -321,7 +328,7 @@ def main():
         "dtype": ("fp8 e4m3 (block GEMM operands) + " + args.dtype) if wl.get("a8") else args.dtype, "data": "synthetic",
         "config": {"workload": args.workload, "latents": [B, cfg["in_channels"] if is_sd3 else 4, H, W], "text": [B, L, cfg["joint_attention_dim" if is_sd3 else "cross_attention_dim"]],
                    "batch_per_gpu": B, "global_batch": B * world, "scheduler": "FlowMatchEuler/28" if is_sd3 else "EulerDiscrete/30",
-                   "weights": f"random-init {args.dtype} (N(0,1/fan_in)), RCCL-broadcast from rank 0" if world > 1
+                   "weights": f"random-init {args.dtype} (N(0,1/fan_in)), RCCL-broadcast from rank 0" if multi
                    else f"random-init {args.dtype} (N(0,1/fan_in))",
                    "parallelism": f"prompt-sharded dp{world}, no per-step collective", "hipgraph": bool(model.use_graph)},
         "tflops_effective": world * args.steps * wl["gflop_step"] / 1e3 / elapsed,
@@ -431,7 +438,7 @@ def main():
     #   "parity":      the benchmarked mode itself (a short loop only: its throughput is the line's `value`)
     #   "parity_mode": the CHEAPEST mode that meets north_star's 1e-3 on the end latents -- fp16 elements with the same 16-bit
     #                  residual stream and the same kernels as the headline (the other instantiation of the element typedef)
-    if rank == 0 and world == 1 and not cpu and not args.no_parity_mode and not args.parity_child and args.workload == "sdxl-1024-bs8":
+    if rank == 0 and not multi and not cpu and not args.no_parity_mode and not args.parity_child and args.workload == "sdxl-1024-bs8":
         import subprocess
 
         def parity_leg(dtype, residual, steps, warmup):

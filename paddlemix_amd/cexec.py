@@ -152,6 +152,11 @@ class CUNet2DConditionModel:
                 # would broadcast a [B] tensor per sample (unet_2d_condition.py:946)
                 raise ValueError("timestep: per-sample timesteps are not implemented (pass one value, or B equal values)")
         if cfgd.get("addition_embed_type") == "text_time":
+            tids = None if added_cond_kwargs is None else added_cond_kwargs.get("time_ids")
+            if tids is not None and tids.dim() == 2 and tids.shape[1] != 6:
+                # (the Python planner takes any count -- the refiner's 5 micro-conditioning ids; the C++ planner lays out six)
+                raise NotImplementedError(f"the C executor (mi355x_sd_unet_*) supports 6 time ids per sample, got {tids.shape[1]}; "
+                                          "use paddlemix_amd.unet.UNet2DConditionModel")
             for key, width in (("text_embeds", cfgd["projection_class_embeddings_input_dim"] - 6 * cfgd["addition_time_embed_dim"]),
                                ("time_ids", 6)):
                 if added_cond_kwargs is None or key not in added_cond_kwargs:

@@ -340,7 +340,11 @@ static int pick_tile_model(const GemmArgs& a) {
       const char* e = getenv("MI355X_SD_GEMM_P160");
       return e ? atof(e) : 0.6;
     }();
-    if (c.id == 160 && !a.conv && !a.geglu && a.K <= 1536 && !a.wscale && !a.rowstat && !a.a_rpb && !a.c_rpb) cost *= p160;   // (measured forms only)
+    static const int k160 = [] {   // MI355X_SD_GEMM_K160: largest K the weight applies to (round 3: 1536; A/B switch)
+      const char* e = getenv("MI355X_SD_GEMM_K160");
+      return e ? atoi(e) : (1 << 30);
+    }();
+    if (c.id == 160 && !a.conv && !a.geglu && a.K <= k160 && !a.wscale && !a.rowstat && !a.a_rpb && !a.c_rpb) cost *= p160;   // (measured forms only)
     static const double p257 = [] {   // MI355X_SD_GEMM_P257: re-weights the phased 256x256 kernel (A/B measurements)
       const char* e = getenv("MI355X_SD_GEMM_P257");
       return e ? atof(e) : 1.0;

@@ -29,7 +29,7 @@ namespace sd {
 
 // loader waves chosen by shape (K >= 4096): -0.45 ms per SDXL bs-8 step in two A/B pairs (profiles/r03_s1_step_ab.txt), after the
 // isolated -10 % / -16 % on FF2 / the 11520-deep convs of round 2 (profiles/r02_gemm_loaders.txt)
-constexpr int GEMM_LOADERS_DEFAULT = -1;
+constexpr int GEMM_LOADERS_DEFAULT = 0;   // round 4: none -- the interleaved loop beats them on the long-K convs too (profiles/r04_s2_*)
 
 #define SD_PIPE_BARRIER()                 \
   do {                                    \
@@ -49,8 +49,16 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 template <int V>
 using ic_t = std::integral_constant<int, V>;
-// step (of NSTEP) at which the i-th of np LDS-DMA pieces of a half-iteration is issued: spread, none at step 0
-constexpr int il_piece_step(int i, int np, int nstep) { return 1 + (i * (nstep - 1)) / np; }
+// Schedules of a half-iteration of the interleaved loop (template IL = 1 + schedule id; all give the same bits):
+//   0  steps of 2 MFMAs; read k at step k; the np DMA pieces spread over the steps, none at step 0           (the default)
+//   1  steps of 2 MFMAs; reads two per step (front-loaded: retired well before the barrier), the pieces in the later steps
+//   2  steps of 4 MFMAs; reads two per step, pieces spread
+//   3  steps of 2 MFMAs; read k at step k; the pieces in the FIRST steps (longest time to land)
+constexpr int il_group(int v) { return v == 2 ? 4 : 2; }
+constexpr int il_reads_per_step(int v) { return (v == 1 || v == 2) ? 2 : 1; }
+constexpr int il_piece_step(int v, int i, int np, int nstep) {
+  return v == 1 ? nstep - np + i : v == 3 ? i : v == 2 ? (i < nstep - 1 ? 1 + i : nstep - 1) : 1 + (i * (nstep - 1)) / np;
+}
 
 // 16-byte-per-lane LDS-DMA from a buffer resource. A plain (non-template) function on purpose: called with
 // type-dependent arguments straight from the kernel template, the builtin makes the host pass of hipcc drop the kernel's
@@ -361,8 +369,9 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& p) {
   // The last iterations are UNROLLED (template R = tiles after this one): what is issued and the wait counts are compile-time
   // facts there, and the main loop has neither the "is there a next tile" conditionals nor the run-time vmcnt switch
   // (wait_vmcnt_dyn: ~40 of the 155 scalar instructions per K-tile of the round-3 PRE loop).
-  constexpr int AHEAD = ST - 1, NM = TM * TN, NR = TM + TN, G = 2, NSTEP = (NM + G - 1) / G;
-  static_assert(NR <= NSTEP && AP < NSTEP && WP < NSTEP, "one read and at most one DMA piece per step");
+  constexpr int SV = IL - 1;   // schedule id
+  constexpr int AHEAD = ST - 1, NM = TM * TN, NR = TM + TN, G = il_group(SV), RPS = il_reads_per_step(SV), NSTEP = (NM + G - 1) / G;
+  static_assert(NR <= NSTEP * RPS && AP < NSTEP && WP < NSTEP, "reads and DMA pieces fit the steps");
   constexpr int LPR = EpiPre<(PRE ? TM : 1), (PRE ? TN : 1)>::LOADS_PER_ROW;
   constexpr int NTAIL = (PRE && TM > AHEAD ? TM : AHEAD) + 1;
   bf16x8 fa[2][TM], fw[2][TN];
@@ -383,14 +392,17 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& p) {
     constexpr int SET = decltype(setc)::value, RD = decltype(rdc)::value, DK = decltype(dkc)::value, PR = decltype(prc)::value;
     static_for<0, NSTEP>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
-      if constexpr (RD && k < NR) read_one(ic_t<SET ^ 1>{}, kc, rstage);
+      if constexpr (RD) static_for<0, RPS>([&](auto rc_) {
+        constexpr int r = k * RPS + decltype(rc_)::value;
+        if constexpr (r < NR) read_one(ic_t<SET ^ 1>{}, ic_t<r>{}, rstage);
+      });
       if constexpr (DK == 1 || DK == 3) static_for<0, WP>([&](auto ic) {
-        if constexpr (il_piece_step(decltype(ic)::value, WP, NSTEP) == k) {
+        if constexpr (il_piece_step(SV, decltype(ic)::value, WP, NSTEP) == k) {
           if (DK == 1 || dma_on) issue_w(ic, dstage);
         }
       });
       if constexpr (DK == 2 || DK == 4) static_for<0, AP>([&](auto ic) {
-        if constexpr (il_piece_step(decltype(ic)::value, AP, NSTEP) == k) {
+        if constexpr (il_piece_step(SV, decltype(ic)::value, AP, NSTEP) == k) {
           if (DK == 2 || dma_on) issue_a(ic, dstage);
         }
       });
@@ -904,6 +916,11 @@ static int launch_pipe(const GemmArgs& a, hipStream_t stream) {
     if (gemm_loaders() == 4) return launch_pipe_lw<CONV, CFG, LN, 4>(a, stream);
     if (gemm_loaders() == 5 || (gemm_loaders() == -1 && a.K >= 4096 && a.splitk <= 1 && !pre_applies<CONV, CFG, LN>(a)))
       return launch_pipe_lw<CONV, CFG, LN, 4, 1>(a, stream);   // + interleaved fragment reads
+  }
+  if constexpr (!CONV && !LN && CFG::NW == 8 && CFG::BN == 160 && CFG::STAGES == 3) {   // schedule experiments: this tile only
+    if (gemm_il() == 2) return launch_pipe_il<CONV, CFG, LN, 2>(a, stream);
+    if (gemm_il() == 3) return launch_pipe_il<CONV, CFG, LN, 3>(a, stream);
+    if (gemm_il() == 4) return launch_pipe_il<CONV, CFG, LN, 4>(a, stream);
   }
   return gemm_il() ? launch_pipe_il<CONV, CFG, LN, 1>(a, stream) : launch_pipe_il<CONV, CFG, LN, 0>(a, stream);
 }

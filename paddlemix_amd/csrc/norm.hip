@@ -294,7 +294,7 @@ int groupnorm_act_fits(int HW, int C, int groups) {
   static const bool off = getenv("MI355X_SD_NO_GN_FUSED") != nullptr;   // A/B switch (read by the program builders too)
   if (off || groups <= 0 || C <= 0 || (C % groups) || HW <= 0) return 0;
   const int cpg = C / groups;
-  if ((cpg & 1) || (C & 7)) return 0;
+  if ((cpg & 1) || (C & 7) || cpg > 128) return 0;   // (128: the kernel's LDS table of a group's gamma / beta)
   return (long)HW * (cpg / 2) <= (long)GNF_THREADS * GNF_MAXD;
 }
 
@@ -377,9 +377,15 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const bf16* __res
 int launch_groupnorm_act(const bf16* x, int B, int HW, int C, int ldx, int groups, float eps, const float* gamma, const float* beta,
                          int silu, bf16* y, int ldy, hipStream_t stream) {
   if (B <= 0 || HW <= 0 || C <= 0) return SD_ERR_INVALID;
-  if (!groupnorm_act_fits(HW, C, groups) || (ldx & 1) || (ldy & 1) || C / groups > 128 || B > 65535) return SD_ERR_UNSUPPORTED;
-  if (silu) hipLaunchKernelGGL(gn_fused_kernel<true>, dim3(groups, B), dim3(GNF_THREADS), 0, stream, x, HW, C, ldx, groups, eps, gamma, beta, y, ldy);
-  else hipLaunchKernelGGL(gn_fused_kernel<false>, dim3(groups, B), dim3(GNF_THREADS), 0, stream, x, HW, C, ldx, groups, eps, gamma, beta, y, ldy);
+  if (!groupnorm_act_fits(HW, C, groups) || (ldx & 1) || (ldy & 1)) return SD_ERR_UNSUPPORTED;
+  // (batch items on grid.y, 65535 per launch: larger batches go out in slices -- the predicate above is the whole contract)
+  for (int b0 = 0; b0 < B; b0 += 65535) {
+    const int nb = B - b0 < 65535 ? B - b0 : 65535;
+    const bf16* xb = x + (size_t)b0 * HW * ldx;
+    bf16* yb = y + (size_t)b0 * HW * ldy;
+    if (silu) hipLaunchKernelGGL(gn_fused_kernel<true>, dim3(groups, nb), dim3(GNF_THREADS), 0, stream, xb, HW, C, ldx, groups, eps, gamma, beta, yb, ldy);
+    else hipLaunchKernelGGL(gn_fused_kernel<false>, dim3(groups, nb), dim3(GNF_THREADS), 0, stream, xb, HW, C, ldx, groups, eps, gamma, beta, yb, ldy);
+  }
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }
 

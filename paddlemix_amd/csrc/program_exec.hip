@@ -340,8 +340,10 @@ int mi355x_sd_program_run(void* handle, void* stream) {
     const int rr = replay();
     void* exec = nullptr;
     rc = mi355x_sd_graph_end(stream, &exec);
-    if (rr) return rr;
-    if (rc) return rc;
+    if (rr || rc) {   // (a replay that failed under capture: the instantiated graph, if any, is not kept)
+      if (exec) (void)mi355x_sd_graph_destroy(exec);
+      return rr ? rr : rc;
+    }
     p->graph = exec;
     p->graph_stream = stream;
   }

@@ -74,7 +74,10 @@ def _pack_str(s: str) -> bytes:
 def export_program(model, plan, path: str, outputs: Iterable[str] = ("out",)) -> dict:
     """Write `plan` of `model` (any DeviceProgram model) to `path`. `outputs`: names of plan attributes the caller reads back
     (everything else that is named is an input); a list attribute `hidden` is addressed as "hidden" (all) or "hidden.3".
-    Returns a summary dict (regions, launches, bytes)."""
+    Returns a summary dict (regions, launches, bytes).
+    Contents: weights and plan-time constants travel with the file; a named I/O region's plan-time contents travel only up to 1 MiB
+    (_IO_DATA_LIMIT) -- a larger INPUT is expected to be written by the caller before every run (all of this library's planners do),
+    it replays as whatever the bound buffer holds otherwise."""
     if getattr(plan, "text_dim", 0) is None:
         raise ValueError("this plan is completed at the first forward (text_time widths): run the model once before exporting")
     outputs = tuple(outputs)
@@ -96,6 +99,16 @@ def export_program(model, plan, path: str, outputs: Iterable[str] = ("out",)) ->
     named = _named_tensors(plan)
     ios = []
     for name, t in named:
+        # an I/O entry IS its region (device address = region base, size = region bytes): a named tensor that is a view into a larger
+        # storage, or that shares its storage with a weight / constant / another named tensor registered before it, would be
+        # reported with the wrong address, size or kind -- refused here instead of exported wrong
+        ptr, nbytes = _storage_span(t)
+        if (t.storage_offset() != 0 or not t.is_contiguous() or nbytes != t.numel() * t.element_size() or ptr != t.data_ptr()):
+            raise ValueError(f"I/O tensor '{name}' must own its storage (contiguous, offset 0): shape {tuple(t.shape)}, "
+                             f"storage offset {t.storage_offset()}, storage bytes {nbytes}")
+        if ptr in by_ptr and regions[by_ptr[ptr]]["kind"] != R_IO:   # (two names of one I/O tensor -- the VAE's mean / out -- are fine)
+            other = regions[by_ptr[ptr]]
+            raise ValueError(f"I/O tensor '{name}' shares its storage with '{other['name']}' (exported earlier as kind {other['kind']})")
         idx = add_region(t, R_IO, name)
         is_out = any(name == o or name.startswith(o + ".") for o in outputs)
         ios.append(dict(region=idx, is_output=int(is_out), dtype=_io_dtype(t), shape=list(t.shape), name=name))

@@ -60,4 +60,6 @@ def test_early_residual_kernels_keep_their_landing_registers():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_landing_zone.py")], capture_output=True, text=True)
     assert p.returncode == 0, p.stdout + p.stderr
-    assert "6 early-residual kernels, 0 compiler-generated uses" in p.stdout, p.stdout
+    import re
+    found = re.findall(r"(\d+) early-residual kernels, (\d+) compiler-generated uses", p.stdout)
+    assert len(found) == 2 and all(int(n) >= 6 and int(bad) == 0 for n, bad in found), p.stdout

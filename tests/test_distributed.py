@@ -105,6 +105,19 @@ def test_bench_gpus_n_starts_its_own_ranks():
     assert r["ms_per_step"] >= max(r["per_rank_ms_per_step"]) * 0.999
 
 
+def test_bench_force_dist_runs_the_collective_path_with_one_rank():
+    """`bench.py --gpus 1 --force-dist`: the multi-rank branch (process group, weight broadcast, barriers, all-gather, the extra JSON
+    fields) with a group of one -- how the RCCL calls are exercised on the single GPU of a `gpurun` box (profiles/r04_*_force_dist*)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "2", "--warmup", "1",
+                        "--selftest-cpu"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert r["n_gpus"] == 1 and r["weight_broadcast_gb"] > 0 and r["gathered_latents"] == [2, 4, 8, 8] and len(r["per_rank_ms_per_step"]) == 1
+
+
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
     import subprocess
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")

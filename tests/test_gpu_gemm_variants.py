@@ -89,3 +89,13 @@ def test_interleaved_k_loop_is_bit_identical_to_the_burst_loop(tile_env):
     for k, v in new.items():
         assert v["rel"] < 4e-3, (tile_env, k, v)
         assert v["sha"] == old[k]["sha"], (tile_env, k, v, old[k])
+
+
+def test_interleaved_loop_schedules_are_bit_identical():
+    """MI355X_SD_GEMM_IL=2|3|4: other placements of the reads and LDS-DMA pieces among the MFMAs of a half-iteration (256x160 tile;
+    csrc/gemm_pipe.hip il_piece_step) -- same bits as the default schedule."""
+    base = _run({"MI355X_SD_GEMM_IL": "1", "MI355X_SD_GEMM_LOADERS": "0"})
+    for v in ("2", "3", "4"):
+        got = _run({"MI355X_SD_GEMM_IL": v, "MI355X_SD_GEMM_LOADERS": "0"})
+        for k in base:
+            assert got[k]["sha"] == base[k]["sha"], (v, k, got[k], base[k])
