@@ -199,9 +199,10 @@ def main():
     if args.residual == "fp32":
         kw["residual_dtype"] = "fp32"
     if cpu:
-        from tests.abi_emulator import Emulator   # test plumbing only (see --selftest-cpu above)
-        kw["_test_backend"] = Emulator()
-    model = UNet2DConditionModel(cfg, P, device=dev, use_graph=not args.no_graph, **kw)
+        from tests.abi_emulator import on_emulator   # test plumbing only (see --selftest-cpu above)
+        model = on_emulator(UNet2DConditionModel, cfg, P, device=dev, use_graph=not args.no_graph, **kw)
+    else:
+        model = UNet2DConditionModel(cfg, P, device=dev, use_graph=not args.no_graph, **kw)
     P_cpu_needed = rank == 0 and not multi and not args.no_cpu_baseline and not is_sd3
     if not P_cpu_needed:
         del P

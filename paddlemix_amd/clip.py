@@ -151,9 +151,8 @@ class CLIPTextModel(DeviceProgram, PretrainedMixin):
     _param_shapes = staticmethod(clip_param_shapes)
 
     def __init__(self, config: Mapping, params: Mapping[str, Tensor], device="cuda", use_graph: bool = True,
-                 profile: bool = False, _test_backend=None):
-        """``_test_backend``: test-only injection (tests/abi_emulator.py); never selected by product code."""
-        self._init_backend(device, use_graph, profile, _test_backend)
+                 profile: bool = False):
+        self._init_backend(device, use_graph, profile)
         self.cfg = normalize_config(dict(config, with_projection=self._WITH_PROJECTION or config.get("with_projection", False)))
         self.config = SimpleNamespace(**self.cfg)
         self._load_weights(params)
@@ -362,9 +361,8 @@ class CLIPVisionModelWithProjection(DeviceProgram, PretrainedMixin):
     _param_shapes = staticmethod(clip_vision_param_shapes)
 
     def __init__(self, config: Mapping, params: Mapping[str, Tensor], device="cuda", use_graph: bool = True,
-                 profile: bool = False, _test_backend=None):
-        """``_test_backend``: test-only injection (tests/abi_emulator.py); never selected by product code."""
-        self._init_backend(device, use_graph, profile, _test_backend)
+                 profile: bool = False):
+        self._init_backend(device, use_graph, profile)
         self.cfg = normalize_vision_config(config)
         self.config = SimpleNamespace(**self.cfg)
         cfg, dev, W = self.cfg, self.device, self.w

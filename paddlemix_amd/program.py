@@ -39,10 +39,18 @@ class _Plan:
     pass
 
 
+# Test plumbing, ONE place: while a backend object is pushed here (tests/abi_emulator.py ``on_emulator`` does that around a
+# constructor call), models built meanwhile send their C-ABI calls to it instead of the HIP library -- the host logic of every
+# model then runs on a machine without a GPU. Product code never pushes anything: the library is the only backend it selects, and
+# a missing library or GPU is an error, not a fallback.
+_BACKEND_OVERRIDE: list = []
+
+
 class DeviceProgram:
     """Backend selection + execution of a plan (``plan.prog``: list of (cfunc, args, kind, flops))."""
 
-    def _init_backend(self, device, use_graph: bool, profile: bool, _test_backend=None):
+    def _init_backend(self, device, use_graph: bool, profile: bool):
+        _test_backend = _BACKEND_OVERRIDE[-1] if _BACKEND_OVERRIDE else None
         self._emulated = _test_backend is not None
         if self._emulated:
             self._lib = _test_backend

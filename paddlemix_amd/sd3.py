@@ -147,10 +147,9 @@ class SD3Transformer2DModel(DeviceProgram, PretrainedMixin):
     _optional_param_shapes = staticmethod(sd3_optional_param_shapes)
 
     def __init__(self, config: Mapping, params: Mapping[str, Tensor], device="cuda", use_graph: bool = True,
-                 profile: bool = False, weight_dtype: str = "bf16", act_dtype: str = "bf16", _test_backend=None):
+                 profile: bool = False, weight_dtype: str = "bf16", act_dtype: str = "bf16"):
         """``weight_dtype``: "bf16" | "fp8" -- fp8 stores the block matrices (QKV, out, FF of both streams) as OCP e4m3
-        with one fp32 scale per output channel (absmax / 448) and runs the weight-only-fp8 GEMM (BASELINE config 5).
-        ``_test_backend``: test-only injection (tests/abi_emulator.py); never selected by product code."""
+        with one fp32 scale per output channel (absmax / 448) and runs the weight-only-fp8 GEMM (BASELINE config 5)."""
         if weight_dtype not in ("bf16", "fp8"):
             raise ValueError(f"weight_dtype must be 'bf16' or 'fp8', got {weight_dtype!r}")
         if act_dtype not in ("bf16", "fp8") or (act_dtype == "fp8" and weight_dtype != "fp8"):
@@ -160,7 +159,7 @@ class SD3Transformer2DModel(DeviceProgram, PretrainedMixin):
         # output, GELU output), their weights per output channel at load; accumulation, epilogues and everything
         # between the GEMMs (attention, residual stream, modulation) stay as in the bf16 path.
         self.weight_dtype, self.act_dtype = weight_dtype, act_dtype
-        self._init_backend(device, use_graph, profile, _test_backend)
+        self._init_backend(device, use_graph, profile)
         self.cfg = normalize_config(config)
         self.config = SimpleNamespace(**self.cfg)
         self._load_weights(params)

@@ -97,9 +97,8 @@ class T5EncoderModel(DeviceProgram, PretrainedMixin):
     _param_shapes = staticmethod(t5_param_shapes)
 
     def __init__(self, config: Mapping, params: Mapping[str, Tensor], device="cuda", use_graph: bool = True,
-                 profile: bool = False, _test_backend=None):
-        """``_test_backend``: test-only injection (tests/abi_emulator.py); never selected by product code."""
-        self._init_backend(device, use_graph, profile, _test_backend)
+                 profile: bool = False):
+        self._init_backend(device, use_graph, profile)
         self.cfg = normalize_config(config)
         self.config = SimpleNamespace(**self.cfg)
         self._load_weights(params)

@@ -293,11 +293,9 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
 
     def __init__(self, config: Mapping, params: Mapping[str, Tensor], device="cuda", use_graph: bool = True,
                  profile: bool = False, fold_layernorm: Optional[bool] = None, residual_dtype: Optional[str] = None,
-                 fold_softmax_scale: Optional[bool] = None, _test_backend=None):
-        """``_test_backend``: test-only injection point (tests/abi_emulator.py interprets the emitted C-ABI
-        program on host memory to check the sequencing / packing logic without a GPU).  It is never selected by
-        product code: without it the model needs the built HIP library and a GPU, and raises otherwise."""
-        self._init_backend(device, use_graph, profile, _test_backend)
+                 fold_softmax_scale: Optional[bool] = None):
+        """The model needs the built HIP library and a GPU, and raises otherwise (there is no CPU fallback)."""
+        self._init_backend(device, use_graph, profile)
         # fold_layernorm: LayerNorms of the transformer blocks folded into their consuming projections (row statistics
         # pass + mi355x_sd_linear_ln on the raw rows). Off by default: on MI355X it removes 2.3 ms of LayerNorm
         # traffic per SDXL step but the GEMMs then multiply the raw residual stream instead of O(1) normalised

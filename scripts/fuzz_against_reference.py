@@ -6,14 +6,14 @@ the MI355X model on the emulated device -- to look for deviations outside the co
 import sys, random, math, torch, traceback
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from oracle import reference_runner as rr, sd3_ref as S3, dit_ref as D, vae_ref as V
-from tests.abi_emulator import Emulator
+from tests.abi_emulator import Emulator, on_emulator
 from paddlemix_amd.sd3 import SD3Transformer2DModel
 from paddlemix_amd.dit import DiTTransformer2DModel
 from paddlemix_amd.vae import AutoencoderKL
 from tests import reference_cases as RC
 rr.install()
 rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
-E = dict(_test_backend=Emulator()); bad = 0
+bad = 0
 bf = lambda P: {k: (v.to(torch.bfloat16).float() if v.dim() > 1 else v) for k, v in P.items()}
 rel = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())
 mx = lambda a, b: float((a - b).abs().max() / b.abs().max())
@@ -34,7 +34,7 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 8):
                 net = rr.ref_module("transformer_sd3").SD3Transformer2DModel(**cfg); net.eval(); rr.load_params(net, P, computed=RC.SD3_COMPUTED + RC.SD3_OPTIONAL)
                 ref = rr.from_shim(net(rr.to_shim(x), encoder_hidden_states=rr.to_shim(enc), pooled_projections=rr.to_shim(pooled), timestep=rr.to_shim(t)).sample)
                 orab = S3.sd3_forward(bf(P), cfg, x, enc, pooled, t)
-            prod = SD3Transformer2DModel(cfg, P, **E)(x, enc, pooled, 421.0).sample
+            prod = on_emulator(SD3Transformer2DModel, cfg, P)(x, enc, pooled, 421.0).sample
         elif kind == "dit":
             heads, hd = rng.choice([(2, 32), (4, 32), (2, 64)])
             cfg = dict(sample_size=rng.choice([16, 32]), num_layers=rng.choice([1, 2, 3]), patch_size=2, attention_head_dim=hd, num_attention_heads=heads, in_channels=4,
@@ -48,7 +48,7 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 8):
                 net = rr.ref_module("transformer_2d").Transformer2DModel(**full); net.eval(); rr.load_params(net, P)
                 ref = rr.from_shim(net(rr.to_shim(x), timestep=rr.to_shim(t), class_labels=rr.to_shim(y)).sample)
                 orab = D.dit_forward(bf(P), cfg, x, t, y)
-            prod = DiTTransformer2DModel(cfg, P, **E)(x, timestep=t, class_labels=y).sample
+            prod = on_emulator(DiTTransformer2DModel, cfg, P)(x, timestep=t, class_labels=y).sample
         else:
             nlev = rng.choice([2, 3, 4]); boc = tuple(rng.choice([32, 64]) for _ in range(nlev))
             cfg = dict(in_channels=3, out_channels=3, latent_channels=rng.choice([4, 16]), block_out_channels=boc, layers_per_block=rng.choice([1, 2]), norm_num_groups=32,
@@ -62,7 +62,7 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 8):
                 net = rr.ref_module("autoencoder_kl").AutoencoderKL(**{k: v for k, v in full.items()}); net.eval(); rr.load_params(net, P)
                 ref = rr.from_shim(net.decode(rr.to_shim(z)).sample); ref_m = rr.from_shim(net.encode(rr.to_shim(img)).latent_dist.mean)
                 orab = V.decode(bf(P), cfg, z); orab_m = V.encode(bf(P), cfg, img)[0]
-            vae = AutoencoderKL(cfg, P, **E)
+            vae = on_emulator(AutoencoderKL, cfg, P)
             prod = vae.decode(z).sample
             d3 = rel(vae.encode(img).latent_dist.mean, orab_m); d4 = mx(ora_m, ref_m)
             if d3 > 2.5e-2 or d4 > 5e-5: print("   vae encode: product-vs-oracle %.2e oracle-vs-reference %.1e  <<<<" % (d3, d4)); bad += 1

@@ -3,7 +3,7 @@
 It executes the same (function, raw-pointer args) program that paddlemix_amd.unet emits for the HIP library, but on
 CPU memory with plain torch fp32 math, so the *host logic* (weight repacking, GEGLU interleave, fused QKV,
 concat-by-construction strides, program order) can be checked against the oracle without a GPU.  It is not a
-fallback: product code never constructs it (see UNet2DConditionModel._test_backend).
+fallback: product code never constructs it (tests push it through paddlemix_amd.program._BACKEND_OVERRIDE, see on_emulator below).
 
 ``round_bf16=False`` keeps intermediate activations in fp32 buffers?  No -- buffers are bf16 by ABI; the emulator
 therefore shows exactly the rounding points of the device path (bf16 stores, fp32 accumulation).
@@ -480,3 +480,15 @@ class Emulator:
         c = _flat(coef, 2, torch.float32)
         _flat(out, n, torch.float32).copy_(c[0] * _flat(x, n, torch.float32) + c[1] * _flat(y, n, torch.float32))
         return 0
+
+
+def on_emulator(ctor, *args, backend=None, **kwargs):
+    """``ctor(*args, **kwargs)`` -- a model class or its ``from_pretrained`` -- with the C-ABI calls of the model it builds routed
+    to ``backend`` (a fresh Emulator by default) instead of the HIP library: the one test hook of the product
+    (paddlemix_amd/program.py _BACKEND_OVERRIDE), held only for the duration of the constructor call."""
+    from paddlemix_amd import program
+    program._BACKEND_OVERRIDE.append(backend if backend is not None else Emulator())
+    try:
+        return ctor(*args, **kwargs)
+    finally:
+        program._BACKEND_OVERRIDE.pop()

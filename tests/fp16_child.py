@@ -95,7 +95,7 @@ def unet_cases(make_model, dev):
     return out
 
 
-def other_models(backend_kw, dev):
+def other_models(emulate, dev):
     """SD3 MMDiT (bf16-named paths run on fp16 elements; W8A8 too), VAE decoder, CLIP and T5 text encoders: rel-L2 against
     their oracles on fp16-rounded weights"""
     from oracle import clip_ref, sd3_ref, t5_ref, vae_ref
@@ -106,6 +106,10 @@ def other_models(backend_kw, dev):
     from tests.configs import MINI_CLIP, MINI_SD3, MINI_T5, MINI_VAE
     from tests.test_clip_host_logic import _ids
     mv = (lambda t: t.to(dev)) if dev else (lambda t: t)
+    if emulate:
+        from tests.abi_emulator import on_emulator as mk
+    else:
+        mk = lambda cls, *a, **k: cls(*a, device=dev, **k)   # noqa: E731
     h = lambda P, skip=(): {k: (v.to(torch.float16).float() if v.dim() > 1 and not any(x in k for x in skip) else v)  # noqa: E731
                             for k, v in P.items()}
     out = {}
@@ -115,15 +119,15 @@ def other_models(backend_kw, dev):
                       torch.randn(2, 10, MINI_SD3["joint_attention_dim"], generator=g),
                       torch.randn(2, MINI_SD3["pooled_projection_dim"], generator=g))
     ref = sd3_ref.sd3_forward(h(P), MINI_SD3, x, enc, pooled, 501.0)
-    got = SD3Transformer2DModel(MINI_SD3, P, **backend_kw)(mv(x), mv(enc), mv(pooled), 501.0).sample.float().cpu()
+    got = mk(SD3Transformer2DModel, MINI_SD3, P)(mv(x), mv(enc), mv(pooled), 501.0).sample.float().cpu()
     out["sd3"] = _rel(got, ref)
     P = synth_decoder_params(MINI_VAE, seed=7)
     z = torch.randn(2, MINI_VAE["latent_channels"], 8, 8, generator=g)
-    out["vae"] = _rel(AutoencoderKL(MINI_VAE, P, **backend_kw).decode(mv(z)).sample.float().cpu(), vae_ref.decode(h(P), MINI_VAE, z))
+    out["vae"] = _rel(mk(AutoencoderKL, MINI_VAE, P).decode(mv(z)).sample.float().cpu(), vae_ref.decode(h(P), MINI_VAE, z))
     P = synth_clip_params(MINI_CLIP, seed=5)
     ids = _ids(2, 16, MINI_CLIP["vocab_size"], MINI_CLIP["eos_token_id"])
     ref = clip_ref.clip_text_forward(h(P), MINI_CLIP, ids)["last_hidden_state"]
-    out["clip"] = _rel(CLIPTextModel(MINI_CLIP, P, **backend_kw)(mv(ids)).last_hidden_state.float().cpu(), ref)
+    out["clip"] = _rel(mk(CLIPTextModel, MINI_CLIP, P)(mv(ids)).last_hidden_state.float().cpu(), ref)
     from oracle import dit_ref
     from paddlemix_amd.dit import DiTTransformer2DModel, synth_dit_params
     from tests.configs import MINI_DIT
@@ -131,24 +135,24 @@ def other_models(backend_kw, dev):
     xd = torch.randn(2, 4, 16, 16, generator=g)
     lab, td = torch.tensor([3, 10]), torch.tensor([999.0, 20.0])
     ref = dit_ref.dit_forward(h(P), MINI_DIT, xd, td, lab)
-    out["dit"] = _rel(DiTTransformer2DModel(MINI_DIT, P, **backend_kw)(mv(xd), timestep=mv(td), class_labels=mv(lab)).sample.float().cpu(), ref)
+    out["dit"] = _rel(mk(DiTTransformer2DModel, MINI_DIT, P)(mv(xd), timestep=mv(td), class_labels=mv(lab)).sample.float().cpu(), ref)
     P = synth_t5_params(MINI_T5, seed=11)
     ids = torch.randint(0, MINI_T5["vocab_size"], (2, 24), generator=g)
     ref = t5_ref.t5_encoder_forward(h(P, skip=("relative_attention_bias",)), MINI_T5, ids)
-    out["t5"] = _rel(T5EncoderModel(MINI_T5, P, **backend_kw)(mv(ids)).last_hidden_state.float().cpu(), ref)
+    out["t5"] = _rel(mk(T5EncoderModel, MINI_T5, P)(mv(ids)).last_hidden_state.float().cpu(), ref)
     return out
 
 
 def main(mode):
     res = dict(elem=_lib.ELEM_NAME, lib=os.path.basename(_lib.LIB_PATH))
     if mode == "cpu":
-        from tests.abi_emulator import Emulator
+        from tests.abi_emulator import Emulator, on_emulator
         lib = _lib.load()   # dlopen works without a GPU: every declared symbol present, element type matches
         res["elem_dtype_symbol"] = lib.mi355x_sd_elem_dtype()
-        res["unet"] = unet_cases(lambda cfg, P: UNet2DConditionModel(cfg, P, _test_backend=Emulator()), None)
+        res["unet"] = unet_cases(lambda cfg, P: on_emulator(UNet2DConditionModel, cfg, P), None)
         res["fp32_residual"] = fp32_residual_cases(
-            lambda cfg, P, rd: UNet2DConditionModel(cfg, P, residual_dtype=rd, _test_backend=Emulator()), None, False)
-        res["models"] = other_models(dict(_test_backend=Emulator()), None)
+            lambda cfg, P, rd: on_emulator(UNet2DConditionModel, cfg, P, residual_dtype=rd), None, False)
+        res["models"] = other_models(True, None)
     else:
         from paddlemix_amd import ops
         ops.init(0)
@@ -197,7 +201,7 @@ def main(mode):
         res["unet"] = unet_cases(lambda cfg, P: UNet2DConditionModel(cfg, P, device="cuda:0"), "cuda:0")
         res["fp32_residual"] = fp32_residual_cases(
             lambda cfg, P, rd: UNet2DConditionModel(cfg, P, device="cuda:0", residual_dtype=rd), "cuda:0", True)
-        res["models"] = other_models(dict(device="cuda:0"), "cuda:0")
+        res["models"] = other_models(False, "cuda:0")
     print(json.dumps(res))
 
 

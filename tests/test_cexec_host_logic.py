@@ -10,7 +10,7 @@ import torch
 from paddlemix_amd import _lib
 from paddlemix_amd.cexec import UNetHandle
 from paddlemix_amd.unet import UNet2DConditionModel, synth_unet_params, unet_param_shapes
-from tests.abi_emulator import Emulator
+from tests.abi_emulator import Emulator, on_emulator
 from tests.configs import MINI_XL, SD15, SDXL, TINY
 
 
@@ -29,7 +29,7 @@ def test_packed_weights_and_plan_equal_python_builder(cfg, rd):
     hd = UNetHandle(cfg, residual_dtype=rd)
     hd.load(P)
     image = hd.pack()
-    model = UNet2DConditionModel(cfg, P, residual_dtype=rd, _test_backend=Emulator())
+    model = on_emulator(UNet2DConditionModel, cfg, P, residual_dtype=rd)
     checked = 0
     for key, t in model.w.items():
         got = hd.packed_tensor(image, key)

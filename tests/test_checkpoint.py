@@ -11,7 +11,7 @@ import torch
 from paddlemix_amd import checkpoint as C
 from paddlemix_amd.unet import UNet2DConditionModel, synth_unet_params, unet_param_shapes
 from paddlemix_amd.vae import AutoencoderKL, synth_decoder_params
-from tests.abi_emulator import Emulator
+from tests.abi_emulator import Emulator, on_emulator
 from tests.configs import MINI_VAE, MINI_XL, TINY
 
 
@@ -32,8 +32,8 @@ def test_unet_from_pretrained_safetensors(tmp_path, fmt):
     lin = next(k for k, s in unet_param_shapes(cfg).items() if len(s) == 2 and s[0] != s[1])
     assert tuple(state[lin].shape) == (tuple(P[lin].shape) if fmt == "pd" else tuple(P[lin].shape)[::-1])
     x, enc = _inputs(cfg)
-    ref = UNet2DConditionModel(cfg, P, _test_backend=Emulator())(x, 10, enc).sample
-    model = UNet2DConditionModel.from_pretrained(str(tmp_path), subfolder="unet", _test_backend=Emulator())
+    ref = on_emulator(UNet2DConditionModel, cfg, P)(x, 10, enc).sample
+    model = on_emulator(UNet2DConditionModel.from_pretrained, str(tmp_path), subfolder="unet")
     assert model.config.cross_attention_dim == cfg["cross_attention_dim"]
     assert torch.equal(model(x, 10, enc).sample, ref)
 
@@ -69,9 +69,9 @@ def test_pdparams_pickle_and_errors(tmp_path):
     blob["StructuredToParameterName@@"] = {k: k for k in P}
     with open(d / "model_state.pdparams", "wb") as fh:
         pickle.dump(blob, fh, protocol=4)
-    vae = AutoencoderKL.from_pretrained(str(d), _test_backend=Emulator())
+    vae = on_emulator(AutoencoderKL.from_pretrained, str(d))
     z = torch.randn(1, 4, 4, 4, generator=torch.Generator().manual_seed(1))
-    assert torch.equal(vae.decode(z).sample, AutoencoderKL(cfg, P, _test_backend=Emulator()).decode(z).sample)
+    assert torch.equal(vae.decode(z).sample, on_emulator(AutoencoderKL, cfg, P).decode(z).sample)
 
     class Evil:
         def __reduce__(self):
@@ -139,7 +139,7 @@ def test_fuse_lora_matches_the_unfused_branch():
     # the fused state dict drives the device program like any other (and moves the output)
     s, e = torch.randn(1, 4, 16, 16, generator=g), torch.randn(1, 7, 64, generator=g)
     Pb = {k: v.to(torch.bfloat16).float() if v.dim() > 1 else v for k, v in fused.items()}
-    out = UNet2DConditionModel(TINY, fused, _test_backend=Emulator())(s, 10, e).sample
+    out = on_emulator(UNet2DConditionModel, TINY, fused)(s, 10, e).sample
     ref = U.unet_forward(Pb, TINY, s, 10, e)
     assert ((out - ref).norm() / ref.norm()).item() < 2e-2
     assert not torch.allclose(ref, U.unet_forward({k: v.to(torch.bfloat16).float() if v.dim() > 1 else v for k, v in P.items()}, TINY, s, 10, e))

@@ -5,7 +5,7 @@ import torch
 
 from oracle import clip_ref as R
 from paddlemix_amd.clip import CLIPTextModel, CLIPTextModelWithProjection, clip_param_shapes, synth_clip_params
-from tests.abi_emulator import Emulator
+from tests.abi_emulator import Emulator, on_emulator
 from tests.configs import CLIP_BIGG, CLIP_L, MINI_CLIP
 
 
@@ -39,7 +39,7 @@ def test_program_matches_oracle(act, eos):
     Pb = {k: (v.to(torch.bfloat16).float() if v.dim() > 1 else v) for k, v in P.items()}
     ids = _ids(2, 16, cfg["vocab_size"], eos)
     ref = R.clip_text_forward(Pb, cfg, ids)
-    model = CLIPTextModel(cfg, P, _test_backend=Emulator())
+    model = on_emulator(CLIPTextModel, cfg, P)
     out = model(ids, output_hidden_states=True)
     assert _rel(out.last_hidden_state, ref["last_hidden_state"]) < 1e-2
     assert _rel(out.pooler_output, ref["pooler_output"]) < 1e-2
@@ -59,7 +59,7 @@ def test_with_projection_and_errors():
     Pp = synth_clip_params(dict(cfg, with_projection=True), seed=6)
     Pb = {k: (v.to(torch.bfloat16).float() if v.dim() > 1 else v) for k, v in Pp.items()}
     ids = _ids(1, 12, cfg["vocab_size"], 2)
-    model = CLIPTextModelWithProjection(cfg, Pp, _test_backend=Emulator())
+    model = on_emulator(CLIPTextModelWithProjection, cfg, Pp)
     out = model(ids, output_hidden_states=True)
     ref = R.clip_text_forward(Pb, dict(cfg, with_projection=True), ids)
     assert out.text_embeds.shape == (1, 32) and _rel(out.text_embeds, ref["text_embeds"]) < 1.5e-2
@@ -72,10 +72,9 @@ def test_with_projection_and_errors():
     with pytest.raises(NotImplementedError):
         model(ids, attention_mask=torch.ones(1, 12))
     with pytest.raises(KeyError):
-        CLIPTextModelWithProjection(cfg, {k: v for k, v in Pp.items() if k != "text_projection.weight"},
-                                    _test_backend=Emulator())
+        on_emulator(CLIPTextModelWithProjection, cfg, {k: v for k, v in Pp.items() if k != "text_projection.weight"})
     with pytest.raises(NotImplementedError):
-        CLIPTextModel(dict(cfg, hidden_act="relu"), Pp, _test_backend=Emulator())
+        on_emulator(CLIPTextModel, dict(cfg, hidden_act="relu"), Pp)
 
 
 def test_vision_tower_matches_oracle():
@@ -92,7 +91,7 @@ def test_vision_tower_matches_oracle():
     Pb = {k: (v.to(torch.bfloat16).float() if v.dim() > 1 else v) for k, v in P.items()}
     Pb["vision_model.embeddings.class_embedding"] = P["vision_model.embeddings.class_embedding"]
     x = torch.randn(2, 3, 56, 56, generator=torch.Generator().manual_seed(1))
-    model = CLIPVisionModelWithProjection(cfg, P, _test_backend=Emulator())
+    model = on_emulator(CLIPVisionModelWithProjection, cfg, P)
     out = model(x, output_hidden_states=True)
     ref = R.clip_vision_forward(Pb, cfg, x)
     assert out.image_embeds.shape == (2, 48) and out.last_hidden_state.shape == (2, 17, 64)
@@ -108,4 +107,4 @@ def test_vision_tower_matches_oracle():
     bad = dict(P)
     bad.pop("visual_projection.weight")
     with pytest.raises(KeyError):
-        CLIPVisionModelWithProjection(cfg, bad, _test_backend=Emulator())
+        on_emulator(CLIPVisionModelWithProjection, cfg, bad)

@@ -20,7 +20,7 @@ def _worker(rank, world, port, q):
     from paddlemix_amd import _lib
     from paddlemix_amd.dist import empty_wire_params, gather_latents, wire_params
     from paddlemix_amd.unet import UNet2DConditionModel, synth_unet_params, unet_param_shapes
-    from tests.abi_emulator import Emulator
+    from tests.abi_emulator import Emulator, on_emulator
     from tests.configs import TINY as cfg
     ed = _lib.elem_dtype()
     torch.manual_seed(100 + rank)
@@ -39,7 +39,7 @@ def _worker(rank, world, port, q):
     g = torch.Generator().manual_seed(1000 + rank)
     sample = torch.randn(2, 4, 8, 8, generator=g)
     enc = torch.randn(2, 7, cfg["cross_attention_dim"], generator=g)
-    model = UNet2DConditionModel(cfg, P, _test_backend=Emulator())
+    model = on_emulator(UNet2DConditionModel, cfg, P)
     out = model(sample, 321, enc).sample
     allz = gather_latents(out)                      # the job's only other collective
     ok = True
@@ -49,7 +49,7 @@ def _worker(rank, world, port, q):
             gr = torch.Generator().manual_seed(1000 + r)
             full_s.append(torch.randn(2, 4, 8, 8, generator=gr))
             full_e.append(torch.randn(2, 7, cfg["cross_attention_dim"], generator=gr))
-        full = UNet2DConditionModel(cfg, ref_P, _test_backend=Emulator())(torch.cat(full_s), 321, torch.cat(full_e)).sample
+        full = on_emulator(UNet2DConditionModel, cfg, ref_P)(torch.cat(full_s), 321, torch.cat(full_e)).sample
         ok = allz.shape == full.shape and torch.allclose(allz, full, atol=1e-5, rtol=1e-5)
         ok = ok and not torch.allclose(allz[:2], allz[2:4])      # the ranks really worked on different prompts
     q.put((same and nbytes == expect, ok))

@@ -5,7 +5,7 @@ import torch
 
 from oracle import dit_ref as R
 from paddlemix_amd.dit import DiTTransformer2DModel, dit_param_shapes, synth_dit_params
-from tests.abi_emulator import Emulator
+from tests.abi_emulator import Emulator, on_emulator
 from tests.configs import DIT_XL2, MINI_DIT
 
 
@@ -34,7 +34,7 @@ def test_program_matches_oracle(B, side):
     labels = torch.randint(0, 11, (B,), generator=g)        # incl. the CFG null class (index num_embeds_ada_norm)
     t = torch.tensor([999.0, 500.0, 3.0])[:B]
     ref = R.dit_forward(Pb, cfg, x, t, labels)
-    model = DiTTransformer2DModel(cfg, P, _test_backend=Emulator())
+    model = on_emulator(DiTTransformer2DModel, cfg, P)
     out = model(x, timestep=t, class_labels=labels, return_dict=False)[0]
     assert out.shape == ref.shape == (B, 8, side, side) and out.dtype == torch.float32
     assert _rel(out, ref) < 2e-2, _rel(out, ref)
@@ -46,16 +46,16 @@ def test_program_matches_oracle(B, side):
 
 def test_errors():
     P = synth_dit_params(MINI_DIT, seed=1)
-    model = DiTTransformer2DModel(MINI_DIT, P, _test_backend=Emulator())
+    model = on_emulator(DiTTransformer2DModel, MINI_DIT, P)
     x = torch.randn(1, 4, 16, 16)
     with pytest.raises(ValueError, match="timestep"):
         model(x, class_labels=torch.tensor([1]))
     with pytest.raises(ValueError, match="square"):
         model(torch.randn(1, 4, 16, 8), timestep=1, class_labels=torch.tensor([1]))
     with pytest.raises(NotImplementedError):
-        DiTTransformer2DModel(dict(MINI_DIT, norm_type="layer_norm"), P, _test_backend=Emulator())
+        on_emulator(DiTTransformer2DModel, dict(MINI_DIT, norm_type="layer_norm"), P)
     with pytest.raises(KeyError):
-        DiTTransformer2DModel(MINI_DIT, {k: v for k, v in P.items() if k != "proj_out_2.bias"}, _test_backend=Emulator())
+        on_emulator(DiTTransformer2DModel, MINI_DIT, {k: v for k, v in P.items() if k != "proj_out_2.bias"})
 
 
 def test_dit_denoiser_loop_matches_reference_semantics():
@@ -67,7 +67,7 @@ def test_dit_denoiser_loop_matches_reference_semantics():
     cfg = MINI_DIT
     P = synth_dit_params(cfg, seed=8)
     Pb = {k: (v.to(torch.bfloat16).float() if v.dim() > 1 else v) for k, v in P.items()}
-    model = DiTTransformer2DModel(cfg, P, _test_backend=Emulator())
+    model = on_emulator(DiTTransformer2DModel, cfg, P)
     kw = dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear", clip_sample=False)
     lat0 = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(4))
     labels = torch.tensor([3, 7])

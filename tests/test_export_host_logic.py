@@ -10,11 +10,11 @@ import torch
 from paddlemix_amd import _lib
 from paddlemix_amd.export import ExportedProgram, export_program
 from tests import export_cases as EC
-from tests.abi_emulator import Emulator
+from tests.abi_emulator import Emulator, on_emulator
 
 
 def _export(name, tmp_path):
-    model, run, outputs = EC.build(name, True, _test_backend=Emulator())
+    model, run, outputs = on_emulator(EC.build, name, True)
     run()
     plan = EC.last_plan(model)
     path = str(tmp_path / (name + ".mi3prg"))
@@ -91,7 +91,7 @@ def test_loader_refuses_what_it_should(tmp_path):
 def test_export_refuses_a_plan_that_is_not_complete(tmp_path):
     from paddlemix_amd.unet import UNet2DConditionModel, synth_unet_params
     from tests.configs import MINI_XL
-    m = UNet2DConditionModel(MINI_XL, synth_unet_params(MINI_XL, seed=1), _test_backend=Emulator())
+    m = on_emulator(UNet2DConditionModel, MINI_XL, synth_unet_params(MINI_XL, seed=1))
     plan = m._get_plan(1, 16, 16, 7)          # text_time widths are only known at the first forward
     with pytest.raises(ValueError, match="run the model once"):
         export_program(m, plan, str(tmp_path / "x.mi3prg"))

@@ -89,8 +89,8 @@ def test_program_exported_on_a_host_without_a_gpu_runs_on_the_device(name, tmp_p
     same packed weights and launch list, and the C runtime replays it on the MI355X -- against the emulated model's own output
     (fp32 math at the device's rounding points). Measured on the MI355X: SDXL-structured UNet 1.47e-2, SD3 and VAE below 1e-2
     (profiles/r03_s22_cpu_exported_program.txt); bar 3e-2 = the distance between two 16-bit evaluations of one step"""
-    from tests.abi_emulator import Emulator
-    model, run, outputs = EC.build(name, True, _test_backend=Emulator())
+    from tests.abi_emulator import Emulator, on_emulator
+    model, run, outputs = on_emulator(EC.build, name, True)
     run()
     plan = EC.last_plan(model)
     named = dict(_named_tensors(plan))

@@ -5,7 +5,7 @@ import torch
 
 from oracle import unet_ref as U
 from paddlemix_amd.unet import UNet2DConditionModel, synth_unet_params, unet_param_shapes
-from tests.abi_emulator import Emulator
+from tests.abi_emulator import Emulator, on_emulator
 from tests.configs import MINI_XL, SD15, SDXL, TINY, UNET_VARIANTS
 
 
@@ -35,7 +35,7 @@ def test_program_matches_oracle(cfg, B, H, W, L):
     t = 501
     ref = U.unet_forward(Pb, cfg, sample, t, enc, added_cond_kwargs=added)
     emu = Emulator()
-    model = UNet2DConditionModel(cfg, P, _test_backend=emu)
+    model = on_emulator(UNet2DConditionModel, cfg, P, backend=emu)
     out = model(sample, t, enc, added_cond_kwargs=added, return_dict=False)[0]
     assert out.shape == ref.shape and out.dtype == torch.float32
     # bf16 activations between ops: a few 1e-3 of relative error is the rounding floor
@@ -47,7 +47,7 @@ def test_program_matches_oracle(cfg, B, H, W, L):
     # optional program variant: LayerNorms folded into their consuming projections (row_stats + linear_ln)
     assert "linear_ln" not in emu.calls
     emu2 = Emulator()
-    folded = UNet2DConditionModel(cfg, P, fold_layernorm=True, _test_backend=emu2)
+    folded = on_emulator(UNet2DConditionModel, cfg, P, fold_layernorm=True, backend=emu2)
     out3 = folded(sample, t, enc, added_cond_kwargs=added).sample
     assert "linear_ln" in emu2.calls and _rel(out3, ref) < 2e-2
 
@@ -62,8 +62,8 @@ def test_fp32_residual_stream_program(cfg, B, H, W, L):
     sample, enc, added = _inputs(cfg, B, H, W, L)
     ref = U.unet_forward(Pb, cfg, sample, 501, enc, added_cond_kwargs=added)
     e16, e32 = Emulator(), Emulator()
-    o16 = UNet2DConditionModel(cfg, P, _test_backend=e16)(sample, 501, enc, added_cond_kwargs=added).sample
-    o32 = UNet2DConditionModel(cfg, P, residual_dtype="fp32", _test_backend=e32)(sample, 501, enc, added_cond_kwargs=added).sample
+    o16 = on_emulator(UNet2DConditionModel, cfg, P, backend=e16)(sample, 501, enc, added_cond_kwargs=added).sample
+    o32 = on_emulator(UNet2DConditionModel, cfg, P, residual_dtype="fp32", backend=e32)(sample, 501, enc, added_cond_kwargs=added).sample
     r16, r32 = _rel(o16, ref), _rel(o32, ref)
     assert r32 < 0.8 * r16 and r32 < 1e-2, (r16, r32)
     # same number of contractions; the extra launches are the operand casts in front of the down / upsampling convs
@@ -71,7 +71,7 @@ def test_fp32_residual_stream_program(cfg, B, H, W, L):
     pair = [c2 for c in e16.calls for c2 in (("gn_stats", "scale_shift_act") if c == "gn_fused" else (c,))]
     assert [c for c in e32.calls if c != "cast_rows"] == pair and "cast_rows" in e32.calls and "gn_fused" in e16.calls
     with pytest.raises(NotImplementedError):
-        UNet2DConditionModel(cfg, P, residual_dtype="fp32", fold_layernorm=True, _test_backend=Emulator())
+        on_emulator(UNet2DConditionModel, cfg, P, residual_dtype="fp32", fold_layernorm=True)
 
 
 @pytest.mark.parametrize("name", sorted(UNET_VARIANTS))
@@ -82,7 +82,7 @@ def test_config_variants_match_oracle(name):
     Pb = {k: v.to(torch.bfloat16).float() if v.dim() > 1 else v for k, v in P.items()}
     sample, enc, _ = _inputs(cfg, 2, 16, 16, 7)
     ref = U.unet_forward(Pb, cfg, sample, 333, enc)
-    out = UNet2DConditionModel(cfg, P, _test_backend=Emulator())(sample, 333, enc, return_dict=False)[0]
+    out = on_emulator(UNet2DConditionModel, cfg, P)(sample, 333, enc, return_dict=False)[0]
     assert out.shape == ref.shape and _rel(out, ref) < 2e-2, _rel(out, ref)
 
 
@@ -110,7 +110,7 @@ def test_class_embeddings_match_oracle(kind, concat):
     sample, enc, _ = _inputs(cfg, 2, 16, 16, 7)
     labels = make(torch.Generator().manual_seed(5), 2, cfg)
     ref = U.unet_forward(Pb, cfg, sample, 333, enc, class_labels=labels)
-    model = UNet2DConditionModel(cfg, P, _test_backend=Emulator())
+    model = on_emulator(UNet2DConditionModel, cfg, P)
     out = model(sample, 333, enc, class_labels=labels, return_dict=False)[0]
     assert _rel(out, ref) < 2e-2, _rel(out, ref)
     # the class embedding matters (different labels -> different output), and is required
@@ -130,13 +130,13 @@ def test_timestep_cond_matches_oracle():
     Pb = {k: v.to(torch.bfloat16).float() if v.dim() > 1 else v for k, v in P.items()}
     sample, enc, _ = _inputs(cfg, 2, 16, 16, 7)
     w = torch.randn(2, 32, generator=torch.Generator().manual_seed(1))
-    model = UNet2DConditionModel(cfg, P, _test_backend=Emulator())
+    model = on_emulator(UNet2DConditionModel, cfg, P)
     out = model(sample, 200, enc, timestep_cond=w).sample
     assert _rel(out, U.unet_forward(Pb, cfg, sample, 200, enc, timestep_cond=w)) < 2e-2
     out0 = model(sample, 200, enc).sample     # no condition: the projection adds nothing
     assert _rel(out0, U.unet_forward(Pb, cfg, sample, 200, enc)) < 2e-2 and not torch.equal(out0, out)
     with pytest.raises(ValueError, match="timestep_cond"):
-        UNet2DConditionModel(TINY, synth_unet_params(TINY, seed=9), _test_backend=Emulator())(sample, 200, enc, timestep_cond=w)
+        on_emulator(UNet2DConditionModel, TINY, synth_unet_params(TINY, seed=9))(sample, 200, enc, timestep_cond=w)
 
 
 def test_ip_adapter_matches_oracle():
@@ -152,7 +152,7 @@ def test_ip_adapter_matches_oracle():
     sample, enc, _ = _inputs(cfg, 2, 16, 16, 7)
     g = torch.Generator().manual_seed(2)
     img, img2 = torch.randn(2, 48, generator=g), torch.randn(2, 48, generator=g)
-    model = UNet2DConditionModel(cfg, P, _test_backend=Emulator())
+    model = on_emulator(UNet2DConditionModel, cfg, P)
     outs = {}
     for sc in (1.0, 0.6, 0.0):
         model.set_ip_adapter_scale(sc)
@@ -160,8 +160,7 @@ def test_ip_adapter_matches_oracle():
         ref = U.unet_forward(Pb, cfg, sample, 10, enc, added_cond_kwargs={"image_embeds": img}, ip_adapter_scale=sc)
         assert _rel(outs[sc], ref) < 2e-2, (sc, _rel(outs[sc], ref))
     # scale 0 launches no image-token attention: exactly the UNet without the adapter on the same weights
-    base = UNet2DConditionModel(TINY, {k: v for k, v in P.items() if "_ip." not in k and "encoder_hid_proj" not in k},
-                                _test_backend=Emulator())
+    base = on_emulator(UNet2DConditionModel, TINY, {k: v for k, v in P.items() if "_ip." not in k and "encoder_hid_proj" not in k})
     assert torch.equal(outs[0.0], base(sample, 10, enc).sample)
     assert _rel(outs[1.0], outs[0.0]) > 1e-2                     # the image prompt matters ...
     model.set_ip_adapter_scale(1.0)
@@ -193,7 +192,7 @@ def test_controlnet_matches_oracle_and_feeds_the_unet():
     Pb = {k: v.to(torch.bfloat16).float() if v.dim() > 1 else v for k, v in P.items()}
     sample, enc, _ = _inputs(TINY, 2, 16, 16, 7)
     cond = torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(4))
-    net = ControlNetModel(cfg, P, _test_backend=Emulator())
+    net = on_emulator(ControlNetModel, cfg, P)
     assert net.config.conditioning_embedding_out_channels == (16, 32, 96, 256) and net.config.in_channels == 4
     for sc, gm in ((1.0, False), (0.6, True)):
         out = net(sample, 20, enc, cond, conditioning_scale=sc, guess_mode=gm)
@@ -203,7 +202,7 @@ def test_controlnet_matches_oracle_and_feeds_the_unet():
             assert a.shape == b.shape and a.dtype == torch.float32 and _rel(a, b) < 2e-2, _rel(a, b)
     d2, m2 = net(sample, 20, enc, cond, return_dict=False)
     Pu = synth_unet_params(TINY, seed=9)
-    unet = UNet2DConditionModel(TINY, Pu, _test_backend=Emulator())
+    unet = on_emulator(UNet2DConditionModel, TINY, Pu)
     got = unet(sample, 20, enc, down_block_additional_residuals=d2, mid_block_additional_residual=m2).sample
     Pub = {k: v.to(torch.bfloat16).float() if v.dim() > 1 else v for k, v in Pu.items()}
     rd, rm = U.controlnet_forward(Pb, cfg, sample, 20, enc, cond)
@@ -214,11 +213,11 @@ def test_controlnet_matches_oracle_and_feeds_the_unet():
     with pytest.raises(NotImplementedError):
         net(sample, 20, enc, cond, conditioning_scale=[1.0] * 7)
     with pytest.raises(NotImplementedError):
-        ControlNetModel(dict(TINY, global_pool_conditions=True), P, _test_backend=Emulator())
+        on_emulator(ControlNetModel, dict(TINY, global_pool_conditions=True), P)
     bad = dict(P)
     bad.pop("controlnet_mid_block.weight")
     with pytest.raises(KeyError):
-        ControlNetModel(cfg, bad, _test_backend=Emulator())
+        on_emulator(ControlNetModel, cfg, bad)
 
 
 def test_param_inventory_matches_oracle():
@@ -234,22 +233,22 @@ def test_synth_params_match_oracle_generator():
 
 def test_errors_mirror_reference():
     P = synth_unet_params(MINI_XL)
-    model = UNet2DConditionModel(MINI_XL, P, _test_backend=Emulator())
+    model = on_emulator(UNet2DConditionModel, MINI_XL, P)
     sample, enc, added = _inputs(MINI_XL, 1, 8, 8)
     with pytest.raises(ValueError, match="text_embeds"):
         model(sample, 1, enc, added_cond_kwargs={})
     with pytest.raises(ValueError, match="time_ids"):
         model(sample, 1, enc, added_cond_kwargs={"text_embeds": added["text_embeds"]})
     with pytest.raises(KeyError):
-        UNet2DConditionModel(MINI_XL, {k: v for k, v in P.items() if k != "conv_in.weight"}, _test_backend=Emulator())
+        on_emulator(UNet2DConditionModel, MINI_XL, {k: v for k, v in P.items() if k != "conv_in.weight"})
     bad = dict(P)
     bad["time_embedding.linear_1.weight"] = bad["time_embedding.linear_1.weight"].t()
     with pytest.raises(ValueError, match="Paddle layout"):
-        UNet2DConditionModel(MINI_XL, bad, _test_backend=Emulator())
+        on_emulator(UNet2DConditionModel, MINI_XL, bad)
     with pytest.raises(NotImplementedError):   # config fields outside the implemented path fail loudly at construction
-        UNet2DConditionModel(dict(MINI_XL, dual_cross_attention=True), P, _test_backend=Emulator())
+        on_emulator(UNet2DConditionModel, dict(MINI_XL, dual_cross_attention=True), P)
     with pytest.raises(ValueError, match="requires `projection_class_embeddings_input_dim`"):   # unet_2d_condition.py:363-366
-        UNet2DConditionModel(dict(TINY, class_embed_type="projection"), P, _test_backend=Emulator())
+        on_emulator(UNet2DConditionModel, dict(TINY, class_embed_type="projection"), P)
 
 
 def test_no_fallback_without_gpu():
@@ -267,7 +266,7 @@ def test_encoder_attention_mask_semantics():
     P = synth_unet_params(cfg, seed=1234)
     Pb = {k: v.to(torch.bfloat16).float() if v.dim() > 1 else v for k, v in P.items()}
     sample, enc, _ = _inputs(cfg, 2, 8, 8, L=7)
-    model = UNet2DConditionModel(cfg, P, _test_backend=Emulator())
+    model = on_emulator(UNet2DConditionModel, cfg, P)
     none = model(sample, 10, enc).sample
     keep = model(sample, 10, enc, encoder_attention_mask=torch.ones(2, 7)).sample
     assert torch.allclose(none, keep, rtol=1e-3, atol=1e-5)
@@ -291,7 +290,7 @@ def test_self_attention_mask_semantics(head_dim64):
     P = synth_unet_params(cfg, seed=1234)
     Pb = {k: v.to(torch.bfloat16).float() if v.dim() > 1 else v for k, v in P.items()}
     sample, enc, _ = _inputs(cfg, 2, 16, 16, L=7)                        # attention at 8 x 8 = 64 latent tokens
-    model = UNet2DConditionModel(cfg, P, _test_backend=Emulator())
+    model = on_emulator(UNet2DConditionModel, cfg, P)
     if head_dim64:
         assert model._log2_blocks
     none = model(sample, 10, enc).sample
@@ -311,7 +310,7 @@ def test_self_attention_mask_semantics(head_dim64):
     with pytest.raises(ValueError, match="batch"):
         model(sample, 10, enc, attention_mask=torch.ones(64))
     # a UNet with attention at several resolutions cannot take one mask length (SD-1.5 / SDXL: no pipeline passes it)
-    multi = UNet2DConditionModel(MINI_XL, synth_unet_params(MINI_XL, seed=1), _test_backend=Emulator())
+    multi = on_emulator(UNet2DConditionModel, MINI_XL, synth_unet_params(MINI_XL, seed=1))
     s2, e2, a2 = _inputs(MINI_XL, 1, 16, 16, L=7)
     with pytest.raises(ValueError, match="key tokens"):
         multi(s2, 10, e2, added_cond_kwargs=a2, attention_mask=torch.ones(1, 64))
@@ -357,7 +356,7 @@ def test_controlnet_residual_inputs(cfg):
     P = synth_unet_params(cfg, seed=1234)
     Pb = {k: v.to(torch.bfloat16).float() if v.dim() > 1 else v for k, v in P.items()}
     sample, enc, added = _inputs(cfg, 2, 16, 16, 7)
-    model = UNet2DConditionModel(cfg, P, _test_backend=Emulator())
+    model = on_emulator(UNet2DConditionModel, cfg, P)
     plain = model(sample, 300, enc, added_cond_kwargs=added).sample
     down, mid = _controlnet_residuals(cfg, 2, 16, 16)
     ref = U.unet_forward(Pb, cfg, sample, 300, enc, added_cond_kwargs=added, down_block_additional_residuals=down,
@@ -392,11 +391,11 @@ def test_latent_sizes_that_are_not_multiples_of_the_up_factor():
     g = torch.Generator().manual_seed(0)
     for hw in ((15, 15), (15, 18), (16, 13)):
         x, enc = torch.randn(2, 4, *hw, generator=g), torch.randn(2, 7, 64, generator=g)
-        out = UNet2DConditionModel(TINY, P, _test_backend=Emulator())(x, 10.0, enc).sample
+        out = on_emulator(UNet2DConditionModel, TINY, P)(x, 10.0, enc).sample
         ref = U.unet_forward(Pb, TINY, x, torch.tensor([10.0, 10.0]), enc)
         assert out.shape == ref.shape == x.shape and ((out - ref).norm() / ref.norm()).item() < 2e-2, hw
     # three levels: 18 -> 9 -> 5, then 5 -> 9 (cropped) and 9 -> 18 (exact x2, still folded into the conv gather)
-    m = UNet2DConditionModel(MINI_XL, synth_unet_params(MINI_XL, seed=1), _test_backend=Emulator())
+    m = on_emulator(UNet2DConditionModel, MINI_XL, synth_unet_params(MINI_XL, seed=1))
     td = MINI_XL["projection_class_embeddings_input_dim"] - 6 * MINI_XL["addition_time_embed_dim"]
     added = dict(text_embeds=torch.randn(1, td, generator=g), time_ids=torch.tensor([[1024., 1024., 0., 0., 1024., 1024.]]))
     x, enc = torch.randn(1, 4, 18, 18, generator=g), torch.randn(1, 7, 128, generator=g)

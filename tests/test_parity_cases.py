@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from tests import parity_cases as PC
-from tests.abi_emulator import Emulator
+from tests.abi_emulator import Emulator, on_emulator
 from tests.configs import TINY
 
 
@@ -37,7 +37,7 @@ def test_loop_replay_through_the_interpreter(tmp_path, monkeypatch, sched, steps
     s0_, rows_ = PC.schedule(case)
     np.savez(PC.golden_path("tiny_test"), x_end=x_end.numpy(), kept=np.array(case["keep"]), x_in=np.stack([xin[i] for i in case["keep"]]),
              pred=np.stack([pred[i] for i in case["keep"]]), x0_scale=np.float64(s0_), sched=np.array(rows_, dtype=np.float64))
-    r = PC.device_report("tiny_test", lambda c, Pm: UNet2DConditionModel(c["cfg"], Pm, _test_backend=Emulator()), dev="cpu")
+    r = PC.device_report("tiny_test", lambda c, Pm: on_emulator(UNet2DConditionModel, c["cfg"], Pm), dev="cpu")
     # the interpreter has the device's 16-bit rounding points: ~1e-2 per prediction, less on the latents
     assert 1e-4 < r["pred_rel_teacher_forced_max"] < 2e-2 and r["end_latents_rel"] < 1e-2 and r["steps"] == steps
     # the loop is the reference scheduler's: one step of run_loop == EulerRef / DDIMRef .step on the same prediction

@@ -9,7 +9,7 @@ from oracle import unet_ref as U
 from paddlemix_amd.pipeline import StableDiffusionDenoiser
 from paddlemix_amd.schedulers import DDIMScheduler, EulerDiscreteScheduler
 from paddlemix_amd.unet import UNet2DConditionModel, synth_unet_params
-from tests.abi_emulator import Emulator
+from tests.abi_emulator import Emulator, on_emulator
 from tests.configs import MINI_XL, TINY
 
 SCHED = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", steps_offset=1)
@@ -23,7 +23,7 @@ def test_sd_ddim_cfg_loop_matches_oracle_loop():
     pe, ne = torch.randn(1, 7, 64, generator=g), torch.randn(1, 7, 64, generator=g)
     lat0 = torch.randn(1, 4, 8, 8, generator=g)
     steps, gs = 20, 7.5
-    pipe = StableDiffusionDenoiser(UNet2DConditionModel(cfg, P, _test_backend=Emulator()),
+    pipe = StableDiffusionDenoiser(on_emulator(UNet2DConditionModel, cfg, P),
                                    DDIMScheduler(clip_sample=False, set_alpha_to_one=False, **SCHED))
     seen = []
     out = pipe(pe, ne, num_inference_steps=steps, guidance_scale=gs, latents=lat0.clone(),
@@ -54,7 +54,7 @@ def test_sdxl_euler_loop_runs_and_matches():
     added = dict(text_embeds=torch.randn(1, td, generator=g), time_ids=torch.tensor([[256., 256., 0., 0., 256., 256.]]))
     lat0 = torch.randn(1, 4, 8, 8, generator=g)
     kw = dict(timestep_spacing="leading", **SCHED)
-    pipe = StableDiffusionDenoiser(UNet2DConditionModel(cfg, P, _test_backend=Emulator()), EulerDiscreteScheduler(**kw))
+    pipe = StableDiffusionDenoiser(on_emulator(UNet2DConditionModel, cfg, P), EulerDiscreteScheduler(**kw))
     out = pipe(pe, num_inference_steps=4, guidance_scale=1.0, latents=lat0.clone(), added_cond_kwargs=added)
     sch = S.EulerRef(**kw)
     sch.set_timesteps(4)
@@ -79,9 +79,9 @@ def test_pipeline_with_vae_decode_outputs_images():
     g = torch.Generator().manual_seed(0)
     pe = torch.randn(1, 7, 64, generator=g)
     lat0 = torch.randn(1, 4, 8, 8, generator=g)
-    pipe = StableDiffusionDenoiser(UNet2DConditionModel(cfg, P, _test_backend=Emulator()),
+    pipe = StableDiffusionDenoiser(on_emulator(UNet2DConditionModel, cfg, P),
                                    DDIMScheduler(clip_sample=False, set_alpha_to_one=False, **SCHED),
-                                   vae=AutoencoderKL(MINI_VAE, Pv, _test_backend=Emulator()))
+                                   vae=on_emulator(AutoencoderKL, MINI_VAE, Pv))
     lat = pipe(pe, num_inference_steps=2, guidance_scale=1.0, latents=lat0.clone())
     img = pipe(pe, num_inference_steps=2, guidance_scale=1.0, latents=lat0.clone(), output_type="pt")
     assert img.shape == (1, 3, 32, 32) and img.min() >= 0 and img.max() <= 1
@@ -92,7 +92,7 @@ def test_pipeline_with_vae_decode_outputs_images():
     assert arr.shape == (1, 32, 32, 3) and arr.dtype == np.float32
     # a VAE that publishes per-channel latent statistics (pipeline_stable_diffusion_xl.py:1105-1110): latents * std / sf + mean
     stats = dict(MINI_VAE, latents_mean=[0.1, -0.2, 0.3, 0.0], latents_std=[1.5, 0.5, 1.0, 2.0])
-    pipe_s = StableDiffusionDenoiser(pipe.unet, pipe.scheduler, vae=AutoencoderKL(stats, Pv, _test_backend=Emulator()))
+    pipe_s = StableDiffusionDenoiser(pipe.unet, pipe.scheduler, vae=on_emulator(AutoencoderKL, stats, Pv))
     img_s = pipe_s.decode_latents(lat, "pt")
     z = lat * torch.tensor(stats["latents_std"]).reshape(1, 4, 1, 1) / MINI_VAE["scaling_factor"] + torch.tensor(stats["latents_mean"]).reshape(1, 4, 1, 1)
     ref_s = (V.decode(Pr, MINI_VAE, z) / 2 + 0.5).clamp(0, 1)
@@ -114,11 +114,11 @@ def test_full_sdxl_style_pipeline_from_token_ids():
     cfg = MINI_XL
     c1, c2 = dict(MINI_CLIP), dict(MINI_CLIP, projection_dim=64, hidden_act="gelu")
     P1, P2 = synth_clip_params(c1, seed=1), synth_clip_params(dict(c2, with_projection=True), seed=2)
-    pipe = StableDiffusionDenoiser(UNet2DConditionModel(cfg, synth_unet_params(cfg, seed=3), _test_backend=Emulator()),
+    pipe = StableDiffusionDenoiser(on_emulator(UNet2DConditionModel, cfg, synth_unet_params(cfg, seed=3)),
                                    EulerDiscreteScheduler(timestep_spacing="leading", **SCHED),
-                                   vae=AutoencoderKL(MINI_VAE, synth_decoder_params(MINI_VAE, seed=4), _test_backend=Emulator()),
-                                   text_encoder=CLIPTextModel(c1, P1, _test_backend=Emulator()),
-                                   text_encoder_2=CLIPTextModelWithProjection(c2, P2, _test_backend=Emulator()))
+                                   vae=on_emulator(AutoencoderKL, MINI_VAE, synth_decoder_params(MINI_VAE, seed=4)),
+                                   text_encoder=on_emulator(CLIPTextModel, c1, P1),
+                                   text_encoder_2=on_emulator(CLIPTextModelWithProjection, c2, P2))
     ids = _ids(1, 12, c1["vocab_size"], 2)
     embeds, pooled = pipe.encode_prompt(ids)
     assert embeds.shape == (1, 12, 128) and pooled.shape == (1, 64)
@@ -163,9 +163,9 @@ def test_sd3_flow_match_cfg_loop_matches_oracle_loop():
     pp, npp = torch.randn(1, 64, generator=g), torch.randn(1, 64, generator=g)
     lat0 = torch.randn(1, 4, 16, 16, generator=g)
     steps, gs = 4, 5.0
-    pipe = StableDiffusion3Denoiser(SD3Transformer2DModel(cfg, P, _test_backend=Emulator()),
+    pipe = StableDiffusion3Denoiser(on_emulator(SD3Transformer2DModel, cfg, P),
                                     FlowMatchEulerDiscreteScheduler(shift=3.0),
-                                    vae=AutoencoderKL(vcfg, Pv, _test_backend=Emulator()))
+                                    vae=on_emulator(AutoencoderKL, vcfg, Pv))
     out = pipe(pe, pp, ne, npp, num_inference_steps=steps, guidance_scale=gs, latents=lat0.clone())
     sch = S.FlowMatchEulerRef(shift=3.0)
     sch.set_timesteps(steps)
@@ -197,9 +197,9 @@ def test_sd3_encode_prompt_three_encoders():
                                                          hidden_act="gelu", with_projection=True)
     t5c = dict(MINI_T5, d_model=128, d_ff=256)
     P1, P2, P3 = synth_clip_params(c1, seed=1), synth_clip_params(c2, seed=2), synth_t5_params(t5c, seed=3)
-    pipe = StableDiffusion3Denoiser(None, None, text_encoder=CLIPTextModelWithProjection(c1, P1, _test_backend=Emulator()),
-                                    text_encoder_2=CLIPTextModelWithProjection(c2, P2, _test_backend=Emulator()),
-                                    text_encoder_3=T5EncoderModel(t5c, P3, _test_backend=Emulator()))
+    pipe = StableDiffusion3Denoiser(None, None, text_encoder=on_emulator(CLIPTextModelWithProjection, c1, P1),
+                                    text_encoder_2=on_emulator(CLIPTextModelWithProjection, c2, P2),
+                                    text_encoder_3=on_emulator(T5EncoderModel, t5c, P3))
     ids = _ids(2, 16, c1["vocab_size"], 2)
     ids3 = torch.randint(0, t5c["vocab_size"], (2, 24), generator=torch.Generator().manual_seed(4))
     emb, pooled = pipe.encode_prompt(ids, ids, ids3)
@@ -229,7 +229,7 @@ def test_fused_cfg_scheduler_update_equals_generic_path():
                   EulerDiscreteScheduler(timestep_spacing="leading", **SCHED)):
         for gs in (7.5, 1.0):
             emu = Emulator()
-            pipe = StableDiffusionDenoiser(UNet2DConditionModel(cfg, P, _test_backend=emu), sched)
+            pipe = StableDiffusionDenoiser(on_emulator(UNet2DConditionModel, cfg, P, backend=emu), sched)
             a = pipe(pe, ne, num_inference_steps=4, guidance_scale=gs, latents=lat0.clone(), fused_update=True)
             b = pipe(pe, ne, num_inference_steps=4, guidance_scale=gs, latents=lat0.clone(), fused_update=False)
             assert torch.allclose(a, b, rtol=2e-5, atol=2e-5), (type(sched).__name__, gs, (a - b).abs().max())
@@ -255,8 +255,8 @@ def test_img2img_loop_matches_oracle_loop():
     steps, strength, gs, sf = 10, 0.6, 5.0, MINI_VAE["scaling_factor"]
     for sched_cls, ref_cls, kw in ((DDIMScheduler, S.DDIMRef, dict(clip_sample=False, set_alpha_to_one=False, **SCHED)),
                                    (EulerDiscreteScheduler, S.EulerRef, dict(timestep_spacing="leading", **SCHED))):
-        pipe = StableDiffusionDenoiser(UNet2DConditionModel(cfg, P, _test_backend=Emulator()), sched_cls(**kw),
-                                       vae=AutoencoderKL(MINI_VAE, Pv, _test_backend=Emulator()))
+        pipe = StableDiffusionDenoiser(on_emulator(UNet2DConditionModel, cfg, P), sched_cls(**kw),
+                                       vae=on_emulator(AutoencoderKL, MINI_VAE, Pv))
         seen = []
         out = pipe(pe, ne, num_inference_steps=steps, guidance_scale=gs, image=image, strength=strength,
                    generator=torch.Generator().manual_seed(11),
@@ -310,7 +310,7 @@ def test_lcm_loop_matches_oracle_loop():
     lat0 = torch.randn(2, 4, 8, 8, generator=g)
     steps, gs = 4, 8.0
     kw = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear")
-    pipe = StableDiffusionDenoiser(UNet2DConditionModel(cfg, P, _test_backend=Emulator()), LCMScheduler(**kw))
+    pipe = StableDiffusionDenoiser(on_emulator(UNet2DConditionModel, cfg, P), LCMScheduler(**kw))
     # the embedding itself: sin | cos of 1000 * w over the 10000^(-i / (half - 1)) frequencies
     emb = pipe.get_guidance_scale_embedding(torch.tensor([gs - 1.0, 0.0]), embedding_dim=32)
     f = np.exp(-np.log(10000.0) * np.arange(16) / 15)
@@ -336,7 +336,7 @@ def test_lcm_loop_matches_oracle_loop():
     assert rel < 3e-2, rel
     # DDIM eta > 0 goes through the generic step with the pipeline's generator (prepare_extra_step_kwargs, :520-535)
     cfg0 = TINY
-    pipe0 = StableDiffusionDenoiser(UNet2DConditionModel(cfg0, synth_unet_params(cfg0, seed=1234), _test_backend=Emulator()),
+    pipe0 = StableDiffusionDenoiser(on_emulator(UNet2DConditionModel, cfg0, synth_unet_params(cfg0, seed=1234)),
                                     DDIMScheduler(clip_sample=False, set_alpha_to_one=False, **SCHED))
     a = pipe0(pe, num_inference_steps=3, guidance_scale=1.0, latents=lat0.clone(), eta=1.0, generator=torch.Generator().manual_seed(2))
     b = pipe0(pe, num_inference_steps=3, guidance_scale=1.0, latents=lat0.clone(), eta=1.0, generator=torch.Generator().manual_seed(2))
@@ -356,7 +356,7 @@ def test_lcm_img2img_runs_all_steps_of_the_shortened_schedule():
     pe = torch.randn(1, 7, 64, generator=g)
     img_lat = torch.randn(1, 4, 8, 8, generator=g)      # already latent-sized: no VAE needed (img2img prepare_latents, :640-643)
     kw = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear")
-    pipe = StableDiffusionDenoiser(UNet2DConditionModel(cfg, P, _test_backend=Emulator()), LCMScheduler(**kw))
+    pipe = StableDiffusionDenoiser(on_emulator(UNet2DConditionModel, cfg, P), LCMScheduler(**kw))
     seen = []
     out = pipe(pe, num_inference_steps=4, guidance_scale=8.0, image=img_lat, strength=0.5,
                generator=torch.Generator().manual_seed(3), callback_on_step_end=lambda p, i, t, k: (seen.append(int(t)), k)[1])
@@ -365,8 +365,8 @@ def test_lcm_img2img_runs_all_steps_of_the_shortened_schedule():
     # different image, so the call must refuse
     from paddlemix_amd.clip import CLIPTextModel, synth_clip_params
     from tests.configs import MINI_CLIP
-    te = CLIPTextModel(MINI_CLIP, synth_clip_params(MINI_CLIP, seed=1), _test_backend=Emulator())
-    pipe2 = StableDiffusionDenoiser(UNet2DConditionModel(TINY, synth_unet_params(TINY, seed=1), _test_backend=Emulator()),
+    te = on_emulator(CLIPTextModel, MINI_CLIP, synth_clip_params(MINI_CLIP, seed=1))
+    pipe2 = StableDiffusionDenoiser(on_emulator(UNet2DConditionModel, TINY, synth_unet_params(TINY, seed=1)),
                                     DDIMScheduler(clip_sample=False, set_alpha_to_one=False, **SCHED), text_encoder=te)
     ids = torch.randint(3, 900, (1, 7))
     with pytest.raises(ValueError, match="negative_prompt_ids"):
@@ -401,8 +401,8 @@ def test_inpaint_loops_match_oracle_loops():
     P = synth_unet_params(cfg, seed=1234)
     Pb = {k: v.to(torch.bfloat16).float() if v.dim() > 1 else v for k, v in P.items()}
     kw = dict(clip_sample=False, set_alpha_to_one=False, **SCHED)
-    vae = AutoencoderKL(MINI_VAE, Pv, _test_backend=Emulator())
-    pipe = StableDiffusionDenoiser(UNet2DConditionModel(cfg, P, _test_backend=Emulator()), DDIMScheduler(**kw), vae=vae)
+    vae = on_emulator(AutoencoderKL, MINI_VAE, Pv)
+    pipe = StableDiffusionDenoiser(on_emulator(UNet2DConditionModel, cfg, P), DDIMScheduler(**kw), vae=vae)
     steps, gs = 5, 4.0
     out = pipe(pe, ne, num_inference_steps=steps, guidance_scale=gs, image=image, mask_image=mask_px,
                generator=torch.Generator().manual_seed(31))
@@ -432,7 +432,7 @@ def test_inpaint_loops_match_oracle_loops():
     P9 = synth_unet_params(cfg9, seed=77)
     P9b = {k: v.to(torch.bfloat16).float() if v.dim() > 1 else v for k, v in P9.items()}
     ekw = dict(timestep_spacing="leading", **SCHED)
-    pipe9 = StableDiffusionDenoiser(UNet2DConditionModel(cfg9, P9, _test_backend=Emulator()), EulerDiscreteScheduler(**ekw), vae=vae)
+    pipe9 = StableDiffusionDenoiser(on_emulator(UNet2DConditionModel, cfg9, P9), EulerDiscreteScheduler(**ekw), vae=vae)
     steps = 10
     out9 = pipe9(pe, num_inference_steps=steps, guidance_scale=1.0, image=image, mask_image=mask_px, strength=0.6,
                  generator=torch.Generator().manual_seed(32))
@@ -452,8 +452,7 @@ def test_inpaint_loops_match_oracle_loops():
     # errors: mask without image; a UNet whose channel count fits neither form
     with pytest.raises(ValueError):
         pipe(pe, ne, num_inference_steps=2, mask_image=mask_px)
-    bad = StableDiffusionDenoiser(UNet2DConditionModel(dict(TINY, in_channels=8), synth_unet_params(dict(TINY, in_channels=8), seed=1),
-                                                       _test_backend=Emulator()), DDIMScheduler(**kw), vae=vae)
+    bad = StableDiffusionDenoiser(on_emulator(UNet2DConditionModel, dict(TINY, in_channels=8), synth_unet_params(dict(TINY, in_channels=8), seed=1)), DDIMScheduler(**kw), vae=vae)
     with pytest.raises(ValueError, match="Incorrect configuration"):
         bad(pe, num_inference_steps=2, guidance_scale=1.0, image=image, mask_image=mask_px)
 
@@ -473,8 +472,8 @@ def test_controlnet_loop_matches_oracle_loop():
     lat0 = torch.randn(1, 4, 8, 8, generator=g)
     hint = torch.rand(1, 3, 64, 64, generator=g)
     kw = dict(clip_sample=False, set_alpha_to_one=False, **SCHED)
-    pipe = StableDiffusionDenoiser(UNet2DConditionModel(cfg, P, _test_backend=Emulator()), DDIMScheduler(**kw),
-                                   controlnet=ControlNetModel(cfg, Pc, _test_backend=Emulator()))
+    pipe = StableDiffusionDenoiser(on_emulator(UNet2DConditionModel, cfg, P), DDIMScheduler(**kw),
+                                   controlnet=on_emulator(ControlNetModel, cfg, Pc))
     steps, gs = 3, 5.0
     for guess, sc in ((False, 0.8), (True, 1.0)):
         out = pipe(pe, ne, num_inference_steps=steps, guidance_scale=gs, latents=lat0.clone(), control_image=hint,

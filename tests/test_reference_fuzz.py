@@ -15,7 +15,7 @@ from oracle import unet_ref as U
 
 def one_trial(trial: int, rng: random.Random):
     from paddlemix_amd.unet import UNet2DConditionModel
-    from tests.abi_emulator import Emulator
+    from tests.abi_emulator import Emulator, on_emulator
     n = rng.choice([2, 3])
     boc = tuple(rng.choice([32, 64]) * (2 ** min(i, 1)) for i in range(n))
     down = tuple(rng.choice(["DownBlock2D", "CrossAttnDownBlock2D"]) for _ in range(n))
@@ -44,7 +44,7 @@ def one_trial(trial: int, rng: random.Random):
         ora = U.unet_forward(P, cfg, x, t, enc, **kw)
         ref = rr.from_shim(rr.build_unet(cfg, P)(rr.to_shim(x), rr.to_shim(t), rr.to_shim(enc), **rr.to_shim(kw)).sample)
         orab = U.unet_forward({k: (v.to(torch.bfloat16).float() if v.dim() > 1 else v) for k, v in P.items()}, cfg, x, t, enc, **kw)
-    prod = UNet2DConditionModel(cfg, P, _test_backend=Emulator())(x, 37.0, enc, **kw).sample
+    prod = on_emulator(UNet2DConditionModel, cfg, P)(x, 37.0, enc, **kw).sample
     d_ref = float((ora - ref).abs().max() / ref.abs().max())
     d_dev = float((prod - orab).norm() / orab.norm())
     return cfg, extra, hw, d_ref, d_dev
@@ -139,7 +139,7 @@ def test_random_pipeline_calls():
     from paddlemix_amd.unet import UNet2DConditionModel
     from tests import configs as C
     from tests import reference_cases as RC
-    from tests.abi_emulator import Emulator
+    from tests.abi_emulator import Emulator, on_emulator
     rng = random.Random(0)
     warnings.simplefilter("ignore")
     for trial in range(8):
@@ -177,7 +177,7 @@ def test_random_pipeline_calls():
                 pipe = RC._sd_parts(rr, "pipeline_stable_diffusion", "StableDiffusionPipeline", cfg, P, _REF_SCHED[cls], cls, kw)
                 ref = pipe(prompt_embeds=sh(pe), negative_prompt_embeds=sh(ne), **common)[0]
         ref = rr.from_shim(ref)
-        out = StableDiffusionDenoiser(UNet2DConditionModel(cfg, P, _test_backend=Emulator()), getattr(PS, cls)(**kw))(
+        out = StableDiffusionDenoiser(on_emulator(UNet2DConditionModel, cfg, P), getattr(PS, cls)(**kw))(
             pe, ne, num_inference_steps=steps, guidance_scale=gs, guidance_rescale=gr, latents=lat0.clone(), **akw)
         d = float((out - ref).norm() / ref.norm())
         assert d < 5e-2, (trial, xl, cls, kw, steps, gs, gr, B, d)

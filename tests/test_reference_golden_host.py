@@ -5,17 +5,16 @@ import pytest
 import torch
 
 from tests import reference_cases as RC
-from tests.abi_emulator import Emulator
+from tests.abi_emulator import Emulator, on_emulator
 from tests.test_gpu_reference_golden import UNET_CASES, _gold, _rel, _row
 
-E = dict(_test_backend=Emulator())
 
 
 @pytest.mark.parametrize("name", UNET_CASES + ["unet_mini_xl_refiner_5_time_ids", "unet_inpaint_9ch", "unet_head_dim_tuple", "unet_upcast_attention"])
 def test_unet(name):
     from paddlemix_amd.unet import UNet2DConditionModel
     i = RC.CASES[name](False)["inputs"]
-    model = UNet2DConditionModel(i["cfg"], i["P"], **E)
+    model = on_emulator(UNet2DConditionModel, i["cfg"], i["P"])
     rows = [model(i["x"][b:b + 1], float(i["t"][b]), i["enc"][b:b + 1], **_row(i["kw"], b)).sample for b in range(i["x"].shape[0])]
     assert _rel(torch.cat(rows), _gold(name)["sample"]) < 2e-2
 
@@ -25,17 +24,17 @@ def test_controlnet_dit_sd3():
     from paddlemix_amd.sd3 import SD3Transformer2DModel
     from paddlemix_amd.unet import ControlNetModel
     i, gold = RC.CASES["controlnet_bgr_guess_mode"](False)["inputs"], _gold("controlnet_bgr_guess_mode")
-    downs, mid = ControlNetModel(i["cfg"], i["P"], **E)(i["x"], float(i["t"][0]), i["enc"], i["cond"], conditioning_scale=i["scale"],
+    downs, mid = on_emulator(ControlNetModel, i["cfg"], i["P"])(i["x"], float(i["t"][0]), i["enc"], i["cond"], conditioning_scale=i["scale"],
                                                         guess_mode=i["guess"], return_dict=False)
     assert all(_rel(d, gold[f"down{k}"]) < 2e-2 for k, d in enumerate(downs)) and _rel(mid, gold["mid"]) < 2e-2
     for name in ("dit_mini", "dit_mini_other_resolution"):
         i = RC.CASES[name](False)["inputs"]
-        m = DiTTransformer2DModel(i["cfg"], i["P"], **E)
+        m = on_emulator(DiTTransformer2DModel, i["cfg"], i["P"])
         rows = [m(i["x"][b:b + 1], timestep=i["t"][b:b + 1], class_labels=i["y"][b:b + 1]).sample for b in range(2)]
         assert _rel(torch.cat(rows), _gold(name)["sample"]) < 2e-2, name
     for name in ("sd3_mini", "sd3_mini_trained_norm_bias", "sd3_mini_nonsquare_8x24"):
         i = RC.CASES[name](False)["inputs"]
-        m = SD3Transformer2DModel(i["cfg"], i["P"], **E)
+        m = on_emulator(SD3Transformer2DModel, i["cfg"], i["P"])
         rows = [m(i["x"][b:b + 1], i["enc"][b:b + 1], i["pooled"][b:b + 1], float(i["t"][b])).sample for b in range(2)]
         assert _rel(torch.cat(rows), _gold(name)["sample"]) < 2e-2, name
 
@@ -45,7 +44,7 @@ def test_vae_and_text_encoders():
     from paddlemix_amd.t5 import T5EncoderModel
     from paddlemix_amd.vae import AutoencoderKL
     i, gold = RC.CASES["vae_mini"](False)["inputs"], _gold("vae_mini")
-    vae = AutoencoderKL(i["cfg"], i["P"], **E)
+    vae = on_emulator(AutoencoderKL, i["cfg"], i["P"])
     assert _rel(vae.decode(i["z"]).sample, gold["decode"]) < 2e-2
     post = vae.encode(i["img"]).latent_dist
     assert _rel(post.mean, gold["encode_mean"]) < 2e-2 and _rel(post.logvar, gold["encode_logvar"]) < 2e-2
@@ -57,9 +56,9 @@ def test_vae_and_text_encoders():
         vae.encode(i["img"])
     for name in ("clip_text_quick_gelu", "clip_text_gelu", "clip_text_eos_by_id"):
         i, gold = RC.CASES[name](False)["inputs"], _gold(name)
-        out = CLIPTextModelWithProjection(i["cfg"], i["P"], **E)(i["ids"], output_hidden_states=True)
+        out = on_emulator(CLIPTextModelWithProjection, i["cfg"], i["P"])(i["ids"], output_hidden_states=True)
         assert _rel(out.last_hidden_state, gold["last_hidden_state"]) < 1.5e-2 and _rel(out.text_embeds, gold["text_embeds"]) < 2e-2
     i, gold = RC.CASES["clip_vision"](False)["inputs"], _gold("clip_vision")
-    assert _rel(CLIPVisionModelWithProjection(i["cfg"], i["P"], **E)(i["px"]).image_embeds, gold["image_embeds"]) < 2e-2
+    assert _rel(on_emulator(CLIPVisionModelWithProjection, i["cfg"], i["P"])(i["px"]).image_embeds, gold["image_embeds"]) < 2e-2
     i, gold = RC.CASES["t5_encoder"](False)["inputs"], _gold("t5_encoder")
-    assert _rel(T5EncoderModel(i["cfg"], i["P"], **E)(i["ids"]).last_hidden_state, gold["last_hidden_state"]) < 3e-2
+    assert _rel(on_emulator(T5EncoderModel, i["cfg"], i["P"])(i["ids"]).last_hidden_state, gold["last_hidden_state"]) < 3e-2

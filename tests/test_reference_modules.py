@@ -57,7 +57,7 @@ def test_product_pipelines_follow_the_reference_pipelines():
     from paddlemix_amd.schedulers import DDIMScheduler, EulerDiscreteScheduler, FlowMatchEulerDiscreteScheduler
     from paddlemix_amd.sd3 import SD3Transformer2DModel, synth_sd3_params
     from paddlemix_amd.unet import UNet2DConditionModel, synth_unet_params
-    from tests.abi_emulator import Emulator
+    from tests.abi_emulator import Emulator, on_emulator
     from tests.configs import MINI_SD3, MINI_XL, TINY
 
     def rel(a, name):
@@ -67,7 +67,7 @@ def test_product_pipelines_follow_the_reference_pipelines():
     SD = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", steps_offset=1)
     g = torch.Generator().manual_seed(0)
     pe, ne, lat0 = torch.randn(1, 7, 64, generator=g), torch.randn(1, 7, 64, generator=g), torch.randn(1, 4, 8, 8, generator=g)
-    pipe = StableDiffusionDenoiser(UNet2DConditionModel(TINY, synth_unet_params(TINY, seed=1), _test_backend=Emulator()),
+    pipe = StableDiffusionDenoiser(on_emulator(UNet2DConditionModel, TINY, synth_unet_params(TINY, seed=1)),
                                    DDIMScheduler(clip_sample=False, set_alpha_to_one=False, **SD))
     out = pipe(pe, ne, num_inference_steps=6, guidance_scale=7.5, guidance_rescale=0.7, latents=lat0.clone())
     assert rel(out, "pipe_sd_ddim_cfg_rescale") < 3e-2, rel(out, "pipe_sd_ddim_cfg_rescale")
@@ -76,7 +76,7 @@ def test_product_pipelines_follow_the_reference_pipelines():
     cd = MINI_XL["cross_attention_dim"]
     pe, ne = torch.randn(1, 9, cd, generator=g), torch.randn(1, 9, cd, generator=g)
     pp, npp, lat0 = torch.randn(1, 64, generator=g), torch.randn(1, 64, generator=g), torch.randn(1, 4, 8, 8, generator=g)
-    pipe = StableDiffusionDenoiser(UNet2DConditionModel(MINI_XL, synth_unet_params(MINI_XL, seed=1), _test_backend=Emulator()),
+    pipe = StableDiffusionDenoiser(on_emulator(UNet2DConditionModel, MINI_XL, synth_unet_params(MINI_XL, seed=1)),
                                    EulerDiscreteScheduler(timestep_spacing="leading", **SD))
     tids = pipe.get_add_time_ids((96, 80), (3, 5), (64, 64), 64, "cpu")          # the reference's _get_add_time_ids
     assert tids.tolist() == [[96.0, 80.0, 3.0, 5.0, 64.0, 64.0]]
@@ -87,7 +87,7 @@ def test_product_pipelines_follow_the_reference_pipelines():
     g = torch.Generator().manual_seed(0)
     pe, ne = torch.randn(1, 9, 64, generator=g), torch.randn(1, 9, 64, generator=g)
     pp, npp, lat0 = torch.randn(1, 64, generator=g), torch.randn(1, 64, generator=g), torch.randn(1, 4, 16, 16, generator=g)
-    pipe3 = StableDiffusion3Denoiser(SD3Transformer2DModel(MINI_SD3, synth_sd3_params(MINI_SD3, seed=3), _test_backend=Emulator()),
+    pipe3 = StableDiffusion3Denoiser(on_emulator(SD3Transformer2DModel, MINI_SD3, synth_sd3_params(MINI_SD3, seed=3)),
                                      FlowMatchEulerDiscreteScheduler(shift=3.0))
     out = pipe3(pe, pp, ne, npp, num_inference_steps=6, guidance_scale=7.0, latents=lat0.clone())
     assert rel(out, "pipe_sd3_flow_match_cfg") < 3e-2, rel(out, "pipe_sd3_flow_match_cfg")
@@ -103,7 +103,7 @@ def test_product_image_pipelines_follow_the_reference_pipelines():
     from paddlemix_amd.schedulers import DDIMScheduler, EulerDiscreteScheduler, LCMScheduler
     from paddlemix_amd.unet import ControlNetModel, UNet2DConditionModel
     from paddlemix_amd.vae import AutoencoderKL
-    from tests.abi_emulator import Emulator
+    from tests.abi_emulator import Emulator, on_emulator
     from tests.configs import MINI_VAE, TINY
 
     def rel(a, name):
@@ -113,8 +113,8 @@ def test_product_image_pipelines_follow_the_reference_pipelines():
     SD = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear")
     ddim = lambda: DDIMScheduler(clip_sample=False, set_alpha_to_one=False, steps_offset=1, **SD)  # noqa: E731
     euler = lambda: EulerDiscreteScheduler(timestep_spacing="leading", steps_offset=1, **SD)  # noqa: E731
-    unet = lambda cfg, seed: UNet2DConditionModel(cfg, U.synth_unet_params(cfg, seed=seed), _test_backend=Emulator())  # noqa: E731
-    vae = AutoencoderKL(MINI_VAE, RC._vae_params(6), _test_backend=Emulator())
+    unet = lambda cfg, seed: on_emulator(UNet2DConditionModel, cfg, U.synth_unet_params(cfg, seed=seed))  # noqa: E731
+    vae = on_emulator(AutoencoderKL, MINI_VAE, RC._vae_params(6))
     # img2img
     g = torch.Generator().manual_seed(3)
     pe, ne = torch.randn(2, 7, 64, generator=g), torch.randn(2, 7, 64, generator=g)
@@ -140,7 +140,7 @@ def test_product_image_pipelines_follow_the_reference_pipelines():
     g = torch.Generator().manual_seed(0)
     pe, ne = torch.randn(1, 7, 64, generator=g), torch.randn(1, 7, 64, generator=g)
     lat0, hint = torch.randn(1, 4, 8, 8, generator=g), torch.rand(1, 3, 64, 64, generator=g)
-    cn = ControlNetModel(TINY, RC._synth(U.controlnet_param_shapes(TINY), 8), _test_backend=Emulator())
+    cn = on_emulator(ControlNetModel, TINY, RC._synth(U.controlnet_param_shapes(TINY), 8))
     pipe = StableDiffusionDenoiser(unet(TINY, 1), ddim(), controlnet=cn)
     for name, guess, sc in (("pipe_controlnet", False, 0.8), ("pipe_controlnet_guess_mode", True, 1.0)):
         out = pipe(pe, ne, num_inference_steps=3, guidance_scale=5.0, latents=lat0.clone(), control_image=hint, controlnet_conditioning_scale=sc,
@@ -151,7 +151,7 @@ def test_product_image_pipelines_follow_the_reference_pipelines():
     from paddlemix_amd.dit import DiTTransformer2DModel
     from paddlemix_amd.pipeline import DiTDenoiser
     lat0 = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(5))
-    dit = DiTDenoiser(DiTTransformer2DModel(RC.DIT_PIPE_CFG, D.synth_dit_params(RC.DIT_PIPE_CFG, seed=2), _test_backend=Emulator()), ddim())
+    dit = DiTDenoiser(on_emulator(DiTTransformer2DModel, RC.DIT_PIPE_CFG, D.synth_dit_params(RC.DIT_PIPE_CFG, seed=2)), ddim())
     out = dit([3, 8], guidance_scale=4.0, num_inference_steps=5, latents=lat0.clone())
     assert rel(out, "pipe_dit_class_cfg") < 5e-2, rel(out, "pipe_dit_class_cfg")
     # latent-consistency sampling
@@ -174,7 +174,7 @@ def test_product_encode_prompt_follows_the_reference_pipelines():
     from paddlemix_amd.clip import CLIPTextModel, CLIPTextModelWithProjection
     from paddlemix_amd.pipeline import StableDiffusion3Denoiser, StableDiffusionDenoiser
     from paddlemix_amd.t5 import T5EncoderModel
-    from tests.abi_emulator import Emulator
+    from tests.abi_emulator import Emulator, on_emulator
     E = RC.encode_prompt_inputs()
     a, b, c = E["ids"]["a"][None], E["ids"]["b"][None], E["t5_ids"][None]
 
@@ -183,28 +183,28 @@ def test_product_encode_prompt_follows_the_reference_pipelines():
         assert x.shape == g.shape, (x.shape, g.shape)
         return float((x.float() - g).norm() / g.norm())
 
-    sd = StableDiffusionDenoiser(None, None, text_encoder=CLIPTextModel(E["c1"], E["P1"], _test_backend=Emulator()))
+    sd = StableDiffusionDenoiser(None, None, text_encoder=on_emulator(CLIPTextModel, E["c1"], E["P1"]))
     assert rel(sd.encode_prompt(a)[0], "encode_prompt_sd_clip_skip", "prompt_embeds") < 1.5e-2
     assert rel(sd.encode_prompt(a, clip_skip=1)[0], "encode_prompt_sd_clip_skip", "prompt_embeds_clip_skip_1") < 1.5e-2
-    xl = StableDiffusionDenoiser(None, None, text_encoder=CLIPTextModel(E["c1"], E["P1"], _test_backend=Emulator()),
-                                 text_encoder_2=CLIPTextModelWithProjection(E["c2"], E["P2"], _test_backend=Emulator()))
+    xl = StableDiffusionDenoiser(None, None, text_encoder=on_emulator(CLIPTextModel, E["c1"], E["P1"]),
+                                 text_encoder_2=on_emulator(CLIPTextModelWithProjection, E["c2"], E["P2"]))
     # the whole single-encoder call from token ids (StableDiffusionPipeline.__call__ from prompt strings on the reference side)
     from oracle import unet_ref as U
     from paddlemix_amd.schedulers import DDIMScheduler
     from paddlemix_amd.unet import UNet2DConditionModel
     from tests.configs import TINY
-    pipe = StableDiffusionDenoiser(UNet2DConditionModel(TINY, U.synth_unet_params(TINY, seed=1), _test_backend=Emulator()),
+    pipe = StableDiffusionDenoiser(on_emulator(UNet2DConditionModel, TINY, U.synth_unet_params(TINY, seed=1)),
                                    DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
                                                  set_alpha_to_one=False, steps_offset=1),
-                                   text_encoder=CLIPTextModel(E["c1"], E["P1"], _test_backend=Emulator()))
+                                   text_encoder=on_emulator(CLIPTextModel, E["c1"], E["P1"]))
     lat0 = torch.randn(1, 4, 8, 8, generator=torch.Generator().manual_seed(9))
     out = pipe(prompt_ids=a, negative_prompt_ids=b, latents=lat0.clone(), num_inference_steps=4, guidance_scale=6.0)
     assert rel(out, "pipe_sd_from_prompt_strings", "latents") < 5e-2
     pe, pooled = xl.encode_prompt(a, b)
     assert rel(pe, "encode_prompt_sdxl", "prompt_embeds") < 1.5e-2 and rel(pooled, "encode_prompt_sdxl", "pooled") < 2e-2
-    s3 = StableDiffusion3Denoiser(None, None, text_encoder=CLIPTextModelWithProjection(E["c1p"], E["P1p"], _test_backend=Emulator()),
-                                  text_encoder_2=CLIPTextModelWithProjection(E["c2"], E["P2"], _test_backend=Emulator()),
-                                  text_encoder_3=T5EncoderModel(E["t5"], E["P3"], _test_backend=Emulator()))
+    s3 = StableDiffusion3Denoiser(None, None, text_encoder=on_emulator(CLIPTextModelWithProjection, E["c1p"], E["P1p"]),
+                                  text_encoder_2=on_emulator(CLIPTextModelWithProjection, E["c2"], E["P2"]),
+                                  text_encoder_3=on_emulator(T5EncoderModel, E["t5"], E["P3"]))
     pe, pooled = s3.encode_prompt(a, b, c)
     assert rel(pe, "encode_prompt_sd3", "prompt_embeds") < 1.5e-2 and rel(pooled, "encode_prompt_sd3", "pooled") < 2e-2
 
@@ -240,7 +240,7 @@ def test_error_behaviour_is_the_references():
     (unet_2d_condition.py:247-281) and the forward's missing-conditioning errors (:959, :991-1002)"""
     from oracle import unet_ref as U
     from paddlemix_amd.unet import UNet2DConditionModel
-    from tests.abi_emulator import Emulator
+    from tests.abi_emulator import Emulator, on_emulator
     from tests.configs import MINI_XL, TINY
     rm = reference_runner.ref_module("unet_2d_condition")
 
@@ -255,7 +255,7 @@ def test_error_behaviour_is_the_references():
                 dict(TINY, layers_per_block=(1,)), dict(TINY, only_cross_attention=(True,)), dict(TINY, cross_attention_dim=[64]),
                 dict(TINY, encoder_hid_dim_type="ip_image_proj")):
         want = message(lambda: rm.UNet2DConditionModel(**bad))
-        got = message(lambda: UNet2DConditionModel(bad, {}, _test_backend=Emulator()))
+        got = message(lambda: on_emulator(UNet2DConditionModel, bad, {}))
         assert want is not None and got == want, (bad, want, got)
     g = torch.Generator().manual_seed(0)
     x = torch.randn(1, 4, 16, 16, generator=g)
@@ -263,7 +263,7 @@ def test_error_behaviour_is_the_references():
                     (dict(TINY, num_class_embeds=10), {})):
         P = U.synth_unet_params(cfg, seed=1)
         enc = torch.randn(1, 7, cfg["cross_attention_dim"], generator=g)
-        ref, prod = reference_runner.build_unet(cfg, P), UNet2DConditionModel(cfg, P, _test_backend=Emulator())
+        ref, prod = reference_runner.build_unet(cfg, P), on_emulator(UNet2DConditionModel, cfg, P)
         sh = reference_runner.to_shim
         want = message(lambda: ref(sh(x), sh(torch.tensor([10.0])), sh(enc), **sh(kw)))
         got = message(lambda: prod(x, 10.0, enc, **kw))
@@ -300,7 +300,7 @@ def test_product_models_drop_into_the_reference_pipelines_call():
     from oracle import unet_ref as U
     from paddlemix_amd.sd3 import SD3Transformer2DModel
     from paddlemix_amd.unet import UNet2DConditionModel
-    from tests.abi_emulator import Emulator
+    from tests.abi_emulator import Emulator, on_emulator
     from tests.configs import MINI_SD3, MINI_XL, TINY
     rr = reference_runner
     SD = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", steps_offset=1)
@@ -313,7 +313,7 @@ def test_product_models_drop_into_the_reference_pipelines_call():
     g = torch.Generator().manual_seed(0)
     pe, ne, lat0 = torch.randn(1, 7, 64, generator=g), torch.randn(1, 7, 64, generator=g), torch.randn(1, 4, 8, 8, generator=g)
     pm = rr.ref_pipeline("pipeline_stable_diffusion")
-    unet = _Bridge(UNet2DConditionModel(TINY, U.synth_unet_params(TINY, seed=1), _test_backend=Emulator()))
+    unet = _Bridge(on_emulator(UNet2DConditionModel, TINY, U.synth_unet_params(TINY, seed=1)))
     sched = rr.ref_module("scheduling_ddim", "schedulers").DDIMScheduler(clip_sample=False, set_alpha_to_one=False, **SD)
     pipe = pm.StableDiffusionPipeline(vae=RC._FakeVAE(rr, scaling_factor=0.18215), text_encoder=None, tokenizer=None, unet=unet, scheduler=sched,
                                       safety_checker=None, feature_extractor=None, requires_safety_checker=False)
@@ -326,7 +326,7 @@ def test_product_models_drop_into_the_reference_pipelines_call():
     pe, ne = torch.randn(1, 9, cd, generator=g), torch.randn(1, 9, cd, generator=g)
     pp, npp, lat0 = torch.randn(1, 64, generator=g), torch.randn(1, 64, generator=g), torch.randn(1, 4, 8, 8, generator=g)
     pmx = rr.ref_pipeline("pipeline_stable_diffusion_xl", "pipelines.stable_diffusion_xl")
-    unet = _Bridge(UNet2DConditionModel(MINI_XL, U.synth_unet_params(MINI_XL, seed=1), _test_backend=Emulator()))
+    unet = _Bridge(on_emulator(UNet2DConditionModel, MINI_XL, U.synth_unet_params(MINI_XL, seed=1)))
     te2 = type("TextEncoder2", (), {"config": rr.FrozenConfig(projection_dim=64), "dtype": torch.float32})()
     pipe = pmx.StableDiffusionXLPipeline(vae=RC._FakeVAE(rr, scaling_factor=0.13025, force_upcast=False), text_encoder=None, text_encoder_2=te2,
                                          tokenizer=None, tokenizer_2=None, unet=unet,
@@ -340,7 +340,7 @@ def test_product_models_drop_into_the_reference_pipelines_call():
     pe, ne = torch.randn(1, 9, 64, generator=g), torch.randn(1, 9, 64, generator=g)
     pp, npp, lat0 = torch.randn(1, 64, generator=g), torch.randn(1, 64, generator=g), torch.randn(1, 4, 16, 16, generator=g)
     pm3 = rr.ref_pipeline("pipeline_stable_diffusion_3", "pipelines.stable_diffusion_3")
-    tr = _Bridge(SD3Transformer2DModel(MINI_SD3, R3.synth_sd3_params(MINI_SD3, seed=3), _test_backend=Emulator()))
+    tr = _Bridge(on_emulator(SD3Transformer2DModel, MINI_SD3, R3.synth_sd3_params(MINI_SD3, seed=3)))
     sched = rr.ref_module("scheduling_flow_match_euler_discrete", "schedulers").FlowMatchEulerDiscreteScheduler(shift=3.0)
     pipe = pm3.StableDiffusion3Pipeline(transformer=tr, scheduler=sched, vae=RC._FakeVAE(rr, scaling_factor=1.5305, shift_factor=0.0609), text_encoder=None,
                                         tokenizer=None, text_encoder_2=None, tokenizer_2=None, text_encoder_3=None, tokenizer_3=None)
@@ -355,7 +355,7 @@ def test_product_models_drop_into_the_reference_pipelines_call():
     pe, ne = torch.randn(2, 7, 64, generator=g), torch.randn(2, 7, 64, generator=g)
     image = torch.rand(1, 3, 32, 32, generator=g) * 2 - 1
     pmi = rr.ref_pipeline("pipeline_stable_diffusion_img2img")
-    unet = _Bridge(UNet2DConditionModel(TINY, U.synth_unet_params(TINY, seed=1), _test_backend=Emulator()))
+    unet = _Bridge(on_emulator(UNet2DConditionModel, TINY, U.synth_unet_params(TINY, seed=1)))
     pipe = pmi.StableDiffusionImg2ImgPipeline(vae=RC._ref_vae(rr, Pv), text_encoder=None, tokenizer=None, unet=unet,
                                               scheduler=rr.ref_module("scheduling_ddim", "schedulers").DDIMScheduler(clip_sample=False, set_alpha_to_one=False, **SD),
                                               safety_checker=None, feature_extractor=None, requires_safety_checker=False)
@@ -370,7 +370,7 @@ def test_product_models_drop_into_the_reference_pipelines_call():
     mask_px[:, :, 8:24, 12:32] = 0.9
     cfg9 = dict(TINY, in_channels=9)
     pmp = rr.ref_pipeline("pipeline_stable_diffusion_inpaint")
-    unet = _Bridge(UNet2DConditionModel(cfg9, U.synth_unet_params(cfg9, seed=77), _test_backend=Emulator()))
+    unet = _Bridge(on_emulator(UNet2DConditionModel, cfg9, U.synth_unet_params(cfg9, seed=77)))
     pipe = pmp.StableDiffusionInpaintPipeline(vae=RC._ref_vae(rr, Pv), text_encoder=None, tokenizer=None, unet=unet,
                                               scheduler=rr.ref_module("scheduling_euler_discrete", "schedulers").EulerDiscreteScheduler(timestep_spacing="leading", **SD),
                                               safety_checker=None, feature_extractor=None, requires_safety_checker=False)
@@ -387,7 +387,7 @@ def test_product_models_drop_into_the_reference_pipelines_call():
     cn = rr.ref_module("controlnet").ControlNetModel(**{k: v for k, v in TINY.items() if k not in ("up_block_types", "sample_size")})
     cn.eval()
     rr.load_params(cn, RC._synth(U.controlnet_param_shapes(TINY), 8))
-    unet = _Bridge(UNet2DConditionModel(TINY, U.synth_unet_params(TINY, seed=1), _test_backend=Emulator()))
+    unet = _Bridge(on_emulator(UNet2DConditionModel, TINY, U.synth_unet_params(TINY, seed=1)))
     pipe = pmc.StableDiffusionControlNetPipeline(vae=RC._FakeVAE(rr, scaling_factor=0.18215), text_encoder=None, tokenizer=None, unet=unet, controlnet=cn,
                                                  scheduler=rr.ref_module("scheduling_ddim", "schedulers").DDIMScheduler(clip_sample=False, set_alpha_to_one=False, **SD),
                                                  safety_checker=None, feature_extractor=None, requires_safety_checker=False)

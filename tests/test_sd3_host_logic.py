@@ -4,7 +4,7 @@ import torch
 
 from oracle import sd3_ref as R
 from paddlemix_amd.sd3 import SD3Transformer2DModel, sd3_param_shapes, synth_sd3_params
-from tests.abi_emulator import Emulator
+from tests.abi_emulator import Emulator, on_emulator
 from tests.configs import MINI_SD3, SD3_MEDIUM
 
 
@@ -25,7 +25,7 @@ def test_sd3_program_matches_oracle(B, H, W, L):
     Pb = {k: v.to(torch.bfloat16).float() if v.dim() > 1 else v for k, v in P.items()}
     x, enc, pooled = _inputs(cfg, B, H, W, L)
     ref = R.sd3_forward(Pb, cfg, x, enc, pooled, 501.0)
-    model = SD3Transformer2DModel(cfg, P, _test_backend=Emulator())
+    model = on_emulator(SD3Transformer2DModel, cfg, P)
     out = model(x, enc, pooled, 501.0, return_dict=False)[0]
     assert out.shape == ref.shape == x.shape and out.dtype == torch.float32
     assert _rel(out, ref) < 2e-2, _rel(out, ref)
@@ -47,10 +47,10 @@ def test_sd3_trained_adaln_continuous_bias_folds_into_the_modulation_rows():
     plain = R.sd3_forward(Pb, cfg, x, enc, pooled, 501.0)
     ref = R.sd3_forward({**Pb, **extra}, cfg, x, enc, pooled, 501.0)
     assert _rel(plain, ref) > 0.1                        # the biases matter
-    out = SD3Transformer2DModel(cfg, {**P, **extra}, _test_backend=Emulator())(x, enc, pooled, 501.0).sample
+    out = on_emulator(SD3Transformer2DModel, cfg, {**P, **extra})(x, enc, pooled, 501.0).sample
     assert _rel(out, ref) < 2e-2, _rel(out, ref)
-    zero = SD3Transformer2DModel(cfg, {**P, **{k: torch.zeros_like(v) for k, v in extra.items()}}, _test_backend=Emulator())(x, enc, pooled, 501.0).sample
-    assert torch.equal(zero, SD3Transformer2DModel(cfg, P, _test_backend=Emulator())(x, enc, pooled, 501.0).sample)
+    zero = on_emulator(SD3Transformer2DModel, cfg, {**P, **{k: torch.zeros_like(v) for k, v in extra.items()}})(x, enc, pooled, 501.0).sample
+    assert torch.equal(zero, on_emulator(SD3Transformer2DModel, cfg, P)(x, enc, pooled, 501.0).sample)
 
 
 def test_sd3_inventory_and_synth_match_oracle():
@@ -76,7 +76,7 @@ def test_sd3_fp8_weights_program_matches_oracle_on_dequantised_weights():
     cfg = MINI_SD3
     P = synth_sd3_params(cfg, seed=1234)
     x, enc, pooled = _inputs(cfg, 2, 16, 16, 10)
-    model = SD3Transformer2DModel(cfg, P, weight_dtype="fp8", _test_backend=Emulator())
+    model = on_emulator(SD3Transformer2DModel, cfg, P, weight_dtype="fp8")
     out = model(x, enc, pooled, 501.0).sample
     Pq = {}
     for k, v in P.items():
@@ -100,7 +100,7 @@ def test_sd3_w8a8_program_matches_fake_quant_oracle():
     P = synth_sd3_params(cfg, seed=1234)
     x, enc, pooled = _inputs(cfg, 2, 16, 16, 10)
     emu = Emulator()
-    model = SD3Transformer2DModel(cfg, P, weight_dtype="fp8", act_dtype="fp8", _test_backend=emu)
+    model = on_emulator(SD3Transformer2DModel, cfg, P, weight_dtype="fp8", act_dtype="fp8", backend=emu)
     out = model(x, enc, pooled, 501.0).sample
     assert "linear_f8" in emu.calls
     Pq = {}
@@ -115,4 +115,4 @@ def test_sd3_w8a8_program_matches_fake_quant_oracle():
     print("W8A8 total quantisation error vs fp32 weights/activations:", _rel(ref, R.sd3_forward(P, cfg, x, enc, pooled, 501.0)))
     import pytest
     with pytest.raises(ValueError):
-        SD3Transformer2DModel(cfg, P, act_dtype="fp8", _test_backend=Emulator())
+        on_emulator(SD3Transformer2DModel, cfg, P, act_dtype="fp8")

@@ -6,7 +6,7 @@ import torch
 from oracle import vae_ref as R
 from paddlemix_amd.vae import (AutoencoderKL, decoder_param_shapes, encoder_param_shapes, synth_decoder_params,
                                synth_vae_params)
-from tests.abi_emulator import Emulator
+from tests.abi_emulator import Emulator, on_emulator
 from tests.configs import MINI_VAE
 
 
@@ -29,9 +29,9 @@ def test_decode_program_matches_oracle(B, h, w):
     z = torch.randn(B, cfg["latent_channels"], h, w, generator=torch.Generator().manual_seed(1))
     if (h * w) % 8:
         with pytest.raises(ValueError):
-            AutoencoderKL(cfg, P, _test_backend=Emulator()).decode(z)
+            on_emulator(AutoencoderKL, cfg, P).decode(z)
         return
-    vae = AutoencoderKL(cfg, P, _test_backend=Emulator())
+    vae = on_emulator(AutoencoderKL, cfg, P)
     out = vae.decode(z).sample
     nl = len(cfg["block_out_channels"])
     assert out.shape == (B, 3, h << (nl - 1), w << (nl - 1)) and out.dtype == torch.float32
@@ -51,7 +51,7 @@ def test_no_post_quant_conv_and_errors():
     P = synth_decoder_params(cfg, seed=3)
     assert "post_quant_conv.weight" not in P
     z = torch.randn(1, 4, 4, 4, generator=torch.Generator().manual_seed(2))
-    vae = AutoencoderKL(cfg, P, _test_backend=Emulator())
+    vae = on_emulator(AutoencoderKL, cfg, P)
     Pr = {k: (v.to(torch.bfloat16).float() if v.dim() > 1 else v) for k, v in P.items()}
     assert _rel(vae.decode(z).sample, R.decode(Pr, cfg, z)) < 2e-2
     from paddlemix_amd._lib import MI355XError
@@ -64,7 +64,7 @@ def test_no_post_quant_conv_and_errors():
     bad = dict(P)
     bad.pop("decoder.conv_out.bias")
     with pytest.raises(KeyError):
-        AutoencoderKL(cfg, bad, _test_backend=Emulator())
+        on_emulator(AutoencoderKL, cfg, bad)
 
 
 def _bf(P):
@@ -87,7 +87,7 @@ def test_encode_program_matches_oracle(B, H, W):
     P = synth_vae_params(cfg, seed=9)
     g = torch.Generator().manual_seed(4)
     x = torch.rand(B, 3, H, W, generator=g) * 2 - 1
-    vae = AutoencoderKL(cfg, P, _test_backend=Emulator())
+    vae = on_emulator(AutoencoderKL, cfg, P)
     assert vae.has_encoder
     post = vae.encode(x).latent_dist
     n = len(cfg["block_out_channels"])
@@ -119,7 +119,7 @@ def test_encode_without_quant_conv_logvar_clip_and_errors():
     P["encoder.conv_out.bias"][4] = 50.0      # logvar channel 0 far above the clip
     P["encoder.conv_out.bias"][5] = -70.0     # channel 1 far below
     x = torch.rand(1, 3, 16, 16, generator=torch.Generator().manual_seed(1)) * 2 - 1
-    vae = AutoencoderKL(cfg, P, _test_backend=Emulator())
+    vae = on_emulator(AutoencoderKL, cfg, P)
     post = vae.encode(x).latent_dist
     mean, logvar, _ = R.encode(_bf(P), cfg, x)
     assert torch.all(post.logvar[:, 0] == 20.0) and torch.all(post.logvar[:, 1] == -30.0)
@@ -133,4 +133,4 @@ def test_encode_without_quant_conv_logvar_clip_and_errors():
     bad = dict(P)
     bad.pop("encoder.conv_norm_out.bias")
     with pytest.raises(KeyError):
-        AutoencoderKL(cfg, bad, _test_backend=Emulator())
+        on_emulator(AutoencoderKL, cfg, bad)
