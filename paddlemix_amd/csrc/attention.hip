@@ -159,11 +159,6 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? ((FL & 4) ? 3 : 2) : 1) v
   };
 
   const int ntiles = (p.Skv + KVBLK - 1) / KVBLK;
-  if (p.dbg & 16) {   // experiment: the blocks that share a CU (ids 256 apart under round-robin placement) start a third of a tile apart
-    const int ph = (blockIdx.x >> 8) % 3;
-    if (ph == 1) __builtin_amdgcn_s_sleep(8);
-    if (ph == 2) __builtin_amdgcn_s_sleep(16);
-  }
   load_q(qb * QT, qf);   // in flight together with the first K/V tile
   load_kv(0);
   store_kv(0);
@@ -187,7 +182,7 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? ((FL & 4) ? 3 : 2) : 1) v
   auto tile_body = [&](const int t, auto mask_tag) {
     constexpr bool MASK = decltype(mask_tag)::value;
     const int buf = (NBUF == 2) ? (t & 1) : 0;
-    if (NBUF == 2 && t + 1 < ntiles && stage_kv && !(p.dbg & 1)) load_kv((t + 1) * KVBLK);
+    if (NBUF == 2 && t + 1 < ntiles && stage_kv) load_kv((t + 1) * KVBLK);
     const unsigned char* ks_ = smem + buf * (L::KBYTES + L::VBYTES);
     const unsigned char* vs_ = ks_ + L::KBYTES;
 
@@ -244,7 +239,7 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? ((FL & 4) ? 3 : 2) : 1) v
     bool exact = true;
     float psum = 0.f;
     bf16x8 pf[4];
-    if (LAZY && t > 0 && !(p.dbg & 2)) {
+    if (LAZY && t > 0) {
       const float mc0 = m_run * c2;
 #pragma unroll
       for (int i = 0; i < 32; ++i) {
@@ -302,10 +297,6 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? ((FL & 4) ? 3 : 2) : 1) v
       }
       const float mc = LOG2 ? shift : m_run * c2;
       psum = 0.f;
-      if (p.dbg & 2) {   // ablation: no exp / conversions
-#pragma unroll
-        for (int i = 0; i < 4; ++i) pf[i] = bf16x8{};
-      } else
 #pragma unroll
       for (int sb = 0; sb < 2; ++sb) {
 #pragma unroll
@@ -319,7 +310,6 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? ((FL & 4) ? 3 : 2) : 1) v
     l_run += psum;
 
     // ---- O^T += V^T P^T ----
-    if (p.dbg & 4) __builtin_amdgcn_s_setprio(1);   // experiment: the matrix interval outranks the co-resident blocks' VALU work
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       // B-operand element i of pf[kk] is key kk*16 + (i&3) + 8*(i>>2) + 4*hi -> the A operand must match
@@ -332,10 +322,9 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? ((FL & 4) ? 3 : 2) : 1) v
         o[db] = mfma_32x32x16(vf, pf[kk], o[db]);
       }
     }
-    if (p.dbg & 4) __builtin_amdgcn_s_setprio(0);
 
     if (NBUF == 2) {
-      if (t + 1 < ntiles && stage_kv && !(p.dbg & 1)) store_kv(buf ^ 1);
+      if (t + 1 < ntiles && stage_kv) store_kv(buf ^ 1);
       __syncthreads();
     } else {
       __syncthreads();
@@ -583,25 +572,12 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_short_kernel(const A
   }
 }
 
-// lazy row maximum: MI355X_SD_ATTN_LAZY=0 turns it off (default on: profiles/r02_attention.txt)
-static bool attn_lazy() {
-  static const bool dyn = getenv("MI355X_SD_ATTN_DYN") != nullptr;   // probes flip the variable between launches
-  static int cached = -1;
-  if (cached < 0 || dyn) {
-    const char* e = getenv("MI355X_SD_ATTN_LAZY");
-    cached = e ? (atoi(e) != 0) : ATTN_LAZY_DEFAULT;
-  }
-  return cached != 0;
-}
+// lazy row maximum (on: profiles/r02_attention.txt)
+static bool attn_lazy() { return ATTN_LAZY_DEFAULT != 0; }
 
 template <int DP>
 static int launch_dp(const AttnArgs& a0, hipStream_t stream) {
-  static const int dbg = [] {
-    const char* e = getenv("MI355X_SD_ATTN_DBG");
-    return e ? atoi(e) : 0;
-  }();
-  AttnArgs a = a0;
-  a.dbg = dbg;
+  const AttnArgs& a = a0;
   // lazy only where it costs no occupancy step: the d <= 64 kernel without mask (158 / 168 VGPRs: still 3 waves per SIMD)
   const bool lazy = DP == 64 && !a.bias && (attn_lazy() || a.log2);
   if (a.log2 && (DP != 64 || a.bias)) return SD_ERR_UNSUPPORTED;
@@ -613,12 +589,10 @@ static int launch_dp(const AttnArgs& a0, hipStream_t stream) {
   if (DP == 64 && a.D == 64 && a.Skv <= 128 && !a.bias && a.accum == 0.f && !no_short && !(a.o_ts & 7) && !(a.o_bs & 7) &&
       !(reinterpret_cast<uintptr_t>(a.O) & 15)) {
     const int ntq = (a.Sq + QBLK - 1) / QBLK;
-    // query tiles per block: ONE. Measured per launch at 8x20x1024x77 / 8x10x4096x77 (profiles/r03_s5_attn.txt): 1 / 2 / 4 / 8 tiles
+    // query tiles per block: ONE. Measured per launch at 8x20x1024x77 / 8x10x4096x77 (profiles/r03_s5_attn_short.txt): 1 / 2 / 4 / 8 tiles
     // per block = 14.8 / 15.2 / 17.1 / 19.5 us and 21.3 / 22.3 / 22.5 / 26.3 us (flash kernel: 21.2 / 31.6 us) -- re-staging 20 KB
     // of L2-resident K / V per tile costs less than the parallelism lost to longer blocks
-    int qtpb = 1;
-    static const int qt_forced = [] { const char* e = getenv("MI355X_SD_ATTN_SHORT_QT"); return e ? atoi(e) : 0; }();
-    if (qt_forced > 0) qtpb = qt_forced;
+    const int qtpb = 1;
     const int nqb = (ntq + qtpb - 1) / qtpb;
     dim3 grid(nqb * a.B * a.H), block(ATT_THREADS);
     const int nsb = (a.Skv + 31) / 32;

@@ -330,26 +330,15 @@ static int pick_tile_model(const GemmArgs& a) {
     const long per_cu = (tiles + 255) / 256;
     double cost = (double)per_cu * (c.bm + c.bn);
     if (c.id == 128) cost *= 0.95;   // two co-resident blocks hide each other's prologue / epilogue
-    // Short-K plain GEMMs (K <= 1536, no GEGLU, not a conv): the 256x160 tile is the best or within 2 % of the best of the five
-    // families on every such shape of the SDXL and SD3 steps (profiles/r03_s8_tile_sweep.txt: fused QKV 104.1 vs 105.8 us on
-    // 256x256 and 119.6 on 256x320, the 640-wide out-projections 50.1 vs 53.8, 32768 x 1920 x 640 125.0 vs 132.8, SD3's
-    // 32768 x 1536 x 1536 + R 175.0 vs 199.3) although the bytes-per-CU model below ranks the larger tiles first: its rounds are
-    // exact multiples of the chip there, its residual arrives early (gemm_pipe_pre_kernel), and with 20-24 K-tiles per output
-    // tile the per-tile fixed costs weigh as much as the loop. Long K keeps the model's choice (FF2 at K = 5120 / 6144, every conv).
-    static const double p160 = [] {   // MI355X_SD_GEMM_P160: the short-K weight of the 256x160 tile (A/B measurements inside the step)
-      const char* e = getenv("MI355X_SD_GEMM_P160");
-      return e ? atof(e) : 0.6;
-    }();
-    static const int k160 = [] {   // MI355X_SD_GEMM_K160: largest K the weight applies to (round 3: 1536; A/B switch)
-      const char* e = getenv("MI355X_SD_GEMM_K160");
-      return e ? atoi(e) : (1 << 30);
-    }();
-    if (c.id == 160 && !a.conv && !a.geglu && a.K <= k160 && !a.wscale && !a.rowstat && !a.a_rpb && !a.c_rpb) cost *= p160;   // (measured forms only)
-    static const double p257 = [] {   // MI355X_SD_GEMM_P257: re-weights the phased 256x256 kernel (A/B measurements)
-      const char* e = getenv("MI355X_SD_GEMM_P257");
-      return e ? atof(e) : 1.0;
-    }();
-    if (c.id == 257) cost *= p257;
+    // Plain GEMMs (no GEGLU, not a conv) prefer the 256x160 tile although the bytes-per-CU model below ranks the larger tiles
+    // first: its rounds are exact multiples of the chip on the SDXL / SD3 widths, its residual arrives early
+    // (gemm_pipe_pre_kernel), and since round 4 it runs the interleaved loop (gemm_pipe.hip). Measured INSIDE the step with every
+    // launch forced onto each family in turn (profiles/r04_s2_step_shapes_ab.txt, ms per step, 160 / 257 / 320): to_out
+    // 8192x1280x1280 7.04 / 10.86 / 11.80, fused QKV 5.70 / 5.94 / 6.93, FF2 (K = 5120) 5.29 / 8.28 / 9.10, 32768x640x2560 1.01 /
+    // 1.66 / 1.09, 32768x1920x640 1.24 / 1.37 / 1.28, the all-layer cross-attention K/V projection 616x166400x2048 0.48 / 0.50 /
+    // 0.51. Round 3 applied the weight for K <= 1536 only: +0.3 ms per step (r04_s3_step_ab.txt). GEGLU launches cannot take the
+    // tile (odd number of sub-tiles per wave); the convs keep the model's choice (forced onto 160 they lose 0.35 ms per step).
+    if (c.id == 160 && !a.conv && !a.geglu && !a.wscale && !a.rowstat && !a.a_rpb && !a.c_rpb) cost *= 0.6;   // (measured forms only)
     if (cost < best_cost) {
       best_cost = cost;
       best = c.id;
@@ -363,14 +352,7 @@ static int pick_tile_model(const GemmArgs& a) {
 // 60.37 / 60.47. Column groups of 4: an XCD's concurrently running tiles keep the same 4 W column-panels (the small operand)
 // hot in its L2 while the A row-panels stream through once.
 constexpr int GEMM_GM_DEFAULT = -4;
-int gemm_gm() {
-  static const int v = [] {
-    const char* e = getenv("MI355X_SD_GEMM_GM");   // experiments only
-    const int n = e ? atoi(e) : 0;
-    return (n != 0 && n >= -64 && n <= 64) ? n : GEMM_GM_DEFAULT;
-  }();
-  return v;
-}
+int gemm_gm() { return GEMM_GM_DEFAULT; }
 
 int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
   GemmArgs a = a_in;

@@ -121,7 +121,6 @@ __global__ __launch_bounds__(g256::THREADS, 2) void gemm256_kernel(const GemmArg
   }
 
   auto issue_A = [&](const int h, int buf) {
-    if (p.dbg & 2) return;   // ablation: no DMA
     unsigned char* dst = smem + buf * BUF + h * HALF + wave * 2048;
     if (CONV) {
       const int ky = tapA[h] / 3, kx = tapA[h] - ky * 3;
@@ -146,7 +145,6 @@ __global__ __launch_bounds__(g256::THREADS, 2) void gemm256_kernel(const GemmArg
     kA[h] += KT;
   };
   auto issue_B = [&](const int h, int buf) {
-    if (p.dbg & 2) return;
     unsigned char* dst = smem + buf * BUF + (2 + h) * HALF + wave * 2048;
     const int soff = (kB[h] < p.K) ? kB[h] * ES : (int)0x7FFFFFF0;
 #pragma unroll
@@ -172,7 +170,6 @@ __global__ __launch_bounds__(g256::THREADS, 2) void gemm256_kernel(const GemmArg
   for (int i = 0; i < 4; ++i) fa[i][0] = fa[i][1] = fb[i][0] = fb[i][1] = bf16x8{};
 
   auto read_A = [&](const unsigned char* base, const int s) {
-    if (p.dbg & 4) return;   // ablation: no LDS fragment reads
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       const unsigned char* r = base + a_off + (s * 64 + mt * 16) * 128;
@@ -181,7 +178,6 @@ __global__ __launch_bounds__(g256::THREADS, 2) void gemm256_kernel(const GemmArg
     }
   };
   auto read_B = [&](const unsigned char* base) {
-    if (p.dbg & 4) return;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       const unsigned char* r = base + b_off + nt * 16 * 128;
@@ -190,13 +186,6 @@ __global__ __launch_bounds__(g256::THREADS, 2) void gemm256_kernel(const GemmArg
     }
   };
   auto mma = [&](const int s, const int j) {   // quadrant: A rows s*64.., B cols j*32..
-    if (p.dbg & 1) {   // ablation: no MFMAs (fragments kept live)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        asm volatile("" ::"v"(fa[i][0]), "v"(fa[i][1]), "v"(fb[i][0]), "v"(fb[i][1]));
-      }
-      return;
-    }
     __builtin_amdgcn_s_setprio(1);
     if constexpr (F8) {
 #pragma unroll
@@ -286,12 +275,7 @@ int launch_gemm256(const GemmArgs& a, hipStream_t stream) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
   }();
   if (!attr_ok) return SD_ERR_HIP;
-  static const int dbg = [] {
-    const char* e = getenv("MI355X_SD_GEMM_DBG");
-    return e ? atoi(e) : 0;
-  }();
-  GemmArgs b = a;
-  b.dbg = dbg;
+  const GemmArgs& b = a;
   const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
   if (a.ascale)   // W8A8: fp8 e4m3 operands (launch_gemm_f8 validated the arguments)
     hipLaunchKernelGGL((gemm256_kernel<false, false, true>), dim3(ntm * ntn), dim3(THREADS), LDS_BYTES, stream, b);

@@ -1,4 +1,4 @@
-// Tile configurations shared by the GEMM kernels (gemm.hip: generic loop; gemm_pipe.hip: software-pipelined loop).
+// Tile configurations shared by the GEMM kernels (gemm.hip: generic loop; gemm_pipe.hip: software-pipelined loops).
 #pragma once
 #include "common.h"
 
@@ -27,7 +27,7 @@ using Cfg256x320 = GemmCfg<2, 4, 8, 5>;   // 256 x 320: N = 640 -> 2 column tile
 using Cfg256x320g = GemmCfg<4, 2, 4, 10>; // 256 x 320 with an even tile count per wave (GEGLU value/gate pairs)
 // a four-wave tile sized for TWO co-resident blocks per CU (<= 80 KiB of LDS, <= 256 VGPRs): while one block sits in its prologue,
 // barrier or epilogue the other one's waves feed the matrix pipe from the same SIMDs. Round 3 measured three of them per shape
-// (profiles/r03_s3_variants.txt): 160 x 160 (80 x 80 per wave) and 192 x 128 (96 x 64) lose everywhere (FF1 921 vs 1069 TFLOP/s,
+// (profiles/r03_s3_gemm_variants_tiles.txt): 160 x 160 (80 x 80 per wave) and 192 x 128 (96 x 64) lose everywhere (FF1 921 vs 1069 TFLOP/s,
 // to_out 580 vs 756) and are gone; 128 x 160 ties the eight-wave 256 x 160 tile on the K = 1280 projections and wins a few
 // 640-wide launches
 using Cfg128x160 = GemmCfg<2, 2, 4, 5>;   // 128 x 160: the 8-wave 256 x 160 tile cut in two, 2 x 36 KiB
@@ -36,17 +36,6 @@ using Cfg128x160 = GemmCfg<2, 2, 4, 5>;   // 128 x 160: the 8-wave 256 x 160 til
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_imm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the immediate is 6 bits; a smaller count is only stricter)
-__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
-#define SD_VMW(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-  switch (n) {
-    SD_VMW(0) SD_VMW(1) SD_VMW(2) SD_VMW(3) SD_VMW(4) SD_VMW(5) SD_VMW(6) SD_VMW(7) SD_VMW(8) SD_VMW(9) SD_VMW(10) SD_VMW(11)
-    SD_VMW(12) SD_VMW(13) SD_VMW(14) SD_VMW(15) SD_VMW(16) SD_VMW(17) SD_VMW(18) SD_VMW(19) SD_VMW(20) SD_VMW(21) SD_VMW(22) SD_VMW(23)
-    default: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
-  }
-#undef SD_VMW
 }
 
 // Candidate tile ids of pick_tile (gemm.hip)

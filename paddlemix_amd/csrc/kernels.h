@@ -50,7 +50,6 @@ struct GemmArgs {
   const float* wsum;      //   wsum[n] = sum_k W[n][k]: acc <- rstd[m]*acc - mean[m]*rstd[m]*wsum[n]   (before bias)
   int c_rpb;              // same remap for the C rows (joint text+image token buffers of the MMDiT attention)
   long c_bstride;
-  int dbg;                // ablation switches of gemm256.hip (MI355X_SD_GEMM_DBG; 0 in production)
   unsigned long long* ts; // diagnostics (scripts/gemm_timeline.py, MI355X_SD_GEMM_TSTAMP=<device address>): per block 4 x 100-MHz
                           // wall-clock stamps (entry, first tile landed, K loop done, stores issued) + (XCC id, block id); NULL in production
   int gm;                 // tile rasterisation group (common.h tile_coords): set by the launchers (gemm_gm())
@@ -82,7 +81,6 @@ struct AttnArgs {
   float scale;
   float accum;   // != 0: O += accum * attention(...) instead of O = attention(...) (IP-Adapter's second key set)
   int log2;      // MI355X_SD_SDPA_LOG2: q already carries scale * log2(e) -- scores are base-2 exponents (D == 64, no mask)
-  int dbg;   // ablation switches (MI355X_SD_ATTN_DBG; 0 in production)
 };
 int launch_attention(const AttnArgs& a, hipStream_t stream);
 

@@ -493,23 +493,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
 // that waves walking 2-4 row groups beat one group per wave (scripts/ln_probe.py: 8192 x 1280 15.7 -> 13.6 us at 256 blocks) and
 // used div = 2; inside the SDXL step, and with the per-wave prologue now 12 vector loads instead of 48 branches, one trip per
 // wave wins (LayerNorm class 3.07 -> 2.79 ms per step, profiles/r02_k_ln_grid.txt): div = 1, at most 1024 blocks.
-// MI355X_SD_LN_GRID="div,min,max" overrides the three constants (experiments only).
 static int ln_grid(int rows, int rows_per_block) {
-  static int cfg[3] = {0, 0, 0};
-  if (!cfg[0]) {
-    int d = 1, lo = 256, hi = 1024;
-    if (const char* e = getenv("MI355X_SD_LN_GRID")) {
-      int a = 0, b = 0, c = 0;
-      if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a > 0 && b > 0 && c >= b) { d = a; lo = b; hi = c; }
-    }
-    cfg[1] = lo;
-    cfg[2] = hi;
-    cfg[0] = d;
-  }
+  constexpr int lo = 256, hi = 1024;   // (div = 1)
   const int needed = (rows + rows_per_block - 1) / rows_per_block;
-  int blocks = needed / cfg[0];
-  if (blocks < cfg[1]) blocks = cfg[1];
-  if (blocks > cfg[2]) blocks = cfg[2];
+  int blocks = needed;
+  if (blocks < lo) blocks = lo;
+  if (blocks > hi) blocks = hi;
   return blocks < needed ? blocks : needed;
 }
 
@@ -521,26 +510,17 @@ int launch_layernorm(const void* x, int x_f32, int rows, int C, int ldx, const f
   const int cv = C >> 3;
   // rows per wave: round 1 measured 4 better than 2 (4.6 vs 5.2 ms per SDXL step) when every wave paid a 48-branch prologue; with
   // the vector prologue and one trip per wave, 2 rows (twice the waves, ~110 instead of 200 registers) is ahead again: class
-  // 2.80 -> 2.65 ms per step (profiles/r02_l_norm_knobs.txt). MI355X_SD_LN_ROWS=4 selects the old shape (experiments only).
-  constexpr int R = 4;
-  static int rows_env = -1;
-  if (rows_env < 0) {
-    const char* e = getenv("MI355X_SD_LN_ROWS");
-    rows_env = (e && atoi(e) == 4) ? 4 : 2;
-  }
-  const int blocks = ln_grid(rows, wpb * (cv <= 192 ? rows_env : 2));
+  // 2.80 -> 2.65 ms per step (profiles/r02_l_norm_knobs.txt).
+  const int blocks = ln_grid(rows, wpb * 2);
 #define SD_LN_LAUNCH(NCH, R_, F_) \
   hipLaunchKernelGGL((layernorm_kernel<NCH, R_, F_>), dim3(blocks), dim3(64 * wpb), 0, stream, x, rows, C, ldx, gamma, beta, eps, y, ldy)
-  if (rows_env == 2 && cv <= 192) {
-    if (x_f32) { if (cv <= 128) SD_LN_LAUNCH(2, 2, true); else SD_LN_LAUNCH(3, 2, true); }
-    else       { if (cv <= 128) SD_LN_LAUNCH(2, 2, false); else SD_LN_LAUNCH(3, 2, false); }
-  } else if (x_f32) {
-    if (cv <= 128) SD_LN_LAUNCH(2, R, true);
-    else if (cv <= 192) SD_LN_LAUNCH(3, R, true);
+  if (x_f32) {
+    if (cv <= 128) SD_LN_LAUNCH(2, 2, true);
+    else if (cv <= 192) SD_LN_LAUNCH(3, 2, true);
     else SD_LN_LAUNCH(5, 2, true);
   } else {
-    if (cv <= 128) SD_LN_LAUNCH(2, R, false);
-    else if (cv <= 192) SD_LN_LAUNCH(3, R, false);
+    if (cv <= 128) SD_LN_LAUNCH(2, 2, false);
+    else if (cv <= 192) SD_LN_LAUNCH(3, 2, false);
     else SD_LN_LAUNCH(5, 2, false);
   }
 #undef SD_LN_LAUNCH

@@ -530,7 +530,7 @@ struct Packer {
   void put_conv(const std::string& key, const std::string& name) {
     const HostT& t = get(name + ".weight");
     const int O = (int)t.shape[0], I = (int)t.shape[1], kh = (int)t.shape[2], kw = (int)t.shape[3];
-    const bool kb64 = kh == 3 && (I % 64) == 0 && !getenv("MI355X_SD_NO_KB64");
+    const bool kb64 = kh == 3 && (I % 64) == 0;
     if (kb64) e.kb64.insert(key);
     uint16_t* d = m16(key + ".w", O, kh * kw * I);
     for (int o = 0; o < O; ++o)

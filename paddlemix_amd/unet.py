@@ -365,7 +365,7 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
         def put_conv(key, name):  # OIHW -> [O][kh][kw][I]; 3x3 with Cin % 64 == 0 -> [O][I/64][kh][kw][64] (MI355X_SD_CONV_KB64)
             w = get(name + ".weight")
             O, I, kh, kw = w.shape
-            if kh == 3 and I % 64 == 0 and not os.environ.get("MI355X_SD_NO_KB64"):
+            if kh == 3 and I % 64 == 0:
                 W[key + ".w"] = bf(w.reshape(O, I // 64, 64, kh, kw).permute(0, 1, 3, 4, 2).reshape(O, -1))
                 self._kb64.add(key)
             else:
