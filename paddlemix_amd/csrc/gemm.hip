@@ -254,7 +254,7 @@ void set_workspace(void* ptr, size_t bytes) {
 static void plan_splitk(GemmArgs& a, int bm, int bn) {
   a.splitk = 0;
   static const bool off = getenv("MI355X_SD_NO_SPLITK") != nullptr;
-  if (!g_ws || off) return;
+  if (!g_ws || off || a.w16) return;   // (a widened fp8 matrix occupies the workspace)
   const long tiles = (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn);
   const int nt = (a.K + BK - 1) / BK;
   if (tiles > 128 || nt < 8) return;
@@ -289,6 +289,7 @@ static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
 // i.e. prefer the largest tile that still gives every CU work and leaves no mostly-empty last round.
 // MI355X_SD_GEMM_TILE forces a configuration for A/B measurements: 128 | 256 | 257 (phased 256x256) | 160 | 320.
 struct TileChoice { int id, bm, bn; };
+static inline bool w_is_f8(const GemmArgs& a) { return a.wscale && !a.w16; }   // the kernel itself reads e4m3 weight bytes
 static int pick_tile_model(const GemmArgs& a);
 static int pick_tile(const GemmArgs& a) {
   static const int forced = [] {
@@ -323,9 +324,9 @@ static int pick_tile_model(const GemmArgs& a) {
   int best = 128;
   double best_cost = 1e30;
   for (const TileChoice& c : cand) {
-    if (c.id == 257 && ((a.K & 63) || (a.conv && (a.Cin & 63)) || !wide_ok || a.a_rpb || a.wscale)) continue;
+    if (c.id == 257 && ((a.K & 63) || (a.conv && (a.Cin & 63)) || !wide_ok || a.a_rpb || a.wscale)) continue;   // (its epilogue set has no weight scale)
     if (a.geglu && c.id == 160) continue;   // odd number of 16-column tiles per wave
-    if (c.id == 256 && !a.wscale && !a.a_rpb) continue;   // the plain 256x256 loop only where the phased kernel cannot run
+    if (c.id == 256 && !w_is_f8(a) && !a.a_rpb) continue;   // the plain 256x256 loop only where the phased kernel cannot run
     const long tiles = (long)((a.M + c.bm - 1) / c.bm) * ((a.N + c.bn - 1) / c.bn);
     const long per_cu = (tiles + 255) / 256;
     double cost = (double)per_cu * (c.bm + c.bn);
@@ -338,7 +339,7 @@ static int pick_tile_model(const GemmArgs& a) {
     // 1.66 / 1.09, 32768x1920x640 1.24 / 1.37 / 1.28, the all-layer cross-attention K/V projection 616x166400x2048 0.48 / 0.50 /
     // 0.51. Round 3 applied the weight for K <= 1536 only: +0.3 ms per step (r04_s3_step_ab.txt). GEGLU launches cannot take the
     // tile (odd number of sub-tiles per wave); the convs keep the model's choice (forced onto 160 they lose 0.35 ms per step).
-    if (c.id == 160 && !a.conv && !a.geglu && !a.wscale && !a.rowstat && !a.a_rpb && !a.c_rpb) cost *= 0.6;   // (measured forms only)
+    if (c.id == 160 && !a.conv && !a.geglu && !w_is_f8(a) && !a.rowstat && !a.a_rpb && !a.c_rpb) cost *= 0.6;   // (measured forms only)
     if (cost < best_cost) {
       best_cost = cost;
       best = c.id;
@@ -354,7 +355,40 @@ static int pick_tile_model(const GemmArgs& a) {
 constexpr int GEMM_GM_DEFAULT = -4;
 int gemm_gm() { return GEMM_GM_DEFAULT; }
 
+// Weight-only fp8 on the pipelined loops (round 4; BASELINE config 5). The generic loop widens e4m3 weight bytes to 16 bits in its
+// fragment load (8 VALU conversions per fragment next to the MFMAs) and was slower than the same model with 16-bit weights --
+// 12.1 vs 13.2 steps/s on SD3-medium bs 8 (profiles/r03_f_bench_sd3_bs8{,_fp8w}.json): the large-M GEMMs are not weight-bound.
+// Large launches now widen the matrix ONCE, just in time, into the caller's workspace (exact: every e4m3 value is a bf16 / fp16
+// value; the per-channel scale stays in the epilogue) and run the 16-bit kernels on it: N x K bytes read + 2 N K written, ~1 % of
+// such a launch, same bits as the in-fragment conversion (same products, same K order). HBM keeps holding one byte per weight.
+// Small-M launches (the 1232-row context stream at bs 8, anything that takes split-K slices) ARE weight-bound and stay on the
+// generic fp8 loop, whose split-K partial sums own the workspace.
+__global__ __launch_bounds__(256) void widen_fp8_kernel(const unsigned* __restrict__ w8, u32x2* __restrict__ w16, long n4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const unsigned raw = w8[i];
+    const auto f0 = __builtin_amdgcn_cvt_pk_f32_fp8(raw, false), f1 = __builtin_amdgcn_cvt_pk_f32_fp8(raw, true);
+    w16[i] = u32x2{pack_bf16(f0[0], f0[1]), pack_bf16(f1[0], f1[1])};
+  }
+}
+static bool widen_fp8_applies(const GemmArgs& a) {
+  static const bool off = getenv("MI355X_SD_NO_WIDEN_F8") != nullptr;   // A/B switch (tests/test_gpu_switches.py: same bits)
+  if (off) return false;
+  if (!a.wscale || a.w16 || !g_ws || a.conv || a.rowstat || (a.K & 63) || (a.N & 3)) return false;
+  if ((size_t)a.N * a.K * 2 > g_ws_bytes || (reinterpret_cast<uintptr_t>(a.W) & 3)) return false;
+  const long tiles = (long)((a.M + 255) / 256) * ((a.N + 159) / 160);
+  return tiles > 128;   // (launches of <= 128 tiles may take split-K slices: plan_splitk)
+}
+
 int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
+  if (widen_fp8_applies(a_in)) {
+    const long n4 = (long)a_in.N * a_in.K / 4;
+    hipLaunchKernelGGL(widen_fp8_kernel, dim3((unsigned)std::min<long>((n4 + 255) / 256, 4096)), dim3(256), 0, stream,
+                       reinterpret_cast<const unsigned*>(a_in.W), reinterpret_cast<u32x2*>(g_ws), n4);
+    GemmArgs b = a_in;
+    b.W = reinterpret_cast<const bf16*>(g_ws);
+    b.w16 = 1;
+    return launch_gemm(b, stream);
+  }
   GemmArgs a = a_in;
   a.splitk = 0;
   a.gm = gemm_gm();
@@ -397,7 +431,7 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
                                     : launch_cfg<false, Cfg256x320, false, true>(a, stream);
     return launch_cfg<false, Cfg128, false, true>(a, stream);
   }
-  if (a.wscale) {   // fp8 weights: generic configurations only
+  if (w_is_f8(a)) {   // fp8 weight bytes read by the kernel: generic configurations only
     if (a.conv || (a.K & 15)) return SD_ERR_UNSUPPORTED;
     if (tile == 160 && !a.geglu) return launch_cfg<false, Cfg256x160, true>(a, stream);
     if (tile == 320) return a.geglu ? launch_cfg<false, Cfg256x320g, true>(a, stream) : launch_cfg<false, Cfg256x320, true>(a, stream);

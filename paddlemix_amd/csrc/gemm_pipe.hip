@@ -575,7 +575,7 @@ int launch_gemm_pipe(const GemmArgs& a_in, int tile, void* stream_) {
   static const bool bias_acc_off = getenv("MI355X_SD_GEMM_NO_BIAS_ACC") != nullptr;   // A/B switch
   a.bias_acc = (a.bias && !a.wscale && a.splitk <= 1 && !a.rowstat && !bias_acc_off) ? 1 : 0;
   static const bool off = getenv("MI355X_SD_NO_PIPE") != nullptr;     // every launch on the generic loop of gemm.hip (the variant test's reference)
-  if (off || a.wscale || (a.K & 63) || (tile == 160 && a.geglu)) return SD_ERR_UNSUPPORTED;
+  if (off || (a.wscale && !a.w16) || (a.K & 63) || (tile == 160 && a.geglu)) return SD_ERR_UNSUPPORTED;   // (e4m3 weight bytes: gemm.hip)
   if (tile == 320 && a.conv && a.geglu) return SD_ERR_UNSUPPORTED;
   // 256x256: the phased kernel (gemm256.hip) stays the default where it can run (id 257); id 256 is what pick_tile
   // returns when it cannot (A row remap of the MMDiT output projections) and takes the pipelined loop here

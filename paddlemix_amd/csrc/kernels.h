@@ -38,6 +38,7 @@ struct GemmArgs {
   int a_rpb;              // A row m lives at (m / a_rpb) * a_bstride + (m % a_rpb) * lda   (0: plain m * lda)
   long a_bstride;
   const float* wscale;    // W is fp8 e4m3 [N][K] (1 byte / element) with per-output-channel scale: acc *= wscale[n]
+  int w16;                // set by launch_gemm: W was widened to the 16-bit element type just in time (wscale still applies)
   // W8A8 with an e4m3 OUTPUT (ff.net.0 -> ff.net.2): row scale from the Cauchy-Schwarz bound |out[m][n]| <= a_l2[m] *
   // w_norm_max + bias_abs_max (no second pass over the row); C is bytes, oscale[m] receives the scale
   int c_wide;             // C rows allow 16-byte stores (set by launch_gemm / launch_gemm_f8)
