@@ -425,7 +425,8 @@ def main():
             cpu_s = time.perf_counter() - t0
         res["cpu_baseline"] = {
             "value": 1.0 / (cpu_s * B), "unit": "steps/s", "cores": threads, "kind": "port",
-            "sample": f"torch-CPU fp32 restatement of ppdiffusers (Paddle unavailable): 1 UNet forward of 1 of the step's {B} "
+            "sample": f"torch-CPU fp32 restatement of ppdiffusers (Paddle unavailable; plain-math attention as the reference's CPU path "
+                      f"computes it, torch's CPU GEMMs underneath): 1 UNet forward of 1 of the step's {B} "
                       f"prompts at the full {H}x{W} latents, {cpu_s:.2f} s on {threads} threads; a step is {B} such forwards "
                       f"(prompts do not interact), value = 1 / ({B} x {cpu_s:.2f} s)",
         }

@@ -360,7 +360,8 @@ int gemm_gm() { return GEMM_GM_DEFAULT; }
 // 12.1 vs 13.2 steps/s on SD3-medium bs 8 (profiles/r03_f_bench_sd3_bs8{,_fp8w}.json): the large-M GEMMs are not weight-bound.
 // Large launches now widen the matrix ONCE, just in time, into the caller's workspace (exact: every e4m3 value is a bf16 / fp16
 // value; the per-channel scale stays in the epilogue) and run the 16-bit kernels on it: N x K bytes read + 2 N K written, ~1 % of
-// such a launch, same bits as the in-fragment conversion (same products, same K order). HBM keeps holding one byte per weight.
+// such a launch, the same products in the same K order as the in-fragment conversion (the bias then starts the accumulators as
+// bias / scale instead of being added after the scale: equal to fp32 rounding). HBM keeps holding one byte per weight.
 // Small-M launches (the 1232-row context stream at bs 8, anything that takes split-K slices) ARE weight-bound and stay on the
 // generic fp8 loop, whose split-K partial sums own the workspace.
 __global__ __launch_bounds__(256) void widen_fp8_kernel(const unsigned* __restrict__ w8, u32x2* __restrict__ w16, long n4) {
@@ -376,7 +377,9 @@ static bool widen_fp8_applies(const GemmArgs& a) {
   if (!a.wscale || a.w16 || !g_ws || a.conv || a.rowstat || (a.K & 63) || (a.N & 3)) return false;
   if ((size_t)a.N * a.K * 2 > g_ws_bytes || (reinterpret_cast<uintptr_t>(a.W) & 3)) return false;
   const long tiles = (long)((a.M + 255) / 256) * ((a.N + 159) / 160);
-  return tiles > 128;   // (launches of <= 128 tiles may take split-K slices: plan_splitk)
+  // (launches of <= 128 tiles may take split-K slices: plan_splitk. M >= 4096: below that -- the 1232-row context stream of SD3 at
+  // bs 8 -- a launch is about as long as the widening pass itself and reads the matrix once either way)
+  return tiles > 128 && a.M >= 4096;
 }
 
 int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
@@ -416,6 +419,12 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
   a.epi_batch = epi_batch_off ? 0 : 1;
   a.bias_acc = 0;   // launch_gemm_pipe decides
   const int tile = pick_tile(a);
+  // Column groups by tile width (round 4). An XCD runs 32 consecutive tile ids per round = 32/g row-tiles x g column-tiles; what
+  // its L2 pulls through the fabric per round is (32/g) A row-panels + g W column-panels, minimal at g = sqrt(32 BM / BN): 7.2 for
+  // the 256x160 tile, 5.1 for 256x320. Round 2 measured g = 4 and 8 inside the step (one g for every tile family) as equal in time
+  // (60.37 / 60.47 ms); the 160-wide launches -- fused QKV walks 24 column tiles -- take 8: their A panels come through the fabric
+  // 3 instead of 6 times (the counter traffic of the class, not its time: the loop does not wait for L2).
+  if (tile == 160 || tile == 129) a.gm = -8;
   if (tile == 128) plan_splitk(a, 128, 128);
   if (a.rowstat && (a.conv || a.wscale || a.a_rpb || a.c_rpb || a.R || a.rowbias || a.gate || !a.wsum))
     return SD_ERR_UNSUPPORTED;

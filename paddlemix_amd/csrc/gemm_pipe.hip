@@ -211,8 +211,13 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& p) {
   f32x4 bias4[TN];
   if (!LN && p.bias_acc) {
 #pragma unroll
-    for (int i = 0; i < TN; ++i)
-      bias4[i] = *reinterpret_cast<const f32x4*>(p.bias + min(n0 + wn * (TN * 16) + acc_col<TN>(i, lane >> 4, p.geglu), p.N - 4));
+    for (int i = 0; i < TN; ++i) {
+      const int nb = min(n0 + wn * (TN * 16) + acc_col<TN>(i, lane >> 4, p.geglu), p.N - 4);
+      bias4[i] = *reinterpret_cast<const f32x4*>(p.bias + nb);
+      // (weight-only fp8 on a widened matrix: the epilogue multiplies the accumulators by the channel's weight scale, so the
+      // initial value is bias / scale -- fp32, the scale is absmax / 448 > 0)
+      if (p.wscale) bias4[i] /= *reinterpret_cast<const f32x4*>(p.wscale + nb);
+    }
   } else {
 #pragma unroll
     for (int i = 0; i < TN; ++i) bias4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -573,7 +578,7 @@ int launch_gemm_pipe(const GemmArgs& a_in, int tile, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   GemmArgs a = a_in;
   static const bool bias_acc_off = getenv("MI355X_SD_GEMM_NO_BIAS_ACC") != nullptr;   // A/B switch
-  a.bias_acc = (a.bias && !a.wscale && a.splitk <= 1 && !a.rowstat && !bias_acc_off) ? 1 : 0;
+  a.bias_acc = (a.bias && (!a.wscale || a.w16) && a.splitk <= 1 && !a.rowstat && !bias_acc_off) ? 1 : 0;
   static const bool off = getenv("MI355X_SD_NO_PIPE") != nullptr;     // every launch on the generic loop of gemm.hip (the variant test's reference)
   if (off || (a.wscale && !a.w16) || (a.K & 63) || (tile == 160 && a.geglu)) return SD_ERR_UNSUPPORTED;   // (e4m3 weight bytes: gemm.hip)
   if (tile == 320 && a.conv && a.geglu) return SD_ERR_UNSUPPORTED;

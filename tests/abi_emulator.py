@@ -54,7 +54,9 @@ class Emulator:
 
     def mi355x_sd_groupnorm_act_fits(self, HW, C, groups):
         cpg = C // groups
-        return int(cpg % 2 == 0 and C % 8 == 0 and HW * (cpg // 2) <= 1024 * 24 and not os.environ.get("MI355X_SD_NO_GN_FUSED"))
+        # (csrc/norm.hip groupnorm_act_fits: even group width <= 128 -- the kernel's LDS table of a group's gamma / beta --, the
+        # (batch, group) chunk within a block's registers)
+        return int(cpg % 2 == 0 and cpg <= 128 and C % 8 == 0 and HW * (cpg // 2) <= 1024 * 24 and not os.environ.get("MI355X_SD_NO_GN_FUSED"))
 
     def mi355x_sd_groupnorm_act(self, x, B, HW, C, ldx, groups, eps, gamma, beta, silu, y, ldy, stream):
         ss = torch.empty(B * 2 * C, dtype=torch.float32)

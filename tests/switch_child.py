@@ -37,9 +37,9 @@ w = (torch.randn(1280, 4096, device="cuda", generator=g) / 64).to(ed)
 b = torch.randn(1280, device="cuda", generator=g)
 put("gemm 64x1280x4096", ops.linear(a, w, b), a.float() @ w.float().t() + b)
 # weight-only fp8 at large M: the matrix is widened once into the workspace and multiplied by the 16-bit kernels
-# (MI355X_SD_NO_WIDEN_F8: converted in the fragment load of the generic loop instead -- the same bits)
+# (MI355X_SD_NO_WIDEN_F8: converted in the fragment load of the generic loop instead)
 from paddlemix_amd.sd3 import dequantize_fp8_rows, quantize_fp8_rows  # noqa: E402
-for M, N, K, resid in ((4096, 1536, 1536, True), (4100, 4608, 1536, False)):
+for M, N, K, resid in ((4096, 1536, 1536, True), (8200, 4608, 1536, False)):
     a = torch.randn(M, K, device="cuda", generator=g).to(ed)
     w8, ws = quantize_fp8_rows(torch.randn(N, K, device="cuda", generator=g) / K ** 0.5)
     b = torch.randn(N, device="cuda", generator=g)

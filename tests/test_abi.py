@@ -63,3 +63,16 @@ def test_early_residual_kernels_keep_their_landing_registers():
     import re
     found = re.findall(r"(\d+) early-residual kernels, (\d+) compiler-generated uses", p.stdout)
     assert len(found) == 2 and all(int(n) >= 3 and int(bad) == 0 for n, bad in found), p.stdout
+
+
+def test_groupnorm_act_fits_is_the_launchers_whole_contract():
+    """mi355x_sd_groupnorm_act_fits == 1 must mean mi355x_sd_groupnorm_act runs (the planners choose the one-launch form on the
+    predicate alone): wide groups (C / groups > 128: the kernel's per-group gamma / beta table) are refused by the predicate itself,
+    in the built library and in the C-ABI emulator alike -- a norm_num_groups = 8 model at C = 1280 then plans statistics + apply."""
+    from paddlemix_amd import _lib
+    from tests.abi_emulator import Emulator
+    lib, emu = _lib.load(), Emulator()
+    for hw, c, groups, want in ((256, 1280, 32, 1), (256, 1280, 8, 0), (64, 2048, 8, 0), (64, 2048, 16, 1), (1 << 16, 320, 32, 0),
+                                (256, 1290, 30, 0)):
+        assert lib.mi355x_sd_groupnorm_act_fits(hw, c, groups) == want, (hw, c, groups)
+        assert emu.mi355x_sd_groupnorm_act_fits(hw, c, groups) == want, (hw, c, groups)
