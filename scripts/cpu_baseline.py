@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--workload", default="sdxl-1024-bs8", choices=["sdxl-1024-bs8", "sd15-512-bs1"])
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--chunk", type=int, default=0, help="prompts per oracle call (0: the whole batch when the host has > 96 GiB free, else 1)")
     a = ap.parse_args()
     wl = bench.WORKLOADS[a.workload]
     cfg, B, H, W, L = wl["cfg"], wl["B"], wl["H"], wl["W"], wl["L"]
@@ -36,8 +37,10 @@ def main():
     torch.set_num_threads(threads)
     avail = psutil.virtual_memory().available / 2 ** 30
     # the reference's math attention materialises [B*h, S, S] fp32 scores (+ the softmax copy): ~11 GB at bs 8, S = 4096
-    chunk = B if avail > 96 else 1
+    chunk = a.chunk or (B if avail > 96 else 1)
+    print(f"cpu_baseline: {threads} threads, {avail:.0f} GiB free, {chunk} prompt(s) per call; drawing the weights ...", flush=True)
     P = synth_unet_params(cfg, seed=1234)
+    print("cpu_baseline: weights drawn", flush=True)
     g = torch.Generator().manual_seed(0)
     s = torch.randn(B, 4, H, W, generator=g)
     e = torch.randn(B, L, cfg["cross_attention_dim"], generator=g)
@@ -54,6 +57,7 @@ def main():
                 sl = slice(b0, b0 + chunk)
                 U.unet_forward(P, cfg, s[sl], 500, e[sl], added_cond_kwargs=None if ad is None else {k: v[sl] for k, v in ad.items()})
             times.append(time.perf_counter() - t0)
+            print(f"cpu_baseline: step {len(times)}/{a.steps}: {times[-1]:.1f} s", flush=True)
     sec = sum(times) / len(times)
     res = {"workload": a.workload, "value": 1.0 / sec, "unit": "steps/s", "seconds_per_step": sec, "timed_steps": a.steps,
            "cores": threads, "host_mem_available_gib": round(avail, 1), "batch_chunk": chunk, "kind": "port",

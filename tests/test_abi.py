@@ -76,3 +76,14 @@ def test_groupnorm_act_fits_is_the_launchers_whole_contract():
                                 (256, 1290, 30, 0)):
         assert lib.mi355x_sd_groupnorm_act_fits(hw, c, groups) == want, (hw, c, groups)
         assert emu.mi355x_sd_groupnorm_act_fits(hw, c, groups) == want, (hw, c, groups)
+
+
+def test_emulator_answers_the_planners_size_queries_like_the_library():
+    """A model planned on the emulator can be exported and replayed on the device (tests/test_gpu_export.py): every size the planner
+    asks the backend for must be the library's own answer. (Round 4: the emulator's GroupNorm workspace was 64 floats flat, the
+    device kernel writes up to thousands -- a CPU-planned VAE program then failed one run in three on the device.)"""
+    from paddlemix_amd import _lib
+    from tests.abi_emulator import Emulator
+    lib, emu = _lib.load(), Emulator()
+    for B, HW, C in ((2, 1024, 32), (2, 256, 64), (2, 64, 64), (8, 16384, 128), (1, 4096, 320), (8, 1024, 1280), (3, 100, 2560), (1, 7, 8)):
+        assert emu.mi355x_sd_groupnorm_workspace_floats(B, HW, C) == lib.mi355x_sd_groupnorm_workspace_floats(B, HW, C), (B, HW, C)
