@@ -1,6 +1,6 @@
 """Self-attention launches of the SDXL bs-8 step in the UNet's own form (scale * log2 e folded into q, MI355X_SD_SDPA_LOG2): parity
-against fp32 math and time per launch under the MI355X_SD_ATTN_* switches of the environment (MI355X_SD_ATTN_DBG bits: 4 = raised
-priority around the P.V matrix interval, 16 = staggered start of co-resident blocks; MI355X_SD_ATTN_NO_WIDE = 8-byte O stores)."""
+against fp32 math and time per launch under the MI355X_SD_ATTN_* switches of the environment (MI355X_SD_ATTN_NO_WIDE = 8-byte O
+stores; the priority / staggered-start experiments of round 3, profiles/r03_s7_attn_self_experiments.txt, were deleted in round 4)."""
 import os
 import sys
 

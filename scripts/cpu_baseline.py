@@ -33,8 +33,7 @@ def main():
     a = ap.parse_args()
     wl = bench.WORKLOADS[a.workload]
     cfg, B, H, W, L = wl["cfg"], wl["B"], wl["H"], wl["W"], wl["L"]
-    threads = os.cpu_count() or 8
-    torch.set_num_threads(threads)
+    threads = torch.get_num_threads()   # physical cores (os.cpu_count() counts SMT siblings: 256 on the GPU box, and ran > 1.7x slower)
     avail = psutil.virtual_memory().available / 2 ** 30
     # the reference's math attention materialises [B*h, S, S] fp32 scores (+ the softmax copy): ~11 GB at bs 8, S = 4096
     chunk = a.chunk or (B if avail > 96 else 1)

@@ -2,7 +2,6 @@
 # usage: prof_gemm.sh <tile>   -- per-shape GEMM kernel durations via rocprofv3 (no python launch overhead in the numbers)
 cd /tmp && export TMPDIR=/tmp
 T=$1
-export MI355X_SD_GEMM_DBG=${2:-0}
 rm -rf /tmp/p$T
 MI355X_SD_GEMM_TILE=$T rocprofv3 --kernel-trace --stats -d /tmp/p$T -o r -- python $GRAFT_REPO_ROOT/scripts/gemm_probe.py > /tmp/p$T.log 2>&1
 python - <<PY
@@ -13,5 +12,5 @@ if not dbs:
     raise SystemExit
 c=sqlite3.connect(dbs[0])
 for r in c.execute("select name, grid_x, workgroup_x, count(*), avg(end-start)/1e3, min(end-start)/1e3 from kernels where name like '%gemm%' group by name, grid_x order by grid_x"):
-    print("tile$T dbg${2:-0}", r[0][20:80], "grid", r[1], "wg", r[2], "n", r[3], "avg_us", round(r[4],1), "min_us", round(r[5],1))
+    print("tile$T", r[0][20:80], "grid", r[1], "wg", r[2], "n", r[3], "avg_us", round(r[4],1), "min_us", round(r[5],1))
 PY
