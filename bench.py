@@ -288,10 +288,35 @@ def main():
             dist.barrier()
             dev_sync()
 
+    # board clock / power WHILE the timed steps run (rank 0; one `rocm-smi` call from a helper thread ~0.4 s into the region: a host
+    # process, nothing on the GPU): the step is power-managed, so `value` is what the chip does at
+    # THIS clock -- recorded next to it, never used in a formula. Absent tool / unparsable output: the field is null.
+    board = {}
+
+    def sample_board():
+        import re
+        import subprocess
+        time.sleep(0.4)
+        try:
+            out = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=20).stdout
+            sclk = re.findall(r"sclk clock level:[^(]*\((\d+)Mhz\)", out)
+            power = re.findall(r"Power \(W\):\s*([\d.]+)", out)
+            if sclk:
+                board["sclk_mhz"] = int(sclk[local_rank if local_rank < len(sclk) else 0])
+            if power:
+                board["power_w"] = float(power[local_rank if local_rank < len(power) else 0])
+        except Exception:
+            pass
+
+    sampler = None
     with (contextlib.nullcontext() if cpu else torch.cuda.stream(stream)):
         for i in range(args.warmup):
             step(i)
         sync_all()
+        if rank == 0 and not cpu and args.steps >= 20:
+            import threading
+            sampler = threading.Thread(target=sample_board, daemon=True)
+            sampler.start()
         t0 = time.perf_counter()
         for i in range(args.steps):
             step(args.warmup + i)
@@ -334,6 +359,9 @@ def main():
                    "parallelism": f"prompt-sharded dp{world}, no per-step collective", "hipgraph": bool(model.use_graph)},
         "tflops_effective": world * args.steps * wl["gflop_step"] / 1e3 / elapsed,
     }
+    if sampler is not None:
+        sampler.join(timeout=25)
+        res["board_during_timed_region"] = dict(board, source="rocm-smi, one sample 0.4 s into the timed steps") if board else None
     if bcast_s is not None:
         res["weight_broadcast_s"] = bcast_s
         res["weight_broadcast_gb"] = bcast_bytes / 1e9
