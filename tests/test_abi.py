@@ -87,3 +87,40 @@ def test_emulator_answers_the_planners_size_queries_like_the_library():
     lib, emu = _lib.load(), Emulator()
     for B, HW, C in ((2, 1024, 32), (2, 256, 64), (2, 64, 64), (8, 16384, 128), (1, 4096, 320), (8, 1024, 1280), (3, 100, 2560), (1, 7, 8)):
         assert emu.mi355x_sd_groupnorm_workspace_floats(B, HW, C) == lib.mi355x_sd_groupnorm_workspace_floats(B, HW, C), (B, HW, C)
+
+
+@pytest.mark.parametrize("src", ["tests/c/unet_exec_test.c", "tests/c/program_test.c", "scripts/c/step_bench.c", "scripts/c/gemm_probe.c"])
+def test_plain_c_clients_build_against_the_header_and_fail_loudly_without_a_device(src, tmp_path):
+    """Every plain-C client of the ABI (the two GPU-test clients and the two torch-free benches) compiles against include/mi355x_sd.h
+    as C11, links against the library, and -- on a machine without a GPU -- exits non-zero with the library's own message instead
+    of computing anything anywhere else."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None or not os.path.isdir("/opt/rocm/include"):
+        pytest.skip("no gcc / ROCm headers")
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    exe = str(tmp_path / "client")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run(["gcc", "-std=c11", "-O2", "-Wall", "-Werror", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, src), "-L" + libdir, "-lmi355x_sd", "-L/opt/rocm/lib", "-lamdhip64", "-lm",
+                    "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
+    import torch
+    if torch.cuda.is_available():
+        return
+    cfg = os.path.join(ROOT, "scripts", "c", "sd15_unet_config.json")
+    args = {"tests/c/unet_exec_test.c": [cfg, "1", "8", "8", "7", str(tmp_path / "o.bin")], "tests/c/program_test.c": [str(tmp_path / "none.prog")],
+            "scripts/c/step_bench.c": [cfg, "1", "8", "8", "7", "1", "0"], "scripts/c/gemm_probe.c": ["1"]}[src]
+    r = subprocess.run([exe] + args, capture_output=True, text=True, env=dict(os.environ, LD_LIBRARY_PATH=libdir), timeout=120)
+    assert r.returncode != 0, r.stdout
+    assert r.stderr.strip(), "a failing client says why"
+
+
+def test_c_bench_configs_are_the_bench_workloads():
+    """scripts/c/*_unet_config.json (what scripts/c/step_bench.c plans) are the configurations bench.py's workloads name."""
+    import json
+    from tests.configs import SD15, SDXL
+    for name, cfg in (("sdxl", SDXL), ("sd15", SD15)):
+        got = json.load(open(os.path.join(ROOT, "scripts", "c", f"{name}_unet_config.json")))
+        assert got == {k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.items()}, name
