@@ -167,7 +167,7 @@ __device__ __forceinline__ void conv_k_next(int kb64, int Cin, int& tap, int& ch
 // Logical tile id -> (tile_m, tile_n), "grouped" order: ids sweep GM row-tiles first, then the column, so the
 // tiles an XCD runs concurrently (a contiguous id range after xcd_remap) form a compact 2-D patch that shares
 // A row-panels and W column-panels in that XCD's L2. gm > 0: groups of gm row-tiles (round 1: 8); gm < 0: the transposed
-// order, groups of -gm column-tiles swept over the rows (production: -4, gemm.hip GEMM_GM_DEFAULT; MI355X_SD_GEMM_GM overrides).
+// order, groups of -gm column-tiles swept over the rows (production: -4, gemm.hip gemm_gm(); -8 for the 256 x 160 family).
 __device__ __forceinline__ void tile_coords(int lid, int ntm, int ntn, int gm, int& tile_m, int& tile_n) {
   if (gm == 0) gm = -4;
   if (gm > 0) {

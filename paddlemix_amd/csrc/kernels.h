@@ -65,7 +65,7 @@ struct GemmArgs {
 void set_workspace(void* ptr, size_t bytes);
 void set_last_error(const char* msg);   // text behind mi355x_sd_last_error() (capi.hip), for the entry points defined elsewhere
 int launch_gemm(const GemmArgs& a, hipStream_t stream);
-int gemm_gm();   // tile rasterisation group of the GEMM kernels (MI355X_SD_GEMM_GM, default -4 = column groups of 4)
+int gemm_gm();   // tile rasterisation group of the GEMM kernels (-4 = column groups of 4)
 int launch_gemm256(const GemmArgs& a, hipStream_t stream);
 int launch_gemm_f8(const GemmArgs& a, hipStream_t stream);   // W8A8 (gemm256.hip); validates
 void launch_splitk_reduce(const GemmArgs& a, hipStream_t stream);   // sums a.splitk slices of a.ws + epilogue (gemm.hip)   // phased 256x256 kernel (gemm256.hip); args pre-validated
