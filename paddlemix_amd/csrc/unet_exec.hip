@@ -137,14 +137,23 @@ struct Cfg {
   int atd = 0, pdim = 0;
 };
 
-std::vector<int> int_or_list(const JVal* v, size_t n, int dflt, const char* key) {
+// A config number that has to be an integer inside [lo, hi]: the text comes from a host (a file someone edited), and a width of
+// 2^31 or a depth of 10^30 must be a refusal here -- not an out-of-range float-to-int conversion, and not a parameter table that
+// exhausts the machine's memory before anything else can object (tests/test_boundary_fuzz.py).
+int as_int(double x, const char* key, int lo, int hi) {
+  if (!(x >= (double)lo && x <= (double)hi) || x != floor(x))
+    die(MI355X_SD_ERR_INVALID, std::string("config ") + key + ": expected an integer between " + std::to_string(lo) + " and " + std::to_string(hi));
+  return (int)x;
+}
+
+std::vector<int> int_or_list(const JVal* v, size_t n, int dflt, const char* key, int lo, int hi) {
   std::vector<int> out(n, dflt);
   if (!v || v->kind == JVal::NUL) return out;
-  if (v->kind == JVal::NUM) return std::vector<int>(n, (int)v->num);
+  if (v->kind == JVal::NUM) return std::vector<int>(n, as_int(v->num, key, lo, hi));
   if (v->kind != JVal::ARR || v->arr.size() != n) die(MI355X_SD_ERR_INVALID, std::string("config ") + key + ": expected an int or one int per block");
   for (size_t i = 0; i < n; ++i) {
     if (v->arr[i].kind != JVal::NUM) die(MI355X_SD_ERR_UNSUPPORTED, std::string("config ") + key + ": nested lists are not implemented");
-    out[i] = (int)v->arr[i].num;
+    out[i] = as_int(v->arr[i].num, key, lo, hi);
   }
   return out;
 }
@@ -200,8 +209,8 @@ Cfg parse_config(const char* json) {
       num("resnet_out_scale_factor", 1.0) != 1.0 || num("dropout", 0.0) != 0.0)
     die(MI355X_SD_ERR_UNSUPPORTED, "mi355x_sd_unet_create: downsample_padding / conv kernels / resnet_out_scale_factor / dropout off default");
 
-  c.in_channels = (int)num("in_channels", 4);
-  c.out_channels = (int)num("out_channels", 4);
+  c.in_channels = as_int(num("in_channels", 4), "in_channels", 1, 64);
+  c.out_channels = as_int(num("out_channels", 4), "out_channels", 1, 64);
   c.flip_sin_to_cos = boolean("flip_sin_to_cos", true);
   c.freq_shift = num("freq_shift", 0);
   c.down = strs("down_block_types", c.down);
@@ -211,7 +220,8 @@ Cfg parse_config(const char* json) {
     c.boc.clear();
     for (auto& e : v->arr) {
       if (e.kind != JVal::NUM) die(MI355X_SD_ERR_INVALID, "config block_out_channels: expected integers");
-      c.boc.push_back((int)e.num);
+      if (c.boc.size() >= 8) die(MI355X_SD_ERR_INVALID, "config block_out_channels: at most 8 levels");
+      c.boc.push_back(as_int(e.num, "block_out_channels", 8, 16384));
     }
   }
   const size_t n = c.down.size();
@@ -220,23 +230,23 @@ Cfg parse_config(const char* json) {
     if (bt != "CrossAttnDownBlock2D" && bt != "DownBlock2D") die(MI355X_SD_ERR_UNSUPPORTED, "block type " + bt + " is not implemented");
   for (auto& bt : c.up)
     if (bt != "CrossAttnUpBlock2D" && bt != "UpBlock2D") die(MI355X_SD_ERR_UNSUPPORTED, "block type " + bt + " is not implemented");
-  c.layers_per_block = int_or_list(root.get("layers_per_block"), n, 2, "layers_per_block");
-  c.tlayers = int_or_list(root.get("transformer_layers_per_block"), n, 1, "transformer_layers_per_block");
-  c.heads = int_or_list(root.get("attention_head_dim"), n, 8, "attention_head_dim");   // the naming quirk at unet_2d_condition.py:245
-  std::vector<int> cross = int_or_list(root.get("cross_attention_dim"), n, 1280, "cross_attention_dim");
+  c.layers_per_block = int_or_list(root.get("layers_per_block"), n, 2, "layers_per_block", 1, 16);
+  c.tlayers = int_or_list(root.get("transformer_layers_per_block"), n, 1, "transformer_layers_per_block", 1, 64);
+  c.heads = int_or_list(root.get("attention_head_dim"), n, 8, "attention_head_dim", 1, 2048);   // the naming quirk at unet_2d_condition.py:245
+  std::vector<int> cross = int_or_list(root.get("cross_attention_dim"), n, 1280, "cross_attention_dim", 8, 65536);
   for (int x : cross)
     if (x != cross[0]) die(MI355X_SD_ERR_UNSUPPORTED, "per-block cross_attention_dim is not implemented");
   c.cross_dim = cross[0];
   c.mid_scale = num("mid_block_scale_factor", 1.0);
-  c.groups = (int)num("norm_num_groups", 32);
+  c.groups = as_int(num("norm_num_groups", 32), "norm_num_groups", 1, 1024);
   c.norm_eps = num("norm_eps", 1e-5);
   c.linear_proj = boolean("use_linear_projection", false);
   if (const JVal* v = root.get("addition_embed_type")) {
     if (v->kind == JVal::STR) {
       if (v->str != "text_time") die(MI355X_SD_ERR_UNSUPPORTED, "addition_embed_type=" + v->str + " is not implemented");
       c.text_time = true;
-      c.atd = (int)num("addition_time_embed_dim", 0);
-      c.pdim = (int)num("projection_class_embeddings_input_dim", 0);
+      c.atd = as_int(num("addition_time_embed_dim", 0), "addition_time_embed_dim", 0, 8192);
+      c.pdim = as_int(num("projection_class_embeddings_input_dim", 0), "projection_class_embeddings_input_dim", 0, 1 << 20);
       if (c.atd <= 0 || c.pdim <= 0) die(MI355X_SD_ERR_INVALID, "text_time needs addition_time_embed_dim and projection_class_embeddings_input_dim");
     }
   }
