@@ -57,11 +57,19 @@ struct JVal {
 };
 struct JParser {
   const char* p;
+  int depth = 0;   // nesting of the value being parsed: a model config nests two deep; a million '[' must not be a stack overflow
   explicit JParser(const char* s) : p(s) {}
   void ws() {
     while (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r') ++p;
   }
   JVal parse() {
+    struct Depth {
+      int& d;
+      explicit Depth(int& d_) : d(d_) {
+        if (++d > 32) die(MI355X_SD_ERR_INVALID, "config_json: nested more than 32 levels deep");
+      }
+      ~Depth() { --d; }
+    } guard(depth);
     ws();
     JVal v;
     if (*p == '{') {

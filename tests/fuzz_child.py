@@ -123,7 +123,7 @@ def fuzz_config(n, seed):
             d[k] = d[k][:rng.randrange(0, len(d[k]))] if rng.random() < 0.5 else d[k] * rng.randrange(2, 40)
             s = json.dumps(d)
         elif kind == 5:    # deep nesting / very long tokens
-            s = rng.choice(["[" * 5000, "{\"a\":" * 3000, "\"" + "x" * 100000, "{\"block_out_channels\":[" + "1," * 50000 + "1]}",
+            s = rng.choice(["[" * 5000, "[" * 1000000, "{\"a\":[" * 400000, "{\"a\":" * 3000, "\"" + "x" * 100000, "{\"block_out_channels\":[" + "1," * 50000 + "1]}",
                             "{\"" + "k" * 70000 + "\":1}", "-" * 1000, "1e" + "9" * 400])
         else:              # unknown and duplicated keys
             d = json.loads(s)
