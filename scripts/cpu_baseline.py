@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--workload", default="sdxl-1024-bs8", choices=["sdxl-1024-bs8", "sd15-512-bs1"])
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--where", default="host of the GPU box", help="which machine this ran on (recorded in the JSON)")
     ap.add_argument("--chunk", type=int, default=0, help="prompts per oracle call (0: the whole batch when the host has > 96 GiB free, else 1)")
     a = ap.parse_args()
     wl = bench.WORKLOADS[a.workload]
@@ -59,7 +60,7 @@ def main():
             print(f"cpu_baseline: step {len(times)}/{a.steps}: {times[-1]:.1f} s", flush=True)
     sec = sum(times) / len(times)
     res = {"workload": a.workload, "value": 1.0 / sec, "unit": "steps/s", "seconds_per_step": sec, "timed_steps": a.steps,
-           "cores": threads, "host_mem_available_gib": round(avail, 1), "batch_chunk": chunk, "kind": "port",
+           "cores": threads, "machine": a.where, "host_mem_available_gib": round(avail, 1), "batch_chunk": chunk, "kind": "port",
            "tflops_effective": wl["gflop_step"] / 1e3 / sec,
            "what": f"torch-CPU fp32 restatement of ppdiffusers (Paddle unavailable), full bs-{B} {H}x{W} UNet forward"}
     print(json.dumps(res))
