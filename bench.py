@@ -91,6 +91,30 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cpus(cgroup_root: str = "/sys/fs/cgroup") -> int:
+    """CPUs this process may actually use: its affinity mask, capped by the container's CPU quota (cgroup v2 `cpu.max`, v1
+    `cpu.cfs_quota_us / cpu.cfs_period_us`). torch sizes its thread pool by the machine's core count; inside a container with a
+    quota that over-subscribes the CPU leg (round 4: 128 threads on the GPU box's host ran the oracle 2.3x SLOWER than 8 threads
+    of the 8-core build container)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open(os.path.join(cgroup_root, "cpu.max")).read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open(os.path.join(cgroup_root, "cpu", "cpu.cfs_quota_us")).read())
+            per = float(open(os.path.join(cgroup_root, "cpu", "cpu.cfs_period_us")).read())
+            if q > 0 and per > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = min(n, max(1, int(quota + 0.5)))
+    return max(1, n)
+
+
 def _free_port() -> int:
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -437,7 +461,8 @@ def main():
     # bs-B steps) is scripts/cpu_baseline.py -> profiles/r*_cpu_baseline_<workload>.json, attached when committed.
     if P_cpu_needed:
         from oracle import unet_ref as U
-        threads = torch.get_num_threads()
+        threads = min(torch.get_num_threads(), usable_cpus())
+        torch.set_num_threads(threads)   # (never more threads than the container's affinity mask / CPU quota grants)
         Pc = {k: v.float().cpu() for k, v in P.items()}
         del P
         gs = torch.Generator().manual_seed(0)

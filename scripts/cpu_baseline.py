@@ -34,7 +34,10 @@ def main():
     a = ap.parse_args()
     wl = bench.WORKLOADS[a.workload]
     cfg, B, H, W, L = wl["cfg"], wl["B"], wl["H"], wl["W"], wl["L"]
-    threads = torch.get_num_threads()   # physical cores (os.cpu_count() counts SMT siblings: 256 on the GPU box, and ran > 1.7x slower)
+    # physical cores (os.cpu_count() counts SMT siblings: 256 on the GPU box, and ran > 1.7x slower), never more than the
+    # container's affinity mask / CPU quota grants
+    threads = min(torch.get_num_threads(), bench.usable_cpus())
+    torch.set_num_threads(threads)
     avail = psutil.virtual_memory().available / 2 ** 30
     # the reference's math attention materialises [B*h, S, S] fp32 scores (+ the softmax copy): ~11 GB at bs 8, S = 4096
     chunk = a.chunk or (B if avail > 96 else 1)

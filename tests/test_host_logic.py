@@ -405,3 +405,22 @@ def test_latent_sizes_that_are_not_multiples_of_the_up_factor():
     assert ((out - ref).norm() / ref.norm()).item() < 2e-2
     names = [fn.__name__ for fn, *_ in list(m._plans.values())[-1].prog]
     assert names.count("mi355x_sd_copy_rows") == 5 * 4 - 2      # 5 source rows x (dy, dx); destination row 9 (source row 4, dy 1) is cropped
+
+
+def test_bench_cpu_leg_respects_the_containers_cpu_quota(tmp_path):
+    """bench.usable_cpus: the affinity mask capped by the cgroup CPU quota (v2 cpu.max, v1 cfs quota / period); no quota = the mask."""
+    import os
+    import bench
+    mask = len(os.sched_getaffinity(0))
+    assert bench.usable_cpus(str(tmp_path)) == mask                       # no cgroup files at all
+    (tmp_path / "cpu.max").write_text("max 100000\n")
+    assert bench.usable_cpus(str(tmp_path)) == mask
+    (tmp_path / "cpu.max").write_text("150000 100000\n")                    # 1.5 CPUs -> 2 threads at most
+    assert bench.usable_cpus(str(tmp_path)) == min(mask, 2)
+    (tmp_path / "cpu.max").write_text("garbage\n")
+    (tmp_path / "cpu").mkdir()
+    (tmp_path / "cpu" / "cpu.cfs_quota_us").write_text("-1\n")
+    (tmp_path / "cpu" / "cpu.cfs_period_us").write_text("100000\n")
+    assert bench.usable_cpus(str(tmp_path)) == mask                       # v1, unlimited
+    (tmp_path / "cpu" / "cpu.cfs_quota_us").write_text("100000\n")
+    assert bench.usable_cpus(str(tmp_path)) == 1
