@@ -398,6 +398,10 @@ def main():
         # the SAME model object that was just timed replays the fixtures' loops (float64 latent state on the host)
         from tests import parity_cases as PC
         res["parity_live"] = {c: PC.device_report(c, model=model, dev=dev) for c in args.parity_cases.split(",") if c}
+        # ... and ONE whole-batch forward at the launch set the metric times (8x4x128x128: M = 8192 / 32768 GEMM tiles, no split-K)
+        # against the committed oracle forward of the same batch (tests/parity_cases.py FWD_CASES)
+        fw = PC.device_fwd_report("sdxl_8x4x128x128_fwd", model, dev=dev)
+        res["parity_live_bs8"] = {k: v for k, v in fw.items() if k != "pred"}
 
     # ---- roofline of the dominant kernel: per-launch HIP-event timing on the launch stream, one eager step ----
     if rank == 0 and not args.no_roofline:
@@ -510,6 +514,9 @@ def main():
                 return {"dtype": dtype, "residual": residual, "steps_per_s": c["value"], "ms_per_step": c["ms_per_step"], "steps": c["steps"],
                         "end_latents_rel_l2": {k: v["end_latents_rel"] for k, v in live.items()},
                         "pred_rel_l2_teacher_forced_max": {k: v["pred_rel_teacher_forced_max"] for k, v in live.items()},
+                        # one forward of the whole 8x4x128x128 batch -- the launches the timed region replays -- vs the oracle's
+                        "pred_rel_bs8": c.get("parity_live_bs8", {}).get("pred_rel_bs8"),
+                        "pred_rel_bs8_per_prompt_max": c.get("parity_live_bs8", {}).get("pred_rel_bs8_per_prompt_max"),
                         "target_rel_l2": 1e-3, "meets_target": all(v["end_latents_rel"] < 1e-3 for v in live.values()),
                         "oracle": "committed trajectories of the torch-CPU restatement of ppdiffusers, reproduced bit for bit by the "
                                   "reference's own model code over a torch-backed paddle shim (tests/golden/parity; Paddle's kernels unpinned)",
@@ -522,6 +529,13 @@ def main():
             res["parity_mode"] = dict(res["parity"], steps_per_s=res["value"], ms_per_step=res["ms_per_step"], steps=args.steps)
         else:
             res["parity_mode"] = parity_leg("fp16", "16", max(20, min(args.steps, 30)), 3)
+        # Top level, not buried: does the mode `value` was measured in meet north_star's 1e-3 on the end latents -- and the throughput
+        # of the cheapest mode that does (same kernels, fp16 elements). BASELINE.json names bf16 for this configuration, so `value`
+        # stays the bf16 number and says so.
+        res["meets_target"] = bool(res["parity"].get("meets_target", False))
+        if res["parity_mode"].get("meets_target"):
+            res["value_meeting_target"] = {"steps_per_s": res["parity_mode"]["steps_per_s"], "dtype": res["parity_mode"]["dtype"],
+                                           "residual": res["parity_mode"]["residual"]}
     if rank == 0:
         print(json.dumps(res))
     if dist is not None:

@@ -59,6 +59,13 @@ int main(int argc, char** argv) {
     printf("sdpa %dx%2dx%4dx%4dx%d %s  x%3d/step  %8.2f us  %7.1f TFLOP/s  %7.3f ms/step  out %016llx\n", sh.B, sh.H, sh.Sq, sh.Skv,
            sh.D, sh.self ? "self " : "cross", sh.per_step, us, gflop / us * 1e3, us * sh.per_step * 1e-3,
            (unsigned long long)device_fnv(O[0], (size_t)sh.B * sh.Sq * C * 2));
+    if (getenv("MI355X_SD_ATTN_ABL") && atoi(getenv("MI355X_SD_ATTN_ABL")) == 64 && sh.self) { /* debug build: the kernel left clock stamps in O */
+      unsigned long long d[4];
+      HK(hipMemcpy(d, (const char*)Q[0] + (((size_t)(sh.B - 1) * sh.Sq * 3 * C + (size_t)(sh.Sq - 1) * 3 * C + C - 16) * 2), sizeof(d), hipMemcpyDeviceToHost));
+      printf("   shader clock while this launch ran: %.0f MHz (block 8: %llu s_memtime ticks in %llu wall ticks of 10 ns), %.0f MHz (a block of the second half)\n",
+             100.0 * d[0] / d[1], d[0], d[1], 100.0 * d[2] / d[3]);
+      printf("   shader clock, second stamp: %llu s_memtime ticks in %llu wall ticks\n", d[2], d[3]);
+    }
     class_ms += us * sh.per_step * 1e-3;
     class_gflop += gflop * sh.per_step;
     for (int b = 0; b < NBUF; ++b) {

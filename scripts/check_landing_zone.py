@@ -4,7 +4,8 @@ v216 .. v255, registers the compiler is told not to allocate (amdgpu_num_vgpr(21
 reservation -- round 4's first interleaved loop made the allocator use v216+ as MFMA temporaries in an unrolled tail and the
 landed rows were overwritten (NaN on the first hardware run). This script disassembles the built libraries and fails if any
 instruction of such a kernel other than the hand-written ones (the asm buffer loads that fill the zone, the v_mov reads that empty
-it) names a register >= v216.
+it) names a register >= v216. WHICH kernels: every kernel whose code contains the marker instruction gemm_epilogue_pre emits
+(`s_mov_b32 m0, m0`), not a list of names.
 
     python scripts/check_landing_zone.py [lib.so ...]          (default: both built libraries; runs without a GPU)
 """
@@ -53,27 +54,40 @@ def code_objects(lib):
     return out
 
 
+MARKER = re.compile(r"^s_mov_b32\s+m0,\s*m0$")
+
+
 def check_disassembly(text, label):
-    bad, kernel, n_k = [], None, 0
+    """Every kernel that carries the landing-zone MARKER (gemm_epilogue.h: `s_mov_b32 m0, m0`, emitted by gemm_epilogue_pre and by
+    nothing else -- hipcc has no reason to move m0 onto itself) is held to the rule, whatever it is called; a kernel NAMED
+    gemm_pipe_pre_kernel without the marker is an error too (the marker was lost)."""
+    kernels, cur = {}, None
     for ln in text.splitlines():
         m = re.match(r"^[0-9a-f]+ <(\S+)>:", ln)
         if m:
-            kernel = m.group(1) if "gemm_pipe_pre_kernel" in m.group(1) else None
-            n_k += kernel is not None
+            cur = kernels.setdefault(m.group(1), [])
             continue
-        if kernel is None or "\t" not in ln:
+        if cur is not None and "\t" in ln:
+            cur.append(ln.split("//")[0].strip())
+    bad, n_k = [], 0
+    for name, body in kernels.items():
+        marked = any(MARKER.match(i) for i in body)
+        if not marked:
+            if "gemm_pipe_pre_kernel" in name:
+                bad.append((name, "<no landing-zone marker in an early-residual kernel>"))
             continue
-        ins = ln.split("//")[0].strip()
-        hi = max([int(g[1] or g[2]) for g in REG.findall(ins)] or [0])
-        if hi < BASE:
-            continue
-        op = ins.split()[0]
-        mv = re.match(r"v_mov_b32(?:_e32)?\s+v(\d+),\s*v(2\d\d)$", ins)
-        ok = (op in ("buffer_load_dwordx4", "buffer_load_dwordx2") and re.match(r"\S+\s+v\[2\d\d:2\d\d\]", ins)) or \
-             (mv is not None and int(mv.group(1)) < BASE)
-        if not ok:
-            bad.append((kernel, ins))
-    print(f"{label}: {n_k} early-residual kernels, {len(bad)} compiler-generated uses of v{BASE}+")
+        n_k += 1
+        for ins in body:
+            hi = max([int(g[1] or g[2]) for g in REG.findall(ins)] or [0])
+            if hi < BASE:
+                continue
+            op = ins.split()[0]
+            mv = re.match(r"v_mov_b32(?:_e32)?\s+v(\d+),\s*v(2\d\d)$", ins)
+            ok = (op in ("buffer_load_dwordx4", "buffer_load_dwordx2") and re.match(r"\S+\s+v\[2\d\d:2\d\d\]", ins)) or \
+                 (mv is not None and int(mv.group(1)) < BASE)
+            if not ok:
+                bad.append((name, ins))
+    print(f"{label}: {n_k} kernels with the landing-zone marker, {len(bad)} compiler-generated uses of v{BASE}+")
     for k, ins in bad[:20]:
         print("   ", k[:70], "|", ins)
     return n_k, bad

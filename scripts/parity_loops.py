@@ -36,7 +36,7 @@ def child(elem: str, names, cache_dir: str) -> dict:
     def params(case):
         """seeded weights, exact in bf16 and fp16; generated once per model family and shared between the two children through a
         bf16 file (drawing 2.6 B normals from the CPU generator takes about a minute)"""
-        key = "sd3" if case["kind"] == "sd3" else ("sdxl" if case["cfg"].get("addition_embed_type") else "sd15")
+        key = "sd3" if case["kind"] == "sd3" else ("sdxl" if case["cfg"].get("addition_embed_type") else "sd15")   # (FWD_CASES entries too)
         if key in params_cache:
             return params_cache[key]
         params_cache.clear()
@@ -52,6 +52,30 @@ def child(elem: str, names, cache_dir: str) -> dict:
         return P
 
     for name in names:
+        if name in PC.FWD_CASES:
+            # one whole-batch forward at the launch set the metric times, vs the oracle's forward of the same batch; plus the same
+            # prompts one at a time through the bs-1 launch set (other GEMM tiles, split-K): how much the batch size itself moves
+            case = PC.FWD_CASES[name]
+            res = {}
+            for mname, kw in (("resid_16", dict(residual_dtype="16")), ("resid_fp32", dict(residual_dtype="fp32"))):
+                from paddlemix_amd.unet import UNet2DConditionModel
+                model = UNet2DConditionModel(case["cfg"], params(case), device="cuda:0", **kw)
+                r = PC.device_fwd_report(name, model)
+                pred8 = r.pop("pred")
+                x_in, t, enc, extra = PC.fwd_inputs(case)
+                rows = []
+                for b in range(case["B"]):
+                    ex = {k: v[b:b + 1].to("cuda:0") for k, v in extra.items()}
+                    p1 = model(x_in[b:b + 1].to("cuda:0"), int(t), enc[b:b + 1].to("cuda:0"), added_cond_kwargs=ex, return_dict=False)[0].float().cpu()
+                    rows.append(PC.rel_l2(pred8[b], p1[0]))
+                r["bs8_row_vs_bs1_forward_rel_max"] = max(rows)
+                del model
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
+                res[mname] = r
+                print(elem, name, mname, json.dumps(r), flush=True)
+            out[name] = res
+            continue
         case = PC.CASES[name]
         if case.get("quant"):   # the oracle trajectory was computed on the same quantised operands (tests/parity_cases.py)
             if elem != "bf16":
@@ -92,7 +116,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r04_parity.json"))
     a = ap.parse_args()
     from tests import parity_cases as PC
-    names = a.cases.split(",") if a.cases else list(PC.CASES)
+    names = a.cases.split(",") if a.cases else list(PC.CASES) + list(PC.FWD_CASES)
     if a.child:
         print("PARITY_JSON " + json.dumps(child(a.child, names, a.cache_dir)))
         return

