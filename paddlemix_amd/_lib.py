@@ -16,6 +16,13 @@ ELEM_NAME = os.environ.get("MI355X_SD_DTYPE", "bf16")
 if ELEM_NAME not in _BUILDS:
     raise ValueError(f"MI355X_SD_DTYPE must be one of {sorted(_BUILDS)}, got {ELEM_NAME!r}")
 LIB_PATH = os.path.join(_HERE, _BUILDS[ELEM_NAME][0])
+# The production libraries never read the environment. The MI355X_SD_* A/B switches of the launchers (tile overrides, "the other
+# way" forms the variant tests compare bit for bit: csrc/common.h sd_switch) exist in a third build only, bf16 elements with
+# -DMI355X_SD_DEBUG_SWITCHES: MI355X_SD_LIB=dbg selects it (tests/test_gpu_switches.py, tests/test_gpu_gemm_variants.py, scripts/).
+if os.environ.get("MI355X_SD_LIB") == "dbg":
+    if ELEM_NAME != "bf16":
+        raise ValueError("MI355X_SD_LIB=dbg: the debug-switch build exists for bf16 elements only")
+    LIB_PATH = os.path.join(_HERE, "libmi355x_sd_dbg.so")
 
 ABI_VERSION = 11
 GEGLU, OUT_F32, SILU, GELU_TANH, PAD_BR, R_F32, CONV_KB64 = 1, 2, 4, 8, 16, 32, 64

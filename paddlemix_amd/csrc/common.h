@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace sd {
 
@@ -27,6 +28,19 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 constexpr int kWave = 64;
+
+// A/B switches of the launchers (environment variables MI355X_SD_*: tile overrides, "do it the other way" forms that tests compare
+// bit for bit, time stamps). They exist in the DEBUG-SWITCH build only (libmi355x_sd_dbg.so, -DMI355X_SD_DEBUG_SWITCHES: what
+// tests/test_gpu_switches.py, tests/test_gpu_gemm_variants.py and the A/B scripts load); the production libraries never read the
+// environment -- a kernel choice there depends on the arguments alone.
+inline const char* sd_switch(const char* name) {
+#ifdef MI355X_SD_DEBUG_SWITCHES
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
 
 // the two MFMA shapes the kernels use, on the build's element type (same issue rate for bf16 and f16)
 __device__ __forceinline__ f32x4 mfma_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {

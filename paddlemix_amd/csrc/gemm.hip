@@ -253,7 +253,7 @@ void set_workspace(void* ptr, size_t bytes) {
 // Target ~2 blocks per CU, at least 4 k-tiles per slice, partial sums bounded by the workspace.
 static void plan_splitk(GemmArgs& a, int bm, int bn) {
   a.splitk = 0;
-  static const bool off = getenv("MI355X_SD_NO_SPLITK") != nullptr;
+  static const bool off = sd_switch("MI355X_SD_NO_SPLITK") != nullptr;
   if (!g_ws || off || a.w16) return;   // (a widened fp8 matrix occupies the workspace)
   const long tiles = (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn);
   const int nt = (a.K + BK - 1) / BK;
@@ -293,14 +293,14 @@ static inline bool w_is_f8(const GemmArgs& a) { return a.wscale && !a.w16; }   /
 static int pick_tile_model(const GemmArgs& a);
 static int pick_tile(const GemmArgs& a) {
   static const int forced = [] {
-    const char* e = getenv("MI355X_SD_GEMM_TILE");
+    const char* e = sd_switch("MI355X_SD_GEMM_TILE");
     return e ? atoi(e) : 0;
   }();
   if (forced) return forced;
   // MI355X_SD_GEMM_TILE_MAP="from:to,from:to" re-maps the model's choice per tile class (A/B measurements inside the step)
   static const std::vector<std::pair<int, int>> remap = [] {
     std::vector<std::pair<int, int>> v;
-    const char* e = getenv("MI355X_SD_GEMM_TILE_MAP");
+    const char* e = sd_switch("MI355X_SD_GEMM_TILE_MAP");
     while (e && *e) {
       char* end = nullptr;
       const long from = strtol(e, &end, 10);
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void widen_fp8_kernel(const unsigned* __restri
   }
 }
 static bool widen_fp8_applies(const GemmArgs& a) {
-  static const bool off = getenv("MI355X_SD_NO_WIDEN_F8") != nullptr;   // A/B switch (tests/test_gpu_switches.py: same bits)
+  static const bool off = sd_switch("MI355X_SD_NO_WIDEN_F8") != nullptr;   // A/B switch (tests/test_gpu_switches.py: same bits)
   if (off) return false;
   if (!a.wscale || a.w16 || !g_ws || a.conv || a.rowstat || (a.K & 63) || (a.N & 3)) return false;
   if ((size_t)a.N * a.K * 2 > g_ws_bytes || (reinterpret_cast<uintptr_t>(a.W) & 3)) return false;
@@ -409,13 +409,13 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
   if (a.rowbias && a.rows_per_batch <= 0) return SD_ERR_INVALID;
   {   // diagnostics only: a device buffer for per-block time stamps, handed over by scripts/gemm_timeline.py as an address
     static unsigned long long* const ts = [] {
-      const char* e = getenv("MI355X_SD_GEMM_TSTAMP");
+      const char* e = sd_switch("MI355X_SD_GEMM_TSTAMP");
       return e ? reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0)) : nullptr;
     }();
     a.ts = ts;
   }
   a.c_wide = !a.out_f32 && !(reinterpret_cast<uintptr_t>(a.C) & 15) && !(a.ldc & 7) && !(a.c_bstride & 7);
-  static const bool epi_batch_off = getenv("MI355X_SD_GEMM_NO_EPI_BATCH") != nullptr;   // A/B switch (gemm_epilogue.h)
+  static const bool epi_batch_off = sd_switch("MI355X_SD_GEMM_NO_EPI_BATCH") != nullptr;   // A/B switch (gemm_epilogue.h)
   a.epi_batch = epi_batch_off ? 0 : 1;
   a.bias_acc = 0;   // launch_gemm_pipe decides
   const int tile = pick_tile(a);

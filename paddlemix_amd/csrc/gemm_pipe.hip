@@ -12,7 +12,6 @@
 // loader waves (gone in round 4: the interleaved loop beats them everywhere, r04_s2_step_shapes_ab.txt); round 3 -- persistent
 // blocks, early residual, bias in the accumulators; round 4 -- the INTERLEAVED register-pipelined loop below.
 #include <stdlib.h>
-#include <string.h>
 
 #include <type_traits>
 
@@ -77,19 +76,6 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& p) {
   // straight on to the next tile's prologue while slower waves are still storing.
   const int nvb = ntm * ntn;
   const bool persist = (int)gridDim.x < nvb;             // launch-uniform
-  // Staggered start (round 5). The blocks of a persistent launch run in lockstep: every CU leaves its K loop at the same moment, the
-  // whole chip then stores for ~5 us with idle matrix pipes (the write path absorbs ~4 TB/s; scripts/gemm_timeline.py: "epilogue
-  // 4.9 us, drain 0.3 us" -- the time is store ISSUE against back-pressure), and the K loops leave HBM idle. Groups of blocks that
-  // start a fraction of an epilogue apart keep that distance for the rest of the launch (same period), so a group's stores meet
-  // the other groups' K loops instead of their stores. Cost: the last group ends (groups - 1) * stagger later -- worth it from
-  // about three tile rounds per CU. Blocks b, b + 8, ... share an XCD: consecutive ones go to different groups.
-  if (persist && p.stagger > 0) {
-    const int grp = (int)((blockIdx.x >> 3) % (unsigned)p.stagger_groups);
-    if (grp) {
-      const unsigned long long t0 = wall_clock64(), dt = (unsigned long long)(grp * p.stagger);
-      while (wall_clock64() - t0 < dt) __builtin_amdgcn_s_sleep(4);
-    }
-  }
   for (int vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
   // (the thread id is re-read through an opaque asm per tile: otherwise every per-lane constant of the prologue is hoisted out of
   // this loop and kept alive across the K loop for the next tile -- 256 VGPRs and spills at the 256x320 tiles)
@@ -532,7 +518,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES) __attribute__((amdgpu
 template <class CFG>
 static int pipe_grid_x(int tiles, int ny) {
   static const bool off = [] {
-    const char* e = getenv("MI355X_SD_GEMM_PERSIST");
+    const char* e = sd_switch("MI355X_SD_GEMM_PERSIST");
     return e && atoi(e) == 0;
   }();
   static const int cus = [] {
@@ -550,7 +536,7 @@ static int pipe_grid_x(int tiles, int ny) {
 template <bool CONV, class CFG, bool LN>
 static bool pre_applies(const GemmArgs& a) {
   if constexpr (!CONV && !LN && (CFG::TM + CFG::TN) <= 10 && CFG::TM <= 4) {
-    static const bool pre_off = getenv("MI355X_SD_GEMM_NO_PRE") != nullptr;   // A/B switch
+    static const bool pre_off = sd_switch("MI355X_SD_GEMM_NO_PRE") != nullptr;   // A/B switch
     return !pre_off && a.R && !a.r_f32 && !a.geglu && !a.gate && !a.wscale && a.splitk <= 1 && (!a.bias || a.bias_acc) &&
            a.K / BK >= CFG::TM + 2 && !(a.N & 7) && ((size_t)(a.M - 1) * a.ldr + a.N) * 2 < 0xFFFF0000ull;
   } else {
@@ -559,11 +545,9 @@ static bool pre_applies(const GemmArgs& a) {
 }
 
 template <bool CONV, class CFG, bool LN>
-static int launch_pipe(const GemmArgs& a_in, hipStream_t stream) {
-  const int ntm = (a_in.M + CFG::BM - 1) / CFG::BM, ntn = (a_in.N + CFG::BN - 1) / CFG::BN;
-  const int ny = a_in.splitk > 1 ? a_in.splitk : 1;
-  GemmArgs a = a_in;
-  if (a.stagger > 0 && ntm * ntn < a.stagger_min_rounds * pipe_grid_x<CFG>(ntm * ntn, ny)) a.stagger = 0;   // too few rounds to pay for the tail
+static int launch_pipe(const GemmArgs& a, hipStream_t stream) {
+  const int ntm = (a.M + CFG::BM - 1) / CFG::BM, ntn = (a.N + CFG::BN - 1) / CFG::BN;
+  const int ny = a.splitk > 1 ? a.splitk : 1;
   if constexpr (!CONV && !LN && (CFG::TM + CFG::TN) <= 10 && CFG::TM <= 4) {
     // residual launches (to_out, proj_out, FF2): the residual is fetched during the last TM K iterations. bf16 residual rows
     // addressed with 32-bit offsets, N % 8 == 0 (a 16-byte pair load never straddles the row's end), bias in the accumulators, no
@@ -593,17 +577,9 @@ static int launch_pipe(const GemmArgs& a_in, hipStream_t stream) {
 int launch_gemm_pipe(const GemmArgs& a_in, int tile, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   GemmArgs a = a_in;
-  static const bool bias_acc_off = getenv("MI355X_SD_GEMM_NO_BIAS_ACC") != nullptr;   // A/B switch
+  static const bool bias_acc_off = sd_switch("MI355X_SD_GEMM_NO_BIAS_ACC") != nullptr;   // A/B switch
   a.bias_acc = (a.bias && (!a.wscale || a.w16) && a.splitk <= 1 && !a.rowstat && !bias_acc_off) ? 1 : 0;
-  {   // staggered start of persistent launches: MI355X_SD_GEMM_STAGGER="<10-ns ticks per group>,<groups>[,<min tile rounds>]"
-    static const int st[3] = {[] { const char* e = getenv("MI355X_SD_GEMM_STAGGER"); return e ? atoi(e) : 0; }(),
-                              [] { const char* e = getenv("MI355X_SD_GEMM_STAGGER"); const char* c = e ? strchr(e, ',') : nullptr; return c ? atoi(c + 1) : 4; }(),
-                              [] { const char* e = getenv("MI355X_SD_GEMM_STAGGER"); const char* c = e ? strchr(e, ',') : nullptr; c = c ? strchr(c + 1, ',') : nullptr; return c ? atoi(c + 1) : 3; }()};
-    a.stagger = st[0];
-    a.stagger_groups = st[1] > 0 ? st[1] : 1;
-    a.stagger_min_rounds = st[2];
-  }
-  static const bool off = getenv("MI355X_SD_NO_PIPE") != nullptr;     // every launch on the generic loop of gemm.hip (the variant test's reference)
+  static const bool off = sd_switch("MI355X_SD_NO_PIPE") != nullptr;     // every launch on the generic loop of gemm.hip (the variant test's reference)
   if (off || (a.wscale && !a.w16) || (a.K & 63) || (tile == 160 && a.geglu)) return SD_ERR_UNSUPPORTED;   // (e4m3 weight bytes: gemm.hip)
   if (tile == 320 && a.conv && a.geglu) return SD_ERR_UNSUPPORTED;
   // 256x256: the phased kernel (gemm256.hip) stays the default where it can run (id 257); id 256 is what pick_tile

@@ -55,7 +55,6 @@ struct GemmArgs {
                           // wall-clock stamps (entry, first tile landed, K loop done, stores issued) + (XCC id, block id); NULL in production
   int gm;                 // tile rasterisation group (common.h tile_coords): set by the launchers (gemm_gm())
   int bias_acc;           // set by launch_gemm_pipe: the kernel starts its accumulators at bias[n] (no bias load in the epilogue)
-  int stagger, stagger_groups, stagger_min_rounds;   // persistent launches: block b starts ((b / 8) % groups) * stagger ticks of 10 ns late (gemm_pipe.hip)
   int epi_batch;          // set by the launchers: the general epilogue fetches a row-tile's operands in one batch (0: one group at a time)
   // split-K (filled in by launch_gemm, callers leave 0): blockIdx.y owns k-tiles [y*kc, (y+1)*kc) and stores its raw
   // fp32 accumulators to ws[y][M][N]; splitk_reduce_kernel sums the slices in fixed order and runs the epilogue.

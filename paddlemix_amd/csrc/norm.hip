@@ -291,7 +291,7 @@ int launch_scale_shift_act(const void* x, int x_f32, int B, int HW, int C, int l
 // 19 % of its 6.3 ms step), and the 32x32 levels of SDXL. Larger groups (HW * cpg * 2 > 96 KB) keep the split form.
 constexpr int GNF_THREADS = 1024, GNF_MAXD = 24;
 int groupnorm_act_fits(int HW, int C, int groups) {
-  static const bool off = getenv("MI355X_SD_NO_GN_FUSED") != nullptr;   // A/B switch (read by the program builders too)
+  static const bool off = sd_switch("MI355X_SD_NO_GN_FUSED") != nullptr;   // A/B switch (read by the program builders too)
   if (off || groups <= 0 || C <= 0 || (C % groups) || HW <= 0) return 0;
   const int cpg = C / groups;
   if ((cpg & 1) || (C & 7) || cpg > 128) return 0;   // (128: the kernel's LDS table of a group's gamma / beta)

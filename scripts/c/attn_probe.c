@@ -27,7 +27,11 @@ int main(int argc, char** argv) {
   HK(hipEventCreate(&e1));
   double class_ms = 0.0, class_gflop = 0.0;
   printf("# elem %s, %d launches per shape after 3 warm-up launches, %d-buffer rotation\n", f16 ? "fp16" : "bf16", reps, NBUF);
+#ifdef ONLY_FIRST_SHAPE /* (power measurements: one shape, many launches) */
+  for (size_t s = 0; s < 1; ++s) {
+#else
   for (size_t s = 0; s < sizeof(SHAPES) / sizeof(SHAPES[0]); ++s) {
+#endif
     const Shape sh = SHAPES[s];
     const int C = sh.H * sh.D;
     void *Q[NBUF], *KV[NBUF], *O[NBUF];
@@ -59,7 +63,7 @@ int main(int argc, char** argv) {
     printf("sdpa %dx%2dx%4dx%4dx%d %s  x%3d/step  %8.2f us  %7.1f TFLOP/s  %7.3f ms/step  out %016llx\n", sh.B, sh.H, sh.Sq, sh.Skv,
            sh.D, sh.self ? "self " : "cross", sh.per_step, us, gflop / us * 1e3, us * sh.per_step * 1e-3,
            (unsigned long long)device_fnv(O[0], (size_t)sh.B * sh.Sq * C * 2));
-    if (getenv("MI355X_SD_ATTN_ABL") && atoi(getenv("MI355X_SD_ATTN_ABL")) == 64 && sh.self) { /* debug build: the kernel left clock stamps in O */
+    if (getenv("MI355X_SD_ATTN_STAMP") && sh.self) { /* debug-switch build (-lmi355x_sd_dbg): the kernel left clock stamps in the last query row */
       unsigned long long d[4];
       HK(hipMemcpy(d, (const char*)Q[0] + (((size_t)(sh.B - 1) * sh.Sq * 3 * C + (size_t)(sh.Sq - 1) * 3 * C + C - 16) * 2), sizeof(d), hipMemcpyDeviceToHost));
       printf("   shader clock while this launch ran: %.0f MHz (block 8: %llu s_memtime ticks in %llu wall ticks of 10 ns), %.0f MHz (a block of the second half)\n",

@@ -7,7 +7,7 @@ instruction of such a kernel other than the hand-written ones (the asm buffer lo
 it) names a register >= v216. WHICH kernels: every kernel whose code contains the marker instruction gemm_epilogue_pre emits
 (`s_mov_b32 m0, m0`), not a list of names.
 
-    python scripts/check_landing_zone.py [lib.so ...]          (default: both built libraries; runs without a GPU)
+    python scripts/check_landing_zone.py [lib.so ...]          (default: the three built libraries; runs without a GPU)
 """
 import os
 import re
@@ -94,7 +94,7 @@ def check_disassembly(text, label):
 
 
 def main():
-    libs = sys.argv[1:] or [os.path.join(ROOT, "paddlemix_amd", n) for n in ("libmi355x_sd.so", "libmi355x_sd_f16.so")]
+    libs = sys.argv[1:] or [os.path.join(ROOT, "paddlemix_amd", n) for n in ("libmi355x_sd.so", "libmi355x_sd_f16.so", "libmi355x_sd_dbg.so")]
     fail = False
     for lib in libs:
         if lib.endswith(".s"):   # an assembly listing (hipcc -S): same rule, labels instead of symbols

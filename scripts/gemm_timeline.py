@@ -9,6 +9,8 @@ block's end).      python scripts/gemm_timeline.py [--iters 5]
 """
 import argparse
 import os
+
+os.environ.setdefault("MI355X_SD_LIB", "dbg")   # the time-stamp hook is an A/B switch: debug-switch build only (csrc/common.h sd_switch)
 import sys
 
 import torch
@@ -21,7 +23,7 @@ args = ap.parse_args()
 
 MAXB = 1 << 16
 ts = torch.zeros(MAXB * 6, dtype=torch.int64, device="cuda")
-os.environ["MI355X_SD_GEMM_TSTAMP"] = hex(ts.data_ptr())   # read once, at the first GEMM launch
+os.environ["MI355X_SD_GEMM_TSTAMP"] = hex(ts.data_ptr())   # (needs the debug-switch build: MI355X_SD_LIB=dbg, set at the top)   # read once, at the first GEMM launch
 
 from paddlemix_amd import ops  # noqa: E402
 

@@ -23,7 +23,7 @@ def _run(env_extra):
 
 
 def _run_child(env_extra):
-    env = dict(os.environ, **env_extra)
+    env = dict(os.environ, MI355X_SD_LIB="dbg", **env_extra)   # the A/B switches exist in the debug-switch build only
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gemm_variant_child.py")], env=env, cwd=ROOT, capture_output=True,
                        text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
