@@ -313,7 +313,7 @@ def main():
             dev_sync()
 
     # board clock / power WHILE the timed steps run (rank 0; one `rocm-smi` call from a helper thread ~0.4 s into the region: a host
-    # process, nothing on the GPU): the step is power-managed, so `value` is what the chip does at
+    # process, nothing on the GPU): the step is power-managed (profiles/HISTORY.md section 5, round 4), so `value` is what the chip does at
     # THIS clock -- recorded next to it, never used in a formula. Absent tool / unparsable output: the field is null.
     board = {}
 

@@ -50,7 +50,13 @@ int mi355x_sd_init(int device);
  * mi355x_sd_conv3x3. Launches that cannot fill the 256 CUs (batch-1 SD-1.5: 64..1024 rows against K up to 23040)
  * split K over blockIdx.y, store fp32 slices here and reduce them in fixed order (deterministic). The pointer is read at
  * launch time, so one stream's launches must not share a workspace with launches running concurrently on another
- * stream. ptr == NULL (the initial state) disables split-K. The library never allocates ("no hidden allocation"). */
+ * stream. ptr == NULL (the initial state) disables split-K. The library never allocates ("no hidden allocation").
+ * SECOND USE (weight-only fp8, mi355x_sd_linear_ex with w_scale != NULL): launches of M >= 4096 rows and more than 128 tiles widen
+ * the e4m3 matrix once, just in time, into the first 2 * N * K bytes of this buffer and multiply by the 16-bit kernels (up to
+ * ~19 MB for SD3-medium's 6144 x 1536 matrices). A workspace smaller than that is not an error -- the launch silently takes the
+ * slower path that converts in the fragment load (same result to fp32 rounding) -- so size it for max(split-K need, 2 * N * K of the
+ * largest fp8 matrix); 32 MiB covers every model of this repository. An exported program's speed depends on the size bound at
+ * replay the same way. */
 int mi355x_sd_set_workspace(void* ptr, size_t bytes);
 
 /* ---- seam B1: the whole UNet2DConditionModel behind one handle (paddlemix_amd/csrc/unet_exec.hip) ----------------------------
@@ -161,7 +167,7 @@ int mi355x_sd_mask_to_bias(const float* mask, float* bias, int64_t n, void* stre
                               * 455, 487, transformer_2d.py:467) never round to 16 bits; combine with MI355X_SD_OUT_F32 */
 #define MI355X_SD_CONV_KB64 64 /* conv3x3, Cin % 64 == 0: W is packed [O][Cin/64][3][3][64] instead of [O][3][3][Cin] -- the K loop then walks the 9
                               * taps of one 64-channel block back to back, so the eight re-reads of a [pixels x 64 channels] region hit the XCD's
-                              * L2 (32 KB per block) instead of coming back through the fabric a full channel sweep later */
+                              * L2 (32 KB per block) instead of coming back through the fabric a full channel sweep later (measured: profiles/HISTORY.md section 5) */
 #define MI355X_SD_PAD_BR 16  /* conv3x3, stride 2 only: zero padding is one row / column at the bottom / right instead of all round
                               * (Downsample2D with padding=0: F.pad (0,1,0,1) then an unpadded conv, PPD/models/resnet.py:277-279 --
                               * the VAE encoder's downsamplers, vae.py:113) */
@@ -179,6 +185,8 @@ int mi355x_sd_linear(const void* A, int lda, const void* W, void* C, int ldc, in
  *   gate  : out = R + gate[m / rows_per_batch][n] * (acc + bias)     (adaLN-Zero gated residuals, attention.py:181-196)
  *   a_/c_ rows_per_batch + batch_stride: row m of A (C) lives at (m / rpb) * batch_stride + (m % rpb) * lda (ldc) -- the
  *   w_scale != NULL: W is OCP fp8 e4m3 [N][K] (one byte per element) with a per-output-channel fp32 scale, W ~ w_scale[n] * q;
+ *     every w_scale[n] must be > 0 (clamp an all-zero channel's absmax / 448 to a tiny positive number, as the library's own
+ *     quantiser does): the widened path starts the accumulators at bias[n] / w_scale[n];
  *   the kernel widens q to bf16 in registers (exact) and scales the fp32 accumulator (weight-only fp8: BASELINE config 5).
  *   projections of the image and the text tokens read / write one joint [B, S_img + S_txt, .] buffer in place, which is
  *   the fused split + concat of paddlemix/triton_ops/triton_ops.py:1652-1752 (split_concat) folded into the GEMMs. */
@@ -275,7 +283,7 @@ int mi355x_sd_sdpa(const void* q, const void* k, const void* v, const float* bia
  * hidden = attn(q, to_k(text), to_v(text)) + self.scale * attn(q, to_k_ip(image tokens), to_v_ip(image tokens)) (:1871-1886). */
 /* mi355x_sd_sdpa with flags. MI355X_SD_SDPA_LOG2: the caller has folded scale * log2(e) into the queries (e.g. into the to_q
  * weights), so q.k IS the base-2 exponent: out = softmax_2(q k^T) v with softmax_2(x) = 2^x / sum 2^x; `scale` is ignored, no mask,
- * D == 64. Saves the multiply-add per score in front of every exponential. */
+ * D == 64. Saves the multiply-add per score in front of every exponential (profiles/HISTORY.md section 5). */
 #define MI355X_SD_SDPA_LOG2 1
 int mi355x_sd_sdpa_ex(const void* q, const void* k, const void* v, const float* bias, void* out, int B, int H, int Sq, int Skv, int D,
                       int64_t q_bs, int q_ts, int64_t k_bs, int k_ts, int64_t v_bs, int v_ts, int64_t o_bs, int o_ts,

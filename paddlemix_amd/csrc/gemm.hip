@@ -372,14 +372,18 @@ __global__ __launch_bounds__(256) void widen_fp8_kernel(const unsigned* __restri
   }
 }
 static bool widen_fp8_applies(const GemmArgs& a) {
-  static const bool off = sd_switch("MI355X_SD_NO_WIDEN_F8") != nullptr;   // A/B switch (tests/test_gpu_switches.py: same bits)
+  static const bool off = sd_switch("MI355X_SD_NO_WIDEN_F8") != nullptr;   // A/B switch (tests/test_gpu_switches.py: equal to fp32 rounding, not the same bits)
   if (off) return false;
   if (!a.wscale || a.w16 || !g_ws || a.conv || a.rowstat || (a.K & 63) || (a.N & 3)) return false;
   if ((size_t)a.N * a.K * 2 > g_ws_bytes || (reinterpret_cast<uintptr_t>(a.W) & 3)) return false;
   const long tiles = (long)((a.M + 255) / 256) * ((a.N + 159) / 160);
   // (launches of <= 128 tiles may take split-K slices: plan_splitk. M >= 4096: below that -- the 1232-row context stream of SD3 at
   // bs 8 -- a launch is about as long as the widening pass itself and reads the matrix once either way)
-  return tiles > 128 && a.M >= 4096;
+  static const int min_m = [] {   // A/B switch of the debug build: MI355X_SD_WIDEN_F8_MIN_M
+    const char* e = sd_switch("MI355X_SD_WIDEN_F8_MIN_M");
+    return e ? atoi(e) : 4096;
+  }();
+  return tiles > 128 && a.M >= min_m;
 }
 
 int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
@@ -423,7 +427,7 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
   // its L2 pulls through the fabric per round is (32/g) A row-panels + g W column-panels, minimal at g = sqrt(32 BM / BN): 7.2 for
   // the 256x160 tile, 5.1 for 256x320. Round 2 measured g = 4 and 8 inside the step (one g for every tile family) as equal in time
   // (60.37 / 60.47 ms); the 160-wide launches -- fused QKV walks 24 column tiles -- take 8: their A panels come through the fabric
-  // 3 instead of 6 times (the counter traffic of the class, not its time: the loop does not wait for L2).
+  // 3 instead of 6 times (the counter traffic of the class, not its time: the loop does not wait for L2, profiles/HISTORY.md section 5).
   if (tile == 160 || tile == 129) a.gm = -8;
   if (tile == 128) plan_splitk(a, 128, 128);
   if (a.rowstat && (a.conv || a.wscale || a.a_rpb || a.c_rpb || a.R || a.rowbias || a.gate || !a.wsum))

@@ -2,6 +2,8 @@
 launches (eager run with optional per-launch HIP-event timing, hipGraph capture / replay on the model's stream)."""
 from __future__ import annotations
 
+import contextvars
+
 import ctypes
 from typing import Dict
 
@@ -9,7 +11,8 @@ import torch
 
 from . import _lib
 
-WORKSPACE_BYTES = 32 << 20   # split-K partial sums (the planner shrinks the split count to fit)
+WORKSPACE_BYTES = 32 << 20   # split-K partial sums (the planner shrinks the split count to fit) AND the just-in-time widened copy of a
+                             # weight-only-fp8 matrix (2 * N * K bytes, <= ~19 MB for SD3-medium): include/mi355x_sd.h mi355x_sd_set_workspace
 
 
 class _Ref:
@@ -43,14 +46,18 @@ class _Plan:
 # constructor call), models built meanwhile send their C-ABI calls to it instead of the HIP library -- the host logic of every
 # model then runs on a machine without a GPU. Product code never pushes anything: the library is the only backend it selects, and
 # a missing library or GPU is an error, not a fallback.
-_BACKEND_OVERRIDE: list = []
+# A context variable, not a module global: the override is seen by the thread / task that set it and by nobody else (a model built
+# meanwhile on another thread gets the HIP library), and it must be an object that SAYS it is a test backend.
+_BACKEND_OVERRIDE: contextvars.ContextVar = contextvars.ContextVar("mi355x_sd_test_backend", default=None)
 
 
 class DeviceProgram:
     """Backend selection + execution of a plan (``plan.prog``: list of (cfunc, args, kind, flops))."""
 
     def _init_backend(self, device, use_graph: bool, profile: bool):
-        _test_backend = _BACKEND_OVERRIDE[-1] if _BACKEND_OVERRIDE else None
+        _test_backend = _BACKEND_OVERRIDE.get()
+        if _test_backend is not None and not getattr(_test_backend, "IS_TEST_BACKEND", False):
+            raise TypeError("paddlemix_amd.program._BACKEND_OVERRIDE holds something that is not a test backend")
         self._emulated = _test_backend is not None
         if self._emulated:
             self._lib = _test_backend

@@ -1104,7 +1104,7 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
         L = encoder_hidden_states.shape[1]
         plan = self._get_plan(B, H, W, L, encoder_attention_mask is not None, controlnet, self_mask_len)
         if self._emulated:
-            self.stage_inputs(plan, sample, timestep, encoder_hidden_states, added_cond_kwargs,
+            self.stage_inputs(plan, sample, timestep, encoder_hidden_states, added_cond_kwargs, in_scale=1.0,
                               encoder_attention_mask=encoder_attention_mask, **ctrl)
             self._run_eager(plan)
             out = plan.out.clone()
@@ -1112,7 +1112,10 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
             cur = torch.cuda.current_stream(self.device)
             self._stream.wait_stream(cur)
             with torch.cuda.stream(self._stream):
-                self.stage_inputs(plan, sample, timestep, encoder_hidden_states, added_cond_kwargs,
+                # in_scale = 1: forward() takes the sample as the model input. (A host that drives the same geometry through the staged API
+                # with scale_model_input folded into conv_in -- bench.py does -- leaves its factor in the plan; round 5's bs-8 parity leg
+                # read 0.68 instead of 1.2e-2 through exactly that.)
+                self.stage_inputs(plan, sample, timestep, encoder_hidden_states, added_cond_kwargs, in_scale=1.0,
                                   encoder_attention_mask=encoder_attention_mask, **ctrl)
                 out = self.run(plan).clone()
             cur.wait_stream(self._stream)
@@ -1295,7 +1298,7 @@ class ControlNetModel(UNet2DConditionModel):
             raise ValueError(f"controlnet_cond of shape {tuple(controlnet_cond.shape)}, expected {tuple(plan.cond.shape)}")
 
         def stage(nb):
-            self.stage_inputs(plan, sample, timestep, encoder_hidden_states, added_cond_kwargs,
+            self.stage_inputs(plan, sample, timestep, encoder_hidden_states, added_cond_kwargs, in_scale=1.0,
                               encoder_attention_mask=encoder_attention_mask, class_labels=class_labels,
                               timestep_cond=timestep_cond)
             plan.cond.copy_(controlnet_cond, non_blocking=nb)

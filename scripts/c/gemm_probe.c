@@ -9,7 +9,7 @@
  *   gcc -std=c11 -O2 -I/opt/rocm/include -Iinclude -Iscripts/c scripts/c/gemm_probe.c -Lpaddlemix_amd -lmi355x_sd -L/opt/rocm/lib -lamdhip64 -lm \
  *       -Wl,-rpath,/opt/rocm/lib -o /tmp/gemm_probe
  *   LD_LIBRARY_PATH=paddlemix_amd /tmp/gemm_probe [reps=20]
- * Isolated launches run at a higher clock than the same kernels inside the step: use this for A/B
+ * Isolated launches run at a higher clock than the same kernels inside the step (profiles/HISTORY.md section 5, round 4): use this for A/B
  * between variants, bench.py / scripts/c/step_bench.c for what a change is worth in the step. */
 #include "probe_common.h"
 

@@ -30,6 +30,9 @@ def code_objects(lib):
     sec = os.path.join(tmp, "fatbin")
     subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, sec], check=True)
     data = open(sec, "rb").read()
+    if b"CCOB" in data[:64] and b"__CLANG_OFFLOAD_BUNDLE__" not in data:
+        sys.exit(f"{lib}: the device code is a COMPRESSED offload bundle (CCOB): build without --offload-compress, or unbundle with "
+                 "clang-offload-bundler first -- this script reads uncompressed bundles")
     # uncompressed bundles: "__CLANG_OFFLOAD_BUNDLE__" header, entries (offset, size, triple)
     pos = 0
     idx = 0

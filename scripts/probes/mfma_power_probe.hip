@@ -1,7 +1,7 @@
 // Probe (round 4): what do the two bf16 MFMA shapes cost at the wall -- rate, clock and board power -- when nothing but MFMAs runs?
 // The GEMM kernels of this library use v_mfma_f32_16x16x32_bf16 (a lane owns 4 consecutive output channels: cheap epilogues); the
 // 32x32x16 shape reads half as many operand registers per FLOP and is the one MI355X_MICROARCH.md quotes the 2.5 PFLOP/s peak for.
-// The step is power-managed, so the energy per FLOP of the shape is a throughput question.
+// The step is power-managed (profiles/HISTORY.md section 5, round 4), so the energy per FLOP of the shape is a throughput question.
 //   hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_probe scripts/probes/mfma_power_probe.hip && /tmp/mfma_probe <shape 16|32> <seconds> <fill 0|1>
 // Every CU gets one block of 8 waves (2 per SIMD, like the GEMM kernels); a wave cycles through 4 A and 5 B fragments of random (or
 // zero) bf16 data and 20 (16x16: 80 registers) / 5 (32x32: 80 registers) independent accumulators. Prints TFLOP/s; run rocm-smi beside it.

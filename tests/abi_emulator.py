@@ -36,6 +36,8 @@ def _rows(ptr: int, rows: int, C: int, ld: int, dtype=None) -> torch.Tensor:
 
 
 class Emulator:
+    IS_TEST_BACKEND = True   # what paddlemix_amd.program accepts in its override slot (anything else is refused)
+
     def __init__(self):
         self.calls = []
 
@@ -497,8 +499,8 @@ def on_emulator(ctor, *args, backend=None, **kwargs):
     to ``backend`` (a fresh Emulator by default) instead of the HIP library: the one test hook of the product
     (paddlemix_amd/program.py _BACKEND_OVERRIDE), held only for the duration of the constructor call."""
     from paddlemix_amd import program
-    program._BACKEND_OVERRIDE.append(backend if backend is not None else Emulator())
+    token = program._BACKEND_OVERRIDE.set(backend if backend is not None else Emulator())   # a ContextVar: this thread only
     try:
         return ctor(*args, **kwargs)
     finally:
-        program._BACKEND_OVERRIDE.pop()
+        program._BACKEND_OVERRIDE.reset(token)

@@ -27,7 +27,9 @@ _CACHE = {}
 def _run(env_extra):
     key = tuple(sorted(env_extra.items()))
     if key not in _CACHE:
-        env = dict(os.environ, MI355X_SD_LIB="dbg", **env_extra)
+        env = dict(os.environ)
+        env.update(MI355X_SD_LIB="dbg")
+        env.update(env_extra)
         if env_extra.get("MI355X_SD_LIB") == "":   # (the production library)
             env.pop("MI355X_SD_LIB")
         p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "switch_child.py")], env=env, cwd=ROOT,

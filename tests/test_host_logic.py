@@ -52,6 +52,23 @@ def test_program_matches_oracle(cfg, B, H, W, L):
     assert "linear_ln" in emu2.calls and _rel(out3, ref) < 2e-2
 
 
+def test_forward_after_staged_steps_takes_the_sample_as_is():
+    """A host that drives a geometry through the staged API with scale_model_input folded into conv_in (stage_inputs(in_scale=...),
+    what bench.py's timed loop does) leaves its factor in the plan; forward() on the same geometry must not inherit it -- the bs-8
+    parity leg of the round-5 bench line read 0.68 through exactly that."""
+    cfg = TINY
+    P = synth_unet_params(cfg, seed=1234)
+    sample, enc, added = _inputs(cfg, 2, 16, 16, 7)
+    model = on_emulator(UNet2DConditionModel, cfg, P)
+    ref = model(sample, 501, enc, added_cond_kwargs=added).sample.clone()
+    plan = model._get_plan(2, 16, 16, 7, False, False, 0)
+    assert len(model._plans) == 1                          # the plan forward() built and will use again
+    model.stage_inputs(plan, sample, 501, enc, added, in_scale=0.25)
+    model._run_eager(plan)
+    assert _rel(plan.out, ref) > 1e-2                      # the staged call did scale its input
+    assert torch.equal(model(sample, 501, enc, added_cond_kwargs=added).sample, ref)
+
+
 @pytest.mark.parametrize("cfg,B,H,W,L", [(TINY, 2, 16, 16, 7), (MINI_XL, 1, 16, 16, 77)])
 def test_fp32_residual_stream_program(cfg, B, H, W, L):
     """residual_dtype="fp32": resnet outputs / transformer hidden state / skip slots are fp32 rows, 16-bit values exist only
