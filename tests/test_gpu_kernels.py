@@ -363,6 +363,34 @@ def test_sdpa_fused_qkv_strides_and_spike(ops):
     check(out, ref, rel=5e-3, what="sdpa fused qkv")
 
 
+@pytest.mark.parametrize("log2", [False, True])
+@pytest.mark.parametrize("tile,half", [(5, 0), (5, 1), (15, 1), (14, 0), (1, 0)])
+def test_sdpa_lazy_maximum_guard_fires(ops, tile, half, log2):
+    """The unmasked d = 64 kernels exponentiate against a running reference without looking for a tile's maximum and redo a tile the
+    exact way when a partial row sum leaves the safe range (csrc/attention.hip, LAZY_PSUM_LIMIT: 2^60, 2^15 in the IEEE-half build).
+    Bounded random data never takes that branch (cdna guide 5.4 rule 26): the keys from one half-tile on are scaled up so that the
+    scores jump by tens of base-2 units there -- at the first and the second half of a tile, the last and the second-to-last tile,
+    and right after the first tile -- in the plain and the folded-scale (log2) form. scripts/c/attn_check.c does the same against a
+    host float64 reference without torch."""
+    from paddlemix_amd import _lib
+    g = torch.Generator().manual_seed(100 * tile + half)
+    B, H, Sq, Skv, D = 1, 3, 512, 1024, 64
+    f = 6.0 if _lib.elem_dtype() == torch.float16 else 24.0
+    q = bfr(torch.randn(B, Sq, H, D, generator=g) * (0.35 if log2 else 1.0))
+    k = torch.randn(B, Skv, H, D, generator=g)
+    k[:, tile * 64 + half * 32:] *= f
+    k = bfr(k)
+    v = bfr(torch.randn(B, Skv, H, D, generator=g))
+    if log2:   # q.k IS the base-2 exponent: softmax_2(q k^T) v = softmax(q k^T ln 2) v
+        ref = U.sdpa_math(q.double(), k.double(), v.double(), scale=math.log(2.0)).float()
+        out = ops.sdpa(dev(q), dev(k), dev(v), log2=True)
+    else:
+        ref = U.sdpa_math(q.double(), k.double(), v.double()).float()
+        out = ops.sdpa(dev(q), dev(k), dev(v))
+    assert torch.isfinite(out.float()).all()
+    check(out, ref, rel=5e-3, what=f"sdpa guard tile {tile} half {half} log2 {log2}")
+
+
 def test_sdpa_additive_mask(ops):
     """mask semantics of test_model_xattn_mask (tests/models/test_models_unet_2d_condition.py:486-515): keep-all ==
     none; masking the last key == truncating it (bias = (1-m)*-10000, unet_2d_condition.py:921-927)."""
