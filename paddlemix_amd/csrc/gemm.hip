@@ -212,7 +212,7 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_bf16_kernel(const GemmAr
     return;
   }
   if constexpr (LN) gemm_epilogue_ln<TM, TN>(p, acc, m0 + wm * (TM * 16), n0 + wn * (TN * 16), lane);
-  else gemm_epilogue<TM, TN>(p, acc, m0 + wm * (TM * 16), n0 + wn * (TN * 16), lane);
+  else gemm_epilogue<TM, TN, W8>(p, acc, m0 + wm * (TM * 16), n0 + wn * (TN * 16), lane);   // (W8 launches always carry the scale)
 }
 
 // Deterministic split-K tail: wave = 16 rows x 32 columns in the MFMA accumulator layout, slices summed in index
@@ -324,8 +324,9 @@ static int pick_tile_model(const GemmArgs& a) {
   int best = 128;
   double best_cost = 1e30;
   for (const TileChoice& c : cand) {
-    if (c.id == 257 && ((a.K & 63) || (a.conv && (a.Cin & 63)) || !wide_ok || a.a_rpb || a.wscale)) continue;   // (its epilogue set has no weight scale)
+    if (c.id == 257 && ((a.K & 63) || (a.conv && (a.Cin & 63)) || !wide_ok || a.a_rpb || w_is_f8(a))) continue;   // (16-bit operands only; a widened e4m3 matrix is one)
     if (a.geglu && c.id == 160) continue;   // odd number of 16-column tiles per wave
+    if (c.id == 320 && a.wscale && a.w16 && !a.geglu) continue;   // widened e4m3 matrix: the tiles whose epilogue holds the scale in registers
     if (c.id == 256 && !w_is_f8(a) && !a.a_rpb) continue;   // the plain 256x256 loop only where the phased kernel cannot run
     const long tiles = (long)((a.M + c.bm - 1) / c.bm) * ((a.N + c.bn - 1) / c.bn);
     const long per_cu = (tiles + 255) / 256;
@@ -364,18 +365,26 @@ int gemm_gm() { return GEMM_GM_DEFAULT; }
 // bias / scale instead of being added after the scale: equal to fp32 rounding). HBM keeps holding one byte per weight.
 // Small-M launches (the 1232-row context stream at bs 8, anything that takes split-K slices) ARE weight-bound and stay on the
 // generic fp8 loop, whose split-K partial sums own the workspace.
-__global__ __launch_bounds__(256) void widen_fp8_kernel(const unsigned* __restrict__ w8, u32x2* __restrict__ w16, long n4) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-    const unsigned raw = w8[i];
-    const auto f0 = __builtin_amdgcn_cvt_pk_f32_fp8(raw, false), f1 = __builtin_amdgcn_cvt_pk_f32_fp8(raw, true);
-    w16[i] = u32x2{pack_bf16(f0[0], f0[1]), pack_bf16(f1[0], f1[1])};
+__global__ __launch_bounds__(256) void widen_fp8_kernel(const u32x4* __restrict__ w8, u32x4* __restrict__ w16, long n16) {
+  // 16 weights per lane and trip: one 16-byte load, two 16-byte stores (round 5; 4-byte loads kept too few bytes in flight)
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) {
+    const u32x4 raw = __builtin_nontemporal_load(w8 + i);
+    u32x4 o[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const auto f0 = __builtin_amdgcn_cvt_pk_f32_fp8(raw[j], false), f1 = __builtin_amdgcn_cvt_pk_f32_fp8(raw[j], true);
+      o[j >> 1][(j & 1) * 2] = pack_bf16(f0[0], f0[1]);
+      o[j >> 1][(j & 1) * 2 + 1] = pack_bf16(f1[0], f1[1]);
+    }
+    w16[2 * i] = o[0];
+    w16[2 * i + 1] = o[1];
   }
 }
 static bool widen_fp8_applies(const GemmArgs& a) {
   static const bool off = sd_switch("MI355X_SD_NO_WIDEN_F8") != nullptr;   // A/B switch (tests/test_gpu_switches.py: equal to fp32 rounding, not the same bits)
   if (off) return false;
   if (!a.wscale || a.w16 || !g_ws || a.conv || a.rowstat || (a.K & 63) || (a.N & 3)) return false;
-  if ((size_t)a.N * a.K * 2 > g_ws_bytes || (reinterpret_cast<uintptr_t>(a.W) & 3)) return false;
+  if ((size_t)a.N * a.K * 2 > g_ws_bytes || (reinterpret_cast<uintptr_t>(a.W) & 15) || (reinterpret_cast<uintptr_t>(g_ws) & 15)) return false;
   const long tiles = (long)((a.M + 255) / 256) * ((a.N + 159) / 160);
   // (launches of <= 128 tiles may take split-K slices: plan_splitk. M >= 4096: below that -- the 1232-row context stream of SD3 at
   // bs 8 -- a launch is about as long as the widening pass itself and reads the matrix once either way)
@@ -388,9 +397,9 @@ static bool widen_fp8_applies(const GemmArgs& a) {
 
 int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
   if (widen_fp8_applies(a_in)) {
-    const long n4 = (long)a_in.N * a_in.K / 4;
-    hipLaunchKernelGGL(widen_fp8_kernel, dim3((unsigned)std::min<long>((n4 + 255) / 256, 4096)), dim3(256), 0, stream,
-                       reinterpret_cast<const unsigned*>(a_in.W), reinterpret_cast<u32x2*>(g_ws), n4);
+    const long n16 = (long)a_in.N * a_in.K / 16;   // (K % 64 == 0)
+    hipLaunchKernelGGL(widen_fp8_kernel, dim3((unsigned)std::min<long>((n16 + 255) / 256, 4096)), dim3(256), 0, stream,
+                       reinterpret_cast<const u32x4*>(a_in.W), reinterpret_cast<u32x4*>(g_ws), n16);
     GemmArgs b = a_in;
     b.W = reinterpret_cast<const bf16*>(g_ws);
     b.w16 = 1;

@@ -51,7 +51,7 @@ constexpr int LDS_BYTES = 2 * BUF;        // 128 KB
 // per-channel (W) dequantisation scales are applied to the fp32 accumulators in gemm_epilogue_f8.
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 
-template <bool CONV, bool LN = false, bool F8 = false>
+template <bool CONV, bool LN = false, bool F8 = false, bool WS = false>   // WS: per-channel weight scale in registers (gemm_epilogue.h)
 __global__ __launch_bounds__(g256::THREADS, 2) void gemm256_kernel(const GemmArgs p) {
   using namespace g256;
   constexpr int ES = F8 ? 1 : 2;        // bytes per element
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(g256::THREADS, 2) void gemm256_kernel(const GemmArg
 
   if constexpr (F8) gemm_epilogue_f8<8, 4>(p, acc, m0 + grp * 128, n0 + wc * 64, lane);
   else if constexpr (LN) gemm_epilogue_ln<8, 4>(p, acc, m0 + grp * 128, n0 + wc * 64, lane);
-  else gemm_epilogue<8, 4>(p, acc, m0 + grp * 128, n0 + wc * 64, lane);
+  else gemm_epilogue<8, 4, WS>(p, acc, m0 + grp * 128, n0 + wc * 64, lane);
 }
 
 int launch_gemm256(const GemmArgs& a, hipStream_t stream) {
@@ -272,6 +272,8 @@ int launch_gemm256(const GemmArgs& a, hipStream_t stream) {
            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<false, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess &&
            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<false, false, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess &&
+           hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<false, false, false, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
   }();
   if (!attr_ok) return SD_ERR_HIP;
@@ -283,6 +285,8 @@ int launch_gemm256(const GemmArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL((gemm256_kernel<false, true>), dim3(ntm * ntn), dim3(THREADS), LDS_BYTES, stream, b);
   else if (a.conv)
     hipLaunchKernelGGL(gemm256_kernel<true>, dim3(ntm * ntn), dim3(THREADS), LDS_BYTES, stream, b);
+  else if (a.wscale)   // a widened e4m3 matrix (launch_gemm) with its per-channel scale
+    hipLaunchKernelGGL((gemm256_kernel<false, false, false, true>), dim3(ntm * ntn), dim3(THREADS), LDS_BYTES, stream, b);
   else
     hipLaunchKernelGGL(gemm256_kernel<false>, dim3(ntm * ntn), dim3(THREADS), LDS_BYTES, stream, b);
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;

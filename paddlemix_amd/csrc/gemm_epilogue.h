@@ -82,9 +82,11 @@ struct Epi4Ops {
 __device__ __forceinline__ bool epi_batched(const GemmArgs& p) {
   return p.epi_batch && !p.geglu && !(p.gate && (p.rowbias || (p.R && p.r_f32)));
 }
+template <bool WS = false>
 __device__ __forceinline__ f32x4 epi4(const GemmArgs& p, f32x4 v, int m, int n, const float* rb, const float* gt, bool batched,
-                                      const Epi4Ops& o) {
-  if (p.wscale) v *= *reinterpret_cast<const f32x4*>(p.wscale + n);
+                                      const Epi4Ops& o, const f32x4& wsc) {
+  if constexpr (WS) v *= wsc;   // (the weight-scale instantiations: the scale is in registers, gemm_epilogue below)
+  else if (p.wscale) v *= *reinterpret_cast<const f32x4*>(p.wscale + n);
   if (p.bias && !p.bias_acc) v += *reinterpret_cast<const f32x4*>(p.bias + n);
   if (batched) {
     if (gt) v *= o.x;
@@ -162,10 +164,26 @@ __device__ __forceinline__ void store_row(const GemmArgs& p, size_t crow, int n_
   }
 }
 
-template <int TM, int TN>
+// WS (round 5): instantiations of their own for launches with a per-channel weight scale (weight-only fp8: the generic e4m3 loop
+// and the 16-bit loops on a just-in-time widened matrix). Read where it is used -- the WS = false form, which those launches ran
+// on before -- the scale is TM x TN dependent load -> wait -> multiply round trips per wave, loads the compiler cannot hoist over
+// the stores: 3-4 us per tile, 59 us of a 32768 x 6144 x 1536 launch (profiles/r05_s17_per_shape_sd3-1024-bs8-fp8w.txt). Here the
+// lane's TN scale vectors are fetched once in front of the row-tile loop -- for tiles of up to 128 accumulator registers; the
+// 160-register tiles (256 x 320) spill 25-340 registers with 4 TN more live ones, fetched up front or per row-tile, and keep the
+// old form (launch_gemm's picker keeps widened matrices off them). Both forms were tried on ALL kernels first: the 256 x 320 kernels
+// spilled, and scaling the accumulators up front made nearly every kernel spill (header, lesson 2) -- hence separate
+// instantiations; the WS = false code is what it was.
+template <int TM, int TN, bool WS = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TN][TM], int m_wave, int n_wave,
                                               int lane) {
   const int lq = lane >> 4;
+  constexpr bool WSH = WS && TM * TN <= 32;   // (the 160-register tiles keep the read-where-used form: they spill otherwise)
+  f32x4 wsc[WSH ? TN : 1];
+  if constexpr (WSH) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+      wsc[tn] = *reinterpret_cast<const f32x4*>(p.wscale + min(n_wave + acc_col<TN>(tn, lq, p.geglu), p.N - 4));
+  }
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     const int m = m_wave + tm * 16 + (lane & 15);
@@ -208,9 +226,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TN
       }
     }
     store_row<TN>(p, crow, n_wave, lq, [&](int tn, int n) {
-      if (!p.geglu) return epi4(p, acc[tn][tm], m, n, rb, gt, batched, ops[TN <= 6 ? tn : 0]);
+      if (!p.geglu) return epi4<WSH>(p, acc[tn][tm], m, n, rb, gt, batched, ops[TN <= 6 ? tn : 0], wsc[WSH ? tn : 0]);
       f32x4 v = acc[tn][tm];   // GEGLU halves: fp8 scale and bias only (launch_gemm rejects the other operands)
-      if (p.wscale) v *= *reinterpret_cast<const f32x4*>(p.wscale + n);
+      if constexpr (WSH) v *= wsc[tn];
+      else if (p.wscale) v *= *reinterpret_cast<const f32x4*>(p.wscale + n);
       if (p.bias && !p.bias_acc) v += *reinterpret_cast<const f32x4*>(p.bias + n);
       return v;
     });
@@ -369,23 +388,37 @@ __device__ __forceinline__ void gemm_epilogue_f8(const GemmArgs& p, f32x4 (&acc)
       if (n_wave == 0 && lq == 0 && m_wave + tm * 16 + (lane & 15) < p.M) p.oscale[mc] = fmaxf(bound, 1e-12f) * (1.0f / 448.0f);
     }
   }
+  // per-channel operands of this lane's TN channel groups, fetched once; per row-tile the gate and the residual of all groups are
+  // requested back to back before the first is used (round 5: the loads used to sit inside fin(), TM x TN dependent round trips)
+  f32x4 wsc[TN], bs[TN];
+  int nc[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    nc[tn] = min(n_wave + (tn >> 1) * 32 + lq * 8 + (tn & 1) * 4, p.N - 4);
+    wsc[tn] = *reinterpret_cast<const f32x4*>(p.wscale + nc[tn]);
+    bs[tn] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nc[tn]) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     const int m = m_wave + tm * 16 + (lane & 15);
     if (m >= p.M) continue;
     const float* gt = p.gate ? p.gate + (size_t)(m / p.rows_per_batch) * p.ld_gate : nullptr;
     const size_t crow = p.c_rpb ? (size_t)(m / p.c_rpb) * p.c_bstride + (size_t)(m % p.c_rpb) * p.ldc : (size_t)m * p.ldc;
-    auto fin = [&](int tn, int n) {
-      f32x4 v = acc[tn][tm] * as[tm] * *reinterpret_cast<const f32x4*>(p.wscale + n);
-      if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-      if (gt) v *= *reinterpret_cast<const f32x4*>(gt + n);
-      if (p.R) {
-        const bf16x4 r4 = *reinterpret_cast<const bf16x4*>(p.R + (size_t)m * p.ldr + n);
-        v[0] += (float)r4[0];
-        v[1] += (float)r4[1];
-        v[2] += (float)r4[2];
-        v[3] += (float)r4[3];
-      }
+    f32x4 g4[TN];
+    u32x2 r4[TN];
+    if (gt) {
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) g4[tn] = *reinterpret_cast<const f32x4*>(gt + nc[tn]);
+    }
+    if (p.R) {
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) r4[tn] = *reinterpret_cast<const u32x2*>(p.R + (size_t)m * p.ldr + nc[tn]);
+    }
+    auto fin = [&](int tn, int) {
+      f32x4 v = acc[tn][tm] * as[tm] * wsc[tn];
+      if (p.bias) v += bs[tn];
+      if (gt) v *= g4[tn];
+      if (p.R) v = add_r16(v, r4[tn]);
       return act4(p, v);
     };
     auto q4 = [&](f32x4 v) {   // 4 x e4m3 with the row's output scale

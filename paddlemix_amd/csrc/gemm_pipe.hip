@@ -55,7 +55,7 @@ __device__ __forceinline__ void dma(__amdgpu_buffer_rsrc_t rsrc, unsigned char* 
 // PRE: the epilogue's residual / bias operands are fetched during the last K iterations (gemm_epilogue.h EpiPre). Its own
 // instantiation, not a run-time branch: two alternative consumers of the accumulators make the register allocator split their
 // live ranges and spill inside the K loop (header of gemm_epilogue.h).
-template <bool CONV, class CFG, bool LN, bool PRE>
+template <bool CONV, class CFG, bool LN, bool PRE, bool WS = false>
 __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& p) {
   static_assert(!PRE || (!LN && (CFG::TM + CFG::TN) <= 10), "early epilogue operands: register-pipelined tiles");
   constexpr int BM = CFG::BM, BN = CFG::BN, TM = CFG::TM, TN = CFG::TN, ST = CFG::STAGES, NW = CFG::NW;
@@ -486,7 +486,7 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& p) {
   } else if constexpr (PRE) {
     gemm_epilogue_pre<TM, TN>(p, acc, m_w, n_w, lane);
   } else {
-    gemm_epilogue<TM, TN>(p, acc, m_w, n_w, lane);
+    gemm_epilogue<TM, TN, WS>(p, acc, m_w, n_w, lane);
   }
   if (p.ts) {
     stamp(3);                                   // stores issued (not yet drained)
@@ -504,6 +504,12 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& p) {
 template <bool CONV, class CFG, bool LN>
 __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES) void gemm_pipe_kernel(const GemmArgs p) {
   gemm_pipe_body<CONV, CFG, LN, false>(p);
+}
+// launches with a per-channel weight scale (a just-in-time widened e4m3 matrix): the scale vectors live in registers in the
+// epilogue (gemm_epilogue.h WS) -- own instantiations so that no other kernel's register allocation sees them
+template <class CFG>
+__global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES) void gemm_pipe_ws_kernel(const GemmArgs p) {
+  gemm_pipe_body<false, CFG, false, false, true>(p);
 }
 // the early-residual form: the compiler is budgeted v0 .. v215, v216 .. v255 are the landing zone of the asm loads
 // (gemm_epilogue.h EpiPre; the attribute takes no template-dependent argument, hence the second entry point). The budget is not
@@ -560,6 +566,17 @@ static int launch_pipe(const GemmArgs& a, hipStream_t stream) {
       }();
       if (!pre_ok) return SD_ERR_HIP;
       hipLaunchKernelGGL((gemm_pipe_pre_kernel<CONV, CFG>), dim3(pipe_grid_x<CFG>(ntm * ntn, ny), ny), dim3(CFG::THREADS), CFG::LDS_BYTES, stream, a);
+      return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
+    }
+  }
+  if constexpr (!CONV && !LN) {
+    if (a.wscale && a.splitk <= 1) {   // (a.w16: launch_gemm_pipe turned e4m3 weight bytes away)
+      static const bool ws_ok = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_ws_kernel<CFG>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS_BYTES) == hipSuccess;
+      }();
+      if (!ws_ok) return SD_ERR_HIP;
+      hipLaunchKernelGGL((gemm_pipe_ws_kernel<CFG>), dim3(pipe_grid_x<CFG>(ntm * ntn, ny), ny), dim3(CFG::THREADS), CFG::LDS_BYTES, stream, a);
       return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
     }
   }

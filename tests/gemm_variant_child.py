@@ -102,4 +102,39 @@ for B, H, W, Cin, Cout in ((8, 32, 32, 1280, 1280), (2, 30, 34, 640, 1280)):    
     res[f"conv {B}x{H}x{W}x{Cin}->{Cout}"] = dict(
         sha=hashlib.sha256(out.cpu().view(torch.int16).numpy().tobytes()).hexdigest()[:16],
         rel=((out[:H * W].float() - ref).norm() / ref.norm()).item())
+# weight-only fp8 on a just-in-time widened matrix (round 5: kernel instantiations that keep the per-channel scale in registers,
+# csrc/gemm_epilogue.h WS; under MI355X_SD_NO_PIPE the same launches run the read-where-used epilogue of the generic loop): plain,
+# tanh-GELU (SD3 FF1), gate + residual (SD3 to_out / FF2), a row-remapped output (the joint QKV buffer), ragged M, ragged N
+from paddlemix_amd.sd3 import dequantize_fp8_rows, quantize_fp8_rows  # noqa: E402
+for M, N, K, kind in ((8200, 1536, 1536, "gate+R"), (4100, 6144, 1536, "gelu"), (8192, 4608, 1536, "remap"), (4096, 1540, 1536, "plain"),
+                      (16384, 1536, 6144, "gate+R")):
+    g = torch.Generator(device="cuda").manual_seed(M + N + K + 4)
+    a = torch.randn(M, K, device="cuda", generator=g).to(ed)
+    w8, ws = quantize_fp8_rows(torch.randn(N, K, device="cuda", generator=g) / K ** 0.5)
+    b = torch.randn(N, device="cuda", generator=g)
+    rows = slice(M - 256, M)
+    ref = a[rows].float() @ dequantize_fp8_rows(w8, ws).t() + b
+    if kind == "gate+R":
+        nb = 4
+        gt = torch.randn(nb, N, device="cuda", generator=g)
+        r = torch.randn(M, N, device="cuda", generator=g).to(ed)
+        out = ops.linear_ex(a, w8, b, w_scale=ws, gate=gt, rows_per_batch=(M + nb - 1) // nb, residual=r)
+        ref = r[rows].float() + gt[nb - 1] * ref
+        got = out[rows].float()
+    elif kind == "gelu":
+        out = ops.linear_ex(a, w8, b, w_scale=ws, gelu_tanh=True)
+        ref = F.gelu(ref, approximate="tanh")
+        got = out[rows].float()
+    elif kind == "remap":   # 4 batches of M/4 rows written behind 154 other rows each (what the MMDiT's joint sequence looks like)
+        rpb, extra = M // 4, 154
+        buf = torch.zeros(4 * (rpb + extra) * N, device="cuda", dtype=ed)
+        ops.linear_ex(a, w8, b, w_scale=ws, out=buf, c_rows_per_batch=rpb, c_batch_stride=(rpb + extra) * N, M=M)
+        out = buf
+        got = buf.view(4, rpb + extra, N)[3, rpb - 256:rpb].float()
+        assert (buf.view(4, rpb + extra, N)[:, rpb:] == 0).all(), "wrote outside the remapped rows"
+    else:
+        out = ops.linear_ex(a, w8, b, w_scale=ws)
+        got = out[rows].float()
+    res[f"gemm fp8w {M}x{N}x{K} {kind}"] = dict(sha=hashlib.sha256(out.cpu().view(torch.int16).numpy().tobytes()).hexdigest()[:16],
+                                                rel=((got - ref).norm() / ref.norm()).item())
 print("VARIANT_JSON " + json.dumps(res))
