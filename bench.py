@@ -435,7 +435,7 @@ def main():
         ach = d["gflop"] / d["ms"]  # GFLOP/ms == TFLOP/s
         names = {"gemm": "linear GEMM class: gemm_pipe_kernel<false,...> / gemm256_kernel<false> / gemm_bf16_kernel<false,...>",
                  "conv": "conv3x3 implicit-GEMM class: gemm_pipe_kernel<true,...> / gemm256_kernel<true>",
-                 "attn": "attention_kernel<64,false>"}
+                 "attn": "attention16_kernel<LOG2> (16x16x32 MFMA; masks / head_dim != 64: attention_kernel<64,false>)"}
         # the W8A8 workload's GEMM class runs on the fp8 matrix pipe: price it against the fp8 peak
         peak = PEAK_FP8_TFLOPS if (wl.get("a8") and dom == "gemm") else PEAK_BF16_TFLOPS
         res["roofline"] = {"bound": "mfma", "kernel": names.get(dom, dom), "achieved": ach, "peak": peak,

@@ -4,13 +4,13 @@
 #   e.g.   scripts/pmc_c.sh gemm_probe 3 gemm_pipe "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" "SQ_INSTS_VALU SQ_INSTS_LDS" "FETCH_SIZE" "WRITE_SIZE"
 # One --pmc pass per counter list, never combined with sys / hip tracing (the pool's rule); FETCH_SIZE and WRITE_SIZE in separate
 # passes (MI355X_MICROARCH.md). Prints, per kernel and grid size, the average of every counter over the launches.
-# LD_LIBRARY_PATH decides which build of the library is profiled (default: the shipped one); PMC_LIB=mi355x_sd_dbg links the
+# PMC_LIBDIR decides which directory's build of the library is profiled (default: the shipped one); PMC_LIB=mi355x_sd_dbg links the
 # debug-switch build (the only one that reads the MI355X_SD_* A/B switches).
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 P=$1; A=$2; KN=$3; shift 3
 L="-I/opt/rocm/include -I$R/include -L$R/paddlemix_amd -l${PMC_LIB:-mi355x_sd} -L/opt/rocm/lib -lamdhip64 -lm -Wl,-rpath,/opt/rocm/lib"
 gcc -std=c11 -O2 $R/scripts/c/$P.c $L -o /tmp/$P || exit 1
-export LD_LIBRARY_PATH=${LD_LIBRARY_PATH:-$R/paddlemix_amd}
+export LD_LIBRARY_PATH=${PMC_LIBDIR:-$R/paddlemix_amd}${LD_LIBRARY_PATH:+:$LD_LIBRARY_PATH}
 cd /tmp && export TMPDIR=/tmp
 i=0
 for C in "$@"; do
