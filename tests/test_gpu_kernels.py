@@ -602,6 +602,7 @@ def test_fp32_residual_forms_of_the_norms(ops, rows, C):
     R = torch.randn(rows, N, generator=g).cuda() * 7
     bias = torch.randn(N, generator=g).cuda()
     out = torch.empty(rows, N, device="cuda")
+    ops._bind_workspace(a.device)   # (a direct ABI call: the split-K workspace is whatever was bound last -- bind the wrappers' own)
     _lib.check(lib.mi355x_sd_linear(a.data_ptr(), C, w.data_ptr(), out.data_ptr(), N, rows, N, C, bias.data_ptr(), None, 0, 0,
                                     R.data_ptr(), N, 1.0, _lib.OUT_F32 | _lib.R_F32, st))
     want = a.float() @ w.float().t() + bias + R
