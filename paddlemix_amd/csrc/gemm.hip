@@ -365,20 +365,31 @@ int gemm_gm() { return GEMM_GM_DEFAULT; }
 // bias / scale instead of being added after the scale: equal to fp32 rounding). HBM keeps holding one byte per weight.
 // Small-M launches (the 1232-row context stream at bs 8, anything that takes split-K slices) ARE weight-bound and stay on the
 // generic fp8 loop, whose split-K partial sums own the workspace.
-__global__ __launch_bounds__(256) void widen_fp8_kernel(const u32x4* __restrict__ w8, u32x4* __restrict__ w16, long n16) {
-  // 16 weights per lane and trip: one 16-byte load, two 16-byte stores (round 5; 4-byte loads kept too few bytes in flight)
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) {
-    const u32x4 raw = __builtin_nontemporal_load(w8 + i);
-    u32x4 o[2];
+__device__ __forceinline__ void widen16(const u32x4 raw, u32x4* __restrict__ dst) {   // 16 e4m3 bytes -> 16 x 16-bit elements
+  u32x4 o[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const auto f0 = __builtin_amdgcn_cvt_pk_f32_fp8(raw[j], false), f1 = __builtin_amdgcn_cvt_pk_f32_fp8(raw[j], true);
-      o[j >> 1][(j & 1) * 2] = pack_bf16(f0[0], f0[1]);
-      o[j >> 1][(j & 1) * 2 + 1] = pack_bf16(f1[0], f1[1]);
-    }
-    w16[2 * i] = o[0];
-    w16[2 * i + 1] = o[1];
+  for (int j = 0; j < 4; ++j) {
+    const auto f0 = __builtin_amdgcn_cvt_pk_f32_fp8(raw[j], false), f1 = __builtin_amdgcn_cvt_pk_f32_fp8(raw[j], true);
+    o[j >> 1][(j & 1) * 2] = pack_bf16(f0[0], f0[1]);
+    o[j >> 1][(j & 1) * 2 + 1] = pack_bf16(f1[0], f1[1]);
   }
+  dst[0] = o[0];
+  dst[1] = o[1];
+}
+__global__ __launch_bounds__(256) void widen_fp8_kernel(const u32x4* __restrict__ w8, u32x4* __restrict__ w16, long n16) {
+  // 16 weights per lane and load: one 16-byte load, two 16-byte stores; four loads in flight per lane (round 5: 4-byte loads, then
+  // one 16-byte load per lane, ran at 1.5-1.8 TB/s -- profiles/r05_s24_sd3_fp8w_kernel_stats.txt: 8.6 us per launch, 0.83 ms per step)
+  const long stride = (long)gridDim.x * 256;
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    const u32x4 r0 = __builtin_nontemporal_load(w8 + i), r1 = __builtin_nontemporal_load(w8 + i + stride),
+                r2 = __builtin_nontemporal_load(w8 + i + 2 * stride), r3 = __builtin_nontemporal_load(w8 + i + 3 * stride);
+    widen16(r0, w16 + 2 * i);
+    widen16(r1, w16 + 2 * (i + stride));
+    widen16(r2, w16 + 2 * (i + 2 * stride));
+    widen16(r3, w16 + 2 * (i + 3 * stride));
+  }
+  for (; i < n16; i += stride) widen16(__builtin_nontemporal_load(w8 + i), w16 + 2 * i);
 }
 static bool widen_fp8_applies(const GemmArgs& a) {
   static const bool off = sd_switch("MI355X_SD_NO_WIDEN_F8") != nullptr;   // A/B switch (tests/test_gpu_switches.py: equal to fp32 rounding, not the same bits)
@@ -398,7 +409,9 @@ static bool widen_fp8_applies(const GemmArgs& a) {
 int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
   if (widen_fp8_applies(a_in)) {
     const long n16 = (long)a_in.N * a_in.K / 16;   // (K % 64 == 0)
-    hipLaunchKernelGGL(widen_fp8_kernel, dim3((unsigned)std::min<long>((n16 + 255) / 256, 4096)), dim3(256), 0, stream,
+    // (grid: every lane four loads where the matrix is large enough to still give each CU two blocks)
+    const long blocks1 = (n16 + 255) / 256;
+    hipLaunchKernelGGL(widen_fp8_kernel, dim3((unsigned)(blocks1 >= 2048 ? (blocks1 + 3) / 4 : blocks1)), dim3(256), 0, stream,
                        reinterpret_cast<const u32x4*>(a_in.W), reinterpret_cast<u32x4*>(g_ws), n16);
     GemmArgs b = a_in;
     b.W = reinterpret_cast<const bf16*>(g_ws);
