@@ -146,6 +146,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)   # does not return
     world = int(os.environ.get("WORLD_SIZE", 1))
+    # stdout carries ONE line, rank 0's JSON. The C libraries of the process write to fd 1 as well -- RCCL prints its version banner
+    # there when the process ends, i.e. AFTER the JSON line (profiles/r04_s3_bench_force_dist_rccl_banner.txt, r05_s26_...) -- so fd 1
+    # becomes stderr for everything except that line, which goes out through a duplicate of the original descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if args.parity_child:
@@ -537,7 +543,7 @@ def main():
             res["value_meeting_target"] = {"steps_per_s": res["parity_mode"]["steps_per_s"], "dtype": res["parity_mode"]["dtype"],
                                            "residual": res["parity_mode"]["residual"]}
     if rank == 0:
-        print(json.dumps(res))
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
     if dist is not None:
         dist.barrier()   # rank 0 ran the roofline pass meanwhile: tear the communicator down together
         dist.destroy_process_group()

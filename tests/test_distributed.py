@@ -86,17 +86,11 @@ def test_bench_gpus_n_starts_its_own_ranks():
         if p.returncode == 0 or "address already in use" not in p.stderr.lower():
             break
     assert p.returncode == 0, p.stderr[-2000:]
-    # the gloo transport of the CPU stand-in announces its connections on stdout (RCCL does not) and two ranks interleave those
-    # banners, fragments included: the JSON line is the one that parses, and there is exactly one
-    lines = []
-    for ln in p.stdout.splitlines():
-        if ln.startswith("{"):
-            try:
-                lines.append(json.loads(ln))
-            except ValueError:
-                pass
-    assert len(lines) == 1, p.stdout
-    r = lines[0]
+    # stdout is the JSON line and nothing else: bench.py points fd 1 at stderr for everything but that line (the gloo transport of
+    # the CPU stand-in announces its connections on fd 1, RCCL its version banner -- after the JSON line, at process exit)
+    out_lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(out_lines) == 1, p.stdout
+    r = json.loads(out_lines[0])
     assert r["n_gpus"] == 2 and r["steps"] == 2 and r["warmup"] == 1 and r["scaling"] == "weak" and "selftest" in r
     assert len(r["per_rank_ms_per_step"]) == 2 and r["gathered_latents"] == [4, 4, 8, 8]
     assert r["config"]["global_batch"] == 2 * r["config"]["batch_per_gpu"]
@@ -114,7 +108,9 @@ def test_bench_force_dist_runs_the_collective_path_with_one_rank():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "2", "--warmup", "1",
                         "--selftest-cpu"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
-    r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    out_lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(out_lines) == 1, p.stdout   # (one line on stdout, whatever the communication library prints)
+    r = json.loads(out_lines[0])
     assert r["n_gpus"] == 1 and r["weight_broadcast_gb"] > 0 and r["gathered_latents"] == [2, 4, 8, 8] and len(r["per_rank_ms_per_step"]) == 1
 
 
