@@ -114,6 +114,25 @@ def test_bench_force_dist_runs_the_collective_path_with_one_rank():
     assert r["n_gpus"] == 1 and r["weight_broadcast_gb"] > 0 and r["gathered_latents"] == [2, 4, 8, 8] and len(r["per_rank_ms_per_step"]) == 1
 
 
+def test_bench_single_process_prints_one_line_with_the_contract_fields():
+    """`python bench.py` with no launcher and one rank (what the driver runs for N = 1), on the CPU stand-in: stdout is ONE JSON line
+    carrying the fields of the bench contract; everything else (library banners, progress) is on stderr."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--selftest-cpu"], env=env,
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out_lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(out_lines) == 1, p.stdout
+    r = json.loads(out_lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config"):
+        assert k in r, k
+    assert r["n_gpus"] == 1 and r["steps"] == 2 and r["warmup"] == 1 and r["higher_is_better"] is True and "workload" in r["config"]
+    assert abs(r["value"] - 1e3 / r["ms_per_step"]) < 1e-6 * r["value"]
+
+
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
     import subprocess
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
