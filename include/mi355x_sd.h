@@ -50,7 +50,8 @@ int mi355x_sd_init(int device);
  * mi355x_sd_conv3x3. Launches that cannot fill the 256 CUs (batch-1 SD-1.5: 64..1024 rows against K up to 23040)
  * split K over blockIdx.y, store fp32 slices here and reduce them in fixed order (deterministic). The pointer is read at
  * launch time, so one stream's launches must not share a workspace with launches running concurrently on another
- * stream. ptr == NULL (the initial state) disables split-K. The library never allocates ("no hidden allocation").
+ * stream. ptr == NULL (the initial state) disables split-K. The library never allocates ("no hidden allocation"). A pointer the HIP
+ * runtime knows to be host / unregistered memory is refused (MI355X_SD_ERR_INVALID): the kernels write through it.
  * SECOND USE (weight-only fp8, mi355x_sd_linear_ex with w_scale != NULL): launches of M >= 4096 rows and more than 128 tiles widen
  * the e4m3 matrix once, just in time, into the first 2 * N * K bytes of this buffer and multiply by the 16-bit kernels (up to
  * ~19 MB for SD3-medium's 6144 x 1536 matrices). A workspace smaller than that is not an error -- the launch silently takes the

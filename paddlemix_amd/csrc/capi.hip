@@ -79,6 +79,16 @@ int mi355x_sd_elem_dtype(void) {
 int mi355x_sd_set_workspace(void* ptr, size_t bytes) {
   if (ptr && (reinterpret_cast<uintptr_t>(ptr) & 15))
     return fail(SD_ERR_INVALID, "mi355x_sd_set_workspace: pointer must be 16-byte aligned");
+  if (ptr) {
+    // a HOST pointer is refused here, not at the first split-K launch that writes through it (round 5: the Python wrappers bound one
+    // on a misuse path; on a box without XNACK the launch after it died of a page fault). Refused: what the runtime KNOWS to be host
+    // or unregistered memory; a query it cannot answer (address ranges mapped by other means) is not this call's business.
+    hipPointerAttribute_t at;
+    const hipError_t e = hipPointerGetAttributes(&at, ptr);
+    if (e != hipSuccess) (void)hipGetLastError();
+    else if (at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeManaged)
+      return fail(SD_ERR_INVALID, "mi355x_sd_set_workspace: the workspace must be device memory");
+  }
   sd::set_workspace(ptr, bytes);
   return SD_OK;
 }

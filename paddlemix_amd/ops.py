@@ -26,6 +26,11 @@ _workspaces = {}
 def _bind_workspace(dev: torch.device, nbytes: int = 32 << 20) -> None:
     """split-K scratch for the stand-alone op wrappers (one per device, bound before every GEMM launch because the
     library reads the pointer at launch time and a DeviceProgram may have bound its own in between)."""
+    if dev.type != "cuda":
+        # (round 5: a wrapper called with CPU tensors used to bind a 32-MB HOST buffer here before its own argument check raised --
+        # and the next split-K launch that did not rebind wrote its partial sums through that pointer: a page fault on boxes
+        # without XNACK, the one-off abort of profiles/r05_s14)
+        raise _lib.MI355XError("tensors must live on the GPU (no CPU fallback)")
     ws = _workspaces.get(dev)
     if ws is None:
         ws = _workspaces[dev] = torch.empty(nbytes, device=dev, dtype=torch.uint8)

@@ -545,6 +545,15 @@ def test_errors_are_loud(ops):
         ops.linear(a, w)  # K not a multiple of 8
     with pytest.raises(MI355XError):
         ops.linear(torch.zeros(8, 16, dtype=torch.bfloat16), torch.zeros(16, 16, dtype=torch.bfloat16))  # CPU tensors
+    # a host buffer as the split-K workspace is refused by the library itself (it used to be accepted and written through by the
+    # next split-K launch: a page fault on boxes without XNACK); the wrappers' device workspace stays bound
+    from paddlemix_amd import _lib
+    lib = _lib.load()
+    host = torch.empty(4096, dtype=torch.uint8)
+    assert lib.mi355x_sd_set_workspace(host.data_ptr() & ~15, 1024) != 0
+    assert b"device memory" in lib.mi355x_sd_last_error()
+    ops._bind_workspace(a.device)
+    assert not any(d.type == "cpu" for d in ops._workspaces)
 
 
 @pytest.mark.parametrize("B,H,Sq,Skv,D", [(2, 5, 256, 77, 64), (1, 4, 128, 130, 64), (1, 8, 64, 77, 40)])

@@ -441,3 +441,29 @@ def test_bench_cpu_leg_respects_the_containers_cpu_quota(tmp_path):
     assert bench.usable_cpus(str(tmp_path)) == mask                       # v1, unlimited
     (tmp_path / "cpu" / "cpu.cfs_quota_us").write_text("100000\n")
     assert bench.usable_cpus(str(tmp_path)) == 1
+
+
+def test_wrappers_called_with_cpu_tensors_do_not_bind_a_host_workspace():
+    """ops.linear(CPU tensors) must raise BEFORE anything reaches the library: it used to bind a 32-MB host buffer as the split-K
+    workspace on its way to the argument check, and the next launch that took split-K slices without rebinding wrote through it."""
+    import pytest
+    import torch
+    from paddlemix_amd import _lib, ops
+    calls = []
+    real = _lib.load
+
+    class Spy:
+        def __getattr__(self, name):
+            calls.append(name)
+            return getattr(real(), name)
+
+    ops._lib.load, saved = (lambda: Spy()), ops._lib.load
+    try:
+        with pytest.raises(_lib.MI355XError):
+            ops.linear(torch.zeros(8, 16, dtype=torch.bfloat16), torch.zeros(16, 16, dtype=torch.bfloat16))
+        with pytest.raises(_lib.MI355XError):
+            ops.linear_ex(torch.zeros(8, 16, dtype=torch.bfloat16), torch.zeros(16, 16, dtype=torch.bfloat16))
+    finally:
+        ops._lib.load = saved
+    assert "mi355x_sd_set_workspace" not in calls and not any(d.type == "cpu" for d in ops._workspaces)
+
