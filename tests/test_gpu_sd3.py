@@ -138,7 +138,7 @@ def test_fp8_row_quantisers(ops):
     assert torch.allclose(l2.cpu(), ref.reshape(B * S, C).norm(dim=1), rtol=2e-3)
 
 
-@pytest.mark.parametrize("M,N,K", [(512, 6144, 1536), (1232, 6144, 1536), (300, 520, 256)])
+@pytest.mark.parametrize("M,N,K", [(512, 6144, 1536), (1232, 6144, 1536), (300, 520, 256), (9000, 6144, 1536)])   # (the last: 864 tiles, persistent blocks, ragged M)
 def test_w8a8_gemm_fp8_output(ops, M, N, K):
     """mi355x_sd_linear_f8_q: e4m3 output with the Cauchy-Schwarz row scale -- scales are exactly the stated bound, no
     element saturates, and the dequantised output is the GEMM result to e4m3 precision."""
