@@ -27,15 +27,13 @@ def main():
         # one whole-batch oracle forward at the launch set the metric times (tests/parity_cases.py FWD_CASES)
         case = PC.FWD_CASES[name]
         t0 = time.time()
-        P = PC.case_params(case)
         x_in, t, enc, extra = PC.fwd_inputs(case)
-        from oracle.unet_ref import unet_forward
         with torch.no_grad():
-            pred = unet_forward(P, case["cfg"], x_in, int(t), enc, added_cond_kwargs=extra).float()
+            pred = PC.oracle_fwd(case)
         np.savez(PC.golden_path(name), pred=pred.numpy(), timestep=np.float64(t), x_in_sum=np.float64(x_in.double().sum().item()),
+                 prompts=np.array(PC.fwd_prompts(case), dtype=np.int64),
                  seconds=np.float64(time.time() - t0), threads=np.int64(torch.get_num_threads()))
         print(f"{name}: |pred| = {pred.norm().item():.4f}; wrote {PC.golden_path(name)} in {time.time() - t0:.0f} s", flush=True)
-        del P
     names = [n for n in names if n not in PC.FWD_CASES]
     for name in names:
         case = PC.CASES[name]
