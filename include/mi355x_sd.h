@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MI355X_SD_ABI_VERSION 11
+#define MI355X_SD_ABI_VERSION 12
 #define MI355X_SD_OK 0
 #define MI355X_SD_ERR_INVALID 1      /* bad argument (shape <= 0, null pointer ...)          */
 #define MI355X_SD_ERR_UNSUPPORTED 2  /* well-formed but outside the implemented configurations */
@@ -46,19 +46,22 @@ const char* mi355x_sd_last_error(void);
 /* Selects `device` and verifies it is a gfx950 part. */
 int mi355x_sd_init(int device);
 
-/* Caller-owned scratch (device memory, 16-byte aligned) for the split-K partial sums of mi355x_sd_linear* /
- * mi355x_sd_conv3x3. Launches that cannot fill the 256 CUs (batch-1 SD-1.5: 64..1024 rows against K up to 23040)
- * split K over blockIdx.y, store fp32 slices here and reduce them in fixed order (deterministic). The pointer is read at
- * launch time, so one stream's launches must not share a workspace with launches running concurrently on another
- * stream. ptr == NULL (the initial state) disables split-K. The library never allocates ("no hidden allocation"). A pointer the HIP
- * runtime knows to be host / unregistered memory is refused (MI355X_SD_ERR_INVALID): the kernels write through it.
- * SECOND USE (weight-only fp8, mi355x_sd_linear_ex with w_scale != NULL): launches of M >= 4096 rows and more than 128 tiles widen
- * the e4m3 matrix once, just in time, into the first 2 * N * K bytes of this buffer and multiply by the 16-bit kernels (up to
- * ~19 MB for SD3-medium's 6144 x 1536 matrices). A workspace smaller than that is not an error -- the launch silently takes the
- * slower path that converts in the fragment load (same result to fp32 rounding) -- so size it for max(split-K need, 2 * N * K of the
- * largest fp8 matrix); 32 MiB covers every model of this repository. An exported program's speed depends on the size bound at
- * replay the same way. */
-int mi355x_sd_set_workspace(void* ptr, size_t bytes);
+/* SCRATCH OF THE GEMM-CLASS CALLS (ABI 12): mi355x_sd_linear, _linear_ex, _linear_ln and mi355x_sd_conv3x3 take `ws, ws_bytes` --
+ * caller-owned device memory, 16-byte aligned, or NULL / 0 -- as ARGUMENTS (until ABI 11 a process-wide binding,
+ * mi355x_sd_set_workspace, whose stale pointer a later call could write through; it is gone). The scratch belongs to the call:
+ * launches that run concurrently (two streams, two handles) must be given different buffers, launches ordered on one stream may
+ * share one. The model handles own theirs (mi355x_sd_unet_*: part of the arena bound with _bind_workspace; mi355x_sd_program_*: a
+ * scratch region of the program). Two uses:
+ *   split-K: launches that cannot fill the 256 CUs (batch-1 SD-1.5: 64..1024 rows against K up to 23040) split K over blockIdx.y,
+ *     store fp32 slices here and reduce them in fixed order (deterministic); the split count is bounded by ws_bytes, so the same
+ *     call with another ws_bytes may sum in another order (results equal to fp32 rounding, bit-stable for a fixed size);
+ *   weight-only fp8 (mi355x_sd_linear_ex, w_scale != NULL): launches of M >= 4096 rows and more than 128 tiles widen the e4m3
+ *     matrix once, just in time, into the first 2 * N * K bytes (up to ~19 MB for SD3-medium's 6144 x 1536 matrices) and multiply
+ *     with the 16-bit kernels; a smaller scratch is not an error -- the launch takes the slower path that converts in the fragment
+ *     load (same result to fp32 rounding).
+ * NULL: neither path. 32 MiB covers every model of this repository. The library never allocates ("no hidden allocation"). A
+ * pointer the HIP runtime does not know as device (or managed) memory is refused with MI355X_SD_ERR_INVALID before anything is
+ * launched: the kernels write through it. */
 
 /* ---- seam B1: the whole UNet2DConditionModel behind one handle (paddlemix_amd/csrc/unet_exec.hip) ----------------------------
  * What a compiled host (Paddle C++, a serving runtime) binds instead of the per-op entry points: the reference calls its UNet once
@@ -180,7 +183,7 @@ int mi355x_sd_mask_to_bias(const float* mask, float* bias, int64_t n, void* stre
  * bias, rowbias, R may be NULL. */
 int mi355x_sd_linear(const void* A, int lda, const void* W, void* C, int ldc, int M, int N, int K,
                      const float* bias, const float* rowbias, int rows_per_batch, int ld_rowbias,
-                     const void* R, int ldr, float out_scale, int flags, void* stream);
+                     const void* R, int ldr, float out_scale, int flags, void* ws, size_t ws_bytes, void* stream);
 
 /* mi355x_sd_linear plus what the SD3 MMDiT blocks (PPD/models/attention.py:164-214, attention_processor.py:916-983) need:
  *   gate  : out = R + gate[m / rows_per_batch][n] * (acc + bias)     (adaLN-Zero gated residuals, attention.py:181-196)
@@ -195,7 +198,7 @@ int mi355x_sd_linear_ex(const void* A, int lda, int a_rows_per_batch, int64_t a_
                         const float* w_scale, void* C,
                         int ldc, int c_rows_per_batch, int64_t c_batch_stride, int M, int N, int K, const float* bias,
                         const float* rowbias, int ld_rowbias, const float* gate, int ld_gate, int rows_per_batch,
-                        const void* R, int ldr, float out_scale, int flags, void* stream);
+                        const void* R, int ldr, float out_scale, int flags, void* ws, size_t ws_bytes, void* stream);
 
 /* LayerNorm folded into the consuming projection (BasicTransformerBlock: norm1 -> attn1.to_q/k/v, norm2 -> attn2.to_q,
  * norm3 -> ff.net.0.proj; PPD/models/attention.py:405-486).  With W' = W diag(gamma) (bf16), w_rowsum[n] = sum_k W'[n][k]
@@ -206,7 +209,7 @@ int mi355x_sd_linear_ex(const void* A, int lda, int a_rows_per_batch, int64_t a_
  * correction to its fp32 accumulators before bias / GEGLU / activation flags. */
 int mi355x_sd_row_stats(const void* x, int rows, int C, int ldx, float eps, float* row_stats, void* stream);
 int mi355x_sd_linear_ln(const void* A, int lda, const float* row_stats, const void* W, const float* w_rowsum, void* C,
-                        int ldc, int M, int N, int K, const float* bias, int flags, void* stream);
+                        int ldc, int M, int N, int K, const float* bias, int flags, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- W8A8: fp8 (OCP e4m3) MFMA path of the MMDiT block GEMMs (BASELINE config 5: "fp8 weights ... CDNA4 fp8 MFMA") ----
  * C[M,N] = (A8 . W8^T) * a_scale[m] * w_scale[n] + bias, then optional gate[m / rows_per_batch][n] * (.) + R, optional
@@ -267,7 +270,7 @@ int mi355x_sd_unpatchify(const void* x, int ldx, int B, int C, int H, int W, int
 int mi355x_sd_conv3x3(const void* X, int ldx, int B, int Hs, int Ws, int Cin, int stride, int upsample,
                       const void* W, void* C, int ldc, int Cout,
                       const float* bias, const float* rowbias, int ld_rowbias,
-                      const void* R, int ldr, float out_scale, int flags, void* stream);
+                      const void* R, int ldr, float out_scale, int flags, void* ws, size_t ws_bytes, void* stream);
 
 /* out = softmax(q k^T * scale + bias) v, layouts q [B,Sq,H,D], k/v [B,Skv,H,D], out [B,Sq,H,D] with explicit
  * batch (bs) and token (ts) strides in elements; bias optional fp32 additive mask addressed

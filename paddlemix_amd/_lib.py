@@ -24,7 +24,7 @@ if os.environ.get("MI355X_SD_LIB") == "dbg":
         raise ValueError("MI355X_SD_LIB=dbg: the debug-switch build exists for bf16 elements only")
     LIB_PATH = os.path.join(_HERE, "libmi355x_sd_dbg.so")
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 GEGLU, OUT_F32, SILU, GELU_TANH, PAD_BR, R_F32, CONV_KB64 = 1, 2, 4, 8, 16, 32, 64
 UNET_ENC_MASK, UNET_SELF_MASK, UNET_CONTROLNET = 1, 2, 4   # mi355x_sd_unet_plan_ex flags
 SDPA_LOG2 = 1
@@ -35,7 +35,6 @@ SIGNATURES = {
     "mi355x_sd_abi_version": (c_int, []),
     "mi355x_sd_elem_dtype": (c_int, []),
     "mi355x_sd_last_error": (c_char_p, []),
-    "mi355x_sd_set_workspace": (c_int, [c_void_p, ctypes.c_size_t]),
     "mi355x_sd_init": (c_int, [c_int]),
     "mi355x_sd_program_load": (c_int, [c_char_p, POINTER(c_void_p)]),
     "mi355x_sd_program_destroy": (c_int, [c_void_p]),
@@ -47,14 +46,15 @@ SIGNATURES = {
     "mi355x_sd_program_io_info": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(c_int), POINTER(c_int), POINTER(c_int64),
                                           POINTER(c_int), POINTER(ctypes.c_size_t), POINTER(c_void_p)]),
     "mi355x_sd_program_run": (c_int, [c_void_p, c_void_p]),
+    # (GEMM-class calls, ABI 12: `ws, ws_bytes` = the call's split-K / widening scratch, before the stream)
     "mi355x_sd_linear": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
-                                 c_int, c_int, c_void_p, c_int, c_float, c_int, c_void_p]),
+                                 c_int, c_int, c_void_p, c_int, c_float, c_int, c_void_p, ctypes.c_size_t, c_void_p]),
     "mi355x_sd_linear_ex": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int,
                                     c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_float,
-                                    c_int, c_void_p]),
+                                    c_int, c_void_p, ctypes.c_size_t, c_void_p]),
     "mi355x_sd_row_stats": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "mi355x_sd_linear_ln": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                                    c_void_p, c_int, c_void_p]),
+                                    c_void_p, c_int, c_void_p, ctypes.c_size_t, c_void_p]),
     "mi355x_sd_linear_f8": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64,
                                     c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "mi355x_sd_adaln_f8": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_int,
@@ -69,7 +69,8 @@ SIGNATURES = {
     "mi355x_sd_patchify": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "mi355x_sd_unpatchify": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mi355x_sd_conv3x3": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
-                                  c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_float, c_int, c_void_p]),
+                                  c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_float, c_int, c_void_p, ctypes.c_size_t,
+                                  c_void_p]),
     "mi355x_sd_sdpa": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                c_int64, c_int, c_int64, c_int, c_int64, c_int, c_int64, c_int, c_int64, c_int64,
                                c_int64, c_float, c_void_p]),

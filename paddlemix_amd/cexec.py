@@ -105,8 +105,8 @@ class UNetHandle:
 
 
 class CUNet2DConditionModel:
-    """``UNet2DConditionModel`` on the handle API. Buffers (weights, workspace, split-K scratch) are torch tensors owned here --
-    i.e. by the caller of the C ABI."""
+    """``UNet2DConditionModel`` on the handle API. Buffers (weights, workspace -- which contains the handle's split-K scratch since ABI 12) are torch
+    tensors owned here -- i.e. by the caller of the C ABI."""
 
     def __init__(self, config: Mapping, params: Mapping[str, torch.Tensor], device="cuda", use_graph: bool = True,
                  residual_dtype: Optional[str] = None, fold_softmax_scale: bool = True):
@@ -127,7 +127,6 @@ class CUNet2DConditionModel:
         self._weights = torch.empty(self.hd.weight_bytes(), device=self.device, dtype=torch.uint8)
         _lib.check(self.hd.lib.mi355x_sd_unet_finalize_weights(self.hd.h, self._weights.data_ptr(), self._weights.numel(),
                                                                 self._stream.cuda_stream))
-        self._splitk = torch.empty(WORKSPACE_BYTES, device=self.device, dtype=torch.uint8)
         self._geom = None
         self._workspace = None
 
@@ -200,7 +199,6 @@ class CUNet2DConditionModel:
             s, tt, e = f32(sample), f32(t.reshape(-1)[:1]), f32(encoder_hidden_states)
             sc = None if in_scale is None else f32(torch.tensor([float(in_scale)]))
             out = torch.empty((B, self.config.__dict__.get("out_channels", 4), H, W), device=self.device, dtype=torch.float32)
-            _lib.check(lib.mi355x_sd_set_workspace(self._splitk.data_ptr(), self._splitk.numel()))
             p = lambda x: None if x is None else x.data_ptr()  # noqa: E731
             em = None if encoder_attention_mask is None else f32(encoder_attention_mask)
             sm = None if attention_mask is None else f32(attention_mask)

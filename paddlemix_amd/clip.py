@@ -104,7 +104,7 @@ def _encoder_layer_shapes(S: Dict[str, tuple], tower: str, n_layers: int, D: int
 def _emit_encoder_layers(model, emit, persist, hidden: List[Tensor], B: int, S: int, mask_ptr: Optional[int]) -> None:
     """CLIPEncoder.forward: pre-LayerNorm attention + MLP blocks, hidden[i] -> hidden[i + 1] (modeling.py CLIPEncoderLayer).
     mask_ptr: fp32 [S, S] additive mask shared by batch items and heads (the text tower's causal mask) or None."""
-    cfg, lib, W, stream = model.cfg, model._lib, model.w, model._stream_ptr
+    cfg, lib, W, stream, gemm_ws = model.cfg, model._lib, model.w, model._stream_ptr, model._gemm_ws
     D, H, I, n = cfg["hidden_size"], cfg["num_attention_heads"], cfg["intermediate_size"], cfg["num_hidden_layers"]
     d, eps, rows = D // H, float(cfg["layer_norm_eps"]), B * S
 
@@ -113,7 +113,7 @@ def _emit_encoder_layers(model, emit, persist, hidden: List[Tensor], B: int, S: 
         N, K = w.shape
         emit(lib.mi355x_sd_linear, (a.data_ptr(), lda, w.data_ptr(), out.data_ptr(), ldc, rows, N, K, W[wkey + ".b"].data_ptr(),
                                     None, 0, 0, R.data_ptr() if R is not None else None, N if R is not None else 0, 1.0, 0,
-                                    stream), "gemm", 2.0 * rows * N * K, f"{rows}x{N}x{K}")
+                                    *gemm_ws, stream), "gemm", 2.0 * rows * N * K, f"{rows}x{N}x{K}")
 
     def lnorm(x: Tensor, key, out: Tensor):
         emit(lib.mi355x_sd_layernorm, (x.data_ptr(), rows, D, D, W[key + ".g"].data_ptr(), W[key + ".b"].data_ptr(), eps,
@@ -291,7 +291,7 @@ class CLIPTextModel(DeviceProgram, PretrainedMixin):
         out = torch.empty((B, N), device=a.device, dtype=torch.float32)
         s = 0 if self._emulated else torch.cuda.current_stream(self.device).cuda_stream
         _lib.check(self._lib.mi355x_sd_linear(a.data_ptr(), K, w.data_ptr(), out.data_ptr(), N, B, N, K, None, None, 0, 0,
-                                              None, 0, 1.0, _lib.OUT_F32, s))
+                                              None, 0, 1.0, _lib.OUT_F32, *self._gemm_ws, s))
         return out
 
 
@@ -422,7 +422,7 @@ class CLIPVisionModelWithProjection(DeviceProgram, PretrainedMixin):
         emit(lib.mi355x_sd_patchify, (plan.pixels.data_ptr(), B, C, side, side, p, cols.data_ptr(), Kp, stream), "misc")
         # patch rows of image b land at token rows b * S + 1 ..: C row remap (rows_per_batch N, batch stride S * D)
         emit(lib.mi355x_sd_linear_ex, (cols.data_ptr(), Kp, 0, 0, W["patch.w"].data_ptr(), None, emb.data_ptr() + 2 * D, D, N,
-                                       S * D, B * N, D, Kp, None, None, 0, None, 0, 0, pos_t.data_ptr(), D, 1.0, 0, stream),
+                                       S * D, B * N, D, Kp, None, None, 0, None, 0, 0, pos_t.data_ptr(), D, 1.0, 0, *self._gemm_ws, stream),
              "gemm", 2.0 * B * N * D * Kp, f"{B * N}x{D}x{Kp}")
         plan.hidden = [persist((B * S, D), _lib.elem_dtype()) for _ in range(n + 1)]
         emit(lib.mi355x_sd_layernorm, (emb.data_ptr(), B * S, D, D, W["pre.g"].data_ptr(), W["pre.b"].data_ptr(), eps,
@@ -435,7 +435,7 @@ class CLIPVisionModelWithProjection(DeviceProgram, PretrainedMixin):
         plan.embeds = persist((B, W["proj.w"].shape[0]), torch.float32)
         emit(lib.mi355x_sd_linear, (plan.pooled.data_ptr(), D, W["proj.w"].data_ptr(), plan.embeds.data_ptr(),
                                     W["proj.w"].shape[0], B, W["proj.w"].shape[0], D, None, None, 0, 0, None, 0, 1.0,
-                                    _lib.OUT_F32, stream), "gemm", 2.0 * B * D * W["proj.w"].shape[0])
+                                    _lib.OUT_F32, *self._gemm_ws, stream), "gemm", 2.0 * B * D * W["proj.w"].shape[0])
         plan.prog, plan.keep, plan.graph = prog, keep, None
         plan.out = plan.embeds
         plan.B, plan.S = B, S

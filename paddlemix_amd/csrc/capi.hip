@@ -64,6 +64,30 @@ __global__ void probe_kernel(float* out) {
   for (int i = 0; i < 4; ++i) out[l * 24 + 20 + i] = (float)t[i];
 }
 
+// Scratch argument of the GEMM-class entry points (ABI 12): NULL or 16-byte aligned DEVICE memory. A host pointer is refused here, not
+// at the first split-K launch that writes through it (round 5: a host buffer bound on a misuse path killed a later launch with a page
+// fault on a box without XNACK). The runtime query sits on every GEMM launch, so the last accepted (pointer, size) is remembered per
+// thread and not asked about again; a pointer the runtime cannot classify (hipErrorInvalidValue: plain malloc memory on some ROCm
+// releases, unregistered ranges) is NOT device memory as far as this library can tell and is refused as well.
+static int check_ws(const void* ws, size_t bytes, const char* who) {
+  if (!ws) return SD_OK;
+  if (reinterpret_cast<uintptr_t>(ws) & 15) return fail(SD_ERR_INVALID, "%s: the workspace pointer must be 16-byte aligned", who);
+  static thread_local const void* ok_ptr = nullptr;
+  static thread_local size_t ok_bytes = 0;
+  if (ws == ok_ptr && bytes <= ok_bytes) return SD_OK;
+  hipPointerAttribute_t at;
+  const hipError_t e = hipPointerGetAttributes(&at, ws);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(SD_ERR_INVALID, "%s: the workspace must be device memory (the HIP runtime does not know this pointer)", who);
+  }
+  if (at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeManaged)
+    return fail(SD_ERR_INVALID, "%s: the workspace must be device memory", who);
+  ok_ptr = ws;
+  ok_bytes = bytes;
+  return SD_OK;
+}
+
 extern "C" {
 
 int mi355x_sd_abi_version(void) { return MI355X_SD_ABI_VERSION; }
@@ -76,22 +100,6 @@ int mi355x_sd_elem_dtype(void) {
 #endif
 }
 
-int mi355x_sd_set_workspace(void* ptr, size_t bytes) {
-  if (ptr && (reinterpret_cast<uintptr_t>(ptr) & 15))
-    return fail(SD_ERR_INVALID, "mi355x_sd_set_workspace: pointer must be 16-byte aligned");
-  if (ptr) {
-    // a HOST pointer is refused here, not at the first split-K launch that writes through it (round 5: the Python wrappers bound one
-    // on a misuse path; on a box without XNACK the launch after it died of a page fault). Refused: what the runtime KNOWS to be host
-    // or unregistered memory; a query it cannot answer (address ranges mapped by other means) is not this call's business.
-    hipPointerAttribute_t at;
-    const hipError_t e = hipPointerGetAttributes(&at, ptr);
-    if (e != hipSuccess) (void)hipGetLastError();
-    else if (at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeManaged)
-      return fail(SD_ERR_INVALID, "mi355x_sd_set_workspace: the workspace must be device memory");
-  }
-  sd::set_workspace(ptr, bytes);
-  return SD_OK;
-}
 const char* mi355x_sd_last_error(void) { return g_err; }
 
 int mi355x_sd_init(int device) {
@@ -109,10 +117,12 @@ int mi355x_sd_init(int device) {
 
 int mi355x_sd_linear(const void* A, int lda, const void* W, void* C, int ldc, int M, int N, int K, const float* bias,
                      const float* rowbias, int rows_per_batch, int ld_rowbias, const void* R, int ldr, float out_scale,
-                     int flags, void* stream) {
+                     int flags, void* ws, size_t ws_bytes, void* stream) {
   if (!A || !W || !C) return fail(SD_ERR_INVALID, "mi355x_sd_linear: null pointer");
+  if (int rc = check_ws(ws, ws_bytes, "mi355x_sd_linear")) return rc;
   GemmArgs g;
   memset(&g, 0, sizeof(g));
+  g.ws_base = ws; g.ws_bytes = ws ? ws_bytes : 0;
   g.A = (const bf16*)A; g.W = (const bf16*)W; g.C = C;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc;
   g.bias = bias; g.rowbias = rowbias; g.rows_per_batch = rows_per_batch; g.ld_rowbias = ld_rowbias;
@@ -128,10 +138,12 @@ int mi355x_sd_linear_ex(const void* A, int lda, int a_rows_per_batch, int64_t a_
                         const float* w_scale, void* C,
                         int ldc, int c_rows_per_batch, int64_t c_batch_stride, int M, int N, int K, const float* bias,
                         const float* rowbias, int ld_rowbias, const float* gate, int ld_gate, int rows_per_batch,
-                        const void* R, int ldr, float out_scale, int flags, void* stream) {
+                        const void* R, int ldr, float out_scale, int flags, void* ws, size_t ws_bytes, void* stream) {
   if (!A || !W || !C) return fail(SD_ERR_INVALID, "mi355x_sd_linear_ex: null pointer");
+  if (int rc = check_ws(ws, ws_bytes, "mi355x_sd_linear_ex")) return rc;
   GemmArgs g;
   memset(&g, 0, sizeof(g));
+  g.ws_base = ws; g.ws_bytes = ws ? ws_bytes : 0;
   g.A = (const bf16*)A; g.W = (const bf16*)W; g.C = C;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc;
   g.a_rpb = a_rows_per_batch; g.a_bstride = (long)a_batch_stride;
@@ -154,10 +166,12 @@ int mi355x_sd_row_stats(const void* x, int rows, int C, int ldx, float eps, floa
 }
 
 int mi355x_sd_linear_ln(const void* A, int lda, const float* row_stats, const void* W, const float* w_rowsum, void* C,
-                        int ldc, int M, int N, int K, const float* bias, int flags, void* stream) {
+                        int ldc, int M, int N, int K, const float* bias, int flags, void* ws, size_t ws_bytes, void* stream) {
   if (!A || !W || !C || !row_stats || !w_rowsum) return fail(SD_ERR_INVALID, "mi355x_sd_linear_ln: null pointer");
+  if (int rc = check_ws(ws, ws_bytes, "mi355x_sd_linear_ln")) return rc;
   GemmArgs g;
   memset(&g, 0, sizeof(g));
+  g.ws_base = ws; g.ws_bytes = ws ? ws_bytes : 0;
   g.A = (const bf16*)A; g.W = (const bf16*)W; g.C = C;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc;
   g.rowstat = row_stats; g.wsum = w_rowsum;
@@ -249,14 +263,16 @@ int mi355x_sd_unpatchify(const void* x, int ldx, int B, int C, int H, int W, int
 
 int mi355x_sd_conv3x3(const void* X, int ldx, int B, int Hs, int Ws, int Cin, int stride, int upsample, const void* W,
                       void* C, int ldc, int Cout, const float* bias, const float* rowbias, int ld_rowbias,
-                      const void* R, int ldr, float out_scale, int flags, void* stream) {
+                      const void* R, int ldr, float out_scale, int flags, void* ws, size_t ws_bytes, void* stream) {
   if (!X || !W || !C) return fail(SD_ERR_INVALID, "mi355x_sd_conv3x3: null pointer");
+  if (int rc = check_ws(ws, ws_bytes, "mi355x_sd_conv3x3")) return rc;
   if (B <= 0 || Hs <= 0 || Ws <= 0 || Cin <= 0 || Cout <= 0 || (stride != 1 && stride != 2) ||
       (upsample != 0 && upsample != 1))
     return fail(SD_ERR_INVALID, "mi355x_sd_conv3x3: bad shape");
   if (flags & MI355X_SD_GEGLU) return fail(SD_ERR_UNSUPPORTED, "mi355x_sd_conv3x3: GEGLU epilogue is linear-only");
   GemmArgs g;
   memset(&g, 0, sizeof(g));
+  g.ws_base = ws; g.ws_bytes = ws ? ws_bytes : 0;
   g.A = (const bf16*)X; g.W = (const bf16*)W; g.C = C;
   g.conv = 1; g.Hs = Hs; g.Ws = Ws; g.Cin = Cin; g.stride = stride; g.up = upsample;
   g.pad = (flags & MI355X_SD_PAD_BR) ? 0 : 1;

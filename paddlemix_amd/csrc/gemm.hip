@@ -241,31 +241,24 @@ void launch_splitk_reduce(const GemmArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((a.M + 15) / 16, (a.N + 127) / 128), dim3(256), 0, stream, a);
 }
 
-static void* g_ws = nullptr;
-static size_t g_ws_bytes = 0;
-void set_workspace(void* ptr, size_t bytes) {
-  g_ws = ptr;
-  g_ws_bytes = ptr ? bytes : 0;
-}
-
 // Split-K plan for launches that cannot fill the chip (SD-1.5 at batch 1: 64..1024 rows against K up to 23040, i.e.
 // weight-streaming problems where 10-40 tiles would otherwise pull the whole weight matrix through 10-40 CUs).
 // Target ~2 blocks per CU, at least 4 k-tiles per slice, partial sums bounded by the workspace.
 static void plan_splitk(GemmArgs& a, int bm, int bn) {
   a.splitk = 0;
   static const bool off = sd_switch("MI355X_SD_NO_SPLITK") != nullptr;
-  if (!g_ws || off || a.w16) return;   // (a widened fp8 matrix occupies the workspace)
+  if (!a.ws_base || off || a.w16) return;   // (a widened fp8 matrix occupies the workspace)
   const long tiles = (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn);
   const int nt = (a.K + BK - 1) / BK;
   if (tiles > 128 || nt < 8) return;
   long s = (512 + tiles - 1) / tiles;
   s = std::min<long>(s, nt / 4);
   const size_t slice = (size_t)a.M * a.N * sizeof(float);
-  s = std::min<long>(s, (long)(g_ws_bytes / slice));
+  s = std::min<long>(s, (long)(a.ws_bytes / slice));
   if (s < 2) return;
   a.kc = (nt + (int)s - 1) / (int)s;
   a.splitk = (nt + a.kc - 1) / a.kc;
-  a.ws = static_cast<float*>(g_ws);
+  a.ws = static_cast<float*>(a.ws_base);
   if (a.splitk < 2) a.splitk = 0;
 }
 
@@ -394,8 +387,8 @@ __global__ __launch_bounds__(256) void widen_fp8_kernel(const u32x4* __restrict_
 static bool widen_fp8_applies(const GemmArgs& a) {
   static const bool off = sd_switch("MI355X_SD_NO_WIDEN_F8") != nullptr;   // A/B switch (tests/test_gpu_switches.py: equal to fp32 rounding, not the same bits)
   if (off) return false;
-  if (!a.wscale || a.w16 || !g_ws || a.conv || a.rowstat || (a.K & 63) || (a.N & 3)) return false;
-  if ((size_t)a.N * a.K * 2 > g_ws_bytes || (reinterpret_cast<uintptr_t>(a.W) & 15) || (reinterpret_cast<uintptr_t>(g_ws) & 15)) return false;
+  if (!a.wscale || a.w16 || !a.ws_base || a.conv || a.rowstat || (a.K & 63) || (a.N & 3)) return false;
+  if ((size_t)a.N * a.K * 2 > a.ws_bytes || (reinterpret_cast<uintptr_t>(a.W) & 15) || (reinterpret_cast<uintptr_t>(a.ws_base) & 15)) return false;
   const long tiles = (long)((a.M + 255) / 256) * ((a.N + 159) / 160);
   // (launches of <= 128 tiles may take split-K slices: plan_splitk. M >= 4096: below that -- the 1232-row context stream of SD3 at
   // bs 8 -- a launch is about as long as the widening pass itself and reads the matrix once either way)
@@ -412,9 +405,9 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
     // (grid: every lane four loads where the matrix is large enough to still give each CU two blocks)
     const long blocks1 = (n16 + 255) / 256;
     hipLaunchKernelGGL(widen_fp8_kernel, dim3((unsigned)(blocks1 >= 2048 ? (blocks1 + 3) / 4 : blocks1)), dim3(256), 0, stream,
-                       reinterpret_cast<const u32x4*>(a_in.W), reinterpret_cast<u32x4*>(g_ws), n16);
+                       reinterpret_cast<const u32x4*>(a_in.W), reinterpret_cast<u32x4*>(a_in.ws_base), n16);
     GemmArgs b = a_in;
-    b.W = reinterpret_cast<const bf16*>(g_ws);
+    b.W = reinterpret_cast<const bf16*>(a_in.ws_base);
     b.w16 = 1;
     return launch_gemm(b, stream);
   }

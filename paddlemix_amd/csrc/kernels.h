@@ -60,9 +60,12 @@ struct GemmArgs {
   // fp32 accumulators to ws[y][M][N]; splitk_reduce_kernel sums the slices in fixed order and runs the epilogue.
   int splitk, kc;
   float* ws;
+  // the CALL's scratch (ABI 12: an argument of the four GEMM-class entry points, owned by the caller / by the handle that plans
+  // the call -- no process-wide binding): split-K partial sums or the just-in-time widened copy of an e4m3 matrix. NULL / 0: the
+  // launch takes neither path.
+  void* ws_base;
+  size_t ws_bytes;
 };
-// caller-owned scratch for split-K partial sums (mi355x_sd_set_workspace); no workspace -> no split-K
-void set_workspace(void* ptr, size_t bytes);
 void set_last_error(const char* msg);   // text behind mi355x_sd_last_error() (capi.hip), for the entry points defined elsewhere
 int launch_gemm(const GemmArgs& a, hipStream_t stream);
 int gemm_gm();   // tile rasterisation group of the GEMM kernels (-4 = column groups of 4)

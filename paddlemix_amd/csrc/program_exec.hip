@@ -35,6 +35,7 @@ struct PArg {
 template <class T> struct Conv;
 template <> struct Conv<int> { static constexpr char kind = 'i'; static int get(const PArg& a) { return (int)a.i; } };
 template <> struct Conv<long> { static constexpr char kind = 'i'; static long get(const PArg& a) { return (long)a.i; } };
+template <> struct Conv<unsigned long> { static constexpr char kind = 'i'; static unsigned long get(const PArg& a) { return (unsigned long)a.i; } };
 template <> struct Conv<float> { static constexpr char kind = 'f'; static float get(const PArg& a) { return (float)a.f; } };
 template <class T> struct Conv<T*> { static constexpr char kind = 'p'; static T* get(const PArg& a) { return (T*)a.p; } };
 
@@ -311,9 +312,9 @@ int mi355x_sd_program_run(void* handle, void* stream) {
   auto p = static_cast<Program*>(handle);
   if (!p) return fail(MI355X_SD_ERR_INVALID, "mi355x_sd_program_run: null handle");
   if (!p->base) return fail(MI355X_SD_ERR_INVALID, "mi355x_sd_program_run: mi355x_sd_program_bind first");
-  // the split-K scratch the program was planned with: same size -> same split decisions -> same bits as the exporting process
-  int rc = mi355x_sd_set_workspace(p->workspace_bytes ? p->base + p->workspace_off : nullptr, p->workspace_bytes);
-  if (rc) return rc;
+  // (the split-K / widening scratch the program was planned with is one of its scratch regions since ABI 12 -- an argument of every
+  // GEMM-class launch, same size -> same split decisions -> same bits as the exporting process; nothing process-wide is bound here)
+  int rc = MI355X_SD_OK;
   auto replay = [&]() {
     for (size_t k = 0; k < p->ops.size(); ++k) {
       auto& op = p->ops[k];

@@ -717,6 +717,11 @@ struct Planner {
   }
   int persist_n = 0;
   Ref persist(size_t bytes) { return sc("persist." + std::to_string(persist_n++), bytes < 16 ? 16 : bytes); }
+  // the split-K scratch of this handle's GEMM-class launches: part of the handle's own arena (ABI 12: an argument of every such
+  // call, not a process-wide binding). Same size as the Python planner's (paddlemix_amd/program.py WORKSPACE_BYTES): the split
+  // count depends on it, and the two planners are held bit-identical (tests/test_gpu_cexec.py)
+  static constexpr size_t GEMM_WS_BYTES = (size_t)32 << 20;
+  Ref gemm_ws() { return sc("gemm_ws", GEMM_WS_BYTES); }
   Ref wref(const std::string& key) {
     auto it = e.w.find(key);
     if (it == e.w.end()) die(MI355X_SD_ERR_INVALID, "internal: packed weight " + key + " missing");
@@ -749,10 +754,11 @@ struct Planner {
     const bool has_rb = rowbias.buf >= 0 || rowbias.abs;
     const bool has_R = R != nullptr;
     const View Rv = R ? *R : View();
+    const Ref gw = gemm_ws();
     emit([=](void* st) {
       return mi355x_sd_linear(ex->at(a.p), a.ld, ex->at(wr), ex->at(out.p), out.ld, a.rows, N, K, bias ? (const float*)ex->at(br) : nullptr,
                               has_rb ? (const float*)ex->at(rowbias) : nullptr, rpb, ld_rb, has_R ? ex->at(Rv.p) : nullptr, has_R ? Rv.ld : 0,
-                              out_scale, flags, st);
+                              out_scale, flags, ex->at(gw), GEMM_WS_BYTES, st);
     });
   }
   void conv3(const View& x, int h, int w_, const std::string& wkey, const View& out, int stride = 1, int up = 0, Ref rowbias = Ref(),
@@ -768,10 +774,11 @@ struct Planner {
     const bool has_R = R != nullptr;
     const View Rv = R ? *R : View();
     const int Bc = B, tt = e.temb_total;
+    const Ref gw = gemm_ws();
     emit([=](void* st) {
       return mi355x_sd_conv3x3(ex->at(x.p), x.ld, Bc, h, w_, x.C, stride, up, ex->at(wr), ex->at(out.p), out.ld, Cout, (const float*)ex->at(br),
                                has_rb ? (const float*)ex->at(rowbias) : nullptr, has_rb ? tt : 0, has_R ? ex->at(Rv.p) : nullptr,
-                               has_R ? Rv.ld : 0, out_scale, flags, st);
+                               has_R ? Rv.ld : 0, out_scale, flags, ex->at(gw), GEMM_WS_BYTES, st);
     });
   }
   View gnorm(const View& x, int hw, const std::string& nkey, float eps, bool silu, const View* raw16 = nullptr) {

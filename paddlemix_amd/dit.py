@@ -201,7 +201,7 @@ class DiTTransformer2DModel(DeviceProgram, PretrainedMixin):
             assert K == a.C, (wkey, K, a.C)
             emit(lib.mi355x_sd_linear_ex,
                  (a.p, a.ld, 0, 0, w.data_ptr(), None, out.p, out.ld, 0, 0, a.rows, N, K, W[wkey + ".b"].data_ptr(), None, 0,
-                  gate, ld_gate, rpb, R.p if R else None, R.ld if R else 0, 1.0, flags, stream), "gemm",
+                  gate, ld_gate, rpb, R.p if R else None, R.ld if R else 0, 1.0, flags, *self._gemm_ws, stream), "gemm",
                  2.0 * a.rows * N * K, f"{a.rows}x{N}x{K}")
 
         def adaln(x: _V, scale_ptr, shift_ptr, ld_mod, eps, out: _V):

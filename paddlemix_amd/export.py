@@ -116,6 +116,9 @@ def export_program(model, plan, path: str, outputs: Iterable[str] = ("out",)) ->
         raise ValueError(f"none of the outputs {outputs} is a tensor attribute of the plan ({[n for n, _ in named]})")
     for i, t in enumerate(plan.keep):
         add_region(t, R_SCRATCH, f"buf{i}")
+    ws = getattr(model, "_workspace", None)
+    if torch.is_tensor(ws):   # the model's split-K / widening scratch: an argument of its GEMM-class launches (ABI 12)
+        add_region(ws, R_SCRATCH, "gemm_workspace")
     spans = sorted((r["ptr"], r["ptr"] + r["bytes"], i) for i, r in enumerate(regions))
 
     def locate(v: int, what: str) -> Tuple[int, int]:
@@ -157,8 +160,7 @@ def export_program(model, plan, path: str, outputs: Iterable[str] = ("out",)) ->
                 raise ValueError(f"{sym}: parameter type {ty} has no tag")
         ops.append((sym, packed))
 
-    ws = getattr(model, "_workspace", None)
-    workspace_bytes = int(ws.numel()) if torch.is_tensor(ws) else 0
+    workspace_bytes = 0   # (reserved: until ABI 11 the size of a process-wide split-K binding; the scratch is a region now)
 
     def wants_data(r) -> bool:
         return r["kind"] in (R_WEIGHT, R_CONST) or (r["kind"] == R_IO and r["bytes"] <= _IO_DATA_LIMIT)

@@ -23,18 +23,20 @@ def _stream() -> int:
 _workspaces = {}
 
 
-def _bind_workspace(dev: torch.device, nbytes: int = 32 << 20) -> None:
-    """split-K scratch for the stand-alone op wrappers (one per device, bound before every GEMM launch because the
-    library reads the pointer at launch time and a DeviceProgram may have bound its own in between)."""
+def _workspace(dev: torch.device, nbytes: int = 32 << 20):
+    """(pointer, bytes) of the split-K / widening scratch handed to a GEMM-class call of the stand-alone op wrappers: one buffer per
+    (device, stream) -- the scratch belongs to the call (ABI 12), launches ordered on one stream may share one, launches on two
+    streams must not."""
     if dev.type != "cuda":
         # (round 5: a wrapper called with CPU tensors used to bind a 32-MB HOST buffer here before its own argument check raised --
         # and the next split-K launch that did not rebind wrote its partial sums through that pointer: a page fault on boxes
         # without XNACK, the one-off abort of profiles/r05_s14)
         raise _lib.MI355XError("tensors must live on the GPU (no CPU fallback)")
-    ws = _workspaces.get(dev)
+    key = (dev, _stream())
+    ws = _workspaces.get(key)
     if ws is None:
-        ws = _workspaces[dev] = torch.empty(nbytes, device=dev, dtype=torch.uint8)
-    check(_lib.load().mi355x_sd_set_workspace(ws.data_ptr(), ws.numel()))
+        ws = _workspaces[key] = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    return ws.data_ptr(), ws.numel()
 
 
 def _p(t: Optional[Tensor]) -> Optional[int]:
@@ -70,7 +72,7 @@ def linear(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, rowbias: Opti
            out_scale: float = 1.0, geglu: bool = False, silu: bool = False, out_f32: bool = False) -> Tensor:
     """out[M,N] = ((a[M,K] @ w[N,K]^T) + bias + rowbias[m // rows_per_batch] + residual) * out_scale."""
     lib = _lib.load()
-    _bind_workspace(a.device)
+    ws = _workspace(a.device)
     lda = _rows(a, "a")
     M, K = a.shape
     if w.dtype != _lib.elem_dtype() or not w.is_contiguous() or w.dim() != 2 or w.shape[1] != K:
@@ -92,7 +94,7 @@ def linear(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, rowbias: Opti
     flags = (GEGLU if geglu else 0) | (OUT_F32 if out_f32 else 0) | (SILU if silu else 0) | (_lib.R_F32 if r_f32 else 0)
     check(lib.mi355x_sd_linear(a.data_ptr(), lda, w.data_ptr(), out.data_ptr(), ldc, M, N, K,
                                _p(_vec(bias, N, "bias")), _p(rowbias), rows_per_batch, ld_rb, _p(residual), ldr,
-                               float(out_scale), flags, _stream()))
+                               float(out_scale), flags, *ws, _stream()))
     return out
 
 
@@ -103,7 +105,7 @@ def conv3x3(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, stride: int 
     padding at the bottom / right only -- Downsample2D(padding=0), resnet.py:277-279. ``kb64``: w is packed
     [Cout][Cin/64][3][3][64] (MI355X_SD_CONV_KB64) instead of [Cout][3][3][Cin]."""
     lib = _lib.load()
-    _bind_workspace(x.device)
+    ws = _workspace(x.device)
     if x.dim() != 4 or x.dtype != _lib.elem_dtype() or x.stride(3) != 1 or not x.is_cuda:
         raise ValueError("x: expected bf16 cuda NHWC [B,H,W,C]")
     B, H, W, C = x.shape
@@ -125,7 +127,7 @@ def conv3x3(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, stride: int 
     ld_rb = rowbias.stride(0) if rowbias is not None else 0
     check(lib.mi355x_sd_conv3x3(x.data_ptr(), ldx, B, H, W, C, stride, up, w.data_ptr(), out.data_ptr(), ldc, Cout,
                                 _p(_vec(bias, Cout, "bias")), _p(rowbias), ld_rb, _p(residual), ldr, float(out_scale),
-                                (_lib.PAD_BR if pad_br else 0) | (_lib.CONV_KB64 if kb64 else 0), _stream()))
+                                (_lib.PAD_BR if pad_br else 0) | (_lib.CONV_KB64 if kb64 else 0), *ws, _stream()))
     return out
 
 
@@ -318,7 +320,7 @@ def linear_ex(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, w_scale: O
     """mi355x_sd_linear_ex: out = residual + gate[m // rows_per_batch] * (a @ w^T + bias), optional row remaps of a / out
     (then `a` / `out` are the flat base tensors and M is given explicitly)."""
     lib = _lib.load()
-    _bind_workspace(a.device)
+    ws = _workspace(a.device)
     N, K = w.shape
     if a_rows_per_batch:
         lda = K if a.dim() == 1 else a.stride(0)
@@ -334,7 +336,7 @@ def linear_ex(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, w_scale: O
     check(lib.mi355x_sd_linear_ex(a.data_ptr(), lda, a_rows_per_batch, a_batch_stride, w.data_ptr(), _p(w_scale), out.data_ptr(), ldc,
                                   c_rows_per_batch, c_batch_stride, M, N, K, _p(_vec(bias, N, "bias")), None, 0, _p(gate),
                                   ld_gate, rows_per_batch, _p(residual), _rows(residual, "residual") if residual is not None else 0,
-                                  1.0, flags, _stream()))
+                                  1.0, flags, *ws, _stream()))
     return out
 
 
@@ -448,7 +450,7 @@ def linear_ln(a: Tensor, stats: Tensor, w: Tensor, w_rowsum: Tensor, bias: Optio
               geglu: bool = False, out: Optional[Tensor] = None) -> Tensor:
     """LayerNorm-folded projection: out = rstd * (a @ w^T) - mean * rstd * w_rowsum + bias (optionally GEGLU)."""
     lib = _lib.load()
-    _bind_workspace(a.device)
+    ws = _workspace(a.device)
     lda = _rows(a, "a")
     M, K = a.shape
     N = w.shape[0]
@@ -461,7 +463,7 @@ def linear_ln(a: Tensor, stats: Tensor, w: Tensor, w_rowsum: Tensor, bias: Optio
         out = torch.empty((M, n_out), device=a.device, dtype=_lib.elem_dtype())
     ldc = _rows(out, "out")
     check(lib.mi355x_sd_linear_ln(a.data_ptr(), lda, stats.data_ptr(), w.data_ptr(), _vec(w_rowsum, N, "w_rowsum").data_ptr(),
-                                  out.data_ptr(), ldc, M, N, K, _p(_vec(bias, N, "bias")), GEGLU if geglu else 0, _stream()))
+                                  out.data_ptr(), ldc, M, N, K, _p(_vec(bias, N, "bias")), GEGLU if geglu else 0, *ws, _stream()))
     return out
 
 

@@ -12,7 +12,8 @@ import torch
 from . import _lib
 
 WORKSPACE_BYTES = 32 << 20   # split-K partial sums (the planner shrinks the split count to fit) AND the just-in-time widened copy of a
-                             # weight-only-fp8 matrix (2 * N * K bytes, <= ~19 MB for SD3-medium): include/mi355x_sd.h mi355x_sd_set_workspace
+                             # weight-only-fp8 matrix (2 * N * K bytes, <= ~19 MB for SD3-medium): the `ws, ws_bytes` arguments of the
+                             # GEMM-class entry points (include/mi355x_sd.h, ABI 12)
 
 
 class _Ref:
@@ -64,6 +65,7 @@ class DeviceProgram:
             self.device = torch.device("cpu")
             self._stream = None
             self._stream_ptr = 0
+            self._gemm_ws = (None, 0)
             use_graph = False
         else:
             self._lib = _lib.load()  # hard failure if the HIP library is not built
@@ -75,8 +77,10 @@ class DeviceProgram:
             _lib.check(self._lib.mi355x_sd_init(self.device.index))
             self._stream = torch.cuda.Stream(device=self.device)
             self._stream_ptr = self._stream.cuda_stream
-            # split-K scratch of this model's stream (mi355x_sd_set_workspace): owned here, baked into the graphs
+            # split-K / widening scratch of this model's GEMM-class launches: owned here, an ARGUMENT of every such call the planners
+            # emit (`*self._gemm_ws` in front of the stream; ABI 12 -- nothing process-wide is bound), baked into the graphs
             self._workspace = torch.empty(WORKSPACE_BYTES, device=self.device, dtype=torch.uint8)
+            self._gemm_ws = (self._workspace.data_ptr(), self._workspace.numel())
         self.dtype = _lib.elem_dtype()
         self.use_graph = use_graph
         self.profile = profile
@@ -87,12 +91,7 @@ class DeviceProgram:
     def weight_bytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self.w.values())
 
-    def _bind_workspace(self) -> None:
-        if not self._emulated:
-            _lib.check(self._lib.mi355x_sd_set_workspace(self._workspace.data_ptr(), self._workspace.numel()))
-
     def _run_eager(self, plan: _Plan) -> None:
-        self._bind_workspace()
         if not self.profile or self._emulated:
             for fn, args, _, _ in plan.prog:
                 rc = fn(*args)
@@ -115,7 +114,6 @@ class DeviceProgram:
     def _capture(self, plan: _Plan) -> None:
         lib = self._lib
         sp = self._stream_ptr
-        self._bind_workspace()
         _lib.check(lib.mi355x_sd_graph_begin(sp))
         try:
             for fn, args, _, _ in plan.prog:

@@ -289,7 +289,7 @@ class SD3Transformer2DModel(DeviceProgram, PretrainedMixin):
                  (a.p, a.ld, a_rpb, a_bs, w.data_ptr(), ws.data_ptr() if ws is not None else None, out.p, out.ld, c_rpb,
                   c_bs, a.rows, N, K,
                   W[wkey + ".b"].data_ptr() if bias else None, None, 0, gate, MT if gate is not None else 0, rpb,
-                  R.p if R else None, R.ld if R else 0, 1.0, flags, stream), "gemm", 2.0 * a.rows * N * K,
+                  R.p if R else None, R.ld if R else 0, 1.0, flags, *self._gemm_ws, stream), "gemm", 2.0 * a.rows * N * K,
                  f"{a.rows}x{N}x{K}")
 
         def adaln(x: _V, scale_ptr, shift_ptr, rpb, out: _V):

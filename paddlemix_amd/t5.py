@@ -163,7 +163,7 @@ class T5EncoderModel(DeviceProgram, PretrainedMixin):
             w = W[wkey]
             N, K = w.shape
             emit(lib.mi355x_sd_linear, (a.data_ptr(), lda, w.data_ptr(), out.data_ptr(), ldc, rows, N, K, None, None, 0, 0,
-                                        R.data_ptr() if R is not None else None, N if R is not None else 0, 1.0, 0, stream),
+                                        R.data_ptr() if R is not None else None, N if R is not None else 0, 1.0, 0, *self._gemm_ws, stream),
                  "gemm", 2.0 * rows * N * K, f"{rows}x{N}x{K}")
 
         def rms(x: Tensor, wkey, out: Tensor):

@@ -533,7 +533,7 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
             flags |= (OUT_F32 if out.es == 4 else 0) | (R_F32 if (R is not None and R.es == 4) else 0)
             emit(lib.mi355x_sd_linear,
                  (a.p, a.ld, w.data_ptr(), out.p, out.ld, a.rows, N, K, b, rowbias, rpb, ld_rb,
-                  R.p if R else None, R.ld if R else 0, out_scale, flags, stream), "gemm", 2.0 * a.rows * N * K,
+                  R.p if R else None, R.ld if R else 0, out_scale, flags, *self._gemm_ws, stream), "gemm", 2.0 * a.rows * N * K,
                  f"{a.rows}x{N}x{K}" + ("g" if flags & GEGLU else ""))
 
         def conv3(x: _V, h, w_, wkey, out: _V, stride=1, up=0, rowbias=None, R: Optional[_V] = None, out_scale=1.0, flags=0):
@@ -547,7 +547,7 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
             emit(lib.mi355x_sd_conv3x3,
                  (x.p, x.ld, B, h, w_, x.C, stride, up, w.data_ptr(), out.p, out.ld, Cout, W[wkey + ".b"].data_ptr(),
                   rowbias, self._temb_total if rowbias is not None else 0, R.p if R else None, R.ld if R else 0,
-                  out_scale, flags, stream), "conv", 2.0 * B * ho * wo * Cout * 9 * x.C,
+                  out_scale, flags, *self._gemm_ws, stream), "conv", 2.0 * B * ho * wo * Cout * 9 * x.C,
                  f"{B * ho * wo}x{Cout}x{9 * x.C}" + ("s2" if stride == 2 else "") + ("up" if up else ""))
 
         def gnorm(x: _V, hw, nkey, eps_, silu, raw16: Optional[_V] = None) -> _V:
@@ -601,7 +601,7 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
             st = sc("t_stats", 8 * x.rows)
             emit(lib.mi355x_sd_row_stats, (x.p, x.rows, x.C, x.ld, 1e-5, st, stream), "ln")
             emit(lib.mi355x_sd_linear_ln, (x.p, x.ld, st, w.data_ptr(), wp(wkey + ".ws"), out.p, out.ld, x.rows, N, K,
-                                           wp(wkey + ".b"), flags, stream), "gemm", 2.0 * x.rows * N * K,
+                                           wp(wkey + ".b"), flags, *self._gemm_ws, stream), "gemm", 2.0 * x.rows * N * K,
                  f"{x.rows}x{N}x{K}" + ("g" if flags & GEGLU else ""))
 
         def attention(q: _V, k: _V, v: _V, out: _V, heads, sq, skv, bias=None, accum: Optional[float] = None, log2=False):

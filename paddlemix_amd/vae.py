@@ -341,7 +341,7 @@ class AutoencoderKL(DeviceProgram, PretrainedMixin):
 
         def gemm(a_p, lda, w_p, c_p, ldc, M, N, K, bias=None, R: Optional[_V] = None, out_scale=1.0, flags=0):
             emit(lib.mi355x_sd_linear, (a_p, lda, w_p, c_p, ldc, M, N, K, bias, None, 0, 0, R.p if R else None,
-                                        R.ld if R else 0, out_scale, flags, stream), "gemm", 2.0 * M * N * K,
+                                        R.ld if R else 0, out_scale, flags, *self._gemm_ws, stream), "gemm", 2.0 * M * N * K,
                  f"{M}x{N}x{K}")
 
         def conv3(x: _V, hh, ww, wkey, out: _V, up=0, R: Optional[_V] = None, stride=1, flags=0):
@@ -350,7 +350,7 @@ class AutoencoderKL(DeviceProgram, PretrainedMixin):
             ho, wo = ((hh << up) + pad2 - 3) // stride + 1, ((ww << up) + pad2 - 3) // stride + 1
             emit(lib.mi355x_sd_conv3x3, (x.p, x.ld, B, hh, ww, x.C, stride, up, wp(wkey + ".w"), out.p, out.ld, cout,
                                          wp(wkey + ".b"), None, 0, R.p if R else None, R.ld if R else 0, 1.0, flags,
-                                         stream),
+                                         *self._gemm_ws, stream),
                  "conv", 2.0 * B * ho * wo * cout * 9 * x.C,
                  f"{B * ho * wo}x{cout}x{9 * x.C}" + ("up" if up else "") + ("s2" if stride == 2 else ""))
 

@@ -26,7 +26,6 @@ int main(int argc, char** argv) {
   const int f16 = mi355x_sd_elem_dtype() == MI355X_SD_ELEM_F16;
   void* splitk = NULL;
   HK(hipMalloc(&splitk, 64u << 20));
-  CK(mi355x_sd_set_workspace(splitk, 64u << 20));
   hipStream_t st;
   HK(hipStreamCreate(&st));
   hipEvent_t e0, e1;
@@ -47,7 +46,7 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 2 + reps; ++i) {
       if (i == 2) HK(hipEventRecord(e0, st));
       CK(mi355x_sd_conv3x3(X[i % NBUF], sh.Cin, B, sh.Hs, sh.Hs, sh.Cin, sh.stride, sh.up, Wt, Y[i % NBUF], sh.Cout, sh.Cout, bias, rowbias,
-                           sh.Cout, NULL, 0, 1.0f, MI355X_SD_CONV_KB64, st));
+                           sh.Cout, NULL, 0, 1.0f, MI355X_SD_CONV_KB64, splitk, 64u << 20, st));
     }
     HK(hipEventRecord(e1, st));
     HK(hipStreamSynchronize(st));

@@ -30,7 +30,6 @@ int main(int argc, char** argv) {
   const int f16 = mi355x_sd_elem_dtype() == MI355X_SD_ELEM_F16;
   void* splitk = NULL;
   HK(hipMalloc(&splitk, 64u << 20));
-  CK(mi355x_sd_set_workspace(splitk, 64u << 20));
   hipStream_t st;
   HK(hipStreamCreate(&st));
   hipEvent_t e0, e1;
@@ -51,7 +50,7 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 3 + reps; ++i) {
       if (i == 3) HK(hipEventRecord(e0, st));
       CK(mi355x_sd_linear(A[i % NBUF], sh.K, Wt, C[i % NBUF], Nout, sh.M, sh.N, sh.K, bias, NULL, 0, 0, R, Nout, 1.0f,
-                          sh.geglu ? MI355X_SD_GEGLU : 0, st));
+                          sh.geglu ? MI355X_SD_GEGLU : 0, splitk, 64u << 20, st));
     }
     HK(hipEventRecord(e1, st));
     HK(hipStreamSynchronize(st));

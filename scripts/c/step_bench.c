@@ -121,14 +121,12 @@ int main(int argc, char** argv) {
   free(w);
   size_t wbytes = 0, sbytes = 0;
   CK(mi355x_sd_unet_weight_bytes(h, &wbytes));
-  void *dw = NULL, *ws = NULL, *splitk = NULL;
+  void *dw = NULL, *ws = NULL;   /* (ws holds the handle's split-K scratch too since ABI 12) */
   HK(hipMalloc(&dw, wbytes));
   CK(mi355x_sd_unet_finalize_weights(h, dw, wbytes, NULL));
   CK(mi355x_sd_unet_plan(h, B, H, W, L, &sbytes));
   HK(hipMalloc(&ws, sbytes));
   CK(mi355x_sd_unet_bind_workspace(h, ws, sbytes));
-  HK(hipMalloc(&splitk, 64u << 20));
-  CK(mi355x_sd_set_workspace(splitk, 64u << 20));
 
   int atd = 0;
   const char* p = strstr(json, "\"addition_time_embed_dim\"");

@@ -45,9 +45,6 @@ class Emulator:
     def mi355x_sd_init(self, device):
         return 0
 
-    def mi355x_sd_set_workspace(self, ptr, nbytes):
-        return 0
-
     def mi355x_sd_last_error(self):
         return b"emulator"
 
@@ -98,7 +95,7 @@ class Emulator:
         dt = torch.float32 if flags & OUT_F32 else _lib.elem_dtype()
         _rows(C, M, N, ldc, dt).copy_(acc.to(dt))
 
-    def mi355x_sd_linear(self, A, lda, W, C, ldc, M, N, K, bias, rowbias, rpb, ld_rb, R, ldr, out_scale, flags, stream):
+    def mi355x_sd_linear(self, A, lda, W, C, ldc, M, N, K, bias, rowbias, rpb, ld_rb, R, ldr, out_scale, flags, ws, ws_bytes, stream):
         self.calls.append("linear")
         assert K % 8 == 0 and N % 4 == 0 and lda % 8 == 0 and ldc % 4 == 0
         a = _rows(A, M, K, lda).float()
@@ -107,7 +104,7 @@ class Emulator:
         return 0
 
     def mi355x_sd_linear_ex(self, A, lda, a_rpb, a_bs, W, w_scale, C, ldc, c_rpb, c_bs, M, N, K, bias, rowbias, ld_rb, gate,
-                            ld_gate, rpb, R, ldr, out_scale, flags, stream):
+                            ld_gate, rpb, R, ldr, out_scale, flags, ws, ws_bytes, stream):
         self.calls.append("linear_ex")
         assert K % 8 == 0 and N % 4 == 0 and lda % 8 == 0 and ldc % 4 == 0
         assert not (flags & GEGLU) and not rowbias
@@ -152,7 +149,7 @@ class Emulator:
         _flat(stats, 2 * rows, torch.float32).copy_(torch.stack([rstd, -mean * rstd], 1).reshape(-1))
         return 0
 
-    def mi355x_sd_linear_ln(self, A, lda, row_stats, W, w_rowsum, C, ldc, M, N, K, bias, flags, stream):
+    def mi355x_sd_linear_ln(self, A, lda, row_stats, W, w_rowsum, C, ldc, M, N, K, bias, flags, ws, ws_bytes, stream):
         self.calls.append("linear_ln")
         a = _rows(A, M, K, lda).float()
         w = _rows(W, N, K, K).float()
@@ -263,7 +260,7 @@ class Emulator:
         return 0
 
     def mi355x_sd_conv3x3(self, X, ldx, B, Hs, Ws, Cin, stride, up, W, C, ldc, Cout, bias, rowbias, ld_rb, R, ldr,
-                          out_scale, flags, stream):
+                          out_scale, flags, ws, ws_bytes, stream):
         self.calls.append("conv3x3")
         assert Cin % 8 == 0 and ldx % 8 == 0
         x = _rows(X, B * Hs * Ws, Cin, ldx).float().reshape(B, Hs, Ws, Cin).permute(0, 3, 1, 2)

@@ -99,14 +99,12 @@ int main(int argc, char** argv) {
   }
   size_t wbytes = 0, sbytes = 0;
   CK(mi355x_sd_unet_weight_bytes(h, &wbytes));
-  void *dw = NULL, *ws = NULL, *splitk = NULL;
+  void *dw = NULL, *ws = NULL;   /* (ws holds the handle's split-K scratch too since ABI 12) */
   HK(hipMalloc(&dw, wbytes));
   CK(mi355x_sd_unet_finalize_weights(h, dw, wbytes, NULL));
   CK(flags ? mi355x_sd_unet_plan_ex(h, B, H, W, L, flags, &sbytes) : mi355x_sd_unet_plan(h, B, H, W, L, &sbytes));
   HK(hipMalloc(&ws, sbytes));
   CK(mi355x_sd_unet_bind_workspace(h, ws, sbytes));
-  HK(hipMalloc(&splitk, 32u << 20));
-  CK(mi355x_sd_set_workspace(splitk, 32u << 20));
 
   /* ---- inputs ---- */
   const int64_t ns = (int64_t)B * in_ch * H * W, ne = (int64_t)B * L * cross_dim, no = (int64_t)B * out_ch * H * W;

@@ -545,15 +545,22 @@ def test_errors_are_loud(ops):
         ops.linear(a, w)  # K not a multiple of 8
     with pytest.raises(MI355XError):
         ops.linear(torch.zeros(8, 16, dtype=torch.bfloat16), torch.zeros(16, 16, dtype=torch.bfloat16))  # CPU tensors
-    # a host buffer as the split-K workspace is refused by the library itself (it used to be accepted and written through by the
-    # next split-K launch: a page fault on boxes without XNACK); the wrappers' device workspace stays bound
+    # a host buffer as a GEMM call's scratch is refused by the library itself, before anything is launched (until ABI 11 a
+    # process-wide binding accepted one and the next split-K launch wrote through it: a page fault on boxes without XNACK)
     from paddlemix_amd import _lib
     lib = _lib.load()
-    host = torch.empty(4096, dtype=torch.uint8)
-    assert lib.mi355x_sd_set_workspace(host.data_ptr() & ~15, 1024) != 0
-    assert b"device memory" in lib.mi355x_sd_last_error()
-    ops._bind_workspace(a.device)
-    assert not any(d.type == "cpu" for d in ops._workspaces)
+    host = torch.empty(4096 + 16, dtype=torch.uint8)
+    a16 = torch.zeros(8, 16, device="cuda", dtype=torch.bfloat16)
+    w16 = torch.zeros(16, 16, device="cuda", dtype=torch.bfloat16)
+    out = torch.zeros(8, 16, device="cuda", dtype=torch.bfloat16)
+    st = torch.cuda.current_stream().cuda_stream
+    rc = lib.mi355x_sd_linear(a16.data_ptr(), 16, w16.data_ptr(), out.data_ptr(), 16, 8, 16, 16, None, None, 0, 0, None, 0, 1.0, 0,
+                              (host.data_ptr() + 15) & ~15, 1024, st)
+    assert rc != 0 and b"device memory" in lib.mi355x_sd_last_error()
+    rc = lib.mi355x_sd_linear(a16.data_ptr(), 16, w16.data_ptr(), out.data_ptr(), 16, 8, 16, 16, None, None, 0, 0, None, 0, 1.0, 0,
+                              out.data_ptr() + 8, 1024, st)
+    assert rc != 0 and b"16-byte aligned" in lib.mi355x_sd_last_error()
+    assert not any(d.type == "cpu" for d, _ in ops._workspaces)
 
 
 @pytest.mark.parametrize("B,H,Sq,Skv,D", [(2, 5, 256, 77, 64), (1, 4, 128, 130, 64), (1, 8, 64, 77, 40)])
@@ -611,9 +618,8 @@ def test_fp32_residual_forms_of_the_norms(ops, rows, C):
     R = torch.randn(rows, N, generator=g).cuda() * 7
     bias = torch.randn(N, generator=g).cuda()
     out = torch.empty(rows, N, device="cuda")
-    ops._bind_workspace(a.device)   # (a direct ABI call: the split-K workspace is whatever was bound last -- bind the wrappers' own)
     _lib.check(lib.mi355x_sd_linear(a.data_ptr(), C, w.data_ptr(), out.data_ptr(), N, rows, N, C, bias.data_ptr(), None, 0, 0,
-                                    R.data_ptr(), N, 1.0, _lib.OUT_F32 | _lib.R_F32, st))
+                                    R.data_ptr(), N, 1.0, _lib.OUT_F32 | _lib.R_F32, *ops._workspace(a.device), st))
     want = a.float() @ w.float().t() + bias + R
     assert (out - want).abs().max() < 2e-4 * want.abs().max()     # fp32 accumulation order only: no 16-bit rounding anywhere
 

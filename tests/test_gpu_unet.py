@@ -452,3 +452,39 @@ def test_from_pretrained_into_the_hip_path(tmp_path):
     ref = U.unet_forward({k: (v.to(torch.bfloat16).float() if v.dim() > 1 else v) for k, v in P.items()}, cfg, sample, 77, enc,
                          added_cond_kwargs=added)
     assert _rel(got.cpu(), ref) < BAR_16
+
+
+def test_two_models_on_two_streams_match_their_serial_runs_bit_for_bit():
+    """ABI 12: the split-K / widening scratch is an argument of every GEMM-class call and belongs to the model that
+    plans the call -- until ABI 11 it was ONE process-wide binding that two models on two streams shared (and that a stale pointer
+    could survive in). Two models with their own weights and inputs, whose batch-2 16x16 geometry puts most GEMMs on split-K: run one
+    after the other, then both at once on their own streams without any synchronisation in between, many times; every concurrent
+    result must equal the model's serial result bit for bit. The C++ handle API takes part as a third concurrent client."""
+    from paddlemix_amd.cexec import CUNet2DConditionModel
+    from paddlemix_amd.unet import UNet2DConditionModel, synth_unet_params
+    cfg = MINI_XL
+    models, inputs, serial = [], [], []
+    for seed in (11, 12):
+        P = synth_unet_params(cfg, seed=seed)
+        m = UNet2DConditionModel(cfg, P, device="cuda:0")
+        s, e, a = _inputs(cfg, 2, 16, 16, seed=seed)
+        s, e, a = _cuda(s), _cuda(e), _cuda(a)
+        plan = m._get_plan(2, 16, 16, 77)
+        m.stage_inputs(plan, s, 500.0, e, a, in_scale=1.0)
+        torch.cuda.synchronize()
+        serial.append(m.run(plan).clone())
+        torch.cuda.synchronize()
+        models.append((m, plan))
+        inputs.append((s, e, a))
+    assert models[0][0]._gemm_ws[0] != models[1][0]._gemm_ws[0]                      # each model owns its scratch
+    assert any(fn.__name__ == "mi355x_sd_linear" and args[-3] == models[0][0]._gemm_ws[0] for fn, args, _, _ in models[0][1].prog)
+    cm = CUNet2DConditionModel(cfg, synth_unet_params(cfg, seed=11), device="cuda:0")
+    c_serial = cm(inputs[0][0], 500.0, inputs[0][1], added_cond_kwargs=inputs[0][2], return_dict=False)[0].clone()
+    torch.cuda.synchronize()
+    for it in range(12):
+        outs = [m.run(plan) for m, plan in models]                                       # two replays in flight, two streams
+        c_out = cm(inputs[0][0], 500.0, inputs[0][1], added_cond_kwargs=inputs[0][2], return_dict=False)[0]
+        torch.cuda.synchronize()
+        for o, ref in zip(outs, serial):
+            assert torch.equal(o, ref), it
+        assert torch.equal(c_out, c_serial), it
