@@ -437,7 +437,12 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
   static const bool epi_batch_off = sd_switch("MI355X_SD_GEMM_NO_EPI_BATCH") != nullptr;   // A/B switch (gemm_epilogue.h)
   a.epi_batch = epi_batch_off ? 0 : 1;
   a.bias_acc = 0;   // launch_gemm_pipe decides
-  const int tile = pick_tile(a);
+  int tile = pick_tile(a);
+  if (tile == 258) {   // four-wave 256 x 256 tile (gemm_w4.hip) where it applies, else the model's choice among the others
+    const int rc = launch_gemm_w4(a, stream);
+    if (rc != SD_ERR_UNSUPPORTED) return rc;
+    tile = pick_tile_model(a);
+  }
   // Column groups by tile width (round 4). An XCD runs 32 consecutive tile ids per round = 32/g row-tiles x g column-tiles; what
   // its L2 pulls through the fabric per round is (32/g) A row-panels + g W column-panels, minimal at g = sqrt(32 BM / BN): 7.2 for
   // the 256x160 tile, 5.1 for 256x320. Round 2 measured g = 4 and 8 inside the step (one g for every tile family) as equal in time

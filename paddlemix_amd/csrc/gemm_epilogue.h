@@ -82,12 +82,13 @@ struct Epi4Ops {
 __device__ __forceinline__ bool epi_batched(const GemmArgs& p) {
   return p.epi_batch && !p.geglu && !(p.gate && (p.rowbias || (p.R && p.r_f32)));
 }
-template <bool WS = false>
+template <bool WS = false, bool BR = false>
 __device__ __forceinline__ f32x4 epi4(const GemmArgs& p, f32x4 v, int m, int n, const float* rb, const float* gt, bool batched,
-                                      const Epi4Ops& o, const f32x4& wsc) {
+                                      const Epi4Ops& o, const f32x4& wsc, const f32x4& breg = f32x4{0.f, 0.f, 0.f, 0.f}) {
   if constexpr (WS) v *= wsc;   // (the weight-scale instantiations: the scale is in registers, gemm_epilogue below)
   else if (p.wscale) v *= *reinterpret_cast<const f32x4*>(p.wscale + n);
-  if (p.bias && !p.bias_acc) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+  if constexpr (BR) v += breg;  // (the bias-in-registers instantiation: zero where there is no bias)
+  else if (p.bias && !p.bias_acc) v += *reinterpret_cast<const f32x4*>(p.bias + n);
   if (batched) {
     if (gt) v *= o.x;
     else if (rb || (p.R && p.r_f32)) v += o.x;
@@ -173,11 +174,21 @@ __device__ __forceinline__ void store_row(const GemmArgs& p, size_t crow, int n_
 // old form (launch_gemm's picker keeps widened matrices off them). Both forms were tried on ALL kernels first: the 256 x 320 kernels
 // spilled, and scaling the accumulators up front made nearly every kernel spill (header, lesson 2) -- hence separate
 // instantiations; the WS = false code is what it was.
-template <int TM, int TN, bool WS = false>
+// BR (round 6, the four-wave 256 x 256 tile of gemm_w4.hip): the lane's TN bias vectors are fetched once in front of the row-tile loop
+// (that kernel's accumulators start at zero -- its first MFMAs take the constant 0 as C operand, no initialisation pass -- so the bias
+// is added here, from registers, instead of one dependent load per 4-channel group).
+template <int TM, int TN, bool WS = false, bool BR = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TN][TM], int m_wave, int n_wave,
                                               int lane) {
   const int lq = lane >> 4;
   constexpr bool WSH = WS && TM * TN <= 32;   // (the 160-register tiles keep the read-where-used form: they spill otherwise)
+  f32x4 bsr[BR ? TN : 1];
+  if constexpr (BR) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+      bsr[tn] = (p.bias && !p.bias_acc) ? *reinterpret_cast<const f32x4*>(p.bias + min(n_wave + acc_col<TN>(tn, lq, p.geglu), p.N - 4))
+                                        : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   f32x4 wsc[WSH ? TN : 1];
   if constexpr (WSH) {
 #pragma unroll
@@ -226,11 +237,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TN
       }
     }
     store_row<TN>(p, crow, n_wave, lq, [&](int tn, int n) {
-      if (!p.geglu) return epi4<WSH>(p, acc[tn][tm], m, n, rb, gt, batched, ops[TN <= 6 ? tn : 0], wsc[WSH ? tn : 0]);
+      if (!p.geglu) return epi4<WSH, BR>(p, acc[tn][tm], m, n, rb, gt, batched, ops[TN <= 6 ? tn : 0], wsc[WSH ? tn : 0], bsr[BR ? tn : 0]);
       f32x4 v = acc[tn][tm];   // GEGLU halves: fp8 scale and bias only (launch_gemm rejects the other operands)
       if constexpr (WSH) v *= wsc[tn];
       else if (p.wscale) v *= *reinterpret_cast<const f32x4*>(p.wscale + n);
-      if (p.bias && !p.bias_acc) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+      if constexpr (BR) v += bsr[tn];
+      else if (p.bias && !p.bias_acc) v += *reinterpret_cast<const f32x4*>(p.bias + n);
       return v;
     });
   }

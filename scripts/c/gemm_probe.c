@@ -26,6 +26,7 @@ enum { NBUF = 4 };
 
 int main(int argc, char** argv) {
   const int reps = argc > 1 ? atoi(argv[1]) : 20;
+  const unsigned mask = argc > 2 ? (unsigned)strtoul(argv[2], NULL, 0) : 0xFFFFFFFFu;   /* bit s: run shape s */
   CK(mi355x_sd_init(0));
   const int f16 = mi355x_sd_elem_dtype() == MI355X_SD_ELEM_F16;
   void* splitk = NULL;
@@ -39,6 +40,7 @@ int main(int argc, char** argv) {
   printf("# elem %s, %d launches per shape after 3 warm-up launches, %d-buffer rotation\n", f16 ? "fp16" : "bf16", reps, NBUF);
   for (size_t s = 0; s < sizeof(SHAPES) / sizeof(SHAPES[0]); ++s) {
     const Shape sh = SHAPES[s];
+    if (!((mask >> s) & 1u)) continue;
     const int Nout = sh.geglu ? sh.N / 2 : sh.N;
     void *A[NBUF], *C[NBUF], *Wt = NULL, *R = NULL;
     float* bias = NULL;

@@ -102,6 +102,21 @@ for B, H, W, Cin, Cout in ((8, 32, 32, 1280, 1280), (2, 30, 34, 640, 1280)):    
     res[f"conv {B}x{H}x{W}x{Cin}->{Cout}"] = dict(
         sha=hashlib.sha256(out.cpu().view(torch.int16).numpy().tobytes()).hexdigest()[:16],
         rel=((out[:H * W].float() - ref).norm() / ref.norm()).item())
+# wide launches without per-row operands (what the four-wave 256 x 256 tile of csrc/gemm_w4.hip takes, round 6): one K-tile (its
+# prologue + last iteration alone), two, an odd count; ragged M and N; SiLU; fewer tiles than CUs and several rounds of persistent blocks
+for M, N, K, kind in ((1000, 1288, 64, "plain"), (515, 1928, 128, "silu"), (3000, 3840, 1280, "plain"), (8192, 3840, 1280, "nobias"),
+                      (33000, 1536, 1536, "plain"), (700, 2048, 320, "plain")):
+    g = torch.Generator(device="cuda").manual_seed(M + N + K + 5)
+    a = torch.randn(M, K, device="cuda", generator=g).to(ed)
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(ed)
+    b = None if kind == "nobias" else torch.randn(N, device="cuda", generator=g)
+    out = ops.linear(a, w, b, silu=kind == "silu")
+    rows = slice(M - 256, M)
+    ref = a[rows].float() @ w.float().t() + (b if b is not None else 0)
+    if kind == "silu":
+        ref = F.silu(ref)
+    res[f"gemm {M}x{N}x{K} wide {kind}"] = dict(sha=hashlib.sha256(out.cpu().view(torch.int16).numpy().tobytes()).hexdigest()[:16],
+                                                rel=((out[rows].float() - ref).norm() / ref.norm()).item())
 # weight-only fp8 on a just-in-time widened matrix (round 5: kernel instantiations that keep the per-channel scale in registers,
 # csrc/gemm_epilogue.h WS; under MI355X_SD_NO_PIPE the same launches run the read-where-used epilogue of the generic loop): plain,
 # tanh-GELU (SD3 FF1), gate + residual (SD3 to_out / FF2), a row-remapped output (the joint QKV buffer), ragged M, ragged N
