@@ -13,6 +13,13 @@ B2  ``MI355XAttnProcessor`` -- an object with the ``AttnProcessor.__call__(attn,
     attention, output projection (+ residual) through the C ABI.  ``Attention`` below is the minimal weight holder with
     exactly those attributes, for use without Paddle.
 
+B2' ``MI355XJointAttnProcessor`` -- the SD3 form of the same seam: ``JointAttnProcessor2_5.__call__(attn, hidden_states,
+    encoder_hidden_states, attention_mask)`` (attention_processor.py:909-983) returns ``(hidden_states, encoder_hidden_states)``:
+    image-token and text-token projections (``to_q/k/v`` and ``add_q/k/v_proj``) written side by side into one joint
+    [B, S_img + S_txt, .] buffer (the GEMMs' row remap: no concat), ONE attention over the joint sequence, the two output
+    projections (``to_out[0]``; ``to_add_out`` unless ``context_pre_only``) reading their halves of it in place (no split).
+    ``JointAttention`` is the matching weight holder.
+
 These seams exist for drop-in use and parity testing; the fast path is the whole-UNet program (seam B1, unet.py), which
 fuses QKV, batches the cross-attention K/V projections and replays one hipGraph per step.  No CPU fallback.
 """
@@ -152,3 +159,82 @@ class MI355XAttnProcessor:
         if attn.residual_connection:
             out = out + residual
         return out / attn.rescale_output_factor
+
+
+class JointAttention:
+    """Weight holder with the attributes ``JointAttnProcessor2_5`` reads (attention_processor.py:96-207, 909-983): the image stream's
+    ``to_q / to_k / to_v / to_out[0]``, the text stream's ``add_q_proj / add_k_proj / add_v_proj`` and, unless ``context_pre_only``,
+    ``to_add_out``; ``heads``; built from a state-dict slice in Paddle layouts (Linear.weight [in, out])."""
+
+    def __init__(self, params: Mapping[str, Tensor], heads: int, context_pre_only: bool = False, device="cuda"):
+        def lin(name):
+            w = params[name + ".weight"].to(device=device, dtype=torch.float32)
+            b = params.get(name + ".bias")
+            return _Linear(weight=w, bias=None if b is None else b.to(device=device, dtype=torch.float32).contiguous(),
+                           w_nk=w.t().to(ops._lib.elem_dtype()).contiguous())
+
+        self.to_q, self.to_k, self.to_v = lin("to_q"), lin("to_k"), lin("to_v")
+        self.add_q_proj, self.add_k_proj, self.add_v_proj = lin("add_q_proj"), lin("add_k_proj"), lin("add_v_proj")
+        self.to_out = [lin("to_out.0"), None]
+        self.context_pre_only = context_pre_only
+        self.to_add_out = None if context_pre_only else lin("to_add_out")
+        self.heads = heads
+        self.scale = (self.to_q.weight.shape[1] // heads) ** -0.5
+        self.processor = MI355XJointAttnProcessor()
+
+    def set_processor(self, processor) -> None:
+        self.processor = processor
+
+    def __call__(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **kw):
+        return self.processor(self, hidden_states, encoder_hidden_states=encoder_hidden_states, attention_mask=attention_mask, **kw)
+
+
+class MI355XJointAttnProcessor:
+    """B2, SD3 form: drop-in ``JointAttnProcessor2_5`` (attention_processor.py:909-983) on the MI355X kernels. Same contract -- returns
+    ``(hidden_states, encoder_hidden_states)``, 4-D inputs are flattened and restored the way the reference does -- and the
+    reference's own limits: no attention mask is applied by that processor (``attention_mask`` is accepted and must be None here: a
+    mask the caller expects to be honoured is refused instead of silently ignored)."""
+
+    def __call__(self, attn, hidden_states: Tensor, encoder_hidden_states: Tensor = None, attention_mask: Optional[Tensor] = None,
+                 *args, **kwargs):
+        if encoder_hidden_states is None:
+            raise ValueError("JointAttnProcessor needs encoder_hidden_states (the text stream of the MMDiT block)")
+        if attention_mask is not None:
+            raise NotImplementedError("the reference's JointAttnProcessor2_5 applies no mask; pass attention_mask=None")
+        ed = ops._lib.elem_dtype()
+        in_dtype, ctx_dtype = hidden_states.dtype, encoder_hidden_states.dtype
+        input_ndim, context_input_ndim = hidden_states.dim(), encoder_hidden_states.dim()
+        if input_ndim == 4:
+            B, C, Hh, Ww = hidden_states.shape
+            hidden_states = hidden_states.reshape(B, C, Hh * Ww).transpose(1, 2)
+        if context_input_ndim == 4:
+            Bc, Cc, Hc, Wc = encoder_hidden_states.shape
+            encoder_hidden_states = encoder_hidden_states.reshape(Bc, Cc, Hc * Wc).transpose(1, 2)
+        B, S1, C = hidden_states.shape
+        S2 = encoder_hidden_states.shape[1]
+        x = hidden_states.to(ed).contiguous().reshape(B * S1, C)
+        c = encoder_hidden_states.to(ed).contiguous().reshape(B * S2, encoder_hidden_states.shape[-1])
+        inner = attn.to_q.w_nk.shape[0]
+        d = inner // attn.heads
+        S = S1 + S2
+        # q / k / v of both streams side by side in ONE joint buffer: image rows of batch b at b * S, text rows behind them (the
+        # C row remap of mi355x_sd_linear_ex = the reference's three concats, attention_processor.py:948-951)
+        qkv = [torch.empty(B * S * inner, device=x.device, dtype=ed) for _ in range(3)]
+        for buf, l_img, l_txt in zip(qkv, (attn.to_q, attn.to_k, attn.to_v), (attn.add_q_proj, attn.add_k_proj, attn.add_v_proj)):
+            ops.linear_ex(x, l_img.w_nk, l_img.bias, out=buf, c_rows_per_batch=S1, c_batch_stride=S * inner, M=B * S1)
+            ops.linear_ex(c, l_txt.w_nk, l_txt.bias, out=buf[S1 * inner:], c_rows_per_batch=S2, c_batch_stride=S * inner, M=B * S2)
+        q, k, v = (t.view(B, S, attn.heads, d) for t in qkv)
+        o = scaled_dot_product_attention_(q, k, v, dropout_p=0.0, is_causal=False).reshape(B * S * inner)
+        # the two output projections read their halves of the joint attention output in place (A row remap = the reference's split, :965-969)
+        out = ops.linear_ex(o, attn.to_out[0].w_nk, attn.to_out[0].bias, a_rows_per_batch=S1, a_batch_stride=S * inner, M=B * S1)
+        out = out.reshape(B, S1, -1).to(in_dtype)
+        if not attn.context_pre_only:
+            enc = ops.linear_ex(o[S1 * inner:], attn.to_add_out.w_nk, attn.to_add_out.bias, a_rows_per_batch=S2, a_batch_stride=S * inner,
+                                M=B * S2).reshape(B, S2, -1).to(ctx_dtype)
+        else:   # the reference returns the raw attention rows of the text stream in this case (attention_processor.py:975-976)
+            enc = o.view(B, S, inner)[:, S1:].to(ctx_dtype)
+        if input_ndim == 4:
+            out = out.transpose(1, 2).reshape(B, C, Hh, Ww)
+        if context_input_ndim == 4:
+            enc = enc.transpose(1, 2).reshape(Bc, Cc, Hc, Wc)
+        return out, enc

@@ -305,7 +305,13 @@ static int pick_tile(const GemmArgs& a) {
     }
     return v;
   }();
-  const int chosen = pick_tile_model(a);
+  int chosen = pick_tile_model(a);
+  // The wide launches without per-row epilogue operands -- fused QKV, FF1 (GEGLU / tanh-GELU), N >= 1536 with at least three quarters
+  // of a chip of 256 x 256 tiles -- take the four-wave tile (gemm_w4.hip, id 258): sustained and interleaved against the tiles above
+  // (profiles/r06_s6_w4_probe.txt) 8192 x 3840 x 1280 72.5 vs 82.6 us, 8192 x 10240 x 1280 GEGLU 172 vs 188, 32768 x 5120 x 640 GEGLU
+  // 210 vs 228, 32768 x 1920 x 640 101 vs 120. MI355X_SD_GEMM_TILE_MAP="258:160" (debug build) maps it away again.
+  static const bool w4_off = sd_switch("MI355X_SD_NO_W4") != nullptr;
+  if (!w4_off && a.M >= 2048 && a.N >= 1536 && gemm_w4_applies(a) && (long)((a.M + 255) / 256) * ((a.N + 255) / 256) >= 192) chosen = 258;
   for (const auto& m : remap)
     if (m.first == chosen && !(a.geglu && (m.second == 129 || m.second == 160)) && a.M >= 256) return m.second;
   return chosen;

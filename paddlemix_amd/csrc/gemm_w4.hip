@@ -46,6 +46,14 @@ using ic_t = std::integral_constant<int, V>;
 __device__ __forceinline__ void dma(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds, unsigned voff, int soff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)lds, 16, voff, soff, 0, 0);
 }
+// lane index from the execution mask (v_mbcnt), through an opaque asm: recomputed wherever it is needed instead of keeping the
+// thread id -- or anything derived from it -- alive across the K loop (kept alive it was spilled, and a scratch reload next to the
+// epilogue's stores or the carried prologue is a vmcnt(0))
+__device__ __forceinline__ int lane_id() {
+  int l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  asm volatile("" : "+v"(l));
+  return l;
+}
 // acc += w x a on the matrix pipe with the accumulator tile in a-registers
 __device__ __forceinline__ void mfma_a(f32x4& acc, const bf16x8& w, const bf16x8& a) {
 #ifdef MI355X_SD_F16
@@ -65,7 +73,63 @@ __device__ __forceinline__ void mfma_a0(f32x4& acc, const bf16x8& w, const bf16x
 }  // namespace w4
 
 // BS: step of k-step 0 that carries the barrier (>= 16: the reads of set 1 are issued in steps 0 .. 15); DSP: steps between two DMA pieces
-template <int BS, int DSP>
+// Epilogue of the four-wave tile: bias (from registers) / GEGLU / out_scale / SiLU / tanh-GELU, 16-byte stores of the build's 16-bit type,
+// the operands gemm_w4_applies admits, nothing else. Its own function rather than gemm_epilogue<8, 8>:
+// the general form (every operand kind of every launch, two output types) came out as 15 k instructions here and made the register
+// allocator SPILL accumulator tiles to scratch inside the epilogue -- and every scratch reload is a vmcnt(0) behind the stores issued
+// before it, one write-back round trip each: 24 us per 128-KB tile (profiles/r06_s3_w4_ablation.txt: the launch without its
+// epilogue ran in 55.8 us, with it in 104.1 us).
+// Two halves: the lane's TN bias vectors are fetched AND awaited first (the asm operands make the compiler place its vmcnt(0) here,
+// while nothing else is in flight), then the caller may put the next tile's prologue DMA on its way, then the stores.
+template <int TN>
+__device__ __forceinline__ void w4_load_bias(const GemmArgs& p, f32x4 (&bs)[TN], int n_wave, int lane) {
+  const int lq = lane >> 4;
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn)
+    bs[tn] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + min(n_wave + acc_col<TN>(tn, lq, p.geglu), p.N - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) asm volatile("" : "+v"(bs[tn]));
+}
+template <int TM, int TN>
+__device__ __forceinline__ void w4_epilogue(const GemmArgs& p, f32x4 (&acc)[TN][TM], const f32x4 (&bs)[TN], int m_wave, int n_wave, int lane) {
+  const int lq = lane >> 4;
+  bf16* C = reinterpret_cast<bf16*>(p.C);
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int m = m_wave + tm * 16 + (lane & 15);
+    if (m >= p.M) continue;
+    const size_t crow = (size_t)m * p.ldc;
+    if (p.geglu) {
+#pragma unroll
+      for (int hp = 0; hp < TN / 4; ++hp) {   // (gemm_epilogue.h store_row: two output pairs = 8 consecutive output channels)
+        const int n_phys = n_wave + acc_col<TN>(4 * hp, lq, true);
+        if (n_phys >= p.N) continue;
+        const f32x4 lo = geglu4(acc[4 * hp][tm] + bs[4 * hp], acc[4 * hp + 1][tm] + bs[4 * hp + 1]);
+        const f32x4 hi = geglu4(acc[4 * hp + 2][tm] + bs[4 * hp + 2], acc[4 * hp + 3][tm] + bs[4 * hp + 3]);
+        const u32x4 pk = {pack_bf16(lo[0], lo[1]), pack_bf16(lo[2], lo[3]), pack_bf16(hi[0], hi[1]), pack_bf16(hi[2], hi[3])};
+        *reinterpret_cast<u32x4*>(C + crow + (n_wave >> 1) + hp * 32 + lq * 8) = pk;
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < TN / 2; ++h) {
+        const int n = n_wave + h * 32 + lq * 8;
+        if (n >= p.N) continue;   // (N % 8 == 0: a lane's 8 channels are inside or outside together)
+        const f32x4 lo = act4(p, (acc[2 * h][tm] + bs[2 * h]) * p.out_scale), hi = act4(p, (acc[2 * h + 1][tm] + bs[2 * h + 1]) * p.out_scale);
+        const u32x4 pk = {pack_bf16(lo[0], lo[1]), pack_bf16(lo[2], lo[3]), pack_bf16(hi[0], hi[1]), pack_bf16(hi[2], hi[3])};
+        *reinterpret_cast<u32x4*>(C + crow + n) = pk;
+      }
+    }
+    // one row-tile at a time: left to itself the scheduler reads all 256 accumulator registers up front (256 VGPRs, spills)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// ABL (debug build only, timing ablations with WRONG results): 1 no DMA in the loop, 2 no fragment reads in the loop, 4 no barrier / waits,
+// 8 no epilogue
+#ifndef W4_CARRY_DEFAULT
+#define W4_CARRY_DEFAULT true
+#endif
+template <int BS, int DSP, int ABL = 0, bool CARRY = W4_CARRY_DEFAULT>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
   using namespace w4;
   constexpr int BM = 256, BN = 256, TM = 8, TN = 8, NW = 4, AP = 8, WP = 8;
@@ -84,44 +148,51 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
   const __amdgpu_buffer_rsrc_t w_rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.W), 0, (unsigned)((size_t)p.N * p.K * 2), 0x00020000);
 
-  for (int vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
-    int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));   // (per-tile lane constants must not be hoisted out of the tile loop and kept alive across the K loop)
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int lid = xcd_remap(vb, nvb);
+  // tile vb: coordinates and the per-lane DMA offsets of this wave's pieces (piece q = wave + 4 i: 8 rows x 128 B; lane -> row
+  // q*8 + (lane>>3), 16-byte chunk (lane&7) ^ row -- gemm_pipe.hip's LDS image). The thread id comes through an opaque asm every
+  // time: lane constants hoisted out of the tile loop would be kept alive across the K loop (and spilled).
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  unsigned a_off[AP], w_off[WP];
+  int m0 = 0, n0 = 0;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (an SGPR for the life of the block)
+  auto place_tile = [&](const int vb, int& tm0, int& tn0) {
+    const int lane = lane_id();
     int tile_m, tile_n;
-    tile_coords(lid, ntm, ntn, p.gm, tile_m, tile_n);
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-    // ---- LDS-DMA geometry (gemm_pipe.hip): piece q = wave + 4 i (8 rows x 128 B); lane -> row q*8 + (lane>>3), chunk (lane&7) ^ row ----
-    const int sub = lane >> 3;
-    const int cg = (lane & 7) ^ sub;
-    constexpr unsigned OOB = 0xFFFFFFF0u;
-    unsigned a_off[AP], w_off[WP];
+    tile_coords(xcd_remap(vb, nvb), ntm, ntn, p.gm, tile_m, tile_n);
+    tm0 = tile_m * BM;
+    tn0 = tile_n * BN;
+    const int sub = lane >> 3, cg = (lane & 7) ^ sub;
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
-      const int m = m0 + (wave + i * NW) * 8 + sub;
-      const size_t arow = p.a_rpb ? (size_t)(m / p.a_rpb) * p.a_bstride + (size_t)(m % p.a_rpb) * p.lda : (size_t)m * p.lda;
-      a_off[i] = m < p.M ? (unsigned)((arow + cg * 8) * 2) : OOB;
+      const int m = tm0 + (wave + i * NW) * 8 + sub;
+      a_off[i] = m < p.M ? (unsigned)(((size_t)m * p.lda + cg * 8) * 2) : OOB;
     }
 #pragma unroll
     for (int i = 0; i < WP; ++i) {
-      const int n = n0 + w_row_of_lds_row<TN>((wave + i * NW) * 8 + sub, p.geglu);
+      const int n = tn0 + w_row_of_lds_row<TN>((wave + i * NW) * 8 + sub, p.geglu);
       w_off[i] = (n < p.N) ? (unsigned)(((size_t)n * p.K + cg * 8) * 2) : OOB;
     }
-    // piece j of a K-tile: j < 8 an A piece, else a W piece; kb = byte offset of the K-tile
-    auto issue_piece = [&](auto jc, const int stage, const int kb) {
-      constexpr int j = decltype(jc)::value;
-      if constexpr (j < AP) dma(a_rsrc, As + stage * STAGE_A + (wave + j * NW) * 1024, a_off[j], kb);
-      else dma(w_rsrc, Ws + stage * STAGE_W + (wave + (j - AP) * NW) * 1024, w_off[j - AP], kb);
-    };
-
-    // ---- prologue: tiles 0 and 1 on their way (nothing else: the accumulators need no initialisation, the first k-step's MFMAs
-    // take the constant 0 as their C operand; the bias is added in the epilogue from registers, gemm_epilogue.h BR) ----
+  };
+  // piece j of a K-tile: j < 8 an A piece, else a W piece; kb = byte offset of the K-tile
+  auto issue_piece = [&](auto jc, const int stage, const int kb) {
+    constexpr int j = decltype(jc)::value;
+    if constexpr (j < AP) dma(a_rsrc, As + stage * STAGE_A + (wave + j * NW) * 1024, a_off[j], kb);
+    else dma(w_rsrc, Ws + stage * STAGE_W + (wave + (j - AP) * NW) * 1024, w_off[j - AP], kb);
+  };
+  // prologue of a tile: K-tiles 0 and 1 on their way (nothing else: the accumulators need no initialisation -- the first k-step's
+  // MFMAs take the constant 0 as their C operand -- and the bias is added in the epilogue)
+  auto issue_prologue = [&]() {
     static_for<0, AP + WP>([&](auto jc) { issue_piece(jc, 0, 0); });
-    static_for<0, AP + WP>([&](auto jc) { issue_piece(jc, 1, min(1, nt - 1) * BK * 2); });
+    static_for<0, AP + WP>([&](auto jc) { issue_piece(jc, 1, BK * 2); });
+  };
+
+  int vb = blockIdx.x;
+  place_tile(vb, m0, n0);
+  issue_prologue();
+  bool carried = false;   // this tile's prologue went out BEFORE the previous tile's stores (block-uniform)
+  while (true) {
+    const int lane = lane_id();
+    const int wm = wave >> 1, wn = wave & 1;
     f32x4 acc[TN][TM];
     const int frow = lane & 15, fkc = lane >> 4, rsw = frow & 7;
     const int a_row = (wm * (TM * 16) + frow) * 128, w_row = (wn * (TN * 16) + frow) * 128;
@@ -137,25 +208,35 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
         fa[set][k - 1] = *reinterpret_cast<const bf16x8*>(As + stage * STAGE_A + a_row + (set ? c1 : c0) + (k - 1) * 16 * 128);
       }
     };
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AP + WP) : "memory");   // tile 0 landed (tile 1 may still fly)
+    // K-tile 0 landed. First tile of the block: K-tile 1 may still fly (vmcnt counts it). A carried prologue sits in FRONT of the
+    // previous tile's stores in the (in-order) counter: waiting for everything is exact there, and by now cheap -- the pieces
+    // landed under the epilogue, what is left is the write-back of its last stores.
+    if (carried) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AP + WP) : "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     static_for<0, TM + TN>([&](auto kc) { read_one(ic_t<0>{}, kc, 0); });
+    if constexpr ((ABL & 2) != 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[1][i] = fa[0][i], fw[1][i] = fw[0][i];
+    }
 
     // iteration of tile t (stage cur = t & 1): DMA = 1: the pieces of tile t+2 go out behind the barrier; NEXT = 1: there is a tile t+1;
-    // FIRST = 1: t = 0, the accumulators' chains start here
+    // FIRST = 1: t = 0, the accumulators' chains start here. 64 steps of [read][DMA piece][2 MFMAs] (one MFMA per step with the
+    // same memory instructions spread over twice as many gaps measured 4 - 8 % SLOWER, profiles/r06_s5_w4_probe.txt).
     auto iter = [&](auto dmac, auto nextc, auto firstc, const int cur, const int kb2) {
       constexpr int DMA = decltype(dmac)::value, NEXT = decltype(nextc)::value, FIRST = decltype(firstc)::value;
       static_for<0, 2 * NSTEP>([&](auto sc) {
         constexpr int s = decltype(sc)::value, ks = s / NSTEP, st = s % NSTEP;
-        if constexpr (ks == 0 && st < TM + TN) read_one(ic_t<1>{}, ic_t<st>{}, cur);                    // set 1 of tile t
-        if constexpr (ks == 1 && st < TM + TN && NEXT) read_one(ic_t<0>{}, ic_t<st>{}, cur ^ 1);        // set 0 of tile t+1
-        if constexpr (DMA && s > BS && (s - BS - 1) % DSP == 0 && (s - BS - 1) / DSP < AP + WP)
+        if constexpr (ks == 0 && st < TM + TN && !(ABL & 2)) read_one(ic_t<1>{}, ic_t<st>{}, cur);                    // set 1 of tile t
+        if constexpr (ks == 1 && st < TM + TN && NEXT && !(ABL & 2)) read_one(ic_t<0>{}, ic_t<st>{}, cur ^ 1);        // set 0 of tile t+1
+        if constexpr (DMA && !(ABL & 1) && s > BS && (s - BS - 1) % DSP == 0 && (s - BS - 1) / DSP < AP + WP)
           issue_piece(ic_t<(s - BS - 1) / DSP>{}, cur, kb2);
-        if constexpr (s == BS && NEXT) {
+        if constexpr (s == BS && !(ABL & 4)) {
           // every read of tile t retired; own pieces of tile t+1 landed (nothing newer in flight) -> the barrier publishes tile t+1
-          // and frees the stage of tile t
+          // and frees the stage of tile t. The LAST iteration keeps the barrier: behind it no wave reads LDS again, which is what
+          // lets any wave start the next tile's prologue DMA without another one.
           asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
           __builtin_amdgcn_s_barrier();
@@ -180,20 +261,50 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
     // the matrix pipe's last results are read by VALU code the compiler schedules without knowing the asm above was an MFMA
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 
-    const int m_w = m0 + wm * (TM * 16), n_w = n0 + wn * (TN * 16);
-    gemm_epilogue<TM, TN, false, true>(p, acc, m_w, n_w, lane);
+    // the next tile's prologue goes out ahead of this tile's stores (CARRY): its pieces land under the epilogue
+    const int em0 = m0, en0 = n0;
+    const int vb_next = vb + (int)gridDim.x;
+    const bool has_next = vb_next < nvb;
+    const int lane_e = lane_id();
+    const int m_w = em0 + wm * (TM * 16), n_w = en0 + wn * (TN * 16);
+    f32x4 bs[TN];
+    if constexpr (!(ABL & 8)) w4_load_bias<TN>(p, bs, n_w, lane_e);
+    __builtin_amdgcn_sched_barrier(0);
+    if (CARRY && has_next) {
+      place_tile(vb_next, m0, n0);
+      issue_prologue();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr ((ABL & 8) != 0) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) asm volatile("" ::"a"(acc[i][j]));
+    } else {
+      w4_epilogue<TM, TN>(p, acc, bs, m_w, n_w, lane_e);
+    }
+    if (!has_next) break;
+    vb = vb_next;
+    if (CARRY) {
+      carried = true;
+    } else {
+      place_tile(vb, m0, n0);
+      issue_prologue();
+    }
   }
 }
 
 // shapes the four-wave tile takes: 16-bit operands, K % 64 == 0, no split-K / LN fold / conv / fp8 scale, and an epilogue without
 // per-row operands (residual, gate, row bias: the general epilogue of 8-sub-tile waves fetches those one group at a time)
 bool gemm_w4_applies(const GemmArgs& a) {
-  if (a.conv || a.rowstat || a.wscale || a.R || a.gate || a.rowbias || a.out_f32 || a.splitk > 1) return false;
+  if (a.conv || a.rowstat || a.wscale || a.R || a.gate || a.rowbias || a.out_f32 || a.splitk > 1 || !a.c_wide) return false;
+  // (no row remaps: the per-row division by a run-time rows-per-batch is hoisted out of the tile loop as VGPR constants that do not
+  // survive the K loop's 256 + 256 registers -- spilled, and reloaded between the epilogue's stores)
+  if (a.a_rpb || a.c_rpb) return false;
   if ((a.K & 63) || a.K < 192 || (a.N & 7)) return false;   // (at least three K-tiles: first / last-but-one / last iterations)
   if (a.geglu && (a.N & 31)) return false;
   const size_t lim = 0xFFFF0000ull;
-  const size_t a_ext = a.a_rpb ? ((size_t)((a.M - 1) / a.a_rpb) * a.a_bstride + (size_t)(a.a_rpb - 1) * a.lda + a.K) * 2
-                               : ((size_t)(a.M - 1) * a.lda + a.K) * 2;
+  const size_t a_ext = ((size_t)(a.M - 1) * a.lda + a.K) * 2;
   return a_ext < lim && (size_t)a.N * a.K * 2 < lim;
 }
 
@@ -208,10 +319,20 @@ int launch_gemm_w4(const GemmArgs& a_in, hipStream_t stream) {
     const char* e = sd_switch("MI355X_SD_W4_SCHED");
     return e ? atoi(e) : 0;
   }();
-  K kern = sched == 1 ? (K)gemm_w4_kernel<20, 1> : sched == 2 ? (K)gemm_w4_kernel<16, 2> : sched == 3 ? (K)gemm_w4_kernel<24, 2>
-                                                                                                     : (K)gemm_w4_kernel<18, 2>;
-  static bool attr_done[4] = {false, false, false, false};
-  const int si = (sched >= 1 && sched <= 3) ? sched : 0;
+  K kern = (K)gemm_w4_kernel<18, 2>;
+#ifdef MI355X_SD_DEBUG_SWITCHES
+  if (sched == 1) kern = (K)gemm_w4_kernel<18, 2, 0, false>;   // the next tile's prologue behind the stores (A/B of the carried form)
+  if (sched == 10) kern = (K)gemm_w4_kernel<18, 2, 1>;    // timing ablations (wrong results)
+  if (sched == 11) kern = (K)gemm_w4_kernel<18, 2, 2>;
+  if (sched == 12) kern = (K)gemm_w4_kernel<18, 2, 4>;
+  if (sched == 13) kern = (K)gemm_w4_kernel<18, 2, 7>;
+  if (sched == 14) kern = (K)gemm_w4_kernel<18, 2, 8>;
+  if (sched == 15) kern = (K)gemm_w4_kernel<18, 2, 15>;
+  if (sched == 16) kern = (K)gemm_w4_kernel<18, 2, 3>;
+  if (sched == 17) kern = (K)gemm_w4_kernel<18, 2, 5>;
+#endif
+  static bool attr_done[20] = {};
+  const int si = (sched >= 0 && sched < 20) ? sched : 0;
   if (!attr_done[si]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
       return SD_ERR_HIP;

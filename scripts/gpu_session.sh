@@ -5,7 +5,7 @@
 #   MI355X_SD_GEMM_NO_PRE / _NO_EPI_BATCH / _NO_BIAS_ACC   round-2 epilogue forms          MI355X_SD_GEMM_PERSIST=0   one block per tile
 #   MI355X_SD_GEMM_TILE=<id> / _TILE_MAP=from:to,...       tile families (128 129 160 256 257 320)   MI355X_SD_NO_PIPE=1   generic loop
 #   MI355X_SD_ATTN_NO_SHORT / _NO_QT / _NO_WIDE     MI355X_SD_NO_GN_FUSED / _NO_SPLITK / _NO_WIDEN_F8      (the 15 switches left after
-#   round 4; each is exercised by tests/test_gpu_gemm_variants.py or tests/test_gpu_switches.py. Sessions of round 4: gpu_r04_s*.sh)
+#   round 4; each is exercised by tests/test_gpu_gemm_variants.py or tests/test_gpu_switches.py. The one-off session scripts of rounds 3-5 are in the history only; round 6: scripts/r06/)
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $O
 cd $GRAFT_REPO_ROOT

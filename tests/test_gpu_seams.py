@@ -99,3 +99,48 @@ def test_attn_processor_4d_groupnorm_residual():
     out = attn(x.cuda())
     ref = V.mid_attention(P, "a", x, 32, 1e-6)
     assert out.shape == x.shape and _rel(out, ref) < 6e-3, _rel(out, ref)
+
+
+@pytest.mark.parametrize("context_pre_only", [False, True])
+def test_joint_attn_processor_seam(context_pre_only):
+    """B2, SD3 form (VERDICT r5 missing #4): an object with JointAttnProcessor2_5's contract -- __call__(attn, hidden_states,
+    encoder_hidden_states, attention_mask) -> (hidden_states, encoder_hidden_states), attention_processor.py:909-983 -- installed on a
+    JointAttention weight holder and called through it; the expected values are that call site's own sequence of operations
+    (six projections, concat on the token axis, one attention over the joint sequence, split, two output projections) in fp32 math.
+    S_img + S_txt = 218 is ragged against every tile; context_pre_only: the last MMDiT block returns the raw text rows."""
+    from paddlemix_amd.attention import JointAttention, MI355XJointAttnProcessor
+    g = torch.Generator().manual_seed(9)
+    B, S1, S2, C, heads = 2, 64, 154, 128, 2
+    names = ["to_q", "to_k", "to_v", "add_q_proj", "add_k_proj", "add_v_proj", "to_out.0"] + ([] if context_pre_only else ["to_add_out"])
+    P = {}
+    for n in names:
+        P[n + ".weight"] = bfr(torch.randn(C, C, generator=g) / math.sqrt(C))   # Paddle layout [in, out]
+        P[n + ".bias"] = torch.randn(C, generator=g) * 0.1
+    x = bfr(torch.randn(B, S1, C, generator=g))
+    c = bfr(torch.randn(B, S2, C, generator=g))
+    attn = JointAttention(P, heads=heads, context_pre_only=context_pre_only)
+    calls = []
+
+    class Counting(MI355XJointAttnProcessor):
+        def __call__(self, *a, **k):
+            calls.append(1)
+            return super().__call__(*a, **k)
+    attn.set_processor(Counting())
+    out, enc = attn(x.cuda(), encoder_hidden_states=c.cuda())
+
+    def lin(t, n):
+        return t @ P[n + ".weight"] + P[n + ".bias"]
+    q = torch.cat([lin(x, "to_q"), lin(c, "add_q_proj")], 1)
+    k = torch.cat([lin(x, "to_k"), lin(c, "add_k_proj")], 1)
+    v = torch.cat([lin(x, "to_v"), lin(c, "add_v_proj")], 1)
+    d = C // heads
+    o = U.sdpa_math(q.reshape(B, -1, heads, d), k.reshape(B, -1, heads, d), v.reshape(B, -1, heads, d), None).reshape(B, S1 + S2, C)
+    ref_out = lin(o[:, :S1], "to_out.0")
+    ref_enc = o[:, S1:] if context_pre_only else lin(o[:, S1:], "to_add_out")
+    assert calls == [1] and out.shape == ref_out.shape and enc.shape == ref_enc.shape
+    assert out.dtype == torch.float32 and enc.dtype == torch.float32
+    assert _rel(out, ref_out) < 6e-3 and _rel(enc, ref_enc) < 6e-3, (_rel(out, ref_out), _rel(enc, ref_enc))
+    with pytest.raises(NotImplementedError):
+        attn(x.cuda(), encoder_hidden_states=c.cuda(), attention_mask=torch.zeros(B, 1, S1 + S2).cuda())
+    with pytest.raises(ValueError):
+        attn(x.cuda())
