@@ -430,6 +430,22 @@ int mi355x_sd_graph_end(void* stream, void** graph_exec);
 int mi355x_sd_graph_launch(void* graph_exec, void* stream);
 int mi355x_sd_graph_destroy(void* graph_exec);
 
+/* ---- multi-GPU (paddlemix_amd/csrc/comm.hip): what a plain-C host needs for "a batch of independent prompts shards across the
+ * GPUs of a node with an RCCL broadcast of the text-encoder / UNet weights over xGMI" (SURVEY.md 8e). One process per GPU. Rank 0 packs
+ * the weights (mi355x_sd_unet_finalize_weights / mi355x_sd_program_bind write them into ONE caller-owned device buffer), every rank
+ * allocates a buffer of the same size and receives it in place with mi355x_sd_comm_broadcast; each rank then denoises its own prompts
+ * with no per-step collective (batch rows never interact), and mi355x_sd_comm_all_gather collects the ranks' latents once at the end.
+ * The reference's precedent: the batch-parallel mode of its SD3 pipeline (PPD/pipelines/stable_diffusion_3/
+ * pipeline_stable_diffusion_3.py:803-839). `id128`: 128 opaque bytes made by rank 0 (mi355x_sd_comm_unique_id) and carried to the
+ * other ranks by the host's own means (file, socket, launcher environment). Collectives are stream-ordered on `stream`; byte counts,
+ * no element type. RCCL is loaded with dlopen at the first call: a machine without it still loads the library, these five entry
+ * points then return MI355X_SD_ERR_UNSUPPORTED with the reason in mi355x_sd_last_error(). */
+int mi355x_sd_comm_unique_id(void* id128);
+int mi355x_sd_comm_init(const void* id128, int rank, int world, void** comm);
+int mi355x_sd_comm_broadcast(void* comm, void* buf, size_t bytes, int root, void* stream);
+int mi355x_sd_comm_all_gather(void* comm, const void* send, void* recv, size_t bytes_per_rank, void* stream);
+int mi355x_sd_comm_destroy(void* comm);
+
 /* Test hook: dumps the lane->element maps of the MFMA / LDS-transpose instructions the kernels rely on
  * (out: 64*(4+16+4) floats, see tests/test_gpu_probe.py). */
 int mi355x_sd_probe_layouts(float* out, void* stream);

@@ -157,6 +157,12 @@ SIGNATURES = {
     "mi355x_sd_graph_launch": (c_int, [c_void_p, c_void_p]),
     "mi355x_sd_graph_destroy": (c_int, [c_void_p]),
     "mi355x_sd_probe_layouts": (c_int, [c_void_p, c_void_p]),
+    # multi-GPU entry points (csrc/comm.hip: RCCL through dlopen)
+    "mi355x_sd_comm_unique_id": (c_int, [c_void_p]),
+    "mi355x_sd_comm_init": (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),
+    "mi355x_sd_comm_broadcast": (c_int, [c_void_p, c_void_p, ctypes.c_size_t, c_int, c_void_p]),
+    "mi355x_sd_comm_all_gather": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p]),
+    "mi355x_sd_comm_destroy": (c_int, [c_void_p]),
 }
 
 _lib = None

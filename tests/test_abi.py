@@ -95,7 +95,7 @@ def test_emulator_answers_the_planners_size_queries_like_the_library():
 
 
 @pytest.mark.parametrize("src", ["tests/c/unet_exec_test.c", "tests/c/program_test.c", "scripts/c/step_bench.c", "scripts/c/gemm_probe.c",
-                                 "scripts/c/conv_probe.c", "scripts/c/attn_probe.c"])
+                                 "scripts/c/conv_probe.c", "scripts/c/attn_probe.c", "tests/c/comm_test.c"])
 def test_plain_c_clients_build_against_the_header_and_fail_loudly_without_a_device(src, tmp_path):
     """Every plain-C client of the ABI (the two GPU-test clients and the torch-free benches / probes) compiles against include/mi355x_sd.h
     as C11, links against the library, and -- on a machine without a GPU -- exits non-zero with the library's own message instead
@@ -110,7 +110,7 @@ def test_plain_c_clients_build_against_the_header_and_fail_loudly_without_a_devi
     exe = str(tmp_path / "client")
     libdir = os.path.dirname(_lib.LIB_PATH)
     subprocess.run(["gcc", "-std=c11", "-O2", "-Wall", "-Werror", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
-                    os.path.join(ROOT, src), "-L" + libdir, "-lmi355x_sd", "-L/opt/rocm/lib", "-lamdhip64", "-lm",
+                    "-I" + os.path.join(ROOT, "scripts", "c"), os.path.join(ROOT, src), "-L" + libdir, "-lmi355x_sd", "-L/opt/rocm/lib", "-lamdhip64", "-lm",
                     "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
     import torch
     if torch.cuda.is_available():
@@ -118,7 +118,7 @@ def test_plain_c_clients_build_against_the_header_and_fail_loudly_without_a_devi
     cfg = os.path.join(ROOT, "scripts", "c", "sd15_unet_config.json")
     args = {"tests/c/unet_exec_test.c": [cfg, "1", "8", "8", "7", str(tmp_path / "o.bin")], "tests/c/program_test.c": [str(tmp_path / "none.prog")],
             "scripts/c/step_bench.c": [cfg, "1", "8", "8", "7", "1", "0"], "scripts/c/gemm_probe.c": ["1"], "scripts/c/conv_probe.c": ["1"],
-            "scripts/c/attn_probe.c": ["1"]}[src]
+            "scripts/c/attn_probe.c": ["1"], "tests/c/comm_test.c": ["0", "1", str(tmp_path / "id.bin")]}[src]
     r = subprocess.run([exe] + args, capture_output=True, text=True, env=dict(os.environ, LD_LIBRARY_PATH=libdir), timeout=120)
     assert r.returncode != 0, r.stdout
     assert r.stderr.strip(), "a failing client says why"
