@@ -312,6 +312,10 @@ static int pick_tile(const GemmArgs& a) {
   // 210 vs 228, 32768 x 1920 x 640 101 vs 120. MI355X_SD_GEMM_TILE_MAP="258:160" (debug build) maps it away again.
   static const bool w4_off = sd_switch("MI355X_SD_NO_W4") != nullptr;
   if (!w4_off && a.M >= 2048 && a.N >= 1536 && gemm_w4_applies(a) && (long)((a.M + 255) / 256) * ((a.N + 255) / 256) >= 192) chosen = 258;
+  // The small launches of a batch-1 step (<= 128 tiles of 128 x 128, K <= 2560: what used to take split-K slices + a reduce kernel)
+  // take the 64 x 64 tile with the six-stage ring (gemm_small.hip, id 64). MI355X_SD_NO_SMALL (debug build): the round-5 path.
+  static const bool small_off = sd_switch("MI355X_SD_NO_SMALL") != nullptr;
+  if (!small_off && chosen == 128 && gemm_small_applies(a)) chosen = 64;
   for (const auto& m : remap)
     if (m.first == chosen && !(a.geglu && (m.second == 129 || m.second == 160)) && a.M >= 256) return m.second;
   return chosen;
@@ -444,6 +448,11 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
   a.epi_batch = epi_batch_off ? 0 : 1;
   a.bias_acc = 0;   // launch_gemm_pipe decides
   int tile = pick_tile(a);
+  if (tile == 64) {    // 64 x 64 tile, six-stage ring (gemm_small.hip), else the 128 x 128 tiles (with split-K slices)
+    const int rc = launch_gemm_small(a, stream);
+    if (rc != SD_ERR_UNSUPPORTED) return rc;
+    tile = 128;
+  }
   if (tile == 258) {   // four-wave 256 x 256 tile (gemm_w4.hip) where it applies, else the model's choice among the others
     const int rc = launch_gemm_w4(a, stream);
     if (rc != SD_ERR_UNSUPPORTED) return rc;

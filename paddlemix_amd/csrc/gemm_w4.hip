@@ -124,12 +124,77 @@ __device__ __forceinline__ void w4_epilogue(const GemmArgs& p, f32x4 (&acc)[TN][
   }
 }
 
+// EX: the epilogue of the MMDiT block GEMMs (mi355x_sd_linear_ex): out = R + gate[batch][n] * (acc + bias) (adaLN-Zero gated residuals,
+// PPD/models/attention.py:181-196) or (acc + bias + R) * out_scale, C rows remapped into / out of the joint [B, S_img + S_txt, .] buffer.
+// The batch of a tile is ONE number (the launcher admits remaps and gates only when their rows-per-batch is a multiple of the 256-row
+// tile): no per-row division. The residual rows of the NEXT row-tile are requested before the current one is finished (two row-tiles of
+// 16-byte loads in flight); the gate vectors sit in registers next to the bias.
+template <int TM, int TN>
+__device__ __forceinline__ void w4_epilogue_ex(const GemmArgs& p, f32x4 (&acc)[TN][TM], const f32x4 (&bs)[TN], int m_tile, int m_wave, int n_wave,
+                                               int lane) {
+  const int lq = lane >> 4;
+  bf16* C = reinterpret_cast<bf16*>(p.C);
+  f32x4 gs[TN];
+  const bool has_gate = p.gate != nullptr;
+  if (has_gate) {
+    const float* gt = p.gate + (size_t)(m_tile / p.rows_per_batch) * p.ld_gate;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) gs[tn] = *reinterpret_cast<const f32x4*>(gt + min(n_wave + acc_col<TN>(tn, lq, false), p.N - 4));
+  } else {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) gs[tn] = f32x4{1.f, 1.f, 1.f, 1.f};
+  }
+  // row m of C lives at c_base + (m - c_m0) * ldc
+  size_t c_base = 0;
+  int c_m0 = 0;
+  if (p.c_rpb) {
+    const int b = m_tile / p.c_rpb;
+    c_base = (size_t)b * p.c_bstride;
+    c_m0 = b * p.c_rpb;
+  }
+  const bool has_r = p.R != nullptr;
+  u32x4 r_cur[TN / 2], r_nxt[TN / 2];
+  auto load_r = [&](const int tm, u32x4 (&r)[TN / 2]) {
+    const int m = min(m_wave + tm * 16 + (lane & 15), p.M - 1);
+#pragma unroll
+    for (int h = 0; h < TN / 2; ++h) r[h] = *reinterpret_cast<const u32x4*>(p.R + (size_t)m * p.ldr + min(n_wave + h * 32 + lq * 8, p.N - 8));
+  };
+  if (has_r) load_r(0, r_nxt);
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    if (has_r) {
+#pragma unroll
+      for (int h = 0; h < TN / 2; ++h) r_cur[h] = r_nxt[h];
+      if (tm + 1 < TM) load_r(tm + 1, r_nxt);
+    }
+    const int m = m_wave + tm * 16 + (lane & 15);
+    if (m < p.M) {
+      const size_t crow = c_base + (size_t)(m - c_m0) * p.ldc;
+#pragma unroll
+      for (int h = 0; h < TN / 2; ++h) {
+        const int n = n_wave + h * 32 + lq * 8;
+        if (n >= p.N) continue;
+        f32x4 lo = (acc[2 * h][tm] + bs[2 * h]) * gs[2 * h], hi = (acc[2 * h + 1][tm] + bs[2 * h + 1]) * gs[2 * h + 1];
+        if (has_r) {
+          lo = add_r16(lo, u32x2{r_cur[h][0], r_cur[h][1]});
+          hi = add_r16(hi, u32x2{r_cur[h][2], r_cur[h][3]});
+        }
+        lo = act4(p, lo * p.out_scale);
+        hi = act4(p, hi * p.out_scale);
+        const u32x4 pk = {pack_bf16(lo[0], lo[1]), pack_bf16(lo[2], lo[3]), pack_bf16(hi[0], hi[1]), pack_bf16(hi[2], hi[3])};
+        *reinterpret_cast<u32x4*>(C + crow + n) = pk;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // ABL (debug build only, timing ablations with WRONG results): 1 no DMA in the loop, 2 no fragment reads in the loop, 4 no barrier / waits,
 // 8 no epilogue
 #ifndef W4_CARRY_DEFAULT
 #define W4_CARRY_DEFAULT true
 #endif
-template <int BS, int DSP, int ABL = 0, bool CARRY = W4_CARRY_DEFAULT>
+template <int BS, int DSP, int ABL = 0, bool CARRY = W4_CARRY_DEFAULT, bool EX = false>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
   using namespace w4;
   constexpr int BM = 256, BN = 256, TM = 8, TN = 8, NW = 4, AP = 8, WP = 8;
@@ -162,10 +227,19 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
     tm0 = tile_m * BM;
     tn0 = tile_n * BN;
     const int sub = lane >> 3, cg = (lane & 7) ^ sub;
+    size_t a_base = 0;   // row m of A lives at a_base + (m - a_m0) * lda (EX: a tile lies inside one batch of the remapped rows)
+    int a_m0 = 0;
+    if constexpr (EX) {
+      if (p.a_rpb) {
+        const int b = tm0 / p.a_rpb;
+        a_base = (size_t)b * p.a_bstride;
+        a_m0 = b * p.a_rpb;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
       const int m = tm0 + (wave + i * NW) * 8 + sub;
-      a_off[i] = m < p.M ? (unsigned)(((size_t)m * p.lda + cg * 8) * 2) : OOB;
+      a_off[i] = m < p.M ? (unsigned)((a_base + (size_t)(m - a_m0) * p.lda + cg * 8) * 2) : OOB;
     }
 #pragma unroll
     for (int i = 0; i < WP; ++i) {
@@ -270,7 +344,10 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
     f32x4 bs[TN];
     if constexpr (!(ABL & 8)) w4_load_bias<TN>(p, bs, n_w, lane_e);
     __builtin_amdgcn_sched_barrier(0);
-    if (CARRY && has_next) {
+    // (EX launches with a residual: its loads are ordinary loads, and the compiler's waits for them would sit behind the carried DMA
+    // in the in-order counter -- there the next prologue goes out after the epilogue)
+    const bool carry_now = CARRY && has_next && !(EX && p.R);
+    if (carry_now) {
       place_tile(vb_next, m0, n0);
       issue_prologue();
       __builtin_amdgcn_sched_barrier(0);
@@ -280,14 +357,15 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
       for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j) asm volatile("" ::"a"(acc[i][j]));
+    } else if constexpr (EX) {
+      w4_epilogue_ex<TM, TN>(p, acc, bs, em0, m_w, n_w, lane_e);
     } else {
       w4_epilogue<TM, TN>(p, acc, bs, m_w, n_w, lane_e);
     }
     if (!has_next) break;
     vb = vb_next;
-    if (CARRY) {
-      carried = true;
-    } else {
+    carried = carry_now;
+    if (!carry_now) {
       place_tile(vb, m0, n0);
       issue_prologue();
     }
@@ -296,15 +374,22 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
 
 // shapes the four-wave tile takes: 16-bit operands, K % 64 == 0, no split-K / LN fold / conv / fp8 scale, and an epilogue without
 // per-row operands (residual, gate, row bias: the general epilogue of 8-sub-tile waves fetches those one group at a time)
+// EX launches (own kernel instantiation): gate / 16-bit residual / row remaps whose rows-per-batch is a multiple of the tile height
+static bool w4_needs_ex(const GemmArgs& a) { return a.R || a.gate || a.a_rpb || a.c_rpb; }
 bool gemm_w4_applies(const GemmArgs& a) {
-  if (a.conv || a.rowstat || a.wscale || a.R || a.gate || a.rowbias || a.out_f32 || a.splitk > 1 || !a.c_wide) return false;
-  // (no row remaps: the per-row division by a run-time rows-per-batch is hoisted out of the tile loop as VGPR constants that do not
-  // survive the K loop's 256 + 256 registers -- spilled, and reloaded between the epilogue's stores)
-  if (a.a_rpb || a.c_rpb) return false;
+  if (a.conv || a.rowstat || a.wscale || a.rowbias || a.out_f32 || a.splitk > 1 || !a.c_wide) return false;
+  if (w4_needs_ex(a)) {
+    // (a tile must lie inside one batch: the per-row division by a run-time rows-per-batch, hoisted out of the tile loop as VGPR
+    // constants, did not survive the K loop's 256 + 256 registers -- spilled, and reloaded between the epilogue's stores)
+    if (a.geglu || (a.R && (a.r_f32 || (a.ldr & 7))) || (a.a_rpb && (a.a_rpb & 255)) || (a.c_rpb && (a.c_rpb & 255)) ||
+        (a.gate && (a.rows_per_batch <= 0 || (a.rows_per_batch & 255))))
+      return false;
+  }
   if ((a.K & 63) || a.K < 192 || (a.N & 7)) return false;   // (at least three K-tiles: first / last-but-one / last iterations)
   if (a.geglu && (a.N & 31)) return false;
   const size_t lim = 0xFFFF0000ull;
-  const size_t a_ext = ((size_t)(a.M - 1) * a.lda + a.K) * 2;
+  const size_t a_ext = a.a_rpb ? ((size_t)((a.M - 1) / a.a_rpb) * a.a_bstride + (size_t)(a.a_rpb - 1) * a.lda + a.K) * 2
+                               : ((size_t)(a.M - 1) * a.lda + a.K) * 2;
   return a_ext < lim && (size_t)a.N * a.K * 2 < lim;
 }
 
@@ -319,8 +404,10 @@ int launch_gemm_w4(const GemmArgs& a_in, hipStream_t stream) {
     const char* e = sd_switch("MI355X_SD_W4_SCHED");
     return e ? atoi(e) : 0;
   }();
-  K kern = (K)gemm_w4_kernel<18, 2>;
+  const bool ex = w4_needs_ex(a);
+  K kern = ex ? (K)gemm_w4_kernel<18, 2, 0, W4_CARRY_DEFAULT, true> : (K)gemm_w4_kernel<18, 2>;
 #ifdef MI355X_SD_DEBUG_SWITCHES
+  if (!ex) {
   if (sched == 1) kern = (K)gemm_w4_kernel<18, 2, 0, false>;   // the next tile's prologue behind the stores (A/B of the carried form)
   if (sched == 10) kern = (K)gemm_w4_kernel<18, 2, 1>;    // timing ablations (wrong results)
   if (sched == 11) kern = (K)gemm_w4_kernel<18, 2, 2>;
@@ -330,9 +417,10 @@ int launch_gemm_w4(const GemmArgs& a_in, hipStream_t stream) {
   if (sched == 15) kern = (K)gemm_w4_kernel<18, 2, 15>;
   if (sched == 16) kern = (K)gemm_w4_kernel<18, 2, 3>;
   if (sched == 17) kern = (K)gemm_w4_kernel<18, 2, 5>;
+  }
 #endif
-  static bool attr_done[20] = {};
-  const int si = (sched >= 0 && sched < 20) ? sched : 0;
+  static bool attr_done[40] = {};
+  const int si = ((sched >= 0 && sched < 20) ? sched : 0) + (ex ? 20 : 0);
   if (!attr_done[si]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
       return SD_ERR_HIP;

@@ -70,6 +70,8 @@ void set_last_error(const char* msg);   // text behind mi355x_sd_last_error() (c
 int launch_gemm(const GemmArgs& a, hipStream_t stream);
 int gemm_gm();   // tile rasterisation group of the GEMM kernels (-4 = column groups of 4)
 int launch_gemm256(const GemmArgs& a, hipStream_t stream);
+bool gemm_small_applies(const GemmArgs& a);                  // 64 x 64 tile, six-stage ring (gemm_small.hip)
+int launch_gemm_small(const GemmArgs& a, hipStream_t stream);
 bool gemm_w4_applies(const GemmArgs& a);                     // four-wave 256 x 256 tile (gemm_w4.hip)
 int launch_gemm_w4(const GemmArgs& a, hipStream_t stream);   // SD_ERR_UNSUPPORTED: caller falls back
 int launch_gemm_f8(const GemmArgs& a, hipStream_t stream);   // W8A8 (gemm256.hip); validates

@@ -37,6 +37,20 @@ SHAPES = [
 ]
 
 
+# the batch-1 SD-1.5 step's most frequent linear shapes (--sd15): 0.84-GFLOP problems that take split-K slices here
+SHAPES_SD15 = [
+    (256, 1280, 1280, 25, "to_q / to_out / proj at 16x16"),
+    (1024, 640, 640, 25, "the same at 32x32"),
+    (4096, 320, 320, 25, "the same at 64x64"),
+    (256, 10240, 1280, 5, "FF1 at 16x16 (step: GEGLU)"),
+    (256, 1280, 5120, 5, "FF2 at 16x16"),
+    (1024, 640, 2560, 5, "FF2 at 32x32"),
+    (4096, 320, 1280, 5, "FF2 at 64x64"),
+    (256, 3840, 1280, 5, "fused QKV at 16x16"),
+    (64, 1280, 1280, 5, "to_q / to_out at 8x8"),
+]
+
+
 def smi():
     try:
         out = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=20).stdout
@@ -73,14 +87,16 @@ def main():
     ap.add_argument("--seconds", type=float, default=1.0)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--sd15", action="store_true", help="the batch-1 SD-1.5 shapes instead of the SDXL bs-8 ones")
     a = ap.parse_args()
+    shapes = SHAPES_SD15 if a.sd15 else SHAPES
     from paddlemix_amd import ops
     dev = torch.device("cuda:0")
     lines = [f"hipBLASLt (torch {torch.__version__} F.linear) vs libmi355x_sd on the SDXL step's linear shapes: {a.rounds} x [{a.seconds} s ours | "
              f"{a.seconds} s hipBLASLt], interleaved, random normal bf16 operands, out = a w^T + bias (bf16)",
              f"{'M x N x K':>22s} {'n/step':>6s} | {'ours us':>9s} {'TF':>7s} {'MHz':>5s} {'W':>5s} | {'hipBLASLt us':>12s} {'TF':>7s} {'MHz':>5s} {'W':>5s} | ours/hipBLASLt time"]
     tot = {"ours": 0.0, "blas": 0.0}
-    for M, N, K, n_step, what in SHAPES:
+    for M, N, K, n_step, what in shapes:
         g = torch.Generator(device=dev).manual_seed(M + N + K)
         x = torch.randn(M, K, generator=g, device=dev).to(torch.bfloat16)
         w = (torch.randn(N, K, generator=g, device=dev) * K ** -0.5).to(torch.bfloat16)

@@ -117,6 +117,44 @@ for M, N, K, kind in ((1000, 1288, 64, "plain"), (515, 1928, 128, "silu"), (3000
         ref = F.silu(ref)
     res[f"gemm {M}x{N}x{K} wide {kind}"] = dict(sha=hashlib.sha256(out.cpu().view(torch.int16).numpy().tobytes()).hexdigest()[:16],
                                                 rel=((out[rows].float() - ref).norm() / ref.norm()).item())
+# the MMDiT block forms on 16-bit weights (csrc/gemm_w4.hip EX: gate + residual, tanh-GELU, C rows remapped into a joint buffer, A rows
+# read out of one) at row counts where a 256-row tile lies inside one batch, and one where it does not (4100 rows in 4 batches: the
+# launcher must leave that to the other kernels)
+for M, N, K, kind in ((8192, 1536, 1536, "gate+R"), (8192, 6144, 1536, "gelu"), (8192, 4608, 1536, "remap"), (8192, 1536, 1536, "a-remap"),
+                      (4100, 1536, 1536, "gate+R"), (16384, 1536, 6144, "gate+R")):
+    g = torch.Generator(device="cuda").manual_seed(M + N + K + 6)
+    a = torch.randn(M, K, device="cuda", generator=g).to(ed)
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(ed)
+    b = torch.randn(N, device="cuda", generator=g)
+    rows = slice(M - 256, M)
+    ref = a[rows].float() @ w.float().t() + b
+    if kind == "gate+R":
+        nb = 4
+        gt = torch.randn(nb, N, device="cuda", generator=g)
+        r = torch.randn(M, N, device="cuda", generator=g).to(ed)
+        out = ops.linear_ex(a, w, b, gate=gt, rows_per_batch=(M + nb - 1) // nb, residual=r)
+        ref = r[rows].float() + gt[nb - 1] * ref
+        got = out[rows].float()
+    elif kind == "gelu":
+        out = ops.linear_ex(a, w, b, gelu_tanh=True)
+        ref = F.gelu(ref, approximate="tanh")
+        got = out[rows].float()
+    elif kind == "remap":
+        rpb, extra = M // 4, 154
+        buf = torch.zeros(4 * (rpb + extra) * N, device="cuda", dtype=ed)
+        ops.linear_ex(a, w, b, out=buf, c_rows_per_batch=rpb, c_batch_stride=(rpb + extra) * N, M=M)
+        out = buf
+        got = buf.view(4, rpb + extra, N)[3, rpb - 256:rpb].float()
+        assert (buf.view(4, rpb + extra, N)[:, rpb:] == 0).all(), "wrote outside the remapped rows"
+    else:   # A rows of 4 batches read out of a buffer with 154 other rows behind each batch
+        rpb, extra = M // 4, 154
+        abuf = torch.randn(4 * (rpb + extra) * K, device="cuda", generator=g).to(ed)
+        out = ops.linear_ex(abuf, w, b, a_rows_per_batch=rpb, a_batch_stride=(rpb + extra) * K, M=M)
+        a_last = abuf.view(4, rpb + extra, K)[3, rpb - 256:rpb].float()
+        ref = a_last @ w.float().t() + b
+        got = out[rows].float()
+    res[f"gemm ex {M}x{N}x{K} {kind}"] = dict(sha=hashlib.sha256(out.cpu().view(torch.int16).numpy().tobytes()).hexdigest()[:16],
+                                              rel=((got - ref).norm() / ref.norm()).item())
 # weight-only fp8 on a just-in-time widened matrix (round 5: kernel instantiations that keep the per-channel scale in registers,
 # csrc/gemm_epilogue.h WS; under MI355X_SD_NO_PIPE the same launches run the read-where-used epilogue of the generic loop): plain,
 # tanh-GELU (SD3 FF1), gate + residual (SD3 to_out / FF2), a row-remapped output (the joint QKV buffer), ragged M, ragged N

@@ -48,6 +48,21 @@ def test_epilogue_operand_variants():
         assert v["rel"] < 4e-3, (k, v)
 
 
+def test_small_tile_ring_is_bit_identical_to_the_128_tile_without_slices():
+    """csrc/gemm_small.hip (round 6): the 64 x 64 tile with the six-stage ring that the small launches of a batch-1 step take instead
+    of split-K slices + a reduce kernel. Against the 128 x 128 tiles walking the same K in one chain (MI355X_SD_NO_SPLITK on both
+    sides, MI355X_SD_NO_SMALL on the reference's): another tile, another ring depth, the same products in the same order -> the same
+    bits on every case of the child (ragged M / N, one to 35 K-tiles, residual rows inside a wider buffer, GEGLU, LayerNorm-free).
+    Against the sliced form it replaces the sums associate differently: equal within the kernels' tolerance (the child's rel)."""
+    new = _run({"MI355X_SD_NO_SPLITK": "1"})
+    ref = _run({"MI355X_SD_NO_SPLITK": "1", "MI355X_SD_NO_SMALL": "1"})
+    for k, v in new.items():
+        assert v["rel"] < 4e-3, (k, v)
+        assert v["sha"] == ref[k]["sha"], (k, v, ref[k])
+    sliced = _run({"MI355X_SD_NO_SMALL": "1"})
+    assert any(sliced[k]["sha"] != v["sha"] for k, v in _run({}).items())   # (the picker does take the small tile somewhere)
+
+
 @pytest.mark.parametrize("tile_map", ["160:129", "257:129,320:129"])
 def test_four_wave_tiles(tile_map):
     """The four-wave tiles built for two co-resident blocks per CU (gemm_cfg.h: 128x160) substituted for the
