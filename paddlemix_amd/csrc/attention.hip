@@ -404,7 +404,7 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 96) ? ((FL & 4) ? 3 : 2) : 1) v
 // ---- d = 64 attention on v_mfma_f32_16x16x32 (round 5) -------------------------------------------------------------------------------
 // Why another MFMA shape. The d = 64 launches of attention_kernel are not stall-bound but CLOCK-bound: the kernel stamps s_memtime
 // against the 100-MHz wall clock and reads 1.5 - 1.6 GHz while the SDXL S = 4096 launch runs (profiles/r05_s6_attn_clock.txt), and a
-// loop that needs 5 % fewer cycles (the software-pipelined attention_il_kernel, profiles/experiments/r05_attention_il_q2.hip.txt) gets the same
+// loop that needs 5 % fewer cycles (the software-pipelined attention_il_kernel, its source is in the history of the repository: profiles/experiments/ before round 6) gets the same
 // TIME at a lower clock. A dense stream of v_mfma_f32_32x32x16_bf16 on random operands is itself held to 1.22 - 1.75 PFLOP/s by this
 // board (1.64 - 1.82 GHz, at only ~1 kW of the ~1.34 kW cap: a current limit, not the power cap), the same stream of
 // v_mfma_f32_16x16x32_bf16 sustains 2.02 PFLOP/s at 2.1 GHz (scripts/probes/mfma_shape_energy_probe.hip,

@@ -13,7 +13,7 @@
 // epilogue load at all; (b) the residual of the register-pipelined tiles is fetched during the last K iterations (EpiPre below);
 // (c) everywhere else the operands of a whole row-tile (row bias, gate, residual: up to 3 x TN loads) are issued back to back in
 // front of its math (GemmArgs::epi_batch), TM round trips instead of TM x TN.
-// Round 1 had tried branch-free batching through zero-sized descriptors (profiles/experiments/r01_gemm_epilogue_batched_loads.h.txt)
+// Round 1 had tried branch-free batching through zero-sized descriptors (source in the history of the repository, profiles/experiments/ before round 6: r01_gemm_epilogue_batched_loads.h.txt)
 // and seen no gain in the step; two lessons kept from it: (1) never give the accumulators two alternative consumer loops (a fast
 // path next to a general one, or an e4m3 and a bf16 store loop) -- the register allocator then splits their live ranges and spills
 // them INSIDE the K loop; (2) per-channel operands folded into all accumulators up front pin the whole accumulator set in VGPRs.

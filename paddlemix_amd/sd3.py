@@ -93,11 +93,14 @@ def sd3_optional_param_shapes(config: Mapping) -> Dict[str, tuple]:
     return {"norm_out.norm.bias": (D,), f"transformer_blocks.{n - 1}.norm1_context.norm.bias": (D,)}
 
 
-def synth_sd3_params(config: Mapping, seed: int = 1234, device="cpu", dtype=torch.float32) -> Dict[str, Tensor]:
-    """Random-init parameters (same recipe as the oracle's synth_sd3_params)."""
-    g = torch.Generator(device=device).manual_seed(seed)
+def synth_sd3_params(config: Mapping, seed: int = 1234, device="cpu", dtype=torch.float32, generator=None,
+                     only: Optional[range] = None) -> Dict[str, Tensor]:
+    """Random-init parameters (same recipe as the oracle's synth_sd3_params). `generator` + `only`: one shard of the construction
+    order from a generator positioned at its start (see unet.synth_unet_params)."""
+    g = generator if generator is not None else torch.Generator(device=device).manual_seed(seed)
     P: Dict[str, Tensor] = {}
-    for name, shape in sd3_param_shapes(config).items():
+    items = list(sd3_param_shapes(config).items())
+    for name, shape in (items if only is None else items[only.start:only.stop]):
         r = torch.randn(shape, generator=g, device=device)
         if name.endswith(".bias"):
             t = r * 0.02

@@ -262,12 +262,16 @@ def unet_param_shapes(config: Mapping) -> Dict[str, tuple]:
     return S
 
 
-def synth_unet_params(config: Mapping, seed: int = 1234, device="cpu", dtype=torch.float32) -> Dict[str, Tensor]:
+def synth_unet_params(config: Mapping, seed: int = 1234, device="cpu", dtype=torch.float32, generator=None,
+                      only: Optional[range] = None) -> Dict[str, Tensor]:
     """Random-init parameters (no checkpoints are available offline): conv/linear N(0, 1/fan_in), biases
-    N(0, 0.02^2), norm gamma 1 + N(0, 0.02^2), beta N(0, 0.02^2); one generator, construction order."""
-    g = torch.Generator(device=device).manual_seed(seed)
+    N(0, 0.02^2), norm gamma 1 + N(0, 0.02^2), beta N(0, 0.02^2); one generator, construction order.
+    `generator` + `only`: draw just the parameters `only` indexes (a run of the construction order) from a generator the caller
+    positioned there -- how a 2.6 B-parameter set is drawn as parallel shards (tests/parity_cases.py)."""
+    g = generator if generator is not None else torch.Generator(device=device).manual_seed(seed)
     P: Dict[str, Tensor] = {}
-    for name, shape in unet_param_shapes(config).items():
+    items = list(unet_param_shapes(config).items())
+    for name, shape in (items if only is None else items[only.start:only.stop]):
         r = torch.randn(shape, generator=g, device=device)
         if name.endswith(".bias"):
             t = r * 0.02

@@ -11,7 +11,6 @@ fed the oracle's own inputs at the stored steps. Modes: UNet cases x residual st
 so every mode is compared with the SAME oracle numbers. Oracle = torch-CPU restatement of ppdiffusers (Paddle unavailable: unpinned).
 """
 import argparse
-import contextlib
 import json
 import os
 import subprocess
@@ -22,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def child(elem: str, names, cache_dir: str) -> dict:
+def child(elem: str, names) -> dict:
     import torch
 
     from paddlemix_amd import _lib
@@ -32,41 +31,23 @@ def child(elem: str, names, cache_dir: str) -> dict:
     assert (elem == "fp16") == (ed == torch.float16)
     out = {}
     params_cache = {}
+    timing = []          # (what, wall seconds) per parameter set and per case: where the suite's longest fixture spends its time
     draw_params = PC.case_params      # (device_report is handed `params` below in its place)
 
     def params(case):
-        """seeded weights, exact in bf16 and fp16; generated once per model family and shared between the two children through a
-        bf16 file (drawing 2.6 B normals from the CPU generator takes about a minute)"""
-        key = "sd3" if case["kind"] == "sd3" else ("sdxl" if case["cfg"].get("addition_embed_type") else "sd15")   # (FWD_CASES entries too)
-        if key in params_cache:
-            return params_cache[key]
-        params_cache.clear()
-        path = os.path.join(cache_dir, f"parity_params_{key}.pt") if cache_dir else None
-        mine = False
-        if path and not os.path.exists(path):
-            # the two children may run side by side (tests/test_gpu_parity_loops.py): whoever creates the lock file draws the set,
-            # the other one waits for the file instead of drawing the same 2.6 B normals again
-            try:
-                os.close(os.open(path + ".lock", os.O_CREAT | os.O_EXCL | os.O_WRONLY))
-                mine = True
-            except FileExistsError:
-                t_wait = time.time()
-                while not os.path.exists(path) and time.time() - t_wait < 900:
-                    time.sleep(1.0)
-        if path and os.path.exists(path):
-            P = {k: (v.float() if v.dtype == torch.bfloat16 else v) for k, v in torch.load(path).items()}
-        else:
-            P = draw_params(case)
-            if path:
-                torch.save({k: (v.to(torch.bfloat16) if v.dim() > 1 else v) for k, v in P.items()}, path + ".tmp")
-                os.replace(path + ".tmp", path)
-        if mine:
-            with contextlib.suppress(OSError):
-                os.remove(path + ".lock")
-        params_cache[key] = P
-        return P
+        """seeded weights, exact in bf16 and fp16; one set per model family at a time (tests/parity_cases.py case_params: drawn as
+        parallel shards from the committed generator states, ~10 s for 2.6 B parameters on the GPU box's host)"""
+        key = PC.family(case)
+        if key not in params_cache:
+            params_cache.clear()
+            t_p = time.time()
+            params_cache[key] = draw_params(case)
+            timing.append((f"params:{key}", round(time.time() - t_p, 1)))
+        return params_cache[key]
 
+    marks = []
     for name in names:
+        marks.append((name, time.time()))
         if name in PC.FWD_CASES:
             # one whole-batch forward at the launch set the metric times, vs the oracle's forward of the same batch; plus the same
             # prompts one at a time through the bs-1 launch set (other GEMM tiles, split-K): how much the batch size itself moves
@@ -134,6 +115,9 @@ def child(elem: str, names, cache_dir: str) -> dict:
             res[mname] = r
             print(elem, name, mname, json.dumps(r), flush=True)
         out[name] = res
+    marks.append((None, time.time()))
+    timing += [(f"case:{n}", round(marks[i + 1][1] - t, 1)) for i, (n, t) in enumerate(marks[:-1])]   # (a case's figure includes its params: entry)
+    print("PARITY_TIMING " + elem + " " + json.dumps(timing), flush=True)
     return out
 
 
@@ -142,20 +126,18 @@ def main():
     ap.add_argument("--child", default=None)
     ap.add_argument("--cases", default=None)
     ap.add_argument("--elems", default="bf16,fp16")
-    ap.add_argument("--cache-dir", default="/tmp")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r04_parity.json"))
     a = ap.parse_args()
     from tests import parity_cases as PC
     names = a.cases.split(",") if a.cases else list(PC.CASES) + list(PC.FWD_CASES)
     if a.child:
-        print("PARITY_JSON " + json.dumps(child(a.child, names, a.cache_dir)))
+        print("PARITY_JSON " + json.dumps(child(a.child, names)))
         return
     res = {}
     for elem in a.elems.split(","):
         env = dict(os.environ, MI355X_SD_DTYPE=elem)
         env.pop("MI355X_SD_RESID", None)
-        p = subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__), "--child", elem, "--cases", ",".join(names),
-                              "--cache-dir", a.cache_dir], env=env, stdout=subprocess.PIPE, text=True)
+        p = subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__), "--child", elem, "--cases", ",".join(names)], env=env, stdout=subprocess.PIPE, text=True)
         line = None
         for ln in p.stdout:
             sys.stdout.write(ln)

@@ -94,14 +94,69 @@ def dual16(P):
     return out
 
 
-def case_params(case):
-    """the seeded synthetic parameter set of SURVEY.md 8(d) (the product's and the oracle's generators draw the same numbers:
-    tests/test_parity_cases.py), made exact in both 16-bit types"""
+DRAW_STATES = os.path.join(GOLDEN_DIR, "param_draw_states.npz")   # scripts/make_param_draw_states.py
+DRAW_SHARDS = 32
+
+
+def family(case) -> str:
+    return "sd3" if case["kind"] == "sd3" else ("sdxl" if case["cfg"].get("addition_embed_type") else "sd15")
+
+
+def _synth(case):
     if case["kind"] == "sd3":
-        from paddlemix_amd.sd3 import synth_sd3_params
-        return dual16(synth_sd3_params(case["cfg"], seed=1234))
-    from paddlemix_amd.unet import synth_unet_params
-    return dual16(synth_unet_params(case["cfg"], seed=1234))
+        from paddlemix_amd.sd3 import sd3_param_shapes, synth_sd3_params
+        return synth_sd3_params, sd3_param_shapes(case["cfg"])
+    from paddlemix_amd.unet import synth_unet_params, unet_param_shapes
+    return synth_unet_params, unet_param_shapes(case["cfg"])
+
+
+def shard_bounds(shapes, n=DRAW_SHARDS):
+    """construction order cut into n runs of about equal element count: n + 1 indices"""
+    numel = np.cumsum([int(np.prod(s)) for s in shapes.values()])
+    cuts = [int(np.searchsorted(numel, numel[-1] * i / n)) for i in range(1, n)]
+    return [0] + [min(c + 1, len(numel)) for c in cuts] + [len(numel)]
+
+
+def shapes_sig(shapes) -> str:
+    import hashlib
+    return hashlib.sha1(repr([(k, tuple(v)) for k, v in shapes.items()]).encode()).hexdigest()
+
+
+def case_params(case, threads=None):
+    """the seeded synthetic parameter set of SURVEY.md 8(d) (the product's and the oracle's generators draw the same numbers:
+    tests/test_parity_cases.py), made exact in both 16-bit types.
+
+    One generator, construction order: 2.6 B normals take a minute or more of ONE core (and 160 s when two children draw side by
+    side: the GPU suite's longest item through round 5). The committed generator states at DRAW_SHARDS cut points of that very
+    sequence (param_draw_states.npz, a few hundred KB) let the shards be drawn by parallel threads -- each checks that it ENDS on the
+    next shard's stored state, so the result is the serial draw bit for bit or an error, never a different parameter set."""
+    synth, shapes = _synth(case)
+    fam = family(case)
+    states = None
+    if threads != 0 and os.path.exists(DRAW_STATES):
+        with np.load(DRAW_STATES) as z:
+            if str(z[fam + "_sig"]) == shapes_sig(shapes):   # (the small test configurations have no stored states: serial)
+                states, bounds = torch.from_numpy(z[fam + "_states"]), [int(b) for b in z[fam + "_bounds"]]
+    if states is None:
+        return dual16(synth(case["cfg"], seed=1234))
+    assert bounds == shard_bounds(shapes, len(bounds) - 1)
+
+    def shard(i):
+        g = torch.Generator()
+        g.set_state(states[i].clone())   # (a row VIEW crashes set_state in torch 2.10)
+        P = synth(case["cfg"], generator=g, only=range(bounds[i], bounds[i + 1]))
+        if not torch.equal(g.get_state(), states[i + 1]):
+            raise RuntimeError(f"{fam}: shard {i} did not end on the stored generator state (another torch RNG?): draw serially (threads=0)")
+        return dual16(P)
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=threads or min(len(bounds) - 1, os.cpu_count() or 1)) as ex:
+        parts = list(ex.map(shard, range(len(bounds) - 1)))
+    out = {}
+    for p in parts:
+        out.update(p)
+    assert list(out) == list(shapes)
+    return out
 
 
 def case_inputs(case):

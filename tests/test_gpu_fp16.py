@@ -31,10 +31,10 @@ def test_fp16_build_kernels_and_unet_parity():
         # (weights-only rounding), the device adds the activation stores -> bar 3e-3 (bf16 build: 2e-2)
         assert c["vs_oracle_same_weights"] < 3e-3, (name, c)
         assert c["vs_oracle_fp32_weights"] < 4e-3, (name, c)
-    # fp16 elements + fp32 residual stream on the device, incl. the headline geometry and the 30-step latents
+    # fp16 elements + fp32 residual stream on the device and the 30-step latents (the headline geometry: test_gpu_parity_loops.py)
     f = r["fp32_residual"]
     print("fp16 build, rel-L2 vs oracle:", f)
-    for name in ("tiny", "mini_xl", "sdxl_1x4x128x128"):
+    for name in ("tiny", "mini_xl"):
         assert f[name]["resid_fp32"] < f[name]["resid_16"] < 3.5e-3, (name, f[name])
     lp = f["euler_loop_mini_xl"]
     assert lp["resid_fp32"]["end_latents"] < 1e-3 and lp["resid_fp32"]["eps_worst"] < 2.5e-3, lp   # north_star's latents bar

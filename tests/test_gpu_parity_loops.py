@@ -32,20 +32,18 @@ ALL = SDXL_CASES + (FWD_CASE,) + OTHER_CASES + FP8_CASES + SD3_FWD_CASES
 
 
 @pytest.fixture(scope="module")
-def loops(tmp_path_factory):
-    """one child process per library build (one element type per process); the seeded weights of a model family are drawn once and
-    shared between the children through a file"""
-    cache = str(tmp_path_factory.mktemp("parity_params"))
+def loops():
+    """one child process per library build (one element type per process)"""
     out, procs = {}, {}
-    # the two children run SIDE BY SIDE (round 6: the suite's longest fixture): most of a child's wall time is host work -- drawing /
-    # loading the seeded weights, float64 latent state, model builds -- and the GPU has room for both. The fp16 child walks the cases in
-    # reverse so that the two rarely want the same parameter set drawn at the same time (scripts/parity_loops.py params: lock file).
+    # the two children run SIDE BY SIDE (round 6: the suite's longest fixture): most of a child's wall time is host work -- drawing the
+    # seeded weights (parallel shards, tests/parity_cases.py case_params), float64 latent state, model builds -- and the GPU has room
+    # for both. The fp16 child walks the cases in reverse (the two then build different model families at any one time).
     for elem in ("bf16", "fp16"):
         env = dict(os.environ, MI355X_SD_DTYPE=elem)
         env.pop("MI355X_SD_RESID", None)
         order = ALL if elem == "bf16" else tuple(reversed(ALL))
-        procs[elem] = subprocess.Popen([sys.executable, os.path.join(ROOT, "scripts", "parity_loops.py"), "--child", elem, "--cases", ",".join(order),
-                                        "--cache-dir", cache], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        procs[elem] = subprocess.Popen([sys.executable, os.path.join(ROOT, "scripts", "parity_loops.py"), "--child", elem, "--cases", ",".join(order)],
+                                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     for elem, p in procs.items():
         try:
             so, se = p.communicate(timeout=3000)
@@ -54,6 +52,7 @@ def loops(tmp_path_factory):
                 q.kill()
             raise
         assert p.returncode == 0, se[-3000:]
+        print("\n".join(ln for ln in so.splitlines() if ln.startswith("PARITY_TIMING ")))
         line = [ln for ln in so.splitlines() if ln.startswith("PARITY_JSON ")][-1]
         out[elem] = json.loads(line[len("PARITY_JSON "):])
     print("full-depth loops, rel-L2 of the end latents vs the oracle trajectories:",

@@ -415,6 +415,13 @@ def test_euler30_latents_vs_float64_oracle_loop():
     sch.set_timesteps(30)
     sig = sch.sigmas.astype(np.float64)
     res = {}
+    # the float64 oracle loop does not depend on the device mode: computed once
+    x_ref = sample.double() * float(sch.init_noise_sigma)
+    xins, e_refs = [], []
+    for i, t in enumerate(sch.timesteps):
+        xins.append(x_ref / (sig[i] * sig[i] + 1.0) ** 0.5)
+        e_refs.append(U.unet_forward(P64, cfg, xins[-1], int(t), enc.double(), added_cond_kwargs=added64))
+        x_ref = x_ref + e_refs[-1] * (sig[i + 1] - sig[i])
     for rd, bar_eps, bar_lat in (("16", BARS["euler30-eps"][0], BARS["euler30-latents"][0]),
                                  ("fp32", BARS["euler30-eps"][1], BARS["euler30-latents"][1])):
         model = UNet2DConditionModel(cfg, P, residual_dtype=rd)
@@ -423,8 +430,7 @@ def test_euler30_latents_vs_float64_oracle_loop():
         worst = 0.0
         for i, t in enumerate(sch.timesteps):
             s = sig[i]
-            xin = x_ref / (s * s + 1.0) ** 0.5
-            e_ref = U.unet_forward(P64, cfg, xin, int(t), enc.double(), added_cond_kwargs=added64)
+            xin, e_ref = xins[i], e_refs[i]
             e_tf = model(_cuda(xin.float()), int(t), _cuda(enc), added_cond_kwargs=_cuda(added)).sample.cpu().double()
             worst = max(worst, _rel(e_tf, e_ref))
             e_fr = model(_cuda((x_dev / (s * s + 1.0) ** 0.5).float()), int(t), _cuda(enc), added_cond_kwargs=_cuda(added)).sample

@@ -80,3 +80,39 @@ def test_product_and_oracle_draw_the_same_synthetic_weights():
     from tests.configs import MINI_SD3, MINI_XL
     for a, b in ((o_unet(MINI_XL, seed=1234), p_unet(MINI_XL, seed=1234)), (o_sd3(MINI_SD3, seed=1234), p_sd3(MINI_SD3, seed=1234))):
         assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a)
+
+
+def test_sharded_parameter_draw_is_the_serial_draw(tmp_path, monkeypatch):
+    """case_params draws the full-size sets as parallel shards from stored generator states (round 6): on a small configuration, with
+    states recorded the way scripts/make_param_draw_states.py records them, the shards reproduce the serial draw bit for bit; a state
+    that does not belong to the sequence is refused; the committed file matches today's parameter lists and starts at seed 1234"""
+    import importlib.util
+    import os
+    from tests.configs import MINI_SD3, MINI_XL
+    spec = importlib.util.spec_from_file_location("make_param_draw_states", os.path.join(os.path.dirname(PC.GOLDEN_DIR), "..", "..", "scripts",
+                                                                                          "make_param_draw_states.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    out = {}
+    cases = (dict(kind="unet", cfg=MINI_XL), dict(kind="sd3", cfg=MINI_SD3))
+    for case in cases:
+        fam = PC.family(case)
+        out[fam + "_states"], out[fam + "_bounds"] = mk.record(case, 8)
+        out[fam + "_sig"] = np.asarray(PC.shapes_sig(PC._synth(case)[1]))
+    path = str(tmp_path / "states.npz")
+    np.savez(path, **out)
+    with np.load(PC.DRAW_STATES) as z:   # the committed file, before the path is patched away
+        seed_state = torch.Generator().manual_seed(1234).get_state().numpy()
+        for name in ("sdxl_1x4x32x32_euler30", "sd15_1x4x64x64_ddim50", "sd3_1x16x64x64_flow28"):
+            c = PC.CASES[name]
+            fam, shapes = PC.family(c), PC._synth(c)[1]
+            assert str(z[fam + "_sig"]) == PC.shapes_sig(shapes) and np.array_equal(z[fam + "_states"][0], seed_state)
+            assert [int(b) for b in z[fam + "_bounds"]] == PC.shard_bounds(shapes, PC.DRAW_SHARDS)
+    monkeypatch.setattr(PC, "DRAW_STATES", path)
+    for case in cases:
+        a, b = PC.case_params(case, threads=3), PC.case_params(case, threads=0)
+        assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a)
+    out["sdxl_states"][3] = out["sdxl_states"][2]
+    np.savez(path, **out)
+    with pytest.raises(RuntimeError, match="did not end on the stored generator state"):
+        PC.case_params(cases[0], threads=2)
