@@ -6,10 +6,10 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
-python bench.py --workload sd15-512-bs1 --steps 50 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_bench_sd15_bs1.json 2>/dev/null
-python bench.py --workload sd3-1024-bs8 --no-cpu-baseline > $OUT/${TAG}_bench_sd3_bs8.json 2>/dev/null
-python bench.py --workload sd3-1024-bs8-fp8w --no-cpu-baseline > $OUT/${TAG}_bench_sd3_bs8_fp8w.json 2>/dev/null
-python bench.py --workload sd3-1024-bs8-w8a8 --no-cpu-baseline > $OUT/${TAG}_bench_sd3_bs8_w8a8.json 2>/dev/null
+python bench.py --workload sd15-512-bs1 --steps 50 --warmup 5 > $OUT/${TAG}_bench_sd15-512-bs1.json 2>/dev/null
+for w in sd3-1024-bs8 sd3-1024-bs8-fp8w sd3-1024-bs8-w8a8; do   # (each line: cpu_baseline + pred_rel_bs8 at config 5's own geometry)
+  python bench.py --workload $w > $OUT/${TAG}_bench_$w.json 2>/dev/null
+done
 python bench.py --dtype fp16 --no-cpu-baseline > $OUT/${TAG}_bench_fp16.json 2>/dev/null
 python scripts/vae_bench.py --side 128 --batch 8 > $OUT/${TAG}_vae_decode_1024_bs8.json 2>/dev/null
 BENCH_SHAPES=1 python bench.py --no-cpu-baseline 2> $OUT/${TAG}_per_shape_ms.txt > /dev/null
