@@ -445,7 +445,7 @@ def main():
         dom = max((k for k in kinds if kinds[k]["gflop"] > 0), key=lambda k: kinds[k]["ms"])
         d = kinds[dom]
         ach = d["gflop"] / d["ms"]  # GFLOP/ms == TFLOP/s
-        names = {"gemm": "linear GEMM class: gemm_pipe_kernel<false,...> / gemm256_kernel<false> / gemm_bf16_kernel<false,...>",
+        names = {"gemm": "linear GEMM class: gemm_w4_kernel / gemm_pipe[_pre]_kernel<false,...> / gemm256_kernel<false> / gemm_small_kernel / gemm_bf16_kernel<false,...>",
                  "conv": "conv3x3 implicit-GEMM class: gemm_pipe_kernel<true,...> / gemm256_kernel<true>",
                  "attn": "attention16_kernel<LOG2> (16x16x32 MFMA; masks / head_dim != 64: attention_kernel<64,false>)"}
         # the W8A8 workload's GEMM class runs on the fp8 matrix pipe: price it against the fp8 peak

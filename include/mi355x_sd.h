@@ -115,8 +115,8 @@ int mi355x_sd_unet_forward(void* handle, void* stream, const float* sample, cons
  *   CONTROLNET down_block_additional_residuals (one fp32 NCHW tensor per skip connection, in the order the down path produces
  *              them: conv_in first) + mid_block_additional_residual (:1121-1132, 1151-1155), e.g. the outputs of
  *              ControlNetModel; both or neither
- * class_labels, timestep_cond and the IP-Adapter image_embeds are inputs of the Python-planned model only (paddlemix_amd/unet.py);
- * a config that needs them is refused at create. */
+ * The IP-Adapter image_embeds are inputs of the Python-planned model only (paddlemix_amd/unet.py); a config that needs them
+ * (encoder_hid_dim_type) is refused at create. class_labels and timestep_cond: mi355x_sd_unet_set_input below. */
 #define MI355X_SD_UNET_ENC_MASK 1
 #define MI355X_SD_UNET_SELF_MASK 2
 #define MI355X_SD_UNET_CONTROLNET 4
@@ -129,6 +129,18 @@ int mi355x_sd_unet_forward_ex(void* handle, void* stream, const float* sample, c
                               const float* in_scale, const float* encoder_attention_mask, const float* attention_mask,
                               const float* const* down_block_additional_residuals, int num_down_residuals,
                               const float* mid_block_additional_residual, float* out, int use_graph);
+/* The tensor inputs of UNet2DConditionModel.forward that belong to the CONFIG -- a model built with a class embedding or with
+ * time_cond_proj_dim reads them in every forward (unet_2d_condition.py:953-975; embeddings.py:284-285) -- are bound by name, not
+ * passed per call: device pointers, read (copied into the plan's static buffers, on the call's stream) by every forward[_ex] call
+ * from then on, until replaced; NULL unbinds.
+ *   "class_labels"   class_embed_type null + num_class_embeds: int32 [B], the row of the nn.Embedding table per sample;
+ *                    "timestep": fp32 [B] (goes through time_proj and a TimestepEmbedding); "projection" / "simple_projection":
+ *                    fp32 [B, projection_class_embeddings_input_dim]; "identity": fp32 [B, 4 * block_out_channels[0]].
+ *                    A forward call of such a model with nothing bound is MI355X_SD_ERR_INVALID (the reference's ValueError,
+ *                    :954-955); class_embeddings_concat=true is refused at create.
+ *   "timestep_cond"  fp32 [B, time_cond_proj_dim] (the LCM guidance-scale embedding); unbound = the reference's None (no term).
+ * Binding an input the model does not have is MI355X_SD_ERR_INVALID. */
+int mi355x_sd_unet_set_input(void* handle, const char* name, const void* device_ptr);
 /* ---- seam B2: any exported step program behind one handle (paddlemix_amd/csrc/program_exec.hip) --------------------------------
  * Every model of the path (UNet2DConditionModel, ControlNetModel, SD3Transformer2DModel, the DiT Transformer2DModel, AutoencoderKL
  * decode / encode, the CLIP and T5 text encoders) runs as a static list of the per-op launches below over weights + scratch. The

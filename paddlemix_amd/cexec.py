@@ -4,8 +4,9 @@ The program builder, the weight packing and the execution live in the C library;
 parameters -> host pointers, two caller-owned device buffers (weights, workspace) as torch tensors, and device pointers per
 call. It presents the reference's call contract (``unet(sample, t, encoder_hidden_states, added_cond_kwargs=...,
 return_dict=False) -> (noise_pred,)``, unet_2d_condition.py:809-1207) like ``paddlemix_amd.unet.UNet2DConditionModel`` does --
-the latter emits the same launches from Python and remains the form with every optional input (class labels, IP-Adapter,
-ControlNet residuals, masks); the handle form is what a compiled host binds.
+the latter emits the same launches from Python and remains the form with EVERY optional input (the handle has the masks, the
+ControlNet residuals, class labels and timestep_cond; not the IP-Adapter image embeddings, class_embeddings_concat or latent sizes
+that need `forward_upsample_size`); the handle form is what a compiled host binds.
 """
 from __future__ import annotations
 
@@ -132,7 +133,7 @@ class CUNet2DConditionModel:
 
     def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None, return_dict: bool = True, in_scale=None,
                 attention_mask=None, encoder_attention_mask=None, down_block_additional_residuals=None,
-                mid_block_additional_residual=None):
+                mid_block_additional_residual=None, class_labels=None, timestep_cond=None):
         lib, h = self.hd.lib, self.hd.h
         cfgd = self.hd.config_dict
         if sample.dim() != 4 or sample.shape[1] != cfgd.get("in_channels", 4):
@@ -163,6 +164,27 @@ class CUNet2DConditionModel:
                                      f"the keyword argument `{key}` to be passed in `added_cond_kwargs`")
                 if tuple(added_cond_kwargs[key].shape) != (B, width):
                     raise ValueError(f"{key}: expected [{B}, {width}], got {tuple(added_cond_kwargs[key].shape)}")
+        # class_labels / timestep_cond: inputs that belong to the config (mi355x_sd_unet_set_input), same checks as the planned model
+        ct, nce, ted = cfgd.get("class_embed_type"), cfgd.get("num_class_embeds"), 4 * cfgd.get("block_out_channels", (320,))[0]
+        cl = None
+        if ct is not None or nce is not None:
+            if class_labels is None:
+                raise ValueError("class_labels should be provided when num_class_embeds > 0")
+            cl = class_labels if torch.is_tensor(class_labels) else torch.as_tensor(class_labels)
+            if ct in (None, "timestep"):
+                cl = cl.reshape(-1)
+                cl = cl.expand(B) if cl.numel() == 1 else cl
+                want = (B,)
+            else:
+                want = (B, ted if ct == "identity" else cfgd["projection_class_embeddings_input_dim"])
+            if tuple(cl.shape) != want:
+                raise ValueError(f"class_labels of shape {tuple(class_labels.shape)}, expected {want}")
+        tcp = cfgd.get("time_cond_proj_dim")
+        if timestep_cond is not None:
+            if tcp is None:
+                raise ValueError("timestep_cond was passed but the model has no `time_cond_proj_dim`")
+            if tuple(timestep_cond.shape) != (B, tcp):
+                raise ValueError(f"timestep_cond of shape {tuple(timestep_cond.shape)}, expected {(B, tcp)}")
         controlnet = down_block_additional_residuals is not None
         if controlnet != (mid_block_additional_residual is not None):
             raise NotImplementedError("ControlNet residuals need both `down_block_additional_residuals` and "
@@ -205,10 +227,17 @@ class CUNet2DConditionModel:
             rs = [f32(r) for r in down_block_additional_residuals] if controlnet else []
             rm = f32(mid_block_additional_residual) if controlnet else None
             arr = (ctypes.c_void_p * max(1, len(rs)))(*[r.data_ptr() for r in rs]) if controlnet else None
+            clt = tc = None
+            if cl is not None:   # table rows travel as int32, everything else as fp32 (include/mi355x_sd.h)
+                clt = cl.to(device=self.device, dtype=torch.int32 if ct is None else torch.float32).contiguous()
+                _lib.check(lib.mi355x_sd_unet_set_input(h, b"class_labels", clt.data_ptr()))
+            if tcp is not None:
+                tc = None if timestep_cond is None else f32(timestep_cond)
+                _lib.check(lib.mi355x_sd_unet_set_input(h, b"timestep_cond", p(tc)))
             _lib.check(lib.mi355x_sd_unet_forward_ex(h, self._stream.cuda_stream, p(s), p(tt), p(e), p(te), p(ti), p(sc), p(em), p(sm), arr,
                                                      len(rs), p(rm), p(out), 1 if self.use_graph else 0))
         cur.wait_stream(self._stream)
-        for x in [s, tt, e, te, ti, sc, em, sm, rm] + rs:     # keep the staging tensors alive until the stream has consumed them
+        for x in [s, tt, e, te, ti, sc, em, sm, rm, clt, tc] + rs:     # keep the staging tensors alive until the stream has consumed them
             if x is not None:
                 x.record_stream(self._stream)
         if not return_dict:

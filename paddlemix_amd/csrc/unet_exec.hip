@@ -143,6 +143,11 @@ struct Cfg {
   bool linear_proj = false;
   bool text_time = false;
   int atd = 0, pdim = 0;
+  // class embedding (unet_2d_condition.py:404-441, 953-975) and TimestepEmbedding.cond_proj (embeddings.py:265-266, 284-285)
+  enum ClassKind { CLASS_NONE, CLASS_TABLE, CLASS_TIMESTEP, CLASS_IDENTITY, CLASS_PROJECTION, CLASS_SIMPLE };
+  ClassKind class_kind = CLASS_NONE;
+  int num_class = 0;      // rows of the nn.Embedding table (CLASS_TABLE)
+  int tcp = 0;            // time_cond_proj_dim (0: none)
 };
 
 // A config number that has to be an integer inside [lo, hi]: the text comes from a host (a file someone edited), and a width of
@@ -187,7 +192,7 @@ Cfg parse_config(const char* json) {
     return o;
   };
   // what this executor does not build must not load silently (same refusals as paddlemix_amd/unet.py normalize_config)
-  static const char* must_be_null[] = {"class_embed_type", "num_class_embeds", "time_cond_proj_dim", "encoder_hid_dim", "encoder_hid_dim_type",
+  static const char* must_be_null[] = {"encoder_hid_dim", "encoder_hid_dim_type",
                                        "time_embedding_dim", "time_embedding_act_fn", "timestep_post_act", "cross_attention_norm",
                                        "mid_block_only_cross_attention", "reverse_transformer_layers_per_block", "num_attention_heads"};
   for (const char* k : must_be_null) {
@@ -256,6 +261,36 @@ Cfg parse_config(const char* json) {
       c.atd = as_int(num("addition_time_embed_dim", 0), "addition_time_embed_dim", 0, 8192);
       c.pdim = as_int(num("projection_class_embeddings_input_dim", 0), "projection_class_embeddings_input_dim", 0, 1 << 20);
       if (c.atd <= 0 || c.pdim <= 0) die(MI355X_SD_ERR_INVALID, "text_time needs addition_time_embed_dim and projection_class_embeddings_input_dim");
+    }
+  }
+  // projection_class_embeddings_input_dim also sizes the "projection" / "simple_projection" class embeddings
+  if (const JVal* v = root.get("projection_class_embeddings_input_dim"))
+    if (v->kind == JVal::NUM) c.pdim = as_int(v->num, "projection_class_embeddings_input_dim", 1, 1 << 20);
+  if (const JVal* v = root.get("time_cond_proj_dim"))
+    if (v->kind != JVal::NUL) {
+      if (v->kind != JVal::NUM) die(MI355X_SD_ERR_INVALID, "config time_cond_proj_dim: expected an integer or null");
+      c.tcp = as_int(v->num, "time_cond_proj_dim", 8, 1 << 16);
+      if (c.tcp & 7) die(MI355X_SD_ERR_UNSUPPORTED, "time_cond_proj_dim must be a multiple of 8");
+    }
+  {
+    const JVal* ct = root.get("class_embed_type");
+    const JVal* nc = root.get("num_class_embeds");
+    const bool has_nc = nc && nc->kind != JVal::NUL;
+    if (ct && ct->kind != JVal::NUL) {
+      if (ct->kind != JVal::STR) die(MI355X_SD_ERR_INVALID, "config class_embed_type: expected a string or null");
+      if (ct->str == "timestep") c.class_kind = Cfg::CLASS_TIMESTEP;
+      else if (ct->str == "identity") c.class_kind = Cfg::CLASS_IDENTITY;
+      else if (ct->str == "projection") c.class_kind = Cfg::CLASS_PROJECTION;
+      else if (ct->str == "simple_projection") c.class_kind = Cfg::CLASS_SIMPLE;
+      else die(MI355X_SD_ERR_INVALID, "class_embed_type '" + ct->str + "'");   // the reference's ValueError (unet_2d_condition.py:439-441)
+      if ((c.class_kind == Cfg::CLASS_PROJECTION || c.class_kind == Cfg::CLASS_SIMPLE) && c.pdim <= 0)
+        die(MI355X_SD_ERR_INVALID, "`class_embed_type`: '" + ct->str + "' requires `projection_class_embeddings_input_dim` be set");
+      if ((c.class_kind == Cfg::CLASS_PROJECTION || c.class_kind == Cfg::CLASS_SIMPLE) && (c.pdim & 7))
+        die(MI355X_SD_ERR_UNSUPPORTED, "projection_class_embeddings_input_dim must be a multiple of 8");
+    } else if (has_nc) {
+      if (nc->kind != JVal::NUM) die(MI355X_SD_ERR_INVALID, "config num_class_embeds: expected an integer or null");
+      c.class_kind = Cfg::CLASS_TABLE;
+      c.num_class = as_int(nc->num, "num_class_embeds", 1, 1 << 24);
     }
   }
   if (c.out_channels > 4) die(MI355X_SD_ERR_UNSUPPORTED, "out_channels > 4");
@@ -416,6 +451,9 @@ struct Exec {
   unsigned char* ws = nullptr;
   std::vector<std::function<int(void*)>> prog_sym;   // built at plan time, read `ws` at run time
   Ref in_sample, in_t, in_scale, in_enc, in_addin, in_tids, out;
+  Ref in_class, in_tcond;                         // class_labels / timestep_cond as the program reads them (mi355x_sd_unet_set_input)
+  const void* class_ptr = nullptr;                // caller's device tensors, read by every forward call until replaced
+  const float* tcond_ptr = nullptr;
   // optional inputs chosen at plan time (mi355x_sd_unet_plan_ex flags)
   int plan_flags = 0;
   Ref enc_mask, enc_bias, self_mask, self_bias, ctrl_mid;
@@ -461,7 +499,16 @@ void build_param_table(Exec& e) {   // == unet_param_shapes for the supported co
   };
   conv("conv_in", c.in_channels, c.boc[0], 3);
   lin("time_embedding.linear_1", c.boc[0], ted);
+  if (c.tcp) lin("time_embedding.cond_proj", c.tcp, c.boc[0], false);
   lin("time_embedding.linear_2", ted, ted);
+  if (c.class_kind == Cfg::CLASS_TABLE) {
+    expect(e, "class_embedding.weight", {c.num_class, ted});   // nn.Embedding [classes, dim]: a table, never transposed
+  } else if (c.class_kind == Cfg::CLASS_TIMESTEP || c.class_kind == Cfg::CLASS_PROJECTION) {
+    lin("class_embedding.linear_1", c.class_kind == Cfg::CLASS_TIMESTEP ? c.boc[0] : c.pdim, ted);
+    lin("class_embedding.linear_2", ted, ted);
+  } else if (c.class_kind == Cfg::CLASS_SIMPLE) {
+    lin("class_embedding", c.pdim, ted);
+  }
   if (c.text_time) {
     lin("add_embedding.linear_1", c.pdim, ted);
     lin("add_embedding.linear_2", ted, ted);
@@ -579,6 +626,17 @@ struct Packer {
     }
     put_lin("time_embedding.linear_1", "time_embedding.linear_1");
     put_lin("time_embedding.linear_2", "time_embedding.linear_2");
+    if (c.tcp) put_lin("time_embedding.cond_proj", "time_embedding.cond_proj", false);
+    if (c.class_kind == Cfg::CLASS_TABLE) {
+      const HostT& t = get("class_embedding.weight");
+      uint16_t* d = m16("class_embedding.table", (int)t.shape[0], (int)t.shape[1]);
+      for (size_t i = 0; i < t.numel(); ++i) d[i] = to_elem16(t.v[i]);
+    } else if (c.class_kind == Cfg::CLASS_TIMESTEP || c.class_kind == Cfg::CLASS_PROJECTION) {
+      put_lin("class_embedding.linear_1", "class_embedding.linear_1");
+      put_lin("class_embedding.linear_2", "class_embedding.linear_2");
+    } else if (c.class_kind == Cfg::CLASS_SIMPLE) {
+      put_lin("class_embedding", "class_embedding");
+    }
     if (c.text_time) {
       put_lin("add_embedding.linear_1", "add_embedding.linear_1");
       put_lin("add_embedding.linear_2", "add_embedding.linear_2");
@@ -879,8 +937,53 @@ struct Planner {
     }
     const View e1 = view(persist((size_t)2 * B * ted), B, ted);
     const View emb = view(persist((size_t)2 * B * ted), B, ted);
+    // class embedding (unet_2d_condition.py:953-975; same launches as paddlemix_amd/unet.py): a gathered / identity embedding exists
+    // before the time MLP and rides in as the residual of its second GEMM; the computed ones add into emb afterwards
+    View pre_cls;
+    bool has_pre = false;
+    if (c.class_kind == Cfg::CLASS_TABLE) {
+      e.in_class = persist((size_t)4 * B);
+      pre_cls = view(persist((size_t)2 * B * ted), B, ted);
+      has_pre = true;
+      const Ref ids = e.in_class, tab = wref("class_embedding.table");
+      const int Bc = B;
+      const View dst = pre_cls;
+      emit([=](void* st) { return mi355x_sd_embed_tokens((const int32_t*)ex->at(ids), Bc, 1, ex->at(tab), nullptr, ted, ex->at(dst.p), dst.ld, st); });
+    } else if (c.class_kind == Cfg::CLASS_IDENTITY) {
+      e.in_class = persist((size_t)2 * B * ted);
+      pre_cls = view(e.in_class, B, ted);
+      has_pre = true;
+    }
+    if (c.tcp) {   // t_emb += cond_proj(timestep_cond) (embeddings.py:284-285; zeros when the caller passes none)
+      e.in_tcond = persist((size_t)2 * B * c.tcp);
+      linear(view(e.in_tcond, B, c.tcp), "time_embedding.cond_proj", t0, false, &t0);
+    }
     linear(t0, "time_embedding.linear_1", e1, true, nullptr, MI355X_SD_SILU);
-    linear(e1, "time_embedding.linear_2", emb);
+    linear(e1, "time_embedding.linear_2", emb, true, has_pre ? &pre_cls : nullptr);
+    if (c.class_kind == Cfg::CLASS_TIMESTEP || c.class_kind == Cfg::CLASS_PROJECTION || c.class_kind == Cfg::CLASS_SIMPLE) {
+      View cin;
+      if (c.class_kind == Cfg::CLASS_TIMESTEP) {   // class_labels -> sinusoid (time_proj) -> TimestepEmbedding
+        e.in_class = persist((size_t)4 * B);
+        cin = view(persist((size_t)2 * B * c.boc[0]), B, c.boc[0]);
+        const Ref lab = e.in_class;
+        const int Bc = B, dim = c.boc[0], flip = c.flip_sin_to_cos ? 1 : 0;
+        const float fs = (float)c.freq_shift;
+        const View cv = cin;
+        emit([=](void* st) {
+          return mi355x_sd_timestep_embedding((const float*)ex->at(lab), Bc, Bc, dim, 1, flip, fs, 1.0f, 10000.0f, ex->at(cv.p), cv.ld, st);
+        });
+      } else {
+        e.in_class = persist((size_t)2 * B * c.pdim);
+        cin = view(e.in_class, B, c.pdim);
+      }
+      if (c.class_kind == Cfg::CLASS_SIMPLE) {
+        linear(cin, "class_embedding", emb, true, &emb);
+      } else {
+        const View c1 = view(persist((size_t)2 * B * ted), B, ted);
+        linear(cin, "class_embedding.linear_1", c1, true, nullptr, MI355X_SD_SILU);
+        linear(c1, "class_embedding.linear_2", emb, true, &emb);
+      }
+    }
     if (c.text_time) {
       e.text_dim = c.pdim - 6 * c.atd;
       e.n_ids = 6;
@@ -1408,6 +1511,35 @@ int mi355x_sd_unet_skip_shape(void* handle, int index, int* C, int* H, int* W) {
   return MI355X_SD_OK;
 }
 
+int mi355x_sd_unet_set_input(void* handle, const char* name, const void* device_ptr) {
+  Exec* e = H_(handle);
+  if (!handle || !name) {
+    sd::set_last_error("mi355x_sd_unet_set_input: null handle or name");
+    return MI355X_SD_ERR_INVALID;
+  }
+  const std::string n(name);
+  if (n == "class_labels") {
+    if (e->cfg.class_kind == Cfg::CLASS_NONE && device_ptr) {
+      // (the reference ignores class_labels on a model without a class embedding, unet_2d_condition.py:953; a binding that
+      // nothing will ever read is more likely a wrong handle than intent)
+      sd::set_last_error("mi355x_sd_unet_set_input: this model has no class embedding");
+      return MI355X_SD_ERR_INVALID;
+    }
+    e->class_ptr = device_ptr;
+    return MI355X_SD_OK;
+  }
+  if (n == "timestep_cond") {
+    if (!e->cfg.tcp && device_ptr) {
+      sd::set_last_error("mi355x_sd_unet_set_input: timestep_cond was passed but the model has no `time_cond_proj_dim`");
+      return MI355X_SD_ERR_INVALID;
+    }
+    e->tcond_ptr = static_cast<const float*>(device_ptr);
+    return MI355X_SD_OK;
+  }
+  sd::set_last_error(("mi355x_sd_unet_set_input: unknown input '" + n + "' (class_labels, timestep_cond)").c_str());
+  return MI355X_SD_ERR_INVALID;
+}
+
 int mi355x_sd_unet_forward(void* handle, void* stream, const float* sample, const float* timestep, const float* encoder_hidden_states,
                            const float* text_embeds, const float* time_ids, const float* in_scale, float* out, int use_graph) {
   return mi355x_sd_unet_forward_ex(handle, stream, sample, timestep, encoder_hidden_states, text_embeds, time_ids, in_scale, nullptr,
@@ -1431,6 +1563,11 @@ int mi355x_sd_unet_forward_ex(void* handle, void* stream, const float* sample, c
   if (e->cfg.text_time && (!text_embeds || !time_ids)) {
     // the reference raises ValueError here (unet_2d_condition.py:993-1001)
     sd::set_last_error("mi355x_sd_unet_forward: addition_embed_type 'text_time' requires text_embeds and time_ids");
+    return MI355X_SD_ERR_INVALID;
+  }
+  if (e->cfg.class_kind != Cfg::CLASS_NONE && !e->class_ptr) {
+    // unet_2d_condition.py:954-955
+    sd::set_last_error("mi355x_sd_unet_forward: class_labels should be provided when num_class_embeds > 0 (mi355x_sd_unet_set_input)");
     return MI355X_SD_ERR_INVALID;
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -1490,6 +1627,25 @@ int mi355x_sd_unet_forward_ex(void* handle, void* stream, const float* sample, c
   }
   int rc = mi355x_sd_cast_rows(encoder_hidden_states, c.cross_dim, e->at(e->in_enc), c.cross_dim, (int64_t)B * L, c.cross_dim, stream);
   if (rc) return rc;
+  if (c.tcp) {
+    if (e->tcond_ptr) {
+      rc = mi355x_sd_cast_rows(e->tcond_ptr, c.tcp, e->at(e->in_tcond), c.tcp, B, c.tcp, stream);
+      if (rc) return rc;
+    } else if (hipMemsetAsync(e->at(e->in_tcond), 0, (size_t)2 * B * c.tcp, st) != hipSuccess) {
+      sd::set_last_error("mi355x_sd_unet_forward: staging copy failed");
+      return MI355X_SD_ERR_HIP;
+    }
+  }
+  if (c.class_kind == Cfg::CLASS_TABLE || c.class_kind == Cfg::CLASS_TIMESTEP) {   // int32 indices / fp32 values, one per sample
+    if (hipMemcpyAsync(e->at(e->in_class), e->class_ptr, (size_t)4 * B, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+      sd::set_last_error("mi355x_sd_unet_forward: staging copy failed");
+      return MI355X_SD_ERR_HIP;
+    }
+  } else if (c.class_kind != Cfg::CLASS_NONE) {
+    const int wdt = c.class_kind == Cfg::CLASS_IDENTITY ? c.boc[0] * 4 : c.pdim;
+    rc = mi355x_sd_cast_rows((const float*)e->class_ptr, wdt, e->at(e->in_class), wdt, B, wdt, stream);
+    if (rc) return rc;
+  }
   if (c.text_time) {
     rc = mi355x_sd_cast_rows(text_embeds, e->text_dim, e->at(e->in_addin), c.pdim, B, e->text_dim, stream);
     if (rc) return rc;

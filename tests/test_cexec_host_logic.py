@@ -14,7 +14,18 @@ from tests.abi_emulator import Emulator, on_emulator
 from tests.configs import MINI_XL, SD15, SDXL, TINY
 
 
-@pytest.mark.parametrize("cfg", [TINY, MINI_XL, SD15, SDXL], ids=["tiny", "mini-xl", "sd15", "sdxl"])
+# the inputs of forward that belong to the config (round 6: the C++ planner builds them too -- unet_2d_condition.py:404-441, 953-975)
+CLASS_CONFIGS = {
+    "lcm-cond": dict(TINY, time_cond_proj_dim=16),
+    "class-table": dict(TINY, num_class_embeds=10),
+    "class-timestep": dict(MINI_XL, class_embed_type="timestep"),       # on top of text_time: both add into the embedding
+    "class-identity": dict(TINY, class_embed_type="identity"),
+    "class-projection": dict(TINY, class_embed_type="projection", projection_class_embeddings_input_dim=24, time_cond_proj_dim=8),
+    "class-simple": dict(TINY, class_embed_type="simple_projection", projection_class_embeddings_input_dim=24),
+}
+
+
+@pytest.mark.parametrize("cfg", [TINY, MINI_XL, SD15, SDXL] + list(CLASS_CONFIGS.values()), ids=["tiny", "mini-xl", "sd15", "sdxl"] + list(CLASS_CONFIGS))
 def test_parameter_table_equals_python_table(cfg):
     hd = UNetHandle(cfg)
     got = hd.param_shapes()
@@ -23,7 +34,8 @@ def test_parameter_table_equals_python_table(cfg):
     assert all(tuple(got[k]) == tuple(want[k]) for k in want)
 
 
-@pytest.mark.parametrize("cfg,rd", [(TINY, None), (MINI_XL, None), (MINI_XL, "fp32")], ids=["tiny", "mini-xl", "mini-xl-f32resid"])
+@pytest.mark.parametrize("cfg,rd", [(TINY, None), (MINI_XL, None), (MINI_XL, "fp32")] + [(c, None) for c in CLASS_CONFIGS.values()],
+                         ids=["tiny", "mini-xl", "mini-xl-f32resid"] + list(CLASS_CONFIGS))
 def test_packed_weights_and_plan_equal_python_builder(cfg, rd):
     P = synth_unet_params(cfg, seed=5)
     hd = UNetHandle(cfg, residual_dtype=rd)
@@ -101,7 +113,8 @@ def test_config_values_are_validated_at_create():
 
 def test_refusals_are_loud():
     lib = _lib.load()
-    for bad in (dict(TINY, class_embed_type="timestep"), dict(TINY, time_cond_proj_dim=32), dict(TINY, attention_type="gated"),
+    for bad in (dict(TINY, class_embed_type="timestep", class_embeddings_concat=True), dict(TINY, time_cond_proj_dim=12), dict(TINY, attention_type="gated"),
+                dict(TINY, class_embed_type="projection"), dict(TINY, class_embed_type="no-such-type"),
                 dict(TINY, down_block_types=("DownBlock2D", "AttnDownBlock2D")), dict(TINY, encoder_hid_dim_type="ip_image_proj", encoder_hid_dim=8)):
         with pytest.raises(_lib.MI355XError):
             UNetHandle(bad)
@@ -110,6 +123,14 @@ def test_refusals_are_loud():
         h = ctypes.c_void_p()      # malformed config text: an error code and a message, never an exception across the C boundary
         assert lib.mi355x_sd_unet_create(bad, ctypes.byref(h)) != 0 and not h.value and lib.mi355x_sd_last_error()
     hd = UNetHandle(TINY)
+    # inputs the model does not have cannot be bound; unknown names neither (mi355x_sd_unet_set_input)
+    dummy = ctypes.c_void_p(64)
+    assert lib.mi355x_sd_unet_set_input(hd.h, b"class_labels", dummy) != 0 and b"no class embedding" in lib.mi355x_sd_last_error()
+    assert lib.mi355x_sd_unet_set_input(hd.h, b"timestep_cond", dummy) != 0 and b"time_cond_proj_dim" in lib.mi355x_sd_last_error()
+    assert lib.mi355x_sd_unet_set_input(hd.h, b"image_embeds", dummy) != 0 and b"unknown input" in lib.mi355x_sd_last_error()
+    assert lib.mi355x_sd_unet_set_input(hd.h, b"class_labels", None) == 0
+    hc = UNetHandle(CLASS_CONFIGS["class-table"])
+    assert lib.mi355x_sd_unet_set_input(hc.h, b"class_labels", dummy) == 0 and lib.mi355x_sd_unet_set_input(hc.h, b"class_labels", None) == 0
     with pytest.raises(_lib.MI355XError, match="never loaded"):
         hd.weight_bytes()
     w = torch.zeros(3, 3)

@@ -47,6 +47,67 @@ def test_handle_model_equals_python_planned_model(name, cfg, B, H, W, L, rd):
             m(_cuda(sample), 501, _cuda(enc))
 
 
+def test_handle_class_labels_and_timestep_cond_equal_python_planned_model():
+    """class embeddings (table / timestep / identity / projection / simple_projection) and TimestepEmbedding.cond_proj behind the C
+    handle (round 6; unet_2d_condition.py:953-975, embeddings.py:284-285; mi355x_sd_unet_set_input): bit-identical to the
+    Python-planned model, eager and as a graph; new values on a later call are read (the staging is outside the graph); a model with
+    a class embedding and nothing bound is refused with the reference's message."""
+    from paddlemix_amd import _lib
+    from paddlemix_amd.cexec import CUNet2DConditionModel
+    from paddlemix_amd.unet import UNet2DConditionModel, synth_unet_params
+    from tests.test_cexec_host_logic import CLASS_CONFIGS
+    g = torch.Generator().manual_seed(11)
+    for name, cfg in CLASS_CONFIGS.items():
+        B, H, W, L = 2, 16, 16, (77 if cfg.get("addition_embed_type") else 7)
+        P = synth_unet_params(cfg, seed=1234)
+        sample, enc, added = _inputs(cfg, B, H, W, L)
+        ct, ted = cfg.get("class_embed_type"), 4 * cfg["block_out_channels"][0]
+        kws = []
+        for rep in range(2):   # two different sets of values
+            kw = {}
+            if cfg.get("num_class_embeds"):
+                kw["class_labels"] = torch.tensor([3, 7] if rep == 0 else [9, 0])
+            elif ct == "timestep":
+                kw["class_labels"] = torch.tensor([12.0, 700.0]) * (rep + 1)
+            elif ct == "identity":
+                kw["class_labels"] = torch.randn(B, ted, generator=g)
+            elif ct in ("projection", "simple_projection"):
+                kw["class_labels"] = torch.randn(B, cfg["projection_class_embeddings_input_dim"], generator=g)
+            if cfg.get("time_cond_proj_dim") and (rep == 0 or "class_labels" not in kw):
+                kw["timestep_cond"] = torch.randn(B, cfg["time_cond_proj_dim"], generator=g)   # (rep 1 of a model with both: None)
+            kws.append({k: v.cuda() for k, v in kw.items()})
+        ref = UNet2DConditionModel(cfg, P, use_graph=False)
+        wants = [ref(_cuda(sample), 501, _cuda(enc), added_cond_kwargs=_cuda(added), **kw).sample.clone() for kw in kws]
+        assert not torch.equal(wants[0], wants[1]), name
+        for graph in (False, True):
+            m = CUNet2DConditionModel(cfg, P, use_graph=graph)
+            for kw, want in list(zip(kws, wants)) + [(kws[0], wants[0])]:
+                got = m(_cuda(sample), 501, _cuda(enc), added_cond_kwargs=_cuda(added), **kw).sample
+                assert torch.equal(got, want), (name, graph, (got - want).abs().max())
+        if "class_labels" in kws[0]:
+            with pytest.raises(ValueError, match="class_labels should be provided"):
+                m(_cuda(sample), 501, _cuda(enc), added_cond_kwargs=_cuda(added))
+            lib = _lib.load()   # ... and the C entry point itself, with nothing bound
+            assert lib.mi355x_sd_unet_set_input(m.hd.h, b"class_labels", None) == 0
+            s32, e32, t32 = sample.cuda().float().contiguous(), enc.cuda().float().contiguous(), torch.tensor([501.0], device="cuda")
+            o = torch.empty(B, 4, H, W, device="cuda")
+            te = ti = None
+            if added:
+                te, ti = added["text_embeds"].cuda().float().contiguous(), added["time_ids"].cuda().float().contiguous()
+            rc = lib.mi355x_sd_unet_forward(m.hd.h, None, s32.data_ptr(), t32.data_ptr(), e32.data_ptr(), te.data_ptr() if added else None,
+                                            ti.data_ptr() if added else None, None, o.data_ptr(), 0)
+            assert rc != 0 and b"class_labels should be provided" in lib.mi355x_sd_last_error()
+            with pytest.raises(ValueError, match="class_labels of shape"):
+                m(_cuda(sample), 501, _cuda(enc), added_cond_kwargs=_cuda(added), class_labels=torch.zeros(B + 1, 3))
+        else:
+            with pytest.raises(ValueError, match="timestep_cond of shape"):
+                m(_cuda(sample), 501, _cuda(enc), timestep_cond=torch.zeros(B, 3).cuda())
+    m = CUNet2DConditionModel(TINY, synth_unet_params(TINY, seed=1), use_graph=False)
+    sample, enc, _ = _inputs(TINY, 2, 16, 16, 7)
+    with pytest.raises(ValueError, match="time_cond_proj_dim"):
+        m(_cuda(sample), 501, _cuda(enc), timestep_cond=torch.zeros(2, 16).cuda())
+
+
 @pytest.mark.parametrize("rd", [None, "fp32"])
 def test_handle_optional_inputs_equal_python_planned_model(rd):
     """mi355x_sd_unet_plan_ex / forward_ex: encoder_attention_mask, the self-attention attention_mask and the ControlNet residual
