@@ -5,8 +5,8 @@ parameters -> host pointers, two caller-owned device buffers (weights, workspace
 call. It presents the reference's call contract (``unet(sample, t, encoder_hidden_states, added_cond_kwargs=...,
 return_dict=False) -> (noise_pred,)``, unet_2d_condition.py:809-1207) like ``paddlemix_amd.unet.UNet2DConditionModel`` does --
 the latter emits the same launches from Python and remains the form with EVERY optional input (the handle has the masks, the
-ControlNet residuals, class labels and timestep_cond; not the IP-Adapter image embeddings, class_embeddings_concat or latent sizes
-that need `forward_upsample_size`); the handle form is what a compiled host binds.
+ControlNet residuals, class labels, timestep_cond and odd latent sizes; not the IP-Adapter image embeddings or
+class_embeddings_concat); the handle form is what a compiled host binds.
 """
 from __future__ import annotations
 

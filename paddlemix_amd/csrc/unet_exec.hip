@@ -1191,9 +1191,38 @@ struct Planner {
         ++u;
       } else if (d.kind == Layer::UP) {
         const View dst = x_slot(u);
-        conv3(cast16(cur, "xc16"), h, w_, d.name, dst, 1, 1);
-        h *= 2;
-        w_ *= 2;
+        const Sk& tgt = skips[skips.size() - 1 - u];   // the skip the next resnet concatenates with: the size to reach
+        const int ht = tgt.h, wt = tgt.w;
+        const View src = cast16(cur, "xc16");
+        if (ht == 2 * h && wt == 2 * w_) {
+          conv3(src, h, w_, d.name, dst, 1, 1);          // nearest x2 folded into the conv's gather
+        } else {
+          // `forward_upsample_size` (unet_2d_condition.py:900-906, 1165-1169; Upsample2D interpolates to the skip's size): latents
+          // that are not multiples of 2^(levels - 1) leave a skip of odd size 2h - 1, and nearest interpolation from h to 2h - 1 reads
+          // source row y >> 1 like the x2 form, cropped. The crop moves the conv's zero padding, so the upsampled tensor is
+          // materialised (strided row copies, one per source row and parity: many small launches, on this rare path only) and a
+          // plain 3x3 conv follows -- the same launches as paddlemix_amd/unet.py.
+          if (!((ht == 2 * h - 1 || ht == 2 * h) && (wt == 2 * w_ - 1 || wt == 2 * w_))) die(MI355X_SD_ERR_INVALID, "internal: upsample target size");
+          const int C_ = src.C;
+          const View upb = view(sc("upx", (size_t)2 * B * ht * wt * C_), B * ht * wt, C_);
+          for (int b = 0; b < B; ++b)
+            for (int i_ = 0; i_ < h; ++i_)
+              for (int dy = 0; dy < 2; ++dy) {
+                const int y = 2 * i_ + dy;
+                if (y >= ht) continue;
+                for (int dx = 0; dx < 2; ++dx) {
+                  const int n = (wt - dx + 1) / 2;
+                  Ref sp = src.p, dp = upb.p;
+                  sp.off += (size_t)2 * ((size_t)(b * h + i_) * w_) * src.ld;
+                  dp.off += (size_t)2 * ((size_t)(b * ht + y) * wt + dx) * C_;
+                  const int lds = src.ld;
+                  emit([=](void* st) { return mi355x_sd_copy_rows(ex->at(sp), lds, ex->at(dp), 2 * C_, n, C_, st); });
+                }
+              }
+          conv3(upb, ht, wt, d.name, dst);
+        }
+        h = ht;
+        w_ = wt;
         cur = dst;
       }
     }
@@ -1445,12 +1474,8 @@ int mi355x_sd_unet_plan_ex(void* handle, int B, int H, int W, int L, int flags, 
   try {
     Exec* e = H_(handle);
     if (!e->dev_w) die(MI355X_SD_ERR_INVALID, "mi355x_sd_unet_plan: call mi355x_sd_unet_finalize_weights first");
-    {   // the reference forwards the skips' sizes to its upsamplers for other sizes (unet_2d_condition.py:900-906); the conv gather folds an exact x2
-      const int up_factor = 1 << (int)(e->cfg.boc.size() - 1);
-      if (H % up_factor || W % up_factor)
-        die(MI355X_SD_ERR_UNSUPPORTED, "mi355x_sd_unet_plan: latent height and width must be multiples of " + std::to_string(up_factor) +
-                                           " (the forward_upsample_size path is not implemented)");
-    }
+    if ((H >> (e->cfg.boc.size() - 1)) < 1 || (W >> (e->cfg.boc.size() - 1)) < 1)
+      die(MI355X_SD_ERR_INVALID, "mi355x_sd_unet_plan: latents smaller than one pixel at the lowest level");
     if (e->graph) {
       (void)hipGraphExecDestroy(e->graph);
       e->graph = nullptr;

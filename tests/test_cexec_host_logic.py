@@ -62,6 +62,24 @@ def test_packed_weights_and_plan_equal_python_builder(cfg, rd):
     assert nbytes > 0 and nbytes % 256 == 0
 
 
+@pytest.mark.parametrize("H,W", [(18, 18), (20, 10), (9, 14)])
+def test_odd_latent_sizes_plan_the_python_planners_launches(H, W):
+    """`forward_upsample_size` (unet_2d_condition.py:900-906, 1165-1169): latents that are not multiples of 2^(levels - 1) -- the
+    C++ planner refused them through round 5; it now materialises the cropped nearest-x2 tensor with the same row copies as the
+    Python planner (bit-identity on the device: tests/test_gpu_cexec.py)"""
+    cfg = MINI_XL
+    P = synth_unet_params(cfg, seed=5)
+    hd = UNetHandle(cfg)
+    hd.load(P)
+    image = hd.pack()
+    hd.attach(image)
+    assert hd.plan(1, H, W, 77) > 0
+    model = on_emulator(UNet2DConditionModel, cfg, P)
+    assert hd.num_launches() == len(model._get_plan(1, H, W, 77).prog) + 1     # (+ the time_ids sinusoid the Python plan inserts at its first call)
+    n = ctypes.c_size_t()
+    assert _lib.load().mi355x_sd_unet_plan(hd.h, 1, 2, 2, 77, ctypes.byref(n)) != 0   # nothing left at the lowest of three levels
+
+
 def test_weight_life_cycle_after_the_host_image_is_released():
     """attach / finalize release the packed host image; every later call has to work from the cached size, never repack
     from the (consumed) fp32 tensors. pack -> attach -> weight_bytes / attach again / pack: sizes stay, pack says why it cannot,

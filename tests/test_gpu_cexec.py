@@ -17,7 +17,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("name,cfg,B,H,W,L", [("tiny", TINY, 2, 16, 16, 7), ("mini-xl", MINI_XL, 2, 32, 32, 77)])
+@pytest.mark.parametrize("name,cfg,B,H,W,L", [("tiny", TINY, 2, 16, 16, 7), ("mini-xl", MINI_XL, 2, 32, 32, 77),
+                                              ("mini-xl-odd", MINI_XL, 2, 18, 22, 77)])   # odd: forward_upsample_size (round 6)
 @pytest.mark.parametrize("rd", [None, "fp32"])
 def test_handle_model_equals_python_planned_model(name, cfg, B, H, W, L, rd):
     from paddlemix_amd.cexec import CUNet2DConditionModel
