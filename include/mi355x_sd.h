@@ -115,8 +115,7 @@ int mi355x_sd_unet_forward(void* handle, void* stream, const float* sample, cons
  *   CONTROLNET down_block_additional_residuals (one fp32 NCHW tensor per skip connection, in the order the down path produces
  *              them: conv_in first) + mid_block_additional_residual (:1121-1132, 1151-1155), e.g. the outputs of
  *              ControlNetModel; both or neither
- * The IP-Adapter image_embeds are inputs of the Python-planned model only (paddlemix_amd/unet.py); a config that needs them
- * (encoder_hid_dim_type) is refused at create. class_labels and timestep_cond: mi355x_sd_unet_set_input below. */
+ * class_labels, timestep_cond and the IP-Adapter image_embeds: mi355x_sd_unet_set_input below. */
 #define MI355X_SD_UNET_ENC_MASK 1
 #define MI355X_SD_UNET_SELF_MASK 2
 #define MI355X_SD_UNET_CONTROLNET 4
@@ -137,10 +136,19 @@ int mi355x_sd_unet_forward_ex(void* handle, void* stream, const float* sample, c
  *                    "timestep": fp32 [B] (goes through time_proj and a TimestepEmbedding); "projection" / "simple_projection":
  *                    fp32 [B, projection_class_embeddings_input_dim]; "identity": fp32 [B, 4 * block_out_channels[0]].
  *                    A forward call of such a model with nothing bound is MI355X_SD_ERR_INVALID (the reference's ValueError,
- *                    :954-955); class_embeddings_concat=true is refused at create.
+ *                    :954-955). class_embeddings_concat=true hands the blocks [emb | class_emb] (:443-449, 972-975); together with
+ *                    addition_embed_type it is refused at create, as by the Python planner.
  *   "timestep_cond"  fp32 [B, time_cond_proj_dim] (the LCM guidance-scale embedding); unbound = the reference's None (no term).
+ *   "image_embeds"   fp32 [B, encoder_hid_dim] of a model with encoder_hid_dim_type "ip_image_proj" (the CLIP image embedding of the
+ *                    IP-Adapter prompt, added_cond_kwargs["image_embeds"], :1054-1061): projected to ip_adapter_num_tokens image
+ *                    tokens (ImageProjection, embeddings.py:507-518) whose attention is added to every cross-attention output with
+ *                    the IP-Adapter scale (IPAdapterAttnProcessor, attention_processor.py:1816-1900). Unbound at a forward call =
+ *                    MI355X_SD_ERR_INVALID (the reference's ValueError).
  * Binding an input the model does not have is MI355X_SD_ERR_INVALID. */
 int mi355x_sd_unet_set_input(void* handle, const char* name, const void* device_ptr);
+/* IPAdapterAttnProcessor.scale of every cross-attention (the reference's set_ip_adapter_scale, loaders/ip_adapter.py; default 1; 0
+ * drops the image-token attention launches). A constant of the planned launches: changing it discards the plan -- plan and bind again. */
+int mi355x_sd_unet_set_ip_adapter_scale(void* handle, float scale);
 /* ---- seam B2: any exported step program behind one handle (paddlemix_amd/csrc/program_exec.hip) --------------------------------
  * Every model of the path (UNet2DConditionModel, ControlNetModel, SD3Transformer2DModel, the DiT Transformer2DModel, AutoencoderKL
  * decode / encode, the CLIP and T5 text encoders) runs as a static list of the per-op launches below over weights + scratch. The

@@ -151,6 +151,7 @@ SIGNATURES = {
     "mi355x_sd_unet_num_skips": (c_int, [c_void_p]),
     "mi355x_sd_unet_skip_shape": (c_int, [c_void_p, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "mi355x_sd_unet_set_input": (c_int, [c_void_p, c_char_p, c_void_p]),
+    "mi355x_sd_unet_set_ip_adapter_scale": (c_int, [c_void_p, c_float]),
     "mi355x_sd_unet_forward_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p, POINTER(c_void_p), c_int, c_void_p, c_void_p, c_int]),
     "mi355x_sd_graph_begin": (c_int, [c_void_p]),

@@ -4,9 +4,9 @@ The program builder, the weight packing and the execution live in the C library;
 parameters -> host pointers, two caller-owned device buffers (weights, workspace) as torch tensors, and device pointers per
 call. It presents the reference's call contract (``unet(sample, t, encoder_hidden_states, added_cond_kwargs=...,
 return_dict=False) -> (noise_pred,)``, unet_2d_condition.py:809-1207) like ``paddlemix_amd.unet.UNet2DConditionModel`` does --
-the latter emits the same launches from Python and remains the form with EVERY optional input (the handle has the masks, the
-ControlNet residuals, class labels, timestep_cond and odd latent sizes; not the IP-Adapter image embeddings or
-class_embeddings_concat); the handle form is what a compiled host binds.
+the latter emits the same launches from Python (since round 6 the C++ planner builds every config field it builds: masks,
+ControlNet residuals, class labels, timestep_cond, the IP-Adapter image embeddings, odd latent sizes); the handle form is what a
+compiled host binds.
 """
 from __future__ import annotations
 
@@ -179,12 +179,22 @@ class CUNet2DConditionModel:
                 want = (B, ted if ct == "identity" else cfgd["projection_class_embeddings_input_dim"])
             if tuple(cl.shape) != want:
                 raise ValueError(f"class_labels of shape {tuple(class_labels.shape)}, expected {want}")
+            if ct is None and not cl.is_cuda and cl.numel() and not (0 <= int(cl.min()) and int(cl.max()) < nce):
+                raise IndexError(f"class_labels must lie in [0, {nce}), got {cl.tolist()}")   # (host labels only: see unet.py)
         tcp = cfgd.get("time_cond_proj_dim")
         if timestep_cond is not None:
             if tcp is None:
                 raise ValueError("timestep_cond was passed but the model has no `time_cond_proj_dim`")
             if tuple(timestep_cond.shape) != (B, tcp):
                 raise ValueError(f"timestep_cond of shape {tuple(timestep_cond.shape)}, expected {(B, tcp)}")
+        ie = None
+        if cfgd.get("encoder_hid_dim_type") == "ip_image_proj":
+            if added_cond_kwargs is None or "image_embeds" not in added_cond_kwargs:
+                raise ValueError(f"{self.__class__} has the config param `encoder_hid_dim_type` set to 'ip_image_proj' which "
+                                 "requires the keyword argument `image_embeds` to be passed in  `added_conditions`")
+            ie = added_cond_kwargs["image_embeds"]
+            if tuple(ie.shape) != (B, cfgd["encoder_hid_dim"]):
+                raise ValueError(f"image_embeds of shape {tuple(ie.shape)}, expected {(B, cfgd['encoder_hid_dim'])}")
         controlnet = down_block_additional_residuals is not None
         if controlnet != (mid_block_additional_residual is not None):
             raise NotImplementedError("ControlNet residuals need both `down_block_additional_residuals` and "
@@ -234,10 +244,13 @@ class CUNet2DConditionModel:
             if tcp is not None:
                 tc = None if timestep_cond is None else f32(timestep_cond)
                 _lib.check(lib.mi355x_sd_unet_set_input(h, b"timestep_cond", p(tc)))
+            if ie is not None:
+                ie = f32(ie)
+                _lib.check(lib.mi355x_sd_unet_set_input(h, b"image_embeds", ie.data_ptr()))
             _lib.check(lib.mi355x_sd_unet_forward_ex(h, self._stream.cuda_stream, p(s), p(tt), p(e), p(te), p(ti), p(sc), p(em), p(sm), arr,
                                                      len(rs), p(rm), p(out), 1 if self.use_graph else 0))
         cur.wait_stream(self._stream)
-        for x in [s, tt, e, te, ti, sc, em, sm, rm, clt, tc] + rs:     # keep the staging tensors alive until the stream has consumed them
+        for x in [s, tt, e, te, ti, sc, em, sm, rm, clt, tc, ie] + rs:     # keep the staging tensors alive until the stream has consumed them
             if x is not None:
                 x.record_stream(self._stream)
         if not return_dict:
@@ -245,3 +258,10 @@ class CUNet2DConditionModel:
         return SimpleNamespace(sample=out)
 
     __call__ = forward
+
+    def set_ip_adapter_scale(self, scale: float) -> None:
+        """IPAdapterAttnProcessor.scale (the reference's ``set_ip_adapter_scale``); a constant of the plan: the next call plans again"""
+        if self.hd.config_dict.get("encoder_hid_dim_type") != "ip_image_proj":
+            raise ValueError("this UNet has no IP-Adapter (config encoder_hid_dim_type != 'ip_image_proj')")
+        _lib.check(self.hd.lib.mi355x_sd_unet_set_ip_adapter_scale(self.hd.h, float(scale)))
+        self._geom = None

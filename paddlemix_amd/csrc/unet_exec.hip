@@ -148,6 +148,10 @@ struct Cfg {
   ClassKind class_kind = CLASS_NONE;
   int num_class = 0;      // rows of the nn.Embedding table (CLASS_TABLE)
   int tcp = 0;            // time_cond_proj_dim (0: none)
+  bool concat = false;    // class_embeddings_concat: the blocks see [emb | class_emb] (blocks_time_embed_dim = 2 x time_embed_dim, :443-449)
+  // IP-Adapter (encoder_hid_dim_type "ip_image_proj": ImageProjection embeddings.py:507-518 + IPAdapterAttnProcessor on every attn2)
+  bool ip = false;
+  int ehd = 0, ip_tokens = 4;   // encoder_hid_dim; ImageProjection.num_image_text_embeds (extension key ip_adapter_num_tokens, as unet.py)
 };
 
 // A config number that has to be an integer inside [lo, hi]: the text comes from a host (a file someone edited), and a width of
@@ -192,7 +196,7 @@ Cfg parse_config(const char* json) {
     return o;
   };
   // what this executor does not build must not load silently (same refusals as paddlemix_amd/unet.py normalize_config)
-  static const char* must_be_null[] = {"encoder_hid_dim", "encoder_hid_dim_type",
+  static const char* must_be_null[] = {
                                        "time_embedding_dim", "time_embedding_act_fn", "timestep_post_act", "cross_attention_norm",
                                        "mid_block_only_cross_attention", "reverse_transformer_layers_per_block", "num_attention_heads"};
   for (const char* k : must_be_null) {
@@ -200,8 +204,7 @@ Cfg parse_config(const char* json) {
     if (v && !(v->kind == JVal::NUL || (v->kind == JVal::BOOL && !v->b)))
       die(MI355X_SD_ERR_UNSUPPORTED, std::string("mi355x_sd_unet_create: config ") + k + " is not implemented by the C executor");
   }
-  static const char* must_be_false[] = {"center_input_sample", "dual_cross_attention", "only_cross_attention", "resnet_skip_time_act",
-                                        "class_embeddings_concat"};
+  static const char* must_be_false[] = {"center_input_sample", "dual_cross_attention", "only_cross_attention", "resnet_skip_time_act"};
   for (const char* k : must_be_false)
     if (boolean(k, false)) die(MI355X_SD_ERR_UNSUPPORTED, std::string("mi355x_sd_unet_create: config ") + k + "=true is not implemented");
   auto str_is = [&](const char* k, const char* want) {
@@ -291,6 +294,28 @@ Cfg parse_config(const char* json) {
       if (nc->kind != JVal::NUM) die(MI355X_SD_ERR_INVALID, "config num_class_embeds: expected an integer or null");
       c.class_kind = Cfg::CLASS_TABLE;
       c.num_class = as_int(nc->num, "num_class_embeds", 1, 1 << 24);
+    }
+    c.concat = boolean("class_embeddings_concat", false);
+    if (c.concat && c.class_kind == Cfg::CLASS_NONE)   // the reference builds 2x-wide time_emb_proj and then feeds them the 1x embedding
+      die(MI355X_SD_ERR_INVALID, "class_embeddings_concat=true needs a class embedding (class_embed_type / num_class_embeds)");
+    if (c.concat && c.text_time) die(MI355X_SD_ERR_UNSUPPORTED, "class_embeddings_concat together with addition_embed_type is not implemented");
+  }
+  {
+    const JVal* ty = root.get("encoder_hid_dim_type");
+    const JVal* hd = root.get("encoder_hid_dim");
+    const bool has_hd = hd && hd->kind != JVal::NUL;
+    if (ty && ty->kind != JVal::NUL) {
+      if (ty->kind != JVal::STR || ty->str != "ip_image_proj")   // text_proj / text_image_proj / image_proj (unet_2d_condition.py:300-335) are not built
+        die(MI355X_SD_ERR_UNSUPPORTED, "mi355x_sd_unet_create: config encoder_hid_dim_type=" + (ty->kind == JVal::STR ? ty->str : std::string("?")) +
+                                           " is not implemented");
+      if (!has_hd) die(MI355X_SD_ERR_INVALID, "`encoder_hid_dim` has to be defined when `encoder_hid_dim_type` is set to ip_image_proj.");
+      if (hd->kind != JVal::NUM) die(MI355X_SD_ERR_INVALID, "config encoder_hid_dim: expected an integer");
+      c.ip = true;
+      c.ehd = as_int(hd->num, "encoder_hid_dim", 8, 1 << 16);
+      if (c.ehd & 7) die(MI355X_SD_ERR_UNSUPPORTED, "encoder_hid_dim must be a multiple of 8");
+      c.ip_tokens = as_int(num("ip_adapter_num_tokens", 4), "ip_adapter_num_tokens", 1, 4096);
+    } else if (has_hd) {
+      die(MI355X_SD_ERR_UNSUPPORTED, "mi355x_sd_unet_create: config encoder_hid_dim without a type (text_proj) is not implemented");
     }
   }
   if (c.out_channels > 4) die(MI355X_SD_ERR_UNSUPPORTED, "out_channels > 4");
@@ -451,7 +476,9 @@ struct Exec {
   unsigned char* ws = nullptr;
   std::vector<std::function<int(void*)>> prog_sym;   // built at plan time, read `ws` at run time
   Ref in_sample, in_t, in_scale, in_enc, in_addin, in_tids, out;
-  Ref in_class, in_tcond;                         // class_labels / timestep_cond as the program reads them (mi355x_sd_unet_set_input)
+  Ref in_class, in_tcond, in_image;               // class_labels / timestep_cond / image_embeds as the program reads them (mi355x_sd_unet_set_input)
+  const float* image_ptr = nullptr;
+  float ip_scale = 1.0f;                          // IPAdapterAttnProcessor.scale (mi355x_sd_unet_set_ip_adapter_scale; a launch constant of the plan)
   const void* class_ptr = nullptr;                // caller's device tensors, read by every forward call until replaced
   const float* tcond_ptr = nullptr;
   // optional inputs chosen at plan time (mi355x_sd_unet_plan_ex flags)
@@ -517,7 +544,7 @@ void build_param_table(Exec& e) {   // == unet_param_shapes for the supported co
     if (d.kind == Layer::RESNET) {
       norm(d.name + ".norm1", d.cin);
       conv(d.name + ".conv1", d.cin, d.cout, 3);
-      lin(d.name + ".time_emb_proj", ted, d.cout);
+      lin(d.name + ".time_emb_proj", ted * (c.concat ? 2 : 1), d.cout);
       norm(d.name + ".norm2", d.cout);
       conv(d.name + ".conv2", d.cout, d.cout, 3);
       if (d.cin != d.cout) conv(d.name + ".conv_shortcut", d.cin, d.cout, 1);
@@ -536,7 +563,12 @@ void build_param_table(Exec& e) {   // == unet_param_shapes for the supported co
           lin(an + ".to_k", kd, ch, false);
           lin(an + ".to_v", kd, ch, false);
           lin(an + ".to_out.0", ch, ch);
-          if (a == 0) norm(b + ".norm2", ch);
+          if (a == 0) {
+            norm(b + ".norm2", ch);
+          } else if (c.ip) {   // IPAdapterAttnProcessor (attention_processor.py:1816-1817)
+            lin(an + ".processor.to_k_ip", kd, ch, false);
+            lin(an + ".processor.to_v_ip", kd, ch, false);
+          }
         }
         norm(b + ".norm3", ch);
         lin(b + ".ff.net.0.proj", ch, 8 * ch);
@@ -550,6 +582,10 @@ void build_param_table(Exec& e) {   // == unet_param_shapes for the supported co
   }
   norm("conv_norm_out", c.boc[0]);
   conv("conv_out", c.boc[0], c.out_channels, 3);
+  if (c.ip) {   // ImageProjection; last, like unet_param_shapes
+    lin("encoder_hid_proj.image_embeds", c.ehd, c.ip_tokens * c.cross_dim);
+    norm("encoder_hid_proj.norm", c.cross_dim);
+  }
 }
 
 // ---- packing (== UNet2DConditionModel._load_weights) ----
@@ -720,8 +756,21 @@ struct Packer {
             lin_rows(get(b + ".attn2.to_v.weight"), kv, r0 + d.cout);
           }
     }
+    if (c.ip) {   // ... and every IPAdapterAttnProcessor's to_k_ip / to_v_ip at the same row offsets
+      uint16_t* kv = m16("kvip_all.w", e.kv_total, c.cross_dim);
+      for (auto& d : e.layers)
+        if (d.kind == Layer::ATTN)
+          for (int l = 0; l < d.layers; ++l) {
+            const std::string b = d.name + ".transformer_blocks." + std::to_string(l);
+            const int r0 = e.kv_off[b];
+            lin_rows(get(b + ".attn2.processor.to_k_ip.weight"), kv, r0);
+            lin_rows(get(b + ".attn2.processor.to_v_ip.weight"), kv, r0 + d.cout);
+          }
+      put_lin("encoder_hid_proj.image_embeds", "encoder_hid_proj.image_embeds");
+      put_norm("encoder_hid_proj.norm", "encoder_hid_proj.norm");
+    }
     {   // every resnet time_emb_proj in one matrix
-      uint16_t* tw = m16("temb_all.w", e.temb_total, ted);
+      uint16_t* tw = m16("temb_all.w", e.temb_total, ted * (c.concat ? 2 : 1));
       float* tb = f32("temb_all.b", e.temb_total);
       for (auto& d : e.layers)
         if (d.kind == Layer::RESNET) {
@@ -936,15 +985,18 @@ struct Planner {
       });
     }
     const View e1 = view(persist((size_t)2 * B * ted), B, ted);
-    const View emb = view(persist((size_t)2 * B * ted), B, ted);
+    const int ted_b = ted * (c.concat ? 2 : 1);
+    const View emb_t = view(persist((size_t)2 * B * ted_b), B, ted_b);
+    const View emb = emb_t.cols(0, ted);                   // the time-embedding half (all of it without concat)
+    const View cls_out = emb_t.cols(c.concat ? ted : 0, ted);   // where the class embedding goes when concatenated
     // class embedding (unet_2d_condition.py:953-975; same launches as paddlemix_amd/unet.py): a gathered / identity embedding exists
     // before the time MLP and rides in as the residual of its second GEMM; the computed ones add into emb afterwards
     View pre_cls;
     bool has_pre = false;
     if (c.class_kind == Cfg::CLASS_TABLE) {
       e.in_class = persist((size_t)4 * B);
-      pre_cls = view(persist((size_t)2 * B * ted), B, ted);
-      has_pre = true;
+      pre_cls = c.concat ? cls_out : view(persist((size_t)2 * B * ted), B, ted);
+      has_pre = !c.concat;
       const Ref ids = e.in_class, tab = wref("class_embedding.table");
       const int Bc = B;
       const View dst = pre_cls;
@@ -952,7 +1004,12 @@ struct Planner {
     } else if (c.class_kind == Cfg::CLASS_IDENTITY) {
       e.in_class = persist((size_t)2 * B * ted);
       pre_cls = view(e.in_class, B, ted);
-      has_pre = true;
+      has_pre = !c.concat;
+      if (c.concat) {
+        const View src = pre_cls, dst = cls_out;
+        const int Bc = B;
+        emit([=](void* st) { return mi355x_sd_copy_rows(ex->at(src.p), src.ld, ex->at(dst.p), dst.ld, Bc, ted, st); });
+      }
     }
     if (c.tcp) {   // t_emb += cond_proj(timestep_cond) (embeddings.py:284-285; zeros when the caller passes none)
       e.in_tcond = persist((size_t)2 * B * c.tcp);
@@ -976,12 +1033,14 @@ struct Planner {
         e.in_class = persist((size_t)2 * B * c.pdim);
         cin = view(e.in_class, B, c.pdim);
       }
+      const View dst = c.concat ? cls_out : emb;
+      const View* res = c.concat ? nullptr : &emb;
       if (c.class_kind == Cfg::CLASS_SIMPLE) {
-        linear(cin, "class_embedding", emb, true, &emb);
+        linear(cin, "class_embedding", dst, true, res);
       } else {
         const View c1 = view(persist((size_t)2 * B * ted), B, ted);
         linear(cin, "class_embedding.linear_1", c1, true, nullptr, MI355X_SD_SILU);
-        linear(c1, "class_embedding.linear_2", emb, true, &emb);
+        linear(c1, "class_embedding.linear_2", dst, true, res);
       }
     }
     if (c.text_time) {
@@ -1003,10 +1062,10 @@ struct Planner {
       linear(view(e.in_addin, B, c.pdim), "add_embedding.linear_1", a1, true, nullptr, MI355X_SD_SILU);
       linear(a1, "add_embedding.linear_2", emb, true, &emb);
     }
-    const View semb = view(persist((size_t)2 * B * ted), B, ted);
+    const View semb = view(persist((size_t)2 * B * ted_b), B, ted_b);
     {
-      const int n = B * ted;
-      emit([=](void* st) { return mi355x_sd_silu(ex->at(emb.p), ex->at(semb.p), n, 0, 0, st); });
+      const int n = B * ted_b;
+      emit([=](void* st) { return mi355x_sd_silu(ex->at(emb_t.p), ex->at(semb.p), n, 0, 0, st); });
     }
     const Ref temb_all = persist((size_t)4 * B * e.temb_total);
     {
@@ -1015,6 +1074,21 @@ struct Planner {
     }
     const View kv_all = view(persist((size_t)2 * B * L * e.kv_total), B * L, e.kv_total);
     linear(enc, "kv_all", kv_all, false);
+    // IP-Adapter (unet_2d_condition.py:1054-1061): image_embeds -> ImageProjection (Linear, view [B*T, Dx], LayerNorm) -> the image
+    // tokens' K/V for every cross-attention in one GEMM; each attn2 then adds scale * attention(q, k_ip, v_ip) (same launches as unet.py)
+    View kvip_all;
+    const int T = c.ip_tokens;
+    if (c.ip) {
+      e.in_image = persist((size_t)2 * B * c.ehd);
+      const View raw = view(persist((size_t)2 * B * T * dx), B, T * dx);
+      const View tok = view(persist((size_t)2 * B * T * dx), B * T, dx);
+      linear(view(e.in_image, B, c.ehd), "encoder_hid_proj.image_embeds", raw);
+      lnorm(view(raw.p, B * T, dx), "encoder_hid_proj.norm", tok);
+      kvip_all = view(persist((size_t)2 * B * T * e.kv_total), B * T, e.kv_total);
+      linear(tok, "kvip_all", kvip_all, false);
+    }
+    const bool ip_on = c.ip && e.ip_scale != 0.0f;
+    const float ip_scale = e.ip_scale;
 
     // ---- optional inputs of this plan (mi355x_sd_unet_plan_ex) ----
     const bool enc_masked = (e.plan_flags & MI355X_SD_UNET_ENC_MASK) != 0, self_masked = (e.plan_flags & MI355X_SD_UNET_SELF_MASK) != 0;
@@ -1110,6 +1184,16 @@ struct Planner {
         linear(ln, b + ".attn2.q", q2, false);
         const int ko = e.kv_off[b];
         attention(q2, kv_all.cols(ko, ch), kv_all.cols(ko + ch, ch), ao, d.heads, hw, L, false, enc_masked, e.enc_bias);
+        if (ip_on) {   // out += scale * attention over the image tokens (IPAdapterAttnProcessor.__call__, attention_processor.py:1880-1900)
+          const View qv = q2, kv = kvip_all.cols(ko, ch), vv = kvip_all.cols(ko + ch, ch), ov = ao;
+          const int Bc = B, heads = d.heads, dh = ch / d.heads, Tc = T;
+          const float sc_ = (float)pow((double)dh, -0.5);
+          emit([=](void* st) {
+            return mi355x_sd_sdpa_accum(ex->at(qv.p), ex->at(kv.p), ex->at(vv.p), nullptr, ex->at(ov.p), Bc, heads, hw, Tc, dh, (int64_t)hw * qv.ld,
+                                        qv.ld, (int64_t)Tc * kv.ld, kv.ld, (int64_t)Tc * vv.ld, vv.ld, (int64_t)hw * ov.ld, ov.ld, 0, 0, 0, sc_,
+                                        ip_scale, st);
+          });
+        }
         linear(ao, b + ".attn2.out", hid, true, &hid);
         lnorm(hid, b + ".norm3", ln);
         linear(ln, b + ".ff1", ff, true, nullptr, MI355X_SD_GEGLU);
@@ -1309,6 +1393,27 @@ int mi355x_sd_unet_set_option(void* handle, const char* key, int value) {
   }
   sd::set_last_error("mi355x_sd_unet_set_option: unknown option");
   return MI355X_SD_ERR_INVALID;
+}
+
+int mi355x_sd_unet_set_ip_adapter_scale(void* handle, float scale) {
+  Exec* e = H_(handle);
+  if (!handle || !e->cfg.ip) {
+    sd::set_last_error("mi355x_sd_unet_set_ip_adapter_scale: this UNet has no IP-Adapter (config encoder_hid_dim_type != 'ip_image_proj')");
+    return MI355X_SD_ERR_INVALID;
+  }
+  if (!(scale == scale) || scale - scale != 0.0f) {
+    sd::set_last_error("mi355x_sd_unet_set_ip_adapter_scale: scale must be finite");
+    return MI355X_SD_ERR_INVALID;
+  }
+  if (scale != e->ip_scale && e->planned) {   // the scale is a constant of the planned launches: the plan (and its graph) go
+    if (e->graph) {
+      (void)hipGraphExecDestroy(e->graph);
+      e->graph = nullptr;
+    }
+    e->drop_plan();
+  }
+  e->ip_scale = scale;
+  return MI355X_SD_OK;
 }
 
 int mi355x_sd_unet_num_params(void* handle) { return handle ? (int)H_(handle)->order.size() : -1; }
@@ -1561,7 +1666,15 @@ int mi355x_sd_unet_set_input(void* handle, const char* name, const void* device_
     e->tcond_ptr = static_cast<const float*>(device_ptr);
     return MI355X_SD_OK;
   }
-  sd::set_last_error(("mi355x_sd_unet_set_input: unknown input '" + n + "' (class_labels, timestep_cond)").c_str());
+  if (n == "image_embeds") {
+    if (!e->cfg.ip && device_ptr) {
+      sd::set_last_error("mi355x_sd_unet_set_input: this model has no IP-Adapter (config encoder_hid_dim_type != 'ip_image_proj')");
+      return MI355X_SD_ERR_INVALID;
+    }
+    e->image_ptr = static_cast<const float*>(device_ptr);
+    return MI355X_SD_OK;
+  }
+  sd::set_last_error(("mi355x_sd_unet_set_input: unknown input '" + n + "' (class_labels, timestep_cond, image_embeds)").c_str());
   return MI355X_SD_ERR_INVALID;
 }
 
@@ -1588,6 +1701,11 @@ int mi355x_sd_unet_forward_ex(void* handle, void* stream, const float* sample, c
   if (e->cfg.text_time && (!text_embeds || !time_ids)) {
     // the reference raises ValueError here (unet_2d_condition.py:993-1001)
     sd::set_last_error("mi355x_sd_unet_forward: addition_embed_type 'text_time' requires text_embeds and time_ids");
+    return MI355X_SD_ERR_INVALID;
+  }
+  if (e->cfg.ip && !e->image_ptr) {
+    // unet_2d_condition.py:1055-1058
+    sd::set_last_error("mi355x_sd_unet_forward: encoder_hid_dim_type 'ip_image_proj' requires image_embeds (mi355x_sd_unet_set_input)");
     return MI355X_SD_ERR_INVALID;
   }
   if (e->cfg.class_kind != Cfg::CLASS_NONE && !e->class_ptr) {
@@ -1652,6 +1770,10 @@ int mi355x_sd_unet_forward_ex(void* handle, void* stream, const float* sample, c
   }
   int rc = mi355x_sd_cast_rows(encoder_hidden_states, c.cross_dim, e->at(e->in_enc), c.cross_dim, (int64_t)B * L, c.cross_dim, stream);
   if (rc) return rc;
+  if (c.ip) {
+    rc = mi355x_sd_cast_rows(e->image_ptr, c.ehd, e->at(e->in_image), c.ehd, B, c.ehd, stream);
+    if (rc) return rc;
+  }
   if (c.tcp) {
     if (e->tcond_ptr) {
       rc = mi355x_sd_cast_rows(e->tcond_ptr, c.tcp, e->at(e->in_tcond), c.tcp, B, c.tcp, stream);

@@ -1030,6 +1030,11 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
                 cl = cl.expand(plan.B) if cl.numel() == 1 else cl
             if tuple(cl.shape) != tuple(plan.class_in.shape):
                 raise ValueError(f"class_labels of shape {tuple(class_labels.shape)}, expected {tuple(plan.class_in.shape)}")
+            if self._class_kind == "embedding" and not cl.is_cuda and cl.numel() and not (
+                    0 <= int(cl.min()) and int(cl.max()) < cfg["num_class_embeds"]):
+                # nn.Embedding's range check, where it costs nothing (host labels; a device tensor is not read back: the gather
+                # kernel trusts its indices, like the reference's GPU kernel)
+                raise IndexError(f"class_labels must lie in [0, {cfg['num_class_embeds']}), got {cl.tolist()}")
             plan.class_in.copy_(cl.to(plan.class_in.dtype), non_blocking=True)
         if getattr(plan, "ctrl_down", None) is not None:
             if len(down_block_additional_residuals) != len(plan.ctrl_down):

@@ -22,6 +22,13 @@ CLASS_CONFIGS = {
     "class-identity": dict(TINY, class_embed_type="identity"),
     "class-projection": dict(TINY, class_embed_type="projection", projection_class_embeddings_input_dim=24, time_cond_proj_dim=8),
     "class-simple": dict(TINY, class_embed_type="simple_projection", projection_class_embeddings_input_dim=24),
+    # class_embeddings_concat: the blocks see [emb | class_emb] (blocks_time_embed_dim = 2 x time_embed_dim)
+    "class-table-concat": dict(TINY, num_class_embeds=6, class_embeddings_concat=True),
+    "class-identity-concat": dict(TINY, class_embed_type="identity", class_embeddings_concat=True),
+    "class-timestep-concat": dict(TINY, class_embed_type="timestep", class_embeddings_concat=True, time_cond_proj_dim=16),
+    # IP-Adapter: ImageProjection + to_k_ip / to_v_ip on every cross-attention (unet_2d_condition.py:1054-1061)
+    "ip-adapter": dict(TINY, encoder_hid_dim_type="ip_image_proj", encoder_hid_dim=96),
+    "ip-adapter-xl": dict(MINI_XL, encoder_hid_dim_type="ip_image_proj", encoder_hid_dim=64, ip_adapter_num_tokens=16),
 }
 
 
@@ -131,9 +138,11 @@ def test_config_values_are_validated_at_create():
 
 def test_refusals_are_loud():
     lib = _lib.load()
-    for bad in (dict(TINY, class_embed_type="timestep", class_embeddings_concat=True), dict(TINY, time_cond_proj_dim=12), dict(TINY, attention_type="gated"),
+    for bad in (dict(TINY, class_embeddings_concat=True), dict(MINI_XL, class_embed_type="timestep", class_embeddings_concat=True),
+                dict(TINY, time_cond_proj_dim=12), dict(TINY, attention_type="gated"),
                 dict(TINY, class_embed_type="projection"), dict(TINY, class_embed_type="no-such-type"),
-                dict(TINY, down_block_types=("DownBlock2D", "AttnDownBlock2D")), dict(TINY, encoder_hid_dim_type="ip_image_proj", encoder_hid_dim=8)):
+                dict(TINY, down_block_types=("DownBlock2D", "AttnDownBlock2D")), dict(TINY, encoder_hid_dim_type="text_proj", encoder_hid_dim=8),
+                dict(TINY, encoder_hid_dim_type="ip_image_proj"), dict(TINY, encoder_hid_dim=8)):
         with pytest.raises(_lib.MI355XError):
             UNetHandle(bad)
     for bad in (b"{not json", b"", b"[]", b'{"block_out_channels": "x"}', b'{"a": {"b": [1,2,',
@@ -145,7 +154,9 @@ def test_refusals_are_loud():
     dummy = ctypes.c_void_p(64)
     assert lib.mi355x_sd_unet_set_input(hd.h, b"class_labels", dummy) != 0 and b"no class embedding" in lib.mi355x_sd_last_error()
     assert lib.mi355x_sd_unet_set_input(hd.h, b"timestep_cond", dummy) != 0 and b"time_cond_proj_dim" in lib.mi355x_sd_last_error()
-    assert lib.mi355x_sd_unet_set_input(hd.h, b"image_embeds", dummy) != 0 and b"unknown input" in lib.mi355x_sd_last_error()
+    assert lib.mi355x_sd_unet_set_input(hd.h, b"image_embeds", dummy) != 0 and b"no IP-Adapter" in lib.mi355x_sd_last_error()
+    assert lib.mi355x_sd_unet_set_input(hd.h, b"no_such_input", dummy) != 0 and b"unknown input" in lib.mi355x_sd_last_error()
+    assert lib.mi355x_sd_unet_set_ip_adapter_scale(hd.h, 0.5) != 0 and b"no IP-Adapter" in lib.mi355x_sd_last_error()
     assert lib.mi355x_sd_unet_set_input(hd.h, b"class_labels", None) == 0
     hc = UNetHandle(CLASS_CONFIGS["class-table"])
     assert lib.mi355x_sd_unet_set_input(hc.h, b"class_labels", dummy) == 0 and lib.mi355x_sd_unet_set_input(hc.h, b"class_labels", None) == 0
@@ -186,3 +197,26 @@ def test_plan_ex_flags_and_skip_shapes():
         hd.plan(2, 16, 16, 7, _lib.UNET_SELF_MASK)
     assert hd.num_launches() == 0 and lib.mi355x_sd_unet_num_skips(hd.h) == -1             # a failed plan leaves no plan behind
     assert hd.plan(2, 16, 16, 7) == base_ws and hd.num_launches() == base
+
+
+def test_ip_adapter_scale_is_a_constant_of_the_plan():
+    """mi355x_sd_unet_set_ip_adapter_scale: 0 drops the image-token attention launches (one per cross-attention, like the Python
+    planner), a new value discards the plan, a non-finite one is refused"""
+    cfg = CLASS_CONFIGS["ip-adapter"]
+    P = synth_unet_params(cfg, seed=5)
+    lib = _lib.load()
+    hd = UNetHandle(cfg)
+    hd.load(P)
+    image = hd.pack()
+    hd.attach(image)
+    hd.plan(2, 16, 16, 7)
+    n1 = hd.num_launches()
+    model = on_emulator(UNet2DConditionModel, cfg, P)
+    assert n1 == len(model._get_plan(2, 16, 16, 7).prog)
+    assert lib.mi355x_sd_unet_set_ip_adapter_scale(hd.h, 1.0) == 0 and hd.num_launches() == n1      # unchanged value: plan kept
+    assert lib.mi355x_sd_unet_set_ip_adapter_scale(hd.h, 0.0) == 0 and hd.num_launches() == 0       # plan discarded
+    hd.plan(2, 16, 16, 7)
+    model.set_ip_adapter_scale(0.0)
+    n0 = hd.num_launches()
+    assert n0 == len(model._get_plan(2, 16, 16, 7).prog) and n0 < n1
+    assert lib.mi355x_sd_unet_set_ip_adapter_scale(hd.h, float("nan")) != 0 and b"finite" in lib.mi355x_sd_last_error()

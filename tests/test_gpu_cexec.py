@@ -59,6 +59,8 @@ def test_handle_class_labels_and_timestep_cond_equal_python_planned_model():
     from tests.test_cexec_host_logic import CLASS_CONFIGS
     g = torch.Generator().manual_seed(11)
     for name, cfg in CLASS_CONFIGS.items():
+        if cfg.get("encoder_hid_dim_type"):
+            continue   # (the IP-Adapter configurations: test_handle_ip_adapter_equals_python_planned_model)
         B, H, W, L = 2, 16, 16, (77 if cfg.get("addition_embed_type") else 7)
         P = synth_unet_params(cfg, seed=1234)
         sample, enc, added = _inputs(cfg, B, H, W, L)
@@ -67,7 +69,7 @@ def test_handle_class_labels_and_timestep_cond_equal_python_planned_model():
         for rep in range(2):   # two different sets of values
             kw = {}
             if cfg.get("num_class_embeds"):
-                kw["class_labels"] = torch.tensor([3, 7] if rep == 0 else [9, 0])
+                kw["class_labels"] = torch.tensor([3, 7] if rep == 0 else [9, 0]) % cfg["num_class_embeds"]
             elif ct == "timestep":
                 kw["class_labels"] = torch.tensor([12.0, 700.0]) * (rep + 1)
             elif ct == "identity":
@@ -107,6 +109,47 @@ def test_handle_class_labels_and_timestep_cond_equal_python_planned_model():
     sample, enc, _ = _inputs(TINY, 2, 16, 16, 7)
     with pytest.raises(ValueError, match="time_cond_proj_dim"):
         m(_cuda(sample), 501, _cuda(enc), timestep_cond=torch.zeros(2, 16).cuda())
+
+
+def test_handle_ip_adapter_equals_python_planned_model():
+    """IP-Adapter behind the C handle (round 6; unet_2d_condition.py:1054-1061, attention_processor.py:1816-1900): image_embeds bound
+    by mi355x_sd_unet_set_input, the scale by mi355x_sd_unet_set_ip_adapter_scale -- bit-identical to the Python-planned model at
+    scales 1, 0.5 and 0 (0 = no image-token launches), eager and as a graph; a missing image_embeds is the reference's ValueError"""
+    from paddlemix_amd import _lib
+    from paddlemix_amd.cexec import CUNet2DConditionModel
+    from paddlemix_amd.unet import UNet2DConditionModel, synth_unet_params
+    from tests.test_cexec_host_logic import CLASS_CONFIGS
+    for name in ("ip-adapter", "ip-adapter-xl"):
+        cfg = CLASS_CONFIGS[name]
+        B, H, W, L = 2, 16, 16, (77 if cfg.get("addition_embed_type") else 7)
+        P = synth_unet_params(cfg, seed=1234)
+        sample, enc, added = _inputs(cfg, B, H, W, L)
+        img = torch.randn(B, cfg["encoder_hid_dim"], generator=torch.Generator().manual_seed(9))
+        ckw = _cuda(dict(added or {}, image_embeds=img))
+        ref = UNet2DConditionModel(cfg, P, use_graph=False)
+        wants = {}
+        for sc in (1.0, 0.5, 0.0):
+            ref.set_ip_adapter_scale(sc)
+            wants[sc] = ref(_cuda(sample), 400, _cuda(enc), added_cond_kwargs=ckw).sample.clone()
+        assert not torch.equal(wants[1.0], wants[0.0]) and not torch.equal(wants[1.0], wants[0.5])
+        for graph in (False, True):
+            m = CUNet2DConditionModel(cfg, P, use_graph=graph)
+            for sc in (1.0, 0.5, 0.0, 1.0):
+                m.set_ip_adapter_scale(sc)
+                got = m(_cuda(sample), 400, _cuda(enc), added_cond_kwargs=ckw).sample
+                assert torch.equal(got, wants[sc]), (name, graph, sc, (got - wants[sc]).abs().max())
+        with pytest.raises(ValueError, match="image_embeds"):
+            m(_cuda(sample), 400, _cuda(enc), added_cond_kwargs={k: v for k, v in ckw.items() if k != "image_embeds"} or None)
+        lib = _lib.load()   # the C entry point with nothing bound
+        assert lib.mi355x_sd_unet_set_input(m.hd.h, b"image_embeds", None) == 0
+        s32, e32, t32 = sample.cuda().float().contiguous(), enc.cuda().float().contiguous(), torch.tensor([400.0], device="cuda")
+        o = torch.empty(B, 4, H, W, device="cuda")
+        te = ti = None
+        if added:
+            te, ti = added["text_embeds"].cuda().float().contiguous(), added["time_ids"].cuda().float().contiguous()
+        rc = lib.mi355x_sd_unet_forward(m.hd.h, None, s32.data_ptr(), t32.data_ptr(), e32.data_ptr(), te.data_ptr() if added else None,
+                                        ti.data_ptr() if added else None, None, o.data_ptr(), 0)
+        assert rc != 0 and b"requires image_embeds" in lib.mi355x_sd_last_error()
 
 
 @pytest.mark.parametrize("rd", [None, "fp32"])

@@ -135,6 +135,9 @@ def test_class_embeddings_match_oracle(kind, concat):
     assert not torch.equal(model(sample, 333, enc, class_labels=other).sample, out)
     with pytest.raises(ValueError, match="class_labels should be provided"):
         model(sample, 333, enc)
+    if "num_class_embeds" in extra:   # nn.Embedding's range check on host labels (the gather kernel trusts device indices)
+        with pytest.raises(IndexError, match="class_labels must lie in"):
+            model(sample, 333, enc, class_labels=torch.tensor([0, cfg["num_class_embeds"]]))
 
 
 def test_timestep_cond_matches_oracle():
