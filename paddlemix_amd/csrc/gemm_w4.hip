@@ -90,8 +90,19 @@ __device__ __forceinline__ void w4_load_bias(const GemmArgs& p, f32x4 (&bs)[TN],
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) asm volatile("" : "+v"(bs[tn]));
 }
-template <int TM, int TN>
-__device__ __forceinline__ void w4_epilogue(const GemmArgs& p, f32x4 (&acc)[TN][TM], const f32x4 (&bs)[TN], int m_wave, int n_wave, int lane) {
+// WS instantiations (a just-in-time widened e4m3 matrix: weight-only fp8, BASELINE config 5): the per-output-channel weight scale,
+// fetched like the bias; v = acc * scale + bias, the order of gemm_epilogue.h epi4
+template <int TN>
+__device__ __forceinline__ void w4_load_wscale(const GemmArgs& p, f32x4 (&ws)[TN], int n_wave, int lane) {
+  const int lq = lane >> 4;
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) ws[tn] = *reinterpret_cast<const f32x4*>(p.wscale + min(n_wave + acc_col<TN>(tn, lq, false), p.N - 4));
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) asm volatile("" : "+v"(ws[tn]));
+}
+template <int TM, int TN, bool WS>
+__device__ __forceinline__ void w4_epilogue(const GemmArgs& p, f32x4 (&acc)[TN][TM], const f32x4 (&bs)[TN], const f32x4 (&ws)[WS ? TN : 1],
+                                            int m_wave, int n_wave, int lane) {
   const int lq = lane >> 4;
   bf16* C = reinterpret_cast<bf16*>(p.C);
 #pragma unroll
@@ -114,7 +125,12 @@ __device__ __forceinline__ void w4_epilogue(const GemmArgs& p, f32x4 (&acc)[TN][
       for (int h = 0; h < TN / 2; ++h) {
         const int n = n_wave + h * 32 + lq * 8;
         if (n >= p.N) continue;   // (N % 8 == 0: a lane's 8 channels are inside or outside together)
-        const f32x4 lo = act4(p, (acc[2 * h][tm] + bs[2 * h]) * p.out_scale), hi = act4(p, (acc[2 * h + 1][tm] + bs[2 * h + 1]) * p.out_scale);
+        f32x4 a0 = acc[2 * h][tm], a1 = acc[2 * h + 1][tm];
+        if constexpr (WS) {
+          a0 *= ws[2 * h];
+          a1 *= ws[2 * h + 1];
+        }
+        const f32x4 lo = act4(p, (a0 + bs[2 * h]) * p.out_scale), hi = act4(p, (a1 + bs[2 * h + 1]) * p.out_scale);
         const u32x4 pk = {pack_bf16(lo[0], lo[1]), pack_bf16(lo[2], lo[3]), pack_bf16(hi[0], hi[1]), pack_bf16(hi[2], hi[3])};
         *reinterpret_cast<u32x4*>(C + crow + n) = pk;
       }
@@ -129,9 +145,9 @@ __device__ __forceinline__ void w4_epilogue(const GemmArgs& p, f32x4 (&acc)[TN][
 // The batch of a tile is ONE number (the launcher admits remaps and gates only when their rows-per-batch is a multiple of the 256-row
 // tile): no per-row division. The residual rows of the NEXT row-tile are requested before the current one is finished (two row-tiles of
 // 16-byte loads in flight); the gate vectors sit in registers next to the bias.
-template <int TM, int TN>
-__device__ __forceinline__ void w4_epilogue_ex(const GemmArgs& p, f32x4 (&acc)[TN][TM], const f32x4 (&bs)[TN], int m_tile, int m_wave, int n_wave,
-                                               int lane) {
+template <int TM, int TN, bool WS>
+__device__ __forceinline__ void w4_epilogue_ex(const GemmArgs& p, f32x4 (&acc)[TN][TM], const f32x4 (&bs)[TN], const f32x4 (&ws)[WS ? TN : 1],
+                                               int m_tile, int m_wave, int n_wave, int lane) {
   const int lq = lane >> 4;
   bf16* C = reinterpret_cast<bf16*>(p.C);
   f32x4 gs[TN];
@@ -174,7 +190,12 @@ __device__ __forceinline__ void w4_epilogue_ex(const GemmArgs& p, f32x4 (&acc)[T
       for (int h = 0; h < TN / 2; ++h) {
         const int n = n_wave + h * 32 + lq * 8;
         if (n >= p.N) continue;
-        f32x4 lo = (acc[2 * h][tm] + bs[2 * h]) * gs[2 * h], hi = (acc[2 * h + 1][tm] + bs[2 * h + 1]) * gs[2 * h + 1];
+        f32x4 a0 = acc[2 * h][tm], a1 = acc[2 * h + 1][tm];
+        if constexpr (WS) {   // (the order of gemm_epilogue.h epi4: scale, bias, gate -- bit-identical to the other kernels)
+          a0 *= ws[2 * h];
+          a1 *= ws[2 * h + 1];
+        }
+        f32x4 lo = (a0 + bs[2 * h]) * gs[2 * h], hi = (a1 + bs[2 * h + 1]) * gs[2 * h + 1];
         if (has_r) {
           lo = add_r16(lo, u32x2{r_cur[h][0], r_cur[h][1]});
           hi = add_r16(hi, u32x2{r_cur[h][2], r_cur[h][3]});
@@ -194,7 +215,7 @@ __device__ __forceinline__ void w4_epilogue_ex(const GemmArgs& p, f32x4 (&acc)[T
 #ifndef W4_CARRY_DEFAULT
 #define W4_CARRY_DEFAULT true
 #endif
-template <int BS, int DSP, int ABL = 0, bool CARRY = W4_CARRY_DEFAULT, bool EX = false>
+template <int BS, int DSP, int ABL = 0, bool CARRY = W4_CARRY_DEFAULT, bool EX = false, bool WS = false>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
   using namespace w4;
   constexpr int BM = 256, BN = 256, TM = 8, TN = 8, NW = 4, AP = 8, WP = 8;
@@ -341,8 +362,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
     const bool has_next = vb_next < nvb;
     const int lane_e = lane_id();
     const int m_w = em0 + wm * (TM * 16), n_w = en0 + wn * (TN * 16);
-    f32x4 bs[TN];
+    f32x4 bs[TN], wsv[WS ? TN : 1];
     if constexpr (!(ABL & 8)) w4_load_bias<TN>(p, bs, n_w, lane_e);
+    if constexpr (WS) w4_load_wscale<TN>(p, wsv, n_w, lane_e);
     __builtin_amdgcn_sched_barrier(0);
     // (EX launches with a residual: its loads are ordinary loads, and the compiler's waits for them would sit behind the carried DMA
     // in the in-order counter -- there the next prologue goes out after the epilogue)
@@ -358,9 +380,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < TM; ++j) asm volatile("" ::"a"(acc[i][j]));
     } else if constexpr (EX) {
-      w4_epilogue_ex<TM, TN>(p, acc, bs, em0, m_w, n_w, lane_e);
+      w4_epilogue_ex<TM, TN, WS>(p, acc, bs, wsv, em0, m_w, n_w, lane_e);
     } else {
-      w4_epilogue<TM, TN>(p, acc, bs, m_w, n_w, lane_e);
+      w4_epilogue<TM, TN, WS>(p, acc, bs, wsv, m_w, n_w, lane_e);
     }
     if (!has_next) break;
     vb = vb_next;
@@ -372,12 +394,14 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
   }
 }
 
-// shapes the four-wave tile takes: 16-bit operands, K % 64 == 0, no split-K / LN fold / conv / fp8 scale, and an epilogue without
-// per-row operands (residual, gate, row bias: the general epilogue of 8-sub-tile waves fetches those one group at a time)
+// shapes the four-wave tile takes: 16-bit operands (a just-in-time widened e4m3 matrix with its per-channel scale is one: WS
+// instantiations), K % 64 == 0, no split-K / LN fold / conv / e4m3 bytes read by the kernel, and an epilogue without per-row operands
+// (row bias: the general epilogue of 8-sub-tile waves fetches those one group at a time)
 // EX launches (own kernel instantiation): gate / 16-bit residual / row remaps whose rows-per-batch is a multiple of the tile height
 static bool w4_needs_ex(const GemmArgs& a) { return a.R || a.gate || a.a_rpb || a.c_rpb; }
 bool gemm_w4_applies(const GemmArgs& a) {
-  if (a.conv || a.rowstat || a.wscale || a.rowbias || a.out_f32 || a.splitk > 1 || !a.c_wide) return false;
+  if (a.conv || a.rowstat || a.rowbias || a.out_f32 || a.splitk > 1 || !a.c_wide) return false;
+  if (a.wscale && (!a.w16 || a.geglu || (a.N & 3))) return false;   // (the scale of a WIDENED matrix, in the epilogue; no GEGLU form of it)
   if (w4_needs_ex(a)) {
     // (a tile must lie inside one batch: the per-row division by a run-time rows-per-batch, hoisted out of the tile loop as VGPR
     // constants, did not survive the K loop's 256 + 256 registers -- spilled, and reloaded between the epilogue's stores)
@@ -404,10 +428,11 @@ int launch_gemm_w4(const GemmArgs& a_in, hipStream_t stream) {
     const char* e = sd_switch("MI355X_SD_W4_SCHED");
     return e ? atoi(e) : 0;
   }();
-  const bool ex = w4_needs_ex(a);
-  K kern = ex ? (K)gemm_w4_kernel<18, 2, 0, W4_CARRY_DEFAULT, true> : (K)gemm_w4_kernel<18, 2>;
+  const bool ex = w4_needs_ex(a), wsc = a.wscale != nullptr;
+  K kern = ex ? (wsc ? (K)gemm_w4_kernel<18, 2, 0, W4_CARRY_DEFAULT, true, true> : (K)gemm_w4_kernel<18, 2, 0, W4_CARRY_DEFAULT, true>)
+              : (wsc ? (K)gemm_w4_kernel<18, 2, 0, W4_CARRY_DEFAULT, false, true> : (K)gemm_w4_kernel<18, 2>);
 #ifdef MI355X_SD_DEBUG_SWITCHES
-  if (!ex) {
+  if (!ex && !wsc) {
   if (sched == 1) kern = (K)gemm_w4_kernel<18, 2, 0, false>;   // the next tile's prologue behind the stores (A/B of the carried form)
   if (sched == 10) kern = (K)gemm_w4_kernel<18, 2, 1>;    // timing ablations (wrong results)
   if (sched == 11) kern = (K)gemm_w4_kernel<18, 2, 2>;
@@ -419,8 +444,8 @@ int launch_gemm_w4(const GemmArgs& a_in, hipStream_t stream) {
   if (sched == 17) kern = (K)gemm_w4_kernel<18, 2, 5>;
   }
 #endif
-  static bool attr_done[40] = {};
-  const int si = ((sched >= 0 && sched < 20) ? sched : 0) + (ex ? 20 : 0);
+  static bool attr_done[80] = {};
+  const int si = ((sched >= 0 && sched < 20) ? sched : 0) + (ex ? 20 : 0) + (wsc ? 40 : 0);
   if (!attr_done[si]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
       return SD_ERR_HIP;
