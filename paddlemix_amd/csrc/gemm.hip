@@ -312,6 +312,11 @@ static int pick_tile(const GemmArgs& a) {
   // 210 vs 228, 32768 x 1920 x 640 101 vs 120. MI355X_SD_GEMM_TILE_MAP="258:160" (debug build) maps it away again.
   static const bool w4_off = sd_switch("MI355X_SD_NO_W4") != nullptr;
   if (!w4_off && a.M >= 2048 && a.N >= 1536 && gemm_w4_applies(a) && (long)((a.M + 255) / 256) * ((a.N + 255) / 256) >= 192) chosen = 258;
+  // The four-wave tile at 256 x 160 (id 259: a wave owns 128 x 80) on the launches the model gives the eight-wave 256 x 160 tile
+  // (N = 640 / 1280: to_q / to_out / FF2 with their residuals) was built and LOST in the step: 57.10 / 56.71 / 56.96 vs 56.40 / 55.91 /
+  // 56.15 ms, three interleaved rounds (profiles/r06_s24_step_ab.txt) -- one tile per CU there: prologue and epilogue dominate, and two
+  // waves per SIMD overlap them where one cannot. It stays selectable (MI355X_SD_GEMM_TILE=259 or MI355X_SD_GEMM_TILE_MAP="160:259",
+  // debug build) and bit-identical to the generic loop (tests/test_gpu_gemm_variants.py).
   // The small launches of a batch-1 step (<= 128 tiles of 128 x 128, K <= 2560: what used to take split-K slices + a reduce kernel)
   // take the 64 x 64 tile with the six-stage ring (gemm_small.hip, id 64). MI355X_SD_NO_SMALL (debug build): the round-5 path.
   static const bool small_off = sd_switch("MI355X_SD_NO_SMALL") != nullptr;
@@ -453,8 +458,8 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
     if (rc != SD_ERR_UNSUPPORTED) return rc;
     tile = 128;
   }
-  if (tile == 258) {   // four-wave 256 x 256 tile (gemm_w4.hip) where it applies, else the model's choice among the others
-    const int rc = launch_gemm_w4(a, stream);
+  if (tile == 258 || tile == 259) {   // four-wave 256 x 256 / 256 x 160 tile (gemm_w4.hip) where it applies, else the model's choice among the others
+    const int rc = launch_gemm_w4(a, stream, tile == 258 ? 256 : 160);
     if (rc != SD_ERR_UNSUPPORTED) return rc;
     tile = pick_tile_model(a);
   }

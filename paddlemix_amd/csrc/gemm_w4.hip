@@ -110,7 +110,7 @@ __device__ __forceinline__ void w4_epilogue(const GemmArgs& p, f32x4 (&acc)[TN][
     const int m = m_wave + tm * 16 + (lane & 15);
     if (m >= p.M) continue;
     const size_t crow = (size_t)m * p.ldc;
-    if (p.geglu) {
+    if (TN % 4 == 0 && p.geglu) {   // (the launcher admits GEGLU on the 256-wide tile only)
 #pragma unroll
       for (int hp = 0; hp < TN / 4; ++hp) {   // (gemm_epilogue.h store_row: two output pairs = 8 consecutive output channels)
         const int n_phys = n_wave + acc_col<TN>(4 * hp, lq, true);
@@ -133,6 +133,15 @@ __device__ __forceinline__ void w4_epilogue(const GemmArgs& p, f32x4 (&acc)[TN][
         const f32x4 lo = act4(p, (a0 + bs[2 * h]) * p.out_scale), hi = act4(p, (a1 + bs[2 * h + 1]) * p.out_scale);
         const u32x4 pk = {pack_bf16(lo[0], lo[1]), pack_bf16(lo[2], lo[3]), pack_bf16(hi[0], hi[1]), pack_bf16(hi[2], hi[3])};
         *reinterpret_cast<u32x4*>(C + crow + n) = pk;
+      }
+      if constexpr ((TN & 1) != 0) {   // (the 160-wide tile: the fifth sub-tile has no partner -- 4 channels per lane, one 8-byte store)
+        const int n = n_wave + (TN - 1) * 16 + lq * 4;
+        if (n < p.N) {
+          f32x4 a0 = acc[TN - 1][tm];
+          if constexpr (WS) a0 *= ws[TN - 1];
+          const f32x4 lo = act4(p, (a0 + bs[TN - 1]) * p.out_scale);
+          *reinterpret_cast<u32x2*>(C + crow + n) = u32x2{pack_bf16(lo[0], lo[1]), pack_bf16(lo[2], lo[3])};
+        }
       }
     }
     // one row-tile at a time: left to itself the scheduler reads all 256 accumulator registers up front (256 VGPRs, spills)
@@ -170,18 +179,21 @@ __device__ __forceinline__ void w4_epilogue_ex(const GemmArgs& p, f32x4 (&acc)[T
   }
   const bool has_r = p.R != nullptr;
   u32x4 r_cur[TN / 2], r_nxt[TN / 2];
-  auto load_r = [&](const int tm, u32x4 (&r)[TN / 2]) {
+  u32x2 rl_cur = {0u, 0u}, rl_nxt = {0u, 0u};   // (odd TN: the last sub-tile's 4 channels)
+  auto load_r = [&](const int tm, u32x4 (&r)[TN / 2], u32x2& rl) {
     const int m = min(m_wave + tm * 16 + (lane & 15), p.M - 1);
 #pragma unroll
     for (int h = 0; h < TN / 2; ++h) r[h] = *reinterpret_cast<const u32x4*>(p.R + (size_t)m * p.ldr + min(n_wave + h * 32 + lq * 8, p.N - 8));
+    if constexpr ((TN & 1) != 0) rl = *reinterpret_cast<const u32x2*>(p.R + (size_t)m * p.ldr + min(n_wave + (TN - 1) * 16 + lq * 4, p.N - 4));
   };
-  if (has_r) load_r(0, r_nxt);
+  if (has_r) load_r(0, r_nxt, rl_nxt);
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     if (has_r) {
 #pragma unroll
       for (int h = 0; h < TN / 2; ++h) r_cur[h] = r_nxt[h];
-      if (tm + 1 < TM) load_r(tm + 1, r_nxt);
+      rl_cur = rl_nxt;
+      if (tm + 1 < TM) load_r(tm + 1, r_nxt, rl_nxt);
     }
     const int m = m_wave + tm * 16 + (lane & 15);
     if (m < p.M) {
@@ -205,6 +217,17 @@ __device__ __forceinline__ void w4_epilogue_ex(const GemmArgs& p, f32x4 (&acc)[T
         const u32x4 pk = {pack_bf16(lo[0], lo[1]), pack_bf16(lo[2], lo[3]), pack_bf16(hi[0], hi[1]), pack_bf16(hi[2], hi[3])};
         *reinterpret_cast<u32x4*>(C + crow + n) = pk;
       }
+      if constexpr ((TN & 1) != 0) {
+        const int n = n_wave + (TN - 1) * 16 + lq * 4;
+        if (n < p.N) {
+          f32x4 a0 = acc[TN - 1][tm];
+          if constexpr (WS) a0 *= ws[TN - 1];
+          f32x4 lo = (a0 + bs[TN - 1]) * gs[TN - 1];
+          if (has_r) lo = add_r16(lo, rl_cur);
+          lo = act4(p, lo * p.out_scale);
+          *reinterpret_cast<u32x2*>(C + crow + n) = u32x2{pack_bf16(lo[0], lo[1]), pack_bf16(lo[2], lo[3])};
+        }
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -215,13 +238,16 @@ __device__ __forceinline__ void w4_epilogue_ex(const GemmArgs& p, f32x4 (&acc)[T
 #ifndef W4_CARRY_DEFAULT
 #define W4_CARRY_DEFAULT true
 #endif
-template <int BS, int DSP, int ABL = 0, bool CARRY = W4_CARRY_DEFAULT, bool EX = false, bool WS = false>
+// TNW: 16-column sub-tiles per wave: 8 = the 256 x 256 tile; 5 = 256 x 160 (a wave owns 128 x 80: 40 accumulator tiles, 80 MFMAs, 26 reads
+// and 13 DMA pieces per K-tile) for the N = 640 / 1280 launches whose 256 x 256 tiling would leave a third of the chip idle -- measured
+// 1.4 % SLOWER in the step than the eight-wave tile of that width (gemm.hip pick_tile), not in the picker, selectable in the debug build
+template <int BS, int DSP, int ABL = 0, bool CARRY = W4_CARRY_DEFAULT, bool EX = false, bool WS = false, int TNW = 8>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
   using namespace w4;
-  constexpr int BM = 256, BN = 256, TM = 8, TN = 8, NW = 4, AP = 8, WP = 8;
-  constexpr int STAGE_A = BM * BK * 2, STAGE_W = BN * BK * 2;   // 32 KiB each
-  constexpr int NSTEP = 32;                                      // steps of two MFMAs per k-step
-  static_assert(BS >= 16 && BS + 1 + 15 * DSP < 2 * NSTEP, "the 16 pieces of a K-tile are issued inside the iteration");
+  constexpr int BM = 256, TM = 8, TN = TNW, BN = 2 * TN * 16, NW = 4, AP = 8, WP = BN / 32;
+  constexpr int STAGE_A = BM * BK * 2, STAGE_W = BN * BK * 2;   // 32 KiB, 32 / 20 KiB
+  constexpr int NSTEP = TM * TN / 2;                             // steps of two MFMAs per k-step
+  static_assert(BS >= TM + TN && BS + 1 + (AP + WP - 1) * DSP < 2 * NSTEP, "the pieces of a K-tile are issued inside the iteration");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* As = smem;                 // [2][BM][128 B]
   unsigned char* Ws = smem + 2 * STAGE_A;   // [2][BN][128 B]
@@ -399,8 +425,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
 // (row bias: the general epilogue of 8-sub-tile waves fetches those one group at a time)
 // EX launches (own kernel instantiation): gate / 16-bit residual / row remaps whose rows-per-batch is a multiple of the tile height
 static bool w4_needs_ex(const GemmArgs& a) { return a.R || a.gate || a.a_rpb || a.c_rpb; }
-bool gemm_w4_applies(const GemmArgs& a) {
+bool gemm_w4_applies(const GemmArgs& a, int bn) {
   if (a.conv || a.rowstat || a.rowbias || a.out_f32 || a.splitk > 1 || !a.c_wide) return false;
+  if (bn != 256 && (bn != 160 || a.geglu)) return false;   // (GEGLU pairs sub-tiles: the 160-wide tile has an odd number per wave)
   if (a.wscale && (!a.w16 || a.geglu || (a.N & 3))) return false;   // (the scale of a WIDENED matrix, in the epilogue; no GEGLU form of it)
   if (w4_needs_ex(a)) {
     // (a tile must lie inside one batch: the per-row division by a run-time rows-per-batch, hoisted out of the tile loop as VGPR
@@ -417,11 +444,13 @@ bool gemm_w4_applies(const GemmArgs& a) {
   return a_ext < lim && (size_t)a.N * a.K * 2 < lim;
 }
 
-int launch_gemm_w4(const GemmArgs& a_in, hipStream_t stream) {
-  if (!gemm_w4_applies(a_in)) return SD_ERR_UNSUPPORTED;
+int launch_gemm_w4(const GemmArgs& a_in, hipStream_t stream, int bn) {
+  if (!gemm_w4_applies(a_in, bn)) return SD_ERR_UNSUPPORTED;
   GemmArgs a = a_in;
   a.bias_acc = 0;   // (this kernel adds the bias in its epilogue, from registers: the order of the other kernels' generic form)
-  constexpr int LDS_BYTES = 2 * (256 + 256) * BK * 2;
+  const int LDS_BYTES = 2 * (256 + bn) * BK * 2;
+  const bool n160 = bn == 160;
+  if (n160) a.gm = -8;   // (column groups of 8 for the 160-wide tiles, as launch_gemm does for the eight-wave ones)
   using K = void (*)(const GemmArgs);
   // (BS, DSP) of the shipped schedule; the debug build can pick another instantiation for A/B runs (MI355X_SD_W4_SCHED=0..3)
   static const int sched = [] {
@@ -431,8 +460,11 @@ int launch_gemm_w4(const GemmArgs& a_in, hipStream_t stream) {
   const bool ex = w4_needs_ex(a), wsc = a.wscale != nullptr;
   K kern = ex ? (wsc ? (K)gemm_w4_kernel<18, 2, 0, W4_CARRY_DEFAULT, true, true> : (K)gemm_w4_kernel<18, 2, 0, W4_CARRY_DEFAULT, true>)
               : (wsc ? (K)gemm_w4_kernel<18, 2, 0, W4_CARRY_DEFAULT, false, true> : (K)gemm_w4_kernel<18, 2>);
+  if (n160)   // (barrier at step 13 = behind the 13 reads of set 1; a piece every 2 steps: 13 pieces inside the 40 steps)
+    kern = ex ? (wsc ? (K)gemm_w4_kernel<13, 2, 0, W4_CARRY_DEFAULT, true, true, 5> : (K)gemm_w4_kernel<13, 2, 0, W4_CARRY_DEFAULT, true, false, 5>)
+              : (wsc ? (K)gemm_w4_kernel<13, 2, 0, W4_CARRY_DEFAULT, false, true, 5> : (K)gemm_w4_kernel<13, 2, 0, W4_CARRY_DEFAULT, false, false, 5>);
 #ifdef MI355X_SD_DEBUG_SWITCHES
-  if (!ex && !wsc) {
+  if (!ex && !wsc && !n160) {
   if (sched == 1) kern = (K)gemm_w4_kernel<18, 2, 0, false>;   // the next tile's prologue behind the stores (A/B of the carried form)
   if (sched == 10) kern = (K)gemm_w4_kernel<18, 2, 1>;    // timing ablations (wrong results)
   if (sched == 11) kern = (K)gemm_w4_kernel<18, 2, 2>;
@@ -444,8 +476,8 @@ int launch_gemm_w4(const GemmArgs& a_in, hipStream_t stream) {
   if (sched == 17) kern = (K)gemm_w4_kernel<18, 2, 5>;
   }
 #endif
-  static bool attr_done[80] = {};
-  const int si = ((sched >= 0 && sched < 20) ? sched : 0) + (ex ? 20 : 0) + (wsc ? 40 : 0);
+  static bool attr_done[160] = {};
+  const int si = ((sched >= 0 && sched < 20) ? sched : 0) + (ex ? 20 : 0) + (wsc ? 40 : 0) + (n160 ? 80 : 0);
   if (!attr_done[si]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
       return SD_ERR_HIP;
@@ -456,7 +488,7 @@ int launch_gemm_w4(const GemmArgs& a_in, hipStream_t stream) {
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
     return n;
   }();
-  const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+  const int tiles = ((a.M + 255) / 256) * ((a.N + bn - 1) / bn);
   hipLaunchKernelGGL(kern, dim3(tiles < cus ? tiles : cus), dim3(256), LDS_BYTES, stream, a);
   return hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP;
 }

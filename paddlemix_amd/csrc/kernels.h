@@ -72,8 +72,8 @@ int gemm_gm();   // tile rasterisation group of the GEMM kernels (-4 = column gr
 int launch_gemm256(const GemmArgs& a, hipStream_t stream);
 bool gemm_small_applies(const GemmArgs& a);                  // 64 x 64 tile, six-stage ring (gemm_small.hip)
 int launch_gemm_small(const GemmArgs& a, hipStream_t stream);
-bool gemm_w4_applies(const GemmArgs& a);                     // four-wave 256 x 256 tile (gemm_w4.hip)
-int launch_gemm_w4(const GemmArgs& a, hipStream_t stream);   // SD_ERR_UNSUPPORTED: caller falls back
+bool gemm_w4_applies(const GemmArgs& a, int bn = 256);       // four-wave 256 x 256 / 256 x 160 tile (gemm_w4.hip)
+int launch_gemm_w4(const GemmArgs& a, hipStream_t stream, int bn = 256);   // SD_ERR_UNSUPPORTED: caller falls back
 int launch_gemm_f8(const GemmArgs& a, hipStream_t stream);   // W8A8 (gemm256.hip); validates
 void launch_splitk_reduce(const GemmArgs& a, hipStream_t stream);   // sums a.splitk slices of a.ws + epilogue (gemm.hip)   // phased 256x256 kernel (gemm256.hip); args pre-validated
 

@@ -78,8 +78,9 @@ def test_four_wave_tiles(tile_map):
 
 
 @pytest.mark.parametrize("tile_env", [{}, {"MI355X_SD_GEMM_TILE": "320"}, {"MI355X_SD_GEMM_TILE": "128"}, {"MI355X_SD_GEMM_TILE": "129"},
-                                      {"MI355X_SD_GEMM_TILE": "160"}, {"MI355X_SD_GEMM_TILE": "256"}, {"MI355X_SD_GEMM_TILE": "258"}],
-                         ids=["picker", "256x320", "128x128", "128x160", "256x160", "256x256-pipelined", "256x256-four-waves"])
+                                      {"MI355X_SD_GEMM_TILE": "160"}, {"MI355X_SD_GEMM_TILE": "256"}, {"MI355X_SD_GEMM_TILE": "258"},
+                                      {"MI355X_SD_GEMM_TILE": "259"}],
+                         ids=["picker", "256x320", "128x128", "128x160", "256x160", "256x256-pipelined", "256x256-four-waves", "256x160-four-waves"])
 def test_pipelined_loops_are_bit_identical_to_the_generic_loop(tile_env):
     """The interleaved register-pipelined loop (round 4: one LDS-DMA piece / one fragment read between MFMA pairs, the A and W
     pieces of a tile issued in different half-iterations, unrolled tail or -- early-residual kernels -- a tail loop, static vmcnt)
