@@ -308,6 +308,13 @@ int launch_gemm_f8(const GemmArgs& a_in, hipStream_t stream) {
   const size_t a_ext = a.a_rpb ? (size_t)((a.M - 1) / a.a_rpb) * a.a_bstride + (size_t)(a.a_rpb - 1) * a.lda + a.K
                                : (size_t)(a.M - 1) * a.lda + a.K;
   if (a_ext >= 0xFFFF0000ull || (size_t)a.N * a.K >= 0xFFFF0000ull) return SD_ERR_UNSUPPORTED;
+  // the wide launches (at least three quarters of a chip of 256 x 256 tiles) take the four-wave tile (gemm_w4f8.hip);
+  // MI355X_SD_NO_W4 (debug build): the phased kernel below
+  static const bool w4_off = sd_switch("MI355X_SD_NO_W4") != nullptr;
+  if (!w4_off && a.M >= 2048 && a.N >= 1536 && (long)((a.M + 255) / 256) * ((a.N + 255) / 256) >= 192) {
+    const int rc = launch_gemm_w4f8(a, stream);
+    if (rc != SD_ERR_UNSUPPORTED) return rc;
+  }
   return launch_gemm256(a, stream);
 }
 

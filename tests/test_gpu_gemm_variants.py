@@ -15,6 +15,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _CACHE = {}
 
 
+def _bar(key):   # rel-L2 of a case against its fp32 reference: 16-bit stores 4e-3; the e4m3-output case is e4m3 precision
+    return 4e-2 if key.endswith("f8q") else 4e-3
+
+
 def _run(env_extra):
     key = tuple(sorted(env_extra.items()))
     if key not in _CACHE:
@@ -36,7 +40,7 @@ def test_epilogue_operand_variants():
     bit-identical to the group-at-a-time epilogue. The bias moves from the end of the fp32 sum to its start: same tolerance."""
     base = _run({})
     for k, v in base.items():
-        assert v["rel"] < 4e-3, (k, v)
+        assert v["rel"] < _bar(k), (k, v)
     for env in ({"MI355X_SD_GEMM_NO_PRE": "1"}, {"MI355X_SD_GEMM_NO_EPI_BATCH": "1"},
                 {"MI355X_SD_GEMM_NO_PRE": "1", "MI355X_SD_GEMM_NO_EPI_BATCH": "1"},
                 {"MI355X_SD_GEMM_PERSIST": "0"}):   # one block per tile instead of persistent blocks walking several
@@ -45,7 +49,7 @@ def test_epilogue_operand_variants():
             assert got[k]["sha"] == base[k]["sha"], (env, k, got[k], base[k])
     got = _run({"MI355X_SD_GEMM_NO_BIAS_ACC": "1"})
     for k, v in got.items():
-        assert v["rel"] < 4e-3, (k, v)
+        assert v["rel"] < _bar(k), (k, v)
 
 
 def test_small_tile_ring_is_bit_identical_to_the_128_tile_without_slices():
@@ -57,10 +61,23 @@ def test_small_tile_ring_is_bit_identical_to_the_128_tile_without_slices():
     new = _run({"MI355X_SD_NO_SPLITK": "1"})
     ref = _run({"MI355X_SD_NO_SPLITK": "1", "MI355X_SD_NO_SMALL": "1"})
     for k, v in new.items():
-        assert v["rel"] < 4e-3, (k, v)
+        assert v["rel"] < _bar(k), (k, v)
         assert v["sha"] == ref[k]["sha"], (k, v, ref[k])
     sliced = _run({"MI355X_SD_NO_SMALL": "1"})
     assert any(sliced[k]["sha"] != v["sha"] for k, v in _run({}).items())   # (the picker does take the small tile somewhere)
+
+
+def test_four_wave_e4m3_tile_is_bit_identical_to_the_phased_kernel():
+    """csrc/gemm_w4f8.hip (round 6): the W8A8 launches of the MMDiT on the four-wave 256 x 256 tile with a rolling fragment set. Against
+    the phased 256 x 256 kernel it replaces (MI355X_SD_NO_W4): products of e4m3 values are exact, both kernels add one K-tile of 128
+    per MFMA in the same order, and the epilogue is the same arithmetic in the same order -> the same bits, bf16 and e4m3 outputs, gate /
+    residual / row-remap forms, ragged M, 3 .. 48 K-tiles."""
+    new, ref = _run({}), _run({"MI355X_SD_NO_W4": "1"})
+    keys = [k for k in new if k.startswith("gemm w8a8")]
+    assert len(keys) >= 6
+    for k in keys:
+        assert new[k]["rel"] < (4e-2 if k.endswith("f8q") else 4e-3), (k, new[k])
+        assert new[k]["sha"] == ref[k]["sha"], (k, new[k], ref[k])
 
 
 @pytest.mark.parametrize("tile_map", ["160:129", "257:129,320:129"])
@@ -70,7 +87,7 @@ def test_four_wave_tiles(tile_map):
     base = _run({})
     got = _run({"MI355X_SD_GEMM_TILE_MAP": tile_map})
     for k in base:
-        assert got[k]["rel"] < 4e-3, (tile_map, k, got[k])
+        assert got[k]["rel"] < _bar(k), (tile_map, k, got[k])
         # same loop, other tile: bit-identical. (Launches the picker gives to the phased 256x256 kernel, id 257, walk K in another
         # order: equal within the tolerance only.)
         if "257" not in tile_map:
@@ -92,5 +109,5 @@ def test_pipelined_loops_are_bit_identical_to_the_generic_loop(tile_env):
     ref = _run(dict(tile_env, MI355X_SD_NO_PIPE="1", MI355X_SD_GEMM_NO_BIAS_ACC="1"))
     new = _run(dict(tile_env, MI355X_SD_GEMM_NO_BIAS_ACC="1"))
     for k, v in new.items():
-        assert v["rel"] < 4e-3, (tile_env, k, v)
+        assert v["rel"] < _bar(k), (tile_env, k, v)
         assert v["sha"] == ref[k]["sha"], (tile_env, k, v, ref[k])
