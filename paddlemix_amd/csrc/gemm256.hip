@@ -308,22 +308,9 @@ int launch_gemm_f8(const GemmArgs& a_in, hipStream_t stream) {
   const size_t a_ext = a.a_rpb ? (size_t)((a.M - 1) / a.a_rpb) * a.a_bstride + (size_t)(a.a_rpb - 1) * a.lda + a.K
                                : (size_t)(a.M - 1) * a.lda + a.K;
   if (a_ext >= 0xFFFF0000ull || (size_t)a.N * a.K >= 0xFFFF0000ull) return SD_ERR_UNSUPPORTED;
-  // Two kernels of the same tile and the same bits (tests/test_gpu_gemm_variants.py). The phased one below runs two blocks per CU:
-  // one block's prologue / epilogue under the other's K loop -- worth 3-5 % on the K = 1536 launches whose tiles fill its 512 slots
-  // evenly (SD3 bs 8: 32768 x 6144 / 4608 x 1536). The four-wave tile (gemm_w4f8.hip, one block per CU, persistent) has the better
-  // loop and no half-empty last round: 32768 x 1536 x 6144 6.48 vs 7.21 ms per step, 32768 x 1536 x 1536 3.02 vs 3.28 (768 tiles =
-  // 1.5 rounds of 512 slots) (profiles/r06_s26_per_shape_*, r05 tables). Rule: the four-wave tile where the phased kernel's last round
-  // would leave more than 15 % of its slots empty, or K is long. MI355X_SD_NO_W4 (debug build): always the phased kernel.
-  static const bool w4_off = sd_switch("MI355X_SD_NO_W4") != nullptr;
-  const long tiles = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-  if (!w4_off && a.M >= 2048 && a.N >= 1536 && tiles >= 192) {
-    const long slots = 512, rounds = (tiles + slots - 1) / slots;
-    const bool ragged_last_round = (double)tiles < 0.85 * (double)(rounds * slots);
-    if (ragged_last_round || a.K >= 4096) {
-      const int rc = launch_gemm_w4f8(a, stream);
-      if (rc != SD_ERR_UNSUPPORTED) return rc;
-    }
-  }
+  // (A four-wave form of this tile with a rolling fragment set -- gemm_w4.hip's structure on e4m3 operands -- was built in round 6:
+  // bit-identical, 7 % faster on the K = 6144 launch in isolation, and no faster in the SD3 W8A8 step: 55.4 vs 55.5 ms, two interleaved
+  // rounds. Removed; source in the history at 745b95f, numbers in profiles/r06_s26_*, r06_s28_switch_check.txt)
   return launch_gemm256(a, stream);
 }
 

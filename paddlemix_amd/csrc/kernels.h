@@ -74,8 +74,6 @@ bool gemm_small_applies(const GemmArgs& a);                  // 64 x 64 tile, si
 int launch_gemm_small(const GemmArgs& a, hipStream_t stream);
 bool gemm_w4_applies(const GemmArgs& a, int bn = 256);       // four-wave 256 x 256 / 256 x 160 tile (gemm_w4.hip)
 int launch_gemm_w4(const GemmArgs& a, hipStream_t stream, int bn = 256);   // SD_ERR_UNSUPPORTED: caller falls back
-bool gemm_w4f8_applies(const GemmArgs& a);                   // the same tile on e4m3 operands (gemm_w4f8.hip: W8A8)
-int launch_gemm_w4f8(const GemmArgs& a, hipStream_t stream);
 int launch_gemm_f8(const GemmArgs& a, hipStream_t stream);   // W8A8 (gemm256.hip); validates
 void launch_splitk_reduce(const GemmArgs& a, hipStream_t stream);   // sums a.splitk slices of a.ws + epilogue (gemm.hip)   // phased 256x256 kernel (gemm256.hip); args pre-validated
 

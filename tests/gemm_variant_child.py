@@ -190,68 +190,4 @@ for M, N, K, kind in ((8200, 1536, 1536, "gate+R"), (4100, 6144, 1536, "gelu"), 
         got = out[rows].float()
     res[f"gemm fp8w {M}x{N}x{K} {kind}"] = dict(sha=hashlib.sha256(out.cpu().view(torch.int16).numpy().tobytes()).hexdigest()[:16],
                                                 rel=((got - ref).norm() / ref.norm()).item())
-# W8A8 (mi355x_sd_linear_f8 / _f8_q) at the sizes the four-wave e4m3 tile takes (csrc/gemm_w4f8.hip, round 6; MI355X_SD_NO_W4: the
-# phased 256 x 256 kernel): gate + residual, tanh-GELU, C rows remapped into a joint buffer, A rows read out of one, the e4m3 output
-# with its row scale on a ragged M, three K-tiles (the minimum) and 48
-from paddlemix_amd import _lib  # noqa: E402
-
-
-def _q8(t):
-    sc = t.abs().amax(dim=1).clamp_min(1e-12) / 448.0
-    return (t / sc[:, None]).to(torch.float8_e4m3fn).view(torch.uint8), sc
-
-
-for M, N, K, kind in ((8192, 1536, 1536, "gate+R"), (8192, 6144, 1536, "gelu"), (8192, 4608, 1536, "remap"), (8192, 1536, 6144, "a-remap"),
-                      (4100, 6144, 1536, "f8q"), (5000, 2048, 384, "plain")):
-    g = torch.Generator(device="cuda").manual_seed(M + N + K + 8)
-    a = torch.randn(M, K, device="cuda", generator=g) * (1 + 3 * torch.rand(M, 1, device="cuda", generator=g))
-    w = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
-    b = torch.randn(N, device="cuda", generator=g) * 0.1
-    qa, sa = _q8(a)
-    qw, sw = _q8(w)
-    rows = slice(M - 256, M)
-    ref = (qa[rows].view(torch.float8_e4m3fn).float() @ qw.view(torch.float8_e4m3fn).float().t()) * sa[rows, None] * sw[None, :] + b
-    lib = _lib.load()
-    st = torch.cuda.current_stream().cuda_stream
-    if kind == "gate+R":
-        nb = 4
-        gt = torch.randn(nb, N, device="cuda", generator=g)
-        r = torch.randn(M, N, device="cuda", generator=g).to(ed)
-        out = ops.linear_f8(qa, sa, qw, sw, b, gate=gt, rows_per_batch=M // nb, residual=r)
-        ref = r[rows].float() + gt[nb - 1] * ref
-        got = out[rows].float()
-    elif kind == "gelu":
-        out = ops.linear_f8(qa, sa, qw, sw, b, gelu_tanh=True)
-        ref = F.gelu(ref, approximate="tanh")
-        got = out[rows].float()
-    elif kind == "plain":
-        out = ops.linear_f8(qa, sa, qw, sw, b)
-        got = out[rows].float()
-    elif kind == "remap":
-        rpb, extra = M // 4, 154
-        out = torch.zeros(4 * (rpb + extra) * N, device="cuda", dtype=ed)
-        _lib.check(lib.mi355x_sd_linear_f8(qa.data_ptr(), K, 0, 0, sa.data_ptr(), qw.data_ptr(), sw.data_ptr(), out.data_ptr(), N, rpb,
-                                           (rpb + extra) * N, M, N, K, b.data_ptr(), None, 0, 0, None, 0, 0, st))
-        got = out.view(4, rpb + extra, N)[3, rpb - 256:rpb].float()
-        assert (out.view(4, rpb + extra, N)[:, rpb:] == 0).all(), "wrote outside the remapped rows"
-    elif kind == "a-remap":
-        rpb, extra = M // 4, 154
-        abuf = torch.zeros(4, rpb + extra, K, device="cuda", dtype=torch.uint8)
-        abuf[:, :rpb] = qa.view(4, rpb, K)
-        abuf[:, rpb:] = 0x7E     # (448.0: would show if a foreign row were read)
-        out = torch.empty(M, N, device="cuda", dtype=ed)
-        _lib.check(lib.mi355x_sd_linear_f8(abuf.data_ptr(), K, rpb, (rpb + extra) * K, sa.data_ptr(), qw.data_ptr(), sw.data_ptr(), out.data_ptr(),
-                                           N, 0, 0, M, N, K, b.data_ptr(), None, 0, 0, None, 0, 0, st))
-        got = out[rows].float()
-    else:   # e4m3 output: bytes + row scales
-        l2 = a.norm(dim=1)
-        wn = float((qw.view(torch.float8_e4m3fn).float() * sw[:, None]).norm(dim=1).max())
-        q, sc = ops.linear_f8_q(qa, sa, l2, qw, sw, wn, b, float(b.abs().max()), gelu_tanh=True)
-        out = torch.cat([q.view(-1), sc.view(torch.uint8).view(-1)])
-        ref = F.gelu(ref, approximate="tanh")
-        got = q[rows].view(torch.float8_e4m3fn).float() * sc[rows, None]
-    torch.cuda.synchronize()
-    raw = out.view(torch.uint8) if out.dtype == torch.uint8 else out.view(torch.int16)
-    res[f"gemm w8a8 {M}x{N}x{K} {kind}"] = dict(sha=hashlib.sha256(raw.cpu().numpy().tobytes()).hexdigest()[:16],
-                                                rel=((got - ref).norm() / ref.norm()).item())
 print("VARIANT_JSON " + json.dumps(res))

@@ -15,8 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _CACHE = {}
 
 
-def _bar(key):   # rel-L2 of a case against its fp32 reference: 16-bit stores 4e-3; the e4m3-output case is e4m3 precision
-    return 4e-2 if key.endswith("f8q") else 4e-3
+def _bar(key):   # rel-L2 of a case against its fp32 reference (16-bit stores)
+    return 4e-3
 
 
 def _run(env_extra):
@@ -65,19 +65,6 @@ def test_small_tile_ring_is_bit_identical_to_the_128_tile_without_slices():
         assert v["sha"] == ref[k]["sha"], (k, v, ref[k])
     sliced = _run({"MI355X_SD_NO_SMALL": "1"})
     assert any(sliced[k]["sha"] != v["sha"] for k, v in _run({}).items())   # (the picker does take the small tile somewhere)
-
-
-def test_four_wave_e4m3_tile_is_bit_identical_to_the_phased_kernel():
-    """csrc/gemm_w4f8.hip (round 6): the W8A8 launches of the MMDiT on the four-wave 256 x 256 tile with a rolling fragment set. Against
-    the phased 256 x 256 kernel it replaces (MI355X_SD_NO_W4): products of e4m3 values are exact, both kernels add one K-tile of 128
-    per MFMA in the same order, and the epilogue is the same arithmetic in the same order -> the same bits, bf16 and e4m3 outputs, gate /
-    residual / row-remap forms, ragged M, 3 .. 48 K-tiles."""
-    new, ref = _run({}), _run({"MI355X_SD_NO_W4": "1"})
-    keys = [k for k in new if k.startswith("gemm w8a8")]
-    assert len(keys) >= 6
-    for k in keys:
-        assert new[k]["rel"] < (4e-2 if k.endswith("f8q") else 4e-3), (k, new[k])
-        assert new[k]["sha"] == ref[k]["sha"], (k, new[k], ref[k])
 
 
 @pytest.mark.parametrize("tile_map", ["160:129", "257:129,320:129"])
