@@ -1123,10 +1123,13 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
             with torch.cuda.stream(self._stream):
                 # in_scale = 1: forward() takes the sample as the model input. (A host that drives the same geometry through the staged API
                 # with scale_model_input folded into conv_in -- bench.py does -- leaves its factor in the plan; round 5's bs-8 parity leg
-                # read 0.68 instead of 1.2e-2 through exactly that.)
+                # read 0.68 instead of 1.2e-2 through exactly that.) The staged host's factor is put back afterwards: its
+                # stage_inputs(in_scale=None) means "keep mine", not "whatever forward() left" (ADVICE r5).
+                kept = plan.in_scale.clone()
                 self.stage_inputs(plan, sample, timestep, encoder_hidden_states, added_cond_kwargs, in_scale=1.0,
                                   encoder_attention_mask=encoder_attention_mask, **ctrl)
                 out = self.run(plan).clone()
+                plan.in_scale.copy_(kept)
             cur.wait_stream(self._stream)
         if not return_dict:
             return (out,)

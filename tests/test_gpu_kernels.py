@@ -317,7 +317,10 @@ def test_conv3x3_splitk(ops, B, H, W, Cin, Cout, stride, up):
 
 @pytest.mark.parametrize("B,H,Sq,Skv,D", [(2, 4, 256, 256, 64), (1, 8, 1024, 1024, 64), (2, 5, 200, 77, 64),
                                           (1, 8, 320, 320, 40), (1, 8, 128, 77, 80), (1, 8, 64, 64, 160),
-                                          (1, 2, 33, 130, 8), (1, 2, 4096, 4096, 64)])
+                                          (1, 2, 33, 130, 8), (1, 2, 4096, 4096, 64),
+                                          # ragged d = 64 launches of the 16x16x32 kernel: query rows past Sq (clamped reads, skipped
+                                          # stores) together with a masked tail key tile; SD3's joint sequence length
+                                          (1, 4, 257, 192, 64), (1, 4, 96, 331, 64), (1, 3, 4250, 4250, 64)])
 def test_sdpa(ops, B, H, Sq, Skv, D):
     g = torch.Generator().manual_seed(Sq + Skv + D)
     q = bfr(torch.randn(B, Sq, H, D, generator=g))
@@ -326,6 +329,11 @@ def test_sdpa(ops, B, H, Sq, Skv, D):
     ref = U.sdpa_math(q, k, v)
     out = ops.sdpa(dev(q), dev(k), dev(v))
     check(out, ref, rel=5e-3, what=f"sdpa {B,H,Sq,Skv,D}")
+    if D == 64 and Skv > 128:   # the base-2 form the UNet builder uses (scale * log2(e) folded into q)
+        q2 = bfr(q * (D ** -0.5 * 1.4426950408889634))
+        ref2 = U.sdpa_math(q2, k, v, scale=0.6931471805599453)
+        out2 = ops.sdpa(dev(q2), dev(k), dev(v), log2=True)
+        check(out2, ref2, rel=5e-3, what=f"sdpa log2 {B,H,Sq,Skv,D}")
 
 
 @pytest.mark.parametrize("B,H,Sq,Skv,T,D,scale", [(2, 8, 1024, 77, 4, 64, 1.0), (1, 10, 4096, 77, 4, 64, 0.6),
