@@ -243,15 +243,28 @@ void launch_splitk_reduce(const GemmArgs& a, hipStream_t stream) {
 
 // Split-K plan for launches that cannot fill the chip (SD-1.5 at batch 1: 64..1024 rows against K up to 23040, i.e.
 // weight-streaming problems where 10-40 tiles would otherwise pull the whole weight matrix through 10-40 CUs).
-// Target ~2 blocks per CU, at least 4 k-tiles per slice, partial sums bounded by the workspace.
+// Up to 160 tiles are sliced, towards ~416 blocks, at least 4 k-tiles per slice, partial sums bounded by the workspace. The two
+// constants were 128 / 512 through round 5; scanned inside the batch-1 SD-1.5 step (plain-C step bench, two interleaved rounds each,
+// profiles/r06_s32*_splitk_policy.txt): 128:512 5.41 ms, 64:512 5.95, 128:256 5.39, 128:384 5.32, 160:384 5.27, 160:416 5.23,
+// 192:384 5.28, 160:512 5.35 -- fewer, longer slices (less slab traffic for the reduce kernel) and slicing a little above 128 tiles.
 static void plan_splitk(GemmArgs& a, int bm, int bn) {
   a.splitk = 0;
   static const bool off = sd_switch("MI355X_SD_NO_SPLITK") != nullptr;
   if (!a.ws_base || off || a.w16) return;   // (a widened fp8 matrix occupies the workspace)
   const long tiles = (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn);
   const int nt = (a.K + BK - 1) / BK;
-  if (tiles > 128 || nt < 8) return;
-  long s = (512 + tiles - 1) / tiles;
+  // (debug build: MI355X_SD_SPLITK_POLICY="max_tiles:target_blocks" for A/B runs of the two constants below)
+  static const std::pair<long, long> pol = [] {
+    std::pair<long, long> v{160, 416};
+    if (const char* e = sd_switch("MI355X_SD_SPLITK_POLICY")) {
+      char* end = nullptr;
+      const long a0 = strtol(e, &end, 10);
+      if (end && *end == ':') v = {a0, strtol(end + 1, nullptr, 10)};
+    }
+    return v;
+  }();
+  if (tiles > pol.first || nt < 8) return;
+  long s = (pol.second + tiles - 1) / tiles;
   s = std::min<long>(s, nt / 4);
   const size_t slice = (size_t)a.M * a.N * sizeof(float);
   s = std::min<long>(s, (long)(a.ws_bytes / slice));
