@@ -253,19 +253,25 @@ static void plan_splitk(GemmArgs& a, int bm, int bn) {
   if (!a.ws_base || off || a.w16) return;   // (a widened fp8 matrix occupies the workspace)
   const long tiles = (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn);
   const int nt = (a.K + BK - 1) / BK;
-  // (debug build: MI355X_SD_SPLITK_POLICY="max_tiles:target_blocks" for A/B runs of the two constants below)
-  static const std::pair<long, long> pol = [] {
-    std::pair<long, long> v{160, 416};
-    if (const char* e = sd_switch("MI355X_SD_SPLITK_POLICY")) {
+  // (debug build: MI355X_SD_SPLITK_POLICY for A/B runs of the constants below; the minimum slice length is flat between 4 and 8
+  // K-tiles, r06_s32d_splitk_policy.txt)
+  struct Pol { long max_tiles, target, min_kc; };
+  static const Pol pol = [] {
+    Pol v{160, 416, 4};
+    if (const char* e = sd_switch("MI355X_SD_SPLITK_POLICY")) {   // "max_tiles:target_blocks[:min_k_tiles_per_slice]"
       char* end = nullptr;
       const long a0 = strtol(e, &end, 10);
-      if (end && *end == ':') v = {a0, strtol(end + 1, nullptr, 10)};
+      if (end && *end == ':') {
+        v.max_tiles = a0;
+        v.target = strtol(end + 1, &end, 10);
+        if (end && *end == ':') v.min_kc = std::max<long>(1, strtol(end + 1, nullptr, 10));
+      }
     }
     return v;
   }();
-  if (tiles > pol.first || nt < 8) return;
-  long s = (pol.second + tiles - 1) / tiles;
-  s = std::min<long>(s, nt / 4);
+  if (tiles > pol.max_tiles || nt < 2 * pol.min_kc) return;
+  long s = (pol.target + tiles - 1) / tiles;
+  s = std::min<long>(s, nt / pol.min_kc);
   const size_t slice = (size_t)a.M * a.N * sizeof(float);
   s = std::min<long>(s, (long)(a.ws_bytes / slice));
   if (s < 2) return;

@@ -6,9 +6,9 @@ cd $GRAFT_REPO_ROOT
 L="-I/opt/rocm/include -Iinclude -Iscripts/c -Lpaddlemix_amd -lmi355x_sd_dbg -L/opt/rocm/lib -lamdhip64 -lm -Wl,-rpath,/opt/rocm/lib"
 gcc -std=c11 -O2 scripts/c/step_bench.c $L -o /tmp/step_bench || exit 1
 export LD_LIBRARY_PATH=paddlemix_amd
-R=$O/r06_s32c_splitk_policy.txt; : > $R
+R=$O/r06_s32d_splitk_policy.txt; : > $R
 for round in 1 2; do
-  for pol in 128:512 160:384 160:448 192:384 160:416 200:400 160:352 144:384 176:384 192:448 160:512; do
+  for pol in 160:416:4 160:416:2 160:416:3 160:416:6 160:416:8 160:416:12 256:416:6 160:320:6; do
     echo -n "round $round  policy $pol  " >> $R
     MI355X_SD_SPLITK_POLICY=$pol timeout 100 /tmp/step_bench scripts/c/sd15_unet_config.json 1 64 64 77 200 20 2>&1 | tail -1 | python -c "
 import json,sys
