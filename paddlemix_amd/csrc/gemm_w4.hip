@@ -451,6 +451,8 @@ int launch_gemm_w4(const GemmArgs& a_in, hipStream_t stream, int bn) {
   const int LDS_BYTES = 2 * (256 + bn) * BK * 2;
   const bool n160 = bn == 160;
   if (n160) a.gm = -8;   // (column groups of 8 for the 160-wide tiles, as launch_gemm does for the eight-wave ones)
+  // (the 256-wide tile keeps the library's column groups of 4: scanned inside the SDXL step, ms per step for groups of columns 2 / 4 / 5 /
+  // 8 / 16: 59.4 / 58.6 / 58.5 / 58.6 / 58.8, of rows 2 / 4 / 8: 59.1 / 59.8 / 59.8 -- profiles/r06_s34_w4_gm.txt)
   using K = void (*)(const GemmArgs);
   // (BS, DSP) of the shipped schedule; the debug build can pick another instantiation for A/B runs (MI355X_SD_W4_SCHED=0..3)
   static const int sched = [] {
