@@ -128,6 +128,8 @@ bool gemm_small_applies(const GemmArgs& a) {
   // are enough blocks that the slices' partial sums would cost more than the chain (rows x columns >= 160 tiles of 64 x 64)
   const long tiles = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
   const int nt = a.K / BK;
+  // (the three constants scanned inside the batch-1 SD-1.5 step, 24 .. 96 / 64 .. 320 / 40 .. 128: 5.22 .. 5.27 ms, flat --
+  // profiles/r06_s35_small_policy.txt)
   if (nt > 48 && !(tiles >= 160 && nt <= 96)) return false;
   const size_t lim = 0xFFFF0000ull;
   size_t a_ext;
