@@ -217,9 +217,12 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_bf16_kernel(const GemmAr
 
 // Deterministic split-K tail: wave = 16 rows x 32 columns in the MFMA accumulator layout, slices summed in index
 // order, then the common epilogue (so every fusion -- bias, temb, residual, GEGLU, fp8 scales -- is shared).
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
+// WAVES per block: 4, or 1 where four-wave blocks would leave most CUs without one (64 x 1280 outputs = 40 blocks of four waves: the
+// 160 waves then sit on 40 CUs and the 14 MB of slabs of a deep batch-1 convolution are pulled through those)
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void splitk_reduce_kernel(const GemmArgs p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int m_wave = blockIdx.x * 16, n_wave = blockIdx.y * 128 + wave * 32;
+  const int m_wave = blockIdx.x * 16, n_wave = blockIdx.y * (32 * WAVES) + wave * 32;
   const int m = m_wave + (lane & 15);
   f32x4 acc[2][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}, {f32x4{0.f, 0.f, 0.f, 0.f}}};
   if (m < p.M) {
@@ -229,8 +232,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
       const int n = n_wave + acc_col<2>(tn, lane >> 4, p.geglu);
       if (n >= p.N) continue;
       const float* src = p.ws + (size_t)m * p.N + n;
-#pragma unroll 4
-      for (int s = 0; s < p.splitk; ++s) acc[tn][0] += *reinterpret_cast<const f32x4*>(src + s * slice);
+#pragma unroll 8
+      for (int s = 0; s < p.splitk; ++s) acc[tn][0] += *reinterpret_cast<const f32x4*>(src + s * slice);   // (index order: deterministic)
     }
   }
   if (p.rowstat) gemm_epilogue_ln<1, 2>(p, acc, m_wave, n_wave, lane);
@@ -238,7 +241,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
 }
 
 void launch_splitk_reduce(const GemmArgs& a, hipStream_t stream) {
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((a.M + 15) / 16, (a.N + 127) / 128), dim3(256), 0, stream, a);
+  const long blocks4 = (long)((a.M + 15) / 16) * ((a.N + 127) / 128);
+  if (blocks4 < 512) hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3((a.M + 15) / 16, (a.N + 31) / 32), dim3(64), 0, stream, a);
+  else hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3((a.M + 15) / 16, (a.N + 127) / 128), dim3(256), 0, stream, a);
 }
 
 // Split-K plan for launches that cannot fill the chip (SD-1.5 at batch 1: 64..1024 rows against K up to 23040, i.e.
@@ -253,25 +258,11 @@ static void plan_splitk(GemmArgs& a, int bm, int bn) {
   if (!a.ws_base || off || a.w16) return;   // (a widened fp8 matrix occupies the workspace)
   const long tiles = (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn);
   const int nt = (a.K + BK - 1) / BK;
-  // (debug build: MI355X_SD_SPLITK_POLICY for A/B runs of the constants below; the minimum slice length is flat between 4 and 8
-  // K-tiles, r06_s32d_splitk_policy.txt)
-  struct Pol { long max_tiles, target, min_kc; };
-  static const Pol pol = [] {
-    Pol v{160, 416, 4};
-    if (const char* e = sd_switch("MI355X_SD_SPLITK_POLICY")) {   // "max_tiles:target_blocks[:min_k_tiles_per_slice]"
-      char* end = nullptr;
-      const long a0 = strtol(e, &end, 10);
-      if (end && *end == ':') {
-        v.max_tiles = a0;
-        v.target = strtol(end + 1, &end, 10);
-        if (end && *end == ':') v.min_kc = std::max<long>(1, strtol(end + 1, nullptr, 10));
-      }
-    }
-    return v;
-  }();
-  if (tiles > pol.max_tiles || nt < 2 * pol.min_kc) return;
-  long s = (pol.target + tiles - 1) / tiles;
-  s = std::min<long>(s, nt / pol.min_kc);
+  // (max tiles / target blocks / minimum K-tiles per slice; the scans behind them: profiles/r06_s32*_splitk_policy.txt -- the
+  // minimum slice length is flat between 4 and 8)
+  if (tiles > 160 || nt < 8) return;
+  long s = (416 + tiles - 1) / tiles;
+  s = std::min<long>(s, nt / 4);
   const size_t slice = (size_t)a.M * a.N * sizeof(float);
   s = std::min<long>(s, (long)(a.ws_bytes / slice));
   if (s < 2) return;
