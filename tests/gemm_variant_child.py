@@ -160,7 +160,7 @@ for M, N, K, kind in ((8192, 1536, 1536, "gate+R"), (8192, 6144, 1536, "gelu"), 
 # tanh-GELU (SD3 FF1), gate + residual (SD3 to_out / FF2), a row-remapped output (the joint QKV buffer), ragged M, ragged N
 from paddlemix_amd.sd3 import dequantize_fp8_rows, quantize_fp8_rows  # noqa: E402
 for M, N, K, kind in ((8200, 1536, 1536, "gate+R"), (4100, 6144, 1536, "gelu"), (8192, 4608, 1536, "remap"), (4096, 1540, 1536, "plain"),
-                      (16384, 1536, 6144, "gate+R")):
+                      (16384, 1536, 6144, "gate+R"), (8200, 1544, 1536, "plain")):   # (the last: ragged M and N on the four-wave tile's WS form)
     g = torch.Generator(device="cuda").manual_seed(M + N + K + 4)
     a = torch.randn(M, K, device="cuda", generator=g).to(ed)
     w8, ws = quantize_fp8_rows(torch.randn(N, K, device="cuda", generator=g) / K ** 0.5)
