@@ -27,6 +27,11 @@ enum { NBUF = 4 };
 int main(int argc, char** argv) {
   const int reps = argc > 1 ? atoi(argv[1]) : 20;
   const unsigned mask = argc > 2 ? (unsigned)strtoul(argv[2], NULL, 0) : 0xFFFFFFFFu;   /* bit s: run shape s */
+  /* weight copies rotated through (1: every launch multiplies by the same, cache-resident matrix -- what a step never does; enough
+   * copies to exceed the 256-MB Infinity Cache: every launch fetches its weights from HBM, like the step's layers) */
+  int wrot = argc > 3 ? atoi(argv[3]) : 1;
+  if (wrot < 1) wrot = 1;
+  if (wrot > 512) wrot = 512;
   CK(mi355x_sd_init(0));
   const int f16 = mi355x_sd_elem_dtype() == MI355X_SD_ELEM_F16;
   void* splitk = NULL;
@@ -43,15 +48,21 @@ int main(int argc, char** argv) {
     if (!((mask >> s) & 1u)) continue;
     const int Nout = sh.geglu ? sh.N / 2 : sh.N;
     void *A[NBUF], *C[NBUF], *Wt = NULL, *R = NULL;
+    void* Wr[512];
     float* bias = NULL;
     if (upload16_rot(A, NBUF, (int64_t)sh.M * sh.K, 1.0f, f16)) return 3;
     for (int b = 0; b < NBUF; ++b) HK(hipMalloc(&C[b], (size_t)sh.M * Nout * 2));
     if (upload16(&Wt, (int64_t)sh.N * sh.K, 1.7f / sqrtf((float)sh.K), f16)) return 3;
+    Wr[0] = Wt;
+    for (int w = 1; w < wrot; ++w) {   /* identical copies: the output hash does not depend on the rotation */
+      HK(hipMalloc(&Wr[w], (size_t)sh.N * sh.K * 2));
+      HK(hipMemcpy(Wr[w], Wt, (size_t)sh.N * sh.K * 2, hipMemcpyDeviceToDevice));
+    }
     if (sh.resid && upload16(&R, (int64_t)sh.M * Nout, 1.0f, f16)) return 3;
     if (upload32(&bias, sh.N, 0.03f)) return 3;
     for (int i = 0; i < 3 + reps; ++i) {
       if (i == 3) HK(hipEventRecord(e0, st));
-      CK(mi355x_sd_linear(A[i % NBUF], sh.K, Wt, C[i % NBUF], Nout, sh.M, sh.N, sh.K, bias, NULL, 0, 0, R, Nout, 1.0f,
+      CK(mi355x_sd_linear(A[i % NBUF], sh.K, Wr[i % wrot], C[i % NBUF], Nout, sh.M, sh.N, sh.K, bias, NULL, 0, 0, R, Nout, 1.0f,
                           sh.geglu ? MI355X_SD_GEGLU : 0, splitk, 64u << 20, st));
     }
     HK(hipEventRecord(e1, st));
@@ -69,7 +80,7 @@ int main(int argc, char** argv) {
       HK(hipFree(A[b]));
       HK(hipFree(C[b]));
     }
-    HK(hipFree(Wt));
+    for (int w = 0; w < wrot; ++w) HK(hipFree(Wr[w]));
     HK(hipFree(bias));
     if (R) HK(hipFree(R));
   }
