@@ -249,6 +249,10 @@ class CUNet2DConditionModel:
                 _lib.check(lib.mi355x_sd_unet_set_input(h, b"image_embeds", ie.data_ptr()))
             _lib.check(lib.mi355x_sd_unet_forward_ex(h, self._stream.cuda_stream, p(s), p(tt), p(e), p(te), p(ti), p(sc), p(em), p(sm), arr,
                                                      len(rs), p(rm), p(out), 1 if self.use_graph else 0))
+            # the bindings pointed at this call's staging tensors: the handle must not keep them past the call
+            for nm, bound in ((b"class_labels", clt), (b"timestep_cond", tc), (b"image_embeds", ie)):
+                if bound is not None:
+                    _lib.check(lib.mi355x_sd_unet_set_input(h, nm, None))
         cur.wait_stream(self._stream)
         for x in [s, tt, e, te, ti, sc, em, sm, rm, clt, tc, ie] + rs:     # keep the staging tensors alive until the stream has consumed them
             if x is not None:
