@@ -304,7 +304,9 @@ class UNet2DConditionModel(DeviceProgram, PretrainedMixin):
         # pass + mi355x_sd_linear_ln on the raw rows). Off by default: on MI355X it removes 2.3 ms of LayerNorm
         # traffic per SDXL step but the GEMMs then multiply the raw residual stream instead of O(1) normalised
         # activations and run 6-12 % slower (operand-dependent MFMA power), a wash end to end
-        # (profiles/r01_lnfold_ab.txt). MI355X_SD_LNFOLD=1 or fold_layernorm=True turns it on.
+        # (profiles/r01_lnfold_ab.txt; round 6, on today's kernels: 58.0 vs 56.3 ms per step -- the folded QKV / FF1 launches also lose
+        # the four-wave tile, which has no row-statistics epilogue: profiles/r06_s40_lnfold_ab.txt). MI355X_SD_LNFOLD=1 or
+        # fold_layernorm=True turns it on.
         self.fold_ln = (os.environ.get("MI355X_SD_LNFOLD") is not None) if fold_layernorm is None else bool(fold_layernorm)
         # residual_dtype="fp32" (or MI355X_SD_RESID=fp32): the residual stream -- resnet outputs, the transformer blocks' hidden
         # state, every skip / concat slot -- is stored in fp32; 16-bit values exist only as MFMA operands (the outputs of
